@@ -1,0 +1,163 @@
+/*
+ * vkradixsort_amd.h -- C ABI of the MI355X-native multi-block LSD radix sort.
+ *
+ * This is the drop-in boundary for VkRadixSort's `multi_radixsort` path.  The reference has no
+ * FFI layer of its own: its boundary is the C++ class API (GPUContext / Buffer / ComputePass /
+ * MultiRadixSortPass / MultiRadixSort).  The C++ host mirror under vkradixsort_amd/host keeps those
+ * classes and calls ONLY the functions below; any other host language binds the same symbols
+ * (see INTEGRATION.md).  Plain C types, opaque handles, no exceptions, 0 == success.
+ *
+ * Each entry point cites the reference interface it replaces (file:line in VkRadixSort @ v2).
+ *
+ * Threading: one HIP stream per context, a context is not thread-safe (the reference is single
+ * threaded: one compute queue, one host thread).  Stage calls are ASYNCHRONOUS and stream-ordered;
+ * the only blocking calls are vrs_queue_wait_idle, upload/download and the profile query.
+ */
+#ifndef VKRADIXSORT_AMD_H
+#define VKRADIXSORT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRS_RADIX_SORT_BINS 256u /* multi_radixsort.comp:12 */
+#define VRS_WORKGROUP_SIZE 256u  /* multi_radixsort.comp:11 -- the CONTRACT workgroup size that
+                                    defines tiles and the [W][256] histogram layout */
+
+typedef enum vrs_status {
+    VRS_OK = 0,
+    VRS_ERROR_INVALID_ARGUMENT = 1,
+    VRS_ERROR_HIP = 2,          /* a HIP runtime call failed; see vrs_last_error */
+    VRS_ERROR_NO_DEVICE = 3,    /* no gfx950-capable device / bad ordinal */
+    VRS_ERROR_OUT_OF_MEMORY = 4
+} vrs_status;
+
+typedef struct vrs_context_t *vrs_context; /* replaces engine::GPUContext (GPUContext.h:15-111) */
+typedef struct vrs_buffer_t *vrs_buffer;   /* replaces engine::Buffer     (Buffer.h:14-177)     */
+
+/*
+ * The 16-byte push-constant block shared by both stages, std430 order:
+ * MultiRadixSortPass::PushConstantsHistograms (MultiRadixSortPass.h:17-22) and
+ * MultiRadixSortPass::PushConstants           (MultiRadixSortPass.h:26-31), mirroring
+ * multi_radixsort_histograms.comp:13-18 and multi_radixsort.comp:17-22.
+ */
+typedef struct vrs_push_constants {
+    uint32_t g_num_elements;             /* N */
+    uint32_t g_shift;                    /* 0, 8, 16, 24 -- set by the caller each pass
+                                            (MultiRadixSort.cpp:57-58) */
+    uint32_t g_num_workgroups;           /* W = ceil(ceil(N/B)/256)  (MultiRadixSort.cpp:13-20) */
+    uint32_t g_num_blocks_per_workgroup; /* B = NUM_BLOCKS_PER_WORKGROUP (MultiRadixSort.cpp:12) */
+} vrs_push_constants;
+
+/* ---- device / context: GPUContext::init / shutdown (GPUContext.cpp:7-13) ------------------- */
+
+int vrs_device_count(int *count);
+/* Creates a context on `device_ordinal` with its own HIP stream.  Never prompts on stdin (the
+ * reference does when >1 device: GPUContext.cpp:167-174). */
+int vrs_context_create(int device_ordinal, vrs_context *out_ctx);
+/* Same, but borrows a caller-owned hipStream_t (e.g. torch's current stream); never destroyed. */
+int vrs_context_create_on_stream(int device_ordinal, void *hip_stream, vrs_context *out_ctx);
+int vrs_context_destroy(vrs_context ctx);
+/* Message of the last failure on this context (ctx may be NULL for creation failures). */
+const char *vrs_last_error(vrs_context ctx);
+/* hipStream_t of the context, for callers that interleave their own work. */
+void *vrs_context_stream(vrs_context ctx);
+/* Device facts for reports: name, CU count, HBM bytes.  Any out pointer may be NULL. */
+int vrs_device_info(vrs_context ctx, char *name, size_t name_cap, int *compute_units,
+                    uint64_t *global_mem_bytes);
+
+/* ---- buffers: Buffer ctor / release / staging copies (Buffer.h:25-72) ---------------------- */
+
+/* Device-local allocation (VK_MEMORY_PROPERTY_DEVICE_LOCAL_BIT buffers of prepareBuffers,
+ * MultiRadixSort.cpp:83-95).  size_t, not the reference's uint32 byte size (Buffer.h:17). */
+int vrs_buffer_create(vrs_context ctx, size_t size_bytes, vrs_buffer *out_buf);
+/* Wraps caller-owned device memory (hipMalloc / torch tensor); release does not free it.
+ * `device_ptr` must be 16-byte aligned.  ("own usage" scenario, README.md:151-241.) */
+int vrs_buffer_wrap(vrs_context ctx, void *device_ptr, size_t size_bytes, vrs_buffer *out_buf);
+/* Idempotent (Buffer::release, Buffer.h:36-45).  Also frees the handle. */
+int vrs_buffer_release(vrs_buffer buf);
+/* Synchronous H2D copy of `size_bytes` (Buffer::fillDeviceWithStagingBuffer, Buffer.h:47-62). */
+int vrs_buffer_upload(vrs_context ctx, vrs_buffer buf, const void *host_data, size_t size_bytes);
+/* Synchronous D2H copy (Buffer::downloadWithStagingBuffer, Buffer.h:64-72). */
+int vrs_buffer_download(vrs_context ctx, vrs_buffer buf, void *host_data, size_t size_bytes);
+/* Stream-ordered device-to-device copy (used to re-arm the unsorted input between timed reps). */
+int vrs_buffer_copy(vrs_context ctx, vrs_buffer dst, vrs_buffer src, size_t size_bytes);
+void *vrs_buffer_device_ptr(vrs_buffer buf);
+size_t vrs_buffer_size_bytes(vrs_buffer buf); /* Buffer::getSizeBytes, Buffer.h:103-105 */
+
+/* ---- launch-shape arithmetic: ComputePass::setGlobalInvocationSize/getWorkGroupCount ------- */
+
+/* gis = ceil(N/B) (MultiRadixSort.cpp:13-15); W = ceil(gis/256) (ComputePass.h:16-29). */
+uint32_t vrs_global_invocation_size(uint32_t num_elements, uint32_t blocks_per_workgroup);
+uint32_t vrs_workgroup_count(uint32_t num_elements, uint32_t blocks_per_workgroup);
+
+/* ---- the two stages: MultiRadixSortPass::recordCommands (MultiRadixSortPass.cpp:10-20) ----- */
+
+/*
+ * Stage RADIX_SORT_HISTOGRAMS (multi_radixsort_histograms.comp:31-55).
+ * bindings: set 0 b0 = keys_in (uint32[N]), set 0 b1 = histograms (uint32[W*256], layout
+ * [workgroup][digit], every entry overwritten).  Asynchronous.
+ */
+int vrs_multi_radixsort_histograms(vrs_context ctx, vrs_buffer keys_in, vrs_buffer histograms,
+                                   const vrs_push_constants *pc);
+/*
+ * Stage RADIX_SORT (multi_radixsort.comp:45-127): global digit prefix + per-workgroup offsets from
+ * `histograms`, then the stable scatter keys_in -> keys_out.  bindings: set 1 b0 in, b1 out,
+ * b2 histograms.  Stream-ordered after the histogram stage (replaces the W->R pipeline barrier,
+ * MultiRadixSortPass.cpp:13-14).  keys_in and keys_out must not alias.  Asynchronous.
+ */
+int vrs_multi_radixsort(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out,
+                        vrs_buffer histograms, const vrs_push_constants *pc);
+/*
+ * Key + payload variant of the RADIX_SORT stage (build extension, BASELINE.json config 4: the
+ * reference has only g_elements_in/out, multi_radixsort.comp:24-30).  values follow their keys;
+ * order among equal digits is the input order (stable), so four passes == std::stable_sort by key.
+ */
+int vrs_multi_radixsort_pairs(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out,
+                              vrs_buffer values_in, vrs_buffer values_out, vrs_buffer histograms,
+                              const vrs_push_constants *pc);
+/* vkQueueWaitIdle on the compute queue (MultiRadixSort.cpp:62). */
+int vrs_queue_wait_idle(vrs_context ctx);
+
+/*
+ * single_radixsort path (single_radixsort.comp:42-140, SingleRadixSort.cpp:5-47): one workgroup,
+ * four passes in one launch, push constant {g_num_elements}; result in buffer0.  Asynchronous.
+ */
+int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1,
+                         uint32_t g_num_elements);
+
+/* ---- measurement (no reference counterpart) ------------------------- */
+
+typedef enum vrs_kernel_id {
+    VRS_KERNEL_HISTOGRAM = 0, /* stage RADIX_SORT_HISTOGRAMS */
+    VRS_KERNEL_PREFIX = 1,    /* global digit prefix + per-workgroup offsets (both launches) */
+    VRS_KERNEL_SCATTER = 2,   /* stable scatter (the dominant kernel) */
+    VRS_KERNEL_SINGLE = 3,    /* single_radixsort */
+    VRS_KERNEL_COUNT = 4
+} vrs_kernel_id;
+
+/* When enabled, every kernel launch is bracketed by hipEvents on the context's stream. */
+int vrs_profile_enable(vrs_context ctx, int enabled);
+int vrs_profile_reset(vrs_context ctx);
+/* Synchronises the stream, then returns launches and summed event time for one kernel id. */
+int vrs_profile_query(vrs_context ctx, int kernel_id, uint64_t *launches, double *total_ms);
+
+/* Test hook: copies the per-workgroup offset table (uint32[W*256], multi_radixsort.comp:76's
+ * global_offsets for every workgroup) computed by the most recent RADIX_SORT stage. */
+int vrs_debug_download_offsets(vrs_context ctx, void *host_data, size_t size_bytes);
+
+/* Tuning knobs (performance only, never results). */
+typedef enum vrs_tuning_key {
+    VRS_TUNE_XCD_REMAP = 0 /* 1 (default): consecutive tiles share an XCD's L2 in the scatter */
+} vrs_tuning_key;
+int vrs_set_tuning(vrs_context ctx, int key, int value);
+
+const char *vrs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKRADIXSORT_AMD_H */

@@ -1,0 +1,125 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol the header declares, does its
+host-side arithmetic like the reference, and fails LOUDLY (no fallback) when there is no GPU."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+import vkradixsort_amd as vrs
+from vkradixsort_amd import capi
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = ROOT / "include" / "vkradixsort_amd.h"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from vkradixsort_amd import build
+    build.build_library()  # hipcc cross-compiles gfx950 without a GPU
+    return capi.load_library()
+
+
+def declared_symbols():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(vrs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_all_exported_and_bound(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in the header but not exported"
+    assert sorted(capi.EXPORTED_SYMBOLS) == syms, "ctypes binding and header diverge"
+
+
+def test_push_constants_layout_is_16_bytes_std430():
+    # MultiRadixSortPass.h:17-22 / :26-31 -- four uint32 in this order
+    assert ctypes.sizeof(capi.PushConstants) == 16
+    assert [f[0] for f in capi.PushConstants._fields_] == ["g_num_elements", "g_shift", "g_num_workgroups",
+                                                           "g_num_blocks_per_workgroup"]
+    assert capi.PushConstants.g_shift.offset == 4 and capi.PushConstants.g_num_blocks_per_workgroup.offset == 12
+
+
+@pytest.mark.parametrize("n,B,W", [(10 ** 6, 32, 123), (10 ** 6, 1, 3907), (10 ** 6, 4096, 1), (10 ** 7, 32, 1221),
+                                   (10 ** 7, 512, 77), (10 ** 8, 32, 12208), (10 ** 8, 128, 3052), (10 ** 8, 4096, 96),
+                                   (1000, 32, 1), (257, 1, 2), (1, 1, 1)])
+def test_workgroup_count(lib, oracle, n, B, W):
+    assert lib.vrs_workgroup_count(n, B) == W == oracle.workgroup_count(n, B)
+    assert lib.vrs_global_invocation_size(n, B) == -(-n // B)
+
+
+def test_compute_pass_launch_shape_matches_c_abi(lib):
+    p = vrs.ComputePass.__new__(vrs.ComputePass)
+    for n, B in [(10 ** 6, 32), (10 ** 8, 4096), (1000, 7), (255, 1)]:
+        gis = n // B + (1 if n % B else 0)
+        d = vrs.ComputePass.getDispatchSize(gis, 1, 1, vrs.Extent3D(256, 1, 1))
+        assert (d.width, d.height, d.depth) == (lib.vrs_workgroup_count(n, B), 1, 1)
+
+
+def test_version_string(lib):
+    assert b"gfx950" in lib.vrs_version()
+
+
+def test_no_device_fails_loudly(lib):
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present; the no-device path is exercised on the CPU box")
+    ctx = vrs.GPUContext(0)
+    with pytest.raises(vrs.VrsError) as e:
+        ctx.init()
+    assert e.value.code == capi.VRS_ERROR_NO_DEVICE
+    # and the high-level entry point does not quietly sort on the CPU
+    with pytest.raises(vrs.VrsError):
+        vrs.MultiRadixSort(1000, quiet=True).execute(vrs.GPUContext(0).__enter__())
+
+
+def test_null_arguments_are_rejected(lib):
+    assert lib.vrs_context_create(0, None) == capi.VRS_ERROR_INVALID_ARGUMENT
+    assert lib.vrs_queue_wait_idle(None) == capi.VRS_ERROR_INVALID_ARGUMENT
+    assert lib.vrs_multi_radixsort_histograms(None, None, None, None) == capi.VRS_ERROR_INVALID_ARGUMENT
+    assert lib.vrs_buffer_release(None) == capi.VRS_OK  # idempotent like Buffer::release
+
+
+def test_product_package_never_touches_the_oracle():
+    for path in list((ROOT / "vkradixsort_amd").rglob("*.py")) + list((ROOT / "vkradixsort_amd").rglob("*.hip")) + \
+            list((ROOT / "vkradixsort_amd").rglob("*.cpp")) + list((ROOT / "vkradixsort_amd").rglob("*.h")):
+        text = path.read_text()
+        assert "vrs_oracle" not in text and "libvrs_oracle" not in text and "_oracle" not in text, path
+
+
+class _FakeContext:
+    """just enough GPUContext for the binding-table logic (no device calls)"""
+
+    def __init__(self):
+        self.m_activeIndex = 0
+
+    def getMultiBufferedCount(self):
+        return 2
+
+    def getActiveIndex(self):
+        return self.m_activeIndex
+
+    def incrementActiveIndex(self):
+        self.m_activeIndex = (self.m_activeIndex + 1) % 2
+
+
+def test_ping_pong_binding_table_matches_reference():
+    """MultiRadixSort.cpp:33-46 + README.md:205-209: iterations 0,2 read buffer0 / write buffer1,
+    iterations 1,3 the reverse; the histogram buffer is bound in both copies."""
+    ctx = _FakeContext()
+    m = vrs.MultiRadixSort(1000, quiet=True)
+    m.m_gpuContext = ctx
+    m.m_pass = vrs.MultiRadixSortPass(ctx)
+    m.m_pass.create()
+    m.m_buffers = ["buf0", "buf1", "hist"]
+    m.bindBuffers()
+    H, R = vrs.MultiRadixSortPass.RADIX_SORT_HISTOGRAMS, vrs.MultiRadixSortPass.RADIX_SORT
+    seen = []
+    for i in range(4):
+        seen.append((m.m_pass._bound(H, 0), m.m_pass._bound(R, 0), m.m_pass._bound(R, 1), m.m_pass._bound(H, 1),
+                     m.m_pass._bound(R, 2)))
+        ctx.incrementActiveIndex()
+    assert seen[0] == ("buf0", "buf0", "buf1", "hist", "hist") == seen[2]
+    assert seen[1] == ("buf1", "buf1", "buf0", "hist", "hist") == seen[3]
+    with pytest.raises(vrs.VrsError):
+        m.m_pass._bound(R, 7)

@@ -1,0 +1,297 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI; the oracle is
+only the checker.  Integer work: bit-exact or fail."""
+import ctypes
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import vkradixsort_amd as vrs
+from vkradixsort_amd import capi
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted((Path(__file__).parent / "golden").glob("*.npz"))
+S = vrs.Buffer.BufferSettings
+
+
+def rand_keys(n, seed):
+    return np.random.RandomState(seed).randint(0, 2 ** 32, size=n, dtype=np.uint32)
+
+
+class StageRunner:
+    """Drives the two stages through MultiRadixSortPass exactly like MultiRadixSort::execute, but keeps
+    every intermediate so each stage can be compared with the oracle."""
+
+    def __init__(self, ctx, keys, B, values=None):
+        self.ctx, self.B, self.n = ctx, B, keys.size
+        self.m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=B, keys=keys, values=values, quiet=True)
+        self.m.setup(ctx)
+        self.W = self.m.m_pass.m_pushConstants.g_num_workgroups
+
+    def run_pass(self, i):
+        p = self.m.m_pass
+        p.m_pushConstantsHistogram.g_shift = 8 * i
+        p.m_pushConstants.g_shift = 8 * i
+        p.execute(None)
+        self.ctx.incrementActiveIndex()
+        self.ctx.waitIdle()
+        hist = np.empty(self.W * 256, np.uint32)
+        self.m.m_buffers[2].downloadWithStagingBuffer(hist)
+        offsets = np.empty(self.W * 256, np.uint32)
+        self.ctx.check(self.ctx.lib.vrs_debug_download_offsets(self.ctx.handle, offsets.ctypes.data_as(ctypes.c_void_p),
+                                                               offsets.nbytes))
+        out = np.empty(self.n, np.uint32)
+        self.m.m_buffers[(i + 1) % 2].downloadWithStagingBuffer(out)
+        return hist, offsets, out
+
+    def close(self):
+        self.m.releaseBuffers()
+        self.m.m_pass.release()
+        # leave the shared context's activeIndex where the next test expects it
+        while self.ctx.getActiveIndex() != 0:
+            self.ctx.incrementActiveIndex()
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: p.stem)
+def test_every_stage_matches_golden(gpu_context, path):
+    g = np.load(path)
+    n, B, seed, tbz, W = (int(x) for x in g["meta"])
+    r = StageRunner(gpu_context, g["keys"], B)
+    assert r.W == W
+    try:
+        for i in range(4):
+            hist, offsets, out = r.run_pass(i)
+            assert np.array_equal(hist, g[f"hist{i}"]), f"histogram table, pass {i}"
+            assert np.array_equal(offsets, g[f"offsets{i}"]), f"offset table, pass {i}"
+            assert np.array_equal(out, g[f"pass{i}"]), f"scatter output, pass {i}"
+        assert np.array_equal(r.m.download(), g["sorted"])  # result in buffer0
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("n,B", [(1, 1), (255, 1), (256, 1), (257, 1), (1000, 32), (1000, 1), (65536, 4), (100003, 7),
+                                 (8192, 32), (8193, 32), (50000, 4096), (300000, 16), (300001, 8), (1 << 20, 32),
+                                 (123457, 64), (99999, 33), (70000, 2)])
+def test_every_stage_matches_oracle(gpu_context, oracle, n, B):
+    keys = rand_keys(n, n * 31 + B)
+    r = StageRunner(gpu_context, keys, B)
+    assert r.W == oracle.workgroup_count(n, B)
+    try:
+        cur = keys
+        for i in range(4):
+            hist, offsets, out = r.run_pass(i)
+            ohist = oracle.histograms(cur, 8 * i, r.W, B)
+            assert np.array_equal(hist, ohist), f"histogram table, pass {i}"
+            assert np.array_equal(offsets, oracle.offsets(ohist, r.W)), f"offset table, pass {i}"
+            cur = oracle.scatter(cur, ohist, 8 * i, r.W, B)
+            assert np.array_equal(out, cur), f"scatter output, pass {i}"
+        ref, _ = oracle.std_sort(keys)
+        assert oracle.test_sort(ref, r.m.download()) == -1
+    finally:
+        r.close()
+
+
+def _distributions(n):
+    rs = np.random.RandomState(1234)
+    yield "all_equal", np.full(n, 0xDEADBEEF, np.uint32)
+    yield "all_zero", np.zeros(n, np.uint32)
+    yield "all_ones", np.full(n, 0xFFFFFFFF, np.uint32)  # collides with the kernel's padding key
+    yield "sorted", np.sort(rs.randint(0, 2 ** 32, n, dtype=np.uint32))
+    yield "reverse", np.sort(rs.randint(0, 2 ** 32, n, dtype=np.uint32))[::-1].copy()
+    yield "28bit_reference_range", rs.randint(0, 2 ** 32, n, dtype=np.uint32) >> np.uint32(4)
+    yield "two_values", rs.randint(0, 2, n).astype(np.uint32) * np.uint32(0x80000001)
+    yield "one_bin_per_pass", (rs.randint(0, 4, n).astype(np.uint32) * np.uint32(0x01010101))
+    yield "low_byte_only", rs.randint(0, 256, n).astype(np.uint32)
+    yield "high_byte_only", rs.randint(0, 256, n).astype(np.uint32) << np.uint32(24)
+    yield "max_at_tail", np.concatenate([rs.randint(0, 2 ** 32, n - 5, dtype=np.uint32), np.full(5, 0xFFFFFFFF, np.uint32)])
+
+
+@pytest.mark.parametrize("n,B", [(200003, 32), (65536 + 100, 8)])
+def test_distributions_end_to_end(gpu_context, oracle, n, B):
+    for name, keys in _distributions(n):
+        m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=B, keys=keys, quiet=True)
+        m.execute(gpu_context)  # raises RuntimeError("TEST FAILED.") on mismatch like the reference
+        ref, _ = oracle.std_sort(keys)
+        assert oracle.test_sort(ref, m.sorted_keys) == -1, name
+        assert np.array_equal(oracle.multi_radixsort(keys, B), m.sorted_keys), name
+
+
+@pytest.mark.parametrize("n,B", [(1000, 32), (100003, 7), (1 << 20, 32), (333333, 16)])
+def test_pairs_equal_stable_sort(gpu_context, oracle, n, B):
+    keys = rand_keys(n, 77) & np.uint32(0x00FF00FF)  # plenty of equal keys -> stability is visible
+    vals = np.arange(n, dtype=np.uint32)
+    m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=B, keys=keys, values=vals, quiet=True)
+    m.execute(gpu_context)
+    rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
+    assert np.array_equal(m.sorted_keys, rk)
+    assert np.array_equal(m.sorted_values, rv)
+    ok, ov = oracle.multi_radixsort(keys, B, vals)
+    assert np.array_equal(m.sorted_keys, ok) and np.array_equal(m.sorted_values, ov)
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 1000, 1024, 1025, 5000, 70001])
+def test_single_radixsort(gpu_context, oracle, n):
+    keys = rand_keys(n, n)
+    s = vrs.SingleRadixSort(keys=keys, quiet=True)
+    s.execute(gpu_context)
+    ref, _ = oracle.std_sort(keys)
+    assert oracle.test_sort(ref, s.sorted_keys) == -1
+    assert np.array_equal(oracle.single_radixsort(keys), s.sorted_keys)
+
+
+def test_single_radixsort_config0_1000_keys(gpu_context, oracle):
+    # BASELINE.json configs[0]: 1000 random uint32 keys, single_radixsort path, std::sort verification
+    keys = oracle.mt19937(1, 1000)
+    s = vrs.SingleRadixSort(keys=keys, quiet=True)
+    s.execute(gpu_context)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], s.sorted_keys) == -1
+
+
+def test_zero_elements_is_a_noop(gpu_context):
+    ctx = gpu_context
+    b0 = vrs.Buffer(ctx, S(0))
+    b1 = vrs.Buffer(ctx, S(0))
+    h = vrs.Buffer(ctx, S(1024))
+    pc = vrs.PushConstants(0, 0, 0, 32)
+    ctx.check(ctx.lib.vrs_multi_radixsort_histograms(ctx.handle, b0.handle, h.handle, ctypes.byref(pc)))
+    ctx.check(ctx.lib.vrs_multi_radixsort(ctx.handle, b0.handle, b1.handle, h.handle, ctypes.byref(pc)))
+    ctx.check(ctx.lib.vrs_single_radixsort(ctx.handle, b0.handle, b1.handle, 0))
+    ctx.waitIdle()
+    for b in (b0, b1, h):
+        b.release()
+
+
+def test_error_behaviour(gpu_context):
+    ctx = gpu_context
+    lib = ctx.lib
+    n = 1000
+    b0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), rand_keys(n, 1))
+    b1 = vrs.Buffer(ctx, S(4 * n))
+    small = vrs.Buffer(ctx, S(4 * (n - 1)))
+    h = vrs.Buffer(ctx, S(1024))
+    good = vrs.PushConstants(n, 0, 1, 32)
+    bad = [vrs.PushConstants(n, 3, 1, 32),   # shift not a multiple of 8
+           vrs.PushConstants(n, 32, 1, 32),  # shift out of range
+           vrs.PushConstants(n, 0, 1, 0),    # B == 0
+           vrs.PushConstants(n, 0, 1, 2),    # tiles do not cover N (would silently drop keys)
+           vrs.PushConstants(n, 0, 3, 32)]   # more workgroups than ceil(ceil(N/B)/256)
+    for pc in bad:
+        assert lib.vrs_multi_radixsort_histograms(ctx.handle, b0.handle, h.handle, ctypes.byref(pc)) == capi.VRS_ERROR_INVALID_ARGUMENT
+        assert lib.vrs_multi_radixsort(ctx.handle, b0.handle, b1.handle, h.handle, ctypes.byref(pc)) == capi.VRS_ERROR_INVALID_ARGUMENT
+        assert lib.vrs_last_error(ctx.handle)
+    # undersized / aliased buffers
+    assert lib.vrs_multi_radixsort(ctx.handle, b0.handle, small.handle, h.handle, ctypes.byref(good)) == capi.VRS_ERROR_INVALID_ARGUMENT
+    assert lib.vrs_multi_radixsort(ctx.handle, b0.handle, b0.handle, h.handle, ctypes.byref(good)) == capi.VRS_ERROR_INVALID_ARGUMENT
+    assert lib.vrs_multi_radixsort_histograms(ctx.handle, b0.handle, small.handle, ctypes.byref(vrs.PushConstants(10 ** 6, 0, 123, 32))) == capi.VRS_ERROR_INVALID_ARGUMENT
+    # released buffer -> exception through the wrapper (the reference throws std::runtime_error)
+    small.release()
+    small.release()  # idempotent
+    with pytest.raises(vrs.VrsError):
+        _ = small.handle
+    # the good call still works afterwards
+    ctx.check(lib.vrs_multi_radixsort_histograms(ctx.handle, b0.handle, h.handle, ctypes.byref(good)))
+    ctx.waitIdle()
+    for b in (b0, b1, h):
+        b.release()
+
+
+def test_wrapped_device_memory_own_usage(gpu_context, oracle):
+    """README.md:151-241 "own usage": caller-owned device memory (here: torch tensors) sorted in place of Buffers."""
+    torch = pytest.importorskip("torch")
+    n, B = 500003, 32
+    keys = rand_keys(n, 5)
+    dev = torch.device("cuda", gpu_context.device_ordinal)
+    t0 = torch.from_numpy(keys.view(np.int32)).to(dev)
+    t1 = torch.empty_like(t0)
+    W = gpu_context.lib.vrs_workgroup_count(n, B)
+    th = torch.empty(W * 256, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    bufs = [vrs.Buffer(gpu_context, S(4 * n), device_ptr=t.data_ptr()) for t in (t0, t1)]
+    hist = vrs.Buffer(gpu_context, S(W * 1024), device_ptr=th.data_ptr())
+    pc = vrs.PushConstants(n, 0, W, B)
+    for i in range(4):
+        pc.g_shift = 8 * i
+        src, dst = bufs[i % 2], bufs[(i + 1) % 2]
+        gpu_context.check(gpu_context.lib.vrs_multi_radixsort_histograms(gpu_context.handle, src.handle, hist.handle, ctypes.byref(pc)))
+        gpu_context.check(gpu_context.lib.vrs_multi_radixsort(gpu_context.handle, src.handle, dst.handle, hist.handle, ctypes.byref(pc)))
+    gpu_context.waitIdle()
+    out = t0.cpu().numpy().view(np.uint32)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    for b in bufs + [hist]:
+        b.release()
+
+
+def test_xcd_remap_is_performance_only(gpu_context, oracle):
+    keys = rand_keys(400000, 9)
+    outs = []
+    for flag in (0, 1):
+        gpu_context.setTuning(capi.VRS_TUNE_XCD_REMAP, flag)
+        m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=8, keys=keys, quiet=True)
+        m.execute(gpu_context)
+        outs.append(m.sorted_keys)
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], np.sort(keys))
+
+
+@pytest.mark.parametrize("n,B", [(10 ** 7, 32), (10 ** 7 + 123, 32)])
+def test_config1_1e7_keys(gpu_context, oracle, n, B):
+    # BASELINE.json configs[1]: 10^7 random uint32 keys, multi_radixsort (seeds 1,2,3)
+    for seed in (1, 2, 3):
+        keys = rand_keys(n, seed)
+        m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=B, keys=keys, quiet=True)
+        m.execute(gpu_context)
+        assert oracle.test_sort(oracle.std_sort(keys)[0], m.sorted_keys) == -1
+
+
+def _check_sorted_permutation(keys, out):
+    # size-independent properties at the full size: sortedness + multiset equality (byte-wise digit
+    # histograms of all four bytes and an order-independent checksum)
+    assert out.size == keys.size
+    assert np.all(out[1:] >= out[:-1]), "not sorted"
+    for shift in (0, 8, 16, 24):
+        a = np.bincount((keys >> np.uint32(shift)) & np.uint32(255), minlength=256)
+        b = np.bincount((out >> np.uint32(shift)) & np.uint32(255), minlength=256)
+        assert np.array_equal(a, b)
+    assert int(keys.astype(np.uint64).sum()) == int(out.astype(np.uint64).sum())
+    assert int(np.bitwise_xor.reduce(keys)) == int(np.bitwise_xor.reduce(out))
+
+
+def test_config2_1e8_keys_roofline_size(gpu_context, oracle):
+    # BASELINE.json configs[2]: 10^8 random uint32 keys -- bit-exact vs std::sort for seed 1
+    n = 10 ** 8
+    keys = rand_keys(n, 1)
+    m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=32, keys=keys, quiet=True)
+    m.setup(gpu_context)
+    m.enqueueSort()
+    gpu_context.waitIdle()
+    out = m.download()
+    m.releaseBuffers()
+    m.m_pass.release()
+    _check_sorted_permutation(keys, out)
+    ref, _ = oracle.std_sort(keys)
+    assert oracle.test_sort(ref, out) == -1
+
+
+def test_config3_1e8_pairs(gpu_context):
+    # BASELINE.json configs[3]: 10^8 key+payload pairs; payload[i] = i; verified by properties:
+    # keys sorted, keys[payload] reproduces the output keys (payload is a permutation that follows its key),
+    # and equal keys keep increasing payloads (stability)
+    n = 10 ** 8
+    keys = rand_keys(n, 2)
+    vals = np.arange(n, dtype=np.uint32)
+    m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=32, keys=keys, values=vals, quiet=True)
+    m.setup(gpu_context)
+    m.enqueueSort()
+    gpu_context.waitIdle()
+    ok = m.download()
+    ov = np.empty(n, np.uint32)
+    m.m_valueBuffers[0].downloadWithStagingBuffer(ov)
+    m.releaseBuffers()
+    m.m_pass.release()
+    assert np.all(ok[1:] >= ok[:-1])
+    assert np.array_equal(keys[ov], ok)
+    same = ok[1:] == ok[:-1]
+    assert np.all(ov[1:][same] > ov[:-1][same])
+    seen = np.zeros(n, np.bool_)
+    seen[ov] = True
+    assert seen.all()

@@ -1,0 +1,110 @@
+"""ctypes binding of the C ABI in include/vkradixsort_amd.h (the ONLY way Python reaches the GPU path).
+
+There is no fallback: if libvkradixsort_amd.so has not been built, or no HIP device is present, the
+calls raise.  Nothing here imports or knows about oracle/.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_int, c_size_t, c_uint32, c_uint64,
+                    c_void_p)
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libvkradixsort_amd.so"
+
+VRS_OK = 0
+VRS_ERROR_INVALID_ARGUMENT = 1
+VRS_ERROR_HIP = 2
+VRS_ERROR_NO_DEVICE = 3
+VRS_ERROR_OUT_OF_MEMORY = 4
+
+VRS_KERNEL_HISTOGRAM = 0
+VRS_KERNEL_PREFIX = 1
+VRS_KERNEL_SCATTER = 2
+VRS_KERNEL_SINGLE = 3
+KERNEL_NAMES = {0: "histogram", 1: "prefix", 2: "scatter", 3: "single"}
+
+VRS_TUNE_XCD_REMAP = 0
+
+
+class PushConstants(Structure):
+    """vrs_push_constants == MultiRadixSortPass::PushConstants(Histograms), 16 bytes std430."""
+    _fields_ = [("g_num_elements", c_uint32), ("g_shift", c_uint32), ("g_num_workgroups", c_uint32),
+                ("g_num_blocks_per_workgroup", c_uint32)]
+
+
+class VrsError(RuntimeError):
+    """Every failure of the reference is a std::runtime_error; this is its Python spelling."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"vkradixsort_amd error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+# every symbol include/vkradixsort_amd.h declares: (name, restype, argtypes)
+_SIGNATURES = [
+    ("vrs_version", c_char_p, []),
+    ("vrs_device_count", c_int, [POINTER(c_int)]),
+    ("vrs_context_create", c_int, [c_int, POINTER(c_void_p)]),
+    ("vrs_context_create_on_stream", c_int, [c_int, c_void_p, POINTER(c_void_p)]),
+    ("vrs_context_destroy", c_int, [c_void_p]),
+    ("vrs_last_error", c_char_p, [c_void_p]),
+    ("vrs_context_stream", c_void_p, [c_void_p]),
+    ("vrs_device_info", c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_int), POINTER(c_uint64)]),
+    ("vrs_buffer_create", c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    ("vrs_buffer_wrap", c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
+    ("vrs_buffer_release", c_int, [c_void_p]),
+    ("vrs_buffer_upload", c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    ("vrs_buffer_download", c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    ("vrs_buffer_copy", c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    ("vrs_buffer_device_ptr", c_void_p, [c_void_p]),
+    ("vrs_buffer_size_bytes", c_size_t, [c_void_p]),
+    ("vrs_global_invocation_size", c_uint32, [c_uint32, c_uint32]),
+    ("vrs_workgroup_count", c_uint32, [c_uint32, c_uint32]),
+    ("vrs_multi_radixsort_histograms", c_int, [c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
+    ("vrs_multi_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
+    ("vrs_multi_radixsort_pairs", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
+    ("vrs_queue_wait_idle", c_int, [c_void_p]),
+    ("vrs_single_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
+    ("vrs_profile_enable", c_int, [c_void_p, c_int]),
+    ("vrs_profile_reset", c_int, [c_void_p]),
+    ("vrs_profile_query", c_int, [c_void_p, c_int, POINTER(c_uint64), POINTER(c_double)]),
+    ("vrs_debug_download_offsets", c_int, [c_void_p, c_void_p, c_size_t]),
+    ("vrs_set_tuning", c_int, [c_void_p, c_int, c_int]),
+]
+
+EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen the in-tree library and type every entry point.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, restype, argtypes in _SIGNATURES:
+        fn = getattr(lib, name)  # AttributeError if the header and the library ever diverge
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, rc: int) -> None:
+    if rc != VRS_OK:
+        msg = load_library().vrs_last_error(ctx_handle)
+        raise VrsError(rc, msg.decode() if msg else "unknown error")
+
+
+def device_count() -> int:
+    n = c_int(0)
+    rc = load_library().vrs_device_count(byref(n))
+    return n.value if rc == VRS_OK else 0

@@ -1,0 +1,473 @@
+// vrs_capi.hip -- implementation of the C ABI declared in include/vkradixsort_amd.h.
+// Host side only: handles, argument validation, stream-ordered launches, event profiling.
+// There is NO CPU fallback: without a HIP device every entry point fails with VRS_ERROR_NO_DEVICE.
+#include "vkradixsort_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "vrs_kernels.h"
+
+struct vrs_context_t {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::string last_error;
+    vrs::PrefixScratch scratch;
+    uint32_t scratch_workgroups = 0;  // capacity of scratch.offsets in workgroups
+    uint32_t scratch_chunks = 0;      // capacity of scratch.chunk_sums in chunks
+    uint32_t last_offsets_workgroups = 0;
+    bool xcd_remap = true;
+    // profiling
+    bool profile = false;
+    struct EventPair {
+        hipEvent_t start, stop;
+    };
+    std::vector<EventPair> events[VRS_KERNEL_COUNT];
+    size_t events_used[VRS_KERNEL_COUNT] = {0, 0, 0, 0};
+};
+
+struct vrs_buffer_t {
+    vrs_context ctx = nullptr;
+    void *ptr = nullptr;
+    size_t size = 0;
+    bool owned = false;
+};
+
+namespace {
+
+thread_local std::string g_global_error;
+
+int fail(vrs_context ctx, int code, const std::string &msg) {
+    if (ctx)
+        ctx->last_error = msg;
+    else
+        g_global_error = msg;
+    return code;
+}
+
+int fail_hip(vrs_context ctx, const char *what, hipError_t e) {
+    std::string msg = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
+    return fail(ctx, e == hipErrorOutOfMemory ? VRS_ERROR_OUT_OF_MEMORY : VRS_ERROR_HIP, msg);
+}
+
+#define VRS_HIP(ctx, call)                                       \
+    do {                                                         \
+        hipError_t e__ = (call);                                 \
+        if (e__ != hipSuccess) return fail_hip((ctx), #call, e__); \
+    } while (0)
+
+int ensure_scratch(vrs_context ctx, uint32_t W) {
+    const uint32_t C = vrs::prefix_chunk_tiles(W);
+    const uint32_t G = (W + C - 1) / C;
+    if (W > ctx->scratch_workgroups) {
+        if (ctx->scratch.offsets) VRS_HIP(ctx, hipFree(ctx->scratch.offsets));
+        ctx->scratch.offsets = nullptr;
+        ctx->scratch_workgroups = 0;
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->scratch.offsets),
+                               static_cast<size_t>(W) * VRS_RADIX_SORT_BINS * sizeof(uint32_t)));
+        ctx->scratch_workgroups = W;
+    }
+    if (G > ctx->scratch_chunks) {
+        if (ctx->scratch.chunk_sums) VRS_HIP(ctx, hipFree(ctx->scratch.chunk_sums));
+        ctx->scratch.chunk_sums = nullptr;
+        ctx->scratch_chunks = 0;
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->scratch.chunk_sums),
+                               static_cast<size_t>(G) * VRS_RADIX_SORT_BINS * sizeof(uint32_t)));
+        ctx->scratch_chunks = G;
+    }
+    return VRS_OK;
+}
+
+// RAII-less event bracket: begin() before the launch, end() after.
+struct ProfileScope {
+    vrs_context ctx;
+    int id;
+    vrs_context_t::EventPair *pair = nullptr;
+    int begin() {
+        if (!ctx->profile) return VRS_OK;
+        auto &pool = ctx->events[id];
+        if (ctx->events_used[id] == pool.size()) {
+            vrs_context_t::EventPair p{};
+            VRS_HIP(ctx, hipEventCreate(&p.start));
+            VRS_HIP(ctx, hipEventCreate(&p.stop));
+            pool.push_back(p);
+        }
+        pair = &pool[ctx->events_used[id]++];
+        VRS_HIP(ctx, hipEventRecord(pair->start, ctx->stream));
+        return VRS_OK;
+    }
+    int end() {
+        if (!pair) return VRS_OK;
+        VRS_HIP(ctx, hipEventRecord(pair->stop, ctx->stream));
+        return VRS_OK;
+    }
+};
+
+int check_push_constants(vrs_context ctx, const vrs_push_constants *pc) {
+    if (!pc) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "push constants are NULL");
+    if (pc->g_shift > 24 || (pc->g_shift & 7u) != 0)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "g_shift must be 0, 8, 16 or 24");
+    if (pc->g_num_elements == 0) return VRS_OK;
+    if (pc->g_num_blocks_per_workgroup == 0)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "g_num_blocks_per_workgroup must be >= 1");
+    // the tiles described by (W, B) must cover all N keys, otherwise keys would silently be dropped
+    const uint64_t covered = static_cast<uint64_t>(pc->g_num_workgroups) * pc->g_num_blocks_per_workgroup *
+                             VRS_WORKGROUP_SIZE;
+    if (covered < pc->g_num_elements)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT,
+                    "g_num_workgroups * g_num_blocks_per_workgroup * 256 does not cover g_num_elements");
+    // and no workgroup may start past the end (the reference never launches one: ComputePass.h:24-29)
+    const uint64_t last_begin = static_cast<uint64_t>(pc->g_num_workgroups - 1) * pc->g_num_blocks_per_workgroup *
+                                VRS_WORKGROUP_SIZE;
+    if (last_begin >= pc->g_num_elements)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "g_num_workgroups is larger than ceil(ceil(N/B)/256)");
+    return VRS_OK;
+}
+
+int check_buffer(vrs_context ctx, vrs_buffer b, size_t need, const char *name) {
+    if (!b || !b->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, std::string(name) + " buffer is NULL or released");
+    if (b->ctx != ctx) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, std::string(name) + " buffer belongs to another context");
+    if (b->size < need) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, std::string(name) + " buffer is too small");
+    return VRS_OK;
+}
+
+int create_context(int device_ordinal, hipStream_t borrowed, bool borrow, vrs_context *out_ctx) {
+    if (!out_ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, VRS_ERROR_NO_DEVICE,
+                    std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device_ordinal < 0 || device_ordinal >= count)
+        return fail(nullptr, VRS_ERROR_NO_DEVICE, "device ordinal out of range");
+    e = hipSetDevice(device_ordinal);
+    if (e != hipSuccess) return fail_hip(nullptr, "hipSetDevice", e);
+    vrs_context ctx = new (std::nothrow) vrs_context_t();
+    if (!ctx) return fail(nullptr, VRS_ERROR_OUT_OF_MEMORY, "host allocation failed");
+    ctx->device = device_ordinal;
+    if (borrow) {
+        ctx->stream = borrowed;
+        ctx->owns_stream = false;
+    } else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return fail_hip(nullptr, "hipStreamCreateWithFlags", e);
+        }
+        ctx->owns_stream = true;
+    }
+    *out_ctx = ctx;
+    return VRS_OK;
+}
+
+int run_sort_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs_buffer values_in,
+                   vrs_buffer values_out, vrs_buffer histograms, const vrs_push_constants *pc, bool pairs) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    int rc = check_push_constants(ctx, pc);
+    if (rc) return rc;
+    const uint32_t n = pc->g_num_elements;
+    if (n == 0) return VRS_OK;
+    const uint32_t W = pc->g_num_workgroups;
+    const size_t key_bytes = static_cast<size_t>(n) * sizeof(uint32_t);
+    if ((rc = check_buffer(ctx, keys_in, key_bytes, "keys_in"))) return rc;
+    if ((rc = check_buffer(ctx, keys_out, key_bytes, "keys_out"))) return rc;
+    if ((rc = check_buffer(ctx, histograms, static_cast<size_t>(W) * VRS_RADIX_SORT_BINS * sizeof(uint32_t),
+                           "histograms")))
+        return rc;
+    if (keys_in->ptr == keys_out->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "keys_in and keys_out alias");
+    if (pairs) {
+        if ((rc = check_buffer(ctx, values_in, key_bytes, "values_in"))) return rc;
+        if ((rc = check_buffer(ctx, values_out, key_bytes, "values_out"))) return rc;
+        if (values_in->ptr == values_out->ptr)
+            return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "values_in and values_out alias");
+    }
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_scratch(ctx, W))) return rc;
+
+    ProfileScope ps{ctx, VRS_KERNEL_PREFIX};
+    if ((rc = ps.begin())) return rc;
+    VRS_HIP(ctx, vrs::launch_prefix(ctx->stream, static_cast<const uint32_t *>(histograms->ptr), ctx->scratch, W));
+    if ((rc = ps.end())) return rc;
+    ctx->last_offsets_workgroups = W;
+
+    ProfileScope ss{ctx, VRS_KERNEL_SCATTER};
+    if ((rc = ss.begin())) return rc;
+    VRS_HIP(ctx, vrs::launch_scatter(ctx->stream, static_cast<const uint32_t *>(keys_in->ptr),
+                                     static_cast<uint32_t *>(keys_out->ptr),
+                                     pairs ? static_cast<const uint32_t *>(values_in->ptr) : nullptr,
+                                     pairs ? static_cast<uint32_t *>(values_out->ptr) : nullptr, ctx->scratch.offsets,
+                                     n, pc->g_shift, W, pc->g_num_blocks_per_workgroup, ctx->xcd_remap));
+    if ((rc = ss.end())) return rc;
+    return VRS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vrs_version(void) { return "vkradixsort_amd 0.1.0 (gfx950)"; }
+
+int vrs_device_count(int *count) {
+    if (!count) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "count is NULL");
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(nullptr, VRS_ERROR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    return VRS_OK;
+}
+
+int vrs_context_create(int device_ordinal, vrs_context *out_ctx) {
+    return create_context(device_ordinal, nullptr, false, out_ctx);
+}
+
+int vrs_context_create_on_stream(int device_ordinal, void *hip_stream, vrs_context *out_ctx) {
+    return create_context(device_ordinal, static_cast<hipStream_t>(hip_stream), true, out_ctx);
+}
+
+int vrs_context_destroy(vrs_context ctx) {
+    if (!ctx) return VRS_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &pool : ctx->events)
+        for (auto &p : pool) {
+            (void)hipEventDestroy(p.start);
+            (void)hipEventDestroy(p.stop);
+        }
+    if (ctx->scratch.offsets) (void)hipFree(ctx->scratch.offsets);
+    if (ctx->scratch.chunk_sums) (void)hipFree(ctx->scratch.chunk_sums);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VRS_OK;
+}
+
+const char *vrs_last_error(vrs_context ctx) { return ctx ? ctx->last_error.c_str() : g_global_error.c_str(); }
+
+void *vrs_context_stream(vrs_context ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
+
+int vrs_device_info(vrs_context ctx, char *name, size_t name_cap, int *compute_units, uint64_t *global_mem_bytes) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    hipDeviceProp_t prop;
+    VRS_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_cap) std::snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (global_mem_bytes) *global_mem_bytes = prop.totalGlobalMem;
+    return VRS_OK;
+}
+
+int vrs_buffer_create(vrs_context ctx, size_t size_bytes, vrs_buffer *out_buf) {
+    if (!ctx || !out_buf) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or out_buf is NULL");
+    *out_buf = nullptr;
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    vrs_buffer b = new (std::nothrow) vrs_buffer_t();
+    if (!b) return fail(ctx, VRS_ERROR_OUT_OF_MEMORY, "host allocation failed");
+    // a zero-sized Buffer is legal at the boundary (N == 0); keep a real allocation behind it
+    hipError_t e = hipMalloc(&b->ptr, size_bytes ? size_bytes : 16);
+    if (e != hipSuccess) {
+        delete b;
+        return fail_hip(ctx, "hipMalloc", e);
+    }
+    b->ctx = ctx;
+    b->size = size_bytes;
+    b->owned = true;
+    *out_buf = b;
+    return VRS_OK;
+}
+
+int vrs_buffer_wrap(vrs_context ctx, void *device_ptr, size_t size_bytes, vrs_buffer *out_buf) {
+    if (!ctx || !out_buf) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or out_buf is NULL");
+    *out_buf = nullptr;
+    if (!device_ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "device_ptr is NULL");
+    if (reinterpret_cast<uintptr_t>(device_ptr) & 15u)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "device_ptr must be 16-byte aligned");
+    vrs_buffer b = new (std::nothrow) vrs_buffer_t();
+    if (!b) return fail(ctx, VRS_ERROR_OUT_OF_MEMORY, "host allocation failed");
+    b->ctx = ctx;
+    b->ptr = device_ptr;
+    b->size = size_bytes;
+    b->owned = false;
+    *out_buf = b;
+    return VRS_OK;
+}
+
+int vrs_buffer_release(vrs_buffer buf) {
+    if (!buf) return VRS_OK;
+    int rc = VRS_OK;
+    if (buf->ptr && buf->owned) {
+        (void)hipSetDevice(buf->ctx->device);
+        hipError_t e = hipFree(buf->ptr);
+        if (e != hipSuccess) rc = fail_hip(buf->ctx, "hipFree", e);
+    }
+    buf->ptr = nullptr;
+    delete buf;
+    return rc;
+}
+
+int vrs_buffer_upload(vrs_context ctx, vrs_buffer buf, const void *host_data, size_t size_bytes) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    int rc = check_buffer(ctx, buf, size_bytes, "upload");
+    if (rc) return rc;
+    if (size_bytes == 0) return VRS_OK;
+    if (!host_data) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "host_data is NULL");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    VRS_HIP(ctx, hipMemcpyAsync(buf->ptr, host_data, size_bytes, hipMemcpyHostToDevice, ctx->stream));
+    VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VRS_OK;
+}
+
+int vrs_buffer_download(vrs_context ctx, vrs_buffer buf, void *host_data, size_t size_bytes) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    int rc = check_buffer(ctx, buf, size_bytes, "download");
+    if (rc) return rc;
+    if (size_bytes == 0) return VRS_OK;
+    if (!host_data) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "host_data is NULL");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    VRS_HIP(ctx, hipMemcpyAsync(host_data, buf->ptr, size_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VRS_OK;
+}
+
+int vrs_buffer_copy(vrs_context ctx, vrs_buffer dst, vrs_buffer src, size_t size_bytes) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    int rc = check_buffer(ctx, dst, size_bytes, "copy dst");
+    if (rc) return rc;
+    if ((rc = check_buffer(ctx, src, size_bytes, "copy src"))) return rc;
+    if (size_bytes == 0) return VRS_OK;
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    VRS_HIP(ctx, hipMemcpyAsync(dst->ptr, src->ptr, size_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return VRS_OK;
+}
+
+void *vrs_buffer_device_ptr(vrs_buffer buf) { return buf ? buf->ptr : nullptr; }
+
+size_t vrs_buffer_size_bytes(vrs_buffer buf) { return buf ? buf->size : 0; }
+
+uint32_t vrs_global_invocation_size(uint32_t num_elements, uint32_t blocks_per_workgroup) {
+    if (blocks_per_workgroup == 0) return 0;
+    return num_elements / blocks_per_workgroup + (num_elements % blocks_per_workgroup ? 1u : 0u);
+}
+
+uint32_t vrs_workgroup_count(uint32_t num_elements, uint32_t blocks_per_workgroup) {
+    const uint32_t gis = vrs_global_invocation_size(num_elements, blocks_per_workgroup);
+    return gis / VRS_WORKGROUP_SIZE + (gis % VRS_WORKGROUP_SIZE ? 1u : 0u);
+}
+
+int vrs_multi_radixsort_histograms(vrs_context ctx, vrs_buffer keys_in, vrs_buffer histograms,
+                                   const vrs_push_constants *pc) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    int rc = check_push_constants(ctx, pc);
+    if (rc) return rc;
+    if (pc->g_num_elements == 0) return VRS_OK;
+    if ((rc = check_buffer(ctx, keys_in, static_cast<size_t>(pc->g_num_elements) * sizeof(uint32_t), "keys_in")))
+        return rc;
+    if ((rc = check_buffer(ctx, histograms,
+                           static_cast<size_t>(pc->g_num_workgroups) * VRS_RADIX_SORT_BINS * sizeof(uint32_t),
+                           "histograms")))
+        return rc;
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    ProfileScope ps{ctx, VRS_KERNEL_HISTOGRAM};
+    if ((rc = ps.begin())) return rc;
+    VRS_HIP(ctx, vrs::launch_histograms(ctx->stream, static_cast<const uint32_t *>(keys_in->ptr),
+                                        static_cast<uint32_t *>(histograms->ptr), pc->g_num_elements, pc->g_shift,
+                                        pc->g_num_workgroups, pc->g_num_blocks_per_workgroup));
+    if ((rc = ps.end())) return rc;
+    return VRS_OK;
+}
+
+int vrs_multi_radixsort(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs_buffer histograms,
+                        const vrs_push_constants *pc) {
+    return run_sort_stage(ctx, keys_in, keys_out, nullptr, nullptr, histograms, pc, false);
+}
+
+int vrs_multi_radixsort_pairs(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs_buffer values_in,
+                              vrs_buffer values_out, vrs_buffer histograms, const vrs_push_constants *pc) {
+    return run_sort_stage(ctx, keys_in, keys_out, values_in, values_out, histograms, pc, true);
+}
+
+int vrs_queue_wait_idle(vrs_context ctx) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VRS_OK;
+}
+
+int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1, uint32_t g_num_elements) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (g_num_elements == 0) return VRS_OK;
+    const size_t bytes = static_cast<size_t>(g_num_elements) * sizeof(uint32_t);
+    int rc = check_buffer(ctx, buffer0, bytes, "buffer0");
+    if (rc) return rc;
+    if ((rc = check_buffer(ctx, buffer1, bytes, "buffer1"))) return rc;
+    if (buffer0->ptr == buffer1->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "buffer0 and buffer1 alias");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    ProfileScope ps{ctx, VRS_KERNEL_SINGLE};
+    if ((rc = ps.begin())) return rc;
+    VRS_HIP(ctx, vrs::launch_single(ctx->stream, static_cast<uint32_t *>(buffer0->ptr),
+                                    static_cast<uint32_t *>(buffer1->ptr), g_num_elements));
+    if ((rc = ps.end())) return rc;
+    return VRS_OK;
+}
+
+int vrs_profile_enable(vrs_context ctx, int enabled) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    ctx->profile = enabled != 0;
+    return VRS_OK;
+}
+
+int vrs_profile_reset(vrs_context ctx) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &u : ctx->events_used) u = 0;
+    return VRS_OK;
+}
+
+int vrs_profile_query(vrs_context ctx, int kernel_id, uint64_t *launches, double *total_ms) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (kernel_id < 0 || kernel_id >= VRS_KERNEL_COUNT)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "kernel_id out of range");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double sum = 0.0;
+    const size_t used = ctx->events_used[kernel_id];
+    for (size_t i = 0; i < used; ++i) {
+        float ms = 0.f;
+        VRS_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[kernel_id][i].start, ctx->events[kernel_id][i].stop));
+        sum += ms;
+    }
+    if (launches) *launches = used;
+    if (total_ms) *total_ms = sum;
+    return VRS_OK;
+}
+
+int vrs_debug_download_offsets(vrs_context ctx, void *host_data, size_t size_bytes) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    const size_t have = static_cast<size_t>(ctx->last_offsets_workgroups) * VRS_RADIX_SORT_BINS * sizeof(uint32_t);
+    if (!host_data || size_bytes > have)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "offset table is smaller than the requested size");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    VRS_HIP(ctx, hipMemcpyAsync(host_data, ctx->scratch.offsets, size_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VRS_OK;
+}
+
+int vrs_set_tuning(vrs_context ctx, int key, int value) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    switch (key) {
+        case VRS_TUNE_XCD_REMAP:
+            ctx->xcd_remap = value != 0;
+            return VRS_OK;
+        default:
+            return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "unknown tuning key");
+    }
+}
+
+}  // extern "C"
