@@ -149,9 +149,20 @@ int vrs_profile_query(vrs_context ctx, int kernel_id, uint64_t *launches, double
  * global_offsets for every workgroup) computed by the most recent RADIX_SORT stage. */
 int vrs_debug_download_offsets(vrs_context ctx, void *host_data, size_t size_bytes);
 
+/* Test hook: checks on the device that one returning LDS atomic hands same-address lanes their
+ * pre-values in ascending lane order (what the RANK_ATOMIC scatter variants rely on); returns the
+ * number of lanes whose rank differs from the __ballot-based rank over `rounds` rounds per wave. */
+int vrs_debug_atomic_rank_selftest(vrs_context ctx, uint32_t rounds, uint32_t seed, uint64_t *mismatches);
+
+/* Ranking method in effect: 1 = __ballot match-any, 2 = returning LDS atomics. */
+int vrs_rank_mode(vrs_context ctx);
+
 /* Tuning knobs (performance only, never results). */
 typedef enum vrs_tuning_key {
-    VRS_TUNE_XCD_REMAP = 0 /* 1 (default): consecutive tiles share an XCD's L2 in the scatter */
+    VRS_TUNE_XCD_REMAP = 0,      /* 1 (default): consecutive tiles share an XCD's L2 in the scatter */
+    VRS_TUNE_SCATTER_VARIANT = 1, /* 0 (default): chosen from B; else ITEMS*1000 + WAVES*10 + RANK */
+    VRS_TUNE_RANK_MODE = 3        /* 0 (default) auto: LDS-atomic ranking if the device self-test passed at
+                                     context creation, else __ballot ranking; 1 force ballot; 2 force atomic */
 } vrs_tuning_key;
 int vrs_set_tuning(vrs_context ctx, int key, int value);
 

@@ -123,3 +123,18 @@ def test_ping_pong_binding_table_matches_reference():
     assert seen[1] == ("buf1", "buf1", "buf0", "hist", "hist") == seen[3]
     with pytest.raises(vrs.VrsError):
         m.m_pass._bound(R, 7)
+
+
+def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu():
+    """g++ builds the engine:: classes against the C ABI; without a device main() reports and returns 1
+    (the reference's catch-all: MultiRadixSortExample.cpp:20-23)."""
+    import subprocess
+    from vkradixsort_amd import build
+    lib, exes = build.build_host()
+    assert lib.exists() and all(e.exists() for e in exes)
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    for exe in exes:
+        p = subprocess.run([str(exe), "1000"], capture_output=True, text=True, timeout=60)
+        assert p.returncode == 1
+        assert "no HIP device" in p.stderr

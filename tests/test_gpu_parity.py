@@ -295,3 +295,51 @@ def test_config3_1e8_pairs(gpu_context):
     seen = np.zeros(n, np.bool_)
     seen[ov] = True
     assert seen.all()
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["ballot", "atomic"])
+def test_both_ranking_methods_are_bit_exact(gpu_context, oracle, mode):
+    """RANK_MODE 1 = __ballot match-any (architecturally ordered), 2 = returning LDS atomics (lane order
+    verified by the device self-test).  Both must reproduce every stage of the oracle."""
+    mm = ctypes.c_uint64(1)
+    gpu_context.check(gpu_context.lib.vrs_debug_atomic_rank_selftest(gpu_context.handle, 2048, 777, ctypes.byref(mm)))
+    assert mm.value == 0, "this device does not serve same-address LDS atomics in lane order"
+    gpu_context.setTuning(capi.VRS_TUNE_RANK_MODE, mode)
+    assert gpu_context.lib.vrs_rank_mode(gpu_context.handle) == mode
+    try:
+        for n, B in [(300001, 32), (100003, 16), (65536, 64), (12345, 8)]:
+            keys = rand_keys(n, n + mode) & np.uint32(0x0F0FFFFF)  # duplicates in the upper digits
+            r = StageRunner(gpu_context, keys, B)
+            try:
+                cur = keys
+                for i in range(4):
+                    hist, offsets, out = r.run_pass(i)
+                    ohist = oracle.histograms(cur, 8 * i, r.W, B)
+                    cur = oracle.scatter(cur, ohist, 8 * i, r.W, B)
+                    assert np.array_equal(hist, ohist) and np.array_equal(out, cur), (mode, n, B, i)
+            finally:
+                r.close()
+        vals = np.arange(200000, dtype=np.uint32)
+        keys = rand_keys(200000, 3) & np.uint32(0xFF)
+        m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=32, keys=keys, values=vals, quiet=True)
+        m.execute(gpu_context)
+        rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
+        assert np.array_equal(m.sorted_keys, rk) and np.array_equal(m.sorted_values, rv)
+    finally:
+        gpu_context.setTuning(capi.VRS_TUNE_RANK_MODE, 0)
+
+
+def test_cpp_host_examples_run_and_verify():
+    """The C++ drop-in (engine::MultiRadixSort over the C ABI) prints the reference's lines and exits 0."""
+    import subprocess
+    from vkradixsort_amd import build
+    _, exes = build.build_host()
+    multi, single = exes
+    for args in (["1000000"], ["1000", "1"], ["100003", "7", "5"], ["2000000", "32", "2", "3", "28bit"]):
+        p = subprocess.run([str(multi), *args], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "[MultiRadixSort] Sorting " + str(int(float(args[0]))) + " 32bit numbers." in p.stdout
+        assert "GPU sort finished in" in p.stdout and "CPU sort finished in" in p.stdout
+        assert "[MultiRadixSort] Test passed." in p.stdout
+    p = subprocess.run([str(single), "1000"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "[SingleRadixSort] Test passed." in p.stdout, p.stdout + p.stderr

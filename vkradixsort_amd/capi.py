@@ -25,6 +25,8 @@ VRS_KERNEL_SINGLE = 3
 KERNEL_NAMES = {0: "histogram", 1: "prefix", 2: "scatter", 3: "single"}
 
 VRS_TUNE_XCD_REMAP = 0
+VRS_TUNE_SCATTER_VARIANT = 1
+VRS_TUNE_RANK_MODE = 3
 
 
 class PushConstants(Structure):
@@ -72,12 +74,35 @@ _SIGNATURES = [
     ("vrs_profile_reset", c_int, [c_void_p]),
     ("vrs_profile_query", c_int, [c_void_p, c_int, POINTER(c_uint64), POINTER(c_double)]),
     ("vrs_debug_download_offsets", c_int, [c_void_p, c_void_p, c_size_t]),
+    ("vrs_debug_atomic_rank_selftest", c_int, [c_void_p, c_uint32, c_uint32, POINTER(c_uint64)]),
+    ("vrs_rank_mode", c_int, [c_void_p]),
     ("vrs_set_tuning", c_int, [c_void_p, c_int, c_int]),
 ]
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 
 _lib = None
+
+
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so (same SONAME as
+    /opt/rocm's).  If this library pulled in the system copy first and torch were imported afterwards, the
+    process would hold two runtimes and torch would report "No HIP GPUs are available".  So when torch is
+    installed, map ITS runtime first (without importing torch); the SONAME match makes our library bind to it."""
+    import importlib.util
+    import os
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load_library() -> ctypes.CDLL:
@@ -89,6 +114,7 @@ def load_library() -> ctypes.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+    _preload_torch_hip_runtime()
     lib = ctypes.CDLL(str(LIB_PATH))
     for name, restype, argtypes in _SIGNATURES:
         fn = getattr(lib, name)  # AttributeError if the header and the library ever diverge

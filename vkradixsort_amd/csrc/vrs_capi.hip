@@ -23,6 +23,8 @@ struct vrs_context_t {
     uint32_t scratch_chunks = 0;      // capacity of scratch.chunk_sums in chunks
     uint32_t last_offsets_workgroups = 0;
     bool xcd_remap = true;
+    vrs::ScatterLaunch scatter;
+    bool atomic_rank_verified = false;  // device self-test result (context creation)
     // profiling
     bool profile = false;
     struct EventPair {
@@ -137,6 +139,21 @@ int check_buffer(vrs_context ctx, vrs_buffer b, size_t need, const char *name) {
     return VRS_OK;
 }
 
+// Runs the lane-order self-test the RANK_ATOMIC scatter variants depend on (see vrs_kernels.hip).
+int atomic_rank_selftest(vrs_context ctx, uint32_t rounds, uint32_t seed, uint64_t *mismatches) {
+    unsigned long long *d = nullptr;
+    VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = vrs::launch_atomic_rank_selftest(ctx->stream, rounds, seed, d);
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(ctx, "atomic rank selftest", e);
+    *mismatches = h;
+    return VRS_OK;
+}
+
 int create_context(int device_ordinal, hipStream_t borrowed, bool borrow, vrs_context *out_ctx) {
     if (!out_ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "out_ctx is NULL");
     *out_ctx = nullptr;
@@ -152,6 +169,11 @@ int create_context(int device_ordinal, hipStream_t borrowed, bool borrow, vrs_co
     vrs_context ctx = new (std::nothrow) vrs_context_t();
     if (!ctx) return fail(nullptr, VRS_ERROR_OUT_OF_MEMORY, "host allocation failed");
     ctx->device = device_ordinal;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->scatter.compute_units = prop.multiProcessorCount;
+    }
     if (borrow) {
         ctx->stream = borrowed;
         ctx->owns_stream = false;
@@ -162,6 +184,16 @@ int create_context(int device_ordinal, hipStream_t borrowed, bool borrow, vrs_co
             return fail_hip(nullptr, "hipStreamCreateWithFlags", e);
         }
         ctx->owns_stream = true;
+    }
+    // Pick the ranking method for this device: returning LDS atomics are ~25 % faster in the scatter but
+    // need same-address lanes served in ascending lane order, which is observed, not promised.  Probe it
+    // (about 0.3 ms); fall back to the __ballot ranking if a single lane disagrees.
+    {
+        uint64_t mismatches = 1;
+        if (atomic_rank_selftest(ctx, 512, 0x5EEDu, &mismatches) == VRS_OK && mismatches == 0)
+            ctx->atomic_rank_verified = true;
+        ctx->scatter.atomic_rank = ctx->atomic_rank_verified;
+        ctx->last_error.clear();
     }
     *out_ctx = ctx;
     return VRS_OK;
@@ -203,7 +235,8 @@ int run_sort_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs
                                      static_cast<uint32_t *>(keys_out->ptr),
                                      pairs ? static_cast<const uint32_t *>(values_in->ptr) : nullptr,
                                      pairs ? static_cast<uint32_t *>(values_out->ptr) : nullptr, ctx->scratch.offsets,
-                                     n, pc->g_shift, W, pc->g_num_blocks_per_workgroup, ctx->xcd_remap));
+                                     n, pc->g_shift, W, pc->g_num_blocks_per_workgroup, ctx->xcd_remap,
+                                     ctx->scatter));
     if ((rc = ss.end())) return rc;
     return VRS_OK;
 }
@@ -459,12 +492,35 @@ int vrs_debug_download_offsets(vrs_context ctx, void *host_data, size_t size_byt
     return VRS_OK;
 }
 
+int vrs_debug_atomic_rank_selftest(vrs_context ctx, uint32_t rounds, uint32_t seed, uint64_t *mismatches) {
+    if (!ctx || !mismatches) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or mismatches is NULL");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    return atomic_rank_selftest(ctx, rounds, seed, mismatches);
+}
+
+int vrs_rank_mode(vrs_context ctx) { return ctx && ctx->scatter.atomic_rank ? 2 : 1; }
+
 int vrs_set_tuning(vrs_context ctx, int key, int value) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     switch (key) {
         case VRS_TUNE_XCD_REMAP:
             ctx->xcd_remap = value != 0;
             return VRS_OK;
+        case VRS_TUNE_SCATTER_VARIANT:
+            ctx->scatter.variant = value;
+            return VRS_OK;
+        case VRS_TUNE_RANK_MODE: {
+            if (value == 1) {
+                ctx->scatter.atomic_rank = false;
+            } else if (value == 2) {
+                ctx->scatter.atomic_rank = true;
+            } else if (value == 0) {
+                ctx->scatter.atomic_rank = ctx->atomic_rank_verified;
+            } else {
+                return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "rank mode must be 0 (auto), 1 (ballot) or 2 (atomic)");
+            }
+            return VRS_OK;
+        }
         default:
             return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "unknown tuning key");
     }

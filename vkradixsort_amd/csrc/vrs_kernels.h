@@ -12,6 +12,14 @@ struct PrefixScratch {
     uint32_t *chunk_sums = nullptr;
 };
 
+// How the scatter is launched (performance only).
+struct ScatterLaunch {
+    int variant = 0;          // 0 = choose from B; else OCC*100000 + ITEMS*1000 + WAVES*10 + RANK
+    bool atomic_rank = false; // rank with returning LDS atomics (only after the device self-test passed)
+    int wgs_per_cu = 0;     // 0 = occupancy API
+    int compute_units = 256;
+};
+
 // tiles per chunk for the two-level prefix: smallest power of two C with C*C >= W
 uint32_t prefix_chunk_tiles(uint32_t num_workgroups);
 
@@ -23,7 +31,11 @@ hipError_t launch_prefix(hipStream_t stream, const uint32_t *hist, const PrefixS
 
 hipError_t launch_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
                           const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets,
-                          uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap);
+                          uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap,
+                          const ScatterLaunch &cfg);
+
+hipError_t launch_atomic_rank_selftest(hipStream_t stream, uint32_t rounds, uint32_t seed,
+                                       unsigned long long *mismatches);
 
 hipError_t launch_single(hipStream_t stream, uint32_t *buffer0, uint32_t *buffer1, uint32_t n);
 

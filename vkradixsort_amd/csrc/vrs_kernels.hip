@@ -16,6 +16,12 @@
 //   K4 single_kernel      the single_radixsort path: four passes inside one workgroup.
 #include "vrs_kernels.h"
 
+// Phase-timing hooks for tools/lab (compiled out of the product library).
+#ifndef VRS_MARK
+#define VRS_MARK(i)
+#define VRS_MARK_FLUSH()
+#endif
+
 namespace vrs {
 
 constexpr int kBins = 256;     // RADIX_SORT_BINS
@@ -66,11 +72,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1: per-tile digit histogram.
-// One LDS counter per digit; a wave whose 64 keys all carry the same digit (sorted / constant /
-// zero upper bytes -- the reference's own 28-bit keys make pass 3 mostly that) is detected with one
-// __ballot and collapsed into a single ds_add of __popcll(mask) instead of a 64-way same-address
-// atomic.
+// K1: per-tile digit histogram.  One workgroup per contract tile, 16-byte coalesced loads, one LDS
+// counter per digit.  The kernel must stay HBM-bound (a bare 400 MB read takes ~64 us on this
+// chip), so the per-key instruction count matters: 2 VALU + 1 ds_add per key on the plain path.
+// Skew guard: a __ballot vote per 4-key vector detects the wave whose 256 keys all carry ONE digit
+// (sorted / constant / zero upper bytes -- the reference's own 28-bit keys make pass 3 mostly that)
+// and collapses 256 same-address LDS atomics into a single ds_add of the population count.
+// (single-key form, used by the single_radixsort kernel)
 __device__ __forceinline__ void histogram_count(uint32_t *s_hist, uint32_t key, uint32_t shift, bool valid) {
     const uint32_t d = digit_of(key, shift);
     const uint64_t active = __ballot(valid);
@@ -82,6 +90,22 @@ __device__ __forceinline__ void histogram_count(uint32_t *s_hist, uint32_t key, 
         if (lane_id() == first) atomicAdd(&s_hist[d0], static_cast<uint32_t>(__popcll(active)));
     } else if (valid) {
         atomicAdd(&s_hist[d], 1u);
+    }
+}
+
+// all 64 lanes hold a valid uint4
+__device__ __forceinline__ void histogram_count4(uint32_t *s_hist, uint4 q, uint32_t shift) {
+    const uint32_t dx = digit_of(q.x, shift), dy = digit_of(q.y, shift), dz = digit_of(q.z, shift),
+                   dw = digit_of(q.w, shift);
+    const uint32_t d0 = __builtin_amdgcn_readfirstlane(dx);
+    const bool mine = ((dx ^ d0) | (dy ^ d0) | (dz ^ d0) | (dw ^ d0)) == 0u;
+    if (__ballot(mine) == ~0ull) {  // wave-uniform branch
+        if (lane_id() == 0u) atomicAdd(&s_hist[d0], 256u);
+    } else {
+        atomicAdd(&s_hist[dx], 1u);
+        atomicAdd(&s_hist[dy], 1u);
+        atomicAdd(&s_hist[dz], 1u);
+        atomicAdd(&s_hist[dw], 1u);
     }
 }
 
@@ -103,22 +127,21 @@ __global__ __launch_bounds__(kThreads) void histogram_kernel(const uint32_t *__r
         // buffer base is (checked by the host).
         const uint4 *v = reinterpret_cast<const uint4 *>(keys + tile_begin);
         const uint32_t nvec = len >> 2;
-        for (uint32_t i0 = 0; i0 < nvec; i0 += kThreads * UNROLL) {
+        constexpr uint32_t kStep = kThreads * UNROLL;  // vectors per fully unrolled step
+        uint32_t i0 = 0;
+        for (; i0 + kStep <= nvec; i0 += kStep) {  // every lane of every wave holds valid vectors
             uint4 q[UNROLL];
-            bool ok[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const uint32_t i = i0 + u * kThreads + tid;
-                ok[u] = i < nvec;
-                q[u] = ok[u] ? v[i] : make_uint4(0, 0, 0, 0);
-            }
+            for (int u = 0; u < UNROLL; ++u) q[u] = v[i0 + u * kThreads + tid];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                histogram_count(s_hist, q[u].x, shift, ok[u]);
-                histogram_count(s_hist, q[u].y, shift, ok[u]);
-                histogram_count(s_hist, q[u].z, shift, ok[u]);
-                histogram_count(s_hist, q[u].w, shift, ok[u]);
-            }
+            for (int u = 0; u < UNROLL; ++u) histogram_count4(s_hist, q[u], shift);
+        }
+        for (uint32_t i = i0 + tid; i < nvec; i += kThreads) {  // ragged remainder of the tile
+            const uint4 q = v[i];
+            atomicAdd(&s_hist[digit_of(q.x, shift)], 1u);
+            atomicAdd(&s_hist[digit_of(q.y, shift)], 1u);
+            atomicAdd(&s_hist[digit_of(q.z, shift)], 1u);
+            atomicAdd(&s_hist[digit_of(q.w, shift)], 1u);
         }
         const uint32_t tail = (nvec << 2) + tid;  // at most 3 keys
         if (tail < len) atomicAdd(&s_hist[digit_of(keys[tile_begin + tail], shift)], 1u);
@@ -129,214 +152,374 @@ __global__ __launch_bounds__(kThreads) void histogram_kernel(const uint32_t *__r
 
 // ---------------------------------------------------------------------------------------------
 // K2: offsets from the [W][256] table in O(W*256) (the reference re-sums the whole table in every
-// workgroup: O(W^2*256), multi_radixsort.comp:58-62).  Tiles are grouped in chunks of C.
-//   chunk_sum_kernel : chunk_sums[g][d] = sum of hist rows of chunk g
-//   offsets_kernel   : base_d = excl_scan_d(sum_g chunk_sums[g][d]); walks chunk g's rows writing
-//                      offsets[w][d] = base_d + (rows before w)
-__global__ __launch_bounds__(kThreads) void chunk_sum_kernel(const uint32_t *__restrict__ hist,
-                                                             uint32_t *__restrict__ chunk_sums, uint32_t W,
-                                                             uint32_t C) {
-    const uint32_t d = threadIdx.x;
-    const uint32_t row0 = blockIdx.x * C;
-    const uint32_t rows = min(C, W - row0);
-    const uint32_t *p = hist + static_cast<size_t>(row0) * kBins + d;
+// workgroup: O(W^2*256), multi_radixsort.comp:58-62).  Tiles are grouped in chunks of C rows.
+//   chunk_sum_kernel : chunk_sums[g][d] = sum of the hist rows of chunk g
+//   offsets_kernel   : base_d = excl_scan_d(sum_g chunk_sums[g][d]); offsets[w][d] = base_d + (rows before w)
+// Both are latency-bound (a few MB), so each workgroup is 1024 threads = 4 row groups x 256 digits
+// and every thread issues all of its independent row loads before it consumes any.
+constexpr int kPrefixThreads = 1024;
+constexpr int kPrefixGroups = kPrefixThreads / kBins;
+
+// sum of rows [r0, r0 + cnt) step `stride` of a [rows][256] table, column d; 8 loads in flight
+__device__ __forceinline__ uint32_t column_sum(const uint32_t *__restrict__ p, uint32_t r0, uint32_t r1,
+                                               uint32_t stride) {
     uint32_t s = 0;
-    uint32_t j = 0;
-    for (; j + 8 <= rows; j += 8) {
+    uint32_t r = r0;
+    for (; r + 7u * stride < r1; r += 8u * stride) {
         uint32_t t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p[static_cast<size_t>(j + u) * kBins];
+        for (int u = 0; u < 8; ++u) t[u] = p[static_cast<size_t>(r + u * stride) * kBins];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += t[u];
     }
-    for (; j < rows; ++j) s += p[static_cast<size_t>(j) * kBins];
-    chunk_sums[static_cast<size_t>(blockIdx.x) * kBins + d] = s;
+    for (; r < r1; r += stride) s += p[static_cast<size_t>(r) * kBins];
+    return s;
 }
 
-__global__ __launch_bounds__(kThreads) void offsets_kernel(const uint32_t *__restrict__ hist,
-                                                           const uint32_t *__restrict__ chunk_sums,
-                                                           uint32_t *__restrict__ offsets, uint32_t W, uint32_t C,
-                                                           uint32_t G) {
-    __shared__ uint32_t s_tmp[kWaves];
-    const uint32_t d = threadIdx.x;
-    const uint32_t g = blockIdx.x;
-    uint32_t before = 0, total = 0;
-    for (uint32_t j = 0; j < G; ++j) {
-        const uint32_t v = chunk_sums[static_cast<size_t>(j) * kBins + d];
-        before += (j < g) ? v : 0u;
-        total += v;
+__global__ __launch_bounds__(kPrefixThreads) void chunk_sum_kernel(const uint32_t *__restrict__ hist,
+                                                                   uint32_t *__restrict__ chunk_sums, uint32_t W,
+                                                                   uint32_t C) {
+    __shared__ uint32_t s_part[kPrefixGroups][kBins];
+    const uint32_t d = threadIdx.x & (kBins - 1), grp = threadIdx.x >> 8;
+    const uint32_t row0 = blockIdx.x * C;
+    const uint32_t rows = min(C, W - row0);
+    s_part[grp][d] = column_sum(hist + static_cast<size_t>(row0) * kBins + d, grp, rows, kPrefixGroups);
+    __syncthreads();
+    if (grp == 0) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < kPrefixGroups; ++k) s += s_part[k][d];
+        chunk_sums[static_cast<size_t>(blockIdx.x) * kBins + d] = s;
     }
-    const uint32_t base = block_exclusive_scan(total, s_tmp, d & 63u, d >> 6);
-    uint32_t run = base + before;
+}
+
+__global__ __launch_bounds__(kPrefixThreads) void offsets_kernel(const uint32_t *__restrict__ hist,
+                                                                 const uint32_t *__restrict__ chunk_sums,
+                                                                 uint32_t *__restrict__ offsets, uint32_t W, uint32_t C,
+                                                                 uint32_t G) {
+    __shared__ uint32_t s_before[kPrefixGroups][kBins];
+    __shared__ uint32_t s_after[kPrefixGroups][kBins];
+    __shared__ uint32_t s_quarter[kPrefixGroups][kBins];
+    __shared__ uint32_t s_base[kBins];
+    __shared__ uint32_t s_tmp[kPrefixThreads / 64];
+    const uint32_t d = threadIdx.x & (kBins - 1), grp = threadIdx.x >> 8;
+    const uint32_t g = blockIdx.x;
+    // (1) chunk totals before this chunk / from this chunk on, split over the 4 row groups
+    s_before[grp][d] = column_sum(chunk_sums + d, grp, g, kPrefixGroups);
+    s_after[grp][d] = column_sum(chunk_sums + d, g + grp, G, kPrefixGroups);
+    // (2) this chunk's rows in 4 contiguous quarters: quarter sums
     const uint32_t row0 = g * C;
     const uint32_t rows = min(C, W - row0);
+    const uint32_t per = (rows + kPrefixGroups - 1) / kPrefixGroups;
+    const uint32_t q0 = min(grp * per, rows), q1 = min(q0 + per, rows);
     const uint32_t *p = hist + static_cast<size_t>(row0) * kBins + d;
+    s_quarter[grp][d] = column_sum(p, q0, q1, 1);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    if (grp == 0) {
+#pragma unroll
+        for (int k = 0; k < kPrefixGroups; ++k) {
+            before += s_before[k][d];
+            total += s_before[k][d] + s_after[k][d];
+        }
+    }
+    // exclusive scan of the 256 digit totals (waves 0..3 carry them, the rest carry zeros)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if (lane >= static_cast<uint32_t>(o)) incl += up;
+    }
+    if (lane == 63u) s_tmp[wave] = incl;
+    __syncthreads();
+    if (grp == 0) {
+        uint32_t base = incl - total;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) base += (static_cast<uint32_t>(j) < wave) ? s_tmp[j] : 0u;
+        s_base[d] = base + before;
+    }
+    __syncthreads();
+    // (3) each quarter walks its rows again (L2-warm) and writes the exclusive offsets
+    uint32_t run = s_base[d];
+    for (uint32_t k = 0; k < grp; ++k) run += s_quarter[k][d];
     uint32_t *o = offsets + static_cast<size_t>(row0) * kBins + d;
-    uint32_t j = 0;
-    for (; j + 8 <= rows; j += 8) {
+    uint32_t r = q0;
+    for (; r + 8 <= q1; r += 8) {
         uint32_t t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p[static_cast<size_t>(j + u) * kBins];
+        for (int u = 0; u < 8; ++u) t[u] = p[static_cast<size_t>(r + u) * kBins];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            o[static_cast<size_t>(j + u) * kBins] = run;
+            o[static_cast<size_t>(r + u) * kBins] = run;
             run += t[u];
         }
     }
-    for (; j < rows; ++j) {
-        o[static_cast<size_t>(j) * kBins] = run;
-        run += p[static_cast<size_t>(j) * kBins];
+    for (; r < q1; ++r) {
+        o[static_cast<size_t>(r) * kBins] = run;
+        run += p[static_cast<size_t>(r) * kBins];
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3 building block: stable scatter of one chunk of <= ITEMS*256 keys.
+// K3 building block: stable scatter of one chunk of <= ITEMS*WAVES*64 keys by a workgroup of WAVES
+// wave64.
 //
 // Layout in the chunk ("wave-striped"): wave v owns the contiguous segment
 // [v*ITEMS*64, (v+1)*ITEMS*64); its item i, lane l is key index v*ITEMS*64 + i*64 + l, so every
 // load instruction of a wave covers 256 contiguous bytes and (wave, item, lane) order == input
 // order, which is what stability needs.
 //
-// Ranking (per wave, per item): eight __ballot votes -- one per digit bit -- give each lane the
-// 64-bit mask of lanes holding the same digit ("match-any").  rank-in-wave = per-wave LDS counter
-// of that digit + number of matching lanes below me (mbcnt); the highest matching lane bumps the
-// counter by __popcll(mask).  LDS operations of one wave execute in order, so item i+1 sees item
-// i's update without a barrier.
-template <int ITEMS>
+// Ranking (per wave, per item), RANK_BALLOT: eight __ballot votes -- one per digit bit -- give each
+// lane the 64-bit mask of lanes holding the same digit ("match-any").  rank-in-wave = per-wave LDS
+// counter of that digit + number of matching lanes below me (mbcnt); the highest matching lane bumps
+// the counter by __popcll(mask).  LDS operations of one wave execute in order, so item i+1 sees
+// item i's update without a barrier.
+// RANK_ATOMIC: one returning LDS atomic add per key on the per-wave counter.  Correct only if the
+// LDS serialises same-address lanes of one instruction in ascending lane order (observed on gfx950,
+// not architecturally promised): selected only after vrs_debug_atomic_rank_selftest passes.
+constexpr int RANK_BALLOT = 0;
+constexpr int RANK_ATOMIC = 1;
+
+template <int ITEMS, int WAVES>
 struct ChunkSmem {
-    uint32_t keys[ITEMS * kThreads];  // re-bucketed keys (then payloads), chunk order by digit
-    uint32_t whist[kWaves][kBins];    // per-wave digit counters -> per-wave digit start positions
-    uint32_t gbase[kBins];            // global offset of digit d minus its start inside the chunk
-    uint32_t scan_tmp[kWaves];
+    uint32_t keys[ITEMS * WAVES * 64];  // re-bucketed keys (then payloads), chunk order by digit
+    uint32_t whist[WAVES][kBins];       // per-wave digit counters -> per-wave digit start positions
+    uint32_t gbase[kBins];              // global offset of digit d minus its start inside the chunk
+    uint32_t scan_tmp[WAVES];
 };
 
+// 64-bit mask of the lanes whose 8-bit digit equals mine ("match-any"), 4 VALU per digit bit:
+//   m  = -bit            v_bfe_i32   (all ones in lanes whose bit is set)
+//   B  = ballot(bit)     v_cmp_ne_u32 -> SGPR pair
+//   peers &= ~(B ^ m)    v_bitop3_b32 (gfx950 three-input boolean, truth table 0x84 = b & ~(a ^ c)),
+//                        once per 32-lane half: lanes that differ from me in this bit drop out.
 __device__ __forceinline__ uint64_t match_any_digit(uint32_t d) {
-    uint64_t peers = ~0ull;
+    uint32_t lo = ~0u, hi = ~0u;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t m = __ballot(bit);
-        peers &= bit ? m : ~m;
+        const uint32_t m = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(d), b, 1));
+        const uint64_t B = __builtin_amdgcn_uicmp(m, 0u, 33 /* ICMP_NE */);
+        lo = __builtin_amdgcn_bitop3_b32(m, lo, static_cast<uint32_t>(B), 0x84);
+        hi = __builtin_amdgcn_bitop3_b32(m, hi, static_cast<uint32_t>(B >> 32), 0x84);
     }
-    return peers;
+    return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
-// `run_off`: thread t's running global offset of digit t (advanced by this chunk's count of t).
-// `valid`: number of real keys in the chunk (the rest is padding that sorts behind everything).
-template <int ITEMS, bool PAIRS>
-__device__ __forceinline__ void scatter_chunk(ChunkSmem<ITEMS> &sm, const uint32_t *kin, const uint32_t *vin,
-                                              uint32_t *kout, uint32_t *vout, uint32_t valid, uint32_t shift,
-                                              uint32_t &run_off) {
+template <int WAVES>
+__device__ __forceinline__ uint32_t block_exclusive_scan_w(uint32_t v, uint32_t *s_tmp, uint32_t lane,
+                                                           uint32_t wave) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= static_cast<uint32_t>(o)) incl += t;
+    }
+    if (lane == 63u) s_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int j = 0; j < WAVES; ++j) base += (static_cast<uint32_t>(j) < wave) ? s_tmp[j] : 0u;
+    return base + incl - v;
+}
+
+// `run_off`: thread t (< 256) holds the running global offset of digit t, advanced by this chunk's
+// count of t.  `valid`: number of real keys in the chunk (the rest is padding that sorts last).
+// FULL: valid == ITEMS*WAVES*64 is known, so no load or store is predicated.
+//
+// Every phase is written as "issue all ITEMS independent LDS/global operations, then consume":
+// a workgroup is latency-bound (one pass over its keys, few waves), so dependent
+// read -> wait -> write chains per item are what must not appear in the ISA.
+template <int ITEMS, int WAVES, bool PAIRS, int RANK, bool FULL>
+__device__ __forceinline__ void scatter_chunk(ChunkSmem<ITEMS, WAVES> &sm, const uint32_t *kin,
+                                              const uint32_t *vin, uint32_t *kout, uint32_t *vout,
+                                              uint32_t valid, uint32_t shift, uint32_t &run_off) {
+    constexpr uint32_t THREADS = WAVES * 64;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
 
-#pragma unroll
-    for (int v = 0; v < kWaves; ++v) sm.whist[v][tid] = 0;
-
+    VRS_MARK(0);
     uint32_t key[ITEMS];
     const uint32_t seg = wave * (ITEMS * 64) + lane;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t idx = seg + i * 64;
-        // padding key 0xFFFFFFFF has digit 255 under every shift and the highest chunk indices,
-        // so it ranks behind every real key and is never stored
-        key[i] = idx < valid ? kin[idx] : 0xFFFFFFFFu;
-    }
-    __syncthreads();
-
-    uint32_t rank[ITEMS];
-    uint32_t *my_hist = sm.whist[wave];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t d = digit_of(key[i], shift);
-        const uint64_t peers = match_any_digit(d);
-        const uint32_t below = count_below(peers);
-        const uint32_t prev = my_hist[d];
-        rank[i] = prev + below;
-        if (below + 1u == static_cast<uint32_t>(__popcll(peers))) my_hist[d] = prev + below + 1u;
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-
-    // thread t == digit t: digit starts inside the chunk, per-wave starts, global base
-    {
-        uint32_t c[kWaves];
-        uint32_t total = 0;
-#pragma unroll
-        for (int v = 0; v < kWaves; ++v) {
-            c[v] = sm.whist[v][tid];
-            total += c[v];
+        if constexpr (FULL) {
+            key[i] = kin[idx];
+        } else {
+            // unpredicated load from a clamped index, then select: padding key 0xFFFFFFFF has digit 255
+            // under every shift and the highest chunk indices, so it ranks behind every real key
+            const uint32_t k = kin[idx < valid ? idx : valid - 1u];
+            key[i] = idx < valid ? k : 0xFFFFFFFFu;
         }
-        const uint32_t excl = block_exclusive_scan(total, sm.scan_tmp, lane, wave);
-        uint32_t acc = excl;
-#pragma unroll
-        for (int v = 0; v < kWaves; ++v) {
-            sm.whist[v][tid] = acc;
-            acc += c[v];
-        }
-        sm.gbase[tid] = run_off - excl;
-        run_off += total;
     }
-    __syncthreads();
-
-    uint32_t pos[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        pos[i] = my_hist[digit_of(key[i], shift)] + rank[i];
-        sm.keys[pos[i]] = key[i];
-    }
-    __syncthreads();
-
-    uint32_t dst[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t p = i * kThreads + tid;
-        const uint32_t k = sm.keys[p];
-        dst[i] = sm.gbase[digit_of(k, shift)] + p;
-        if (p < valid) kout[dst[i]] = k;
-    }
-
+    uint32_t val[PAIRS ? ITEMS : 1];
     if constexpr (PAIRS) {
-        uint32_t val[ITEMS];
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const uint32_t idx = seg + i * 64;
-            val[i] = idx < valid ? vin[idx] : 0u;
+            val[i] = vin[FULL ? idx : (idx < valid ? idx : valid - 1u)];
         }
-        __syncthreads();  // everyone has read its keys back
+    }
+    {
+        uint32_t *z = &sm.whist[0][0];
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) sm.keys[pos[i]] = val[i];
-        __syncthreads();
+        for (int v = 0; v < 4; ++v) z[v * THREADS + tid] = 0;  // WAVES*256 words / THREADS = 4 each
+    }
+    __syncthreads();
+    VRS_MARK(1);
+
+    // ---- rank inside the wave
+    uint32_t rank[ITEMS];
+    uint32_t *my_hist = sm.whist[wave];
+    if constexpr (RANK == RANK_ATOMIC) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            rank[i] = __hip_atomic_fetch_add(&my_hist[digit_of(key[i], shift)], 1u, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            const uint32_t p = i * kThreads + tid;
-            if (p < valid) vout[dst[i]] = sm.keys[p];
+            const uint32_t d = digit_of(key[i], shift);
+            const uint64_t peers = match_any_digit(d);
+            const uint32_t below = count_below(peers);
+            // all lanes read the counter, then the lowest matching lane adds the group's size with a
+            // NON-returning atomic: no value flows from the read into the add, so the LDS operations of
+            // all items pipeline; the LDS executes a wave's operations in order, so item i+1's read
+            // observes item i's add.
+            const uint32_t prev = my_hist[d];
+            if (below == 0u)
+                __hip_atomic_fetch_add(&my_hist[d], static_cast<uint32_t>(__popcll(peers)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_wave_barrier();
+            rank[i] = prev + below;
+        }
+    }
+    __syncthreads();
+    VRS_MARK(2);
+
+    // ---- thread t == digit t: digit starts inside the chunk, per-wave starts, global base
+    {
+        uint32_t c[WAVES];
+        uint32_t total = 0;
+        if (tid < kBins) {
+#pragma unroll
+            for (int v = 0; v < WAVES; ++v) {
+                c[v] = sm.whist[v][tid];
+                total += c[v];
+            }
+        }
+        const uint32_t excl = block_exclusive_scan_w<WAVES>(total, sm.scan_tmp, lane, wave);
+        if (tid < kBins) {
+            uint32_t acc = excl;
+#pragma unroll
+            for (int v = 0; v < WAVES; ++v) {
+                sm.whist[v][tid] = acc;
+                acc += c[v];
+            }
+            sm.gbase[tid] = run_off - excl;
+            run_off += total;
+        }
+    }
+    __syncthreads();
+    VRS_MARK(3);
+
+    // ---- re-bucket through LDS: all counter reads first, then all key writes
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) rank[i] += my_hist[digit_of(key[i], shift)];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) sm.keys[rank[i]] = key[i];
+    __syncthreads();
+    VRS_MARK(4);
+
+    // ---- write out: position p of the chunk goes to gbase[digit] + p; reads batched before stores
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) key[i] = sm.keys[i * THREADS + tid];
+    uint32_t dst[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) dst[i] = sm.gbase[digit_of(key[i], shift)] + (i * THREADS + tid);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        if (FULL || i * THREADS + tid < valid) kout[dst[i]] = key[i];
+    }
+    VRS_MARK(5);
+
+    if constexpr (PAIRS) {
+        __syncthreads();  // everyone has read its keys back
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) sm.keys[rank[i]] = val[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) val[i] = sm.keys[i * THREADS + tid];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            if (FULL || i * THREADS + tid < valid) vout[dst[i]] = val[i];
         }
         __syncthreads();  // sm.keys is reused by the next chunk's keys
     }
 }
 
-template <int ITEMS, bool PAIRS>
-__global__ __launch_bounds__(kThreads) void scatter_kernel(const uint32_t *__restrict__ keys_in,
-                                                           uint32_t *__restrict__ keys_out,
-                                                           const uint32_t *__restrict__ values_in,
-                                                           uint32_t *__restrict__ values_out,
-                                                           const uint32_t *__restrict__ offsets, uint32_t n,
-                                                           uint32_t shift, uint32_t W, uint32_t B, int xcd_remap) {
-    __shared__ ChunkSmem<ITEMS> sm;
+template <int ITEMS, int WAVES, bool PAIRS, int RANK, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const uint32_t *__restrict__ keys_in,
+                                                             uint32_t *__restrict__ keys_out,
+                                                             const uint32_t *__restrict__ values_in,
+                                                             uint32_t *__restrict__ values_out,
+                                                             const uint32_t *__restrict__ offsets, uint32_t n,
+                                                             uint32_t shift, uint32_t W, uint32_t B, int xcd_remap) {
+    __shared__ ChunkSmem<ITEMS, WAVES> sm;
     const uint32_t w = xcd_remap ? xcd_contiguous_tile(blockIdx.x, W) : blockIdx.x;
     const uint64_t tile_begin = static_cast<uint64_t>(w) * B * kThreads;
     if (tile_begin >= n) return;  // uniform per workgroup
     const uint64_t tile_keys = static_cast<uint64_t>(B) * kThreads;
     const uint32_t tile_len = static_cast<uint32_t>(tile_begin + tile_keys <= n ? tile_keys : n - tile_begin);
-    uint32_t run_off = offsets[static_cast<size_t>(w) * kBins + threadIdx.x];
-    constexpr uint32_t kChunk = ITEMS * kThreads;
+    uint32_t run_off = threadIdx.x < kBins ? offsets[static_cast<size_t>(w) * kBins + threadIdx.x] : 0u;
+    constexpr uint32_t kChunk = ITEMS * WAVES * 64;
     for (uint32_t c0 = 0; c0 < tile_len; c0 += kChunk) {
         const uint32_t valid = min(kChunk, tile_len - c0);
-        scatter_chunk<ITEMS, PAIRS>(sm, keys_in + tile_begin + c0, PAIRS ? values_in + tile_begin + c0 : nullptr,
-                                    keys_out, values_out, valid, shift, run_off);
+        const uint32_t *kin = keys_in + tile_begin + c0;
+        const uint32_t *vin = PAIRS ? values_in + tile_begin + c0 : nullptr;
+        if (valid == kChunk)  // workgroup-uniform
+            scatter_chunk<ITEMS, WAVES, PAIRS, RANK, true>(sm, kin, vin, keys_out, values_out, valid, shift, run_off);
+        else
+            scatter_chunk<ITEMS, WAVES, PAIRS, RANK, false>(sm, kin, vin, keys_out, values_out, valid, shift, run_off);
     }
+    VRS_MARK_FLUSH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self-test of the property RANK_ATOMIC relies on: for one ds_add_rtn_u32 wave-instruction, lanes
+// hitting the same address receive their pre-values in ascending lane order.  Each wave draws
+// pseudo-random digits of varying skew, ranks them both ways and counts disagreements.
+__global__ __launch_bounds__(kThreads) void atomic_rank_selftest_kernel(uint32_t rounds, uint32_t seed,
+                                                                        unsigned long long *mismatches) {
+    __shared__ uint32_t s_a[kWaves][kBins];
+    __shared__ uint32_t s_b[kWaves][kBins];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (int v = 0; v < kWaves; ++v) {
+        s_a[v][tid] = 0;
+        s_b[v][tid] = 0;
+    }
+    __syncthreads();
+    uint32_t x = seed ^ (blockIdx.x * 0x9E3779B9u) ^ (tid * 0x85EBCA6Bu);
+    unsigned long long bad = 0;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        x ^= x << 13;
+        x ^= x >> 17;
+        x ^= x << 5;
+        const uint32_t bits = (r + blockIdx.x) % 9u;  // 0..8 significant digit bits: heavy to no skew
+        uint32_t d = (x >> 7) & ((1u << bits) - 1u);
+        if ((r & 3u) == 3u) d = (d * 32u) & 255u;  // same-bank different-address collisions too
+        const uint32_t ra = __hip_atomic_fetch_add(&s_a[wave][d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint64_t peers = match_any_digit(d);
+        const uint32_t below = count_below(peers);
+        const uint32_t prev = s_b[wave][d];
+        const uint32_t rb = prev + below;
+        if (below + 1u == static_cast<uint32_t>(__popcll(peers))) s_b[wave][d] = prev + below + 1u;
+        __builtin_amdgcn_wave_barrier();
+        bad += (ra != rb) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -346,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const uint32_t *__res
 constexpr int kSingleItems = 4;
 
 __global__ __launch_bounds__(kThreads) void single_kernel(uint32_t *buffer0, uint32_t *buffer1, uint32_t n) {
-    __shared__ ChunkSmem<kSingleItems> sm;
+    __shared__ ChunkSmem<kSingleItems, kWaves> sm;
     __shared__ uint32_t s_hist[kBins];
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kChunk = kSingleItems * kThreads;
@@ -366,7 +549,12 @@ __global__ __launch_bounds__(kThreads) void single_kernel(uint32_t *buffer0, uin
         __syncthreads();
         for (uint32_t c0 = 0; c0 < n; c0 += kChunk) {
             const uint32_t valid = min(kChunk, n - c0);
-            scatter_chunk<kSingleItems, false>(sm, in + c0, nullptr, out, nullptr, valid, shift, run_off);
+            if (valid == kChunk)
+                scatter_chunk<kSingleItems, kWaves, false, RANK_BALLOT, true>(sm, in + c0, nullptr, out, nullptr, valid,
+                                                                              shift, run_off);
+            else
+                scatter_chunk<kSingleItems, kWaves, false, RANK_BALLOT, false>(sm, in + c0, nullptr, out, nullptr, valid,
+                                                                               shift, run_off);
         }
         // the next pass reads what this pass wrote: same CU, so a workgroup barrier (with its
         // workgroup-scope fence) orders the global stores before the loads
@@ -395,39 +583,58 @@ hipError_t launch_prefix(hipStream_t stream, const uint32_t *hist, const PrefixS
     if (W == 0) return hipSuccess;
     const uint32_t C = prefix_chunk_tiles(W);
     const uint32_t G = (W + C - 1) / C;
-    hipLaunchKernelGGL(chunk_sum_kernel, dim3(G), dim3(kThreads), 0, stream, hist, scratch.chunk_sums, W, C);
-    hipLaunchKernelGGL(offsets_kernel, dim3(G), dim3(kThreads), 0, stream, hist, scratch.chunk_sums,
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3(G), dim3(kPrefixThreads), 0, stream, hist, scratch.chunk_sums, W, C);
+    hipLaunchKernelGGL(offsets_kernel, dim3(G), dim3(kPrefixThreads), 0, stream, hist, scratch.chunk_sums,
                        scratch.offsets, W, C, G);
     return hipGetLastError();
 }
 
-template <int ITEMS>
-static void launch_scatter_items(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
-                                 const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets,
-                                 uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap) {
-    if (values_in != nullptr) {
-        hipLaunchKernelGGL((scatter_kernel<ITEMS, true>), dim3(W), dim3(kThreads), 0, stream, keys_in, keys_out,
-                           values_in, values_out, offsets, n, shift, W, B, xcd_remap ? 1 : 0);
-    } else {
-        hipLaunchKernelGGL((scatter_kernel<ITEMS, false>), dim3(W), dim3(kThreads), 0, stream, keys_in, keys_out,
-                           values_in, values_out, offsets, n, shift, W, B, xcd_remap ? 1 : 0);
-    }
+template <int ITEMS, int WAVES, int RANK, int OCC>
+static hipError_t launch_scatter_variant(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
+                                         const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets,
+                                         uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap) {
+    if (values_in != nullptr)
+        hipLaunchKernelGGL((scatter_kernel<ITEMS, WAVES, true, RANK, OCC>), dim3(W), dim3(WAVES * 64), 0, stream,
+                           keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap ? 1 : 0);
+    else
+        hipLaunchKernelGGL((scatter_kernel<ITEMS, WAVES, false, RANK, OCC>), dim3(W), dim3(WAVES * 64), 0, stream,
+                           keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap ? 1 : 0);
+    return hipGetLastError();
 }
+
+#define VRS_SCATTER_ARGS stream, keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap
 
 hipError_t launch_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
                           const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets, uint32_t n,
-                          uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap) {
+                          uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap, const ScatterLaunch &cfg) {
     if (W == 0) return hipSuccess;
-    // chunk = ITEMS*256 keys held in registers + LDS at once; a tile of B blocks is walked in
-    // ceil(B/ITEMS) chunks
-    if (B >= 32)
-        launch_scatter_items<32>(stream, keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap);
-    else if (B >= 16)
-        launch_scatter_items<16>(stream, keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap);
-    else if (B >= 8)
-        launch_scatter_items<8>(stream, keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap);
-    else
-        launch_scatter_items<4>(stream, keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap);
+    // chunk = ITEMS*WAVES*64 keys held in registers + LDS at once; a tile of B blocks is walked in
+    // ceil(B*256/chunk) chunks.  cfg.variant (tuning only) = OCC*100000 + ITEMS*1000 + WAVES*10 + RANK
+    // (OCC = waves per SIMD the register allocation is held to); 0 = default for this B and rank mode.
+    int variant = cfg.variant;
+    if (variant == 0) {
+        const int rank = cfg.atomic_rank ? RANK_ATOMIC : RANK_BALLOT;
+        if (B >= 32) variant = 416080 + rank;       // 8192-key chunks, 512 threads
+        else if (B >= 16) variant = 416040 + rank;  // 4096-key chunks
+        else if (B >= 8) variant = 408040;
+        else variant = 404040;
+    }
+    switch (variant) {
+        case 332040: return launch_scatter_variant<32, 4, RANK_BALLOT, 3>(VRS_SCATTER_ARGS);
+        case 332041: return launch_scatter_variant<32, 4, RANK_ATOMIC, 3>(VRS_SCATTER_ARGS);
+        case 416080: return launch_scatter_variant<16, 8, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
+        case 416081: return launch_scatter_variant<16, 8, RANK_ATOMIC, 4>(VRS_SCATTER_ARGS);
+        case 416040: return launch_scatter_variant<16, 4, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
+        case 416041: return launch_scatter_variant<16, 4, RANK_ATOMIC, 4>(VRS_SCATTER_ARGS);
+        case 408040: return launch_scatter_variant<8, 4, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
+        case 404040: return launch_scatter_variant<4, 4, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_atomic_rank_selftest(hipStream_t stream, uint32_t rounds, uint32_t seed,
+                                       unsigned long long *mismatches) {
+    hipLaunchKernelGGL(atomic_rank_selftest_kernel, dim3(1024), dim3(kThreads), 0, stream, rounds, seed, mismatches);
     return hipGetLastError();
 }
 

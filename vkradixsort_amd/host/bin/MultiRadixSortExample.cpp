@@ -1,0 +1,30 @@
+// multiradixsortexample [NUM_ELEMENTS] [NUM_BLOCKS_PER_WORKGROUP] [seed] [timed repetitions] [28bit]
+// Counterpart of the reference's multiradixsort/src/bin/MultiRadixSortExample.cpp: context -> execute ->
+// shutdown, std::exception -> EXIT_FAILURE.  Without arguments it sorts the reference's 1 000 000 keys.
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <memory>
+
+#include "MultiRadixSort.h"
+#include "engine/core/GPUContext.h"
+
+int main(int argc, char **argv) {
+    const uint32_t numElements = argc > 1 ? static_cast<uint32_t>(std::strtod(argv[1], nullptr)) : 1000000u;
+    const uint32_t blocks = argc > 2 ? static_cast<uint32_t>(std::atoi(argv[2])) : 32u;
+    const uint32_t seed = argc > 3 ? static_cast<uint32_t>(std::atoi(argv[3])) : 1u;
+    const uint32_t reps = argc > 4 ? static_cast<uint32_t>(std::atoi(argv[4])) : 1u;
+    const bool keys28 = argc > 5 && std::strcmp(argv[5], "28bit") == 0;
+
+    engine::GPUContext gpu(engine::Queues::QueueFamilies::COMPUTE_FAMILY | engine::Queues::TRANSFER_FAMILY);
+    try {
+        gpu.init();
+        auto app = std::make_shared<engine::MultiRadixSort>(numElements, blocks, seed, keys28, reps);
+        app->execute(&gpu);
+        gpu.shutdown();
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return EXIT_FAILURE;
+    }
+    return EXIT_SUCCESS;
+}

@@ -1,0 +1,58 @@
+// engine::MultiRadixSort -- program logic of the multi_radixsort example
+// (reference: multiradixsort/include/MultiRadixSort.h:9-54, src/MultiRadixSort.cpp:5-161).
+// NUM_ELEMENTS stays THE entry-point parameter but is a constructor argument (default 1 000 000, the
+// reference's compile-time value, MultiRadixSort.h:29); NUM_BLOCKS_PER_WORKGROUP likewise (default 32,
+// MultiRadixSort.cpp:12).  Keys are generated from std::mt19937(seed)() -- reproducible, full 32 bit.
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "MultiRadixSortPass.h"
+
+namespace engine {
+
+class MultiRadixSort {
+public:
+    using SORT_TYPE = uint32_t;  // SORT_32BIT
+
+    explicit MultiRadixSort(uint32_t numElements = 1000000, uint32_t numBlocksPerWorkgroup = 32, uint32_t seed = 1,
+                            bool reference28BitKeys = false, uint32_t timedRepetitions = 1);
+
+    void execute(GPUContext *gpuContext);
+
+    // results of the last execute() for programmatic callers / the sweep harness
+    [[nodiscard]] double gpuSortTimeMs() const { return m_gpuSortTime; }
+    [[nodiscard]] double cpuSortTimeMs() const { return m_cpuSortTime; }
+
+    // host helpers, public so tests can exercise them without a device
+    static void generateRandomNumbers(std::vector<SORT_TYPE> &buffer, uint32_t numElements, uint32_t seed,
+                                      bool reference28BitKeys);
+    static double sort(std::vector<SORT_TYPE> &buffer);
+    static bool testSort(std::vector<SORT_TYPE> &reference, std::vector<SORT_TYPE> &outBuffer);
+
+private:
+    GPUContext *m_gpuContext = nullptr;
+    std::shared_ptr<MultiRadixSortPass> m_pass;
+
+    const uint32_t RADIX_SORT_BINS = 256;
+    const uint32_t NUM_ELEMENTS;
+    const uint32_t NUM_BLOCKS_PER_WORKGROUP;
+    const size_t NUM_ELEMENTS_BYTES;
+    const uint32_t m_seed;
+    const bool m_reference28BitKeys;
+    const uint32_t m_timedRepetitions;
+
+    std::vector<std::shared_ptr<Buffer>> m_buffers = std::vector<std::shared_ptr<Buffer>>(3);
+    std::vector<SORT_TYPE> m_elementsIn;
+    double m_gpuSortTime = 0.0, m_cpuSortTime = 0.0;
+
+    static inline const char *PRINT_PREFIX = "[MultiRadixSort] ";
+
+    void prepareBuffers();
+    void verify(std::vector<SORT_TYPE> &reference);
+    void releaseBuffers();
+};
+
+}  // namespace engine
