@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""bench.py -- Gkeys/s sorting uint32 keys with the MI355X-native multi_radixsort path.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A step = one complete sort (4 passes x [histograms, prefix, scatter]) of one batch of synthetic keys that is
+already resident in HBM when the timed region starts.  N = 1 sorts BASELINE.json configs[2]: 10^8 uniform
+random uint32 (std::mt19937 raw outputs, seeds 1/2/3 cycled over the K pre-staged batches).  N > 1 sorts
+N x 10^8 keys sharded by key range (configs[4] at N = 8): top-byte partition pass, RCCL all-to-all, local sort.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+BYTES_PER_KEY_SORT = 48  # 4 passes x (histogram read 4 + scatter read 4 + scatter write 4)   SURVEY.md section 8d
+BYTES_PER_KEY_SCATTER = 8  # the dominant kernel, per launch: read 4 + write 4
+
+
+def mt19937_keys(seed: int, n: int) -> np.ndarray:
+    # numpy's RandomState is MT19937 with the same seeding as std::mt19937(seed); 32-bit draws are the raw outputs
+    return np.random.RandomState(seed).randint(0, 2 ** 32, size=n, dtype=np.uint32)
+
+
+def load_traffic_profile():
+    """HBM bytes per scatter launch from the committed rocprofv3 --pmc passes (profiles/), if present."""
+    p = ROOT / "profiles" / "scatter_traffic.json"
+    if not p.exists():
+        return None
+    try:
+        return json.loads(p.read_text()).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(keys: np.ndarray):
+    """The reference's verification path (single-threaded std::sort, MultiRadixSort.cpp:141-146) timed on this
+    host through the oracle library.  Only this leg of bench.py touches oracle/."""
+    from tests import _oracle
+    orc = _oracle.load()
+    ref, ms = orc.std_sort(keys)
+    cores, model = orc.cpu_info()
+    return ref, {"value": round(keys.size / (ms * 1e-3) / 1e9, 5), "unit": "Gkeys/s", "cores": 1, "kind": "port",
+                 "sample": f"std::sort of the full {keys.size}-key seed-1 batch, 1 repetition, {ms:.0f} ms",
+                 "host": f"1 thread of {cores} hardware threads ({model})"}
+
+
+def bench_single(args):
+    import vkradixsort_amd as vrs
+    from vkradixsort_amd import capi
+
+    n, B, K, W = args.n, args.blocks, args.steps, args.warmup
+    S = vrs.Buffer.BufferSettings
+    seeds = [1, 2, 3]
+    host_keys = [mt19937_keys(s, n) for s in seeds[:max(1, min(3, K))]]
+    gpu = vrs.GPUContext(int(os.environ.get("LOCAL_RANK", "0")))
+    gpu.init()
+    if args.rank_mode:
+        gpu.setTuning(capi.VRS_TUNE_RANK_MODE, args.rank_mode)
+    if args.variant:
+        gpu.setTuning(capi.VRS_TUNE_SCATTER_VARIANT, args.variant)
+    dev_name, cus, mem = gpu.deviceInfo()
+    nbuf = max(K, W, 1)
+    need = (nbuf + len(host_keys) + 1) * 4 * n
+    if need > 0.8 * mem:
+        raise SystemExit(f"{nbuf} pre-staged batches need {need / 2 ** 30:.0f} GiB; lower --steps")
+    pristine = [vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), k) for k in host_keys]
+    batches = [vrs.Buffer(gpu, S(4 * n)) for _ in range(nbuf)]
+    buf1 = vrs.Buffer(gpu, S(4 * n))
+    Wg = gpu.lib.vrs_workgroup_count(n, B)
+    hist = vrs.Buffer(gpu, S(Wg * 256 * 4))
+    p = vrs.MultiRadixSortPass(gpu)
+    p.create()
+    gis = n // B + (1 if n % B else 0)
+    p.setGlobalInvocationSize(p.RADIX_SORT_HISTOGRAMS, gis, 1, 1)
+    p.setGlobalInvocationSize(p.RADIX_SORT, gis, 1, 1)
+    for pc in (p.m_pushConstantsHistogram, p.m_pushConstants):
+        pc.g_num_elements, pc.g_num_workgroups, pc.g_num_blocks_per_workgroup = n, Wg, B
+    p.setStorageBuffer(p.RADIX_SORT_HISTOGRAMS, 1, hist)
+    p.setStorageBuffer(p.RADIX_SORT, 2, hist)
+
+    def rearm():
+        for i, b in enumerate(batches):
+            b.copyFrom(pristine[i % len(pristine)])
+        gpu.waitIdle()
+
+    def sort_batch(b0):
+        # MultiRadixSort::execute's hot loop (MultiRadixSort.cpp:37-61): ping-pong binding + four passes
+        a = gpu.getActiveIndex()
+        o = (a + 1) % 2
+        H, R = p.RADIX_SORT_HISTOGRAMS, p.RADIX_SORT
+        p.setStorageBuffer(a, H, 0, b0)
+        p.setStorageBuffer(a, R, 0, b0)
+        p.setStorageBuffer(o, R, 1, b0)
+        p.setStorageBuffer(o, H, 0, buf1)
+        p.setStorageBuffer(a, R, 1, buf1)
+        p.setStorageBuffer(o, R, 0, buf1)
+        tok = None
+        for i in range(4):
+            p.m_pushConstantsHistogram.g_shift = 8 * i
+            p.m_pushConstants.g_shift = 8 * i
+            tok = p.execute(tok)
+            gpu.incrementActiveIndex()
+
+    rearm()
+    for i in range(W):
+        sort_batch(batches[i])
+    gpu.waitIdle()
+    rearm()
+
+    # ---- timed region: exactly K steps, inputs resident, per-kernel HIP events on the sort's own stream
+    gpu.profileReset()
+    gpu.profileEnable(True)
+    gpu.waitIdle()
+    t0 = time.perf_counter()
+    for i in range(K):
+        sort_batch(batches[i])
+    gpu.waitIdle()
+    t1 = time.perf_counter()
+    gpu.profileEnable(False)
+    elapsed = t1 - t0
+    kernels = {}
+    for kid, name in capi.KERNEL_NAMES.items():
+        cnt, ms = gpu.profileQuery(kid)
+        if cnt:
+            kernels[name] = {"launches": cnt, "avg_us": round(ms / cnt * 1e3, 2)}
+
+    # ---- outside the timed region: the same K steps once more without event brackets (overhead check)
+    rearm()
+    t2 = time.perf_counter()
+    for i in range(K):
+        sort_batch(batches[i])
+    gpu.waitIdle()
+    unprofiled = time.perf_counter() - t2
+
+    # ---- verification of what the timed steps produced (result is in each batch buffer = "buffer0")
+    out0 = np.empty(n, dtype=np.uint32)
+    batches[0].downloadWithStagingBuffer(out0)
+    check = {"sorted": bool(np.all(out0[1:] >= out0[:-1])),
+             "checksum_ok": int(out0.astype(np.uint64).sum()) == int(host_keys[0].astype(np.uint64).sum())}
+    base = None
+    if not args.no_cpu_baseline:
+        ref, base = cpu_baseline(host_keys[0])
+        check["bit_exact_vs_std_sort"] = bool(np.array_equal(ref, out0))
+    if not all(check.values()):
+        raise SystemExit(f"VERIFICATION FAILED: {check}")
+
+    scatter_us = kernels.get("scatter", {}).get("avg_us")
+    achieved = (BYTES_PER_KEY_SCATTER * n / (scatter_us * 1e-6) / 1e9) if scatter_us else None
+    value = n * K / elapsed / 1e9
+    result = {
+        "metric": "Gkeys/s sorting 10^8 uint32 at 1/2/4/8 MI355X; % of HBM roofline",
+        "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[2]: {n} uniform random uint32 keys (std::mt19937 seeds 1,2,3), "
+                               f"multi_radixsort, 1xMI355X, keys resident in HBM",
+                   "num_elements": n, "num_blocks_per_workgroup": B, "num_workgroups": Wg, "passes": 4,
+                   "rank_mode": {1: "ballot", 2: "lds_atomic"}[gpu.lib.vrs_rank_mode(gpu.handle)], "device": dev_name,
+                   "compute_units": cus},
+        "roofline": {"bound": "hbm", "kernel": "scatter (stage RADIX_SORT, one launch per pass)",
+                     "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                     "algorithmic_bytes_per_launch": BYTES_PER_KEY_SCATTER * n, "avg_launch_us": scatter_us,
+                     "traffic": load_traffic_profile()},
+        "sort_roofline": {"algorithmic_bytes": BYTES_PER_KEY_SORT * n,
+                          "achieved_GBps": round(BYTES_PER_KEY_SORT * n * K / elapsed / 1e9, 1),
+                          "frac_of_peak": round(BYTES_PER_KEY_SORT * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
+        "kernels": kernels,
+        "ms_per_step_without_event_brackets": round(unprofiled / K * 1e3, 4),
+        "verified": check,
+    }
+    if base:
+        result["cpu_baseline"] = base
+    for b in batches + pristine + [buf1, hist]:
+        b.release()
+    p.release()
+    gpu.shutdown()
+    return result
+
+
+def bench_multi(args):
+    import torch
+    import torch.distributed as dist
+
+    from vkradixsort_amd.distributed import HipLocalSortBackend, RangeShardedSort
+
+    rank = int(os.environ["RANK"])
+    world = int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n, B, K, W = args.n, args.blocks, args.steps, args.warmup
+    shard = mt19937_keys(1000 + rank, n)  # shard g uses seed 1000+g
+    pristine = torch.from_numpy(shard.view(np.int32)).to(dev)
+    nbuf = max(K, W, 1)
+    batches = [torch.empty_like(pristine) for _ in range(nbuf)]
+    cap = int(n * 1.25) + 4096
+    backend = HipLocalSortBackend(local, capacity=cap, blocks_per_workgroup=B)
+    sorter = RangeShardedSort(backend, recv_capacity=cap, make_empty=lambda m: torch.empty(m, dtype=torch.int32, device=dev))
+
+    def rearm():
+        for b in batches:
+            b.copy_(pristine)
+        torch.cuda.synchronize()
+
+    rearm()
+    res = None
+    for i in range(W):
+        res = sorter.step(batches[i], n)
+    torch.cuda.synchronize()
+    rearm()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        res = sorter.step(batches[i], n)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # verification outside the timed region: every range ascending, ranges ordered across ranks, nothing lost
+    out = res.keys[:res.count]
+    flipped = out ^ torch.tensor(-2 ** 31, dtype=torch.int32, device=dev)  # unsigned order on int32 storage
+    ok_sorted = bool((flipped[1:] >= flipped[:-1]).all().item()) if res.count > 1 else True
+    lo = int(flipped[0].item()) if res.count else 2 ** 31 - 1
+    hi = int(flipped[-1].item()) if res.count else -2 ** 31
+    edges = torch.tensor([lo, hi, res.count, int(out.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())],
+                         dtype=torch.int64, device=dev)
+    gathered = [torch.empty_like(edges) for _ in range(world)]
+    dist.all_gather(gathered, edges)
+    src_sum = torch.tensor([int(shard.astype(np.uint64).sum())], dtype=torch.int64, device=dev)
+    dist.all_reduce(src_sum)
+    oks = torch.tensor([1 if ok_sorted else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(oks, op=dist.ReduceOp.MIN)
+    g = [x.cpu().tolist() for x in gathered]
+    nonempty = [x for x in g if x[2] > 0]
+    ordered = all(nonempty[i][1] <= nonempty[i + 1][0] for i in range(len(nonempty) - 1))
+    total = sum(x[2] for x in g)
+    check = {"ranges_sorted": bool(oks.item()), "ranges_ordered_across_ranks": ordered, "count_ok": total == n * world,
+             "checksum_ok": sum(x[3] for x in g) == int(src_sum.item())}
+    result = None
+    if rank == 0:
+        if not all(check.values()):
+            raise SystemExit(f"VERIFICATION FAILED: {check}")
+        value = n * world * K / elapsed / 1e9
+        result = {
+            "metric": "Gkeys/s sorting 10^8 uint32 at 1/2/4/8 MI355X; % of HBM roofline",
+            "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{world} x {n} uniform random uint32 keys (std::mt19937 seed 1000+rank), sharded by key "
+                                   f"range: top-byte partition pass, RCCL all-to-all over xGMI, local 4-pass multi_radixsort",
+                       "num_elements_per_gpu": n, "num_blocks_per_workgroup": B, "parallelism": f"range-sharded x{world}",
+                       "hbm_bytes_per_key": 60},
+            "roofline": {"bound": "hbm", "achieved": round(60 * n * K / elapsed / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(60 * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "note": "per GPU, whole step incl. the xGMI exchange: 12 B/key partition pass + 48 B/key local sort"},
+            "shard_sizes": [x[2] for x in g],
+            "verified": check,
+        }
+    backend.close()
+    dist.destroy_process_group()
+    return result
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=lambda s: int(float(s)), default=10 ** 8, help="keys per GPU")
+    ap.add_argument("--blocks", type=int, default=32, help="NUM_BLOCKS_PER_WORKGROUP")
+    ap.add_argument("--rank-mode", type=int, default=0, help="0 auto, 1 ballot, 2 LDS atomic")
+    ap.add_argument("--variant", type=int, default=0, help="scatter variant code (tuning)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # convenience: re-launch under torch.distributed.run the way the driver does
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"), __file__] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
+    from vkradixsort_amd import capi
+    capi.load_library()  # fails loudly if the HIP extension was not built; there is no fallback path
+
+    if args.gpus > 1 or os.environ.get("VRS_BENCH_FORCE_MULTI") == "1":  # the latter: exchange path at world size 1
+        result = bench_multi(args)
+    else:
+        result = bench_single(args)
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -119,6 +119,13 @@ int vrs_multi_radixsort(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out
 int vrs_multi_radixsort_pairs(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out,
                               vrs_buffer values_in, vrs_buffer values_out, vrs_buffer histograms,
                               const vrs_push_constants *pc);
+/*
+ * Global exclusive digit prefix (uint32[256]) computed by the most recent RADIX_SORT stage on this
+ * context -- the `global_histogram` of multi_radixsort.comp:74-75: position of the first key of each
+ * digit in that stage's output.  Synchronous.  Used by the multi-GPU key-range exchange (build
+ * extension) to cut the locally grouped shard into per-rank slices.
+ */
+int vrs_multi_radixsort_digit_offsets(vrs_context ctx, void *host_u32x256);
 /* vkQueueWaitIdle on the compute queue (MultiRadixSort.cpp:62). */
 int vrs_queue_wait_idle(vrs_context ctx);
 

@@ -343,3 +343,35 @@ def test_cpp_host_examples_run_and_verify():
         assert "[MultiRadixSort] Test passed." in p.stdout
     p = subprocess.run([str(single), "1000"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "[SingleRadixSort] Test passed." in p.stdout, p.stdout + p.stderr
+
+
+def test_range_sharded_sort_product_backend_world1_rccl(oracle):
+    """The multi-GPU path end to end with the PRODUCT backend (C ABI on torch's stream) and RCCL, at world
+    size 1 (one GPU per box here; world size 2 is covered on CPU with gloo in test_distributed_cpu.py)."""
+    import os
+    import socket
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    from vkradixsort_amd.distributed import HipLocalSortBackend, RangeShardedSort
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n = 3000017
+        keys = rand_keys(n, 4242)
+        cap = int(n * 1.25) + 4096
+        backend = HipLocalSortBackend(0, capacity=cap, blocks_per_workgroup=32)
+        sorter = RangeShardedSort(backend, recv_capacity=cap, make_empty=lambda m: torch.empty(m, dtype=torch.int32, device=dev))
+        t = torch.from_numpy(keys.view(np.int32)).to(dev)
+        res = sorter.step(t, n)
+        torch.cuda.synchronize()
+        out = res.keys[:res.count].cpu().numpy().view(np.uint32)
+        assert res.count == n and res.bounds.tolist() == [0, 256]
+        assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+        backend.close()
+    finally:
+        dist.destroy_process_group()

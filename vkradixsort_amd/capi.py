@@ -68,6 +68,7 @@ _SIGNATURES = [
     ("vrs_multi_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
     ("vrs_multi_radixsort_pairs", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
+    ("vrs_multi_radixsort_digit_offsets", c_int, [c_void_p, c_void_p]),
     ("vrs_queue_wait_idle", c_int, [c_void_p]),
     ("vrs_single_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_profile_enable", c_int, [c_void_p, c_int]),

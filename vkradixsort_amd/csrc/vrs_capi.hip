@@ -86,30 +86,23 @@ int ensure_scratch(vrs_context ctx, uint32_t W) {
     return VRS_OK;
 }
 
-// RAII-less event bracket: begin() before the launch, end() after.
-struct ProfileScope {
-    vrs_context ctx;
-    int id;
-    vrs_context_t::EventPair *pair = nullptr;
-    int begin() {
-        if (!ctx->profile) return VRS_OK;
-        auto &pool = ctx->events[id];
-        if (ctx->events_used[id] == pool.size()) {
-            vrs_context_t::EventPair p{};
-            VRS_HIP(ctx, hipEventCreate(&p.start));
-            VRS_HIP(ctx, hipEventCreate(&p.stop));
-            pool.push_back(p);
-        }
-        pair = &pool[ctx->events_used[id]++];
-        VRS_HIP(ctx, hipEventRecord(pair->start, ctx->stream));
-        return VRS_OK;
+// Hands out a (start, stop) event pair for one launch when profiling is on; the events ride on the
+// kernel's own dispatch packet (hipExtLaunchKernel), so profiling does not insert barrier packets.
+int profile_events(vrs_context ctx, int id, vrs::LaunchEvents *ev) {
+    *ev = vrs::LaunchEvents{};
+    if (!ctx->profile) return VRS_OK;
+    auto &pool = ctx->events[id];
+    if (ctx->events_used[id] == pool.size()) {
+        vrs_context_t::EventPair p{};
+        VRS_HIP(ctx, hipEventCreate(&p.start));
+        VRS_HIP(ctx, hipEventCreate(&p.stop));
+        pool.push_back(p);
     }
-    int end() {
-        if (!pair) return VRS_OK;
-        VRS_HIP(ctx, hipEventRecord(pair->stop, ctx->stream));
-        return VRS_OK;
-    }
-};
+    const auto &pair = pool[ctx->events_used[id]++];
+    ev->start = pair.start;
+    ev->stop = pair.stop;
+    return VRS_OK;
+}
 
 int check_push_constants(vrs_context ctx, const vrs_push_constants *pc) {
     if (!pc) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "push constants are NULL");
@@ -223,21 +216,18 @@ int run_sort_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs
     VRS_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = ensure_scratch(ctx, W))) return rc;
 
-    ProfileScope ps{ctx, VRS_KERNEL_PREFIX};
-    if ((rc = ps.begin())) return rc;
-    VRS_HIP(ctx, vrs::launch_prefix(ctx->stream, static_cast<const uint32_t *>(histograms->ptr), ctx->scratch, W));
-    if ((rc = ps.end())) return rc;
+    vrs::LaunchEvents ev;
+    if ((rc = profile_events(ctx, VRS_KERNEL_PREFIX, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_prefix(ctx->stream, static_cast<const uint32_t *>(histograms->ptr), ctx->scratch, W, ev));
     ctx->last_offsets_workgroups = W;
 
-    ProfileScope ss{ctx, VRS_KERNEL_SCATTER};
-    if ((rc = ss.begin())) return rc;
+    if ((rc = profile_events(ctx, VRS_KERNEL_SCATTER, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_scatter(ctx->stream, static_cast<const uint32_t *>(keys_in->ptr),
                                      static_cast<uint32_t *>(keys_out->ptr),
                                      pairs ? static_cast<const uint32_t *>(values_in->ptr) : nullptr,
                                      pairs ? static_cast<uint32_t *>(values_out->ptr) : nullptr, ctx->scratch.offsets,
                                      n, pc->g_shift, W, pc->g_num_blocks_per_workgroup, ctx->xcd_remap,
-                                     ctx->scatter));
-    if ((rc = ss.end())) return rc;
+                                     ctx->scatter, ev));
     return VRS_OK;
 }
 
@@ -406,12 +396,11 @@ int vrs_multi_radixsort_histograms(vrs_context ctx, vrs_buffer keys_in, vrs_buff
                            "histograms")))
         return rc;
     VRS_HIP(ctx, hipSetDevice(ctx->device));
-    ProfileScope ps{ctx, VRS_KERNEL_HISTOGRAM};
-    if ((rc = ps.begin())) return rc;
+    vrs::LaunchEvents ev;
+    if ((rc = profile_events(ctx, VRS_KERNEL_HISTOGRAM, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_histograms(ctx->stream, static_cast<const uint32_t *>(keys_in->ptr),
                                         static_cast<uint32_t *>(histograms->ptr), pc->g_num_elements, pc->g_shift,
-                                        pc->g_num_workgroups, pc->g_num_blocks_per_workgroup));
-    if ((rc = ps.end())) return rc;
+                                        pc->g_num_workgroups, pc->g_num_blocks_per_workgroup, ev));
     return VRS_OK;
 }
 
@@ -441,11 +430,10 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
     if ((rc = check_buffer(ctx, buffer1, bytes, "buffer1"))) return rc;
     if (buffer0->ptr == buffer1->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "buffer0 and buffer1 alias");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
-    ProfileScope ps{ctx, VRS_KERNEL_SINGLE};
-    if ((rc = ps.begin())) return rc;
+    vrs::LaunchEvents ev;
+    if ((rc = profile_events(ctx, VRS_KERNEL_SINGLE, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_single(ctx->stream, static_cast<uint32_t *>(buffer0->ptr),
-                                    static_cast<uint32_t *>(buffer1->ptr), g_num_elements));
-    if ((rc = ps.end())) return rc;
+                                    static_cast<uint32_t *>(buffer1->ptr), g_num_elements, ev));
     return VRS_OK;
 }
 
@@ -478,6 +466,18 @@ int vrs_profile_query(vrs_context ctx, int kernel_id, uint64_t *launches, double
     }
     if (launches) *launches = used;
     if (total_ms) *total_ms = sum;
+    return VRS_OK;
+}
+
+int vrs_multi_radixsort_digit_offsets(vrs_context ctx, void *host_u32x256) {
+    if (!ctx || !host_u32x256) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or output is NULL");
+    if (ctx->last_offsets_workgroups == 0)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "no RADIX_SORT stage has run on this context yet");
+    // workgroup 0 has no predecessors, so its offset row IS the global exclusive digit prefix
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    VRS_HIP(ctx, hipMemcpyAsync(host_u32x256, ctx->scratch.offsets, VRS_RADIX_SORT_BINS * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VRS_OK;
 }
 

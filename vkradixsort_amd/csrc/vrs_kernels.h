@@ -12,6 +12,12 @@ struct PrefixScratch {
     uint32_t *chunk_sums = nullptr;
 };
 
+// Optional timing events attached to a launch's own dispatch packet (no extra barrier packets).
+struct LaunchEvents {
+    hipEvent_t start = nullptr;
+    hipEvent_t stop = nullptr;
+};
+
 // How the scatter is launched (performance only).
 struct ScatterLaunch {
     int variant = 0;          // 0 = choose from B; else OCC*100000 + ITEMS*1000 + WAVES*10 + RANK
@@ -24,19 +30,20 @@ struct ScatterLaunch {
 uint32_t prefix_chunk_tiles(uint32_t num_workgroups);
 
 hipError_t launch_histograms(hipStream_t stream, const uint32_t *keys_in, uint32_t *hist,
-                             uint32_t n, uint32_t shift, uint32_t W, uint32_t B);
+                             uint32_t n, uint32_t shift, uint32_t W, uint32_t B, LaunchEvents ev = {});
 
 hipError_t launch_prefix(hipStream_t stream, const uint32_t *hist, const PrefixScratch &scratch,
-                         uint32_t W);
+                         uint32_t W, LaunchEvents ev = {});
 
 hipError_t launch_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
                           const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets,
                           uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap,
-                          const ScatterLaunch &cfg);
+                          const ScatterLaunch &cfg, LaunchEvents ev = {});
 
 hipError_t launch_atomic_rank_selftest(hipStream_t stream, uint32_t rounds, uint32_t seed,
                                        unsigned long long *mismatches);
 
-hipError_t launch_single(hipStream_t stream, uint32_t *buffer0, uint32_t *buffer1, uint32_t n);
+hipError_t launch_single(hipStream_t stream, uint32_t *buffer0, uint32_t *buffer1, uint32_t n,
+                         LaunchEvents ev = {});
 
 }  // namespace vrs

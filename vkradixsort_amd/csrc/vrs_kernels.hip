@@ -16,6 +16,18 @@
 //   K4 single_kernel      the single_radixsort path: four passes inside one workgroup.
 #include "vrs_kernels.h"
 
+#include <hip/hip_ext.h>
+
+// Launch with optional timing events bound to the dispatch packet itself (hipExtLaunchKernel): unlike
+// hipEventRecord brackets this adds no barrier packets between dependent kernels.
+#define VRS_LAUNCH(kernel, grid, block, stream, ev, ...)                                                        \
+    do {                                                                                                        \
+        if ((ev).start != nullptr || (ev).stop != nullptr)                                                      \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (ev).start, (ev).stop, 0, __VA_ARGS__);       \
+        else                                                                                                    \
+            hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                    \
+    } while (0)
+
 // Phase-timing hooks for tools/lab (compiled out of the product library).
 #ifndef VRS_MARK
 #define VRS_MARK(i)
@@ -573,40 +585,45 @@ uint32_t prefix_chunk_tiles(uint32_t W) {
 }
 
 hipError_t launch_histograms(hipStream_t stream, const uint32_t *keys_in, uint32_t *hist, uint32_t n,
-                             uint32_t shift, uint32_t W, uint32_t B) {
+                             uint32_t shift, uint32_t W, uint32_t B, LaunchEvents ev) {
     if (W == 0) return hipSuccess;
-    hipLaunchKernelGGL(histogram_kernel<8>, dim3(W), dim3(kThreads), 0, stream, keys_in, hist, n, shift, W, B);
+    VRS_LAUNCH(histogram_kernel<8>, dim3(W), dim3(kThreads), stream, ev, keys_in, hist, n, shift, W, B);
     return hipGetLastError();
 }
 
-hipError_t launch_prefix(hipStream_t stream, const uint32_t *hist, const PrefixScratch &scratch, uint32_t W) {
+hipError_t launch_prefix(hipStream_t stream, const uint32_t *hist, const PrefixScratch &scratch, uint32_t W,
+                         LaunchEvents ev) {
     if (W == 0) return hipSuccess;
     const uint32_t C = prefix_chunk_tiles(W);
     const uint32_t G = (W + C - 1) / C;
-    hipLaunchKernelGGL(chunk_sum_kernel, dim3(G), dim3(kPrefixThreads), 0, stream, hist, scratch.chunk_sums, W, C);
-    hipLaunchKernelGGL(offsets_kernel, dim3(G), dim3(kPrefixThreads), 0, stream, hist, scratch.chunk_sums,
-                       scratch.offsets, W, C, G);
+    const LaunchEvents first{ev.start, nullptr}, second{nullptr, ev.stop};
+    VRS_LAUNCH(chunk_sum_kernel, dim3(G), dim3(kPrefixThreads), stream, first, hist, scratch.chunk_sums, W, C);
+    VRS_LAUNCH(offsets_kernel, dim3(G), dim3(kPrefixThreads), stream, second, hist, scratch.chunk_sums,
+               scratch.offsets, W, C, G);
     return hipGetLastError();
 }
 
 template <int ITEMS, int WAVES, int RANK, int OCC>
 static hipError_t launch_scatter_variant(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
                                          const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets,
-                                         uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap) {
+                                         uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap,
+                                         LaunchEvents ev) {
+    const int remap = xcd_remap ? 1 : 0;
     if (values_in != nullptr)
-        hipLaunchKernelGGL((scatter_kernel<ITEMS, WAVES, true, RANK, OCC>), dim3(W), dim3(WAVES * 64), 0, stream,
-                           keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap ? 1 : 0);
+        VRS_LAUNCH((scatter_kernel<ITEMS, WAVES, true, RANK, OCC>), dim3(W), dim3(WAVES * 64), stream, ev, keys_in,
+                   keys_out, values_in, values_out, offsets, n, shift, W, B, remap);
     else
-        hipLaunchKernelGGL((scatter_kernel<ITEMS, WAVES, false, RANK, OCC>), dim3(W), dim3(WAVES * 64), 0, stream,
-                           keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap ? 1 : 0);
+        VRS_LAUNCH((scatter_kernel<ITEMS, WAVES, false, RANK, OCC>), dim3(W), dim3(WAVES * 64), stream, ev, keys_in,
+                   keys_out, values_in, values_out, offsets, n, shift, W, B, remap);
     return hipGetLastError();
 }
 
-#define VRS_SCATTER_ARGS stream, keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap
+#define VRS_SCATTER_ARGS stream, keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap, ev
 
 hipError_t launch_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
                           const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets, uint32_t n,
-                          uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap, const ScatterLaunch &cfg) {
+                          uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap, const ScatterLaunch &cfg,
+                          LaunchEvents ev) {
     if (W == 0) return hipSuccess;
     // chunk = ITEMS*WAVES*64 keys held in registers + LDS at once; a tile of B blocks is walked in
     // ceil(B*256/chunk) chunks.  cfg.variant (tuning only) = OCC*100000 + ITEMS*1000 + WAVES*10 + RANK
@@ -638,9 +655,9 @@ hipError_t launch_atomic_rank_selftest(hipStream_t stream, uint32_t rounds, uint
     return hipGetLastError();
 }
 
-hipError_t launch_single(hipStream_t stream, uint32_t *buffer0, uint32_t *buffer1, uint32_t n) {
+hipError_t launch_single(hipStream_t stream, uint32_t *buffer0, uint32_t *buffer1, uint32_t n, LaunchEvents ev) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(single_kernel, dim3(1), dim3(kThreads), 0, stream, buffer0, buffer1, n);
+    VRS_LAUNCH(single_kernel, dim3(1), dim3(kThreads), stream, ev, buffer0, buffer1, n);
     return hipGetLastError();
 }
 

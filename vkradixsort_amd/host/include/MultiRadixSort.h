@@ -20,6 +20,8 @@ public:
     explicit MultiRadixSort(uint32_t numElements = 1000000, uint32_t numBlocksPerWorkgroup = 32, uint32_t seed = 1,
                             bool reference28BitKeys = false, uint32_t timedRepetitions = 1);
 
+    static inline const char *PRINT_PREFIX = "[MultiRadixSort] ";
+
     void execute(GPUContext *gpuContext);
 
     // results of the last execute() for programmatic callers / the sweep harness
@@ -30,7 +32,8 @@ public:
     static void generateRandomNumbers(std::vector<SORT_TYPE> &buffer, uint32_t numElements, uint32_t seed,
                                       bool reference28BitKeys);
     static double sort(std::vector<SORT_TYPE> &buffer);
-    static bool testSort(std::vector<SORT_TYPE> &reference, std::vector<SORT_TYPE> &outBuffer);
+    static bool testSort(std::vector<SORT_TYPE> &reference, std::vector<SORT_TYPE> &outBuffer,
+                         const char *printPrefix = PRINT_PREFIX);
 
 private:
     GPUContext *m_gpuContext = nullptr;
@@ -47,8 +50,6 @@ private:
     std::vector<std::shared_ptr<Buffer>> m_buffers = std::vector<std::shared_ptr<Buffer>>(3);
     std::vector<SORT_TYPE> m_elementsIn;
     double m_gpuSortTime = 0.0, m_cpuSortTime = 0.0;
-
-    static inline const char *PRINT_PREFIX = "[MultiRadixSort] ";
 
     void prepareBuffers();
     void verify(std::vector<SORT_TYPE> &reference);

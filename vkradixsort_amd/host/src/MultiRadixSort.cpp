@@ -134,19 +134,20 @@ double MultiRadixSort::sort(std::vector<SORT_TYPE> &buffer) {
     return elapsedMs(begin, std::chrono::steady_clock::now());
 }
 
-bool MultiRadixSort::testSort(std::vector<SORT_TYPE> &reference, std::vector<SORT_TYPE> &outBuffer) {
+bool MultiRadixSort::testSort(std::vector<SORT_TYPE> &reference, std::vector<SORT_TYPE> &outBuffer,
+                              const char *printPrefix) {
     if (reference.size() != outBuffer.size()) {
-        std::cerr << PRINT_PREFIX << "reference.size() != outBuffer.size()" << std::endl;
+        std::cerr << printPrefix << "reference.size() != outBuffer.size()" << std::endl;
         throw std::runtime_error("TEST FAILED.");
     }
     const auto mismatch = std::mismatch(reference.begin(), reference.end(), outBuffer.begin());
     if (mismatch.first != reference.end()) {
         const auto i = mismatch.first - reference.begin();
-        std::cerr << PRINT_PREFIX << *mismatch.first << " = reference[" << i << "] != outBuffer[" << i
+        std::cerr << printPrefix << *mismatch.first << " = reference[" << i << "] != outBuffer[" << i
                   << "] = " << *mismatch.second << std::endl;
         throw std::runtime_error("TEST FAILED.");
     }
-    std::cout << PRINT_PREFIX << "Test passed." << std::endl;
+    std::cout << printPrefix << "Test passed." << std::endl;
     return true;
 }
 

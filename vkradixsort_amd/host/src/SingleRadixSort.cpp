@@ -49,7 +49,7 @@ void SingleRadixSort::execute(GPUContext *gpuContext) {
 
     std::vector<SORT_TYPE> data(NUM_ELEMENTS);
     m_buffers[INPUT_BUFFER_INDEX]->downloadWithStagingBuffer(data.data());
-    MultiRadixSort::testSort(m_elementsIn, data);
+    MultiRadixSort::testSort(m_elementsIn, data, PRINT_PREFIX);
 
     for (const auto &buffer : m_buffers) buffer->release();
     m_pass->release();
