@@ -146,8 +146,12 @@ typedef enum vrs_kernel_id {
     VRS_KERNEL_COUNT = 4
 } vrs_kernel_id;
 
-/* When enabled, every kernel launch is bracketed by hipEvents on the context's stream. */
+/* When enabled, every kernel launch carries a (start, stop) hipEvent pair on its own dispatch packet
+ * (hipExtLaunchKernel) on the context's stream -- no separate event-record packets. */
 int vrs_profile_enable(vrs_context ctx, int enabled);
+/* Same, for a subset: bit k of `kernel_mask` selects vrs_kernel_id k (timing only the dominant kernel
+ * keeps the instrumentation out of the other launches of a timed region). */
+int vrs_profile_enable_mask(vrs_context ctx, uint32_t kernel_mask);
 int vrs_profile_reset(vrs_context ctx);
 /* Synchronises the stream, then returns launches and summed event time for one kernel id. */
 int vrs_profile_query(vrs_context ctx, int kernel_id, uint64_t *launches, double *total_ms);

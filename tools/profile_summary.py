@@ -1,0 +1,62 @@
+"""Condenses the rocprofv3 outputs of tools/collect_profiles.sh into the small files committed under profiles/."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+out, rnd = sys.argv[1], sys.argv[2]
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+# kernel stats from the trace
+dur = defaultdict(list)
+for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        dur[short(row["Kernel_Name"])].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+total = sum(sum(v) for v in dur.values())
+lines = ["kernel,calls,total_us,avg_us,min_us,max_us,percent"]
+for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+    lines.append(f"{k},{len(v)},{sum(v):.1f},{sum(v)/len(v):.2f},{min(v):.2f},{max(v):.2f},{100*sum(v)/total:.2f}")
+open(f"{out}/{rnd}_bench_kernel_stats.csv", "w").write("\n".join(lines) + "\n")
+
+# rocprofv3's own stats file, verbatim
+for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
+    open(f"{out}/{rnd}_rocprofv3_kernel_stats.csv", "w").write(open(f).read())
+
+
+def counter_per_dispatch(sub, counter):
+    acc = defaultdict(float)
+    disp = defaultdict(set)
+    for f in glob.glob(f"{out}/{sub}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            k = short(row["Kernel_Name"])
+            acc[k] += float(row["Counter_Value"])
+            disp[k].add(row["Dispatch_Id"])
+    return {k: acc[k] / max(len(disp[k]), 1) for k in acc}
+
+
+fetch = counter_per_dispatch("pmc_fetch", "FETCH_SIZE")
+write = counter_per_dispatch("pmc_write", "WRITE_SIZE")
+rows = {}
+for k in sorted(set(fetch) | set(write)):
+    # FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B,
+    # i.e. reports half of the bytes a coalesced stream fetches (MI355X_MICROARCH.md, HBM section) -> x2.
+    # Calibration on this access pattern: the scatter's corrected read bytes = N*4 keys + W*1 KiB offsets.
+    fb = fetch.get(k, 0.0) * 1024 * 2
+    wb = write.get(k, 0.0) * 1024
+    rows[k] = {"fetch_bytes_corrected_x2": fb, "write_bytes": wb, "hbm_bytes_per_launch": fb + wb,
+               "raw_FETCH_SIZE": fetch.get(k, 0.0), "raw_WRITE_SIZE": write.get(k, 0.0)}
+json.dump(rows, open(f"{out}/{rnd}_hbm_traffic_per_launch.json", "w"), indent=1)
+scat = [v for k, v in rows.items() if "scatter_kernel" in k]
+if scat:
+    json.dump({"kernel": "scatter_kernel", "round": rnd, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 10 --warmup 2 --no-cpu-baseline`",
+               "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE x1; both x1024 B",
+               **scat[0]}, open(f"{out}/scatter_traffic.json", "w"), indent=1)
+print(open(f"{out}/{rnd}_bench_kernel_stats.csv").read())
+print(json.dumps(rows, indent=1))

@@ -72,6 +72,7 @@ _SIGNATURES = [
     ("vrs_queue_wait_idle", c_int, [c_void_p]),
     ("vrs_single_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_profile_enable", c_int, [c_void_p, c_int]),
+    ("vrs_profile_enable_mask", c_int, [c_void_p, c_uint32]),
     ("vrs_profile_reset", c_int, [c_void_p]),
     ("vrs_profile_query", c_int, [c_void_p, c_int, POINTER(c_uint64), POINTER(c_double)]),
     ("vrs_debug_download_offsets", c_int, [c_void_p, c_void_p, c_size_t]),

@@ -26,7 +26,7 @@ struct vrs_context_t {
     vrs::ScatterLaunch scatter;
     bool atomic_rank_verified = false;  // device self-test result (context creation)
     // profiling
-    bool profile = false;
+    uint32_t profile_mask = 0;  // bit k: attach timing events to launches of vrs_kernel_id k
     struct EventPair {
         hipEvent_t start, stop;
     };
@@ -90,7 +90,7 @@ int ensure_scratch(vrs_context ctx, uint32_t W) {
 // kernel's own dispatch packet (hipExtLaunchKernel), so profiling does not insert barrier packets.
 int profile_events(vrs_context ctx, int id, vrs::LaunchEvents *ev) {
     *ev = vrs::LaunchEvents{};
-    if (!ctx->profile) return VRS_OK;
+    if (!(ctx->profile_mask & (1u << id))) return VRS_OK;
     auto &pool = ctx->events[id];
     if (ctx->events_used[id] == pool.size()) {
         vrs_context_t::EventPair p{};
@@ -439,7 +439,13 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
 
 int vrs_profile_enable(vrs_context ctx, int enabled) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
-    ctx->profile = enabled != 0;
+    ctx->profile_mask = enabled ? (1u << VRS_KERNEL_COUNT) - 1u : 0u;
+    return VRS_OK;
+}
+
+int vrs_profile_enable_mask(vrs_context ctx, uint32_t kernel_mask) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    ctx->profile_mask = kernel_mask & ((1u << VRS_KERNEL_COUNT) - 1u);
     return VRS_OK;
 }
 

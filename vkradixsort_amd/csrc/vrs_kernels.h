@@ -30,7 +30,8 @@ struct ScatterLaunch {
 uint32_t prefix_chunk_tiles(uint32_t num_workgroups);
 
 hipError_t launch_histograms(hipStream_t stream, const uint32_t *keys_in, uint32_t *hist,
-                             uint32_t n, uint32_t shift, uint32_t W, uint32_t B, LaunchEvents ev = {});
+                             uint32_t n, uint32_t shift, uint32_t W, uint32_t B, LaunchEvents ev = {},
+                             const uint32_t *tile_order = nullptr);
 
 hipError_t launch_prefix(hipStream_t stream, const uint32_t *hist, const PrefixScratch &scratch,
                          uint32_t W, LaunchEvents ev = {});
@@ -38,7 +39,8 @@ hipError_t launch_prefix(hipStream_t stream, const uint32_t *hist, const PrefixS
 hipError_t launch_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
                           const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets,
                           uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap,
-                          const ScatterLaunch &cfg, LaunchEvents ev = {});
+                          const ScatterLaunch &cfg, LaunchEvents ev = {},
+                          const uint32_t *tile_order = nullptr);
 
 hipError_t launch_atomic_rank_selftest(hipStream_t stream, uint32_t rounds, uint32_t seed,
                                        unsigned long long *mismatches);

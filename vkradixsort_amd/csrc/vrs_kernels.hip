@@ -124,10 +124,12 @@ __device__ __forceinline__ void histogram_count4(uint32_t *s_hist, uint4 q, uint
 template <int UNROLL>
 __global__ __launch_bounds__(kThreads) void histogram_kernel(const uint32_t *__restrict__ keys,
                                                              uint32_t *__restrict__ hist, uint32_t n,
-                                                             uint32_t shift, uint32_t W, uint32_t B) {
+                                                             uint32_t shift, uint32_t W, uint32_t B,
+                                                             const uint32_t *__restrict__ tile_order) {
     __shared__ uint32_t s_hist[kBins];
     const uint32_t tid = threadIdx.x;
-    const uint32_t w = blockIdx.x;
+    // which tile this workgroup takes is a pure scheduling choice (cache residency), never a result
+    const uint32_t w = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
     s_hist[tid] = 0;
     __syncthreads();
 
@@ -478,9 +480,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const uint32_t
                                                              const uint32_t *__restrict__ values_in,
                                                              uint32_t *__restrict__ values_out,
                                                              const uint32_t *__restrict__ offsets, uint32_t n,
-                                                             uint32_t shift, uint32_t W, uint32_t B, int xcd_remap) {
+                                                             uint32_t shift, uint32_t W, uint32_t B, int xcd_remap,
+                                                             const uint32_t *__restrict__ tile_order) {
     __shared__ ChunkSmem<ITEMS, WAVES> sm;
-    const uint32_t w = xcd_remap ? xcd_contiguous_tile(blockIdx.x, W) : blockIdx.x;
+    const uint32_t w = tile_order ? tile_order[blockIdx.x]
+                                  : (xcd_remap ? xcd_contiguous_tile(blockIdx.x, W) : blockIdx.x);
     const uint64_t tile_begin = static_cast<uint64_t>(w) * B * kThreads;
     if (tile_begin >= n) return;  // uniform per workgroup
     const uint64_t tile_keys = static_cast<uint64_t>(B) * kThreads;
@@ -585,9 +589,9 @@ uint32_t prefix_chunk_tiles(uint32_t W) {
 }
 
 hipError_t launch_histograms(hipStream_t stream, const uint32_t *keys_in, uint32_t *hist, uint32_t n,
-                             uint32_t shift, uint32_t W, uint32_t B, LaunchEvents ev) {
+                             uint32_t shift, uint32_t W, uint32_t B, LaunchEvents ev, const uint32_t *tile_order) {
     if (W == 0) return hipSuccess;
-    VRS_LAUNCH(histogram_kernel<8>, dim3(W), dim3(kThreads), stream, ev, keys_in, hist, n, shift, W, B);
+    VRS_LAUNCH(histogram_kernel<8>, dim3(W), dim3(kThreads), stream, ev, keys_in, hist, n, shift, W, B, tile_order);
     return hipGetLastError();
 }
 
@@ -607,23 +611,23 @@ template <int ITEMS, int WAVES, int RANK, int OCC>
 static hipError_t launch_scatter_variant(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
                                          const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets,
                                          uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap,
-                                         LaunchEvents ev) {
+                                         LaunchEvents ev, const uint32_t *tile_order) {
     const int remap = xcd_remap ? 1 : 0;
     if (values_in != nullptr)
         VRS_LAUNCH((scatter_kernel<ITEMS, WAVES, true, RANK, OCC>), dim3(W), dim3(WAVES * 64), stream, ev, keys_in,
-                   keys_out, values_in, values_out, offsets, n, shift, W, B, remap);
+                   keys_out, values_in, values_out, offsets, n, shift, W, B, remap, tile_order);
     else
         VRS_LAUNCH((scatter_kernel<ITEMS, WAVES, false, RANK, OCC>), dim3(W), dim3(WAVES * 64), stream, ev, keys_in,
-                   keys_out, values_in, values_out, offsets, n, shift, W, B, remap);
+                   keys_out, values_in, values_out, offsets, n, shift, W, B, remap, tile_order);
     return hipGetLastError();
 }
 
-#define VRS_SCATTER_ARGS stream, keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap, ev
+#define VRS_SCATTER_ARGS stream, keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap, ev, tile_order
 
 hipError_t launch_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
                           const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets, uint32_t n,
                           uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap, const ScatterLaunch &cfg,
-                          LaunchEvents ev) {
+                          LaunchEvents ev, const uint32_t *tile_order) {
     if (W == 0) return hipSuccess;
     // chunk = ITEMS*WAVES*64 keys held in registers + LDS at once; a tile of B blocks is walked in
     // ceil(B*256/chunk) chunks.  cfg.variant (tuning only) = OCC*100000 + ITEMS*1000 + WAVES*10 + RANK

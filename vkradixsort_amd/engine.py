@@ -101,6 +101,9 @@ class GPUContext:
     def profileEnable(self, on: bool) -> None:
         self.check(self._lib.vrs_profile_enable(self.handle, 1 if on else 0))
 
+    def profileEnableMask(self, kernel_mask: int) -> None:
+        self.check(self._lib.vrs_profile_enable_mask(self.handle, kernel_mask))
+
     def profileReset(self) -> None:
         self.check(self._lib.vrs_profile_reset(self.handle))
 
