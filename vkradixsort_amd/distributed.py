@@ -5,10 +5,10 @@ The reference is single-GPU; this is the build's multi-GPU path.  One process pe
 
   1. local step   one radix pass on the TOP byte (histograms + stable scatter, shift 24) groups the shard
                   by top byte, so every key range [byte lo, byte hi) is one contiguous slice
-  2. splitters    all-reduce of the 256 top-byte counts (2 KiB, latency bound) -> world-1 byte boundaries
-                  that balance the ranges
-  3. exchange     counts all-to-all (8 x int64), then ONE variable-size all-to-all of the keys
-                  (dist.all_to_all_single with split sizes: grouped send/recv on every xGMI link at once)
+  2. splitters    ONE all-gather of every rank's 256 top-byte counts (world x 2 KiB, latency bound); each rank
+                  derives the same world-1 byte boundaries plus its own send and receive counts from it
+  3. exchange     ONE variable-size all-to-all of the keys (dist.all_to_all_single with split sizes: grouped
+                  send/recv on every xGMI link at once)
   4. merge step   the received runs are sorted locally by the four-pass multi_radixsort
 
 Rank g ends up holding range g in ascending order; the global result is the concatenation of ranks 0..W-1.
@@ -158,19 +158,20 @@ class RangeShardedSort:
         grouped, digit_base = self.backend.group_by_top_byte(keys, n)
         base = np.concatenate([digit_base.astype(np.int64), [n]])
         local_counts = np.diff(base)
-        # 2. splitters from the global top-byte histogram
-        counts_t = torch.from_numpy(local_counts.copy()).to(self.device)
-        dist.all_reduce(counts_t, op=dist.ReduceOp.SUM, group=self.group)
-        bounds = plan_splitters(counts_t.cpu().numpy(), self.world)
-        # 3. exchange: counts, then keys
+        # 2. ONE small collective: everybody learns everybody's 256 top-byte counts (world x 2 KiB), from which
+        #    each rank derives the same splitters, its send counts and its receive counts without further traffic
+        mine = torch.from_numpy(local_counts.copy()).to(self.device)
+        table = torch.empty(self.world * RADIX_SORT_BINS, dtype=mine.dtype, device=self.device)
+        dist.all_gather_into_tensor(table, mine, group=self.group)
+        all_counts = table.cpu().numpy().reshape(self.world, RADIX_SORT_BINS)
+        bounds = plan_splitters(all_counts.sum(axis=0), self.world)
         send_counts = send_counts_from_digit_base(digit_base, n, bounds)
-        send_t = torch.from_numpy(send_counts.copy()).to(self.device)
-        recv_t = torch.empty_like(send_t)
-        dist.all_to_all_single(recv_t, send_t, group=self.group)
-        recv_counts = recv_t.cpu().numpy()
+        lo, hi = int(bounds[self.rank]), int(bounds[self.rank + 1])
+        recv_counts = all_counts[:, lo:hi].sum(axis=1).astype(np.int64)
         total = int(recv_counts.sum())
         if total > self.recv_capacity:
             raise RuntimeError(f"rank {self.rank}: receives {total} keys, capacity {self.recv_capacity}")
+        # 3. exchange the keys: one variable-size all-to-all (grouped send/recv over every xGMI link at once)
         dist.all_to_all_single(self.recv[:total], grouped[:n], output_split_sizes=[int(c) for c in recv_counts],
                                input_split_sizes=[int(c) for c in send_counts], group=self.group)
         # 4. merge step: local four-pass sort of the received runs
