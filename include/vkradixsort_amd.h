@@ -136,6 +136,28 @@ int vrs_queue_wait_idle(vrs_context ctx);
 int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1,
                          uint32_t g_num_elements);
 
+/*
+ * One-call form of MultiRadixSort::execute's hot loop (MultiRadixSort.cpp:50-61): four passes with
+ * g_shift = 0, 8, 16, 24 ping-ponging `keys` <-> `keys_tmp` (the reference's buffer0 / buffer1); the
+ * library picks NUM_BLOCKS_PER_WORKGROUP (32) and owns the histogram table.  Result in `keys`.
+ * Asynchronous.  The pairs form is stable (== std::stable_sort by key); `values` follow their keys.
+ */
+int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements);
+int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
+                       vrs_buffer values_tmp, uint32_t num_elements);
+
+/*
+ * Key preprocessing the reference leaves to the integrator ("you have to preprocess negative numbers",
+ * README.md:154-155): in-place, order-preserving maps between int32 / float32 bit patterns and the uint32
+ * keys the sort orders.  Asynchronous.  Apply *_TO_SORTABLE before the four passes and the inverse after.
+ */
+typedef enum vrs_key_transform {
+    VRS_KEYS_INT32 = 0,               /* int32 <-> sortable: flips the sign bit (self-inverse) */
+    VRS_KEYS_FLOAT32_TO_SORTABLE = 1, /* IEEE-754 total order: -NaN < -inf < ... < -0 < +0 < ... < +inf < +NaN */
+    VRS_KEYS_SORTABLE_TO_FLOAT32 = 2
+} vrs_key_transform;
+int vrs_transform_keys(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, int mode);
+
 /* ---- measurement (no reference counterpart) ------------------------- */
 
 typedef enum vrs_kernel_id {

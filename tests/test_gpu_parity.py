@@ -375,3 +375,84 @@ def test_range_sharded_sort_product_backend_world1_rccl(oracle):
         backend.close()
     finally:
         dist.destroy_process_group()
+
+
+def _sort_with_transform(ctx, raw_u32, to_mode, from_mode, B=32):
+    """transform -> four passes -> inverse transform, all on the device through the C ABI"""
+    n = raw_u32.size
+    lib = ctx.lib
+    b0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), raw_u32)
+    b1 = vrs.Buffer(ctx, S(4 * n))
+    W = lib.vrs_workgroup_count(n, B)
+    h = vrs.Buffer(ctx, S(W * 1024))
+    ctx.check(lib.vrs_transform_keys(ctx.handle, b0.handle, n, to_mode))
+    pc = vrs.PushConstants(n, 0, W, B)
+    bufs = [b0, b1]
+    for i in range(4):
+        pc.g_shift = 8 * i
+        ctx.check(lib.vrs_multi_radixsort_histograms(ctx.handle, bufs[i % 2].handle, h.handle, ctypes.byref(pc)))
+        ctx.check(lib.vrs_multi_radixsort(ctx.handle, bufs[i % 2].handle, bufs[(i + 1) % 2].handle, h.handle, ctypes.byref(pc)))
+    ctx.check(lib.vrs_transform_keys(ctx.handle, b0.handle, n, from_mode))
+    out = np.empty(n, np.uint32)
+    b0.downloadWithStagingBuffer(out)
+    for b in (b0, b1, h):
+        b.release()
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 3, 1000, 100003, 1 << 20])
+def test_int32_keys_via_sign_flip(gpu_context, n):
+    vals = np.random.RandomState(n).randint(-2 ** 31, 2 ** 31, size=n, dtype=np.int64).astype(np.int32)
+    out = _sort_with_transform(gpu_context, vals.view(np.uint32), capi.VRS_KEYS_INT32, capi.VRS_KEYS_INT32)
+    assert np.array_equal(out.view(np.int32), np.sort(vals))
+
+
+@pytest.mark.parametrize("n", [2, 1000, 100003, 1 << 20])
+def test_float32_keys_total_order(gpu_context, n):
+    rs = np.random.RandomState(n)
+    vals = (rs.standard_normal(n) * 10.0 ** rs.randint(-30, 30, n)).astype(np.float32)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, 1e-45, -1e-45, 3.4e38, -3.4e38], dtype=np.float32)
+    vals[:min(n, special.size)] = special[:min(n, special.size)]
+    out = _sort_with_transform(gpu_context, vals.view(np.uint32), capi.VRS_KEYS_FLOAT32_TO_SORTABLE,
+                               capi.VRS_KEYS_SORTABLE_TO_FLOAT32).view(np.float32)
+    ref = np.sort(vals)  # no NaNs in the input: numpy's order == IEEE total order except for the sign of zero
+    assert np.array_equal(out, ref)
+    if n >= 2:  # -0.0 sorts before +0.0 (bit-exact total order), which numpy does not promise
+        zeros = np.flatnonzero(out == 0.0)
+        signs = np.signbit(out[zeros])
+        assert np.all(signs[:-1] >= signs[1:])
+    assert np.array_equal(np.sort(out.view(np.uint32)), np.sort(vals.view(np.uint32)))  # a permutation of the input bits
+
+
+def test_float32_nans_sort_to_the_ends(gpu_context):
+    vals = np.array([np.nan, 1.0, -np.nan, -1.0, np.inf, -np.inf, 0.0], dtype=np.float32)
+    vals.view(np.uint32)[2] |= np.uint32(0x80000000)  # a negative NaN
+    out = _sort_with_transform(gpu_context, vals.view(np.uint32), capi.VRS_KEYS_FLOAT32_TO_SORTABLE,
+                               capi.VRS_KEYS_SORTABLE_TO_FLOAT32).view(np.float32)
+    assert np.isnan(out[0]) and np.signbit(out[0]) and np.isnan(out[-1]) and not np.signbit(out[-1])
+    assert out[1:-1].tolist() == [-np.inf, -1.0, 0.0, 1.0, np.inf]
+
+
+@pytest.mark.parametrize("n", [1, 257, 100003, 3000001])
+def test_one_call_sort_entry_points(gpu_context, oracle, n):
+    ctx, lib = gpu_context, gpu_context.lib
+    keys = rand_keys(n, n) & np.uint32(0xFFFF00FF)
+    vals = np.arange(n, dtype=np.uint32)
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)
+    k1 = vrs.Buffer(ctx, S(4 * n))
+    ctx.check(lib.vrs_sort_keys_u32(ctx.handle, k0.handle, k1.handle, n))
+    out = np.empty(n, np.uint32)
+    k0.downloadWithStagingBuffer(out)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    k0.release()
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)
+    v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
+    v1 = vrs.Buffer(ctx, S(4 * n))
+    ctx.check(lib.vrs_sort_pairs_u32(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+    ov = np.empty(n, np.uint32)
+    k0.downloadWithStagingBuffer(out)
+    v0.downloadWithStagingBuffer(ov)
+    rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
+    assert np.array_equal(out, rk) and np.array_equal(ov, rv)
+    for b in (k0, k1, v0, v1):
+        b.release()

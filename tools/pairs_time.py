@@ -48,10 +48,5 @@ def run(gpu, n, B, pairs, reps=5, variant=0):
 
 with vrs.GPUContext(0) as gpu:
     run(gpu, 10 ** 8, 32, True)
-    run(gpu, 10 ** 8, 32, True, variant=416040 + 0)
-    run(gpu, 10 ** 8, 32, True, variant=332041)
-    for n in (10 ** 7, 10 ** 6, 10 ** 5, 10 ** 4, 10 ** 3):
-        for B in (32, 8, 1):
-            if n // (B * 256) > 200000:
-                continue
-            run(gpu, n, B, False)
+    run(gpu, 10 ** 8, 16, True)
+    run(gpu, 10 ** 8, 32, False)

@@ -24,6 +24,10 @@ VRS_KERNEL_SCATTER = 2
 VRS_KERNEL_SINGLE = 3
 KERNEL_NAMES = {0: "histogram", 1: "prefix", 2: "scatter", 3: "single"}
 
+VRS_KEYS_INT32 = 0
+VRS_KEYS_FLOAT32_TO_SORTABLE = 1
+VRS_KEYS_SORTABLE_TO_FLOAT32 = 2
+
 VRS_TUNE_XCD_REMAP = 0
 VRS_TUNE_SCATTER_VARIANT = 1
 VRS_TUNE_RANK_MODE = 3
@@ -71,6 +75,9 @@ _SIGNATURES = [
     ("vrs_multi_radixsort_digit_offsets", c_int, [c_void_p, c_void_p]),
     ("vrs_queue_wait_idle", c_int, [c_void_p]),
     ("vrs_single_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
+    ("vrs_sort_keys_u32", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
+    ("vrs_sort_pairs_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
+    ("vrs_transform_keys", c_int, [c_void_p, c_void_p, c_uint32, c_int]),
     ("vrs_profile_enable", c_int, [c_void_p, c_int]),
     ("vrs_profile_enable_mask", c_int, [c_void_p, c_uint32]),
     ("vrs_profile_reset", c_int, [c_void_p]),

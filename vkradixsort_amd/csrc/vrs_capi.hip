@@ -25,6 +25,7 @@ struct vrs_context_t {
     bool xcd_remap = true;
     vrs::ScatterLaunch scatter;
     bool atomic_rank_verified = false;  // device self-test result (context creation)
+    vrs_buffer sort_hist = nullptr;     // histogram table owned by the one-call entry points
     // profiling
     uint32_t profile_mask = 0;  // bit k: attach timing events to launches of vrs_kernel_id k
     struct EventPair {
@@ -265,6 +266,7 @@ int vrs_context_destroy(vrs_context ctx) {
             (void)hipEventDestroy(p.start);
             (void)hipEventDestroy(p.stop);
         }
+    if (ctx->sort_hist) (void)vrs_buffer_release(ctx->sort_hist);
     if (ctx->scratch.offsets) (void)hipFree(ctx->scratch.offsets);
     if (ctx->scratch.chunk_sums) (void)hipFree(ctx->scratch.chunk_sums);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -434,6 +436,61 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
     if ((rc = profile_events(ctx, VRS_KERNEL_SINGLE, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_single(ctx->stream, static_cast<uint32_t *>(buffer0->ptr),
                                     static_cast<uint32_t *>(buffer1->ptr), g_num_elements, ev));
+    return VRS_OK;
+}
+
+// One-call form: the four passes of MultiRadixSort::execute's hot loop (MultiRadixSort.cpp:50-61) with the
+// library choosing NUM_BLOCKS_PER_WORKGROUP and owning the histogram table.
+static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
+                           vrs_buffer values_tmp, uint32_t n) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (n == 0) return VRS_OK;
+    const uint32_t B = 32;
+    vrs_push_constants pc{n, 0, vrs_workgroup_count(n, B), B};
+    const size_t need = static_cast<size_t>(pc.g_num_workgroups) * VRS_RADIX_SORT_BINS * sizeof(uint32_t);
+    if (!ctx->sort_hist || ctx->sort_hist->size < need) {
+        if (ctx->sort_hist) {
+            VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            vrs_buffer_release(ctx->sort_hist);
+            ctx->sort_hist = nullptr;
+        }
+        int rc = vrs_buffer_create(ctx, need, &ctx->sort_hist);
+        if (rc) return rc;
+    }
+    for (uint32_t i = 0; i < 4; ++i) {
+        pc.g_shift = 8 * i;
+        vrs_buffer kin = (i & 1u) ? keys_tmp : keys, kout = (i & 1u) ? keys : keys_tmp;
+        int rc = vrs_multi_radixsort_histograms(ctx, kin, ctx->sort_hist, &pc);
+        if (rc) return rc;
+        if (values)
+            rc = vrs_multi_radixsort_pairs(ctx, kin, kout, (i & 1u) ? values_tmp : values,
+                                           (i & 1u) ? values : values_tmp, ctx->sort_hist, &pc);
+        else
+            rc = vrs_multi_radixsort(ctx, kin, kout, ctx->sort_hist, &pc);
+        if (rc) return rc;
+    }
+    return VRS_OK;
+}
+
+int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements) {
+    return sort_all_passes(ctx, keys, keys_tmp, nullptr, nullptr, num_elements);
+}
+
+int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
+                       vrs_buffer values_tmp, uint32_t num_elements) {
+    if (!values || !values_tmp) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "values buffers are NULL");
+    return sort_all_passes(ctx, keys, keys_tmp, values, values_tmp, num_elements);
+}
+
+int vrs_transform_keys(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, int mode) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (mode < VRS_KEYS_INT32 || mode > VRS_KEYS_SORTABLE_TO_FLOAT32)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "unknown key transform");
+    if (num_elements == 0) return VRS_OK;
+    int rc = check_buffer(ctx, keys, static_cast<size_t>(num_elements) * sizeof(uint32_t), "keys");
+    if (rc) return rc;
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    VRS_HIP(ctx, vrs::launch_transform_keys(ctx->stream, static_cast<uint32_t *>(keys->ptr), num_elements, mode));
     return VRS_OK;
 }
 

@@ -45,6 +45,8 @@ hipError_t launch_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t 
 hipError_t launch_atomic_rank_selftest(hipStream_t stream, uint32_t rounds, uint32_t seed,
                                        unsigned long long *mismatches);
 
+hipError_t launch_transform_keys(hipStream_t stream, uint32_t *keys, uint32_t n, int mode);
+
 hipError_t launch_single(hipStream_t stream, uint32_t *buffer0, uint32_t *buffer1, uint32_t n,
                          LaunchEvents ev = {});
 

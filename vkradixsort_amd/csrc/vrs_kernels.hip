@@ -295,9 +295,10 @@ __global__ __launch_bounds__(kPrefixThreads) void offsets_kernel(const uint32_t 
 constexpr int RANK_BALLOT = 0;
 constexpr int RANK_ATOMIC = 1;
 
-template <int ITEMS, int WAVES>
+template <int ITEMS, int WAVES, bool PAIRS = false>
 struct ChunkSmem {
-    uint32_t keys[ITEMS * WAVES * 64];  // re-bucketed keys (then payloads), chunk order by digit
+    uint32_t keys[ITEMS * WAVES * 64];  // re-bucketed keys, chunk order by digit
+    uint32_t vals[PAIRS ? ITEMS * WAVES * 64 : 1];  // re-bucketed payloads (pairs only)
     uint32_t whist[WAVES][kBins];       // per-wave digit counters -> per-wave digit start positions
     uint32_t gbase[kBins];              // global offset of digit d minus its start inside the chunk
     uint32_t scan_tmp[WAVES];
@@ -345,7 +346,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_w(uint32_t v, uint32_t 
 // a workgroup is latency-bound (one pass over its keys, few waves), so dependent
 // read -> wait -> write chains per item are what must not appear in the ISA.
 template <int ITEMS, int WAVES, bool PAIRS, int RANK, bool FULL>
-__device__ __forceinline__ void scatter_chunk(ChunkSmem<ITEMS, WAVES> &sm, const uint32_t *kin,
+__device__ __forceinline__ void scatter_chunk(ChunkSmem<ITEMS, WAVES, PAIRS> &sm, const uint32_t *kin,
                                               const uint32_t *vin, uint32_t *kout, uint32_t *vout,
                                               uint32_t valid, uint32_t shift, uint32_t &run_off) {
     constexpr uint32_t THREADS = WAVES * 64;
@@ -444,6 +445,10 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<ITEMS, WAVES> &sm, const
     for (int i = 0; i < ITEMS; ++i) rank[i] += my_hist[digit_of(key[i], shift)];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) sm.keys[rank[i]] = key[i];
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) sm.vals[rank[i]] = val[i];
+    }
     __syncthreads();
     VRS_MARK(4);
 
@@ -460,18 +465,14 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<ITEMS, WAVES> &sm, const
     VRS_MARK(5);
 
     if constexpr (PAIRS) {
-        __syncthreads();  // everyone has read its keys back
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) sm.keys[rank[i]] = val[i];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) val[i] = sm.keys[i * THREADS + tid];
+        for (int i = 0; i < ITEMS; ++i) val[i] = sm.vals[i * THREADS + tid];
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             if (FULL || i * THREADS + tid < valid) vout[dst[i]] = val[i];
         }
-        __syncthreads();  // sm.keys is reused by the next chunk's keys
     }
+    // the next chunk's first barrier (after it zeroes the counters) separates these LDS reads from its writes
 }
 
 template <int ITEMS, int WAVES, bool PAIRS, int RANK, int OCC>
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const uint32_t
                                                              const uint32_t *__restrict__ offsets, uint32_t n,
                                                              uint32_t shift, uint32_t W, uint32_t B, int xcd_remap,
                                                              const uint32_t *__restrict__ tile_order) {
-    __shared__ ChunkSmem<ITEMS, WAVES> sm;
+    __shared__ ChunkSmem<ITEMS, WAVES, PAIRS> sm;
     const uint32_t w = tile_order ? tile_order[blockIdx.x]
                                   : (xcd_remap ? xcd_contiguous_tile(blockIdx.x, W) : blockIdx.x);
     const uint64_t tile_begin = static_cast<uint64_t>(w) * B * kThreads;
@@ -580,7 +581,42 @@ __global__ __launch_bounds__(kThreads) void single_kernel(uint32_t *buffer0, uin
 }
 
 // ---------------------------------------------------------------------------------------------
+// Key preprocessing the reference leaves to the integrator ("you have to preprocess negative numbers",
+// README.md:154-155): order-preserving bijections between int32 / float32 bit patterns and the uint32
+// keys the sort orders.  In place, 16 bytes per lane, grid-stride.
+//   mode 0  int32   <-> sortable : flip the sign bit (self-inverse)
+//   mode 1  float32  -> sortable : negative: flip all bits, else flip the sign bit (IEEE total order)
+//   mode 2  sortable -> float32  : inverse of mode 1
+__device__ __forceinline__ uint32_t transform_key(uint32_t x, int mode) {
+    if (mode == 0) return x ^ 0x80000000u;
+    if (mode == 1) return x ^ ((x & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
+    return x ^ ((x & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu);
+}
+
+__global__ __launch_bounds__(kThreads) void transform_keys_kernel(uint32_t *keys, uint32_t n, int mode) {
+    uint4 *v = reinterpret_cast<uint4 *>(keys);
+    const uint32_t nvec = n >> 2;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < nvec; i += gridDim.x * kThreads) {
+        uint4 q = v[i];
+        q.x = transform_key(q.x, mode);
+        q.y = transform_key(q.y, mode);
+        q.z = transform_key(q.z, mode);
+        q.w = transform_key(q.w, mode);
+        v[i] = q;
+    }
+    const uint32_t tail = (nvec << 2) + blockIdx.x * kThreads + threadIdx.x;
+    if (blockIdx.x == 0 && tail < n) keys[tail] = transform_key(keys[tail], mode);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launch wrappers
+
+hipError_t launch_transform_keys(hipStream_t stream, uint32_t *keys, uint32_t n, int mode) {
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = min((n / 4 + kThreads - 1) / kThreads + 1, 4096u);
+    hipLaunchKernelGGL(transform_keys_kernel, dim3(blocks), dim3(kThreads), 0, stream, keys, n, mode);
+    return hipGetLastError();
+}
 
 uint32_t prefix_chunk_tiles(uint32_t W) {
     uint32_t c = 1;
