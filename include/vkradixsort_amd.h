@@ -194,6 +194,7 @@ int vrs_rank_mode(vrs_context ctx);
 typedef enum vrs_tuning_key {
     VRS_TUNE_XCD_REMAP = 0,      /* 1 (default): consecutive tiles share an XCD's L2 in the scatter */
     VRS_TUNE_SCATTER_VARIANT = 1, /* 0 (default): chosen from B; else ITEMS*1000 + WAVES*10 + RANK */
+    VRS_TUNE_FUSED_PREFIX = 2,    /* 1 (default): single-launch prefix (chunk sums exchanged through tagged granules) */
     VRS_TUNE_RANK_MODE = 3        /* 0 (default) auto: LDS-atomic ranking if the device self-test passed at
                                      context creation, else __ballot ranking; 1 force ballot; 2 force atomic */
 } vrs_tuning_key;

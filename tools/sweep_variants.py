@@ -25,7 +25,9 @@ def main():
         for combo in combos:
             parts = [int(x) for x in combo.split(":")]
             parts += [0, 1, 0, 1][len(parts) - 1:]
-            B, variant, persistent, wgs, remap = parts[:5]
+            B, variant, fused, wgs, remap = parts[:5]
+            persistent = fused
+            gpu.setTuning(capi.VRS_TUNE_FUSED_PREFIX, fused)
             gpu.setTuning(capi.VRS_TUNE_SCATTER_VARIANT, variant)
             gpu.setTuning(capi.VRS_TUNE_XCD_REMAP, remap)
             m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=B, keys=keys, quiet=True)
@@ -53,7 +55,7 @@ def main():
                 ref = np.sort(keys)
             ok = bool(np.array_equal(out, ref))
             t = min(times)
-            line = f"N={n} B={B} variant={variant} pers={persistent} wgs={wgs} remap={remap} exact={ok} min={t*1e3:.3f}ms {n/t/1e9:.2f} Gkeys/s {48*n/t/8e12*100:.1f}%roof"
+            line = f"N={n} B={B} variant={variant} fusedprefix={persistent} wgs={wgs} remap={remap} exact={ok} min={t*1e3:.3f}ms {n/t/1e9:.2f} Gkeys/s {48*n/t/8e12*100:.1f}%roof"
             for kid, name in capi.KERNEL_NAMES.items():
                 cnt, ms = gpu.profileQuery(kid)
                 if cnt:

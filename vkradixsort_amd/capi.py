@@ -30,6 +30,7 @@ VRS_KEYS_SORTABLE_TO_FLOAT32 = 2
 
 VRS_TUNE_XCD_REMAP = 0
 VRS_TUNE_SCATTER_VARIANT = 1
+VRS_TUNE_FUSED_PREFIX = 2
 VRS_TUNE_RANK_MODE = 3
 
 

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -23,6 +24,7 @@ struct vrs_context_t {
     uint32_t scratch_chunks = 0;      // capacity of scratch.chunk_sums in chunks
     uint32_t last_offsets_workgroups = 0;
     bool xcd_remap = true;
+    bool fused_prefix = true;
     vrs::ScatterLaunch scatter;
     bool atomic_rank_verified = false;  // device self-test result (context creation)
     vrs_buffer sort_hist = nullptr;     // histogram table owned by the one-call entry points
@@ -78,12 +80,21 @@ int ensure_scratch(vrs_context ctx, uint32_t W) {
     }
     if (G > ctx->scratch_chunks) {
         if (ctx->scratch.chunk_sums) VRS_HIP(ctx, hipFree(ctx->scratch.chunk_sums));
+        if (ctx->scratch.granules) VRS_HIP(ctx, hipFree(ctx->scratch.granules));
         ctx->scratch.chunk_sums = nullptr;
+        ctx->scratch.granules = nullptr;
         ctx->scratch_chunks = 0;
         VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->scratch.chunk_sums),
                                static_cast<size_t>(G) * VRS_RADIX_SORT_BINS * sizeof(uint32_t)));
+        const size_t gbytes = static_cast<size_t>(G) * VRS_RADIX_SORT_BINS * sizeof(unsigned long long);
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->scratch.granules), gbytes));
+        VRS_HIP(ctx, hipMemsetAsync(ctx->scratch.granules, 0, gbytes, ctx->stream));  // tag 0 == never published
         ctx->scratch_chunks = G;
     }
+    // the fused single-launch prefix needs all G chunk workgroups resident at once
+    ctx->scratch.fused_max_chunks =
+        ctx->fused_prefix ? std::min<uint32_t>(ctx->scratch_chunks, static_cast<uint32_t>(ctx->scatter.compute_units)) : 0u;
+    if (++ctx->scratch.epoch == 0) ctx->scratch.epoch = 1;
     return VRS_OK;
 }
 
@@ -269,6 +280,7 @@ int vrs_context_destroy(vrs_context ctx) {
     if (ctx->sort_hist) (void)vrs_buffer_release(ctx->sort_hist);
     if (ctx->scratch.offsets) (void)hipFree(ctx->scratch.offsets);
     if (ctx->scratch.chunk_sums) (void)hipFree(ctx->scratch.chunk_sums);
+    if (ctx->scratch.granules) (void)hipFree(ctx->scratch.granules);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VRS_OK;
@@ -571,6 +583,9 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             return VRS_OK;
         case VRS_TUNE_SCATTER_VARIANT:
             ctx->scatter.variant = value;
+            return VRS_OK;
+        case VRS_TUNE_FUSED_PREFIX:
+            ctx->fused_prefix = value != 0;
             return VRS_OK;
         case VRS_TUNE_RANK_MODE: {
             if (value == 1) {

@@ -10,6 +10,10 @@ namespace vrs {
 struct PrefixScratch {
     uint32_t *offsets = nullptr;
     uint32_t *chunk_sums = nullptr;
+    // fused single-launch prefix: [G][256] {epoch, value} granules, zero-initialised; nullptr = two-launch form
+    unsigned long long *granules = nullptr;
+    uint32_t fused_max_chunks = 0;  // largest G the fused form may be used for (<= compute units, <= allocation)
+    uint32_t epoch = 0;             // bumped by the caller before every launch_prefix; never 0 when used
 };
 
 // Optional timing events attached to a launch's own dispatch packet (no extra barrier packets).
