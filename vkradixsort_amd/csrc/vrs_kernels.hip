@@ -174,19 +174,26 @@ __global__ __launch_bounds__(kThreads) void histogram_kernel(const uint32_t *__r
 constexpr int kPrefixThreads = 1024;
 constexpr int kPrefixGroups = kPrefixThreads / kBins;
 
-// sum of rows [r0, r0 + cnt) step `stride` of a [rows][256] table, column d; 8 loads in flight
+// sum of rows r0, r0+stride, ... < r1 of a [rows][256] table, column d; kDepth independent loads in flight
+constexpr int kDepth = 16;
 __device__ __forceinline__ uint32_t column_sum(const uint32_t *__restrict__ p, uint32_t r0, uint32_t r1,
                                                uint32_t stride) {
     uint32_t s = 0;
     uint32_t r = r0;
-    for (; r + 7u * stride < r1; r += 8u * stride) {
-        uint32_t t[8];
+    for (; r + (kDepth - 1) * stride < r1; r += kDepth * stride) {
+        uint32_t t[kDepth];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p[static_cast<size_t>(r + u * stride) * kBins];
+        for (int u = 0; u < kDepth; ++u) t[u] = p[static_cast<size_t>(r + u * stride) * kBins];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += t[u];
+        for (int u = 0; u < kDepth; ++u) s += t[u];
     }
-    for (; r < r1; r += stride) s += p[static_cast<size_t>(r) * kBins];
+    if (r < r1) {  // remainder: still one batch of predicated independent loads
+        uint32_t t[kDepth];
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) t[u] = (r + u * stride < r1) ? p[static_cast<size_t>(r + u * stride) * kBins] : 0u;
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) s += t[u];
+    }
     return s;
 }
 
@@ -258,20 +265,15 @@ __global__ __launch_bounds__(kPrefixThreads) void offsets_kernel(const uint32_t 
     uint32_t run = s_base[d];
     for (uint32_t k = 0; k < grp; ++k) run += s_quarter[k][d];
     uint32_t *o = offsets + static_cast<size_t>(row0) * kBins + d;
-    uint32_t r = q0;
-    for (; r + 8 <= q1; r += 8) {
-        uint32_t t[8];
+    for (uint32_t r = q0; r < q1; r += kDepth) {
+        uint32_t t[kDepth];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p[static_cast<size_t>(r + u) * kBins];
+        for (int u = 0; u < kDepth; ++u) t[u] = (r + u < q1) ? p[static_cast<size_t>(r + u) * kBins] : 0u;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            o[static_cast<size_t>(r + u) * kBins] = run;
+        for (int u = 0; u < kDepth; ++u) {
+            if (r + u < q1) o[static_cast<size_t>(r + u) * kBins] = run;
             run += t[u];
         }
-    }
-    for (; r < q1; ++r) {
-        o[static_cast<size_t>(r) * kBins] = run;
-        run += p[static_cast<size_t>(r) * kBins];
     }
 }
 
@@ -364,20 +366,15 @@ __global__ __launch_bounds__(kPrefixThreads) void prefix_fused_kernel(const uint
     uint32_t run = s_base[d];
     for (uint32_t k = 0; k < grp; ++k) run += s_quarter[k][d];
     uint32_t *o = offsets + static_cast<size_t>(row0) * kBins + d;
-    uint32_t r = q0;
-    for (; r + 8 <= q1; r += 8) {
-        uint32_t t[8];
+    for (uint32_t r = q0; r < q1; r += kDepth) {
+        uint32_t t[kDepth];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p[static_cast<size_t>(r + u) * kBins];
+        for (int u = 0; u < kDepth; ++u) t[u] = (r + u < q1) ? p[static_cast<size_t>(r + u) * kBins] : 0u;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            o[static_cast<size_t>(r + u) * kBins] = run;
+        for (int u = 0; u < kDepth; ++u) {
+            if (r + u < q1) o[static_cast<size_t>(r + u) * kBins] = run;
             run += t[u];
         }
-    }
-    for (; r < q1; ++r) {
-        o[static_cast<size_t>(r) * kBins] = run;
-        run += p[static_cast<size_t>(r) * kBins];
     }
 }
 
