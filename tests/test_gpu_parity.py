@@ -456,3 +456,50 @@ def test_one_call_sort_entry_points(gpu_context, oracle, n):
     assert np.array_equal(out, rk) and np.array_equal(ov, rv)
     for b in (k0, k1, v0, v1):
         b.release()
+
+
+@pytest.mark.parametrize("n,B", [(300007, 64), (300007, 32), (300007, 8), (1 << 20, 256), (50001, 4096), (9000, 1)])
+def test_sort_stage_accepts_a_caller_filled_histogram_table(gpu_context, oracle, n, B):
+    """The RADIX_SORT stage consumes only the [W][256] buffer (multi_radixsort.comp:56-63): a caller may fill it
+    without ever running the histogram stage here -- the sub-tile shortcut for large B must not be assumed."""
+    ctx, lib = gpu_context, gpu_context.lib
+    keys = rand_keys(n, n + B)
+    W = oracle.workgroup_count(n, B)
+    for shift in (0, 16):
+        ohist = oracle.histograms(keys, shift, W, B)
+        b0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)
+        b1 = vrs.Buffer(ctx, S(4 * n))
+        h = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(W * 1024), ohist)
+        pc = vrs.PushConstants(n, shift, W, B)
+        ctx.check(lib.vrs_multi_radixsort(ctx.handle, b0.handle, b1.handle, h.handle, ctypes.byref(pc)))
+        out = np.empty(n, np.uint32)
+        b1.downloadWithStagingBuffer(out)
+        assert np.array_equal(out, oracle.scatter(keys, ohist, shift, W, B)), (n, B, shift)
+        # and a histogram stage for OTHER keys in between must not leak its cached sub-tile table
+        other = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys[::-1].copy())
+        h2 = vrs.Buffer(ctx, S(W * 1024))
+        ctx.check(lib.vrs_multi_radixsort_histograms(ctx.handle, other.handle, h2.handle, ctypes.byref(pc)))
+        ctx.check(lib.vrs_multi_radixsort(ctx.handle, b0.handle, b1.handle, h.handle, ctypes.byref(pc)))
+        b1.downloadWithStagingBuffer(out)
+        assert np.array_equal(out, oracle.scatter(keys, ohist, shift, W, B)), (n, B, shift, "after foreign histogram stage")
+        for b in (b0, b1, h, other, h2):
+            b.release()
+
+
+@pytest.mark.parametrize("B", [1, 2, 4, 8, 16, 64, 128, 512, 4096, 16384])
+def test_every_block_count_of_the_reference_sweeps(gpu_context, oracle, B):
+    """NUM_BLOCKS_PER_WORKGROUP values of the reference's timing plots (README.md:253-265): tables and outputs per stage."""
+    n = 700001
+    keys = rand_keys(n, B)
+    r = StageRunner(gpu_context, keys, B)
+    try:
+        cur = keys
+        for i in range(4):
+            hist, offsets, out = r.run_pass(i)
+            ohist = oracle.histograms(cur, 8 * i, r.W, B)
+            assert np.array_equal(hist, ohist), f"histogram table, pass {i}"
+            assert np.array_equal(offsets, oracle.offsets(ohist, r.W)), f"offset table, pass {i}"
+            cur = oracle.scatter(cur, ohist, 8 * i, r.W, B)
+            assert np.array_equal(out, cur), f"scatter output, pass {i}"
+    finally:
+        r.close()

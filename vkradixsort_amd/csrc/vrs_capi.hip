@@ -22,7 +22,17 @@ struct vrs_context_t {
     vrs::PrefixScratch scratch;
     uint32_t scratch_workgroups = 0;  // capacity of scratch.offsets in workgroups
     uint32_t scratch_chunks = 0;      // capacity of scratch.chunk_sums in chunks
-    uint32_t last_offsets_workgroups = 0;
+    uint32_t last_offsets_workgroups = 0;  // contract workgroups of the most recent RADIX_SORT stage
+    uint32_t last_offsets_stride = 1;      // rows of scratch.offsets per contract workgroup (sub-tiled launches)
+    // NUM_BLOCKS_PER_WORKGROUP > 32: the histogram stage also keeps the 8192-key sub-tile table it folded the
+    // caller's table from; the sort stage uses it iff it is called for exactly the same (keys, N, shift, B)
+    uint32_t *sub_hist = nullptr;
+    uint32_t sub_hist_rows = 0;
+    struct {
+        const void *keys = nullptr;
+        uint32_t n = 0, shift = 0, blocks = 0;
+        bool valid = false;
+    } sub_cache;
     bool xcd_remap = true;
     bool fused_prefix = true;
     vrs::ScatterLaunch scatter;
@@ -45,6 +55,8 @@ struct vrs_buffer_t {
 };
 
 namespace {
+
+constexpr uint32_t kLaunchTileBlocks = 32;  // the kernels' own tile: 32 blocks x 256 = 8192 keys
 
 thread_local std::string g_global_error;
 
@@ -226,20 +238,44 @@ int run_sort_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs
             return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "values_in and values_out alias");
     }
     VRS_HIP(ctx, hipSetDevice(ctx->device));
-    if ((rc = ensure_scratch(ctx, W))) return rc;
+    const uint32_t B = pc->g_num_blocks_per_workgroup;
+    const uint32_t *table = static_cast<const uint32_t *>(histograms->ptr);
+    uint32_t launch_W = W, launch_B = B, row_stride = 1, rows_per_contract_tile = 1;
+    if (B > kLaunchTileBlocks && B % kLaunchTileBlocks == 0 && ctx->sub_cache.valid &&
+        ctx->sub_cache.keys == keys_in->ptr && ctx->sub_cache.n == n && ctx->sub_cache.shift == pc->g_shift &&
+        ctx->sub_cache.blocks == B) {
+        // large contract tiles: prefix + scatter at 8192-key sub-tile granularity from the table the histogram
+        // stage kept (the caller's table is its fold, so both describe the same keys)
+        launch_B = kLaunchTileBlocks;
+        launch_W = vrs_workgroup_count(n, launch_B);
+        rows_per_contract_tile = B / kLaunchTileBlocks;
+        table = ctx->sub_hist;
+    } else if (B < kLaunchTileBlocks && kLaunchTileBlocks % B == 0 && W > 1) {
+        // small contract tiles: consecutive tiles are adjacent in every digit's output range, so the scatter
+        // walks 8192-key launch tiles and takes the offset row of the first contract tile inside each
+        row_stride = kLaunchTileBlocks / B;
+    }
+    ctx->sub_cache.valid = false;
+    const uint32_t prefix_rows = rows_per_contract_tile > 1 ? launch_W : W;
+    if ((rc = ensure_scratch(ctx, prefix_rows))) return rc;
 
     vrs::LaunchEvents ev;
     if ((rc = profile_events(ctx, VRS_KERNEL_PREFIX, &ev))) return rc;
-    VRS_HIP(ctx, vrs::launch_prefix(ctx->stream, static_cast<const uint32_t *>(histograms->ptr), ctx->scratch, W, ev));
+    VRS_HIP(ctx, vrs::launch_prefix(ctx->stream, table, ctx->scratch, prefix_rows, ev));
     ctx->last_offsets_workgroups = W;
+    ctx->last_offsets_stride = rows_per_contract_tile;
 
+    if (row_stride > 1) {
+        launch_B = kLaunchTileBlocks;
+        launch_W = vrs_workgroup_count(n, launch_B);
+    }
     if ((rc = profile_events(ctx, VRS_KERNEL_SCATTER, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_scatter(ctx->stream, static_cast<const uint32_t *>(keys_in->ptr),
                                      static_cast<uint32_t *>(keys_out->ptr),
                                      pairs ? static_cast<const uint32_t *>(values_in->ptr) : nullptr,
                                      pairs ? static_cast<uint32_t *>(values_out->ptr) : nullptr, ctx->scratch.offsets,
-                                     n, pc->g_shift, W, pc->g_num_blocks_per_workgroup, ctx->xcd_remap,
-                                     ctx->scatter, ev));
+                                     n, pc->g_shift, launch_W, launch_B, ctx->xcd_remap, ctx->scatter, ev, nullptr,
+                                     row_stride));
     return VRS_OK;
 }
 
@@ -281,6 +317,7 @@ int vrs_context_destroy(vrs_context ctx) {
     if (ctx->scratch.offsets) (void)hipFree(ctx->scratch.offsets);
     if (ctx->scratch.chunk_sums) (void)hipFree(ctx->scratch.chunk_sums);
     if (ctx->scratch.granules) (void)hipFree(ctx->scratch.granules);
+    if (ctx->sub_hist) (void)hipFree(ctx->sub_hist);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VRS_OK;
@@ -412,9 +449,35 @@ int vrs_multi_radixsort_histograms(vrs_context ctx, vrs_buffer keys_in, vrs_buff
     VRS_HIP(ctx, hipSetDevice(ctx->device));
     vrs::LaunchEvents ev;
     if ((rc = profile_events(ctx, VRS_KERNEL_HISTOGRAM, &ev))) return rc;
+    const uint32_t B = pc->g_num_blocks_per_workgroup, n = pc->g_num_elements;
+    ctx->sub_cache.valid = false;
+    if (B > kLaunchTileBlocks && B % kLaunchTileBlocks == 0) {
+        // contract tile = S sub-tiles of 8192 keys: histogram the sub-tiles (enough workgroups to fill the chip
+        // whatever B is), then fold them into the caller's [W][256] table
+        const uint32_t S = B / kLaunchTileBlocks;
+        const uint32_t sub_rows = vrs_workgroup_count(n, kLaunchTileBlocks);
+        if (sub_rows > ctx->sub_hist_rows) {
+            if (ctx->sub_hist) VRS_HIP(ctx, hipFree(ctx->sub_hist));
+            ctx->sub_hist = nullptr;
+            ctx->sub_hist_rows = 0;
+            VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sub_hist),
+                                   static_cast<size_t>(sub_rows) * VRS_RADIX_SORT_BINS * sizeof(uint32_t)));
+            ctx->sub_hist_rows = sub_rows;
+        }
+        VRS_HIP(ctx, vrs::launch_histograms(ctx->stream, static_cast<const uint32_t *>(keys_in->ptr), ctx->sub_hist, n,
+                                            pc->g_shift, sub_rows, kLaunchTileBlocks, vrs::LaunchEvents{ev.start, nullptr}));
+        VRS_HIP(ctx, vrs::launch_fold_histograms(ctx->stream, ctx->sub_hist, static_cast<uint32_t *>(histograms->ptr),
+                                                 sub_rows, pc->g_num_workgroups, S, vrs::LaunchEvents{nullptr, ev.stop}));
+        ctx->sub_cache.keys = keys_in->ptr;
+        ctx->sub_cache.n = n;
+        ctx->sub_cache.shift = pc->g_shift;
+        ctx->sub_cache.blocks = B;
+        ctx->sub_cache.valid = true;
+        return VRS_OK;
+    }
     VRS_HIP(ctx, vrs::launch_histograms(ctx->stream, static_cast<const uint32_t *>(keys_in->ptr),
-                                        static_cast<uint32_t *>(histograms->ptr), pc->g_num_elements, pc->g_shift,
-                                        pc->g_num_workgroups, pc->g_num_blocks_per_workgroup, ev));
+                                        static_cast<uint32_t *>(histograms->ptr), n, pc->g_shift,
+                                        pc->g_num_workgroups, B, ev));
     return VRS_OK;
 }
 
@@ -558,11 +621,14 @@ int vrs_multi_radixsort_digit_offsets(vrs_context ctx, void *host_u32x256) {
 
 int vrs_debug_download_offsets(vrs_context ctx, void *host_data, size_t size_bytes) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
-    const size_t have = static_cast<size_t>(ctx->last_offsets_workgroups) * VRS_RADIX_SORT_BINS * sizeof(uint32_t);
-    if (!host_data || size_bytes > have)
+    const size_t row = VRS_RADIX_SORT_BINS * sizeof(uint32_t);
+    const size_t have = static_cast<size_t>(ctx->last_offsets_workgroups) * row;
+    if (!host_data || size_bytes > have || size_bytes % row != 0)
         return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "offset table is smaller than the requested size");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
-    VRS_HIP(ctx, hipMemcpyAsync(host_data, ctx->scratch.offsets, size_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    // sub-tiled launches keep one row per 8192-key sub-tile: the contract tile's row is its first sub-tile's
+    VRS_HIP(ctx, hipMemcpy2DAsync(host_data, row, ctx->scratch.offsets, row * ctx->last_offsets_stride, row,
+                                  size_bytes / row, hipMemcpyDeviceToHost, ctx->stream));
     VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VRS_OK;
 }

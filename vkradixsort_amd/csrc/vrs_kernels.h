@@ -44,7 +44,11 @@ hipError_t launch_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t 
                           const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets,
                           uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap,
                           const ScatterLaunch &cfg, LaunchEvents ev = {},
-                          const uint32_t *tile_order = nullptr);
+                          const uint32_t *tile_order = nullptr, uint32_t offset_row_stride = 1);
+
+// hist[w][d] = sum of sub rows [w*S, (w+1)*S): contract table from the 8192-key sub-tile table
+hipError_t launch_fold_histograms(hipStream_t stream, const uint32_t *sub, uint32_t *hist, uint32_t sub_rows,
+                                  uint32_t W, uint32_t S, LaunchEvents ev = {});
 
 hipError_t launch_atomic_rank_selftest(hipStream_t stream, uint32_t rounds, uint32_t seed,
                                        unsigned long long *mismatches);

@@ -588,7 +588,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const uint32_t
                                                              uint32_t *__restrict__ values_out,
                                                              const uint32_t *__restrict__ offsets, uint32_t n,
                                                              uint32_t shift, uint32_t W, uint32_t B, int xcd_remap,
-                                                             const uint32_t *__restrict__ tile_order) {
+                                                             const uint32_t *__restrict__ tile_order,
+                                                             uint32_t offset_row_stride) {
     __shared__ ChunkSmem<ITEMS, WAVES, PAIRS> sm;
     const uint32_t w = tile_order ? tile_order[blockIdx.x]
                                   : (xcd_remap ? xcd_contiguous_tile(blockIdx.x, W) : blockIdx.x);
@@ -596,7 +597,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const uint32_t
     if (tile_begin >= n) return;  // uniform per workgroup
     const uint64_t tile_keys = static_cast<uint64_t>(B) * kThreads;
     const uint32_t tile_len = static_cast<uint32_t>(tile_begin + tile_keys <= n ? tile_keys : n - tile_begin);
-    uint32_t run_off = threadIdx.x < kBins ? offsets[static_cast<size_t>(w) * kBins + threadIdx.x] : 0u;
+    // consecutive contract tiles are adjacent in every digit's output range (offset[t+1][d] = offset[t][d] +
+    // hist[t][d]), so a launch tile made of `offset_row_stride` contract tiles needs only the first one's row
+    uint32_t run_off =
+        threadIdx.x < kBins ? offsets[static_cast<size_t>(w) * offset_row_stride * kBins + threadIdx.x] : 0u;
     constexpr uint32_t kChunk = ITEMS * WAVES * 64;
     for (uint32_t c0 = 0; c0 < tile_len; c0 += kChunk) {
         const uint32_t valid = min(kChunk, tile_len - c0);
@@ -687,6 +691,19 @@ __global__ __launch_bounds__(kThreads) void single_kernel(uint32_t *buffer0, uin
 }
 
 // ---------------------------------------------------------------------------------------------
+// Contract tiles larger than the 8192-key launch tile (NUM_BLOCKS_PER_WORKGROUP = 64 ... 4096, what the
+// reference's own sweeps favour) are histogrammed and scattered as 8192-key sub-tiles; the caller-visible
+// [W][256] table is the fold of the sub-tile table:  hist[w][d] = sum_s sub[w*S + s][d].
+__global__ __launch_bounds__(kThreads) void fold_histograms_kernel(const uint32_t *__restrict__ sub,
+                                                                   uint32_t *__restrict__ hist, uint32_t sub_rows,
+                                                                   uint32_t S) {
+    const uint32_t d = threadIdx.x;
+    const uint32_t r0 = blockIdx.x * S;
+    const uint32_t r1 = min(r0 + S, sub_rows);
+    hist[static_cast<size_t>(blockIdx.x) * kBins + d] = column_sum(sub + static_cast<size_t>(r0) * kBins + d, 0, r1 - r0, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Key preprocessing the reference leaves to the integrator ("you have to preprocess negative numbers",
 // README.md:154-155): order-preserving bijections between int32 / float32 bit patterns and the uint32
 // keys the sort orders.  In place, 16 bytes per lane, grid-stride.
@@ -716,6 +733,13 @@ __global__ __launch_bounds__(kThreads) void transform_keys_kernel(uint32_t *keys
 
 // ---------------------------------------------------------------------------------------------
 // host-side launch wrappers
+
+hipError_t launch_fold_histograms(hipStream_t stream, const uint32_t *sub, uint32_t *hist, uint32_t sub_rows,
+                                  uint32_t W, uint32_t S, LaunchEvents ev) {
+    if (W == 0) return hipSuccess;
+    VRS_LAUNCH(fold_histograms_kernel, dim3(W), dim3(kThreads), stream, ev, sub, hist, sub_rows, S);
+    return hipGetLastError();
+}
 
 hipError_t launch_transform_keys(hipStream_t stream, uint32_t *keys, uint32_t n, int mode) {
     if (n == 0) return hipSuccess;
@@ -759,23 +783,24 @@ template <int ITEMS, int WAVES, int RANK, int OCC>
 static hipError_t launch_scatter_variant(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
                                          const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets,
                                          uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap,
-                                         LaunchEvents ev, const uint32_t *tile_order) {
+                                         LaunchEvents ev, const uint32_t *tile_order, uint32_t offset_row_stride) {
     const int remap = xcd_remap ? 1 : 0;
     if (values_in != nullptr)
         VRS_LAUNCH((scatter_kernel<ITEMS, WAVES, true, RANK, OCC>), dim3(W), dim3(WAVES * 64), stream, ev, keys_in,
-                   keys_out, values_in, values_out, offsets, n, shift, W, B, remap, tile_order);
+                   keys_out, values_in, values_out, offsets, n, shift, W, B, remap, tile_order, offset_row_stride);
     else
         VRS_LAUNCH((scatter_kernel<ITEMS, WAVES, false, RANK, OCC>), dim3(W), dim3(WAVES * 64), stream, ev, keys_in,
-                   keys_out, values_in, values_out, offsets, n, shift, W, B, remap, tile_order);
+                   keys_out, values_in, values_out, offsets, n, shift, W, B, remap, tile_order, offset_row_stride);
     return hipGetLastError();
 }
 
-#define VRS_SCATTER_ARGS stream, keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap, ev, tile_order
+#define VRS_SCATTER_ARGS \
+    stream, keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap, ev, tile_order, offset_row_stride
 
 hipError_t launch_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
                           const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets, uint32_t n,
                           uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap, const ScatterLaunch &cfg,
-                          LaunchEvents ev, const uint32_t *tile_order) {
+                          LaunchEvents ev, const uint32_t *tile_order, uint32_t offset_row_stride) {
     if (W == 0) return hipSuccess;
     // chunk = ITEMS*WAVES*64 keys held in registers + LDS at once; a tile of B blocks is walked in
     // ceil(B*256/chunk) chunks.  cfg.variant (tuning only) = OCC*100000 + ITEMS*1000 + WAVES*10 + RANK
