@@ -126,6 +126,19 @@ int vrs_multi_radixsort_pairs(vrs_context ctx, vrs_buffer keys_in, vrs_buffer ke
  * extension) to cut the locally grouped shard into per-rank slices.
  */
 int vrs_multi_radixsort_digit_offsets(vrs_context ctx, void *host_u32x256);
+/*
+ * 64-bit keys: the reference's SORT_64_BIT switch (MultiRadixSort.h:10-18; NUM_ITERATIONS = 8,
+ * MultiRadixSort.cpp:51-55), which it leaves as a stub ("requires changes in the two shaders").  Same two
+ * stages, same [W][256] table and push constants; keys are uint64, g_shift is 0, 8, ..., 56, the caller runs
+ * eight passes (even count: the result is in buffer 0 again).  Payloads of the pairs form stay uint32.
+ */
+int vrs_multi_radixsort_histograms_u64(vrs_context ctx, vrs_buffer keys_in, vrs_buffer histograms,
+                                       const vrs_push_constants *pc);
+int vrs_multi_radixsort_u64(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out,
+                            vrs_buffer histograms, const vrs_push_constants *pc);
+int vrs_multi_radixsort_pairs_u64(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out,
+                                  vrs_buffer values_in, vrs_buffer values_out, vrs_buffer histograms,
+                                  const vrs_push_constants *pc);
 /* vkQueueWaitIdle on the compute queue (MultiRadixSort.cpp:62). */
 int vrs_queue_wait_idle(vrs_context ctx);
 
@@ -145,6 +158,7 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
 int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements);
 int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
                        vrs_buffer values_tmp, uint32_t num_elements);
+int vrs_sort_keys_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements); /* 8 passes */
 
 /*
  * Key preprocessing the reference leaves to the integrator ("you have to preprocess negative numbers",

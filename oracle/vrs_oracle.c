@@ -249,3 +249,55 @@ void vrs_oracle_mt19937_fill(uint32_t seed, uint32_t *out, uint64_t n, uint32_t 
         out[k] = y >> top_bits_zeroed;
     }
 }
+
+/*
+ * 64-bit keys: the reference's SORT_64_BIT stub (MultiRadixSort.h:10-18, NUM_ITERATIONS = 8 at
+ * MultiRadixSort.cpp:51-55; its generator draws uniform_int_distribution<uint64_t>(0, 0x0FFFFFFFFFFF), :128).
+ * The shaders were never adapted ("requires changes in the two shaders"), so these restatements apply the
+ * SAME stage definitions as above to uint64 keys and shifts 0..56 -- parity unpinned by any reference run,
+ * end-to-end pinned to std::sort of the same uint64 input.
+ */
+void vrs_oracle_histograms_u64(const uint64_t *keys_in, uint32_t *hist, uint32_t num_elements, uint32_t shift,
+                               uint32_t num_workgroups, uint32_t blocks_per_workgroup) {
+    for (uint32_t w = 0; w < num_workgroups; ++w) {
+        uint32_t *h = hist + (size_t)VRS_RADIX_SORT_BINS * w;
+        memset(h, 0, VRS_RADIX_SORT_BINS * sizeof(uint32_t));
+        uint64_t begin = (uint64_t)w * blocks_per_workgroup * VRS_WORKGROUP_SIZE;
+        uint64_t end = begin + (uint64_t)blocks_per_workgroup * VRS_WORKGROUP_SIZE;
+        if (end > num_elements) end = num_elements;
+        for (uint64_t e = begin; e < end; ++e) h[(keys_in[e] >> shift) & 255u] += 1u;
+    }
+}
+
+void vrs_oracle_scatter_u64(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *values_in,
+                            uint32_t *values_out, const uint32_t *hist, uint32_t num_elements, uint32_t shift,
+                            uint32_t num_workgroups, uint32_t blocks_per_workgroup) {
+    uint32_t *offsets = (uint32_t *)malloc((size_t)num_workgroups * VRS_RADIX_SORT_BINS * sizeof(uint32_t));
+    vrs_oracle_offsets(hist, offsets, num_workgroups);
+    for (uint32_t w = 0; w < num_workgroups; ++w) {
+        uint32_t *global_offsets = offsets + (size_t)VRS_RADIX_SORT_BINS * w;
+        uint64_t begin = (uint64_t)w * blocks_per_workgroup * VRS_WORKGROUP_SIZE;
+        uint64_t end = begin + (uint64_t)blocks_per_workgroup * VRS_WORKGROUP_SIZE;
+        if (end > num_elements) end = num_elements;
+        /* blocks of 256 in order, threads in order: the running offset per bin is the stable rank */
+        for (uint64_t e = begin; e < end; ++e) {
+            uint32_t bin = (uint32_t)(keys_in[e] >> shift) & 255u;
+            uint32_t dst = global_offsets[bin]++;
+            keys_out[dst] = keys_in[e];
+            if (values_in) values_out[dst] = values_in[e];
+        }
+    }
+    free(offsets);
+}
+
+void vrs_oracle_multi_radixsort_u64(uint64_t *kbuf0, uint64_t *kbuf1, uint32_t *vbuf0, uint32_t *vbuf1, uint32_t *hist,
+                                    uint32_t num_elements, uint32_t blocks_per_workgroup) {
+    uint32_t W = vrs_oracle_workgroup_count(num_elements, blocks_per_workgroup);
+    for (uint32_t i = 0; i < 8u; ++i) { /* NUM_ITERATIONS = 8, MultiRadixSort.cpp:54 */
+        uint64_t *kin = (i % 2u == 0u) ? kbuf0 : kbuf1, *kout = (i % 2u == 0u) ? kbuf1 : kbuf0;
+        uint32_t *vin = vbuf0 ? ((i % 2u == 0u) ? vbuf0 : vbuf1) : NULL;
+        uint32_t *vout = vbuf0 ? ((i % 2u == 0u) ? vbuf1 : vbuf0) : NULL;
+        vrs_oracle_histograms_u64(kin, hist, num_elements, 8u * i, W, blocks_per_workgroup);
+        vrs_oracle_scatter_u64(kin, kout, vin, vout, hist, num_elements, 8u * i, W, blocks_per_workgroup);
+    }
+}

@@ -104,3 +104,16 @@ int vrs_cpu_model(char *out, uint32_t cap) {
 }
 
 }  // extern "C"
+
+extern "C" {
+// 64-bit flavour of the same verification path (SORT_TYPE uint64_t)
+double vrs_stdsort_u64(uint64_t *data, uint64_t n) {
+    std::vector<uint64_t> buffer(data, data + n);
+    auto begin = std::chrono::steady_clock::now();
+    std::sort(buffer.begin(), buffer.end());
+    auto end = std::chrono::steady_clock::now();
+    std::memcpy(data, buffer.data(), n * sizeof(uint64_t));
+    return static_cast<double>(std::chrono::duration_cast<std::chrono::microseconds>(end - begin).count()) *
+           std::pow(10, -3);
+}
+}

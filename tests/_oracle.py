@@ -4,6 +4,8 @@ from __future__ import annotations
 import ctypes
 import subprocess
 from ctypes import POINTER, c_char_p, c_double, c_int64, c_uint32, c_uint64, c_void_p
+
+u64p = POINTER(c_uint64)
 from pathlib import Path
 
 import numpy as np
@@ -48,6 +50,14 @@ class Oracle:
         L.vrs_stable_sort_pairs_u32.argtypes = [u32p, u32p, c_uint64]
         L.vrs_test_sort.restype = c_int64
         L.vrs_test_sort.argtypes = [u32p, c_uint64, u32p, c_uint64]
+        L.vrs_oracle_histograms_u64.restype = None
+        L.vrs_oracle_histograms_u64.argtypes = [u64p, u32p, c_uint32, c_uint32, c_uint32, c_uint32]
+        L.vrs_oracle_scatter_u64.restype = None
+        L.vrs_oracle_scatter_u64.argtypes = [u64p, u64p, u32p, u32p, u32p, c_uint32, c_uint32, c_uint32, c_uint32]
+        L.vrs_oracle_multi_radixsort_u64.restype = None
+        L.vrs_oracle_multi_radixsort_u64.argtypes = [u64p, u64p, u32p, u32p, u32p, c_uint32, c_uint32]
+        L.vrs_stdsort_u64.restype = c_double
+        L.vrs_stdsort_u64.argtypes = [u64p, c_uint64]
         L.vrs_hardware_concurrency.restype = c_uint32
         L.vrs_cpu_model.argtypes = [c_char_p, c_uint32]
 
@@ -95,6 +105,34 @@ class Oracle:
         b1 = np.zeros_like(b0)
         self.lib.vrs_oracle_single_radixsort(_p(b0), _p(b1), keys.size)
         return b0
+
+    # ---- 64-bit keys
+    def histograms_u64(self, keys, shift, W, B):
+        hist = np.empty(W * 256, dtype=np.uint32)
+        self.lib.vrs_oracle_histograms_u64(keys.ctypes.data_as(u64p), _p(hist), keys.size, shift, W, B)
+        return hist
+
+    def scatter_u64(self, keys, hist, shift, W, B, values=None):
+        out = np.zeros_like(keys)
+        vout = None if values is None else np.zeros_like(values)
+        self.lib.vrs_oracle_scatter_u64(keys.ctypes.data_as(u64p), out.ctypes.data_as(u64p), _p(values), _p(vout), _p(hist),
+                                        keys.size, shift, W, B)
+        return out if values is None else (out, vout)
+
+    def multi_radixsort_u64(self, keys, B, values=None):
+        n = keys.size
+        W = self.workgroup_count(n, B) if n else 0
+        b0, b1 = keys.copy(), np.zeros_like(keys)
+        hist = np.zeros(max(W, 1) * 256, dtype=np.uint32)
+        v0 = None if values is None else values.copy()
+        v1 = None if values is None else np.zeros_like(values)
+        self.lib.vrs_oracle_multi_radixsort_u64(b0.ctypes.data_as(u64p), b1.ctypes.data_as(u64p), _p(v0), _p(v1), _p(hist), n, B)
+        return b0 if values is None else (b0, v0)
+
+    def std_sort_u64(self, keys):
+        out = keys.copy()
+        ms = self.lib.vrs_stdsort_u64(out.ctypes.data_as(u64p), out.size)
+        return out, ms
 
     def std_sort(self, keys):
         """the reference's verification path: returns (sorted copy, milliseconds)"""

@@ -503,3 +503,94 @@ def test_every_block_count_of_the_reference_sweeps(gpu_context, oracle, B):
             assert np.array_equal(out, cur), f"scatter output, pass {i}"
     finally:
         r.close()
+
+
+def rand_keys_u64(n, seed):
+    rs = np.random.RandomState(seed)
+    return (rs.randint(0, 2 ** 32, n, dtype=np.uint64) << np.uint64(32)) | rs.randint(0, 2 ** 32, n, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("n,B", [(1, 1), (255, 1), (4097, 16), (100003, 7), (300007, 32), (700001, 64), (50001, 4096), (123457, 8)])
+def test_u64_every_stage_matches_oracle(gpu_context, oracle, n, B):
+    """SORT_64_BIT (MultiRadixSort.h:10-18): eight passes, shifts 0..56, same [W][256] table and push constants."""
+    ctx, lib = gpu_context, gpu_context.lib
+    keys = rand_keys_u64(n, n + B)
+    if n > 1000:
+        keys[:500] &= np.uint64(0x0FFFFFFFFFFF)  # some keys in the reference's own 44-bit range
+    W = oracle.workgroup_count(n, B)
+    b = [vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(8 * n), keys), vrs.Buffer(ctx, S(8 * n))]
+    h = vrs.Buffer(ctx, S(W * 1024))
+    cur = keys
+    for i in range(8):
+        pc = vrs.PushConstants(n, 8 * i, W, B)
+        ctx.check(lib.vrs_multi_radixsort_histograms_u64(ctx.handle, b[i % 2].handle, h.handle, ctypes.byref(pc)))
+        ctx.check(lib.vrs_multi_radixsort_u64(ctx.handle, b[i % 2].handle, b[(i + 1) % 2].handle, h.handle, ctypes.byref(pc)))
+        hist = np.empty(W * 256, np.uint32)
+        h.downloadWithStagingBuffer(hist)
+        out = np.empty(n, np.uint64)
+        b[(i + 1) % 2].downloadWithStagingBuffer(out)
+        ohist = oracle.histograms_u64(cur, 8 * i, W, B)
+        assert np.array_equal(hist, ohist), f"histogram table, pass {i}"
+        cur = oracle.scatter_u64(cur, ohist, 8 * i, W, B)
+        assert np.array_equal(out, cur), f"scatter output, pass {i}"
+    ref, _ = oracle.std_sort_u64(keys)
+    final = np.empty(n, np.uint64)
+    b[0].downloadWithStagingBuffer(final)  # eight passes: back in buffer 0
+    assert np.array_equal(final, ref)
+    bad = vrs.PushConstants(n, 64, W, B)
+    assert lib.vrs_multi_radixsort_histograms_u64(ctx.handle, b[0].handle, h.handle, ctypes.byref(bad)) == capi.VRS_ERROR_INVALID_ARGUMENT
+    for x in b + [h]:
+        x.release()
+
+
+@pytest.mark.parametrize("n", [1, 1000, 1000003, 5000000])
+def test_u64_one_call_sort_and_pairs(gpu_context, oracle, n):
+    ctx, lib = gpu_context, gpu_context.lib
+    keys = rand_keys_u64(n, n)
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(8 * n), keys)
+    k1 = vrs.Buffer(ctx, S(8 * n))
+    ctx.check(lib.vrs_sort_keys_u64(ctx.handle, k0.handle, k1.handle, n))
+    out = np.empty(n, np.uint64)
+    k0.downloadWithStagingBuffer(out)
+    assert np.array_equal(out, oracle.std_sort_u64(keys)[0])
+    # pairs: uint64 keys with many duplicates + uint32 payloads, stable
+    dup = keys & np.uint64(0x00FF0000FF0000FF)
+    vals = np.arange(n, dtype=np.uint32)
+    B = 16
+    W = oracle.workgroup_count(n, B)
+    kb = [vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(8 * n), dup), vrs.Buffer(ctx, S(8 * n))]
+    vb = [vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals), vrs.Buffer(ctx, S(4 * n))]
+    h = vrs.Buffer(ctx, S(W * 1024))
+    for i in range(8):
+        pc = vrs.PushConstants(n, 8 * i, W, B)
+        ctx.check(lib.vrs_multi_radixsort_histograms_u64(ctx.handle, kb[i % 2].handle, h.handle, ctypes.byref(pc)))
+        ctx.check(lib.vrs_multi_radixsort_pairs_u64(ctx.handle, kb[i % 2].handle, kb[(i + 1) % 2].handle, vb[i % 2].handle,
+                                                    vb[(i + 1) % 2].handle, h.handle, ctypes.byref(pc)))
+    ov = np.empty(n, np.uint32)
+    kb[0].downloadWithStagingBuffer(out)
+    vb[0].downloadWithStagingBuffer(ov)
+    order = np.argsort(dup, kind="stable")
+    assert np.array_equal(out, dup[order]) and np.array_equal(ov, vals[order])
+    for x in [k0, k1, h] + kb + vb:
+        x.release()
+
+
+def test_u64_through_the_host_mirrors(gpu_context, oracle):
+    """engine.MultiRadixSort with uint64 keys (SORT_64_BIT) and the C++ MultiRadixSort64 example."""
+    import subprocess
+    from vkradixsort_amd import build
+    n = 400003
+    keys = rand_keys_u64(n, 64)
+    m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=32, keys=keys, quiet=True)
+    m.execute(gpu_context)
+    assert m.sorted_keys.dtype == np.uint64 and np.array_equal(m.sorted_keys, oracle.std_sort_u64(keys)[0])
+    vals = np.arange(n, dtype=np.uint32)
+    dup = keys & np.uint64(0xFFFF)
+    m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=64, keys=dup, values=vals, quiet=True)
+    m.execute(gpu_context)
+    order = np.argsort(dup, kind="stable")
+    assert np.array_equal(m.sorted_keys, dup[order]) and np.array_equal(m.sorted_values, vals[order])
+    _, exes = build.build_host()
+    for args in (["1000000", "32", "1", "1", "full", "64bit"], ["300001", "7", "2", "1", "28bit", "64bit"]):
+        p = subprocess.run([str(exes[0]), *args], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "64bit numbers." in p.stdout and "[MultiRadixSort] Test passed." in p.stdout, p.stdout + p.stderr

@@ -86,3 +86,20 @@ def test_test_sort_reports_first_mismatch(oracle):
     assert oracle.test_sort(a, a.copy()) == -1
     assert oracle.test_sort(a, b) == 7
     assert oracle.test_sort(a, a[:9].copy()) == -2
+
+
+@pytest.mark.parametrize("n,B", [(1, 1), (257, 1), (1000, 32), (100003, 7), (70000, 64)])
+def test_oracle_u64_equals_std_sort(oracle, n, B):
+    rs = np.random.RandomState(n + B)
+    keys = (rs.randint(0, 2 ** 32, n, dtype=np.uint64) << np.uint64(32)) | rs.randint(0, 2 ** 32, n, dtype=np.uint64)
+    ref, _ = oracle.std_sort_u64(keys)
+    assert np.array_equal(ref, np.sort(keys))
+    assert np.array_equal(oracle.multi_radixsort_u64(keys, B), ref)
+    # the reference's own 64-bit key range [0, 0x0FFFFFFFFFFF] (MultiRadixSort.cpp:128)
+    k44 = keys & np.uint64(0x0FFFFFFFFFFF)
+    assert np.array_equal(oracle.multi_radixsort_u64(k44, B), np.sort(k44))
+    vals = np.arange(n, dtype=np.uint32)
+    dup = keys & np.uint64(0xFF00FF00FF)
+    k, v = oracle.multi_radixsort_u64(dup, B, vals)
+    order = np.argsort(dup, kind="stable")
+    assert np.array_equal(k, dup[order]) and np.array_equal(v, vals[order])

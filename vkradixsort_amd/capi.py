@@ -73,11 +73,16 @@ _SIGNATURES = [
     ("vrs_multi_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
     ("vrs_multi_radixsort_pairs", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
+    ("vrs_multi_radixsort_histograms_u64", c_int, [c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
+    ("vrs_multi_radixsort_u64", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
+    ("vrs_multi_radixsort_pairs_u64", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
     ("vrs_multi_radixsort_digit_offsets", c_int, [c_void_p, c_void_p]),
     ("vrs_queue_wait_idle", c_int, [c_void_p]),
     ("vrs_single_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_sort_keys_u32", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_sort_pairs_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
+    ("vrs_sort_keys_u64", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_transform_keys", c_int, [c_void_p, c_void_p, c_uint32, c_int]),
     ("vrs_profile_enable", c_int, [c_void_p, c_int]),
     ("vrs_profile_enable_mask", c_int, [c_void_p, c_uint32]),

@@ -31,6 +31,7 @@ struct vrs_context_t {
     struct {
         const void *keys = nullptr;
         uint32_t n = 0, shift = 0, blocks = 0;
+        int key_bytes = 4;
         bool valid = false;
     } sub_cache;
     bool xcd_remap = true;
@@ -56,7 +57,8 @@ struct vrs_buffer_t {
 
 namespace {
 
-constexpr uint32_t kLaunchTileBlocks = 32;  // the kernels' own tile: 32 blocks x 256 = 8192 keys
+// the kernels' own launch tile: 8192 uint32 keys or 4096 uint64 keys (32 KiB either way)
+constexpr uint32_t launch_tile_blocks(int key_bytes) { return key_bytes == 8 ? 16u : 32u; }
 
 thread_local std::string g_global_error;
 
@@ -128,10 +130,11 @@ int profile_events(vrs_context ctx, int id, vrs::LaunchEvents *ev) {
     return VRS_OK;
 }
 
-int check_push_constants(vrs_context ctx, const vrs_push_constants *pc) {
+int check_push_constants(vrs_context ctx, const vrs_push_constants *pc, int key_bytes = 4) {
     if (!pc) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "push constants are NULL");
-    if (pc->g_shift > 24 || (pc->g_shift & 7u) != 0)
-        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "g_shift must be 0, 8, 16 or 24");
+    if (pc->g_shift > 8u * key_bytes - 8u || (pc->g_shift & 7u) != 0)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT,
+                    key_bytes == 8 ? "g_shift must be a multiple of 8 in [0, 56]" : "g_shift must be 0, 8, 16 or 24");
     if (pc->g_num_elements == 0) return VRS_OK;
     if (pc->g_num_blocks_per_workgroup == 0)
         return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "g_num_blocks_per_workgroup must be >= 1");
@@ -217,33 +220,35 @@ int create_context(int device_ordinal, hipStream_t borrowed, bool borrow, vrs_co
 }
 
 int run_sort_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs_buffer values_in,
-                   vrs_buffer values_out, vrs_buffer histograms, const vrs_push_constants *pc, bool pairs) {
+                   vrs_buffer values_out, vrs_buffer histograms, const vrs_push_constants *pc, bool pairs,
+                   int key_bytes = 4) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
-    int rc = check_push_constants(ctx, pc);
+    int rc = check_push_constants(ctx, pc, key_bytes);
     if (rc) return rc;
     const uint32_t n = pc->g_num_elements;
     if (n == 0) return VRS_OK;
     const uint32_t W = pc->g_num_workgroups;
-    const size_t key_bytes = static_cast<size_t>(n) * sizeof(uint32_t);
-    if ((rc = check_buffer(ctx, keys_in, key_bytes, "keys_in"))) return rc;
-    if ((rc = check_buffer(ctx, keys_out, key_bytes, "keys_out"))) return rc;
+    const size_t keys_size = static_cast<size_t>(n) * key_bytes, values_size = static_cast<size_t>(n) * sizeof(uint32_t);
+    if ((rc = check_buffer(ctx, keys_in, keys_size, "keys_in"))) return rc;
+    if ((rc = check_buffer(ctx, keys_out, keys_size, "keys_out"))) return rc;
     if ((rc = check_buffer(ctx, histograms, static_cast<size_t>(W) * VRS_RADIX_SORT_BINS * sizeof(uint32_t),
                            "histograms")))
         return rc;
     if (keys_in->ptr == keys_out->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "keys_in and keys_out alias");
     if (pairs) {
-        if ((rc = check_buffer(ctx, values_in, key_bytes, "values_in"))) return rc;
-        if ((rc = check_buffer(ctx, values_out, key_bytes, "values_out"))) return rc;
+        if ((rc = check_buffer(ctx, values_in, values_size, "values_in"))) return rc;
+        if ((rc = check_buffer(ctx, values_out, values_size, "values_out"))) return rc;
         if (values_in->ptr == values_out->ptr)
             return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "values_in and values_out alias");
     }
     VRS_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t B = pc->g_num_blocks_per_workgroup;
     const uint32_t *table = static_cast<const uint32_t *>(histograms->ptr);
+    const uint32_t kLaunchTileBlocks = launch_tile_blocks(key_bytes);
     uint32_t launch_W = W, launch_B = B, row_stride = 1, rows_per_contract_tile = 1;
     if (B > kLaunchTileBlocks && B % kLaunchTileBlocks == 0 && ctx->sub_cache.valid &&
         ctx->sub_cache.keys == keys_in->ptr && ctx->sub_cache.n == n && ctx->sub_cache.shift == pc->g_shift &&
-        ctx->sub_cache.blocks == B) {
+        ctx->sub_cache.blocks == B && ctx->sub_cache.key_bytes == key_bytes) {
         // large contract tiles: prefix + scatter at 8192-key sub-tile granularity from the table the histogram
         // stage kept (the caller's table is its fold, so both describe the same keys)
         launch_B = kLaunchTileBlocks;
@@ -270,12 +275,11 @@ int run_sort_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs
         launch_W = vrs_workgroup_count(n, launch_B);
     }
     if ((rc = profile_events(ctx, VRS_KERNEL_SCATTER, &ev))) return rc;
-    VRS_HIP(ctx, vrs::launch_scatter(ctx->stream, static_cast<const uint32_t *>(keys_in->ptr),
-                                     static_cast<uint32_t *>(keys_out->ptr),
+    VRS_HIP(ctx, vrs::launch_scatter(ctx->stream, keys_in->ptr, keys_out->ptr,
                                      pairs ? static_cast<const uint32_t *>(values_in->ptr) : nullptr,
                                      pairs ? static_cast<uint32_t *>(values_out->ptr) : nullptr, ctx->scratch.offsets,
                                      n, pc->g_shift, launch_W, launch_B, ctx->xcd_remap, ctx->scatter, ev, nullptr,
-                                     row_stride));
+                                     row_stride, key_bytes));
     return VRS_OK;
 }
 
@@ -434,13 +438,13 @@ uint32_t vrs_workgroup_count(uint32_t num_elements, uint32_t blocks_per_workgrou
     return gis / VRS_WORKGROUP_SIZE + (gis % VRS_WORKGROUP_SIZE ? 1u : 0u);
 }
 
-int vrs_multi_radixsort_histograms(vrs_context ctx, vrs_buffer keys_in, vrs_buffer histograms,
-                                   const vrs_push_constants *pc) {
+static int run_histogram_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer histograms,
+                               const vrs_push_constants *pc, int key_bytes) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
-    int rc = check_push_constants(ctx, pc);
+    int rc = check_push_constants(ctx, pc, key_bytes);
     if (rc) return rc;
     if (pc->g_num_elements == 0) return VRS_OK;
-    if ((rc = check_buffer(ctx, keys_in, static_cast<size_t>(pc->g_num_elements) * sizeof(uint32_t), "keys_in")))
+    if ((rc = check_buffer(ctx, keys_in, static_cast<size_t>(pc->g_num_elements) * key_bytes, "keys_in")))
         return rc;
     if ((rc = check_buffer(ctx, histograms,
                            static_cast<size_t>(pc->g_num_workgroups) * VRS_RADIX_SORT_BINS * sizeof(uint32_t),
@@ -450,6 +454,7 @@ int vrs_multi_radixsort_histograms(vrs_context ctx, vrs_buffer keys_in, vrs_buff
     vrs::LaunchEvents ev;
     if ((rc = profile_events(ctx, VRS_KERNEL_HISTOGRAM, &ev))) return rc;
     const uint32_t B = pc->g_num_blocks_per_workgroup, n = pc->g_num_elements;
+    const uint32_t kLaunchTileBlocks = launch_tile_blocks(key_bytes);
     ctx->sub_cache.valid = false;
     if (B > kLaunchTileBlocks && B % kLaunchTileBlocks == 0) {
         // contract tile = S sub-tiles of 8192 keys: histogram the sub-tiles (enough workgroups to fill the chip
@@ -464,21 +469,41 @@ int vrs_multi_radixsort_histograms(vrs_context ctx, vrs_buffer keys_in, vrs_buff
                                    static_cast<size_t>(sub_rows) * VRS_RADIX_SORT_BINS * sizeof(uint32_t)));
             ctx->sub_hist_rows = sub_rows;
         }
-        VRS_HIP(ctx, vrs::launch_histograms(ctx->stream, static_cast<const uint32_t *>(keys_in->ptr), ctx->sub_hist, n,
-                                            pc->g_shift, sub_rows, kLaunchTileBlocks, vrs::LaunchEvents{ev.start, nullptr}));
+        VRS_HIP(ctx, vrs::launch_histograms(ctx->stream, keys_in->ptr, ctx->sub_hist, n, pc->g_shift, sub_rows,
+                                            kLaunchTileBlocks, vrs::LaunchEvents{ev.start, nullptr}, nullptr, key_bytes));
         VRS_HIP(ctx, vrs::launch_fold_histograms(ctx->stream, ctx->sub_hist, static_cast<uint32_t *>(histograms->ptr),
                                                  sub_rows, pc->g_num_workgroups, S, vrs::LaunchEvents{nullptr, ev.stop}));
         ctx->sub_cache.keys = keys_in->ptr;
         ctx->sub_cache.n = n;
         ctx->sub_cache.shift = pc->g_shift;
         ctx->sub_cache.blocks = B;
+        ctx->sub_cache.key_bytes = key_bytes;
         ctx->sub_cache.valid = true;
         return VRS_OK;
     }
-    VRS_HIP(ctx, vrs::launch_histograms(ctx->stream, static_cast<const uint32_t *>(keys_in->ptr),
-                                        static_cast<uint32_t *>(histograms->ptr), n, pc->g_shift,
-                                        pc->g_num_workgroups, B, ev));
+    VRS_HIP(ctx, vrs::launch_histograms(ctx->stream, keys_in->ptr, static_cast<uint32_t *>(histograms->ptr), n,
+                                        pc->g_shift, pc->g_num_workgroups, B, ev, nullptr, key_bytes));
     return VRS_OK;
+}
+
+int vrs_multi_radixsort_histograms(vrs_context ctx, vrs_buffer keys_in, vrs_buffer histograms,
+                                   const vrs_push_constants *pc) {
+    return run_histogram_stage(ctx, keys_in, histograms, pc, 4);
+}
+
+int vrs_multi_radixsort_histograms_u64(vrs_context ctx, vrs_buffer keys_in, vrs_buffer histograms,
+                                       const vrs_push_constants *pc) {
+    return run_histogram_stage(ctx, keys_in, histograms, pc, 8);
+}
+
+int vrs_multi_radixsort_u64(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs_buffer histograms,
+                            const vrs_push_constants *pc) {
+    return run_sort_stage(ctx, keys_in, keys_out, nullptr, nullptr, histograms, pc, false, 8);
+}
+
+int vrs_multi_radixsort_pairs_u64(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs_buffer values_in,
+                                  vrs_buffer values_out, vrs_buffer histograms, const vrs_push_constants *pc) {
+    return run_sort_stage(ctx, keys_in, keys_out, values_in, values_out, histograms, pc, true, 8);
 }
 
 int vrs_multi_radixsort(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs_buffer histograms,
@@ -517,10 +542,10 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
 // One-call form: the four passes of MultiRadixSort::execute's hot loop (MultiRadixSort.cpp:50-61) with the
 // library choosing NUM_BLOCKS_PER_WORKGROUP and owning the histogram table.
 static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
-                           vrs_buffer values_tmp, uint32_t n) {
+                           vrs_buffer values_tmp, uint32_t n, int key_bytes = 4) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     if (n == 0) return VRS_OK;
-    const uint32_t B = 32;
+    const uint32_t B = launch_tile_blocks(key_bytes);
     vrs_push_constants pc{n, 0, vrs_workgroup_count(n, B), B};
     const size_t need = static_cast<size_t>(pc.g_num_workgroups) * VRS_RADIX_SORT_BINS * sizeof(uint32_t);
     if (!ctx->sort_hist || ctx->sort_hist->size < need) {
@@ -532,19 +557,21 @@ static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp
         int rc = vrs_buffer_create(ctx, need, &ctx->sort_hist);
         if (rc) return rc;
     }
-    for (uint32_t i = 0; i < 4; ++i) {
+    for (uint32_t i = 0; i < static_cast<uint32_t>(key_bytes); ++i) {  // one pass per key byte: 4 or 8 (even either way)
         pc.g_shift = 8 * i;
         vrs_buffer kin = (i & 1u) ? keys_tmp : keys, kout = (i & 1u) ? keys : keys_tmp;
-        int rc = vrs_multi_radixsort_histograms(ctx, kin, ctx->sort_hist, &pc);
+        int rc = run_histogram_stage(ctx, kin, ctx->sort_hist, &pc, key_bytes);
         if (rc) return rc;
-        if (values)
-            rc = vrs_multi_radixsort_pairs(ctx, kin, kout, (i & 1u) ? values_tmp : values,
-                                           (i & 1u) ? values : values_tmp, ctx->sort_hist, &pc);
-        else
-            rc = vrs_multi_radixsort(ctx, kin, kout, ctx->sort_hist, &pc);
+        rc = run_sort_stage(ctx, kin, kout, values ? ((i & 1u) ? values_tmp : values) : nullptr,
+                            values ? ((i & 1u) ? values : values_tmp) : nullptr, ctx->sort_hist, &pc, values != nullptr,
+                            key_bytes);
         if (rc) return rc;
     }
     return VRS_OK;
+}
+
+int vrs_sort_keys_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements) {
+    return sort_all_passes(ctx, keys, keys_tmp, nullptr, nullptr, num_elements, 8);
 }
 
 int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements) {

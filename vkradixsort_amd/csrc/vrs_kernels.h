@@ -33,18 +33,18 @@ struct ScatterLaunch {
 // tiles per chunk for the two-level prefix: smallest power of two C with C*C >= W
 uint32_t prefix_chunk_tiles(uint32_t num_workgroups);
 
-hipError_t launch_histograms(hipStream_t stream, const uint32_t *keys_in, uint32_t *hist,
-                             uint32_t n, uint32_t shift, uint32_t W, uint32_t B, LaunchEvents ev = {},
-                             const uint32_t *tile_order = nullptr);
+// keys are uint32 (key_bytes == 4) or uint64 (key_bytes == 8)
+hipError_t launch_histograms(hipStream_t stream, const void *keys_in, uint32_t *hist, uint32_t n, uint32_t shift,
+                             uint32_t W, uint32_t B, LaunchEvents ev = {}, const uint32_t *tile_order = nullptr,
+                             int key_bytes = 4);
 
 hipError_t launch_prefix(hipStream_t stream, const uint32_t *hist, const PrefixScratch &scratch,
                          uint32_t W, LaunchEvents ev = {});
 
-hipError_t launch_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
-                          const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets,
-                          uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap,
-                          const ScatterLaunch &cfg, LaunchEvents ev = {},
-                          const uint32_t *tile_order = nullptr, uint32_t offset_row_stride = 1);
+hipError_t launch_scatter(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
+                          uint32_t *values_out, const uint32_t *offsets, uint32_t n, uint32_t shift, uint32_t W,
+                          uint32_t B, bool xcd_remap, const ScatterLaunch &cfg, LaunchEvents ev = {},
+                          const uint32_t *tile_order = nullptr, uint32_t offset_row_stride = 1, int key_bytes = 4);
 
 // hist[w][d] = sum of sub rows [w*S, (w+1)*S): contract table from the 8192-key sub-tile table
 hipError_t launch_fold_histograms(hipStream_t stream, const uint32_t *sub, uint32_t *hist, uint32_t sub_rows,

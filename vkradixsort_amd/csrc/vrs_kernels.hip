@@ -50,9 +50,29 @@ __device__ __forceinline__ uint32_t count_below(uint64_t mask) {
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
+// Keys are uint32 (the reference's SORT_32BIT, four passes) or uint64 (its SORT_64_BIT stub,
+// MultiRadixSort.h:10-18 / MultiRadixSort.cpp:51-55: eight passes); every kernel is a template on the key type.
 __device__ __forceinline__ uint32_t digit_of(uint32_t key, uint32_t shift) {
     return (key >> shift) & (kBins - 1);
 }
+__device__ __forceinline__ uint32_t digit_of(uint64_t key, uint32_t shift) {
+    return static_cast<uint32_t>(key >> shift) & (kBins - 1);
+}
+
+template <typename K>
+struct KeyVec;  // 16-byte vector of keys for the histogram's coalesced loads
+template <>
+struct KeyVec<uint32_t> {
+    using type = uint4;
+    static constexpr int kKeys = 4;
+    static __device__ __forceinline__ uint32_t get(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+};
+template <>
+struct KeyVec<uint64_t> {
+    using type = ulonglong2;
+    static constexpr int kKeys = 2;
+    static __device__ __forceinline__ uint64_t get(const ulonglong2 &v, int i) { return i == 0 ? v.x : v.y; }
+};
 
 // Observed dispatch places workgroup b on XCD b % 8 (speed only, never correctness).  Remap so
 // that XCD x walks a CONTIGUOUS range of tiles: the partial cache lines at the two ends of every
@@ -105,27 +125,32 @@ __device__ __forceinline__ void histogram_count(uint32_t *s_hist, uint32_t key, 
     }
 }
 
-// all 64 lanes hold a valid uint4
-__device__ __forceinline__ void histogram_count4(uint32_t *s_hist, uint4 q, uint32_t shift) {
-    const uint32_t dx = digit_of(q.x, shift), dy = digit_of(q.y, shift), dz = digit_of(q.z, shift),
-                   dw = digit_of(q.w, shift);
-    const uint32_t d0 = __builtin_amdgcn_readfirstlane(dx);
-    const bool mine = ((dx ^ d0) | (dy ^ d0) | (dz ^ d0) | (dw ^ d0)) == 0u;
-    if (__ballot(mine) == ~0ull) {  // wave-uniform branch
-        if (lane_id() == 0u) atomicAdd(&s_hist[d0], 256u);
+// all 64 lanes hold a valid 16-byte vector of keys
+template <typename K>
+__device__ __forceinline__ void histogram_count_vec(uint32_t *s_hist, const typename KeyVec<K>::type &q, uint32_t shift) {
+    constexpr int V = KeyVec<K>::kKeys;
+    uint32_t d[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) d[i] = digit_of(KeyVec<K>::get(q, i), shift);
+    const uint32_t d0 = __builtin_amdgcn_readfirstlane(d[0]);
+    uint32_t diff = 0;
+#pragma unroll
+    for (int i = 0; i < V; ++i) diff |= d[i] ^ d0;
+    if (__ballot(diff == 0u) == ~0ull) {  // wave-uniform branch
+        if (lane_id() == 0u) atomicAdd(&s_hist[d0], 64u * V);
     } else {
-        atomicAdd(&s_hist[dx], 1u);
-        atomicAdd(&s_hist[dy], 1u);
-        atomicAdd(&s_hist[dz], 1u);
-        atomicAdd(&s_hist[dw], 1u);
+#pragma unroll
+        for (int i = 0; i < V; ++i) atomicAdd(&s_hist[d[i]], 1u);
     }
 }
 
-template <int UNROLL>
-__global__ __launch_bounds__(kThreads) void histogram_kernel(const uint32_t *__restrict__ keys,
+template <typename K, int UNROLL>
+__global__ __launch_bounds__(kThreads) void histogram_kernel(const K *__restrict__ keys,
                                                              uint32_t *__restrict__ hist, uint32_t n,
                                                              uint32_t shift, uint32_t W, uint32_t B,
                                                              const uint32_t *__restrict__ tile_order) {
+    using Vec = typename KeyVec<K>::type;
+    constexpr uint32_t V = KeyVec<K>::kKeys;
     __shared__ uint32_t s_hist[kBins];
     const uint32_t tid = threadIdx.x;
     // which tile this workgroup takes is a pure scheduling choice (cache residency), never a result
@@ -137,27 +162,25 @@ __global__ __launch_bounds__(kThreads) void histogram_kernel(const uint32_t *__r
     if (tile_begin < n) {
         const uint64_t tile_keys = static_cast<uint64_t>(B) * kThreads;
         const uint32_t len = static_cast<uint32_t>(tile_begin + tile_keys <= n ? tile_keys : n - tile_begin);
-        // tile_begin is a multiple of 256 keys = 1 KiB, so 16-byte loads are aligned whenever the
+        // tile_begin is a multiple of 256 keys (>= 1 KiB), so 16-byte loads are aligned whenever the
         // buffer base is (checked by the host).
-        const uint4 *v = reinterpret_cast<const uint4 *>(keys + tile_begin);
-        const uint32_t nvec = len >> 2;
+        const Vec *v = reinterpret_cast<const Vec *>(keys + tile_begin);
+        const uint32_t nvec = len / V;
         constexpr uint32_t kStep = kThreads * UNROLL;  // vectors per fully unrolled step
         uint32_t i0 = 0;
         for (; i0 + kStep <= nvec; i0 += kStep) {  // every lane of every wave holds valid vectors
-            uint4 q[UNROLL];
+            Vec q[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) q[u] = v[i0 + u * kThreads + tid];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) histogram_count4(s_hist, q[u], shift);
+            for (int u = 0; u < UNROLL; ++u) histogram_count_vec<K>(s_hist, q[u], shift);
         }
         for (uint32_t i = i0 + tid; i < nvec; i += kThreads) {  // ragged remainder of the tile
-            const uint4 q = v[i];
-            atomicAdd(&s_hist[digit_of(q.x, shift)], 1u);
-            atomicAdd(&s_hist[digit_of(q.y, shift)], 1u);
-            atomicAdd(&s_hist[digit_of(q.z, shift)], 1u);
-            atomicAdd(&s_hist[digit_of(q.w, shift)], 1u);
+            const Vec q = v[i];
+#pragma unroll
+            for (int k = 0; k < static_cast<int>(V); ++k) atomicAdd(&s_hist[digit_of(KeyVec<K>::get(q, k), shift)], 1u);
         }
-        const uint32_t tail = (nvec << 2) + tid;  // at most 3 keys
+        const uint32_t tail = nvec * V + tid;  // at most V-1 keys
         if (tail < len) atomicAdd(&s_hist[digit_of(keys[tile_begin + tail], shift)], 1u);
     }
     __syncthreads();
@@ -401,9 +424,9 @@ constexpr uint32_t kFusedMaxChunks = 48;
 constexpr int RANK_BALLOT = 0;
 constexpr int RANK_ATOMIC = 1;
 
-template <int ITEMS, int WAVES, bool PAIRS = false>
+template <typename K, int ITEMS, int WAVES, bool PAIRS = false>
 struct ChunkSmem {
-    uint32_t keys[ITEMS * WAVES * 64];  // re-bucketed keys, chunk order by digit
+    K keys[ITEMS * WAVES * 64];  // re-bucketed keys, chunk order by digit
     uint32_t vals[PAIRS ? ITEMS * WAVES * 64 : 1];  // re-bucketed payloads (pairs only)
     uint32_t whist[WAVES][kBins];       // per-wave digit counters -> per-wave digit start positions
     uint32_t gbase[kBins];              // global offset of digit d minus its start inside the chunk
@@ -451,9 +474,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_w(uint32_t v, uint32_t 
 // Every phase is written as "issue all ITEMS independent LDS/global operations, then consume":
 // a workgroup is latency-bound (one pass over its keys, few waves), so dependent
 // read -> wait -> write chains per item are what must not appear in the ISA.
-template <int ITEMS, int WAVES, bool PAIRS, int RANK, bool FULL>
-__device__ __forceinline__ void scatter_chunk(ChunkSmem<ITEMS, WAVES, PAIRS> &sm, const uint32_t *kin,
-                                              const uint32_t *vin, uint32_t *kout, uint32_t *vout,
+template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, bool FULL>
+__device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> &sm, const K *kin,
+                                              const uint32_t *vin, K *kout, uint32_t *vout,
                                               uint32_t valid, uint32_t shift, uint32_t &run_off) {
     constexpr uint32_t THREADS = WAVES * 64;
     const uint32_t tid = threadIdx.x;
@@ -461,7 +484,7 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<ITEMS, WAVES, PAIRS> &sm
     const uint32_t wave = tid >> 6;
 
     VRS_MARK(0);
-    uint32_t key[ITEMS];
+    K key[ITEMS];
     const uint32_t seg = wave * (ITEMS * 64) + lane;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -469,10 +492,10 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<ITEMS, WAVES, PAIRS> &sm
         if constexpr (FULL) {
             key[i] = kin[idx];
         } else {
-            // unpredicated load from a clamped index, then select: padding key 0xFFFFFFFF has digit 255
+            // unpredicated load from a clamped index, then select: the all-ones padding key has digit 255
             // under every shift and the highest chunk indices, so it ranks behind every real key
-            const uint32_t k = kin[idx < valid ? idx : valid - 1u];
-            key[i] = idx < valid ? k : 0xFFFFFFFFu;
+            const K k = kin[idx < valid ? idx : valid - 1u];
+            key[i] = idx < valid ? k : static_cast<K>(~static_cast<K>(0));
         }
     }
     uint32_t val[PAIRS ? ITEMS : 1];
@@ -581,16 +604,16 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<ITEMS, WAVES, PAIRS> &sm
     // the next chunk's first barrier (after it zeroes the counters) separates these LDS reads from its writes
 }
 
-template <int ITEMS, int WAVES, bool PAIRS, int RANK, int OCC>
-__global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const uint32_t *__restrict__ keys_in,
-                                                             uint32_t *__restrict__ keys_out,
+template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__restrict__ keys_in,
+                                                             K *__restrict__ keys_out,
                                                              const uint32_t *__restrict__ values_in,
                                                              uint32_t *__restrict__ values_out,
                                                              const uint32_t *__restrict__ offsets, uint32_t n,
                                                              uint32_t shift, uint32_t W, uint32_t B, int xcd_remap,
                                                              const uint32_t *__restrict__ tile_order,
                                                              uint32_t offset_row_stride) {
-    __shared__ ChunkSmem<ITEMS, WAVES, PAIRS> sm;
+    __shared__ ChunkSmem<K, ITEMS, WAVES, PAIRS> sm;
     const uint32_t w = tile_order ? tile_order[blockIdx.x]
                                   : (xcd_remap ? xcd_contiguous_tile(blockIdx.x, W) : blockIdx.x);
     const uint64_t tile_begin = static_cast<uint64_t>(w) * B * kThreads;
@@ -604,12 +627,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const uint32_t
     constexpr uint32_t kChunk = ITEMS * WAVES * 64;
     for (uint32_t c0 = 0; c0 < tile_len; c0 += kChunk) {
         const uint32_t valid = min(kChunk, tile_len - c0);
-        const uint32_t *kin = keys_in + tile_begin + c0;
+        const K *kin = keys_in + tile_begin + c0;
         const uint32_t *vin = PAIRS ? values_in + tile_begin + c0 : nullptr;
         if (valid == kChunk)  // workgroup-uniform
-            scatter_chunk<ITEMS, WAVES, PAIRS, RANK, true>(sm, kin, vin, keys_out, values_out, valid, shift, run_off);
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, kin, vin, keys_out, values_out, valid, shift, run_off);
         else
-            scatter_chunk<ITEMS, WAVES, PAIRS, RANK, false>(sm, kin, vin, keys_out, values_out, valid, shift, run_off);
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, kin, vin, keys_out, values_out, valid, shift, run_off);
     }
     VRS_MARK_FLUSH();
 }
@@ -656,7 +679,7 @@ __global__ __launch_bounds__(kThreads) void atomic_rank_selftest_kernel(uint32_t
 constexpr int kSingleItems = 4;
 
 __global__ __launch_bounds__(kThreads) void single_kernel(uint32_t *buffer0, uint32_t *buffer1, uint32_t n) {
-    __shared__ ChunkSmem<kSingleItems, kWaves> sm;
+    __shared__ ChunkSmem<uint32_t, kSingleItems, kWaves> sm;
     __shared__ uint32_t s_hist[kBins];
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kChunk = kSingleItems * kThreads;
@@ -677,10 +700,10 @@ __global__ __launch_bounds__(kThreads) void single_kernel(uint32_t *buffer0, uin
         for (uint32_t c0 = 0; c0 < n; c0 += kChunk) {
             const uint32_t valid = min(kChunk, n - c0);
             if (valid == kChunk)
-                scatter_chunk<kSingleItems, kWaves, false, RANK_BALLOT, true>(sm, in + c0, nullptr, out, nullptr, valid,
+                scatter_chunk<uint32_t, kSingleItems, kWaves, false, RANK_BALLOT, true>(sm, in + c0, nullptr, out, nullptr, valid,
                                                                               shift, run_off);
             else
-                scatter_chunk<kSingleItems, kWaves, false, RANK_BALLOT, false>(sm, in + c0, nullptr, out, nullptr, valid,
+                scatter_chunk<uint32_t, kSingleItems, kWaves, false, RANK_BALLOT, false>(sm, in + c0, nullptr, out, nullptr, valid,
                                                                                shift, run_off);
         }
         // the next pass reads what this pass wrote: same CU, so a workgroup barrier (with its
@@ -754,10 +777,15 @@ uint32_t prefix_chunk_tiles(uint32_t W) {
     return c;
 }
 
-hipError_t launch_histograms(hipStream_t stream, const uint32_t *keys_in, uint32_t *hist, uint32_t n,
-                             uint32_t shift, uint32_t W, uint32_t B, LaunchEvents ev, const uint32_t *tile_order) {
+hipError_t launch_histograms(hipStream_t stream, const void *keys_in, uint32_t *hist, uint32_t n, uint32_t shift,
+                             uint32_t W, uint32_t B, LaunchEvents ev, const uint32_t *tile_order, int key_bytes) {
     if (W == 0) return hipSuccess;
-    VRS_LAUNCH(histogram_kernel<8>, dim3(W), dim3(kThreads), stream, ev, keys_in, hist, n, shift, W, B, tile_order);
+    if (key_bytes == 8)
+        VRS_LAUNCH((histogram_kernel<uint64_t, 8>), dim3(W), dim3(kThreads), stream, ev,
+                   static_cast<const uint64_t *>(keys_in), hist, n, shift, W, B, tile_order);
+    else
+        VRS_LAUNCH((histogram_kernel<uint32_t, 8>), dim3(W), dim3(kThreads), stream, ev,
+                   static_cast<const uint32_t *>(keys_in), hist, n, shift, W, B, tile_order);
     return hipGetLastError();
 }
 
@@ -779,47 +807,56 @@ hipError_t launch_prefix(hipStream_t stream, const uint32_t *hist, const PrefixS
     return hipGetLastError();
 }
 
-template <int ITEMS, int WAVES, int RANK, int OCC>
-static hipError_t launch_scatter_variant(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
+template <typename K, int ITEMS, int WAVES, int RANK, int OCC>
+static hipError_t launch_scatter_variant(hipStream_t stream, const void *keys_in, void *keys_out,
                                          const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets,
                                          uint32_t n, uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap,
                                          LaunchEvents ev, const uint32_t *tile_order, uint32_t offset_row_stride) {
     const int remap = xcd_remap ? 1 : 0;
+    const K *kin = static_cast<const K *>(keys_in);
+    K *kout = static_cast<K *>(keys_out);
     if (values_in != nullptr)
-        VRS_LAUNCH((scatter_kernel<ITEMS, WAVES, true, RANK, OCC>), dim3(W), dim3(WAVES * 64), stream, ev, keys_in,
-                   keys_out, values_in, values_out, offsets, n, shift, W, B, remap, tile_order, offset_row_stride);
+        VRS_LAUNCH((scatter_kernel<K, ITEMS, WAVES, true, RANK, OCC>), dim3(W), dim3(WAVES * 64), stream, ev, kin, kout,
+                   values_in, values_out, offsets, n, shift, W, B, remap, tile_order, offset_row_stride);
     else
-        VRS_LAUNCH((scatter_kernel<ITEMS, WAVES, false, RANK, OCC>), dim3(W), dim3(WAVES * 64), stream, ev, keys_in,
-                   keys_out, values_in, values_out, offsets, n, shift, W, B, remap, tile_order, offset_row_stride);
+        VRS_LAUNCH((scatter_kernel<K, ITEMS, WAVES, false, RANK, OCC>), dim3(W), dim3(WAVES * 64), stream, ev, kin, kout,
+                   values_in, values_out, offsets, n, shift, W, B, remap, tile_order, offset_row_stride);
     return hipGetLastError();
 }
 
 #define VRS_SCATTER_ARGS \
     stream, keys_in, keys_out, values_in, values_out, offsets, n, shift, W, B, xcd_remap, ev, tile_order, offset_row_stride
 
-hipError_t launch_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out,
-                          const uint32_t *values_in, uint32_t *values_out, const uint32_t *offsets, uint32_t n,
-                          uint32_t shift, uint32_t W, uint32_t B, bool xcd_remap, const ScatterLaunch &cfg,
-                          LaunchEvents ev, const uint32_t *tile_order, uint32_t offset_row_stride) {
+hipError_t launch_scatter(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
+                          uint32_t *values_out, const uint32_t *offsets, uint32_t n, uint32_t shift, uint32_t W,
+                          uint32_t B, bool xcd_remap, const ScatterLaunch &cfg, LaunchEvents ev,
+                          const uint32_t *tile_order, uint32_t offset_row_stride, int key_bytes) {
     if (W == 0) return hipSuccess;
+    const int rank = cfg.atomic_rank ? RANK_ATOMIC : RANK_BALLOT;
+    if (key_bytes == 8) {
+        // uint64 keys: 4096-key chunks keep the LDS footprint of the uint32 path (32 KiB of keys)
+        if (B >= 16)
+            return rank == RANK_ATOMIC ? launch_scatter_variant<uint64_t, 8, 8, RANK_ATOMIC, 4>(VRS_SCATTER_ARGS)
+                                       : launch_scatter_variant<uint64_t, 8, 8, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
+        return launch_scatter_variant<uint64_t, 4, 4, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
+    }
     // chunk = ITEMS*WAVES*64 keys held in registers + LDS at once; a tile of B blocks is walked in
     // ceil(B*256/chunk) chunks.  cfg.variant (tuning only) = OCC*100000 + ITEMS*1000 + WAVES*10 + RANK
     // (OCC = waves per SIMD the register allocation is held to); 0 = default for this B and rank mode.
     int variant = cfg.variant;
     if (variant == 0) {
-        const int rank = cfg.atomic_rank ? RANK_ATOMIC : RANK_BALLOT;
         if (B >= 32) variant = 416080 + rank;       // 8192-key chunks, 512 threads
         else if (B >= 16) variant = 416040 + rank;  // 4096-key chunks
         else if (B >= 8) variant = 408040;
         else variant = 404040;
     }
     switch (variant) {
-        case 416080: return launch_scatter_variant<16, 8, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
-        case 416081: return launch_scatter_variant<16, 8, RANK_ATOMIC, 4>(VRS_SCATTER_ARGS);
-        case 416040: return launch_scatter_variant<16, 4, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
-        case 416041: return launch_scatter_variant<16, 4, RANK_ATOMIC, 4>(VRS_SCATTER_ARGS);
-        case 408040: return launch_scatter_variant<8, 4, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
-        case 404040: return launch_scatter_variant<4, 4, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
+        case 416080: return launch_scatter_variant<uint32_t, 16, 8, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
+        case 416081: return launch_scatter_variant<uint32_t, 16, 8, RANK_ATOMIC, 4>(VRS_SCATTER_ARGS);
+        case 416040: return launch_scatter_variant<uint32_t, 16, 4, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
+        case 416041: return launch_scatter_variant<uint32_t, 16, 4, RANK_ATOMIC, 4>(VRS_SCATTER_ARGS);
+        case 408040: return launch_scatter_variant<uint32_t, 8, 4, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
+        case 404040: return launch_scatter_variant<uint32_t, 4, 4, RANK_BALLOT, 4>(VRS_SCATTER_ARGS);
         default: return hipErrorInvalidValue;
     }
 }

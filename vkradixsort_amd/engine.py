@@ -267,19 +267,23 @@ class MultiRadixSortPass(ComputePass):
         self.m_pushConstantsHistogram = PushConstants()  # MultiRadixSortPass.h:24
         self.m_pushConstants = PushConstants()  # MultiRadixSortPass.h:33
         self.m_pairs = False  # build extension: bindings (1,3)/(1,4) carry values in/out
+        self.m_sort64Bit = False  # the reference's SORT_64_BIT switch (MultiRadixSort.h:10-18): uint64 keys
 
     def recordCommands(self) -> None:  # MultiRadixSortPass.cpp:10-20
         ctx = self.m_gpuContext
         lib = ctx.lib
-        ctx.check(lib.vrs_multi_radixsort_histograms(ctx.handle, self._bound(0, 0).handle, self._bound(0, 1).handle,
-                                                     ctypes.byref(self.m_pushConstantsHistogram)))
+        hist = lib.vrs_multi_radixsort_histograms_u64 if self.m_sort64Bit else lib.vrs_multi_radixsort_histograms
+        sort_pairs = lib.vrs_multi_radixsort_pairs_u64 if self.m_sort64Bit else lib.vrs_multi_radixsort_pairs
+        sort_keys = lib.vrs_multi_radixsort_u64 if self.m_sort64Bit else lib.vrs_multi_radixsort
+        ctx.check(hist(ctx.handle, self._bound(0, 0).handle, self._bound(0, 1).handle,
+                       ctypes.byref(self.m_pushConstantsHistogram)))
         if self.m_pairs:
-            ctx.check(lib.vrs_multi_radixsort_pairs(ctx.handle, self._bound(1, 0).handle, self._bound(1, 1).handle,
+            ctx.check(sort_pairs(ctx.handle, self._bound(1, 0).handle, self._bound(1, 1).handle,
                                                     self._bound(1, 3).handle, self._bound(1, 4).handle,
                                                     self._bound(1, 2).handle, ctypes.byref(self.m_pushConstants)))
         else:
-            ctx.check(lib.vrs_multi_radixsort(ctx.handle, self._bound(1, 0).handle, self._bound(1, 1).handle,
-                                              self._bound(1, 2).handle, ctypes.byref(self.m_pushConstants)))
+            ctx.check(sort_keys(ctx.handle, self._bound(1, 0).handle, self._bound(1, 1).handle,
+                                self._bound(1, 2).handle, ctypes.byref(self.m_pushConstants)))
 
 
 class SingleRadixSortPass(ComputePass):
@@ -318,10 +322,13 @@ class MultiRadixSort:
     def __init__(self, NUM_ELEMENTS: int = 1000000, NUM_BLOCKS_PER_WORKGROUP: int = 32, seed: int = 1,
                  keys: np.ndarray | None = None, values: np.ndarray | None = None, quiet: bool = False):
         self.NUM_ELEMENTS = int(NUM_ELEMENTS if keys is None else keys.size)
-        self.NUM_ELEMENTS_BYTES = self.NUM_ELEMENTS * 4
+        # SORT_TYPE: uint32 (SORT_32BIT, four passes) unless uint64 keys are handed in (SORT_64_BIT, eight passes)
+        self.SORT_TYPE = np.uint64 if (keys is not None and keys.dtype == np.uint64) else np.uint32
+        self.KEY_BYTES = np.dtype(self.SORT_TYPE).itemsize
+        self.NUM_ELEMENTS_BYTES = self.NUM_ELEMENTS * self.KEY_BYTES
         self.NUM_BLOCKS_PER_WORKGROUP = int(NUM_BLOCKS_PER_WORKGROUP)
         self.seed = seed
-        self.m_elementsIn = None if keys is None else np.ascontiguousarray(keys, dtype=np.uint32)
+        self.m_elementsIn = None if keys is None else np.ascontiguousarray(keys, dtype=self.SORT_TYPE)
         self.m_valuesIn = None if values is None else np.ascontiguousarray(values, dtype=np.uint32)
         self.m_buffers: list = [None, None, None]
         self.m_valueBuffers: list = [None, None]
@@ -342,6 +349,7 @@ class MultiRadixSort:
         self.m_gpuContext = gpuContext
         self.m_pass = MultiRadixSortPass(gpuContext)
         self.m_pass.create()
+        self.m_pass.m_sort64Bit = self.KEY_BYTES == 8
         B = self.NUM_BLOCKS_PER_WORKGROUP
         globalInvocationSize = self.NUM_ELEMENTS // B
         remainder = self.NUM_ELEMENTS % B
@@ -371,9 +379,9 @@ class MultiRadixSort:
         self.m_buffers[2] = Buffer(ctx, S(W * RADIX_SORT_BINS * 4, "radixSort.histogramsBuffer"))
         if self.m_valuesIn is not None:
             self.m_pass.m_pairs = True
-            self.m_valueBuffers[0] = Buffer.fillDeviceWithStagingBuffer(ctx, S(self.NUM_ELEMENTS_BYTES, "radixSort.valueBuffer0"),
+            self.m_valueBuffers[0] = Buffer.fillDeviceWithStagingBuffer(ctx, S(self.NUM_ELEMENTS * 4, "radixSort.valueBuffer0"),
                                                                         self.m_valuesIn)
-            self.m_valueBuffers[1] = Buffer(ctx, S(self.NUM_ELEMENTS_BYTES, "radixSort.valueBuffer1"))
+            self.m_valueBuffers[1] = Buffer(ctx, S(self.NUM_ELEMENTS * 4, "radixSort.valueBuffer1"))
 
     def bindBuffers(self) -> None:  # MultiRadixSort.cpp:33-46
         p = self.m_pass
@@ -396,7 +404,7 @@ class MultiRadixSort:
 
     def enqueueSort(self) -> None:  # the hot loop, MultiRadixSort.cpp:50-61 (no blocking call inside)
         awaitBeforeExecution = None
-        NUM_ITERATIONS = 4  # SORT_32BIT
+        NUM_ITERATIONS = self.KEY_BYTES  # 4 (SORT_32BIT) or 8 (SORT_64_BIT), MultiRadixSort.cpp:50-55
         for i in range(NUM_ITERATIONS):
             self.m_pass.m_pushConstantsHistogram.g_shift = 8 * i
             self.m_pass.m_pushConstants.g_shift = 8 * i
@@ -422,7 +430,7 @@ class MultiRadixSort:
         return True
 
     def download(self) -> np.ndarray:  # verify()'s download, MultiRadixSort.cpp:97-100: result is in buffer0
-        data = np.empty(self.NUM_ELEMENTS, dtype=np.uint32)
+        data = np.empty(self.NUM_ELEMENTS, dtype=self.SORT_TYPE)
         self.m_buffers[0].downloadWithStagingBuffer(data)
         return data
 
@@ -433,7 +441,7 @@ class MultiRadixSort:
 
     def execute(self, gpuContext: GPUContext) -> None:  # MultiRadixSort.cpp:5-81
         self.setup(gpuContext)
-        self._print(f"Sorting {self.NUM_ELEMENTS} 32bit numbers.")
+        self._print(f"Sorting {self.NUM_ELEMENTS} {8 * self.KEY_BYTES}bit numbers.")
         begin = time.perf_counter()
         self.enqueueSort()
         gpuContext.waitIdle()

@@ -13,14 +13,18 @@
 
 namespace engine {
 
-class MultiRadixSort {
+// SORT_TYPE_T = uint32_t is the reference's SORT_32BIT (four passes), uint64_t its SORT_64_BIT (eight passes,
+// MultiRadixSort.h:10-18 / MultiRadixSort.cpp:51-55, 44-bit keys from its generator, :128).
+template <typename SORT_TYPE_T>
+class BasicMultiRadixSort {
 public:
-    using SORT_TYPE = uint32_t;  // SORT_32BIT
+    using SORT_TYPE = SORT_TYPE_T;
 
-    explicit MultiRadixSort(uint32_t numElements = 1000000, uint32_t numBlocksPerWorkgroup = 32, uint32_t seed = 1,
+    explicit BasicMultiRadixSort(uint32_t numElements = 1000000, uint32_t numBlocksPerWorkgroup = 32, uint32_t seed = 1,
                             bool reference28BitKeys = false, uint32_t timedRepetitions = 1);
 
     static inline const char *PRINT_PREFIX = "[MultiRadixSort] ";
+    static constexpr uint32_t NUM_ITERATIONS = sizeof(SORT_TYPE);  // one pass per key byte: 4 or 8
 
     void execute(GPUContext *gpuContext);
 
@@ -55,5 +59,8 @@ private:
     void verify(std::vector<SORT_TYPE> &reference);
     void releaseBuffers();
 };
+
+using MultiRadixSort = BasicMultiRadixSort<uint32_t>;
+using MultiRadixSort64 = BasicMultiRadixSort<uint64_t>;
 
 }  // namespace engine

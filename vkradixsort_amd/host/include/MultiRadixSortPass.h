@@ -34,6 +34,8 @@ public:
 
     // Build extension (BASELINE.json config 4): when set, bindings (1,3)/(1,4) carry payload in/out.
     bool m_sortPairs = false;
+    // The reference's SORT_64_BIT switch (MultiRadixSort.h:10-18): buffers hold uint64 keys, g_shift runs to 56.
+    bool m_sort64Bit = false;
 
 protected:
     [[nodiscard]] uint32_t stageCount() const override { return 2; }

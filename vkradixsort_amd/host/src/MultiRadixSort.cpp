@@ -15,23 +15,26 @@ double elapsedMs(std::chrono::steady_clock::time_point a, std::chrono::steady_cl
 }
 }  // namespace
 
-MultiRadixSort::MultiRadixSort(uint32_t numElements, uint32_t numBlocksPerWorkgroup, uint32_t seed,
+template <typename T>
+BasicMultiRadixSort<T>::BasicMultiRadixSort(uint32_t numElements, uint32_t numBlocksPerWorkgroup, uint32_t seed,
                                bool reference28BitKeys, uint32_t timedRepetitions)
     : NUM_ELEMENTS(numElements),
       NUM_BLOCKS_PER_WORKGROUP(numBlocksPerWorkgroup),
-      NUM_ELEMENTS_BYTES(static_cast<size_t>(numElements) * sizeof(SORT_TYPE)),
+      NUM_ELEMENTS_BYTES(static_cast<size_t>(numElements) * sizeof(T)),
       m_seed(seed),
       m_reference28BitKeys(reference28BitKeys),
       m_timedRepetitions(timedRepetitions ? timedRepetitions : 1) {
     if (numBlocksPerWorkgroup == 0) throw std::runtime_error("NUM_BLOCKS_PER_WORKGROUP must be >= 1");
 }
 
-void MultiRadixSort::execute(GPUContext *gpuContext) {
+template <typename T>
+void BasicMultiRadixSort<T>::execute(GPUContext *gpuContext) {
     m_gpuContext = gpuContext;
 
     // launch shape: one contract workgroup covers NUM_BLOCKS_PER_WORKGROUP blocks of 256 keys
     m_pass = std::make_shared<MultiRadixSortPass>(gpuContext);
     m_pass->create();
+    m_pass->m_sort64Bit = sizeof(T) == 8;
     const uint32_t globalInvocationSize =
         NUM_ELEMENTS / NUM_BLOCKS_PER_WORKGROUP + (NUM_ELEMENTS % NUM_BLOCKS_PER_WORKGROUP ? 1u : 0u);
     m_pass->setGlobalInvocationSize(MultiRadixSortPass::RADIX_SORT_HISTOGRAMS, globalInvocationSize, 1, 1);
@@ -63,7 +66,7 @@ void MultiRadixSort::execute(GPUContext *gpuContext) {
     // timed region, as in the reference: first pass enqueue -> queue idle; data already resident
     std::shared_ptr<Buffer> pristine;
     if (m_timedRepetitions > 1)
-        pristine = Buffer::fillDeviceWithStagingBuffer(m_gpuContext, {NUM_ELEMENTS_BYTES}, m_elementsIn.data());
+        pristine = Buffer::fillDeviceWithStagingBuffer(m_gpuContext, {.m_sizeBytes = NUM_ELEMENTS_BYTES}, m_elementsIn.data());
     double best = 0.0;
     for (uint32_t rep = 0; rep < m_timedRepetitions; rep++) {
         if (rep > 0) {
@@ -72,7 +75,6 @@ void MultiRadixSort::execute(GPUContext *gpuContext) {
         }
         const auto begin = std::chrono::steady_clock::now();
         Semaphore awaitBeforeExecution = NULL_SEMAPHORE;
-        const uint32_t NUM_ITERATIONS = 4;  // four 8-bit digits of a 32-bit key
         for (uint32_t i = 0; i < NUM_ITERATIONS; i++) {
             m_pass->m_pushConstantsHistogram.g_shift = 8 * i;
             m_pass->m_pushConstants.g_shift = 8 * i;
@@ -95,7 +97,8 @@ void MultiRadixSort::execute(GPUContext *gpuContext) {
     m_pass->release();
 }
 
-void MultiRadixSort::prepareBuffers() {
+template <typename T>
+void BasicMultiRadixSort<T>::prepareBuffers() {
     generateRandomNumbers(m_elementsIn, NUM_ELEMENTS, m_seed, m_reference28BitKeys);
     m_buffers[0] = Buffer::fillDeviceWithStagingBuffer(
         m_gpuContext, {.m_sizeBytes = NUM_ELEMENTS_BYTES, .m_name = "radixSort.elementBuffer0"}, m_elementsIn.data());
@@ -108,33 +111,46 @@ void MultiRadixSort::prepareBuffers() {
         m_gpuContext, Buffer::BufferSettings{.m_sizeBytes = histogramBytes, .m_name = "radixSort.histogramsBuffer"});
 }
 
-void MultiRadixSort::verify(std::vector<SORT_TYPE> &reference) {
-    std::vector<SORT_TYPE> data(NUM_ELEMENTS);
-    m_buffers[0]->downloadWithStagingBuffer(data.data());  // four passes: the result is back in buffer0
+template <typename T>
+void BasicMultiRadixSort<T>::verify(std::vector<T> &reference) {
+    std::vector<T> data(NUM_ELEMENTS);
+    m_buffers[0]->downloadWithStagingBuffer(data.data());  // an even number of passes: the result is back in buffer0
     testSort(reference, data);
 }
 
-void MultiRadixSort::releaseBuffers() {
+template <typename T>
+void BasicMultiRadixSort<T>::releaseBuffers() {
     for (const auto &buffer : m_buffers)
         if (buffer) buffer->release();
 }
 
-void MultiRadixSort::generateRandomNumbers(std::vector<SORT_TYPE> &buffer, uint32_t numElements, uint32_t seed,
+template <typename T>
+void BasicMultiRadixSort<T>::generateRandomNumbers(std::vector<T> &buffer, uint32_t numElements, uint32_t seed,
                                            bool reference28BitKeys) {
     std::mt19937 gen(seed);
     buffer.resize(numElements);
-    // reference-faithful range [0, 0x0FFFFFFF] == raw >> 4 under libstdc++'s uniform_int_distribution
-    const uint32_t drop = reference28BitKeys ? 4u : 0u;
-    for (auto &key : buffer) key = static_cast<SORT_TYPE>(gen()) >> drop;
+    // reference-faithful ranges: [0, 0x0FFFFFFF] (32 bit) / [0, 0x0FFFFFFFFFFF] (64 bit), i.e. the top 4 / 20 bits clear
+    const uint32_t drop = reference28BitKeys ? (sizeof(T) == 8 ? 20u : 4u) : 0u;
+    const auto draw = [](std::mt19937 &g) -> T {
+        if constexpr (sizeof(T) == 8) {
+            const uint64_t hi = g();
+            return static_cast<T>((hi << 32) | g());
+        } else {
+            return static_cast<T>(g());
+        }
+    };
+    for (auto &key : buffer) key = draw(gen) >> drop;
 }
 
-double MultiRadixSort::sort(std::vector<SORT_TYPE> &buffer) {
+template <typename T>
+double BasicMultiRadixSort<T>::sort(std::vector<T> &buffer) {
     const auto begin = std::chrono::steady_clock::now();
     std::sort(buffer.begin(), buffer.end());
     return elapsedMs(begin, std::chrono::steady_clock::now());
 }
 
-bool MultiRadixSort::testSort(std::vector<SORT_TYPE> &reference, std::vector<SORT_TYPE> &outBuffer,
+template <typename T>
+bool BasicMultiRadixSort<T>::testSort(std::vector<T> &reference, std::vector<T> &outBuffer,
                               const char *printPrefix) {
     if (reference.size() != outBuffer.size()) {
         std::cerr << printPrefix << "reference.size() != outBuffer.size()" << std::endl;
@@ -150,5 +166,8 @@ bool MultiRadixSort::testSort(std::vector<SORT_TYPE> &reference, std::vector<SOR
     std::cout << printPrefix << "Test passed." << std::endl;
     return true;
 }
+
+template class BasicMultiRadixSort<uint32_t>;
+template class BasicMultiRadixSort<uint64_t>;
 
 }  // namespace engine
