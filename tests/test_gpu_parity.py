@@ -594,3 +594,49 @@ def test_u64_through_the_host_mirrors(gpu_context, oracle):
     for args in (["1000000", "32", "1", "1", "full", "64bit"], ["300001", "7", "2", "1", "28bit", "64bit"]):
         p = subprocess.run([str(exes[0]), *args], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0 and "64bit numbers." in p.stdout and "[MultiRadixSort] Test passed." in p.stdout, p.stdout + p.stderr
+
+
+@pytest.mark.parametrize("n", [2 ** 31 + 12345, 2 ** 32 - 1])
+def test_maximum_sizes_index_arithmetic(gpu_context, n):
+    """g_num_elements is a uint32 (push constant): sort up to 2^32 - 1 keys (17 GB per buffer) and check the
+    size-independent properties on the device: strictly increasing (the input is a bijection image, so all keys
+    are distinct) and the same order-independent fingerprint as the input."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", gpu_context.device_ordinal)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 12 * n + (8 << 30):
+        pytest.skip("not enough free HBM for the maximum-size test")
+    chunks = []
+    step = 1 << 28
+    for a in range(0, n, step):  # keys[i] = (i * 2654435761) mod 2^32, an injective map on [0, 2^32)
+        i = torch.arange(a, min(a + step, n), dtype=torch.int64, device=dev)
+        chunks.append(((i * 2654435761) & 0xFFFFFFFF).to(torch.int32))  # wraps into the int32 bit pattern
+        del i
+    keys = torch.cat(chunks)
+    del chunks
+    mask = torch.tensor(0xFFFFFFFF, dtype=torch.int64, device=dev)
+
+    def sums(t):  # (sum, sum of squares mod 2^61-ish): an order-independent fingerprint of the multiset
+        s, q = 0, 0
+        for a in range(0, n, step):
+            u = t[a:a + step].to(torch.int64) & mask
+            s += int(u.sum().item())
+            q += int(((u & 0xFFFF) * (u >> 16)).sum().item())
+            del u
+        return s, q
+
+    before = sums(keys)
+    tmp = torch.empty_like(keys)
+    torch.cuda.synchronize()
+    k0 = vrs.Buffer(gpu_context, S(4 * n), device_ptr=keys.data_ptr())
+    k1 = vrs.Buffer(gpu_context, S(4 * n), device_ptr=tmp.data_ptr())
+    gpu_context.check(gpu_context.lib.vrs_sort_keys_u32(gpu_context.handle, k0.handle, k1.handle, n))
+    gpu_context.waitIdle()
+    assert sums(keys) == before
+    flip = torch.tensor(-2 ** 31, dtype=torch.int32, device=dev)
+    for a in range(0, n - 1, step):
+        seg = keys[a:min(a + step + 1, n)] ^ flip  # unsigned order on int32 storage
+        assert bool((seg[1:] > seg[:-1]).all().item()), f"not strictly increasing in [{a}, {a + step}]"
+        del seg
+    k0.release()
+    k1.release()
