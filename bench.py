@@ -208,6 +208,21 @@ def bench_single(args):
     return result
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line
+    there.  Route fd 1 to fd 2 while the process group initialises."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def bench_multi(args):
     import torch
     import torch.distributed as dist
@@ -220,7 +235,11 @@ def bench_multi(args):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    with _StdoutToStderr():
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        warm = torch.zeros(8, dtype=torch.int64, device=dev)
+        dist.all_reduce(warm)  # brings the communicator up (and its banner out) now
+        torch.cuda.synchronize()
     n, B, K, W = args.n, args.blocks, args.steps, args.warmup
     shard = mt19937_keys(1000 + rank, n)  # shard g uses seed 1000+g
     pristine = torch.from_numpy(shard.view(np.int32)).to(dev)
@@ -228,7 +247,8 @@ def bench_multi(args):
     batches = [torch.empty_like(pristine) for _ in range(nbuf)]
     cap = int(n * 1.25) + 4096
     backend = HipLocalSortBackend(local, capacity=cap, blocks_per_workgroup=B)
-    sorter = RangeShardedSort(backend, recv_capacity=cap, make_empty=lambda m: torch.empty(m, dtype=torch.int32, device=dev))
+    sorter = RangeShardedSort(backend, recv_capacity=cap, make_empty=lambda m: torch.empty(m, dtype=torch.int32, device=dev),
+                              rounds=args.rounds if world > 1 or args.rounds_forced else 1)
 
     def rearm():
         for b in batches:
@@ -287,6 +307,7 @@ def bench_multi(args):
             "config": {"workload": f"{world} x {n} uniform random uint32 keys (std::mt19937 seed 1000+rank), sharded by key "
                                    f"range: top-byte partition pass, RCCL all-to-all over xGMI, local 4-pass multi_radixsort",
                        "num_elements_per_gpu": n, "num_blocks_per_workgroup": B, "parallelism": f"range-sharded x{world}",
+                       "exchange_rounds": sorter.rounds,
                        "hbm_bytes_per_key": 60},
             "roofline": {"bound": "hbm", "achieved": round(60 * n * K / elapsed / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(60 * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
@@ -308,6 +329,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=32, help="NUM_BLOCKS_PER_WORKGROUP")
     ap.add_argument("--rank-mode", type=int, default=0, help="0 auto, 1 ballot, 2 LDS atomic")
     ap.add_argument("--variant", type=int, default=0, help="scatter variant code (tuning)")
+    ap.add_argument("--rounds", type=int, default=4, help="multi-GPU: sub-ranges per rank (exchange/sort pipelining)")
+    ap.add_argument("--rounds-forced", action="store_true", help="use --rounds even at world size 1 (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

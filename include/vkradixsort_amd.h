@@ -75,7 +75,8 @@ int vrs_device_info(vrs_context ctx, char *name, size_t name_cap, int *compute_u
  * MultiRadixSort.cpp:83-95).  size_t, not the reference's uint32 byte size (Buffer.h:17). */
 int vrs_buffer_create(vrs_context ctx, size_t size_bytes, vrs_buffer *out_buf);
 /* Wraps caller-owned device memory (hipMalloc / torch tensor); release does not free it.
- * `device_ptr` must be 16-byte aligned.  ("own usage" scenario, README.md:151-241.) */
+ * `device_ptr` must be aligned to the element size (4 bytes; 8 for uint64 keys); 16-byte aligned bases
+ * (every hipMalloc / torch allocation) take the fastest load path.  ("own usage", README.md:151-241.) */
 int vrs_buffer_wrap(vrs_context ctx, void *device_ptr, size_t size_bytes, vrs_buffer *out_buf);
 /* Idempotent (Buffer::release, Buffer.h:36-45).  Also frees the handle. */
 int vrs_buffer_release(vrs_buffer buf);

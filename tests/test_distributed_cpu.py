@@ -53,7 +53,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_per_rank, mode, q):
+def _worker(rank, world, port, n_per_rank, mode, q, rounds=4):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         import torch
@@ -84,7 +84,7 @@ def _worker(rank, world, port, n_per_rank, mode, q):
         else:  # skewed: rank 0 holds only large keys, rank 1 only small ones
             shard = rs.randint(0, 2 ** 31, n_per_rank, dtype=np.uint32) + (np.uint32(2 ** 31) if rank == 0 else np.uint32(0))
         sorter = RangeShardedSort(NumpyBackend(), recv_capacity=2 * n_per_rank * world,
-                                  make_empty=lambda n: torch.empty(n, dtype=torch.int32))
+                                  make_empty=lambda n: torch.empty(n, dtype=torch.int32), rounds=rounds)
         res = sorter.step(torch.from_numpy(shard.view(np.int32).copy()), n_per_rank)
         out = res.keys[:res.count].numpy().view(np.uint32).copy()
         gathered = [None] * world
@@ -102,14 +102,15 @@ def _worker(rank, world, port, n_per_rank, mode, q):
         raise
 
 
-@pytest.mark.parametrize("mode", ["uniform", "28bit", "skewed"])
-def test_range_sharded_sort_world2_gloo(mode):
+@pytest.mark.parametrize("mode,world,rounds", [("uniform", 2, 4), ("28bit", 2, 4), ("skewed", 2, 4), ("uniform", 2, 1),
+                                               ("uniform", 3, 2)])
+def test_range_sharded_sort_gloo(mode, world, rounds):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     n = 20000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, mode, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, mode, q, rounds)) for r in range(world)]
     for p in procs:
         p.start()
     result = q.get(timeout=180)
@@ -117,6 +118,6 @@ def test_range_sharded_sort_world2_gloo(mode):
         p.join(timeout=60)
     assert result[0] is True, result
     ok, sizes, bounds = result
-    assert sum(sizes) == 2 * n and bounds[0] == 0 and bounds[-1] == 256
+    assert sum(sizes) == world * n and bounds[0] == 0 and bounds[-1] == 256
     if mode == "uniform":
         assert abs(sizes[0] - n) < 0.05 * n  # balanced ranges

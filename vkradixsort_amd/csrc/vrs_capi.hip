@@ -235,6 +235,8 @@ int run_sort_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs
                            "histograms")))
         return rc;
     if (keys_in->ptr == keys_out->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "keys_in and keys_out alias");
+    if ((reinterpret_cast<uintptr_t>(keys_in->ptr) | reinterpret_cast<uintptr_t>(keys_out->ptr)) & (key_bytes - 1))
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "key buffers must be aligned to the key size");
     if (pairs) {
         if ((rc = check_buffer(ctx, values_in, values_size, "values_in"))) return rc;
         if ((rc = check_buffer(ctx, values_out, values_size, "values_out"))) return rc;
@@ -364,8 +366,8 @@ int vrs_buffer_wrap(vrs_context ctx, void *device_ptr, size_t size_bytes, vrs_bu
     if (!ctx || !out_buf) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or out_buf is NULL");
     *out_buf = nullptr;
     if (!device_ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "device_ptr is NULL");
-    if (reinterpret_cast<uintptr_t>(device_ptr) & 15u)
-        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "device_ptr must be 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(device_ptr) & 3u)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "device_ptr must be 4-byte aligned");
     vrs_buffer b = new (std::nothrow) vrs_buffer_t();
     if (!b) return fail(ctx, VRS_ERROR_OUT_OF_MEMORY, "host allocation failed");
     b->ctx = ctx;
@@ -446,6 +448,8 @@ static int run_histogram_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer h
     if (pc->g_num_elements == 0) return VRS_OK;
     if ((rc = check_buffer(ctx, keys_in, static_cast<size_t>(pc->g_num_elements) * key_bytes, "keys_in")))
         return rc;
+    if (reinterpret_cast<uintptr_t>(keys_in->ptr) & (key_bytes - 1))
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "key buffers must be aligned to the key size");
     if ((rc = check_buffer(ctx, histograms,
                            static_cast<size_t>(pc->g_num_workgroups) * VRS_RADIX_SORT_BINS * sizeof(uint32_t),
                            "histograms")))

@@ -162,10 +162,14 @@ __global__ __launch_bounds__(kThreads) void histogram_kernel(const K *__restrict
     if (tile_begin < n) {
         const uint64_t tile_keys = static_cast<uint64_t>(B) * kThreads;
         const uint32_t len = static_cast<uint32_t>(tile_begin + tile_keys <= n ? tile_keys : n - tile_begin);
-        // tile_begin is a multiple of 256 keys (>= 1 KiB), so 16-byte loads are aligned whenever the
-        // buffer base is (checked by the host).
-        const Vec *v = reinterpret_cast<const Vec *>(keys + tile_begin);
-        const uint32_t nvec = len / V;
+        // 16-byte loads need a 16-byte aligned address; tile_begin is a multiple of 256 keys, so the misalignment
+        // is that of the buffer base (a sub-range of a larger allocation may start anywhere): peel `head` keys.
+        const K *tile = keys + tile_begin;
+        const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(tile) / sizeof(K)) % V);
+        const uint32_t head = min(mis ? V - mis : 0u, len);
+        if (tid < head) atomicAdd(&s_hist[digit_of(tile[tid], shift)], 1u);
+        const Vec *v = reinterpret_cast<const Vec *>(tile + head);
+        const uint32_t nvec = (len - head) / V;
         constexpr uint32_t kStep = kThreads * UNROLL;  // vectors per fully unrolled step
         uint32_t i0 = 0;
         for (; i0 + kStep <= nvec; i0 += kStep) {  // every lane of every wave holds valid vectors
@@ -180,8 +184,8 @@ __global__ __launch_bounds__(kThreads) void histogram_kernel(const K *__restrict
 #pragma unroll
             for (int k = 0; k < static_cast<int>(V); ++k) atomicAdd(&s_hist[digit_of(KeyVec<K>::get(q, k), shift)], 1u);
         }
-        const uint32_t tail = nvec * V + tid;  // at most V-1 keys
-        if (tail < len) atomicAdd(&s_hist[digit_of(keys[tile_begin + tail], shift)], 1u);
+        const uint32_t tail = head + nvec * V + tid;  // at most V-1 keys
+        if (tail < len) atomicAdd(&s_hist[digit_of(tile[tail], shift)], 1u);
     }
     __syncthreads();
     hist[static_cast<size_t>(w) * kBins + tid] = s_hist[tid];
@@ -740,6 +744,11 @@ __device__ __forceinline__ uint32_t transform_key(uint32_t x, int mode) {
 }
 
 __global__ __launch_bounds__(kThreads) void transform_keys_kernel(uint32_t *keys, uint32_t n, int mode) {
+    if (reinterpret_cast<uintptr_t>(keys) & 15u) {  // sub-range of a larger allocation: plain 4-byte accesses
+        for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
+            keys[i] = transform_key(keys[i], mode);
+        return;
+    }
     uint4 *v = reinterpret_cast<uint4 *>(keys);
     const uint32_t nvec = n >> 2;
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < nvec; i += gridDim.x * kThreads) {

@@ -7,12 +7,14 @@ The reference is single-GPU; this is the build's multi-GPU path.  One process pe
                   by top byte, so every key range [byte lo, byte hi) is one contiguous slice
   2. splitters    ONE all-gather of every rank's 256 top-byte counts (world x 2 KiB, latency bound); each rank
                   derives the same world-1 byte boundaries plus its own send and receive counts from it
-  3. exchange     ONE variable-size all-to-all of the keys (dist.all_to_all_single with split sizes: grouped
-                  send/recv on every xGMI link at once)
-  4. merge step   the received runs are sorted locally by the four-pass multi_radixsort
+  3. exchange     the range of every rank is cut into R sub-ranges ("rounds", still top-byte boundaries); round r
+                  moves every rank's keys of sub-range r with one batch of grouped send/recv (all xGMI links at once)
+  4. merge step   round r's keys are sorted by the four-pass multi_radixsort WHILE round r+1 is on the wire;
+                  the sub-ranges are disjoint and ascending, so their concatenation is the sorted range -- no merge
 
 Rank g ends up holding range g in ascending order; the global result is the concatenation of ranks 0..W-1.
-HBM bytes per key: 12 (step 1) + 48 (step 4) = 60, plus one trip over xGMI for (world-1)/world of the keys.
+HBM bytes per key: 12 (step 1) + 48 (step 4) = 60, plus one trip over xGMI for (world-1)/world of the keys; only the
+first round's transfer and the last round's sort are not overlapped.
 
 The device work is behind `LocalSortBackend`; the product backend drives the C ABI on torch's current stream.
 The CPU tests substitute a numpy backend to exercise steps 2-3 under gloo (the product never does).
@@ -90,7 +92,8 @@ class HipLocalSortBackend(LocalSortBackend):
         self.ctx = engine.GPUContext(device_index, stream=torch.cuda.current_stream().cuda_stream)
         self.ctx.init()
         self.capacity = int(capacity)
-        self.scratch = torch.empty(self.capacity, dtype=torch.int32, device=self.device)
+        self.grouped = torch.empty(self.capacity, dtype=torch.int32, device=self.device)  # output of step 1, read by the sends
+        self.scratch = torch.empty(self.capacity, dtype=torch.int32, device=self.device)  # ping-pong partner of the local sorts
         w_max = self.ctx.lib.vrs_workgroup_count(self.capacity, self.B)
         self.hist = torch.empty(max(w_max, 1) * RADIX_SORT_BINS, dtype=torch.int32, device=self.device)
         self._wrapped = {}
@@ -103,6 +106,10 @@ class HipLocalSortBackend(LocalSortBackend):
 
     def _buf(self, t):
         key = (t.data_ptr(), t.numel())
+        if key not in self._wrapped and len(self._wrapped) > 256:  # sub-range views differ from step to step
+            for b in self._wrapped.values():
+                b[0].release()
+            self._wrapped.clear()
         if key not in self._wrapped:
             S = self.engine.Buffer.BufferSettings
             self._wrapped[key] = (self.engine.Buffer(self.ctx, S(t.numel() * 4), device_ptr=t.data_ptr()), t)
@@ -119,11 +126,11 @@ class HipLocalSortBackend(LocalSortBackend):
     def group_by_top_byte(self, keys, n):
         if n > self.capacity:
             raise ValueError("shard larger than the backend capacity")
-        self._pass(keys, self.scratch, n, 24)
+        self._pass(keys, self.grouped, n, 24)
         digit_base = np.empty(RADIX_SORT_BINS, dtype=np.uint32)
         self.ctx.check(self.ctx.lib.vrs_multi_radixsort_digit_offsets(self.ctx.handle,
                                                                      digit_base.ctypes.data_as(ctypes.c_void_p)))
-        return self.scratch, digit_base
+        return self.grouped, digit_base
 
     def sort(self, keys, n):
         if n == 0:
@@ -140,7 +147,7 @@ class HipLocalSortBackend(LocalSortBackend):
 class RangeShardedSort:
     """Steps 1-4 over a torch.distributed process group."""
 
-    def __init__(self, backend: LocalSortBackend, recv_capacity: int, make_empty, process_group=None):
+    def __init__(self, backend: LocalSortBackend, recv_capacity: int, make_empty, process_group=None, rounds: int = 4):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -148,12 +155,14 @@ class RangeShardedSort:
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
+        self.rounds = max(1, min(int(rounds), RADIX_SORT_BINS // max(self.world, 1)))
         self.recv_capacity = int(recv_capacity)
         self.recv = make_empty(self.recv_capacity)  # int32 storage for uint32 keys
         self.device = self.recv.device
 
     def step(self, keys, n: int) -> StepResult:
         torch, dist = self.torch, self.dist
+        world, R, me = self.world, self.rounds, self.rank
         # 1. local step
         grouped, digit_base = self.backend.group_by_top_byte(keys, n)
         base = np.concatenate([digit_base.astype(np.int64), [n]])
@@ -161,19 +170,50 @@ class RangeShardedSort:
         # 2. ONE small collective: everybody learns everybody's 256 top-byte counts (world x 2 KiB), from which
         #    each rank derives the same splitters, its send counts and its receive counts without further traffic
         mine = torch.from_numpy(local_counts.copy()).to(self.device)
-        table = torch.empty(self.world * RADIX_SORT_BINS, dtype=mine.dtype, device=self.device)
+        table = torch.empty(world * RADIX_SORT_BINS, dtype=mine.dtype, device=self.device)
         dist.all_gather_into_tensor(table, mine, group=self.group)
-        all_counts = table.cpu().numpy().reshape(self.world, RADIX_SORT_BINS)
-        bounds = plan_splitters(all_counts.sum(axis=0), self.world)
+        all_counts = table.cpu().numpy().reshape(world, RADIX_SORT_BINS)
+        # world*R parts of (almost) equal size; part q*R + r = rank q, round r
+        parts = plan_splitters(all_counts.sum(axis=0), world * R)
+        bounds = parts[::R]
         send_counts = send_counts_from_digit_base(digit_base, n, bounds)
-        lo, hi = int(bounds[self.rank]), int(bounds[self.rank + 1])
-        recv_counts = all_counts[:, lo:hi].sum(axis=1).astype(np.int64)
-        total = int(recv_counts.sum())
+        # what I receive in round r from source s, and where it lands: rounds ascending, sources ascending
+        my_parts = parts[me * R:(me + 1) * R + 1]
+        recv_rs = np.stack([all_counts[:, my_parts[r]:my_parts[r + 1]].sum(axis=1) for r in range(R)]).astype(np.int64)
+        round_total = recv_rs.sum(axis=1)
+        round_off = np.concatenate([[0], np.cumsum(round_total)])
+        total = int(round_off[-1])
         if total > self.recv_capacity:
             raise RuntimeError(f"rank {self.rank}: receives {total} keys, capacity {self.recv_capacity}")
-        # 3. exchange the keys: one variable-size all-to-all (grouped send/recv over every xGMI link at once)
-        dist.all_to_all_single(self.recv[:total], grouped[:n], output_split_sizes=[int(c) for c in recv_counts],
-                               input_split_sizes=[int(c) for c in send_counts], group=self.group)
-        # 4. merge step: local four-pass sort of the received runs
-        out = self.backend.sort(self.recv, total)
-        return StepResult(out, total, bounds, send_counts, recv_counts)
+
+        def issue(r):
+            """round r: grouped send/recv with every peer; my own slice is a device copy"""
+            ops = []
+            off = int(round_off[r])
+            for src in range(world):
+                cnt = int(recv_rs[r, src])
+                if cnt and src != me:
+                    ops.append(dist.P2POp(dist.irecv, self.recv[off:off + cnt], src, group=self.group))
+                if cnt and src == me:
+                    a = int(base[my_parts[r]])
+                    self.recv[off:off + cnt].copy_(grouped[a:a + cnt])
+                off += cnt
+            for dst in range(world):
+                lo, hi = int(parts[dst * R + r]), int(parts[dst * R + r + 1])
+                a, b = int(base[lo]), int(base[hi])
+                if b > a and dst != me:
+                    ops.append(dist.P2POp(dist.isend, grouped[a:b], dst, group=self.group))
+            return dist.batch_isend_irecv(ops) if ops else []
+
+        # 3 + 4. round r+1 is put on the wire before round r is sorted
+        pending = issue(0)
+        for r in range(R):
+            nxt = issue(r + 1) if r + 1 < R else []
+            for w in pending:
+                w.wait()
+            cnt = int(round_total[r])
+            if cnt:
+                off = int(round_off[r])
+                self.backend.sort(self.recv[off:off + cnt], cnt)
+            pending = nxt
+        return StepResult(self.recv, total, bounds, send_counts, recv_rs.sum(axis=0))
