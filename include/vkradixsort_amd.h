@@ -140,6 +140,15 @@ int vrs_multi_radixsort_u64(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys
 int vrs_multi_radixsort_pairs_u64(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out,
                                   vrs_buffer values_in, vrs_buffer values_out, vrs_buffer histograms,
                                   const vrs_push_constants *pc);
+/*
+ * Range partition (build extension for the multi-GPU key-range exchange; no reference counterpart): one
+ * stable pass that groups uint32 keys by range instead of by digit.  `splitters` holds `num_splitters` <= 255
+ * ascending uint32 values on the device; a key goes to range r = number of splitters <= key.  keys_out holds
+ * range 0's keys, then range 1's, ... each in input order; vrs_multi_radixsort_digit_offsets then returns
+ * the first position of every range (entries 0..num_splitters).  Asynchronous.
+ */
+int vrs_range_partition(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs_buffer splitters,
+                        uint32_t num_splitters, uint32_t num_elements);
 /* vkQueueWaitIdle on the compute queue (MultiRadixSort.cpp:62). */
 int vrs_queue_wait_idle(vrs_context ctx);
 

@@ -640,3 +640,31 @@ def test_maximum_sizes_index_arithmetic(gpu_context, n):
         del seg
     k0.release()
     k1.release()
+
+
+@pytest.mark.parametrize("n,nsplit", [(1, 0), (1000, 1), (100003, 7), (1 << 20, 31), (3000017, 255), (500000, 3)])
+def test_range_partition_by_splitters(gpu_context, n, nsplit):
+    """vrs_range_partition: stable grouping by range r = #splitters <= key (the multi-GPU exchange's robust local step)."""
+    ctx, lib = gpu_context, gpu_context.lib
+    rs = np.random.RandomState(n + nsplit)
+    keys = rs.randint(0, 2 ** 32, n, dtype=np.uint32)
+    if n > 1000:
+        keys[: n // 3] = rs.randint(0, 1 << 12, n // 3, dtype=np.uint32)  # heavy skew towards small keys
+        keys[-5:] = 0xFFFFFFFF  # collides with the padding key
+    splitters = np.sort(rs.choice(keys, size=nsplit, replace=True)).astype(np.uint32) if nsplit else np.zeros(0, np.uint32)
+    if nsplit >= 7:
+        splitters[2] = splitters[3]  # an empty range
+    kin = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)
+    kout = vrs.Buffer(ctx, S(4 * n))
+    sp = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * max(nsplit, 1)), np.concatenate([splitters, np.zeros(1, np.uint32)])[:max(nsplit, 1)])
+    ctx.check(lib.vrs_range_partition(ctx.handle, kin.handle, kout.handle, sp.handle, nsplit, n))
+    out = np.empty(n, np.uint32)
+    kout.downloadWithStagingBuffer(out)
+    base = np.empty(256, np.uint32)
+    ctx.check(lib.vrs_multi_radixsort_digit_offsets(ctx.handle, base.ctypes.data_as(ctypes.c_void_p)))
+    bucket = np.searchsorted(splitters, keys, side="right")
+    assert np.array_equal(out, keys[np.argsort(bucket, kind="stable")])
+    counts = np.bincount(bucket, minlength=256)
+    assert np.array_equal(base, np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32))
+    for b in (kin, kout, sp):
+        b.release()

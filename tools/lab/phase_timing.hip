@@ -39,8 +39,8 @@ void run(const char *name, uint32_t n, uint32_t B, uint32_t *d_in, uint32_t *d_o
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((vrs::scatter_kernel<ITEMS, WAVES, false, RANK, OCC>), dim3(W), dim3(WAVES * 64), 0, 0, d_in, d_out,
-                           nullptr, nullptr, sc.offsets, n, 0u, W, B, 1);
+        hipLaunchKernelGGL((vrs::scatter_kernel<uint32_t, ITEMS, WAVES, false, RANK, OCC>), dim3(W), dim3(WAVES * 64), 0, 0, d_in, d_out,
+                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)sc.offsets, n, 0u, W, B, 1, (const uint32_t *)nullptr, 1u, (const uint32_t *)nullptr, 0u);
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
     }

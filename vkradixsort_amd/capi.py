@@ -77,6 +77,7 @@ _SIGNATURES = [
     ("vrs_multi_radixsort_u64", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
     ("vrs_multi_radixsort_pairs_u64", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
+    ("vrs_range_partition", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_uint32]),
     ("vrs_multi_radixsort_digit_offsets", c_int, [c_void_p, c_void_p]),
     ("vrs_queue_wait_idle", c_int, [c_void_p]),
     ("vrs_single_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),

@@ -638,6 +638,48 @@ int vrs_profile_query(vrs_context ctx, int kernel_id, uint64_t *launches, double
     return VRS_OK;
 }
 
+int vrs_range_partition(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs_buffer splitters,
+                        uint32_t num_splitters, uint32_t num_elements) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (num_splitters > 255) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "at most 255 splitters (256 ranges)");
+    const uint32_t n = num_elements;
+    if (n == 0) return VRS_OK;
+    int rc;
+    const size_t keys_size = static_cast<size_t>(n) * sizeof(uint32_t);
+    if ((rc = check_buffer(ctx, keys_in, keys_size, "keys_in"))) return rc;
+    if ((rc = check_buffer(ctx, keys_out, keys_size, "keys_out"))) return rc;
+    if ((rc = check_buffer(ctx, splitters, static_cast<size_t>(num_splitters) * sizeof(uint32_t), "splitters"))) return rc;
+    if (keys_in->ptr == keys_out->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "keys_in and keys_out alias");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t B = launch_tile_blocks(4);
+    const uint32_t W = vrs_workgroup_count(n, B);
+    // the [W][256] bucket-count table lives in the context (same scratch as the sub-tile histograms)
+    if (W > ctx->sub_hist_rows) {
+        if (ctx->sub_hist) VRS_HIP(ctx, hipFree(ctx->sub_hist));
+        ctx->sub_hist = nullptr;
+        ctx->sub_hist_rows = 0;
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sub_hist),
+                               static_cast<size_t>(W) * VRS_RADIX_SORT_BINS * sizeof(uint32_t)));
+        ctx->sub_hist_rows = W;
+    }
+    ctx->sub_cache.valid = false;
+    if ((rc = ensure_scratch(ctx, W))) return rc;
+    vrs::LaunchEvents ev;
+    if ((rc = profile_events(ctx, VRS_KERNEL_HISTOGRAM, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_histograms(ctx->stream, keys_in->ptr, ctx->sub_hist, n, 0, W, B, ev, nullptr, 4, splitters->ptr,
+                                        num_splitters));
+    if ((rc = profile_events(ctx, VRS_KERNEL_PREFIX, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_prefix(ctx->stream, ctx->sub_hist, ctx->scratch, W, ev));
+    ctx->last_offsets_workgroups = W;
+    ctx->last_offsets_stride = 1;
+    if ((rc = profile_events(ctx, VRS_KERNEL_SCATTER, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_range_partition(ctx->stream, static_cast<const uint32_t *>(keys_in->ptr),
+                                             static_cast<uint32_t *>(keys_out->ptr), ctx->scratch.offsets, n, W,
+                                             ctx->xcd_remap, ctx->scatter.atomic_rank,
+                                             static_cast<const uint32_t *>(splitters->ptr), num_splitters, ev));
+    return VRS_OK;
+}
+
 int vrs_multi_radixsort_digit_offsets(vrs_context ctx, void *host_u32x256) {
     if (!ctx || !host_u32x256) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or output is NULL");
     if (ctx->last_offsets_workgroups == 0)

@@ -36,7 +36,12 @@ uint32_t prefix_chunk_tiles(uint32_t num_workgroups);
 // keys are uint32 (key_bytes == 4) or uint64 (key_bytes == 8)
 hipError_t launch_histograms(hipStream_t stream, const void *keys_in, uint32_t *hist, uint32_t n, uint32_t shift,
                              uint32_t W, uint32_t B, LaunchEvents ev = {}, const uint32_t *tile_order = nullptr,
-                             int key_bytes = 4);
+                             int key_bytes = 4, const void *splitters = nullptr, uint32_t num_splitters = 0);
+
+// range partition of uint32 keys (8192-key tiles, B = 32): stable scatter by bucket = #splitters <= key
+hipError_t launch_range_partition(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *offsets,
+                                  uint32_t n, uint32_t W, bool xcd_remap, bool atomic_rank, const uint32_t *splitters,
+                                  uint32_t num_splitters, LaunchEvents ev = {});
 
 hipError_t launch_prefix(hipStream_t stream, const uint32_t *hist, const PrefixScratch &scratch,
                          uint32_t W, LaunchEvents ev = {});

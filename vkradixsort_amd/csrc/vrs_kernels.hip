@@ -18,6 +18,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 // Launch with optional timing events bound to the dispatch packet itself (hipExtLaunchKernel): unlike
 // hipEventRecord brackets this adds no barrier packets between dependent kernels.
 #define VRS_LAUNCH(kernel, grid, block, stream, ev, ...)                                                        \
@@ -74,6 +76,36 @@ struct KeyVec<uint64_t> {
     static __device__ __forceinline__ uint64_t get(const ulonglong2 &v, int i) { return i == 0 ? v.x : v.y; }
 };
 
+// What a pass buckets by.  RadixDigit: the 8-bit digit at `shift` (the reference's passes).  SplitDigit: the
+// index of the key range a key falls in, given up to 255 ascending splitters staged in LDS -- the multi-GPU
+// range partition for keys whose top byte is too skewed to cut at byte boundaries (build extension).
+template <typename K>
+struct RadixDigit {
+    uint32_t shift;
+    __device__ __forceinline__ uint32_t operator()(K key) const { return digit_of(key, shift); }
+};
+template <typename K>
+struct SplitDigit {
+    const K *splitters;  // LDS, ascending, 256 slots (slots >= count are never counted)
+    uint32_t count;
+    // number of splitters <= key, in eight fixed halving steps (branch-free upper bound over 255 slots)
+    __device__ __forceinline__ uint32_t operator()(K key) const {
+        uint32_t pos = 0;
+#pragma unroll
+        for (uint32_t step = 128; step >= 1; step >>= 1) {
+            const uint32_t probe = pos + step - 1;
+            pos += (probe < count && splitters[probe] <= key) ? step : 0u;
+        }
+        return pos;
+    }
+};
+// stage `count` splitters into LDS (all threads of the workgroup call this; ends with a barrier)
+template <typename K>
+__device__ __forceinline__ void stage_splitters(K *s_split, const K *splitters, uint32_t count) {
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) s_split[i] = i < count ? splitters[i] : static_cast<K>(~static_cast<K>(0));
+    __syncthreads();
+}
+
 // Observed dispatch places workgroup b on XCD b % 8 (speed only, never correctness).  Remap so
 // that XCD x walks a CONTIGUOUS range of tiles: the partial cache lines at the two ends of every
 // digit run are then completed by the neighbouring tile inside the SAME L2.
@@ -126,12 +158,12 @@ __device__ __forceinline__ void histogram_count(uint32_t *s_hist, uint32_t key, 
 }
 
 // all 64 lanes hold a valid 16-byte vector of keys
-template <typename K>
-__device__ __forceinline__ void histogram_count_vec(uint32_t *s_hist, const typename KeyVec<K>::type &q, uint32_t shift) {
+template <typename K, typename DG>
+__device__ __forceinline__ void histogram_count_vec(uint32_t *s_hist, const typename KeyVec<K>::type &q, const DG &dg) {
     constexpr int V = KeyVec<K>::kKeys;
     uint32_t d[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) d[i] = digit_of(KeyVec<K>::get(q, i), shift);
+    for (int i = 0; i < V; ++i) d[i] = dg(KeyVec<K>::get(q, i));
     const uint32_t d0 = __builtin_amdgcn_readfirstlane(d[0]);
     uint32_t diff = 0;
 #pragma unroll
@@ -144,14 +176,25 @@ __device__ __forceinline__ void histogram_count_vec(uint32_t *s_hist, const type
     }
 }
 
-template <typename K, int UNROLL>
+template <typename K, int UNROLL, bool SPLIT>
 __global__ __launch_bounds__(kThreads) void histogram_kernel(const K *__restrict__ keys,
                                                              uint32_t *__restrict__ hist, uint32_t n,
                                                              uint32_t shift, uint32_t W, uint32_t B,
-                                                             const uint32_t *__restrict__ tile_order) {
+                                                             const uint32_t *__restrict__ tile_order,
+                                                             const K *__restrict__ splitters, uint32_t num_splitters) {
     using Vec = typename KeyVec<K>::type;
+    using DG = typename std::conditional<SPLIT, SplitDigit<K>, RadixDigit<K>>::type;
     constexpr uint32_t V = KeyVec<K>::kKeys;
     __shared__ uint32_t s_hist[kBins];
+    __shared__ K s_split[SPLIT ? 256 : 1];
+    DG dg;
+    if constexpr (SPLIT) {
+        stage_splitters(s_split, splitters, num_splitters);
+        dg.splitters = s_split;
+        dg.count = num_splitters;
+    } else {
+        dg.shift = shift;
+    }
     const uint32_t tid = threadIdx.x;
     // which tile this workgroup takes is a pure scheduling choice (cache residency), never a result
     const uint32_t w = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
@@ -167,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void histogram_kernel(const K *__restrict
         const K *tile = keys + tile_begin;
         const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(tile) / sizeof(K)) % V);
         const uint32_t head = min(mis ? V - mis : 0u, len);
-        if (tid < head) atomicAdd(&s_hist[digit_of(tile[tid], shift)], 1u);
+        if (tid < head) atomicAdd(&s_hist[dg(tile[tid])], 1u);
         const Vec *v = reinterpret_cast<const Vec *>(tile + head);
         const uint32_t nvec = (len - head) / V;
         constexpr uint32_t kStep = kThreads * UNROLL;  // vectors per fully unrolled step
@@ -177,15 +220,15 @@ __global__ __launch_bounds__(kThreads) void histogram_kernel(const K *__restrict
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) q[u] = v[i0 + u * kThreads + tid];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) histogram_count_vec<K>(s_hist, q[u], shift);
+            for (int u = 0; u < UNROLL; ++u) histogram_count_vec<K>(s_hist, q[u], dg);
         }
         for (uint32_t i = i0 + tid; i < nvec; i += kThreads) {  // ragged remainder of the tile
             const Vec q = v[i];
 #pragma unroll
-            for (int k = 0; k < static_cast<int>(V); ++k) atomicAdd(&s_hist[digit_of(KeyVec<K>::get(q, k), shift)], 1u);
+            for (int k = 0; k < static_cast<int>(V); ++k) atomicAdd(&s_hist[dg(KeyVec<K>::get(q, k))], 1u);
         }
         const uint32_t tail = head + nvec * V + tid;  // at most V-1 keys
-        if (tail < len) atomicAdd(&s_hist[digit_of(tile[tail], shift)], 1u);
+        if (tail < len) atomicAdd(&s_hist[dg(tile[tail])], 1u);
     }
     __syncthreads();
     hist[static_cast<size_t>(w) * kBins + tid] = s_hist[tid];
@@ -478,10 +521,10 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_w(uint32_t v, uint32_t 
 // Every phase is written as "issue all ITEMS independent LDS/global operations, then consume":
 // a workgroup is latency-bound (one pass over its keys, few waves), so dependent
 // read -> wait -> write chains per item are what must not appear in the ISA.
-template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, bool FULL>
+template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, bool FULL, typename DG>
 __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> &sm, const K *kin,
                                               const uint32_t *vin, K *kout, uint32_t *vout,
-                                              uint32_t valid, uint32_t shift, uint32_t &run_off) {
+                                              uint32_t valid, const DG &dg, uint32_t &run_off) {
     constexpr uint32_t THREADS = WAVES * 64;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -524,12 +567,12 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     if constexpr (RANK == RANK_ATOMIC) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i)
-            rank[i] = __hip_atomic_fetch_add(&my_hist[digit_of(key[i], shift)], 1u, __ATOMIC_RELAXED,
+            rank[i] = __hip_atomic_fetch_add(&my_hist[dg(key[i])], 1u, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            const uint32_t d = digit_of(key[i], shift);
+            const uint32_t d = dg(key[i]);
             const uint64_t peers = match_any_digit(d);
             const uint32_t below = count_below(peers);
             // all lanes read the counter, then the lowest matching lane adds the group's size with a
@@ -575,7 +618,7 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
 
     // ---- re-bucket through LDS: all counter reads first, then all key writes
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) rank[i] += my_hist[digit_of(key[i], shift)];
+    for (int i = 0; i < ITEMS; ++i) rank[i] += my_hist[dg(key[i])];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) sm.keys[rank[i]] = key[i];
     if constexpr (PAIRS) {
@@ -590,7 +633,7 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     for (int i = 0; i < ITEMS; ++i) key[i] = sm.keys[i * THREADS + tid];
     uint32_t dst[ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) dst[i] = sm.gbase[digit_of(key[i], shift)] + (i * THREADS + tid);
+    for (int i = 0; i < ITEMS; ++i) dst[i] = sm.gbase[dg(key[i])] + (i * THREADS + tid);
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         if (FULL || i * THREADS + tid < valid) kout[dst[i]] = key[i];
@@ -608,7 +651,7 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     // the next chunk's first barrier (after it zeroes the counters) separates these LDS reads from its writes
 }
 
-template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, int OCC>
+template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, int OCC, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__restrict__ keys_in,
                                                              K *__restrict__ keys_out,
                                                              const uint32_t *__restrict__ values_in,
@@ -616,8 +659,19 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
                                                              const uint32_t *__restrict__ offsets, uint32_t n,
                                                              uint32_t shift, uint32_t W, uint32_t B, int xcd_remap,
                                                              const uint32_t *__restrict__ tile_order,
-                                                             uint32_t offset_row_stride) {
+                                                             uint32_t offset_row_stride,
+                                                             const K *__restrict__ splitters, uint32_t num_splitters) {
+    using DG = typename std::conditional<SPLIT, SplitDigit<K>, RadixDigit<K>>::type;
     __shared__ ChunkSmem<K, ITEMS, WAVES, PAIRS> sm;
+    __shared__ K s_split[SPLIT ? 256 : 1];
+    DG dg;
+    if constexpr (SPLIT) {
+        stage_splitters(s_split, splitters, num_splitters);
+        dg.splitters = s_split;
+        dg.count = num_splitters;
+    } else {
+        dg.shift = shift;
+    }
     const uint32_t w = tile_order ? tile_order[blockIdx.x]
                                   : (xcd_remap ? xcd_contiguous_tile(blockIdx.x, W) : blockIdx.x);
     const uint64_t tile_begin = static_cast<uint64_t>(w) * B * kThreads;
@@ -634,9 +688,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
         const K *kin = keys_in + tile_begin + c0;
         const uint32_t *vin = PAIRS ? values_in + tile_begin + c0 : nullptr;
         if (valid == kChunk)  // workgroup-uniform
-            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, kin, vin, keys_out, values_out, valid, shift, run_off);
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, kin, vin, keys_out, values_out, valid, dg, run_off);
         else
-            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, kin, vin, keys_out, values_out, valid, shift, run_off);
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, kin, vin, keys_out, values_out, valid, dg, run_off);
     }
     VRS_MARK_FLUSH();
 }
@@ -701,14 +755,15 @@ __global__ __launch_bounds__(kThreads) void single_kernel(uint32_t *buffer0, uin
         __syncthreads();
         uint32_t run_off = block_exclusive_scan(s_hist[tid], sm.scan_tmp, tid & 63u, tid >> 6);
         __syncthreads();
+        const RadixDigit<uint32_t> dg{shift};
         for (uint32_t c0 = 0; c0 < n; c0 += kChunk) {
             const uint32_t valid = min(kChunk, n - c0);
             if (valid == kChunk)
                 scatter_chunk<uint32_t, kSingleItems, kWaves, false, RANK_BALLOT, true>(sm, in + c0, nullptr, out, nullptr, valid,
-                                                                              shift, run_off);
+                                                                              dg, run_off);
             else
                 scatter_chunk<uint32_t, kSingleItems, kWaves, false, RANK_BALLOT, false>(sm, in + c0, nullptr, out, nullptr, valid,
-                                                                               shift, run_off);
+                                                                               dg, run_off);
         }
         // the next pass reads what this pass wrote: same CU, so a workgroup barrier (with its
         // workgroup-scope fence) orders the global stores before the loads
@@ -787,14 +842,23 @@ uint32_t prefix_chunk_tiles(uint32_t W) {
 }
 
 hipError_t launch_histograms(hipStream_t stream, const void *keys_in, uint32_t *hist, uint32_t n, uint32_t shift,
-                             uint32_t W, uint32_t B, LaunchEvents ev, const uint32_t *tile_order, int key_bytes) {
+                             uint32_t W, uint32_t B, LaunchEvents ev, const uint32_t *tile_order, int key_bytes,
+                             const void *splitters, uint32_t num_splitters) {
     if (W == 0) return hipSuccess;
-    if (key_bytes == 8)
-        VRS_LAUNCH((histogram_kernel<uint64_t, 8>), dim3(W), dim3(kThreads), stream, ev,
-                   static_cast<const uint64_t *>(keys_in), hist, n, shift, W, B, tile_order);
-    else
-        VRS_LAUNCH((histogram_kernel<uint32_t, 8>), dim3(W), dim3(kThreads), stream, ev,
-                   static_cast<const uint32_t *>(keys_in), hist, n, shift, W, B, tile_order);
+    if (splitters != nullptr) {  // range partition (uint32 keys): bucket = number of splitters <= key
+        if (key_bytes != 4 || num_splitters > 255) return hipErrorInvalidValue;
+        VRS_LAUNCH((histogram_kernel<uint32_t, 8, true>), dim3(W), dim3(kThreads), stream, ev,
+                   static_cast<const uint32_t *>(keys_in), hist, n, shift, W, B, tile_order,
+                   static_cast<const uint32_t *>(splitters), num_splitters);
+    } else if (key_bytes == 8) {
+        VRS_LAUNCH((histogram_kernel<uint64_t, 8, false>), dim3(W), dim3(kThreads), stream, ev,
+                   static_cast<const uint64_t *>(keys_in), hist, n, shift, W, B, tile_order,
+                   static_cast<const uint64_t *>(nullptr), 0u);
+    } else {
+        VRS_LAUNCH((histogram_kernel<uint32_t, 8, false>), dim3(W), dim3(kThreads), stream, ev,
+                   static_cast<const uint32_t *>(keys_in), hist, n, shift, W, B, tile_order,
+                   static_cast<const uint32_t *>(nullptr), 0u);
+    }
     return hipGetLastError();
 }
 
@@ -824,12 +888,31 @@ static hipError_t launch_scatter_variant(hipStream_t stream, const void *keys_in
     const int remap = xcd_remap ? 1 : 0;
     const K *kin = static_cast<const K *>(keys_in);
     K *kout = static_cast<K *>(keys_out);
+    const K *no_split = nullptr;
     if (values_in != nullptr)
         VRS_LAUNCH((scatter_kernel<K, ITEMS, WAVES, true, RANK, OCC>), dim3(W), dim3(WAVES * 64), stream, ev, kin, kout,
-                   values_in, values_out, offsets, n, shift, W, B, remap, tile_order, offset_row_stride);
+                   values_in, values_out, offsets, n, shift, W, B, remap, tile_order, offset_row_stride, no_split, 0u);
     else
         VRS_LAUNCH((scatter_kernel<K, ITEMS, WAVES, false, RANK, OCC>), dim3(W), dim3(WAVES * 64), stream, ev, kin, kout,
-                   values_in, values_out, offsets, n, shift, W, B, remap, tile_order, offset_row_stride);
+                   values_in, values_out, offsets, n, shift, W, B, remap, tile_order, offset_row_stride, no_split, 0u);
+    return hipGetLastError();
+}
+
+hipError_t launch_range_partition(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *offsets,
+                                  uint32_t n, uint32_t W, bool xcd_remap, bool atomic_rank, const uint32_t *splitters,
+                                  uint32_t num_splitters, LaunchEvents ev) {
+    if (W == 0) return hipSuccess;
+    if (num_splitters > 255) return hipErrorInvalidValue;
+    const int remap = xcd_remap ? 1 : 0;
+    const uint32_t *no_values = nullptr;
+    uint32_t *no_values_out = nullptr;
+    const uint32_t *no_order = nullptr;
+    if (atomic_rank)
+        VRS_LAUNCH((scatter_kernel<uint32_t, 16, 8, false, RANK_ATOMIC, 4, true>), dim3(W), dim3(512), stream, ev, keys_in,
+                   keys_out, no_values, no_values_out, offsets, n, 0u, W, 32u, remap, no_order, 1u, splitters, num_splitters);
+    else
+        VRS_LAUNCH((scatter_kernel<uint32_t, 16, 8, false, RANK_BALLOT, 4, true>), dim3(W), dim3(512), stream, ev, keys_in,
+                   keys_out, no_values, no_values_out, offsets, n, 0u, W, 32u, remap, no_order, 1u, splitters, num_splitters);
     return hipGetLastError();
 }
 
