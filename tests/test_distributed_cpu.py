@@ -70,6 +70,14 @@ def _worker(rank, world, port, n_per_rank, mode, q, rounds=4):
                 base = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32)
                 return torch.from_numpy(k[order].view(np.int32).copy()), base
 
+            def partition_by_splitters(self, keys, n, splitters):
+                k = keys[:n].numpy().view(np.uint32)
+                bucket = np.searchsorted(splitters, k, side="right")
+                order = np.argsort(bucket, kind="stable")
+                counts = np.bincount(bucket, minlength=len(splitters) + 1)
+                base = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+                return torch.from_numpy(k[order].view(np.int32).copy()), base
+
             def sort(self, keys, n):
                 k = np.sort(keys[:n].numpy().view(np.uint32))
                 keys[:n] = torch.from_numpy(k.view(np.int32))
@@ -81,6 +89,10 @@ def _worker(rank, world, port, n_per_rank, mode, q, rounds=4):
             shard = rs.randint(0, 2 ** 32, n_per_rank, dtype=np.uint32)
         elif mode == "28bit":
             shard = rs.randint(0, 2 ** 32, n_per_rank, dtype=np.uint32) >> np.uint32(4)
+        elif mode == "small":  # every key below 2^20: one top byte holds everything -> sampled splitters
+            shard = rs.randint(0, 2 ** 20, n_per_rank, dtype=np.uint32)
+        elif mode == "clustered":  # two narrow clusters far apart
+            shard = (rs.randint(0, 5000, n_per_rank, dtype=np.uint32) + np.where(rs.rand(n_per_rank) < 0.7, 3_000_000_000, 17)).astype(np.uint32)
         else:  # skewed: rank 0 holds only large keys, rank 1 only small ones
             shard = rs.randint(0, 2 ** 31, n_per_rank, dtype=np.uint32) + (np.uint32(2 ** 31) if rank == 0 else np.uint32(0))
         sorter = RangeShardedSort(NumpyBackend(), recv_capacity=2 * n_per_rank * world,
@@ -103,7 +115,7 @@ def _worker(rank, world, port, n_per_rank, mode, q, rounds=4):
 
 
 @pytest.mark.parametrize("mode,world,rounds", [("uniform", 2, 4), ("28bit", 2, 4), ("skewed", 2, 4), ("uniform", 2, 1),
-                                               ("uniform", 3, 2)])
+                                               ("uniform", 3, 2), ("small", 2, 4), ("clustered", 3, 2)])
 def test_range_sharded_sort_gloo(mode, world, rounds):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -118,6 +130,6 @@ def test_range_sharded_sort_gloo(mode, world, rounds):
         p.join(timeout=60)
     assert result[0] is True, result
     ok, sizes, bounds = result
-    assert sum(sizes) == world * n and bounds[0] == 0 and bounds[-1] == 256
-    if mode == "uniform":
-        assert abs(sizes[0] - n) < 0.05 * n  # balanced ranges
+    assert sum(sizes) == world * n and bounds[0] == 0 and bounds[-1] in (256, world * rounds)  # byte cuts or sampled parts
+    if mode in ("uniform", "small", "clustered"):
+        assert max(sizes) < 1.3 * n, sizes  # balanced ranges (byte cuts or sampled splitters)

@@ -668,3 +668,36 @@ def test_range_partition_by_splitters(gpu_context, n, nsplit):
     assert np.array_equal(base, np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32))
     for b in (kin, kout, sp):
         b.release()
+
+
+def test_range_sharded_sort_small_keys_take_the_sampled_splitter_path(oracle):
+    """Keys below 2^20 share one top byte: byte-aligned cuts are useless, the step must switch to sampled splitters
+    and vrs_range_partition (product backend, RCCL, world size 1 with 4 rounds = 4 ranges)."""
+    import os
+    import socket
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    from vkradixsort_amd.distributed import HipLocalSortBackend, RangeShardedSort
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n = 2000003
+        keys = np.random.RandomState(7).randint(0, 2 ** 20, n, dtype=np.uint32)
+        cap = int(n * 1.25) + 4096
+        backend = HipLocalSortBackend(0, capacity=cap, blocks_per_workgroup=32)
+        # max_imbalance < 1 forces the decision even at world size 1 (one rank always holds 100 %)
+        sorter = RangeShardedSort(backend, recv_capacity=cap, make_empty=lambda m: torch.empty(m, dtype=torch.int32, device=dev),
+                                  rounds=4, max_imbalance=0.5)
+        res = sorter.step(torch.from_numpy(keys.view(np.int32)).to(dev), n)
+        torch.cuda.synchronize()
+        out = res.keys[:res.count].cpu().numpy().view(np.uint32)
+        assert res.count == n and res.bounds.tolist() == [0, 4]  # part-index space: the sampled path was taken
+        assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+        backend.close()
+    finally:
+        dist.destroy_process_group()

@@ -6,7 +6,10 @@ The reference is single-GPU; this is the build's multi-GPU path.  One process pe
   1. local step   one radix pass on the TOP byte (histograms + stable scatter, shift 24) groups the shard
                   by top byte, so every key range [byte lo, byte hi) is one contiguous slice
   2. splitters    ONE all-gather of every rank's 256 top-byte counts (world x 2 KiB, latency bound); each rank
-                  derives the same world-1 byte boundaries plus its own send and receive counts from it
+                  derives the same world-1 byte boundaries plus its own send and receive counts from it.
+                  If byte-aligned cuts would overload a rank by more than 15 % (small or clustered keys), the ranks
+                  pool 2048 sampled keys each, cut at sample quantiles and redo step 1 as a range partition
+                  (vrs_range_partition: bucket = number of splitters <= key) -- any distribution without massive ties
   3. exchange     the range of every rank is cut into R sub-ranges ("rounds", still top-byte boundaries); round r
                   moves every rank's keys of sub-range r with one batch of grouped send/recv (all xGMI links at once)
   4. merge step   round r's keys are sorted by the four-pass multi_radixsort WHILE round r+1 is on the wire;
@@ -61,6 +64,11 @@ class LocalSortBackend:
 
     def group_by_top_byte(self, keys, n: int):
         """-> (grouped keys tensor (len >= n), digit_base uint32[256])"""
+        raise NotImplementedError
+
+    def partition_by_splitters(self, keys, n: int, splitters: np.ndarray):
+        """stable grouping by range r = #splitters <= key -> (grouped keys tensor, first position of every range,
+        int64[len(splitters) + 2] with the total appended)"""
         raise NotImplementedError
 
     def sort(self, keys, n: int):
@@ -132,6 +140,22 @@ class HipLocalSortBackend(LocalSortBackend):
                                                                      digit_base.ctypes.data_as(ctypes.c_void_p)))
         return self.grouped, digit_base
 
+    def partition_by_splitters(self, keys, n, splitters):
+        if n > self.capacity:
+            raise ValueError("shard larger than the backend capacity")
+        torch = self.torch
+        sp = np.ascontiguousarray(splitters, dtype=np.uint32)
+        sp_t = torch.from_numpy(np.concatenate([sp, np.zeros(1, np.uint32)]).view(np.int32)).to(self.device)
+        torch.cuda.current_stream().synchronize()  # the upload ran on torch's stream == the context's stream; keep it simple
+        lib, ctx = self.ctx.lib, self.ctx
+        spb = self.engine.Buffer(ctx, self.engine.Buffer.BufferSettings(sp_t.numel() * 4), device_ptr=sp_t.data_ptr())
+        ctx.check(lib.vrs_range_partition(ctx.handle, self._buf(keys).handle, self._buf(self.grouped).handle, spb.handle,
+                                          sp.size, n))
+        first = np.empty(RADIX_SORT_BINS, dtype=np.uint32)
+        ctx.check(lib.vrs_multi_radixsort_digit_offsets(ctx.handle, first.ctypes.data_as(ctypes.c_void_p)))  # synchronous
+        spb.release()
+        return self.grouped, np.concatenate([first[:sp.size + 1].astype(np.int64), [n]])
+
     def sort(self, keys, n):
         if n == 0:
             return keys
@@ -147,7 +171,8 @@ class HipLocalSortBackend(LocalSortBackend):
 class RangeShardedSort:
     """Steps 1-4 over a torch.distributed process group."""
 
-    def __init__(self, backend: LocalSortBackend, recv_capacity: int, make_empty, process_group=None, rounds: int = 4):
+    def __init__(self, backend: LocalSortBackend, recv_capacity: int, make_empty, process_group=None, rounds: int = 4,
+                 max_imbalance: float = 1.15, samples_per_rank: int = 2048):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -156,6 +181,8 @@ class RangeShardedSort:
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self.rounds = max(1, min(int(rounds), RADIX_SORT_BINS // max(self.world, 1)))
+        self.max_imbalance = float(max_imbalance)
+        self.samples_per_rank = int(samples_per_rank)
         self.recv_capacity = int(recv_capacity)
         self.recv = make_empty(self.recv_capacity)  # int32 storage for uint32 keys
         self.device = self.recv.device
@@ -176,7 +203,28 @@ class RangeShardedSort:
         # world*R parts of (almost) equal size; part q*R + r = rank q, round r
         parts = plan_splitters(all_counts.sum(axis=0), world * R)
         bounds = parts[::R]
-        send_counts = send_counts_from_digit_base(digit_base, n, bounds)
+        per_rank = np.array([all_counts[:, bounds[q]:bounds[q + 1]].sum() for q in range(world)], dtype=np.int64)
+        ideal = max(int(all_counts.sum()) / world, 1.0)
+        if per_rank.max() > self.max_imbalance * ideal or per_rank.max() > self.recv_capacity:
+            # top bytes too concentrated for byte-aligned cuts (small keys, clustered keys): cut at sampled key
+            # values instead.  Same decision on every rank (it only depends on the gathered table).
+            S = self.samples_per_rank
+            idx = torch.linspace(0, max(n - 1, 0), S, device=self.device).long()
+            mine_s = keys[:n][idx] if n else torch.zeros(S, dtype=keys.dtype, device=self.device)
+            pool = torch.empty(world * S, dtype=keys.dtype, device=self.device)
+            dist.all_gather_into_tensor(pool, mine_s.contiguous(), group=self.group)
+            sample = np.sort(pool.cpu().numpy().view(np.uint32))
+            P = world * R
+            splitters = sample[(np.arange(1, P) * sample.size) // P]
+            grouped, base = self.backend.partition_by_splitters(keys, n, splitters)
+            local = np.diff(base)  # P ranges
+            mine2 = torch.from_numpy(local.astype(np.int64)).to(self.device)
+            table2 = torch.empty(world * P, dtype=mine2.dtype, device=self.device)
+            dist.all_gather_into_tensor(table2, mine2, group=self.group)
+            all_counts = table2.cpu().numpy().reshape(world, P)
+            parts = np.arange(P + 1, dtype=np.int64)
+            bounds = parts[::R]
+        send_counts = (base[bounds[1:]] - base[bounds[:-1]]).astype(np.int64)
         # what I receive in round r from source s, and where it lands: rounds ascending, sources ascending
         my_parts = parts[me * R:(me + 1) * R + 1]
         recv_rs = np.stack([all_counts[:, my_parts[r]:my_parts[r + 1]].sum(axis=1) for r in range(R)]).astype(np.int64)
@@ -184,7 +232,8 @@ class RangeShardedSort:
         round_off = np.concatenate([[0], np.cumsum(round_total)])
         total = int(round_off[-1])
         if total > self.recv_capacity:
-            raise RuntimeError(f"rank {self.rank}: receives {total} keys, capacity {self.recv_capacity}")
+            raise RuntimeError(f"rank {self.rank}: receives {total} keys, capacity {self.recv_capacity} "
+                               "(too many equal keys to balance by key range)")
 
         def issue(r):
             """round r: grouped send/recv with every peer; my own slice is a device copy"""
