@@ -1,0 +1,95 @@
+"""Randomised end-to-end check on the GPU: random N, B, key width, distribution, pairs, ranking method, against numpy.
+   python tools/fuzz_gpu.py [seconds] [seed]"""
+import ctypes
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import vkradixsort_amd as vrs  # noqa: E402
+from vkradixsort_amd import capi  # noqa: E402
+
+S = vrs.Buffer.BufferSettings
+
+
+def make_keys(rs, n, bits64):
+    kind = rs.randint(0, 8)
+    if bits64:
+        k = (rs.randint(0, 2 ** 32, n, dtype=np.uint64) << np.uint64(32)) | rs.randint(0, 2 ** 32, n, dtype=np.uint64)
+        full = np.uint64(0xFFFFFFFFFFFFFFFF)
+    else:
+        k = rs.randint(0, 2 ** 32, n, dtype=np.uint32)
+        full = np.uint32(0xFFFFFFFF)
+    if kind == 1:
+        k = k & k.dtype.type(0xFF00FF if not bits64 else 0xFF000000FF0000FF)
+    elif kind == 2:
+        k = np.sort(k)
+    elif kind == 3:
+        k = np.sort(k)[::-1].copy()
+    elif kind == 4:
+        k[:] = k[0]
+    elif kind == 5:
+        k = k >> k.dtype.type(rs.randint(1, 30))
+    elif kind == 6 and n > 10:
+        k[rs.randint(0, n, max(1, n // 10))] = full
+    return k, kind
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    rs = np.random.RandomState(seed)
+    t_end = time.time() + budget
+    cases = 0
+    with vrs.GPUContext(0) as ctx:
+        lib = ctx.lib
+        while time.time() < t_end:
+            bits64 = bool(rs.randint(0, 3) == 0)
+            pairs = bool(rs.randint(0, 3) == 0)
+            n = int(rs.choice([rs.randint(1, 300), rs.randint(1, 20000), rs.randint(1, 3000000)]))
+            B = int(rs.choice([1, 2, 3, 4, 7, 8, 16, 31, 32, 33, 64, 96, 128, 1024, 4096]))
+            if n // (B * 256) > 60000:
+                B = 32
+            mode = int(rs.choice([1, 2]))
+            ctx.setTuning(capi.VRS_TUNE_RANK_MODE, mode)
+            ctx.setTuning(capi.VRS_TUNE_FUSED_PREFIX, int(rs.randint(0, 2)))
+            ctx.setTuning(capi.VRS_TUNE_XCD_REMAP, int(rs.randint(0, 2)))
+            keys, kind = make_keys(rs, n, bits64)
+            vals = rs.randint(0, 2 ** 32, n, dtype=np.uint32) if pairs else None
+            kb = 8 if bits64 else 4
+            W = lib.vrs_workgroup_count(n, B)
+            kbuf = [vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(kb * n), keys), vrs.Buffer(ctx, S(kb * n))]
+            vbuf = [vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals), vrs.Buffer(ctx, S(4 * n))] if pairs else None
+            h = vrs.Buffer(ctx, S(W * 1024))
+            hist_fn = lib.vrs_multi_radixsort_histograms_u64 if bits64 else lib.vrs_multi_radixsort_histograms
+            for i in range(kb):
+                pc = vrs.PushConstants(n, 8 * i, W, B)
+                ctx.check(hist_fn(ctx.handle, kbuf[i % 2].handle, h.handle, ctypes.byref(pc)))
+                if pairs:
+                    fn = lib.vrs_multi_radixsort_pairs_u64 if bits64 else lib.vrs_multi_radixsort_pairs
+                    ctx.check(fn(ctx.handle, kbuf[i % 2].handle, kbuf[(i + 1) % 2].handle, vbuf[i % 2].handle,
+                                 vbuf[(i + 1) % 2].handle, h.handle, ctypes.byref(pc)))
+                else:
+                    fn = lib.vrs_multi_radixsort_u64 if bits64 else lib.vrs_multi_radixsort
+                    ctx.check(fn(ctx.handle, kbuf[i % 2].handle, kbuf[(i + 1) % 2].handle, h.handle, ctypes.byref(pc)))
+            out = np.empty(n, keys.dtype)
+            kbuf[0].downloadWithStagingBuffer(out)
+            order = np.argsort(keys, kind="stable")
+            ok = np.array_equal(out, keys[order])
+            if pairs:
+                ov = np.empty(n, np.uint32)
+                vbuf[0].downloadWithStagingBuffer(ov)
+                ok = ok and np.array_equal(ov, vals[order])
+            for b in kbuf + (vbuf or []) + [h]:
+                b.release()
+            cases += 1
+            if not ok:
+                print(f"MISMATCH n={n} B={B} bits64={bits64} pairs={pairs} kind={kind} mode={mode} seed={seed} case={cases}")
+                sys.exit(1)
+    print(f"fuzz ok: {cases} random cases in {budget:.0f} s (seed {seed})")
+
+
+if __name__ == "__main__":
+    main()
