@@ -258,14 +258,14 @@ def bench_multi(args):
     rearm()
     res = None
     for i in range(W):
-        res = sorter.step(batches[i], n)
+        res = sorter.step(batches[i], n, n_total_hint=n * world)
     torch.cuda.synchronize()
     rearm()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
-        res = sorter.step(batches[i], n)
+        res = sorter.step(batches[i], n, n_total_hint=n * world)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()

@@ -89,6 +89,8 @@ def _worker(rank, world, port, n_per_rank, mode, q, rounds=4):
             shard = rs.randint(0, 2 ** 32, n_per_rank, dtype=np.uint32)
         elif mode == "28bit":
             shard = rs.randint(0, 2 ** 32, n_per_rank, dtype=np.uint32) >> np.uint32(4)
+        elif mode == "tiny":  # below RangeShardedSort.small_total: gather path, ragged shards
+            shard = rs.randint(0, 2 ** 32, 500 + 37 * rank, dtype=np.uint32)
         elif mode == "small":  # every key below 2^20: one top byte holds everything -> sampled splitters
             shard = rs.randint(0, 2 ** 20, n_per_rank, dtype=np.uint32)
         elif mode == "clustered":  # two narrow clusters far apart
@@ -97,7 +99,8 @@ def _worker(rank, world, port, n_per_rank, mode, q, rounds=4):
             shard = rs.randint(0, 2 ** 31, n_per_rank, dtype=np.uint32) + (np.uint32(2 ** 31) if rank == 0 else np.uint32(0))
         sorter = RangeShardedSort(NumpyBackend(), recv_capacity=2 * n_per_rank * world,
                                   make_empty=lambda n: torch.empty(n, dtype=torch.int32), rounds=rounds)
-        res = sorter.step(torch.from_numpy(shard.view(np.int32).copy()), n_per_rank)
+        res = sorter.step(torch.from_numpy(shard.view(np.int32).copy()), shard.size,
+                          n_total_hint=(shard.size * world if mode == "tiny" else None))
         out = res.keys[:res.count].numpy().view(np.uint32).copy()
         gathered = [None] * world
         dist.all_gather_object(gathered, (shard, out))
@@ -115,7 +118,7 @@ def _worker(rank, world, port, n_per_rank, mode, q, rounds=4):
 
 
 @pytest.mark.parametrize("mode,world,rounds", [("uniform", 2, 4), ("28bit", 2, 4), ("skewed", 2, 4), ("uniform", 2, 1),
-                                               ("uniform", 3, 2), ("small", 2, 4), ("clustered", 3, 2)])
+                                               ("uniform", 3, 2), ("small", 2, 4), ("clustered", 3, 2), ("tiny", 3, 4)])
 def test_range_sharded_sort_gloo(mode, world, rounds):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -130,6 +133,9 @@ def test_range_sharded_sort_gloo(mode, world, rounds):
         p.join(timeout=60)
     assert result[0] is True, result
     ok, sizes, bounds = result
+    if mode == "tiny":
+        assert sum(sizes) == sum(500 + 37 * r for r in range(world)) and max(sizes) - min(sizes) <= 1
+        return
     assert sum(sizes) == world * n and bounds[0] == 0 and bounds[-1] in (256, world * rounds)  # byte cuts or sampled parts
     if mode in ("uniform", "small", "clustered"):
         assert max(sizes) < 1.3 * n, sizes  # balanced ranges (byte cuts or sampled splitters)

@@ -172,7 +172,7 @@ class RangeShardedSort:
     """Steps 1-4 over a torch.distributed process group."""
 
     def __init__(self, backend: LocalSortBackend, recv_capacity: int, make_empty, process_group=None, rounds: int = 4,
-                 max_imbalance: float = 1.15, samples_per_rank: int = 2048):
+                 max_imbalance: float = 1.15, samples_per_rank: int = 2048, small_total: int = 1 << 21):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -181,15 +181,47 @@ class RangeShardedSort:
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self.rounds = max(1, min(int(rounds), RADIX_SORT_BINS // max(self.world, 1)))
+        self.small_total = int(small_total)  # below this many keys in total the exchange does not pay: gather + local sort
         self.max_imbalance = float(max_imbalance)
         self.samples_per_rank = int(samples_per_rank)
         self.recv_capacity = int(recv_capacity)
         self.recv = make_empty(self.recv_capacity)  # int32 storage for uint32 keys
         self.device = self.recv.device
 
-    def step(self, keys, n: int) -> StepResult:
+    def _step_small(self, keys, n: int, sizes: np.ndarray) -> StepResult:
+        """Too few keys to amortise a partition pass, an exchange and per-range sorts (fixed costs of ~0.3 ms): every rank
+        gathers all keys (one all-gather), sorts them locally and keeps its 1/world slice by position."""
+        torch, dist = self.torch, self.dist
+        world, me = self.world, self.rank
+        m = int(sizes.max())
+        total = int(sizes.sum())
+        if total > self.recv_capacity or world * m > self.recv_capacity:
+            raise RuntimeError("receive buffer too small for the gather path")
+        padded = keys[:n] if n == m else torch.cat([keys[:n], torch.zeros(m - n, dtype=keys.dtype, device=self.device)])
+        pool = torch.empty(world * m, dtype=keys.dtype, device=self.device)
+        dist.all_gather_into_tensor(pool, padded.contiguous(), group=self.group)
+        off = 0
+        for q in range(world):  # compact the ragged shards
+            c = int(sizes[q])
+            self.recv[off:off + c].copy_(pool[q * m:q * m + c])
+            off += c
+        self.backend.sort(self.recv[:total], total)
+        cuts = (np.arange(world + 1) * total) // world
+        lo, hi = int(cuts[me]), int(cuts[me + 1])
+        mine = self.recv[lo:hi].clone()
+        self.recv[:hi - lo].copy_(mine)
+        return StepResult(self.recv, hi - lo, cuts, np.zeros(world, np.int64), np.zeros(world, np.int64))
+
+    def step(self, keys, n: int, n_total_hint: int | None = None) -> StepResult:
+        """n_total_hint: total number of keys over all ranks if the caller knows it (avoids a size collective);
+        totals below `small_total` take the gather path -- the all-to-all only runs where N amortises it."""
         torch, dist = self.torch, self.dist
         world, R, me = self.world, self.rounds, self.rank
+        if world > 1 and n_total_hint is not None and n_total_hint < self.small_total:
+            sz = torch.tensor([n], dtype=torch.int64, device=self.device)
+            all_sz = torch.empty(world, dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(all_sz, sz, group=self.group)
+            return self._step_small(keys, n, all_sz.cpu().numpy())
         # 1. local step
         grouped, digit_base = self.backend.group_by_top_byte(keys, n)
         base = np.concatenate([digit_base.astype(np.int64), [n]])
