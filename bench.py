@@ -240,6 +240,10 @@ def bench_multi(args):
         warm = torch.zeros(8, dtype=torch.int64, device=dev)
         dist.all_reduce(warm)  # brings the communicator up (and its banner out) now
         torch.cuda.synchronize()
+    # run the sort on a non-blocking stream of its own: work on the legacy null stream would implicitly serialise
+    # with every blocking stream, and the exchange of round r+1 (RCCL's stream) is meant to overlap the sort of round r
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
     n, B, K, W = args.n, args.blocks, args.steps, args.warmup
     shard = mt19937_keys(1000 + rank, n)  # shard g uses seed 1000+g
     pristine = torch.from_numpy(shard.view(np.int32)).to(dev)
