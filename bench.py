@@ -261,8 +261,26 @@ def bench_multi(args):
 
     rearm()
     res = None
+    # warm-up steps double as a measurement of the exchange pipelining depth: how many rounds pay off depends on the
+    # xGMI all-to-all rate relative to the local sort, which only shows on the real node.  Every rank takes the same
+    # decision (MAX over ranks of each candidate's time).
+    candidates = [r for r in (args.rounds, 2, 1) if r <= sorter.rounds] if (world > 1 and not args.rounds_forced) else []
+    candidates = list(dict.fromkeys(candidates))[:W]
+    tried = {}
     for i in range(W):
+        if i < len(candidates):
+            sorter.rounds = candidates[i]
+            dist.barrier()
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
         res = sorter.step(batches[i], n, n_total_hint=n * world)
+        if i < len(candidates):
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tried[candidates[i]] = float(tt.item())
+    if tried:
+        sorter.rounds = min(tried, key=tried.get)
     torch.cuda.synchronize()
     rearm()
     dist.barrier()
@@ -311,7 +329,7 @@ def bench_multi(args):
             "config": {"workload": f"{world} x {n} uniform random uint32 keys (std::mt19937 seed 1000+rank), sharded by key "
                                    f"range: top-byte partition pass, RCCL all-to-all over xGMI, local 4-pass multi_radixsort",
                        "num_elements_per_gpu": n, "num_blocks_per_workgroup": B, "parallelism": f"range-sharded x{world}",
-                       "exchange_rounds": sorter.rounds,
+                       "exchange_rounds": sorter.rounds, "rounds_tried_in_warmup_ms": {str(k): round(v * 1e3, 3) for k, v in tried.items()},
                        "hbm_bytes_per_key": 60},
             "roofline": {"bound": "hbm", "achieved": round(60 * n * K / elapsed / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(60 * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
