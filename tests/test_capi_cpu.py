@@ -138,3 +138,13 @@ def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu():
         p = subprocess.run([str(exe), "1000"], capture_output=True, text=True, timeout=60)
         assert p.returncode == 1
         assert "no HIP device" in p.stderr
+
+
+def test_cpp_host_logic_unit_test_binary():
+    """vkradixsort_amd/host/test/host_logic_test.cpp: launch shapes, the mt19937 key generator, std::sort timing,
+    testSort's "TEST FAILED." behaviour, push-constant layout, activeIndex toggling -- all without a device."""
+    import subprocess
+    from vkradixsort_amd import build
+    exe = build.build_host_logic_test()
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "host logic ok" in p.stdout, p.stdout + p.stderr

@@ -74,3 +74,16 @@ def build_host(force: bool = False):
             _run([cxx, *common, src, "-o", exe, f"-L{PKG_DIR}", "-lvkradixsort_host", *link])
         exes.append(exe)
     return out_lib, exes
+
+
+def build_host_logic_test(force: bool = False) -> Path:
+    """g++ -> the CPU-only unit test of the C++ host mirror's logic (vkradixsort_amd/host/test)."""
+    out_lib, _ = build_host(force)
+    src = HOST / "test" / "host_logic_test.cpp"
+    exe = PKG_DIR / "host_logic_test"
+    hdrs = list((HOST / "include").rglob("*.h")) + [INCLUDE / "vkradixsort_amd.h"]
+    if force or _stale(exe, [src, out_lib] + hdrs):
+        cxx = shutil.which("g++") or "g++"
+        _run([cxx, "-O2", "-std=c++20", f"-I{HOST / 'include'}", f"-I{INCLUDE}", src, "-o", exe, f"-L{PKG_DIR}",
+              "-lvkradixsort_host", "-lvkradixsort_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
