@@ -49,7 +49,8 @@ struct vrs_context_t {
 };
 
 struct vrs_buffer_t {
-    vrs_context ctx = nullptr;
+    vrs_context ctx = nullptr;  // owner, compared for identity only after creation (may be destroyed before the buffer)
+    int device = 0;
     void *ptr = nullptr;
     size_t size = 0;
     bool owned = false;
@@ -356,6 +357,7 @@ int vrs_buffer_create(vrs_context ctx, size_t size_bytes, vrs_buffer *out_buf) {
         return fail_hip(ctx, "hipMalloc", e);
     }
     b->ctx = ctx;
+    b->device = ctx->device;
     b->size = size_bytes;
     b->owned = true;
     *out_buf = b;
@@ -371,6 +373,7 @@ int vrs_buffer_wrap(vrs_context ctx, void *device_ptr, size_t size_bytes, vrs_bu
     vrs_buffer b = new (std::nothrow) vrs_buffer_t();
     if (!b) return fail(ctx, VRS_ERROR_OUT_OF_MEMORY, "host allocation failed");
     b->ctx = ctx;
+    b->device = ctx->device;
     b->ptr = device_ptr;
     b->size = size_bytes;
     b->owned = false;
@@ -382,9 +385,10 @@ int vrs_buffer_release(vrs_buffer buf) {
     if (!buf) return VRS_OK;
     int rc = VRS_OK;
     if (buf->ptr && buf->owned) {
-        (void)hipSetDevice(buf->ctx->device);
+        // the owning context may already be gone (host-language finalisers run in any order): touch only the buffer
+        (void)hipSetDevice(buf->device);
         hipError_t e = hipFree(buf->ptr);
-        if (e != hipSuccess) rc = fail_hip(buf->ctx, "hipFree", e);
+        if (e != hipSuccess) rc = fail_hip(nullptr, "hipFree", e);
     }
     buf->ptr = nullptr;
     delete buf;
