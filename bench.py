@@ -4,8 +4,10 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-A step = one complete sort (4 passes x [histograms, prefix, scatter]) of one batch of synthetic keys that is
-already resident in HBM when the timed region starts.  N = 1 sorts BASELINE.json configs[2]: 10^8 uniform
+A step = one complete sort (four 8-bit passes) of one batch of synthetic keys that is already resident in HBM when
+the timed region starts.  N = 1 times the library's one-call sort (vrs_sort_keys_u32: one counting read + four
+look-back scatter passes, 36 B/key) and reports the reference's stage-by-stage contract path (4 x [histograms,
+prefix, scatter], 48 B/key) beside it; --path contract swaps the two.  N = 1 sorts BASELINE.json configs[2]: 10^8 uniform
 random uint32 (std::mt19937 raw outputs, seeds 1/2/3 cycled over the K pre-staged batches).  N > 1 sorts
 N x 10^8 keys sharded by key range (configs[4] at N = 8): top-byte partition pass, RCCL all-to-all, local sort.
 Rank 0 prints ONE JSON line.
@@ -28,7 +30,8 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 BYTES_PER_KEY_SORT = 48  # 4 passes x (histogram read 4 + scatter read 4 + scatter write 4)   SURVEY.md section 8d
-BYTES_PER_KEY_SCATTER = 8  # the dominant kernel, per launch: read 4 + write 4
+BYTES_PER_KEY_SORT_ONE_READ = 36  # one counting read 4 + 4 passes x (scatter read 4 + scatter write 4): SURVEY.md section 8d's rule
+BYTES_PER_KEY_SCATTER = 8  # the dominant kernel of either path, per launch: read 4 + write 4
 
 
 def mt19937_keys(seed: int, n: int) -> np.ndarray:
@@ -36,9 +39,9 @@ def mt19937_keys(seed: int, n: int) -> np.ndarray:
     return np.random.RandomState(seed).randint(0, 2 ** 32, size=n, dtype=np.uint32)
 
 
-def load_traffic_profile():
-    """HBM bytes per scatter launch from the committed rocprofv3 --pmc passes (profiles/), if present."""
-    p = ROOT / "profiles" / "scatter_traffic.json"
+def load_traffic_profile(kernel: str = "scatter"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), if present."""
+    p = ROOT / "profiles" / f"{kernel}_traffic.json"
     if not p.exists():
         return None
     try:
@@ -116,66 +119,84 @@ def bench_single(args):
             tok = p.execute(tok)
             gpu.incrementActiveIndex()
 
+    def sort_one_call(b0):
+        # the library's own loop over the four passes: one counting read + four look-back scatter passes (K5)
+        gpu.check(gpu.lib.vrs_sort_keys_u32(gpu.handle, b0.handle, buf1.handle, n))
+
+    one_call = args.path == "one_call"
+    paths = {"one_call": (sort_one_call, capi.VRS_KERNEL_LOOKBACK_SCATTER, "lookback_scatter"),
+             "contract": (sort_batch, capi.VRS_KERNEL_SCATTER, "scatter")}
+    primary, dominant_id, dominant_name = paths[args.path]
+
+    def kernel_table():
+        t = {}
+        for kid, name in capi.KERNEL_NAMES.items():
+            cnt, ms = gpu.profileQuery(kid)
+            if cnt:
+                t[name] = {"launches": cnt, "avg_us": round(ms / cnt * 1e3, 2)}
+        return t
+
+    def run_steps(fn, count, mask):
+        """count steps of fn over the pre-staged batches; mask = kernels that carry events (0 = none)"""
+        gpu.profileReset()
+        gpu.profileEnableMask(mask)
+        gpu.waitIdle()
+        t0 = time.perf_counter()
+        for i in range(count):
+            fn(batches[i])
+        gpu.waitIdle()
+        dt = time.perf_counter() - t0
+        gpu.profileEnable(False)
+        return dt, kernel_table()
+
     rearm()
-    for i in range(W):
-        sort_batch(batches[i])
-    gpu.waitIdle()
+    run_steps(primary, W, 0)
     rearm()
 
-    # ---- timed region: exactly K steps, inputs resident.  The dominant kernel's launches (scatter) carry HIP
-    # events on their own dispatch packets, on the stream they are launched on; nothing else is instrumented.
-    gpu.profileReset()
-    gpu.profileEnableMask(1 << capi.VRS_KERNEL_SCATTER)
-    gpu.waitIdle()
-    t0 = time.perf_counter()
-    for i in range(K):
-        sort_batch(batches[i])
-    gpu.waitIdle()
-    t1 = time.perf_counter()
-    gpu.profileEnable(False)
-    elapsed = t1 - t0
-    kernels = {}
-    for kid, name in capi.KERNEL_NAMES.items():
-        cnt, ms = gpu.profileQuery(kid)
-        if cnt:
-            kernels[name] = {"launches": cnt, "avg_us": round(ms / cnt * 1e3, 2)}
+    # ---- timed region: exactly K steps, inputs resident.  The dominant kernel's launches carry HIP events on their
+    # own dispatch packets, on the stream they are launched on; nothing else is instrumented.
+    elapsed, kernels = run_steps(primary, K, 1 << dominant_id)
 
     # ---- outside the timed region: (a) the same K steps with no events at all (instrumentation overhead check),
     # (b) once more with every kernel timed, for the per-kernel breakdown
     rearm()
-    t2 = time.perf_counter()
-    for i in range(K):
-        sort_batch(batches[i])
-    gpu.waitIdle()
-    unprofiled = time.perf_counter() - t2
+    unprofiled, _ = run_steps(primary, K, 0)
     rearm()
-    gpu.profileReset()
-    gpu.profileEnable(True)
-    for i in range(K):
-        sort_batch(batches[i])
-    gpu.waitIdle()
-    gpu.profileEnable(False)
-    breakdown = {}
-    for kid, name in capi.KERNEL_NAMES.items():
-        cnt, ms = gpu.profileQuery(kid)
-        if cnt:
-            breakdown[name] = {"launches": cnt, "avg_us": round(ms / cnt * 1e3, 2)}
+    _, breakdown = run_steps(primary, K, (1 << capi.VRS_KERNEL_COUNT) - 1)
 
-    # ---- verification of what the timed steps produced (result is in each batch buffer = "buffer0")
+    # ---- verification of what the steps produced (result is in each batch buffer = "buffer0")
     out0 = np.empty(n, dtype=np.uint32)
     batches[0].downloadWithStagingBuffer(out0)
     check = {"sorted": bool(np.all(out0[1:] >= out0[:-1])),
              "checksum_ok": int(out0.astype(np.uint64).sum()) == int(host_keys[0].astype(np.uint64).sum())}
     base = None
+    ref = None
     if not args.no_cpu_baseline:
         ref, base = cpu_baseline(host_keys[0])
         check["bit_exact_vs_std_sort"] = bool(np.array_equal(ref, out0))
+
+    # ---- the other path over the same batches, reported beside the headline (never as `value`)
+    other_name = "contract" if one_call else "one_call"
+    other_fn, other_dom_id, other_dom_name = paths[other_name]
+    rearm()
+    run_steps(other_fn, 1, 0)
+    rearm()
+    other_elapsed, _ = run_steps(other_fn, K, 0)
+    rearm()
+    _, other_breakdown = run_steps(other_fn, K, (1 << capi.VRS_KERNEL_COUNT) - 1)
+    batches[0].downloadWithStagingBuffer(out0)
+    check[f"{other_name}_path_sorted"] = bool(np.all(out0[1:] >= out0[:-1]))
+    if ref is not None:
+        check[f"{other_name}_path_bit_exact_vs_std_sort"] = bool(np.array_equal(ref, out0))
     if not all(check.values()):
         raise SystemExit(f"VERIFICATION FAILED: {check}")
 
-    scatter_us = kernels.get("scatter", {}).get("avg_us")
-    achieved = (BYTES_PER_KEY_SCATTER * n / (scatter_us * 1e-6) / 1e9) if scatter_us else None
+    bytes_per_key_sort = {"one_call": BYTES_PER_KEY_SORT_ONE_READ, "contract": BYTES_PER_KEY_SORT}
+    dom_us = kernels.get(dominant_name, {}).get("avg_us")
+    achieved = (BYTES_PER_KEY_SCATTER * n / (dom_us * 1e-6) / 1e9) if dom_us else None
     value = n * K / elapsed / 1e9
+    sort_bytes = bytes_per_key_sort[args.path] * n
+    other_dom_us = other_breakdown.get(other_dom_name, {}).get("avg_us")
     result = {
         "metric": "Gkeys/s sorting 10^8 uint32 at 1/2/4/8 MI355X; % of HBM roofline",
         "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": 1, "steps": K, "warmup": W,
@@ -183,20 +204,32 @@ def bench_single(args):
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[2]: {n} uniform random uint32 keys (std::mt19937 seeds 1,2,3), "
                                f"multi_radixsort, 1xMI355X, keys resident in HBM",
+                   "path": ("vrs_sort_keys_u32: the library runs the four 8-bit passes itself -- one counting read of the "
+                            "keys, then four stable scatter passes with decoupled look-back (36 B/key)") if one_call else
+                           ("MultiRadixSortPass stages, as MultiRadixSort::execute drives them: 4 x [histograms, prefix, "
+                            "scatter] with the caller-visible [W][256] table (48 B/key)"),
                    "num_elements": n, "num_blocks_per_workgroup": B, "num_workgroups": Wg, "passes": 4,
                    "rank_mode": {1: "ballot", 2: "lds_atomic"}[gpu.lib.vrs_rank_mode(gpu.handle)], "device": dev_name,
                    "compute_units": cus},
-        "roofline": {"bound": "hbm", "kernel": "scatter (stage RADIX_SORT, one launch per pass)",
+        "roofline": {"bound": "hbm", "kernel": f"{dominant_name} (one launch per pass: reads and writes every key once)",
                      "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                     "algorithmic_bytes_per_launch": BYTES_PER_KEY_SCATTER * n, "avg_launch_us": scatter_us,
-                     "traffic": load_traffic_profile()},
-        "sort_roofline": {"algorithmic_bytes": BYTES_PER_KEY_SORT * n,
-                          "achieved_GBps": round(BYTES_PER_KEY_SORT * n * K / elapsed / 1e9, 1),
-                          "frac_of_peak": round(BYTES_PER_KEY_SORT * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
+                     "algorithmic_bytes_per_launch": BYTES_PER_KEY_SCATTER * n, "avg_launch_us": dom_us,
+                     "traffic": load_traffic_profile(dominant_name)},
+        "sort_roofline": {"algorithmic_bytes": sort_bytes, "bytes_per_key": bytes_per_key_sort[args.path],
+                          "achieved_GBps": round(sort_bytes * K / elapsed / 1e9, 1),
+                          "frac_of_peak": round(sort_bytes * K / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
         "kernels_timed_region": kernels,
         "kernels_all_instrumented_rerun": breakdown,
         "ms_per_step_uninstrumented_rerun": round(unprofiled / K * 1e3, 4),
+        f"{other_name}_path": {
+            "value": round(n * K / other_elapsed / 1e9, 3), "unit": "Gkeys/s", "ms_per_step": round(other_elapsed / K * 1e3, 4),
+            "bytes_per_key": bytes_per_key_sort[other_name],
+            "frac_of_peak": round(bytes_per_key_sort[other_name] * n * K / other_elapsed / 1e9 / HBM_PEAK_GBS, 4),
+            "dominant_kernel": {"name": other_dom_name, "avg_us": other_dom_us,
+                                "frac": round(BYTES_PER_KEY_SCATTER * n / (other_dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                                if other_dom_us else None},
+            "kernels": other_breakdown, "note": "same batches, uninstrumented timing; not the headline"},
         "verified": check,
     }
     if base:
@@ -358,6 +391,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=4, help="multi-GPU: sub-ranges per rank (exchange/sort pipelining)")
     ap.add_argument("--rounds-forced", action="store_true", help="use --rounds even at world size 1 (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", choices=["one_call", "contract"], default="one_call",
+                    help="N = 1: which path is timed as `value` (the other is reported beside it): the one-call sort "
+                         "(one counting read + look-back scatters) or the reference's stage-by-stage contract path")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:

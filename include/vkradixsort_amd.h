@@ -189,7 +189,9 @@ typedef enum vrs_kernel_id {
     VRS_KERNEL_PREFIX = 1,    /* global digit prefix + per-workgroup offsets (both launches) */
     VRS_KERNEL_SCATTER = 2,   /* stable scatter (the dominant kernel) */
     VRS_KERNEL_SINGLE = 3,    /* single_radixsort */
-    VRS_KERNEL_COUNT = 4
+    VRS_KERNEL_DIGIT_TABLES = 4,     /* one-call sort, large N: the single counting read of all four digits */
+    VRS_KERNEL_LOOKBACK_SCATTER = 5, /* one-call sort, large N: stable scatter with decoupled look-back */
+    VRS_KERNEL_COUNT = 6
 } vrs_kernel_id;
 
 /* When enabled, every kernel launch carries a (start, stop) hipEvent pair on its own dispatch packet
@@ -201,6 +203,8 @@ int vrs_profile_enable_mask(vrs_context ctx, uint32_t kernel_mask);
 int vrs_profile_reset(vrs_context ctx);
 /* Synchronises the stream, then returns launches and summed event time for one kernel id. */
 int vrs_profile_query(vrs_context ctx, int kernel_id, uint64_t *launches, double *total_ms);
+/* Same for ONE launch: `index` counts the instrumented launches of `kernel_id` since vrs_profile_reset. */
+int vrs_profile_query_launch(vrs_context ctx, int kernel_id, uint64_t index, double *ms);
 
 /* Test hook: copies the per-workgroup offset table (uint32[W*256], multi_radixsort.comp:76's
  * global_offsets for every workgroup) computed by the most recent RADIX_SORT stage. */
@@ -219,8 +223,14 @@ typedef enum vrs_tuning_key {
     VRS_TUNE_XCD_REMAP = 0,      /* 1 (default): consecutive tiles share an XCD's L2 in the scatter */
     VRS_TUNE_SCATTER_VARIANT = 1, /* 0 (default): chosen from B; else ITEMS*1000 + WAVES*10 + RANK */
     VRS_TUNE_FUSED_PREFIX = 2,    /* 1 (default): single-launch prefix (chunk sums exchanged through tagged granules) */
-    VRS_TUNE_RANK_MODE = 3        /* 0 (default) auto: LDS-atomic ranking if the device self-test passed at
+    VRS_TUNE_RANK_MODE = 3,       /* 0 (default) auto: LDS-atomic ranking if the device self-test passed at
                                      context creation, else __ballot ranking; 1 force ballot; 2 force atomic */
+    VRS_TUNE_ONE_CALL_MIN_KEYS = 4 /* vrs_sort_keys_u32 / vrs_sort_pairs_u32 count all four digits in ONE read and
+                                     scatter with decoupled look-back (36 instead of 48 bytes per key) from this many
+                                     keys on; 0 = never (always the four contract passes).  Default 2^20. */
+    ,
+    VRS_TUNE_DEBUG_MISPLACE_STREAMS = 5 /* test hook (default 0): run every other tile of a look-back stream behind a
+                                     different XCD's L2, i.e. without the placement the fast hand-off relies on */
 } vrs_tuning_key;
 int vrs_set_tuning(vrs_context ctx, int key, int value);
 

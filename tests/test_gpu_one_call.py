@@ -1,0 +1,184 @@
+"""GPU parity tests of the one-call sort's large-N form (K5 in vrs_kernels.hip): ONE counting read of the keys
+(digit_tables_kernel), then four scatter passes that find their offsets by decoupled look-back along 32 streams.
+The reference has no such entry point (its loop is MultiRadixSort.cpp:50-61); the acceptance criterion is the
+reference's own: the output must equal std::sort (MultiRadixSort.cpp:141-161), bit for bit, and pairs must
+equal std::stable_sort by key."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import vkradixsort_amd as vrs
+from vkradixsort_amd import capi
+
+pytestmark = pytest.mark.gpu
+S = vrs.Buffer.BufferSettings
+
+
+def make_keys(n, dist, seed=7):
+    rs = np.random.RandomState(seed)
+    k = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    if dist == "uniform":
+        return k
+    if dist == "28bit":  # the reference's own generator, MultiRadixSort.cpp:121-133
+        return k >> np.uint32(4)
+    if dist == "mult256":  # digit 0 constant: every key of pass 1 falls into stream 0 -> that pass must fall back
+        return k & np.uint32(0xFFFFFF00)
+    if dist == "lowbyte":
+        return k & np.uint32(0xFF)
+    if dist == "sorted":
+        return np.sort(k)
+    if dist == "reverse":
+        return np.sort(k)[::-1].copy()
+    if dist == "const":
+        return np.full(n, 0xDEADBEEF, dtype=np.uint32)
+    if dist == "two_values":
+        return np.where(k & 1, np.uint32(0xFFFFFFFF), np.uint32(0)).astype(np.uint32)
+    if dist == "max_keys":  # the padding value of a ragged tile is a legal key
+        return np.where(k % 3 == 0, np.uint32(0xFFFFFFFF), k).astype(np.uint32)
+    if dist == "skewed_stream":  # 40 % of the keys share digit-1 stream 5: more than the 25 % slack of pass 2's grid
+        heavy = (k % 5) < 2
+        return np.where(heavy, (k & np.uint32(0xFFFF07FF)) | np.uint32(0x2800), k).astype(np.uint32)
+    if dist == "clustered":  # few distinct top bytes, long runs
+        return (np.sort(k >> np.uint32(8)) | (rs.randint(0, 4, size=n).astype(np.uint32) << np.uint32(30))).astype(np.uint32)
+    raise ValueError(dist)
+
+
+def launches(ctx, kid):
+    return ctx.profileQuery(kid)[0]
+
+
+def sort_keys(ctx, keys, min_keys=1):
+    n = keys.size
+    ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, min_keys)
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)
+    k1 = vrs.Buffer(ctx, S(4 * n))
+    ctx.profileReset()
+    ctx.profileEnable(True)
+    try:
+        ctx.check(ctx.lib.vrs_sort_keys_u32(ctx.handle, k0.handle, k1.handle, n))
+        out = np.empty(n, np.uint32)
+        k0.downloadWithStagingBuffer(out)
+        stats = {name: launches(ctx, kid) for kid, name in capi.KERNEL_NAMES.items()}
+    finally:
+        ctx.profileEnable(False)
+        ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, 1 << 20)
+        k0.release()
+        k1.release()
+    return out, stats
+
+
+DISTS = ["uniform", "28bit", "mult256", "lowbyte", "sorted", "reverse", "const", "two_values", "max_keys",
+         "skewed_stream", "clustered"]
+
+
+@pytest.mark.parametrize("dist", DISTS)
+@pytest.mark.parametrize("n", [(1 << 20) + 1, 3000001])
+def test_one_read_sort_equals_std_sort(gpu_context, oracle, n, dist):
+    keys = make_keys(n, dist, seed=n % 1000)
+    out, stats = sort_keys(gpu_context, keys)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    # the one-read form really ran: one counting read, and every pass is either a look-back scatter or a contract pass
+    assert stats["digit_tables"] == 1
+    assert stats["lookback_scatter"] + stats["scatter"] == 4 and stats["histogram"] == stats["scatter"]
+    if dist in ("uniform", "28bit", "sorted", "reverse"):
+        assert stats["lookback_scatter"] == 4
+    if dist in ("mult256", "const", "skewed_stream"):
+        assert stats["scatter"] >= 1  # unbalanced streams -> contract pass
+
+
+@pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 8191, (1 << 22) - 1, 5000000, (1 << 23) + 12345])
+def test_one_read_and_contract_passes_agree(gpu_context, n):
+    keys = make_keys(n, "uniform", seed=n % 977)
+    a, sa = sort_keys(gpu_context, keys, min_keys=1)
+    b, sb = sort_keys(gpu_context, keys, min_keys=0)
+    assert sa["lookback_scatter"] == 4 and sb["lookback_scatter"] == 0 and sb["scatter"] == 4
+    assert np.array_equal(a, b) and np.array_equal(a, np.sort(keys))
+
+
+def test_threshold_selects_the_form(gpu_context):
+    keys = make_keys(600000, "uniform")
+    _, below = sort_keys(gpu_context, keys, min_keys=1 << 20)
+    assert below["digit_tables"] == 0 and below["scatter"] == 4
+    _, above = sort_keys(gpu_context, keys, min_keys=500000)
+    assert above["digit_tables"] == 1 and above["lookback_scatter"] == 4
+    with pytest.raises(vrs.VrsError):
+        gpu_context.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, -1)
+
+
+@pytest.mark.parametrize("dist", ["uniform", "mult256", "two_values", "sorted"])
+def test_one_read_pairs_are_stable(gpu_context, oracle, dist):
+    ctx, lib, n = gpu_context, gpu_context.lib, 2500003
+    keys = make_keys(n, dist) if dist != "uniform" else (make_keys(n, "uniform") & np.uint32(0x00FFFFFF))
+    vals = np.arange(n, dtype=np.uint32)
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)
+    v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
+    k1, v1 = vrs.Buffer(ctx, S(4 * n)), vrs.Buffer(ctx, S(4 * n))
+    ctx.check(lib.vrs_sort_pairs_u32(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+    ok, ov = np.empty(n, np.uint32), np.empty(n, np.uint32)
+    k0.downloadWithStagingBuffer(ok)
+    v0.downloadWithStagingBuffer(ov)
+    rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
+    assert np.array_equal(ok, rk) and np.array_equal(ov, rv)
+    for b in (k0, k1, v0, v1):
+        b.release()
+
+
+def test_context_reuse_across_sizes(gpu_context):
+    """The digit tables must come back zeroed and the status words re-armed whatever the previous sort was."""
+    for n, dist in [(1 << 22, "uniform"), ((1 << 20) + 7, "mult256"), (5000000, "28bit"), (1 << 22, "const"),
+                    (3000000, "uniform"), (1 << 21, "sorted")]:
+        keys = make_keys(n, dist, seed=n % 101)
+        out, stats = sort_keys(gpu_context, keys)
+        assert stats["digit_tables"] == 1
+        assert np.array_equal(out, np.sort(keys)), (n, dist)
+
+
+def test_look_back_does_not_depend_on_xcd_placement(gpu_context):
+    """The fast hand-off of the look-back words assumes a stream's tiles share one XCD's L2; the test hook moves
+    every other tile to the neighbouring XCD: those workgroups must notice (HW_REG_XCC_ID) and take the
+    placement-independent route -- slower, same result, no hang."""
+    ctx = gpu_context
+    n = (1 << 21) + 4097
+    keys = make_keys(n, "uniform", seed=5)
+    ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 1)
+    try:
+        out, stats = sort_keys(ctx, keys)
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 0)
+    assert stats["lookback_scatter"] == 4
+    assert np.array_equal(out, np.sort(keys))
+
+
+def test_unaligned_keys_take_the_contract_passes(gpu_context):
+    """The counting read uses 16-byte loads: a wrapped pointer that is not 16-byte aligned must still sort."""
+    ctx, lib = gpu_context, gpu_context.lib
+    n = (1 << 20) + 77
+    keys = make_keys(n, "uniform", seed=3)
+    big = vrs.Buffer(ctx, S(4 * (n + 4)))
+    tmp = vrs.Buffer(ctx, S(4 * n))
+    host = np.concatenate([np.zeros(1, np.uint32), keys, np.zeros(3, np.uint32)])
+    ctx.check(lib.vrs_buffer_upload(ctx.handle, big.handle, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
+    view = vrs.Buffer(ctx, S(4 * n), device_ptr=big.getDeviceAddress() + 4)
+    ctx.profileReset()
+    ctx.profileEnable(True)
+    try:
+        ctx.check(lib.vrs_sort_keys_u32(ctx.handle, view.handle, tmp.handle, n))
+        ctx.waitIdle()
+        assert launches(ctx, capi.VRS_KERNEL_DIGIT_TABLES) == 0
+    finally:
+        ctx.profileEnable(False)
+    ctx.check(lib.vrs_buffer_download(ctx.handle, big.handle, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
+    assert host[0] == 0 and not host[-3:].any()
+    assert np.array_equal(host[1:n + 1], np.sort(keys))
+    for b in (view, big, tmp):
+        b.release()
+
+
+def test_one_read_sort_1e8_equals_std_sort(gpu_context, oracle):
+    """BASELINE.json config 3 through the one-call entry point."""
+    n = 10 ** 8
+    keys = np.random.RandomState(1).randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    out, stats = sort_keys(gpu_context, keys)
+    assert stats["lookback_scatter"] == 4 and stats["digit_tables"] == 1
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1

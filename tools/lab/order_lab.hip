@@ -37,6 +37,19 @@ static std::vector<uint32_t> recency(uint32_t W, uint32_t segments) {
     return p;
 }
 
+// groups of g consecutive tiles per XCD, super-groups of 8g tiles in launch order (what a decoupled look-back would need:
+// tile t only depends on tiles dispatched at most 8g blocks earlier)
+static std::vector<uint32_t> grouped(uint32_t W, uint32_t g) {
+    std::vector<uint32_t> p(W);
+    const uint32_t full = W / (8 * g) * (8 * g);
+    for (uint32_t b = 0; b < W; ++b) {
+        if (b >= full) { p[b] = b; continue; }
+        const uint32_t sup = b / (8 * g), x = b % 8, within = (b / 8) % g;
+        p[b] = sup * 8 * g + x * g + within;
+    }
+    return p;
+}
+
 struct Order { const char *name; std::vector<uint32_t> hist, scat; bool scat_default; };
 
 int main(int argc, char **argv) {
@@ -67,6 +80,16 @@ int main(int argc, char **argv) {
     orders.push_back({"S7 hist recency(256)   | scatter xcd-range asc", recency(W, 256), {}, true});
     orders.push_back({"S8 hist recency(2048)  | scatter xcd-range desc", recency(W, 2048), xcd_range(W, true), false});
 
+    if (argc > 2) {
+        orders.resize(1);
+        orders.push_back({"G1  scatter launch order (round-robin XCDs)", identity(W), identity(W), false});
+        static char names[8][64];
+        int k = 0;
+        for (uint32_t g : {2u, 4u, 8u, 16u, 32u, 64u, 256u}) {
+            snprintf(names[k], 64, "G%-3u scatter groups of %u tiles per XCD", g, g);
+            orders.push_back({names[k++], identity(W), grouped(W, g), false});
+        }
+    }
     hipEvent_t ev[4][3][2], t0, t1;
     for (auto &a : ev) for (auto &b : a) for (auto &c : b) CK(hipEventCreate(&c));
     CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));

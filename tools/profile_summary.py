@@ -53,10 +53,13 @@ for k in sorted(set(fetch) | set(write)):
     rows[k] = {"fetch_bytes_corrected_x2": fb, "write_bytes": wb, "hbm_bytes_per_launch": fb + wb,
                "raw_FETCH_SIZE": fetch.get(k, 0.0), "raw_WRITE_SIZE": write.get(k, 0.0)}
 json.dump(rows, open(f"{out}/{rnd}_hbm_traffic_per_launch.json", "w"), indent=1)
-scat = [v for k, v in rows.items() if "scatter_kernel" in k]
-if scat:
-    json.dump({"kernel": "scatter_kernel", "round": rnd, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 10 --warmup 2 --no-cpu-baseline`",
-               "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE x1; both x1024 B",
-               **scat[0]}, open(f"{out}/scatter_traffic.json", "w"), indent=1)
+src = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 10 --warmup 2 --no-cpu-baseline`"
+corr = "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE x1; both x1024 B"
+# bench.py reads <dominant kernel>_traffic.json: the contract path's scatter and the one-call path's look-back scatter
+for fname, kname, pick in (("scatter_traffic.json", "scatter_kernel", lambda k: "scatter_kernel" in k and "onesweep" not in k),
+                           ("lookback_scatter_traffic.json", "onesweep_scatter_kernel", lambda k: "onesweep_scatter_kernel" in k)):
+    hit = [v for k, v in rows.items() if pick(k)]
+    if hit:
+        json.dump({"kernel": kname, "round": rnd, "source": src, "correction": corr, **hit[0]}, open(f"{out}/{fname}", "w"), indent=1)
 print(open(f"{out}/{rnd}_bench_kernel_stats.csv").read())
 print(json.dumps(rows, indent=1))

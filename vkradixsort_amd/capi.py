@@ -22,7 +22,9 @@ VRS_KERNEL_HISTOGRAM = 0
 VRS_KERNEL_PREFIX = 1
 VRS_KERNEL_SCATTER = 2
 VRS_KERNEL_SINGLE = 3
-KERNEL_NAMES = {0: "histogram", 1: "prefix", 2: "scatter", 3: "single"}
+VRS_KERNEL_DIGIT_TABLES = 4
+VRS_KERNEL_LOOKBACK_SCATTER = 5
+KERNEL_NAMES = {0: "histogram", 1: "prefix", 2: "scatter", 3: "single", 4: "digit_tables", 5: "lookback_scatter"}
 
 VRS_KEYS_INT32 = 0
 VRS_KEYS_FLOAT32_TO_SORTABLE = 1
@@ -32,6 +34,8 @@ VRS_TUNE_XCD_REMAP = 0
 VRS_TUNE_SCATTER_VARIANT = 1
 VRS_TUNE_FUSED_PREFIX = 2
 VRS_TUNE_RANK_MODE = 3
+VRS_TUNE_ONE_CALL_MIN_KEYS = 4
+VRS_TUNE_DEBUG_MISPLACE_STREAMS = 5
 
 
 class PushConstants(Structure):
@@ -89,6 +93,7 @@ _SIGNATURES = [
     ("vrs_profile_enable_mask", c_int, [c_void_p, c_uint32]),
     ("vrs_profile_reset", c_int, [c_void_p]),
     ("vrs_profile_query", c_int, [c_void_p, c_int, POINTER(c_uint64), POINTER(c_double)]),
+    ("vrs_profile_query_launch", c_int, [c_void_p, c_int, c_uint64, POINTER(c_double)]),
     ("vrs_debug_download_offsets", c_int, [c_void_p, c_void_p, c_size_t]),
     ("vrs_debug_atomic_rank_selftest", c_int, [c_void_p, c_uint32, c_uint32, POINTER(c_uint64)]),
     ("vrs_rank_mode", c_int, [c_void_p]),

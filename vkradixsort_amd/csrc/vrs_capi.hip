@@ -45,7 +45,19 @@ struct vrs_context_t {
         hipEvent_t start, stop;
     };
     std::vector<EventPair> events[VRS_KERNEL_COUNT];
-    size_t events_used[VRS_KERNEL_COUNT] = {0, 0, 0, 0};
+    size_t events_used[VRS_KERNEL_COUNT] = {};
+    // one-call sort for large N (K5 in vrs_kernels.hip)
+    uint32_t one_call_min_keys = 1u << 20;
+    uint32_t *os_tables = nullptr;       // [4][kStreams][256] digit tables, zero between sorts
+    vrs::OnesweepPlan *os_plan = nullptr;
+    uint32_t *os_status = nullptr;       // look-back status rows
+    size_t os_status_rows = 0;
+    uint32_t *os_host_max_tiles = nullptr;  // pinned copy of plan->max_tiles
+    hipEvent_t os_plan_ready = nullptr;
+    bool os_misplace = false;            // test hook, VRS_TUNE_DEBUG_MISPLACE_STREAMS
+    bool xcc_map_valid = false;          // the probe found block b on an XCC that depends on b % 8 only
+    unsigned long long xcc_map = 0;      // byte x = that XCC for b % 8 == x
+    uint64_t os_fallback_passes = 0;     // passes the one-call sort ran through the contract path (unbalanced streams)
 };
 
 struct vrs_buffer_t {
@@ -175,6 +187,32 @@ int atomic_rank_selftest(vrs_context ctx, uint32_t rounds, uint32_t seed, uint64
     return VRS_OK;
 }
 
+// Where do the blocks of a big grid run?  The look-back streams of the one-call sort are laid out for "block b runs
+// on XCC b % 8" (any fixed function of b % 8 will do, a single XCC included).  That placement is observed, not
+// promised, so it is probed here; the kernels re-check it per workgroup and stay correct without it.
+int probe_xcc_map(vrs_context ctx) {
+    constexpr uint32_t kBlocks = 4096;
+    uint32_t *d = nullptr;
+    VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), kBlocks * sizeof(uint32_t)));
+    std::vector<uint32_t> h(kBlocks, 0);
+    hipError_t e = vrs::launch_xcc_probe(ctx->stream, d, kBlocks);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, kBlocks * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(ctx, "XCC placement probe", e);
+    unsigned long long map = 0;
+    bool valid = true;
+    for (uint32_t b = 0; b < kBlocks && valid; ++b) {
+        if (b < 8)
+            map |= static_cast<unsigned long long>(h[b] & 0xFFu) << (8 * b);
+        else
+            valid = h[b] == h[b & 7u];
+    }
+    ctx->xcc_map = map;
+    ctx->xcc_map_valid = valid;
+    return VRS_OK;
+}
+
 int create_context(int device_ordinal, hipStream_t borrowed, bool borrow, vrs_context *out_ctx) {
     if (!out_ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "out_ctx is NULL");
     *out_ctx = nullptr;
@@ -214,6 +252,7 @@ int create_context(int device_ordinal, hipStream_t borrowed, bool borrow, vrs_co
         if (atomic_rank_selftest(ctx, 512, 0x5EEDu, &mismatches) == VRS_OK && mismatches == 0)
             ctx->atomic_rank_verified = true;
         ctx->scatter.atomic_rank = ctx->atomic_rank_verified;
+        (void)probe_xcc_map(ctx);
         ctx->last_error.clear();
     }
     *out_ctx = ctx;
@@ -325,6 +364,11 @@ int vrs_context_destroy(vrs_context ctx) {
     if (ctx->scratch.chunk_sums) (void)hipFree(ctx->scratch.chunk_sums);
     if (ctx->scratch.granules) (void)hipFree(ctx->scratch.granules);
     if (ctx->sub_hist) (void)hipFree(ctx->sub_hist);
+    if (ctx->os_tables) (void)hipFree(ctx->os_tables);
+    if (ctx->os_plan) (void)hipFree(ctx->os_plan);
+    if (ctx->os_status) (void)hipFree(ctx->os_status);
+    if (ctx->os_host_max_tiles) (void)hipHostFree(ctx->os_host_max_tiles);
+    if (ctx->os_plan_ready) (void)hipEventDestroy(ctx->os_plan_ready);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VRS_OK;
@@ -547,15 +591,8 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
     return VRS_OK;
 }
 
-// One-call form: the four passes of MultiRadixSort::execute's hot loop (MultiRadixSort.cpp:50-61) with the
-// library choosing NUM_BLOCKS_PER_WORKGROUP and owning the histogram table.
-static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
-                           vrs_buffer values_tmp, uint32_t n, int key_bytes = 4) {
-    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
-    if (n == 0) return VRS_OK;
-    const uint32_t B = launch_tile_blocks(key_bytes);
-    vrs_push_constants pc{n, 0, vrs_workgroup_count(n, B), B};
-    const size_t need = static_cast<size_t>(pc.g_num_workgroups) * VRS_RADIX_SORT_BINS * sizeof(uint32_t);
+static int ensure_sort_hist(vrs_context ctx, uint32_t workgroups) {
+    const size_t need = static_cast<size_t>(workgroups) * VRS_RADIX_SORT_BINS * sizeof(uint32_t);
     if (!ctx->sort_hist || ctx->sort_hist->size < need) {
         if (ctx->sort_hist) {
             VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -565,15 +602,114 @@ static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp
         int rc = vrs_buffer_create(ctx, need, &ctx->sort_hist);
         if (rc) return rc;
     }
-    for (uint32_t i = 0; i < static_cast<uint32_t>(key_bytes); ++i) {  // one pass per key byte: 4 or 8 (even either way)
-        pc.g_shift = 8 * i;
+    return VRS_OK;
+}
+
+// one contract pass (stage 0 + stage 1) of the one-call forms
+static int contract_pass(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values, vrs_buffer values_tmp,
+                         vrs_push_constants *pc, uint32_t i, int key_bytes) {
+    pc->g_shift = 8 * i;
+    vrs_buffer kin = (i & 1u) ? keys_tmp : keys, kout = (i & 1u) ? keys : keys_tmp;
+    int rc = run_histogram_stage(ctx, kin, ctx->sort_hist, pc, key_bytes);
+    if (rc) return rc;
+    return run_sort_stage(ctx, kin, kout, values ? ((i & 1u) ? values_tmp : values) : nullptr,
+                          values ? ((i & 1u) ? values : values_tmp) : nullptr, ctx->sort_hist, pc, values != nullptr,
+                          key_bytes);
+}
+
+// Large-N form of the one-call sort (K5): ONE counting read of the keys, then four scatter passes that find their
+// offsets by look-back along kStreams independent streams -- 36 instead of 48 bytes per key.  A pass whose streams
+// are too unequal for the fixed grid (they follow the data) runs as a contract pass instead.
+static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values, vrs_buffer values_tmp,
+                         uint32_t n) {
+    constexpr uint32_t S = vrs::kStreams, T = vrs::kOnesweepTile;
+    const uint32_t W = (n + T - 1) / T;
+    const uint32_t tiles0 = (W + S - 1) / S;           // tiles per pass-0 stream
+    const uint32_t stream_len = tiles0 * T;             // < 2^30 + 8192
+    const uint32_t tile_cap = tiles0 + tiles0 / 4 + 2;  // streams of later passes may be up to 25 % longer
+    if (!ctx->os_tables) {
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_tables), vrs::kDigitTableWords * sizeof(uint32_t)));
+        VRS_HIP(ctx, hipMemsetAsync(ctx->os_tables, 0, vrs::kDigitTableWords * sizeof(uint32_t), ctx->stream));
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_plan), sizeof(vrs::OnesweepPlan)));
+        VRS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->os_host_max_tiles), 4 * sizeof(uint32_t)));
+        VRS_HIP(ctx, hipEventCreateWithFlags(&ctx->os_plan_ready, hipEventDisableTiming));
+    }
+    const size_t pass_rows = static_cast<size_t>(S) * tile_cap;  // status rows of one pass
+    const size_t rows = 4 * pass_rows;
+    if (rows > ctx->os_status_rows) {
+        if (ctx->os_status) {
+            VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            VRS_HIP(ctx, hipFree(ctx->os_status));
+            ctx->os_status = nullptr;
+            ctx->os_status_rows = 0;
+        }
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_status), rows * VRS_RADIX_SORT_BINS * sizeof(uint32_t)));
+        ctx->os_status_rows = rows;
+    }
+    int rc;
+    vrs::LaunchEvents ev;
+    if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, static_cast<const uint32_t *>(keys->ptr), n, stream_len,
+                                          ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS, ev));
+    VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, n, stream_len));
+    VRS_HIP(ctx, hipMemcpyAsync(ctx->os_host_max_tiles, ctx->os_plan->max_tiles, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    VRS_HIP(ctx, hipEventRecord(ctx->os_plan_ready, ctx->stream));
+    vrs_push_constants pc{n, 0, W, 32};
+    for (uint32_t i = 0; i < 4; ++i) {
+        // pass 0's streams are slices of the input (known here); the others come back from the plan while pass 0 runs
+        uint32_t max_tiles = tiles0;
+        if (i == 1) VRS_HIP(ctx, hipEventSynchronize(ctx->os_plan_ready));
+        if (i > 0) max_tiles = ctx->os_host_max_tiles[i];
+        if (max_tiles > tile_cap) {
+            ctx->os_fallback_passes++;
+            if ((rc = ensure_sort_hist(ctx, W))) return rc;
+            if ((rc = contract_pass(ctx, keys, keys_tmp, values, values_tmp, &pc, i, 4))) return rc;
+            continue;
+        }
         vrs_buffer kin = (i & 1u) ? keys_tmp : keys, kout = (i & 1u) ? keys : keys_tmp;
-        int rc = run_histogram_stage(ctx, kin, ctx->sort_hist, &pc, key_bytes);
-        if (rc) return rc;
-        rc = run_sort_stage(ctx, kin, kout, values ? ((i & 1u) ? values_tmp : values) : nullptr,
-                            values ? ((i & 1u) ? values : values_tmp) : nullptr, ctx->sort_hist, &pc, values != nullptr,
-                            key_bytes);
-        if (rc) return rc;
+        vrs_buffer vin = values ? ((i & 1u) ? values_tmp : values) : nullptr;
+        vrs_buffer vout = values ? ((i & 1u) ? values : values_tmp) : nullptr;
+        if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+        VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, static_cast<const uint32_t *>(kin->ptr),
+                                                  static_cast<uint32_t *>(kout->ptr),
+                                                  vin ? static_cast<const uint32_t *>(vin->ptr) : nullptr,
+                                                  vout ? static_cast<uint32_t *>(vout->ptr) : nullptr, ctx->os_plan, i,
+                                                  ctx->os_status + i * pass_rows * VRS_RADIX_SORT_BINS, max_tiles,
+                                                  ctx->scatter.atomic_rank, ctx->xcc_map, ev, ctx->os_misplace));
+    }
+    return VRS_OK;
+}
+
+// One-call form: the four passes of MultiRadixSort::execute's hot loop (MultiRadixSort.cpp:50-61) with the
+// library choosing NUM_BLOCKS_PER_WORKGROUP and owning the histogram table.
+static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
+                           vrs_buffer values_tmp, uint32_t n, int key_bytes = 4) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (n == 0) return VRS_OK;
+    const uint32_t B = launch_tile_blocks(key_bytes);
+    vrs_push_constants pc{n, 0, vrs_workgroup_count(n, B), B};
+    int rc;
+    {
+        const size_t bytes = static_cast<size_t>(n) * key_bytes;
+        if ((rc = check_buffer(ctx, keys, bytes, "keys"))) return rc;
+        if ((rc = check_buffer(ctx, keys_tmp, bytes, "keys_tmp"))) return rc;
+        if (keys->ptr == keys_tmp->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "keys and keys_tmp alias");
+        if (values) {
+            const size_t vbytes = static_cast<size_t>(n) * sizeof(uint32_t);
+            if ((rc = check_buffer(ctx, values, vbytes, "values"))) return rc;
+            if ((rc = check_buffer(ctx, values_tmp, vbytes, "values_tmp"))) return rc;
+            if (values->ptr == values_tmp->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "values and values_tmp alias");
+        }
+    }
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    // the look-back status words carry 30-bit counts; the counting read uses 16-byte loads
+    if (key_bytes == 4 && ctx->xcc_map_valid && ctx->one_call_min_keys != 0 && n >= ctx->one_call_min_keys && n < (1u << 30) &&
+        (reinterpret_cast<uintptr_t>(keys->ptr) & 15u) == 0)
+        return sort_one_read(ctx, keys, keys_tmp, values, values_tmp, n);
+    if ((rc = ensure_sort_hist(ctx, pc.g_num_workgroups))) return rc;
+    for (uint32_t i = 0; i < static_cast<uint32_t>(key_bytes); ++i) {  // one pass per key byte: 4 or 8 (even either way)
+        if ((rc = contract_pass(ctx, keys, keys_tmp, values, values_tmp, &pc, i, key_bytes))) return rc;
     }
     return VRS_OK;
 }
@@ -639,6 +775,19 @@ int vrs_profile_query(vrs_context ctx, int kernel_id, uint64_t *launches, double
     }
     if (launches) *launches = used;
     if (total_ms) *total_ms = sum;
+    return VRS_OK;
+}
+
+int vrs_profile_query_launch(vrs_context ctx, int kernel_id, uint64_t index, double *ms) {
+    if (!ctx || !ms) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or ms is NULL");
+    if (kernel_id < 0 || kernel_id >= VRS_KERNEL_COUNT)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "kernel_id out of range");
+    if (index >= ctx->events_used[kernel_id]) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "no such instrumented launch");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float t = 0.f;
+    VRS_HIP(ctx, hipEventElapsedTime(&t, ctx->events[kernel_id][index].start, ctx->events[kernel_id][index].stop));
+    *ms = t;
     return VRS_OK;
 }
 
@@ -742,6 +891,13 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             }
             return VRS_OK;
         }
+        case VRS_TUNE_ONE_CALL_MIN_KEYS:
+            if (value < 0) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "one-call threshold must be >= 0");
+            ctx->one_call_min_keys = static_cast<uint32_t>(value);
+            return VRS_OK;
+        case VRS_TUNE_DEBUG_MISPLACE_STREAMS:
+            ctx->os_misplace = value != 0;
+            return VRS_OK;
         default:
             return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "unknown tuning key");
     }

@@ -60,6 +60,32 @@ hipError_t launch_atomic_rank_selftest(hipStream_t stream, uint32_t rounds, uint
 
 hipError_t launch_transform_keys(hipStream_t stream, uint32_t *keys, uint32_t n, int mode);
 
+// ---- one-call sort for large N (K5): one counting read, four look-back scatter passes
+#ifndef VRS_STREAMS
+#define VRS_STREAMS 32
+#endif
+constexpr int kStreams = VRS_STREAMS;    // independent look-back streams per pass (a multiple of 8: stream s runs on XCD s % 8)
+constexpr uint32_t kOnesweepTile = 8192; // keys per tile
+constexpr int kTableSlices = 8;          // digit_tables workgroups per pass-0 stream
+struct OnesweepPlan {
+    uint32_t seed[4][kStreams][256];  // global offset of digit d at the start of stream s of pass p
+    uint32_t start[4][kStreams];      // first key of the stream in the pass's input
+    uint32_t len[4][kStreams];
+    uint32_t max_tiles[4];            // tiles of the longest stream of each pass
+};
+constexpr size_t kDigitTableWords = 4u * kStreams * 256u;
+// also zeroes status[0, status_words) (a multiple of 4 words, 16-byte aligned): the look-back words of all passes
+hipError_t launch_digit_tables(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t stream_len, uint32_t *tables,
+                               uint32_t *status, size_t status_words, LaunchEvents ev = {});
+hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t stream_len);
+// status: kStreams * max_tiles rows of 256 words, zeroed
+hipError_t launch_onesweep_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *values_in,
+                                   uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t *status,
+                                   uint32_t max_tiles, bool atomic_rank, unsigned long long xcc_map, LaunchEvents ev = {},
+                                   bool misplace = false);
+// out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups
+hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks);
+
 hipError_t launch_single(hipStream_t stream, uint32_t *buffer0, uint32_t *buffer1, uint32_t n,
                          LaunchEvents ev = {});
 

@@ -18,6 +18,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 // Launch with optional timing events bound to the dispatch packet itself (hipExtLaunchKernel): unlike
@@ -514,6 +516,85 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_w(uint32_t v, uint32_t 
     return base + incl - v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decoupled look-back along a STREAM of tiles (the one-call sort, see "K5" below).  One 32-bit status word per
+// (tile, digit): bits 31:30 = 0 not published / 1 the tile's own count / 2 inclusive count of the stream up to
+// and including the tile; bits 29:0 the count.  The word carries its own flag, so no fence is needed.
+//
+// All tiles of a stream are meant to run behind ONE XCD's L2 (block b -> XCD b % 8: observed, probed at context
+// creation, not promised by HIP), so the words are published with L2-resident stores and polled with loads that
+// bypass only the CU's L1: a hand-off costs an L2 round trip instead of a trip through the fabric (measured: 181
+// vs 223 us per pass; writing every word through as well costs 30 us per pass).  Placement is speed only: every
+// workgroup compares HW_REG_XCC_ID with its stream's XCD, and one that finds itself behind another L2 ("foreign")
+// neither reads status words (it re-counts its stream's earlier tiles from the keys) nor publishes L2-resident
+// ones (it stores write-through, which the agent-scope polls of the others do see).
+constexpr uint32_t kLbAggregate = 1u << 30, kLbInclusive = 2u << 30, kLbValue = (1u << 30) - 1u;
+constexpr int kLbBatch = 4;  // status rows fetched per round trip
+
+__device__ __forceinline__ uint32_t lb_load(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load sc1: L1 bypassed, L2 served
+}
+__device__ __forceinline__ void lb_store_through(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store sc1: written through
+}
+__device__ __forceinline__ void lb_store_l2(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // stays (dirty) in this XCD's L2
+}
+
+struct NoLookback {
+    static constexpr bool kEnabled = false;
+};
+__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3u << 11) | 20u); }  // HW_REG_XCC_ID[3:0]
+
+struct StreamLookback {
+    static constexpr bool kEnabled = true;
+    bool foreign = false;     // this workgroup is not behind its stream's L2 (workgroup-uniform)
+    uint32_t recounted = 0;   // foreign only: exclusive count of my digit over the stream's earlier tiles
+    uint32_t *col = nullptr;  // status word of (tile 0 of my stream, digit == my thread)
+    size_t stride = 0;        // words between consecutive tiles of the stream
+    int index = 0;            // this tile's position in its stream
+    uint32_t seed = 0;        // global offset of my digit at the start of the stream
+
+    __device__ __forceinline__ void publish(uint32_t v) const {
+        uint32_t *p = col + static_cast<size_t>(index) * stride;
+        if (foreign) lb_store_through(p, v); else lb_store_l2(p, v);
+    }
+    // rows first, first-1, ...: the row before the stream's first tile reads as "inclusive, 0"
+    __device__ __forceinline__ void fetch(int first, uint32_t (&v)[kLbBatch]) const {
+#pragma unroll
+        for (int r = 0; r < kLbBatch; ++r)
+            v[r] = first - r >= 0 ? lb_load(col + static_cast<size_t>(first - r) * stride) : kLbInclusive;
+    }
+    // exclusive count of my digit over the tiles before mine; v = fetch(index - 1) issued earlier.
+    // Every round trip consumes all rows that are published; at the first unpublished one the REST of the batch is
+    // fetched again in one go (re-polling row by row would serialise one round trip per row).
+    __device__ __forceinline__ uint32_t resolve(uint32_t (&v)[kLbBatch]) const {
+        uint32_t acc = 0;
+        int first = index - 1;
+        for (;;) {
+            bool done = false, blocked = false;
+            int consumed = 0;
+#pragma unroll
+            for (int r = 0; r < kLbBatch; ++r) {
+                if (!done && !blocked) {
+                    const uint32_t x = v[r];
+                    if ((x >> 30) == 0u) {
+                        blocked = true;  // the tile is resident (dispatched before mine) and will publish
+                    } else {
+                        acc += x & kLbValue;
+                        consumed = r + 1;
+                        done = (x >> 30) == 2u;
+                    }
+                }
+            }
+            if (done) return acc;
+            first -= consumed;
+            if (blocked) __builtin_amdgcn_s_sleep(4);
+            fetch(first, v);
+        }
+    }
+};
+
 // `run_off`: thread t (< 256) holds the running global offset of digit t, advanced by this chunk's
 // count of t.  `valid`: number of real keys in the chunk (the rest is padding that sorts last).
 // FULL: valid == ITEMS*WAVES*64 is known, so no load or store is predicated.
@@ -521,10 +602,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_w(uint32_t v, uint32_t 
 // Every phase is written as "issue all ITEMS independent LDS/global operations, then consume":
 // a workgroup is latency-bound (one pass over its keys, few waves), so dependent
 // read -> wait -> write chains per item are what must not appear in the ISA.
-template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, bool FULL, typename DG>
+// LB: StreamLookback obtains the digit offsets by decoupled look-back instead of from `run_off`.
+template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, bool FULL, typename DG, typename LB = NoLookback>
 __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> &sm, const K *kin,
                                               const uint32_t *vin, K *kout, uint32_t *vout,
-                                              uint32_t valid, const DG &dg, uint32_t &run_off) {
+                                              uint32_t valid, const DG &dg, uint32_t &run_off, const LB lb = {}) {
     constexpr uint32_t THREADS = WAVES * 64;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -591,6 +673,8 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     VRS_MARK(2);
 
     // ---- thread t == digit t: digit starts inside the chunk, per-wave starts, global base
+    uint32_t lb_total = 0, lb_excl = 0;
+    uint32_t lb_rows[LB::kEnabled ? kLbBatch : 1];
     {
         uint32_t c[WAVES];
         uint32_t total = 0;
@@ -609,8 +693,17 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
                 sm.whist[v][tid] = acc;
                 acc += c[v];
             }
-            sm.gbase[tid] = run_off - excl;
-            run_off += total;
+            if constexpr (LB::kEnabled) {
+                // publish my count first (successors can add it without waiting for my look-back), then put the
+                // first batch of predecessor rows in flight: the re-bucketing below hides their latency
+                lb.publish(kLbAggregate | total);
+                if (!lb.foreign) lb.fetch(lb.index - 1, lb_rows);
+                lb_total = total;
+                lb_excl = excl;
+            } else {
+                sm.gbase[tid] = run_off - excl;
+                run_off += total;
+            }
         }
     }
     __syncthreads();
@@ -624,6 +717,13 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     if constexpr (PAIRS) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) sm.vals[rank[i]] = val[i];
+    }
+    if constexpr (LB::kEnabled) {
+        if (tid < kBins) {
+            const uint32_t before = lb.foreign ? lb.recounted : lb.resolve(lb_rows);
+            lb.publish(kLbInclusive | (before + lb_total));
+            sm.gbase[tid] = lb.seed + before - lb_excl;
+        }
     }
     __syncthreads();
     VRS_MARK(4);
@@ -693,6 +793,258 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
             scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, kin, vin, keys_out, values_out, valid, dg, run_off);
     }
     VRS_MARK_FLUSH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: the one-call sort (vrs_sort_keys_u32 / vrs_sort_pairs_u32) for large N: 36 instead of 48 bytes per key.
+//
+// The contract path reads the keys once per pass just to count them, because the [W][256] table is part of the
+// reference's interface.  When the library owns all four passes it can count ONCE, before the first pass, and let
+// every scatter pass find its offsets by decoupled look-back.  A single look-back chain over all tiles does not
+// fit this chip (tiles must stay in XCD-contiguous order for the L2s to merge their partial lines, and ~500
+// resident tiles finish 12 ns apart while an agent-scope round trip takes ~1 us), so the tiles of a pass are cut
+// into kStreams independent STREAMS whose starting offsets are known before the pass starts:
+//   pass 0   stream s = the s-th slice of the input (whole 8192-key tiles);
+//   pass p>0 stream s = the keys whose digit p-1 lies in [8s, 8s+8): after pass p-1 they are the contiguous range
+//            [P_{p-1}[8s], P_{p-1}[8s+8]) of its output (P = exclusive digit prefix), whatever their order inside.
+// digit_tables_kernel counts, in one read of the keys, H[p][s][d] = #keys of stream s of pass p with digit p == d
+// (97 KiB of LDS counters per workgroup); plan_kernel turns H into stream ranges and seeds
+// seed[p][s][d] = P_p[d] + sum_{s'<s} H[p][s'][d]; onesweep_scatter_kernel walks stream s in tile order on XCD
+// s % 8 (tiles of one stream are neighbours in that L2) and looks back only along its own stream.
+// Streams follow the data: a pass whose streams are too unequal (keys that are all multiples of 256, say) is run
+// through the contract path instead (the host reads max_tiles).
+constexpr int kTableThreads = 1024;
+constexpr int kTableUnroll = 4;
+constexpr int kStreamDigits = kBins / kStreams;  // digits of pass p-1 per stream of pass p
+// LDS row of one stream's 256 counters, padded by one word: keys that share the counted digit but not the stream
+// (sorted input) would otherwise hit one LDS bank from every lane
+constexpr int kTableRow = kBins + 1;
+
+__device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t key) {
+    const uint32_t d0 = key & 255u, d1 = (key >> 8) & 255u, d2 = (key >> 16) & 255u, d3 = key >> 24;
+    atomicAdd(&t0[d0], 1u);
+    atomicAdd(&t1[(d0 / kStreamDigits) * kTableRow + d1], 1u);
+    atomicAdd(&t2[(d1 / kStreamDigits) * kTableRow + d2], 1u);
+    atomicAdd(&t3[(d2 / kStreamDigits) * kTableRow + d3], 1u);
+}
+
+// Four counters per lane (one 16-byte vector of keys).  Same-address lanes of one LDS atomic are served one after the
+// other, so input with few distinct counters per wave (constant bytes, sorted or clustered keys) would crawl.  When
+// (nearly) every lane's four keys share a counter -- the signature of such input -- the wave adds once per DISTINCT
+// counter (up to 8 of them, found by __ballot peeling) instead of once per key; uniform-random keys fail the vote
+// at once and take the plain path.
+__device__ __forceinline__ void table_add4(uint32_t *t, const uint32_t (&idx)[4], uint32_t lane) {
+    const bool same = idx[0] == idx[1] && idx[1] == idx[2] && idx[2] == idx[3];
+    const uint64_t clustered = __ballot(same);
+    if (__popcll(clustered) >= 48) {  // wave-uniform
+        uint64_t rest = clustered;
+#pragma unroll 1
+        for (int round = 0; round < 8 && rest != 0ull; ++round) {
+            const uint32_t first = static_cast<uint32_t>(__ffsll(static_cast<long long>(rest))) - 1u;
+            const uint32_t v = __builtin_amdgcn_readlane(idx[0], first);
+            const uint64_t peers = __ballot(idx[0] == v) & rest;
+            if (lane == first) atomicAdd(&t[v], 4u * static_cast<uint32_t>(__popcll(peers)));
+            rest &= ~peers;
+        }
+        if ((rest >> lane) & 1ull) atomicAdd(&t[idx[0]], 4u);
+        if (!same) {  // the few lanes that straddle two counters
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(&t[idx[j]], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&t[idx[j]], 1u);
+    }
+}
+
+__device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, const uint4 &q) {
+    const uint32_t k[4] = {q.x, q.y, q.z, q.w};
+    const uint32_t lane = lane_id();
+    uint32_t i0[4], i1[4], i2[4], i3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t d0 = k[j] & 255u, d1 = (k[j] >> 8) & 255u, d2 = (k[j] >> 16) & 255u, d3 = k[j] >> 24;
+        i0[j] = d0;
+        i1[j] = (d0 / kStreamDigits) * kTableRow + d1;
+        i2[j] = (d1 / kStreamDigits) * kTableRow + d2;
+        i3[j] = (d2 / kStreamDigits) * kTableRow + d3;
+    }
+    table_add4(t0, i0, lane);
+    table_add4(t1, i1, lane);
+    table_add4(t2, i2, lane);
+    table_add4(t3, i3, lane);
+}
+
+// grid = kStreams * slices workgroups; workgroup (s, g) counts the g-th part of pass-0 stream s and zeroes its share
+// of the look-back status words of all four passes.  keys must be 16-byte aligned; stream_len is a multiple of
+// 4 * slices.  One workgroup per CU (97 KiB of LDS), so the loads of step k+1 are issued before step k is counted.
+__global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const uint32_t *__restrict__ keys, uint32_t n,
+                                                                     uint32_t stream_len, uint32_t slices,
+                                                                     uint32_t *__restrict__ tables,
+                                                                     uint4 *__restrict__ status, uint32_t status_vecs) {
+    __shared__ uint32_t t0[kBins];
+    __shared__ uint32_t t[3][kStreams * kTableRow];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t c = tid; c < 3u * kStreams * kTableRow; c += kTableThreads) (&t[0][0])[c] = 0;
+    if (tid < kBins) t0[tid] = 0;
+    {
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        const uint32_t per = (status_vecs + gridDim.x - 1) / gridDim.x;
+        const uint32_t z0 = blockIdx.x * per, z1 = min(z0 + per, status_vecs);
+        for (uint32_t c = z0 + tid; c < z1; c += kTableThreads) status[c] = zero;
+    }
+    __syncthreads();
+    const uint32_t s = blockIdx.x / slices, g = blockIdx.x % slices;
+    const uint32_t part = stream_len / slices;
+    const uint64_t begin64 = static_cast<uint64_t>(s) * stream_len + static_cast<uint64_t>(g) * part;
+    if (begin64 < n) {
+        const uint32_t begin = static_cast<uint32_t>(begin64);
+        const uint32_t len = min(part, n - begin);
+        const uint4 *v = reinterpret_cast<const uint4 *>(keys + begin);
+        const uint32_t nvec = len / 4u;
+        constexpr uint32_t kStep = kTableThreads * kTableUnroll;
+        uint32_t i0 = 0;
+        uint4 cur[kTableUnroll], nxt[kTableUnroll];
+        if (kStep <= nvec) {
+#pragma unroll
+            for (int r = 0; r < kTableUnroll; ++r) cur[r] = v[r * kTableThreads + tid];
+        }
+        for (; i0 + kStep <= nvec; i0 += kStep) {
+            const bool more = i0 + 2u * kStep <= nvec;  // workgroup-uniform
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < kTableUnroll; ++r) nxt[r] = v[i0 + kStep + r * kTableThreads + tid];
+            }
+#pragma unroll
+            for (int r = 0; r < kTableUnroll; ++r) digit_tables_count_vec(t0, t[0], t[1], t[2], cur[r]);
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < kTableUnroll; ++r) cur[r] = nxt[r];
+            }
+        }
+        for (uint32_t i = i0 + tid; i < nvec; i += kTableThreads) {
+            const uint4 q = v[i];
+            digit_tables_count(t0, t[0], t[1], t[2], q.x);
+            digit_tables_count(t0, t[0], t[1], t[2], q.y);
+            digit_tables_count(t0, t[0], t[1], t[2], q.z);
+            digit_tables_count(t0, t[0], t[1], t[2], q.w);
+        }
+        const uint32_t tail = nvec * 4u + tid;  // at most 3 keys, only at the very end of the input
+        if (tail < len) digit_tables_count(t0, t[0], t[1], t[2], keys[begin + tail]);
+    }
+    __syncthreads();
+    if (tid < kBins && t0[tid])
+        __hip_atomic_fetch_add(&tables[static_cast<size_t>(s) * kBins + tid], t0[tid], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t c = tid; c < 3u * kStreams * kBins; c += kTableThreads) {  // c = (pass - 1, stream, digit)
+        const uint32_t x = (&t[0][0])[(c >> 8) * kTableRow + (c & 255u)];
+        if (x) __hip_atomic_fetch_add(&tables[kStreams * kBins + c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// one workgroup; thread (p, d).  Leaves `tables` zeroed for the next sort.
+__global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ tables, OnesweepPlan *__restrict__ plan,
+                                                        uint32_t n, uint32_t stream_len) {
+    __shared__ uint32_t s_prefix[4][kBins + 1];
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_max[4];
+    const uint32_t tid = threadIdx.x, p = tid >> 8, d = tid & 255u, lane = tid & 63u, wave = tid >> 6;
+    uint32_t before[kStreams];
+    uint32_t total = 0;
+#pragma unroll
+    for (int s = 0; s < kStreams; ++s) before[s] = tables[(static_cast<size_t>(p) * kStreams + s) * kBins + d];
+#pragma unroll
+    for (int s = 0; s < kStreams; ++s) {
+        const uint32_t c = before[s];
+        before[s] = total;
+        total += c;
+        tables[(static_cast<size_t>(p) * kStreams + s) * kBins + d] = 0;
+    }
+    uint32_t incl = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t x = __shfl_up(incl, o);
+        if (lane >= static_cast<uint32_t>(o)) incl += x;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    if (tid < 4) s_max[tid] = 0;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t j = p * 4u; j < wave; ++j) base += s_wave[j];
+    const uint32_t digit_start = base + incl - total;
+    s_prefix[p][d] = digit_start;
+    if (d == 255u) s_prefix[p][kBins] = n;
+#pragma unroll
+    for (int s = 0; s < kStreams; ++s) plan->seed[p][s][d] = digit_start + before[s];
+    __syncthreads();
+    if (tid < 4u * kStreams) {
+        const uint32_t q = tid / kStreams, s = tid % kStreams;
+        uint32_t start, end;
+        if (q == 0) {
+            const uint64_t a = static_cast<uint64_t>(s) * stream_len, b = a + stream_len;
+            start = static_cast<uint32_t>(a < n ? a : n);
+            end = static_cast<uint32_t>(b < n ? b : n);
+        } else {
+            start = s_prefix[q - 1][s * kStreamDigits];
+            end = s_prefix[q - 1][(s + 1) * kStreamDigits];
+        }
+        plan->start[q][s] = start;
+        plan->len[q][s] = end - start;
+        atomicMax(&s_max[q], (end - start + kOnesweepTile - 1u) / kOnesweepTile);
+    }
+    __syncthreads();
+    if (tid < 4) plan->max_tiles[tid] = s_max[tid];
+}
+
+// grid = kStreams * T workgroups (T = tiles of the longest stream); block b -> XCD b % 8 -> stream b%8 + 8*((b/8) % (kStreams/8)),
+// tile (b/8) / (kStreams/8): every tile's predecessors in its stream sit in lower-numbered blocks of the same XCD.
+template <int ITEMS, int WAVES, bool PAIRS, int RANK, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const uint32_t *__restrict__ keys_in,
+                                                                       uint32_t *__restrict__ keys_out,
+                                                                       const uint32_t *__restrict__ values_in,
+                                                                       uint32_t *__restrict__ values_out,
+                                                                       const OnesweepPlan *__restrict__ plan,
+                                                                       uint32_t pass, uint32_t *__restrict__ status,
+                                                                       unsigned long long xcc_map, int misplace) {
+    static_assert(ITEMS * WAVES * 64 == kOnesweepTile, "the plan counts tiles of kOnesweepTile keys");
+    __shared__ ChunkSmem<uint32_t, ITEMS, WAVES, PAIRS> sm;
+    const uint32_t k = blockIdx.x >> 3, i = k / (kStreams / 8);
+    // misplace (test hook): odd tiles of every stream run on the neighbouring XCD, so the look-back has to work
+    // through the write-through copies instead of one L2
+    const uint32_t s = ((blockIdx.x + (misplace ? (i & 1u) : 0u)) & 7u) + 8u * (k % (kStreams / 8));
+    const uint32_t len = plan->len[pass][s];
+    if (static_cast<uint64_t>(i) * kOnesweepTile >= len) return;  // uniform per workgroup
+    const uint32_t done = i * kOnesweepTile;
+    const uint32_t begin = plan->start[pass][s] + done;
+    const uint32_t valid = min(static_cast<uint32_t>(kOnesweepTile), len - done);
+    RadixDigit<uint32_t> dg;
+    dg.shift = 8u * pass;
+    StreamLookback lb;
+    // byte x of xcc_map = XCC of the blocks with blockIdx % 8 == x (probed); my stream's tiles sit in blocks = s (mod 8)
+    lb.foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * (s & 7u))) & 0xFFu);
+    if (lb.foreign) {
+        // the earlier tiles of the stream are all full: count their digits from the keys themselves
+        uint32_t *cnt = sm.whist[0];
+        if (threadIdx.x < kBins) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t *k0 = keys_in + plan->start[pass][s];
+        for (uint32_t j = threadIdx.x; j < done; j += WAVES * 64) atomicAdd(&cnt[dg(k0[j])], 1u);
+        __syncthreads();
+        if (threadIdx.x < kBins) lb.recounted = cnt[threadIdx.x];
+        __syncthreads();
+    }
+    lb.col = status + static_cast<size_t>(s) * kBins + (threadIdx.x & 255u);
+    lb.stride = static_cast<size_t>(kStreams) * kBins;
+    lb.index = static_cast<int>(i);
+    lb.seed = threadIdx.x < kBins ? plan->seed[pass][s][threadIdx.x] : 0u;
+    uint32_t unused = 0;
+    const uint32_t *vin = PAIRS ? values_in + begin : nullptr;
+    if (valid == kOnesweepTile)
+        scatter_chunk<uint32_t, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg,
+                                                                 unused, lb);
+    else
+        scatter_chunk<uint32_t, ITEMS, WAVES, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg,
+                                                                  unused, lb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -956,6 +1308,47 @@ hipError_t launch_scatter(hipStream_t stream, const void *keys_in, void *keys_ou
 hipError_t launch_atomic_rank_selftest(hipStream_t stream, uint32_t rounds, uint32_t seed,
                                        unsigned long long *mismatches) {
     hipLaunchKernelGGL(atomic_rank_selftest_kernel, dim3(1024), dim3(kThreads), 0, stream, rounds, seed, mismatches);
+    return hipGetLastError();
+}
+
+__global__ void xcc_probe_kernel(uint32_t *out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
+}
+
+hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks) {
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(blocks), dim3(512), 0, stream, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_digit_tables(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t stream_len, uint32_t *tables,
+                               uint32_t *status, size_t status_words, LaunchEvents ev) {
+    VRS_LAUNCH(digit_tables_kernel, dim3(kStreams * kTableSlices), dim3(kTableThreads), stream, ev, keys, n, stream_len,
+               static_cast<uint32_t>(kTableSlices), tables, reinterpret_cast<uint4 *>(status),
+               static_cast<uint32_t>(status_words / 4));
+    return hipGetLastError();
+}
+
+hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t stream_len) {
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(4 * kBins), 0, stream, tables, plan, n, stream_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_onesweep_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *values_in,
+                                   uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t *status,
+                                   uint32_t max_tiles, bool atomic_rank, unsigned long long xcc_map, LaunchEvents ev,
+                                   bool misplace) {
+    const int mis = misplace ? 1 : 0;
+    const dim3 grid(kStreams * max_tiles), block(512);
+    const bool pairs = values_in != nullptr;
+#define VRS_ONESWEEP(PAIRS, RANK)                                                                                       \
+    VRS_LAUNCH((onesweep_scatter_kernel<16, 8, PAIRS, RANK, 4>), grid, block, stream, ev, keys_in, keys_out, values_in, \
+               values_out, plan, pass, status, xcc_map, mis)
+    if (pairs) {
+        if (atomic_rank) VRS_ONESWEEP(true, RANK_ATOMIC); else VRS_ONESWEEP(true, RANK_BALLOT);
+    } else {
+        if (atomic_rank) VRS_ONESWEEP(false, RANK_ATOMIC); else VRS_ONESWEEP(false, RANK_BALLOT);
+    }
+#undef VRS_ONESWEEP
     return hipGetLastError();
 }
 
