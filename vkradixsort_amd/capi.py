@@ -24,6 +24,7 @@ VRS_KERNEL_SCATTER = 2
 VRS_KERNEL_SINGLE = 3
 VRS_KERNEL_DIGIT_TABLES = 4
 VRS_KERNEL_LOOKBACK_SCATTER = 5
+VRS_KERNEL_COUNT = 6
 KERNEL_NAMES = {0: "histogram", 1: "prefix", 2: "scatter", 3: "single", 4: "digit_tables", 5: "lookback_scatter"}
 
 VRS_KEYS_INT32 = 0
