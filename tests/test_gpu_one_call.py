@@ -150,27 +150,29 @@ def test_look_back_does_not_depend_on_xcd_placement(gpu_context):
     assert np.array_equal(out, np.sort(keys))
 
 
-def test_unaligned_keys_take_the_contract_passes(gpu_context):
-    """The counting read uses 16-byte loads: a wrapped pointer that is not 16-byte aligned must still sort."""
+@pytest.mark.parametrize("offset_keys", [1, 2, 3])
+def test_unaligned_keys(gpu_context, offset_keys):
+    """The counting read uses 16-byte loads: a wrapped pointer that is only 4-byte aligned (a sub-range of a larger
+    allocation, as the multi-GPU exchange produces) must peel its way to alignment and touch nothing outside."""
     ctx, lib = gpu_context, gpu_context.lib
     n = (1 << 20) + 77
-    keys = make_keys(n, "uniform", seed=3)
-    big = vrs.Buffer(ctx, S(4 * (n + 4)))
+    keys = make_keys(n, "uniform", seed=3 + offset_keys)
+    big = vrs.Buffer(ctx, S(4 * (n + 8)))
     tmp = vrs.Buffer(ctx, S(4 * n))
-    host = np.concatenate([np.zeros(1, np.uint32), keys, np.zeros(3, np.uint32)])
+    host = np.concatenate([np.full(offset_keys, 0xAAAAAAAA, np.uint32), keys, np.full(8 - offset_keys, 0xBBBBBBBB, np.uint32)])
     ctx.check(lib.vrs_buffer_upload(ctx.handle, big.handle, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
-    view = vrs.Buffer(ctx, S(4 * n), device_ptr=big.getDeviceAddress() + 4)
+    view = vrs.Buffer(ctx, S(4 * n), device_ptr=big.getDeviceAddress() + 4 * offset_keys)
     ctx.profileReset()
     ctx.profileEnable(True)
     try:
         ctx.check(lib.vrs_sort_keys_u32(ctx.handle, view.handle, tmp.handle, n))
         ctx.waitIdle()
-        assert launches(ctx, capi.VRS_KERNEL_DIGIT_TABLES) == 0
+        assert launches(ctx, capi.VRS_KERNEL_DIGIT_TABLES) == 1 and launches(ctx, capi.VRS_KERNEL_LOOKBACK_SCATTER) == 4
     finally:
         ctx.profileEnable(False)
     ctx.check(lib.vrs_buffer_download(ctx.handle, big.handle, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
-    assert host[0] == 0 and not host[-3:].any()
-    assert np.array_equal(host[1:n + 1], np.sort(keys))
+    assert (host[:offset_keys] == 0xAAAAAAAA).all() and (host[n + offset_keys:] == 0xBBBBBBBB).all()
+    assert np.array_equal(host[offset_keys:n + offset_keys], np.sort(keys))
     for b in (view, big, tmp):
         b.release()
 

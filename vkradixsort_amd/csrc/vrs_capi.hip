@@ -703,9 +703,8 @@ static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp
         }
     }
     VRS_HIP(ctx, hipSetDevice(ctx->device));
-    // the look-back status words carry 30-bit counts; the counting read uses 16-byte loads
-    if (key_bytes == 4 && ctx->xcc_map_valid && ctx->one_call_min_keys != 0 && n >= ctx->one_call_min_keys && n < (1u << 30) &&
-        (reinterpret_cast<uintptr_t>(keys->ptr) & 15u) == 0)
+    // the look-back status words carry 30-bit counts
+    if (key_bytes == 4 && ctx->xcc_map_valid && ctx->one_call_min_keys != 0 && n >= ctx->one_call_min_keys && n < (1u << 30))
         return sort_one_read(ctx, keys, keys_tmp, values, values_tmp, n);
     if ((rc = ensure_sort_hist(ctx, pc.g_num_workgroups))) return rc;
     for (uint32_t i = 0; i < static_cast<uint32_t>(key_bytes); ++i) {  // one pass per key byte: 4 or 8 (even either way)

@@ -876,8 +876,7 @@ __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t
 }
 
 // grid = kStreams * slices workgroups; workgroup (s, g) counts the g-th part of pass-0 stream s and zeroes its share
-// of the look-back status words of all four passes.  keys must be 16-byte aligned; stream_len is a multiple of
-// 4 * slices.  One workgroup per CU (97 KiB of LDS), so the loads of step k+1 are issued before step k is counted.
+// of the look-back status words of all four passes.  stream_len is a multiple of 4 * slices.  One workgroup per CU (97 KiB of LDS), so the loads of step k+1 are issued before step k is counted.
 __global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const uint32_t *__restrict__ keys, uint32_t n,
                                                                      uint32_t stream_len, uint32_t slices,
                                                                      uint32_t *__restrict__ tables,
@@ -900,8 +899,13 @@ __global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const uint3
     if (begin64 < n) {
         const uint32_t begin = static_cast<uint32_t>(begin64);
         const uint32_t len = min(part, n - begin);
-        const uint4 *v = reinterpret_cast<const uint4 *>(keys + begin);
-        const uint32_t nvec = len / 4u;
+        // 16-byte loads need a 16-byte aligned address: peel `head` keys (the buffer may start anywhere in a larger
+        // allocation; every slice starts a multiple of 4 keys after it)
+        const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
+        const uint32_t head = min((4u - mis) & 3u, len);
+        if (tid < head) digit_tables_count(t0, t[0], t[1], t[2], keys[begin + tid]);
+        const uint4 *v = reinterpret_cast<const uint4 *>(keys + begin + head);
+        const uint32_t nvec = (len - head) / 4u;
         constexpr uint32_t kStep = kTableThreads * kTableUnroll;
         uint32_t i0 = 0;
         uint4 cur[kTableUnroll], nxt[kTableUnroll];
@@ -929,7 +933,7 @@ __global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const uint3
             digit_tables_count(t0, t[0], t[1], t[2], q.z);
             digit_tables_count(t0, t[0], t[1], t[2], q.w);
         }
-        const uint32_t tail = nvec * 4u + tid;  // at most 3 keys, only at the very end of the input
+        const uint32_t tail = head + nvec * 4u + tid;  // at most 3 keys
         if (tail < len) digit_tables_count(t0, t[0], t[1], t[2], keys[begin + tail]);
     }
     __syncthreads();

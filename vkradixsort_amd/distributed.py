@@ -161,11 +161,11 @@ class HipLocalSortBackend(LocalSortBackend):
             return keys
         if n > self.capacity or keys.numel() < n:
             raise ValueError("received more keys than the backend capacity")
-        a, b = keys, self.scratch
-        for i in range(4):
-            self._pass(a, b, n, 8 * i)
-            a, b = b, a
-        return a  # four passes: back in `keys`
+        # the library's own four-pass loop (one counting read + look-back scatters from 2^20 keys on); the result is
+        # back in `keys`, `scratch` is the ping-pong partner
+        ctx = self.ctx
+        ctx.check(ctx.lib.vrs_sort_keys_u32(ctx.handle, self._buf(keys).handle, self._buf(self.scratch).handle, n))
+        return keys
 
 
 class RangeShardedSort:
