@@ -364,13 +364,14 @@ def bench_multi(args):
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{world} x {n} uniform random uint32 keys (std::mt19937 seed 1000+rank), sharded by key "
-                                   f"range: top-byte partition pass, RCCL all-to-all over xGMI, local 4-pass multi_radixsort",
+                                   f"range: top-byte partition pass, RCCL all-to-all over xGMI, local 4-pass multi_radixsort (one-call form)",
                        "num_elements_per_gpu": n, "num_blocks_per_workgroup": B, "parallelism": f"range-sharded x{world}",
                        "exchange_rounds": sorter.rounds, "rounds_tried_in_warmup_ms": {str(k): round(v * 1e3, 3) for k, v in tried.items()},
-                       "hbm_bytes_per_key": 60},
-            "roofline": {"bound": "hbm", "achieved": round(60 * n * K / elapsed / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(60 * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "note": "per GPU, whole step incl. the xGMI exchange: 12 B/key partition pass + 48 B/key local sort"},
+                       "hbm_bytes_per_key": 48},
+            "roofline": {"bound": "hbm", "achieved": round(48 * n * K / elapsed / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(48 * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "note": "per GPU, whole step incl. the xGMI exchange: 12 B/key partition pass + 36 B/key local "
+                                 "sorts (one counting read + four look-back scatter passes per received sub-range)"},
             "shard_sizes": [x[2] for x in g],
             "verified": check,
         }

@@ -335,7 +335,8 @@ def test_cpp_host_examples_run_and_verify():
     from vkradixsort_amd import build
     _, exes = build.build_host()
     multi, single = exes
-    for args in (["1000000"], ["1000", "1"], ["100003", "7", "5"], ["2000000", "32", "2", "3", "28bit"]):
+    for args in (["1000000"], ["1000", "1"], ["100003", "7", "5"], ["2000000", "32", "2", "3", "28bit"],
+                 ["3000000", "32", "1", "2", "full", "32bit", "onecall"]):  # m_oneCallSort: the library runs the passes
         p = subprocess.run([str(multi), *args], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stdout + p.stderr
         assert "[MultiRadixSort] Sorting " + str(int(float(args[0]))) + " 32bit numbers." in p.stdout

@@ -28,6 +28,12 @@ public:
 
     void execute(GPUContext *gpuContext);
 
+    // false (default): execute() drives the two stages pass by pass, exactly like the reference's loop
+    // (MultiRadixSort.cpp:50-61).  true: the library runs the passes itself (vrs_sort_keys_u32 / _u64) -- for 32-bit
+    // keys from 2^20 elements on that is ONE counting read plus four look-back scatter passes, 36 instead of
+    // 48 bytes per key.  Same buffers, same result in buffer 0.
+    bool m_oneCallSort = false;
+
     // results of the last execute() for programmatic callers / the sweep harness
     [[nodiscard]] double gpuSortTimeMs() const { return m_gpuSortTime; }
     [[nodiscard]] double cpuSortTimeMs() const { return m_cpuSortTime; }

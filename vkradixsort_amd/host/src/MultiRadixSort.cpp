@@ -74,12 +74,18 @@ void BasicMultiRadixSort<T>::execute(GPUContext *gpuContext) {
             m_gpuContext->waitIdle();
         }
         const auto begin = std::chrono::steady_clock::now();
-        Semaphore awaitBeforeExecution = NULL_SEMAPHORE;
-        for (uint32_t i = 0; i < NUM_ITERATIONS; i++) {
-            m_pass->m_pushConstantsHistogram.g_shift = 8 * i;
-            m_pass->m_pushConstants.g_shift = 8 * i;
-            awaitBeforeExecution = m_pass->execute(awaitBeforeExecution);
-            m_gpuContext->incrementActiveIndex();
+        if (m_oneCallSort) {
+            const auto sortKeys = sizeof(T) == 8 ? vrs_sort_keys_u64 : vrs_sort_keys_u32;
+            m_gpuContext->check(sortKeys(m_gpuContext->handle(), m_buffers[0]->getBuffer(), m_buffers[1]->getBuffer(), NUM_ELEMENTS),
+                                "Failed to enqueue the one-call sort");
+        } else {
+            Semaphore awaitBeforeExecution = NULL_SEMAPHORE;
+            for (uint32_t i = 0; i < NUM_ITERATIONS; i++) {
+                m_pass->m_pushConstantsHistogram.g_shift = 8 * i;
+                m_pass->m_pushConstants.g_shift = 8 * i;
+                awaitBeforeExecution = m_pass->execute(awaitBeforeExecution);
+                m_gpuContext->incrementActiveIndex();
+            }
         }
         m_gpuContext->waitIdle();
         const double ms = elapsedMs(begin, std::chrono::steady_clock::now());
