@@ -1,4 +1,6 @@
 """Randomised end-to-end check on the GPU: random N, B, key width, distribution, pairs, ranking method, against numpy.
+Every third 32-bit case goes through the one-call sort with a random threshold (one counting read + look-back scatter
+passes above it), on a sub-range of a larger allocation at a random 4-byte alignment.
    python tools/fuzz_gpu.py [seconds] [seed]"""
 import ctypes
 import sys
@@ -15,7 +17,7 @@ S = vrs.Buffer.BufferSettings
 
 
 def make_keys(rs, n, bits64):
-    kind = rs.randint(0, 8)
+    kind = rs.randint(0, 11)
     if bits64:
         k = (rs.randint(0, 2 ** 32, n, dtype=np.uint64) << np.uint64(32)) | rs.randint(0, 2 ** 32, n, dtype=np.uint64)
         full = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -34,6 +36,14 @@ def make_keys(rs, n, bits64):
         k = k >> k.dtype.type(rs.randint(1, 30))
     elif kind == 6 and n > 10:
         k[rs.randint(0, n, max(1, n // 10))] = full
+    elif kind == 8:  # one byte constant (some pass of the one-call sort must fall back)
+        k = k & ~(k.dtype.type(0xFF) << k.dtype.type(8 * rs.randint(0, k.dtype.itemsize)))
+    elif kind == 9:  # a heavy group of 8 digit values in one byte: unbalanced look-back streams
+        byte = k.dtype.type(8 * rs.randint(0, k.dtype.itemsize))
+        heavy = rs.randint(0, 100, n) < rs.randint(20, 90)
+        k = np.where(heavy, (k & ~(k.dtype.type(0xF8) << byte)) | (k.dtype.type(8 * rs.randint(0, 32)) << byte), k).astype(k.dtype)
+    elif kind == 10:  # few distinct keys
+        k = rs.choice(k[:max(1, min(n, rs.randint(1, 50)))], n).astype(k.dtype)
     return k, kind
 
 
@@ -56,8 +66,43 @@ def main():
             ctx.setTuning(capi.VRS_TUNE_RANK_MODE, mode)
             ctx.setTuning(capi.VRS_TUNE_FUSED_PREFIX, int(rs.randint(0, 2)))
             ctx.setTuning(capi.VRS_TUNE_XCD_REMAP, int(rs.randint(0, 2)))
+            one_call = (not bits64) and rs.randint(0, 3) == 0
+            if one_call:
+                n = int(rs.choice([rs.randint(1, 20000), rs.randint(1, 3000000), rs.randint(1000000, 9000000)]))
             keys, kind = make_keys(rs, n, bits64)
             vals = rs.randint(0, 2 ** 32, n, dtype=np.uint32) if pairs else None
+            if one_call:
+                ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, int(rs.choice([0, 1, n, max(1, n // 2), 1 << 20])))
+                off = int(rs.randint(0, 4))
+                big = vrs.Buffer(ctx, S(4 * (n + 8)))
+                host = np.concatenate([np.full(off, 0x11111111, np.uint32), keys, np.full(8 - off, 0x22222222, np.uint32)])
+                ctx.check(lib.vrs_buffer_upload(ctx.handle, big.handle, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
+                k0 = vrs.Buffer(ctx, S(4 * n), device_ptr=big.getDeviceAddress() + 4 * off)
+                k1 = vrs.Buffer(ctx, S(4 * n))
+                if pairs:
+                    v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
+                    v1 = vrs.Buffer(ctx, S(4 * n))
+                    ctx.check(lib.vrs_sort_pairs_u32(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+                else:
+                    ctx.check(lib.vrs_sort_keys_u32(ctx.handle, k0.handle, k1.handle, n))
+                ctx.check(lib.vrs_buffer_download(ctx.handle, big.handle, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
+                order = np.argsort(keys, kind="stable")
+                ok = np.array_equal(host[off:off + n], keys[order]) and (host[:off] == 0x11111111).all() and \
+                    (host[off + n:] == 0x22222222).all()
+                if pairs:
+                    ov = np.empty(n, np.uint32)
+                    v0.downloadWithStagingBuffer(ov)
+                    ok = ok and np.array_equal(ov, vals[order])
+                    v0.release()
+                    v1.release()
+                for b in (k0, k1, big):
+                    b.release()
+                ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, 1 << 20)
+                cases += 1
+                if not ok:
+                    print(f"MISMATCH one-call n={n} pairs={pairs} kind={kind} mode={mode} off={off} seed={seed} case={cases}")
+                    sys.exit(1)
+                continue
             kb = 8 if bits64 else 4
             W = lib.vrs_workgroup_count(n, B)
             kbuf = [vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(kb * n), keys), vrs.Buffer(ctx, S(kb * n))]
