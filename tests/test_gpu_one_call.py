@@ -177,6 +177,55 @@ def test_unaligned_keys(gpu_context, offset_keys):
         b.release()
 
 
+def make_keys64(n, dist, seed=11):
+    rs = np.random.RandomState(seed)
+    k = (rs.randint(0, 2 ** 32, n, dtype=np.uint64) << np.uint64(32)) | rs.randint(0, 2 ** 32, n, dtype=np.uint64)
+    if dist == "uniform":
+        return k
+    if dist == "44bit":  # the reference's SORT_64_BIT generator, MultiRadixSort.cpp:128
+        return k >> np.uint64(20)
+    if dist == "low32":  # upper word zero: passes 5-7 have every key in stream 0 -> contract passes
+        return k & np.uint64(0xFFFFFFFF)
+    if dist == "high32":
+        return k & np.uint64(0xFFFFFFFF00000000)
+    if dist == "sorted":
+        return np.sort(k)
+    if dist == "max_keys":
+        return np.where(k % np.uint64(3) == 0, np.uint64(0xFFFFFFFFFFFFFFFF), k).astype(np.uint64)
+    raise ValueError(dist)
+
+
+@pytest.mark.parametrize("dist", ["uniform", "44bit", "low32", "high32", "sorted", "max_keys"])
+@pytest.mark.parametrize("n", [(1 << 20) + 3, 2500001])
+def test_one_read_sort_u64(gpu_context, n, dist):
+    """64-bit keys (the reference's SORT_64_BIT stub): two groups of four passes, each with its own counting read."""
+    ctx, lib = gpu_context, gpu_context.lib
+    keys = make_keys64(n, dist, seed=n % 89)
+    big = vrs.Buffer(ctx, S(8 * (n + 2)))
+    tmp = vrs.Buffer(ctx, S(8 * n))
+    host = np.concatenate([np.full(1, 0x1111111111111111, np.uint64), keys, np.full(1, 0x2222222222222222, np.uint64)])
+    ctx.check(lib.vrs_buffer_upload(ctx.handle, big.handle, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
+    view = vrs.Buffer(ctx, S(8 * n), device_ptr=big.getDeviceAddress() + 8)  # 8-byte, not 16-byte aligned
+    ctx.profileReset()
+    ctx.profileEnable(True)
+    try:
+        ctx.check(lib.vrs_sort_keys_u64(ctx.handle, view.handle, tmp.handle, n))
+        ctx.waitIdle()
+        stats = {name: launches(ctx, kid) for kid, name in capi.KERNEL_NAMES.items()}
+    finally:
+        ctx.profileEnable(False)
+    ctx.check(lib.vrs_buffer_download(ctx.handle, big.handle, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
+    assert host[0] == 0x1111111111111111 and host[-1] == 0x2222222222222222
+    assert np.array_equal(host[1:-1], np.sort(keys))
+    assert stats["digit_tables"] == 2 and stats["lookback_scatter"] + stats["scatter"] == 8
+    if dist in ("uniform", "sorted"):
+        assert stats["lookback_scatter"] == 8
+    if dist in ("low32", "high32"):
+        assert stats["scatter"] >= 3
+    for b in (view, big, tmp):
+        b.release()
+
+
 def test_one_read_sort_1e8_equals_std_sort(gpu_context, oracle):
     """BASELINE.json config 3 through the one-call entry point."""
     n = 10 ** 8

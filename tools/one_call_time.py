@@ -36,12 +36,15 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     dist = sys.argv[3] if len(sys.argv) > 3 else "uniform"
     pairs = len(sys.argv) > 4 and sys.argv[4] == "pairs"
+    u64 = len(sys.argv) > 4 and sys.argv[4] == "u64"
     keys = make(n, dist)
+    if u64:
+        keys = (keys.astype(np.uint64) << np.uint64(32)) | make(n, "uniform")[::-1].astype(np.uint64)
     ref = np.sort(keys, kind="stable")
     vals = np.arange(n, dtype=np.uint32)
     with vrs.GPUContext(0) as gpu:
         lib = gpu.lib
-        S = vrs.Buffer.BufferSettings(4 * n)
+        S = vrs.Buffer.BufferSettings(keys.itemsize * n)
         src = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S, keys)
         k0, k1 = vrs.Buffer(gpu, S), vrs.Buffer(gpu, S)
         if pairs:
@@ -62,6 +65,8 @@ def main():
                 t0 = time.perf_counter()
                 if pairs:
                     rc = lib.vrs_sort_pairs_u32(gpu.handle, k0.handle, k1.handle, v0.handle, v1.handle, n)
+                elif u64:
+                    rc = lib.vrs_sort_keys_u64(gpu.handle, k0.handle, k1.handle, n)
                 else:
                     rc = lib.vrs_sort_keys_u32(gpu.handle, k0.handle, k1.handle, n)
                 if rc and not os.environ.get("VRS_DT_DEBUG"):
@@ -70,7 +75,7 @@ def main():
                 if r >= 2:
                     times.append(time.perf_counter() - t0)
             gpu.profileEnable(False)
-            out = np.empty(n, dtype=np.uint32)
+            out = np.empty(n, dtype=keys.dtype)
             k0.downloadWithStagingBuffer(out)
             ok = bool(np.array_equal(out, ref))
             if pairs:
@@ -78,7 +83,7 @@ def main():
                 v0.downloadWithStagingBuffer(vo)
                 ok = ok and bool(np.array_equal(vo, np.argsort(keys, kind="stable").astype(np.uint32)))
             t = min(times)
-            line = f"N={n} {dist} {'pairs' if pairs else 'keys'} one_read={'on' if min_keys else 'off'} exact={ok} min={t*1e3:.3f}ms med={np.median(times)*1e3:.3f}ms {n/t/1e9:.2f} G/s"
+            line = f"N={n} {dist} {'pairs' if pairs else 'u64 keys' if u64 else 'keys'} one_read={'on' if min_keys else 'off'} exact={ok} min={t*1e3:.3f}ms med={np.median(times)*1e3:.3f}ms {n/t/1e9:.2f} G/s"
             for kid, name in capi.KERNEL_NAMES.items():
                 cnt, ms = gpu.profileQuery(kid)
                 if cnt:

@@ -617,16 +617,18 @@ static int contract_pass(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
                           key_bytes);
 }
 
-// Large-N form of the one-call sort (K5): ONE counting read of the keys, then four scatter passes that find their
-// offsets by look-back along kStreams independent streams -- 36 instead of 48 bytes per key.  A pass whose streams
-// are too unequal for the fixed grid (they follow the data) runs as a contract pass instead.
+// Large-N form of the one-call sort (K5): ONE counting read of the keys per group of four passes, then four scatter
+// passes that find their offsets by look-back along kStreams independent streams -- 36 instead of 48 bytes per key
+// (64-bit keys: two groups, 136 instead of 192).  A pass whose streams are too unequal for the fixed grid (they
+// follow the data) runs as a contract pass instead.
 static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values, vrs_buffer values_tmp,
-                         uint32_t n) {
-    constexpr uint32_t S = vrs::kStreams, T = vrs::kOnesweepTile;
-    const uint32_t W = (n + T - 1) / T;
-    const uint32_t tiles0 = (W + S - 1) / S;           // tiles per pass-0 stream
-    const uint32_t stream_len = tiles0 * T;             // < 2^30 + 8192
-    const uint32_t tile_cap = tiles0 + tiles0 / 4 + 2;  // streams of later passes may be up to 25 % longer
+                         uint32_t n, int key_bytes) {
+    constexpr uint32_t S = vrs::kStreams;
+    const uint32_t T = vrs::onesweep_tile_keys(key_bytes);
+    const uint32_t tiles_total = (n + T - 1) / T;
+    const uint32_t tiles0 = (tiles_total + S - 1) / S;  // tiles per pass-0 stream
+    const uint32_t stream_len = tiles0 * T;              // < 2^30 + 8192
+    const uint32_t tile_cap = tiles0 + tiles0 / 4 + 2;   // streams of later passes may be up to 25 % longer
     if (!ctx->os_tables) {
         VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_tables), vrs::kDigitTableWords * sizeof(uint32_t)));
         VRS_HIP(ctx, hipMemsetAsync(ctx->os_tables, 0, vrs::kDigitTableWords * sizeof(uint32_t), ctx->stream));
@@ -648,35 +650,41 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
     }
     int rc;
     vrs::LaunchEvents ev;
-    if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
-    VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, static_cast<const uint32_t *>(keys->ptr), n, stream_len,
-                                          ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS, ev));
-    VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, n, stream_len));
-    VRS_HIP(ctx, hipMemcpyAsync(ctx->os_host_max_tiles, ctx->os_plan->max_tiles, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    VRS_HIP(ctx, hipEventRecord(ctx->os_plan_ready, ctx->stream));
-    vrs_push_constants pc{n, 0, W, 32};
-    for (uint32_t i = 0; i < 4; ++i) {
-        // pass 0's streams are slices of the input (known here); the others come back from the plan while pass 0 runs
-        uint32_t max_tiles = tiles0;
-        if (i == 1) VRS_HIP(ctx, hipEventSynchronize(ctx->os_plan_ready));
-        if (i > 0) max_tiles = ctx->os_host_max_tiles[i];
-        if (max_tiles > tile_cap) {
-            ctx->os_fallback_passes++;
-            if ((rc = ensure_sort_hist(ctx, W))) return rc;
-            if ((rc = contract_pass(ctx, keys, keys_tmp, values, values_tmp, &pc, i, 4))) return rc;
-            continue;
+    // the contract pass a group may fall back to walks launch tiles of 32 (uint32) / 16 (uint64) blocks
+    const uint32_t B = launch_tile_blocks(key_bytes);
+    vrs_push_constants pc{n, 0, vrs_workgroup_count(n, B), B};
+    for (uint32_t group = 0; group < static_cast<uint32_t>(key_bytes) / 4u; ++group) {
+        // the group's input is in `keys`: every group is four passes long
+        if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
+        VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, keys->ptr, n, key_bytes, 32u * group, stream_len, ctx->os_tables,
+                                              ctx->os_status, rows * VRS_RADIX_SORT_BINS, ev));
+        VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, n, stream_len, T));
+        VRS_HIP(ctx, hipMemcpyAsync(ctx->os_host_max_tiles, ctx->os_plan->max_tiles, 4 * sizeof(uint32_t),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        VRS_HIP(ctx, hipEventRecord(ctx->os_plan_ready, ctx->stream));
+        for (uint32_t i = 0; i < 4; ++i) {
+            const uint32_t pass = 4u * group + i;  // == shift / 8
+            // pass 0's streams are slices of the input (known here); the others come back from the plan while it runs
+            uint32_t max_tiles = tiles0;
+            if (i == 1) VRS_HIP(ctx, hipEventSynchronize(ctx->os_plan_ready));
+            if (i > 0) max_tiles = ctx->os_host_max_tiles[i];
+            if (max_tiles > tile_cap) {
+                ctx->os_fallback_passes++;
+                if ((rc = ensure_sort_hist(ctx, pc.g_num_workgroups))) return rc;
+                if ((rc = contract_pass(ctx, keys, keys_tmp, values, values_tmp, &pc, pass, key_bytes))) return rc;
+                continue;
+            }
+            vrs_buffer kin = (pass & 1u) ? keys_tmp : keys, kout = (pass & 1u) ? keys : keys_tmp;
+            vrs_buffer vin = values ? ((pass & 1u) ? values_tmp : values) : nullptr;
+            vrs_buffer vout = values ? ((pass & 1u) ? values : values_tmp) : nullptr;
+            if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+            VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kin->ptr, kout->ptr,
+                                                      vin ? static_cast<const uint32_t *>(vin->ptr) : nullptr,
+                                                      vout ? static_cast<uint32_t *>(vout->ptr) : nullptr, ctx->os_plan, i,
+                                                      8u * pass, ctx->os_status + i * pass_rows * VRS_RADIX_SORT_BINS,
+                                                      max_tiles, ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes, ev,
+                                                      ctx->os_misplace));
         }
-        vrs_buffer kin = (i & 1u) ? keys_tmp : keys, kout = (i & 1u) ? keys : keys_tmp;
-        vrs_buffer vin = values ? ((i & 1u) ? values_tmp : values) : nullptr;
-        vrs_buffer vout = values ? ((i & 1u) ? values : values_tmp) : nullptr;
-        if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
-        VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, static_cast<const uint32_t *>(kin->ptr),
-                                                  static_cast<uint32_t *>(kout->ptr),
-                                                  vin ? static_cast<const uint32_t *>(vin->ptr) : nullptr,
-                                                  vout ? static_cast<uint32_t *>(vout->ptr) : nullptr, ctx->os_plan, i,
-                                                  ctx->os_status + i * pass_rows * VRS_RADIX_SORT_BINS, max_tiles,
-                                                  ctx->scatter.atomic_rank, ctx->xcc_map, ev, ctx->os_misplace));
     }
     return VRS_OK;
 }
@@ -703,9 +711,10 @@ static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp
         }
     }
     VRS_HIP(ctx, hipSetDevice(ctx->device));
-    // the look-back status words carry 30-bit counts
-    if (key_bytes == 4 && ctx->xcc_map_valid && ctx->one_call_min_keys != 0 && n >= ctx->one_call_min_keys && n < (1u << 30))
-        return sort_one_read(ctx, keys, keys_tmp, values, values_tmp, n);
+    // the look-back status words carry 30-bit counts; there is no one-call pairs entry point for 64-bit keys
+    if (ctx->xcc_map_valid && ctx->one_call_min_keys != 0 && n >= ctx->one_call_min_keys && n < (1u << 30) &&
+        (key_bytes == 4 || !values))
+        return sort_one_read(ctx, keys, keys_tmp, values, values_tmp, n, key_bytes);
     if ((rc = ensure_sort_hist(ctx, pc.g_num_workgroups))) return rc;
     for (uint32_t i = 0; i < static_cast<uint32_t>(key_bytes); ++i) {  // one pass per key byte: 4 or 8 (even either way)
         if ((rc = contract_pass(ctx, keys, keys_tmp, values, values_tmp, &pc, i, key_bytes))) return rc;

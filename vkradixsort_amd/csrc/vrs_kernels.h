@@ -65,7 +65,6 @@ hipError_t launch_transform_keys(hipStream_t stream, uint32_t *keys, uint32_t n,
 #define VRS_STREAMS 32
 #endif
 constexpr int kStreams = VRS_STREAMS;    // independent look-back streams per pass (a multiple of 8: stream s runs on XCD s % 8)
-constexpr uint32_t kOnesweepTile = 8192; // keys per tile
 constexpr int kTableSlices = 8;          // digit_tables workgroups per pass-0 stream
 struct OnesweepPlan {
     uint32_t seed[4][kStreams][256];  // global offset of digit d at the start of stream s of pass p
@@ -74,15 +73,21 @@ struct OnesweepPlan {
     uint32_t max_tiles[4];            // tiles of the longest stream of each pass
 };
 constexpr size_t kDigitTableWords = 4u * kStreams * 256u;
-// also zeroes status[0, status_words) (a multiple of 4 words, 16-byte aligned): the look-back words of all passes
-hipError_t launch_digit_tables(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t stream_len, uint32_t *tables,
-                               uint32_t *status, size_t status_words, LaunchEvents ev = {});
-hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t stream_len);
-// status: kStreams * max_tiles rows of 256 words, zeroed
-hipError_t launch_onesweep_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *values_in,
-                                   uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t *status,
-                                   uint32_t max_tiles, bool atomic_rank, unsigned long long xcc_map, LaunchEvents ev = {},
-                                   bool misplace = false);
+// keys per look-back tile: 8192 uint32 or 4096 uint64 (32 KiB either way)
+uint32_t onesweep_tile_keys(int key_bytes);
+// counts the four digits at bits [base_shift, base_shift + 32) of every key; also zeroes status[0, status_words)
+// (a multiple of 4 words, 16-byte aligned): the look-back words of the four passes
+hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
+                               uint32_t stream_len, uint32_t *tables, uint32_t *status, size_t status_words,
+                               LaunchEvents ev = {});
+hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t stream_len,
+                       uint32_t tile);
+// pass = 0..3 inside the group the plan was made for, shift = the pass's absolute bit position; status: kStreams *
+// max_tiles rows of 256 words, zeroed
+hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
+                                   uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
+                                   uint32_t *status, uint32_t max_tiles, bool atomic_rank, unsigned long long xcc_map,
+                                   int key_bytes, LaunchEvents ev = {}, bool misplace = false);
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups
 hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks);
 

@@ -828,13 +828,16 @@ __device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, u
     atomicAdd(&t3[(d2 / kStreamDigits) * kTableRow + d3], 1u);
 }
 
-// Four counters per lane (one 16-byte vector of keys).  Same-address lanes of one LDS atomic are served one after the
+// V counters per lane (one 16-byte vector of keys).  Same-address lanes of one LDS atomic are served one after the
 // other, so input with few distinct counters per wave (constant bytes, sorted or clustered keys) would crawl.  When
-// (nearly) every lane's four keys share a counter -- the signature of such input -- the wave adds once per DISTINCT
+// (nearly) every lane's keys share a counter -- the signature of such input -- the wave adds once per DISTINCT
 // counter (up to 8 of them, found by __ballot peeling) instead of once per key; uniform-random keys fail the vote
 // at once and take the plain path.
-__device__ __forceinline__ void table_add4(uint32_t *t, const uint32_t (&idx)[4], uint32_t lane) {
-    const bool same = idx[0] == idx[1] && idx[1] == idx[2] && idx[2] == idx[3];
+template <int V>
+__device__ __forceinline__ void table_add(uint32_t *t, const uint32_t (&idx)[V], uint32_t lane) {
+    bool same = true;
+#pragma unroll
+    for (int j = 1; j < V; ++j) same = same && idx[j] == idx[0];
     const uint64_t clustered = __ballot(same);
     if (__popcll(clustered) >= 48) {  // wave-uniform
         uint64_t rest = clustered;
@@ -843,44 +846,59 @@ __device__ __forceinline__ void table_add4(uint32_t *t, const uint32_t (&idx)[4]
             const uint32_t first = static_cast<uint32_t>(__ffsll(static_cast<long long>(rest))) - 1u;
             const uint32_t v = __builtin_amdgcn_readlane(idx[0], first);
             const uint64_t peers = __ballot(idx[0] == v) & rest;
-            if (lane == first) atomicAdd(&t[v], 4u * static_cast<uint32_t>(__popcll(peers)));
+            if (lane == first) atomicAdd(&t[v], static_cast<uint32_t>(V) * static_cast<uint32_t>(__popcll(peers)));
             rest &= ~peers;
         }
-        if ((rest >> lane) & 1ull) atomicAdd(&t[idx[0]], 4u);
+        if ((rest >> lane) & 1ull) atomicAdd(&t[idx[0]], static_cast<uint32_t>(V));
         if (!same) {  // the few lanes that straddle two counters
 #pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(&t[idx[j]], 1u);
+            for (int j = 0; j < V; ++j) atomicAdd(&t[idx[j]], 1u);
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(&t[idx[j]], 1u);
+        for (int j = 0; j < V; ++j) atomicAdd(&t[idx[j]], 1u);
     }
 }
 
-__device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, const uint4 &q) {
-    const uint32_t k[4] = {q.x, q.y, q.z, q.w};
+// the 32-bit word of a key that holds the four digits of this group of passes (bits [base_shift, base_shift + 32))
+__device__ __forceinline__ uint32_t digit_word(uint32_t key, uint32_t) { return key; }
+__device__ __forceinline__ uint32_t digit_word(uint64_t key, uint32_t base_shift) {
+    return static_cast<uint32_t>(key >> base_shift);
+}
+
+// one 16-byte vector of keys per lane: 4 uint32 or 2 uint64
+template <typename K>
+__device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3,
+                                                       const typename KeyVec<K>::type &q, uint32_t base_shift) {
+    constexpr int V = KeyVec<K>::kKeys;
     const uint32_t lane = lane_id();
-    uint32_t i0[4], i1[4], i2[4], i3[4];
+    uint32_t i0[V], i1[V], i2[V], i3[V];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t d0 = k[j] & 255u, d1 = (k[j] >> 8) & 255u, d2 = (k[j] >> 16) & 255u, d3 = k[j] >> 24;
+    for (int j = 0; j < V; ++j) {
+        const uint32_t w = digit_word(KeyVec<K>::get(q, j), base_shift);
+        const uint32_t d0 = w & 255u, d1 = (w >> 8) & 255u, d2 = (w >> 16) & 255u, d3 = w >> 24;
         i0[j] = d0;
         i1[j] = (d0 / kStreamDigits) * kTableRow + d1;
         i2[j] = (d1 / kStreamDigits) * kTableRow + d2;
         i3[j] = (d2 / kStreamDigits) * kTableRow + d3;
     }
-    table_add4(t0, i0, lane);
-    table_add4(t1, i1, lane);
-    table_add4(t2, i2, lane);
-    table_add4(t3, i3, lane);
+    table_add<V>(t0, i0, lane);
+    table_add<V>(t1, i1, lane);
+    table_add<V>(t2, i2, lane);
+    table_add<V>(t3, i3, lane);
 }
 
 // grid = kStreams * slices workgroups; workgroup (s, g) counts the g-th part of pass-0 stream s and zeroes its share
-// of the look-back status words of all four passes.  stream_len is a multiple of 4 * slices.  One workgroup per CU (97 KiB of LDS), so the loads of step k+1 are issued before step k is counted.
-__global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const uint32_t *__restrict__ keys, uint32_t n,
-                                                                     uint32_t stream_len, uint32_t slices,
-                                                                     uint32_t *__restrict__ tables,
+// of the look-back status words of all four passes.  stream_len is a multiple of 4 * slices.  One workgroup per CU
+// (97 KiB of LDS), so the loads of step k+1 are issued before step k is counted.  64-bit keys are sorted in two groups
+// of four passes, each with its own counting read: base_shift = 0, then 32.
+template <typename K>
+__global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const K *__restrict__ keys, uint32_t n,
+                                                                     uint32_t base_shift, uint32_t stream_len,
+                                                                     uint32_t slices, uint32_t *__restrict__ tables,
                                                                      uint4 *__restrict__ status, uint32_t status_vecs) {
+    using Vec = typename KeyVec<K>::type;
+    constexpr uint32_t V = KeyVec<K>::kKeys;
     __shared__ uint32_t t0[kBins];
     __shared__ uint32_t t[3][kStreams * kTableRow];
     const uint32_t tid = threadIdx.x;
@@ -900,15 +918,15 @@ __global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const uint3
         const uint32_t begin = static_cast<uint32_t>(begin64);
         const uint32_t len = min(part, n - begin);
         // 16-byte loads need a 16-byte aligned address: peel `head` keys (the buffer may start anywhere in a larger
-        // allocation; every slice starts a multiple of 4 keys after it)
-        const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
-        const uint32_t head = min((4u - mis) & 3u, len);
-        if (tid < head) digit_tables_count(t0, t[0], t[1], t[2], keys[begin + tid]);
-        const uint4 *v = reinterpret_cast<const uint4 *>(keys + begin + head);
-        const uint32_t nvec = (len - head) / 4u;
+        // allocation; every slice starts a multiple of V keys after it)
+        const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) / sizeof(K)) % V);
+        const uint32_t head = min((V - mis) % V, len);
+        if (tid < head) digit_tables_count(t0, t[0], t[1], t[2], digit_word(keys[begin + tid], base_shift));
+        const Vec *v = reinterpret_cast<const Vec *>(keys + begin + head);
+        const uint32_t nvec = (len - head) / V;
         constexpr uint32_t kStep = kTableThreads * kTableUnroll;
         uint32_t i0 = 0;
-        uint4 cur[kTableUnroll], nxt[kTableUnroll];
+        Vec cur[kTableUnroll], nxt[kTableUnroll];
         if (kStep <= nvec) {
 #pragma unroll
             for (int r = 0; r < kTableUnroll; ++r) cur[r] = v[r * kTableThreads + tid];
@@ -920,21 +938,20 @@ __global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const uint3
                 for (int r = 0; r < kTableUnroll; ++r) nxt[r] = v[i0 + kStep + r * kTableThreads + tid];
             }
 #pragma unroll
-            for (int r = 0; r < kTableUnroll; ++r) digit_tables_count_vec(t0, t[0], t[1], t[2], cur[r]);
+            for (int r = 0; r < kTableUnroll; ++r) digit_tables_count_vec<K>(t0, t[0], t[1], t[2], cur[r], base_shift);
             if (more) {
 #pragma unroll
                 for (int r = 0; r < kTableUnroll; ++r) cur[r] = nxt[r];
             }
         }
         for (uint32_t i = i0 + tid; i < nvec; i += kTableThreads) {
-            const uint4 q = v[i];
-            digit_tables_count(t0, t[0], t[1], t[2], q.x);
-            digit_tables_count(t0, t[0], t[1], t[2], q.y);
-            digit_tables_count(t0, t[0], t[1], t[2], q.z);
-            digit_tables_count(t0, t[0], t[1], t[2], q.w);
+            const Vec q = v[i];
+#pragma unroll
+            for (int j = 0; j < static_cast<int>(V); ++j)
+                digit_tables_count(t0, t[0], t[1], t[2], digit_word(KeyVec<K>::get(q, j), base_shift));
         }
-        const uint32_t tail = head + nvec * 4u + tid;  // at most 3 keys
-        if (tail < len) digit_tables_count(t0, t[0], t[1], t[2], keys[begin + tail]);
+        const uint32_t tail = head + nvec * V + tid;  // at most V - 1 keys
+        if (tail < len) digit_tables_count(t0, t[0], t[1], t[2], digit_word(keys[begin + tail], base_shift));
     }
     __syncthreads();
     if (tid < kBins && t0[tid])
@@ -948,7 +965,7 @@ __global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const uint3
 
 // one workgroup; thread (p, d).  Leaves `tables` zeroed for the next sort.
 __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ tables, OnesweepPlan *__restrict__ plan,
-                                                        uint32_t n, uint32_t stream_len) {
+                                                        uint32_t n, uint32_t stream_len, uint32_t tile) {
     __shared__ uint32_t s_prefix[4][kBins + 1];
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max[4];
@@ -994,7 +1011,7 @@ __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ 
         }
         plan->start[q][s] = start;
         plan->len[q][s] = end - start;
-        atomicMax(&s_max[q], (end - start + kOnesweepTile - 1u) / kOnesweepTile);
+        atomicMax(&s_max[q], (end - start + tile - 1u) / tile);
     }
     __syncthreads();
     if (tid < 4) plan->max_tiles[tid] = s_max[tid];
@@ -1002,27 +1019,28 @@ __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ 
 
 // grid = kStreams * T workgroups (T = tiles of the longest stream); block b -> XCD b % 8 -> stream b%8 + 8*((b/8) % (kStreams/8)),
 // tile (b/8) / (kStreams/8): every tile's predecessors in its stream sit in lower-numbered blocks of the same XCD.
-template <int ITEMS, int WAVES, bool PAIRS, int RANK, int OCC>
-__global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const uint32_t *__restrict__ keys_in,
-                                                                       uint32_t *__restrict__ keys_out,
+template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const K *__restrict__ keys_in,
+                                                                       K *__restrict__ keys_out,
                                                                        const uint32_t *__restrict__ values_in,
                                                                        uint32_t *__restrict__ values_out,
                                                                        const OnesweepPlan *__restrict__ plan,
-                                                                       uint32_t pass, uint32_t *__restrict__ status,
+                                                                       uint32_t pass, uint32_t shift,
+                                                                       uint32_t *__restrict__ status,
                                                                        unsigned long long xcc_map, int misplace) {
-    static_assert(ITEMS * WAVES * 64 == kOnesweepTile, "the plan counts tiles of kOnesweepTile keys");
-    __shared__ ChunkSmem<uint32_t, ITEMS, WAVES, PAIRS> sm;
+    constexpr uint32_t kTile = ITEMS * WAVES * 64;  // the tile the plan counted with (onesweep_tile_keys)
+    __shared__ ChunkSmem<K, ITEMS, WAVES, PAIRS> sm;
     const uint32_t k = blockIdx.x >> 3, i = k / (kStreams / 8);
     // misplace (test hook): odd tiles of every stream run on the neighbouring XCD, so the look-back has to work
     // through the write-through copies instead of one L2
     const uint32_t s = ((blockIdx.x + (misplace ? (i & 1u) : 0u)) & 7u) + 8u * (k % (kStreams / 8));
     const uint32_t len = plan->len[pass][s];
-    if (static_cast<uint64_t>(i) * kOnesweepTile >= len) return;  // uniform per workgroup
-    const uint32_t done = i * kOnesweepTile;
+    if (static_cast<uint64_t>(i) * kTile >= len) return;  // uniform per workgroup
+    const uint32_t done = i * kTile;
     const uint32_t begin = plan->start[pass][s] + done;
-    const uint32_t valid = min(static_cast<uint32_t>(kOnesweepTile), len - done);
-    RadixDigit<uint32_t> dg;
-    dg.shift = 8u * pass;
+    const uint32_t valid = min(kTile, len - done);
+    RadixDigit<K> dg;
+    dg.shift = shift;
     StreamLookback lb;
     // byte x of xcc_map = XCC of the blocks with blockIdx % 8 == x (probed); my stream's tiles sit in blocks = s (mod 8)
     lb.foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * (s & 7u))) & 0xFFu);
@@ -1031,7 +1049,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
         uint32_t *cnt = sm.whist[0];
         if (threadIdx.x < kBins) cnt[threadIdx.x] = 0;
         __syncthreads();
-        const uint32_t *k0 = keys_in + plan->start[pass][s];
+        const K *k0 = keys_in + plan->start[pass][s];
         for (uint32_t j = threadIdx.x; j < done; j += WAVES * 64) atomicAdd(&cnt[dg(k0[j])], 1u);
         __syncthreads();
         if (threadIdx.x < kBins) lb.recounted = cnt[threadIdx.x];
@@ -1043,12 +1061,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     lb.seed = threadIdx.x < kBins ? plan->seed[pass][s][threadIdx.x] : 0u;
     uint32_t unused = 0;
     const uint32_t *vin = PAIRS ? values_in + begin : nullptr;
-    if (valid == kOnesweepTile)
-        scatter_chunk<uint32_t, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg,
-                                                                 unused, lb);
+    if (valid == kTile)
+        scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     else
-        scatter_chunk<uint32_t, ITEMS, WAVES, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg,
-                                                                  unused, lb);
+        scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused,
+                                                          lb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1324,33 +1341,45 @@ hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks) 
     return hipGetLastError();
 }
 
-hipError_t launch_digit_tables(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t stream_len, uint32_t *tables,
-                               uint32_t *status, size_t status_words, LaunchEvents ev) {
-    VRS_LAUNCH(digit_tables_kernel, dim3(kStreams * kTableSlices), dim3(kTableThreads), stream, ev, keys, n, stream_len,
-               static_cast<uint32_t>(kTableSlices), tables, reinterpret_cast<uint4 *>(status),
-               static_cast<uint32_t>(status_words / 4));
+uint32_t onesweep_tile_keys(int key_bytes) { return key_bytes == 8 ? 4096u : 8192u; }
+
+hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
+                               uint32_t stream_len, uint32_t *tables, uint32_t *status, size_t status_words, LaunchEvents ev) {
+    const dim3 grid(kStreams * kTableSlices), block(kTableThreads);
+    const uint32_t slices = kTableSlices, vecs = static_cast<uint32_t>(status_words / 4);
+    if (key_bytes == 8)
+        VRS_LAUNCH(digit_tables_kernel<uint64_t>, grid, block, stream, ev, static_cast<const uint64_t *>(keys), n, base_shift,
+                   stream_len, slices, tables, reinterpret_cast<uint4 *>(status), vecs);
+    else
+        VRS_LAUNCH(digit_tables_kernel<uint32_t>, grid, block, stream, ev, static_cast<const uint32_t *>(keys), n, base_shift,
+                   stream_len, slices, tables, reinterpret_cast<uint4 *>(status), vecs);
     return hipGetLastError();
 }
 
-hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t stream_len) {
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(4 * kBins), 0, stream, tables, plan, n, stream_len);
+hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t stream_len,
+                       uint32_t tile) {
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(4 * kBins), 0, stream, tables, plan, n, stream_len, tile);
     return hipGetLastError();
 }
 
-hipError_t launch_onesweep_scatter(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *values_in,
-                                   uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t *status,
-                                   uint32_t max_tiles, bool atomic_rank, unsigned long long xcc_map, LaunchEvents ev,
-                                   bool misplace) {
+hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
+                                   uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
+                                   uint32_t *status, uint32_t max_tiles, bool atomic_rank, unsigned long long xcc_map,
+                                   int key_bytes, LaunchEvents ev, bool misplace) {
     const int mis = misplace ? 1 : 0;
     const dim3 grid(kStreams * max_tiles), block(512);
     const bool pairs = values_in != nullptr;
-#define VRS_ONESWEEP(PAIRS, RANK)                                                                                       \
-    VRS_LAUNCH((onesweep_scatter_kernel<16, 8, PAIRS, RANK, 4>), grid, block, stream, ev, keys_in, keys_out, values_in, \
-               values_out, plan, pass, status, xcc_map, mis)
-    if (pairs) {
-        if (atomic_rank) VRS_ONESWEEP(true, RANK_ATOMIC); else VRS_ONESWEEP(true, RANK_BALLOT);
+#define VRS_ONESWEEP(K, ITEMS, PAIRS, RANK)                                                                           \
+    VRS_LAUNCH((onesweep_scatter_kernel<K, ITEMS, 8, PAIRS, RANK, 4>), grid, block, stream, ev,                       \
+               static_cast<const K *>(keys_in), static_cast<K *>(keys_out), values_in, values_out, plan, pass, shift, \
+               status, xcc_map, mis)
+    if (key_bytes == 8) {
+        if (pairs) return hipErrorInvalidValue;  // no one-call pairs entry point for 64-bit keys
+        if (atomic_rank) VRS_ONESWEEP(uint64_t, 8, false, RANK_ATOMIC); else VRS_ONESWEEP(uint64_t, 8, false, RANK_BALLOT);
+    } else if (pairs) {
+        if (atomic_rank) VRS_ONESWEEP(uint32_t, 16, true, RANK_ATOMIC); else VRS_ONESWEEP(uint32_t, 16, true, RANK_BALLOT);
     } else {
-        if (atomic_rank) VRS_ONESWEEP(false, RANK_ATOMIC); else VRS_ONESWEEP(false, RANK_BALLOT);
+        if (atomic_rank) VRS_ONESWEEP(uint32_t, 16, false, RANK_ATOMIC); else VRS_ONESWEEP(uint32_t, 16, false, RANK_BALLOT);
     }
 #undef VRS_ONESWEEP
     return hipGetLastError();
