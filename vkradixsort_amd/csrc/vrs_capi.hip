@@ -653,12 +653,23 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
     // the contract pass a group may fall back to walks launch tiles of 32 (uint32) / 16 (uint64) blocks
     const uint32_t B = launch_tile_blocks(key_bytes);
     vrs_push_constants pc{n, 0, vrs_workgroup_count(n, B), B};
+    // the digit tables must be all zero when a counting read starts; plan_kernel leaves them so.  Should anything fail
+    // between the two launches, re-arm them for the next sort.
+    struct TablesGuard {
+        vrs_context ctx;
+        bool armed = false;
+        ~TablesGuard() {
+            if (armed) (void)hipMemsetAsync(ctx->os_tables, 0, vrs::kDigitTableWords * sizeof(uint32_t), ctx->stream);
+        }
+    } guard{ctx};
     for (uint32_t group = 0; group < static_cast<uint32_t>(key_bytes) / 4u; ++group) {
         // the group's input is in `keys`: every group is four passes long
         if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
+        guard.armed = true;
         VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, keys->ptr, n, key_bytes, 32u * group, stream_len, ctx->os_tables,
                                               ctx->os_status, rows * VRS_RADIX_SORT_BINS, ev));
         VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, n, stream_len, T));
+        guard.armed = false;
         VRS_HIP(ctx, hipMemcpyAsync(ctx->os_host_max_tiles, ctx->os_plan->max_tiles, 4 * sizeof(uint32_t),
                                     hipMemcpyDeviceToHost, ctx->stream));
         VRS_HIP(ctx, hipEventRecord(ctx->os_plan_ready, ctx->stream));
