@@ -830,9 +830,8 @@ __device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, u
 
 // V counters per lane (one 16-byte vector of keys).  Same-address lanes of one LDS atomic are served one after the
 // other, so input with few distinct counters per wave (constant bytes, sorted or clustered keys) would crawl.  When
-// (nearly) every lane's keys share a counter -- the signature of such input -- the wave adds once per DISTINCT
-// counter (up to 8 of them, found by __ballot peeling) instead of once per key; uniform-random keys fail the vote
-// at once and take the plain path.
+// (nearly) every lane's keys share a counter -- the signature of such input -- the wave adds once per RUN of equal
+// counters across its lanes instead of once per key; uniform-random keys fail the vote at once and take the plain path.
 template <int V>
 __device__ __forceinline__ void table_add(uint32_t *t, const uint32_t (&idx)[V], uint32_t lane) {
     bool same = true;
@@ -840,17 +839,16 @@ __device__ __forceinline__ void table_add(uint32_t *t, const uint32_t (&idx)[V],
     for (int j = 1; j < V; ++j) same = same && idx[j] == idx[0];
     const uint64_t clustered = __ballot(same);
     if (__popcll(clustered) >= 48) {  // wave-uniform
-        uint64_t rest = clustered;
-#pragma unroll 1
-        for (int round = 0; round < 8 && rest != 0ull; ++round) {
-            const uint32_t first = static_cast<uint32_t>(__ffsll(static_cast<long long>(rest))) - 1u;
-            const uint32_t v = __builtin_amdgcn_readlane(idx[0], first);
-            const uint64_t peers = __ballot(idx[0] == v) & rest;
-            if (lane == first) atomicAdd(&t[v], static_cast<uint32_t>(V) * static_cast<uint32_t>(__popcll(peers)));
-            rest &= ~peers;
-        }
-        if ((rest >> lane) & 1ull) atomicAdd(&t[idx[0]], static_cast<uint32_t>(V));
-        if (!same) {  // the few lanes that straddle two counters
+        // run-length aggregation across the lanes: the first lane of every run of equal counters adds the whole run.
+        // (Equal counters in different runs just add twice: always correct, best on sorted / clustered input.)
+        const uint32_t mine = same ? idx[0] : 0xFFFFFFFFu;  // lanes that straddle two counters break the runs
+        const uint32_t prev = __shfl_up(mine, 1);
+        const bool head = same && (lane == 0u || prev != mine);
+        const uint64_t breaks = __ballot(head) | ~clustered;
+        const uint64_t after = lane == 63u ? 0ull : breaks >> (lane + 1u);
+        const uint32_t run = after ? static_cast<uint32_t>(__ffsll(static_cast<long long>(after))) : 64u - lane;
+        if (head) atomicAdd(&t[idx[0]], static_cast<uint32_t>(V) * run);
+        if (!same) {
 #pragma unroll
             for (int j = 0; j < V; ++j) atomicAdd(&t[idx[j]], 1u);
         }
