@@ -163,7 +163,15 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * One-call form of MultiRadixSort::execute's hot loop (MultiRadixSort.cpp:50-61): four passes with
  * g_shift = 0, 8, 16, 24 ping-ponging `keys` <-> `keys_tmp` (the reference's buffer0 / buffer1); the
  * library picks NUM_BLOCKS_PER_WORKGROUP (32) and owns the histogram table.  Result in `keys`.
- * Asynchronous.  The pairs form is stable (== std::stable_sort by key); `values` follow their keys.
+ * The pairs form is stable (== std::stable_sort by key); `values` follow their keys.
+ *
+ * Below VRS_TUNE_ONE_CALL_MIN_KEYS elements (default 2^20) these are the four (eight) contract passes,
+ * fully asynchronous.  From there on -- the library owns all passes, so the per-pass [W][256] table of the
+ * reference's interface is not needed -- the keys are read ONCE to count all four digits of a 32-bit word
+ * and every pass is a stable scatter that finds its offsets by decoupled look-back (36 instead of 48 bytes
+ * per 32-bit key, 136 instead of 192 per 64-bit key; DESIGN.md "K5").  That form waits on the host ONCE per
+ * four passes for a 16-byte plan read-back while the first pass already runs; it never waits for the sort
+ * itself, which still completes asynchronously on the context's stream.  Same result, bit for bit.
  */
 int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements);
 int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
@@ -225,10 +233,9 @@ typedef enum vrs_tuning_key {
     VRS_TUNE_FUSED_PREFIX = 2,    /* 1 (default): single-launch prefix (chunk sums exchanged through tagged granules) */
     VRS_TUNE_RANK_MODE = 3,       /* 0 (default) auto: LDS-atomic ranking if the device self-test passed at
                                      context creation, else __ballot ranking; 1 force ballot; 2 force atomic */
-    VRS_TUNE_ONE_CALL_MIN_KEYS = 4 /* vrs_sort_keys_u32 / vrs_sort_pairs_u32 count all four digits in ONE read and
-                                     scatter with decoupled look-back (36 instead of 48 bytes per key) from this many
-                                     keys on; 0 = never (always the four contract passes).  Default 2^20. */
-    ,
+    VRS_TUNE_ONE_CALL_MIN_KEYS = 4, /* vrs_sort_keys_u32 / _u64 / vrs_sort_pairs_u32 count all four digits in ONE read
+                                     and scatter with decoupled look-back (36 instead of 48 bytes per key) from this many
+                                     keys on; 0 = never (always the contract passes).  Default 2^20. */
     VRS_TUNE_DEBUG_MISPLACE_STREAMS = 5 /* test hook (default 0): run every other tile of a look-back stream behind a
                                      different XCD's L2, i.e. without the placement the fast hand-off relies on */
 } vrs_tuning_key;
