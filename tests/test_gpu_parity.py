@@ -597,9 +597,10 @@ def test_u64_through_the_host_mirrors(gpu_context, oracle):
         assert p.returncode == 0 and "64bit numbers." in p.stdout and "[MultiRadixSort] Test passed." in p.stdout, p.stdout + p.stderr
 
 
-@pytest.mark.parametrize("n", [2 ** 31 + 12345, 2 ** 32 - 1])
+@pytest.mark.parametrize("n", [2 ** 30 - 1, 2 ** 31 + 12345, 2 ** 32 - 1])
 def test_maximum_sizes_index_arithmetic(gpu_context, n):
-    """g_num_elements is a uint32 (push constant): sort up to 2^32 - 1 keys (17 GB per buffer) and check the
+    """g_num_elements is a uint32 (push constant): sort up to 2^32 - 1 keys (17 GB per buffer; 2^30 - 1 is the largest
+    count the one-read form of the one-call sort takes, above it come the contract passes) and check the
     size-independent properties on the device: strictly increasing (the input is a bijection image, so all keys
     are distinct) and the same order-independent fingerprint as the input."""
     torch = pytest.importorskip("torch")
