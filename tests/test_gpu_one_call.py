@@ -124,6 +124,24 @@ def test_one_read_pairs_are_stable(gpu_context, oracle, dist):
         b.release()
 
 
+@pytest.mark.parametrize("kind", ["keys", "pairs", "u64"])
+def test_engine_mirror_one_call_flag(gpu_context, kind):
+    """engine.MultiRadixSort.m_oneCallSort (C++: engine::MultiRadixSort::m_oneCallSort): same execute(), same checks."""
+    n = 1500003
+    keys = make_keys64(n, "uniform") if kind == "u64" else make_keys(n, "uniform", seed=21)
+    vals = np.arange(n, dtype=np.uint32)[::-1].copy() if kind == "pairs" else None
+    app = vrs.MultiRadixSort(keys=keys, values=vals, quiet=True)
+    app.m_oneCallSort = True
+    gpu_context.profileReset()
+    gpu_context.profileEnable(True)
+    try:
+        app.execute(gpu_context)  # raises "TEST FAILED." on any mismatch, like the reference
+        assert launches(gpu_context, capi.VRS_KERNEL_LOOKBACK_SCATTER) == (8 if kind == "u64" else 4)
+    finally:
+        gpu_context.profileEnable(False)
+    assert np.array_equal(app.sorted_keys, np.sort(keys))
+
+
 def test_context_reuse_across_sizes(gpu_context):
     """The digit tables must come back zeroed and the status words re-armed whatever the previous sort was."""
     for n, dist in [(1 << 22, "uniform"), ((1 << 20) + 7, "mult256"), (5000000, "28bit"), (1 << 22, "const"),

@@ -335,6 +335,10 @@ class MultiRadixSort:
         self.m_pass: MultiRadixSortPass | None = None
         self.m_gpuContext: GPUContext | None = None
         self.quiet = quiet
+        # False (default): enqueueSort() drives the two stages pass by pass like the reference's loop.  True: the
+        # library runs the passes itself (vrs_sort_keys_u32 / _u64 / vrs_sort_pairs_u32: one counting read + look-back
+        # scatter passes from 2^20 keys on).  Same buffers, same result in buffer 0.  (C++: m_oneCallSort.)
+        self.m_oneCallSort = False
         self.gpuSortTime = None
         self.cpuSortTime = None
         self.sorted_keys = None
@@ -403,6 +407,17 @@ class MultiRadixSort:
             p.setStorageBuffer(o, R, 4, self.m_valueBuffers[0])
 
     def enqueueSort(self) -> None:  # the hot loop, MultiRadixSort.cpp:50-61 (no blocking call inside)
+        ctx = self.m_gpuContext
+        if self.m_oneCallSort and not (self.m_pass.m_pairs and self.KEY_BYTES == 8):
+            k0, k1 = self.m_buffers[0].handle, self.m_buffers[1].handle
+            if self.m_pass.m_pairs:
+                ctx.check(ctx.lib.vrs_sort_pairs_u32(ctx.handle, k0, k1, self.m_valueBuffers[0].handle,
+                                                     self.m_valueBuffers[1].handle, self.NUM_ELEMENTS))
+            elif self.KEY_BYTES == 8:
+                ctx.check(ctx.lib.vrs_sort_keys_u64(ctx.handle, k0, k1, self.NUM_ELEMENTS))
+            else:
+                ctx.check(ctx.lib.vrs_sort_keys_u32(ctx.handle, k0, k1, self.NUM_ELEMENTS))
+            return
         awaitBeforeExecution = None
         NUM_ITERATIONS = self.KEY_BYTES  # 4 (SORT_32BIT) or 8 (SORT_64_BIT), MultiRadixSort.cpp:50-55
         for i in range(NUM_ITERATIONS):
