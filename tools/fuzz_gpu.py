@@ -1,5 +1,5 @@
 """Randomised end-to-end check on the GPU: random N, B, key width, distribution, pairs, ranking method, against numpy.
-Every third 32-bit case goes through the one-call sort with a random threshold (one counting read + look-back scatter
+Every third case goes through the one-call sort with a random threshold (one counting read + look-back scatter
 passes above it), on a sub-range of a larger allocation at a random 4-byte alignment.
    python tools/fuzz_gpu.py [seconds] [seed]"""
 import ctypes
@@ -66,29 +66,33 @@ def main():
             ctx.setTuning(capi.VRS_TUNE_RANK_MODE, mode)
             ctx.setTuning(capi.VRS_TUNE_FUSED_PREFIX, int(rs.randint(0, 2)))
             ctx.setTuning(capi.VRS_TUNE_XCD_REMAP, int(rs.randint(0, 2)))
-            one_call = (not bits64) and rs.randint(0, 3) == 0
+            one_call = rs.randint(0, 3) == 0 and not (bits64 and pairs)  # no one-call pairs entry point for 64-bit keys
             if one_call:
                 n = int(rs.choice([rs.randint(1, 20000), rs.randint(1, 3000000), rs.randint(1000000, 9000000)]))
             keys, kind = make_keys(rs, n, bits64)
             vals = rs.randint(0, 2 ** 32, n, dtype=np.uint32) if pairs else None
             if one_call:
                 ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, int(rs.choice([0, 1, n, max(1, n // 2), 1 << 20])))
-                off = int(rs.randint(0, 4))
-                big = vrs.Buffer(ctx, S(4 * (n + 8)))
-                host = np.concatenate([np.full(off, 0x11111111, np.uint32), keys, np.full(8 - off, 0x22222222, np.uint32)])
+                kb = keys.itemsize
+                off = int(rs.randint(0, 16 // kb))
+                g0, g1 = keys.dtype.type(0x11111111), keys.dtype.type(0x22222222)
+                big = vrs.Buffer(ctx, S(kb * (n + 8)))
+                host = np.concatenate([np.full(off, g0, keys.dtype), keys, np.full(8 - off, g1, keys.dtype)])
                 ctx.check(lib.vrs_buffer_upload(ctx.handle, big.handle, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
-                k0 = vrs.Buffer(ctx, S(4 * n), device_ptr=big.getDeviceAddress() + 4 * off)
-                k1 = vrs.Buffer(ctx, S(4 * n))
+                k0 = vrs.Buffer(ctx, S(kb * n), device_ptr=big.getDeviceAddress() + kb * off)
+                k1 = vrs.Buffer(ctx, S(kb * n))
                 if pairs:
                     v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
                     v1 = vrs.Buffer(ctx, S(4 * n))
                     ctx.check(lib.vrs_sort_pairs_u32(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+                elif bits64:
+                    ctx.check(lib.vrs_sort_keys_u64(ctx.handle, k0.handle, k1.handle, n))
                 else:
                     ctx.check(lib.vrs_sort_keys_u32(ctx.handle, k0.handle, k1.handle, n))
                 ctx.check(lib.vrs_buffer_download(ctx.handle, big.handle, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
                 order = np.argsort(keys, kind="stable")
-                ok = np.array_equal(host[off:off + n], keys[order]) and (host[:off] == 0x11111111).all() and \
-                    (host[off + n:] == 0x22222222).all()
+                ok = np.array_equal(host[off:off + n], keys[order]) and (host[:off] == g0).all() and \
+                    (host[off + n:] == g1).all()
                 if pairs:
                     ov = np.empty(n, np.uint32)
                     v0.downloadWithStagingBuffer(ov)
@@ -100,7 +104,7 @@ def main():
                 ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, 1 << 20)
                 cases += 1
                 if not ok:
-                    print(f"MISMATCH one-call n={n} pairs={pairs} kind={kind} mode={mode} off={off} seed={seed} case={cases}")
+                    print(f"MISMATCH one-call n={n} bits64={bits64} pairs={pairs} kind={kind} mode={mode} off={off} seed={seed} case={cases}")
                     sys.exit(1)
                 continue
             kb = 8 if bits64 else 4
