@@ -796,15 +796,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
 }
 
 // ---------------------------------------------------------------------------------------------
-// K5: the one-call sort (vrs_sort_keys_u32 / vrs_sort_pairs_u32) for large N: 36 instead of 48 bytes per key.
+// K5: the one-call sort (vrs_sort_keys_u32 / _u64 / vrs_sort_pairs_u32) for large N: 36 instead of 48 bytes per key.
 //
 // The contract path reads the keys once per pass just to count them, because the [W][256] table is part of the
 // reference's interface.  When the library owns all four passes it can count ONCE, before the first pass, and let
 // every scatter pass find its offsets by decoupled look-back.  A single look-back chain over all tiles does not
-// fit this chip (tiles must stay in XCD-contiguous order for the L2s to merge their partial lines, and ~500
-// resident tiles finish 12 ns apart while an agent-scope round trip takes ~1 us), so the tiles of a pass are cut
+// fit this chip (tiles must stay in XCD-contiguous order for the L2s to merge their partial lines, and 500-750
+// resident tiles finish 12 ns apart while a hand-off between workgroups takes 1-3 us under load), so the tiles of a pass are cut
 // into kStreams independent STREAMS whose starting offsets are known before the pass starts:
-//   pass 0   stream s = the s-th slice of the input (whole 8192-key tiles);
+//   pass 0   stream s = the s-th slice of the input (whole tiles of 8192 uint32 / 4096 uint64 keys);
 //   pass p>0 stream s = the keys whose digit p-1 lies in [8s, 8s+8): after pass p-1 they are the contiguous range
 //            [P_{p-1}[8s], P_{p-1}[8s+8]) of its output (P = exclusive digit prefix), whatever their order inside.
 // digit_tables_kernel counts, in one read of the keys, H[p][s][d] = #keys of stream s of pass p with digit p == d
