@@ -171,7 +171,8 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * and every pass is a stable scatter that finds its offsets by decoupled look-back (36 instead of 48 bytes
  * per 32-bit key, 136 instead of 192 per 64-bit key; DESIGN.md "K5").  That form waits on the host ONCE per
  * four passes for a 16-byte plan read-back while the first pass already runs; it never waits for the sort
- * itself, which still completes asynchronously on the context's stream.  Same result, bit for bit.
+ * itself, which still completes asynchronously on the context's stream.  Passes whose digit is the same for every
+ * key (small keys, constant bytes) are the identity and are left out.  Same result, bit for bit.
  */
 int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements);
 int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,

@@ -24,8 +24,10 @@ def make_keys(n, dist, seed=7):
         return k >> np.uint32(4)
     if dist == "mult256":  # digit 0 constant: every key of pass 1 falls into stream 0 -> that pass must fall back
         return k & np.uint32(0xFFFFFF00)
-    if dist == "lowbyte":
+    if dist == "lowbyte":  # passes 1-3 are the identity: one pass runs, the result is copied home
         return k & np.uint32(0xFF)
+    if dist == "16bit":  # passes 2-3 are the identity: two passes run
+        return k & np.uint32(0xFFFF)
     if dist == "sorted":
         return np.sort(k)
     if dist == "reverse":
@@ -48,6 +50,19 @@ def launches(ctx, kid):
     return ctx.profileQuery(kid)[0]
 
 
+def identity_passes(keys):
+    """Passes the one-call sort may leave out: every key has the same digit there (not the first pass of a group of
+    four -- that one is enqueued before the plan is back on the host)."""
+    nbytes = keys.dtype.itemsize
+    skipped = 0
+    for p in range(nbytes):
+        if p % 4 == 0:
+            continue
+        d = (keys >> keys.dtype.type(8 * p)) & keys.dtype.type(255)
+        skipped += int(d.min() == d.max())
+    return skipped
+
+
 def sort_keys(ctx, keys, min_keys=1):
     n = keys.size
     ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, min_keys)
@@ -68,7 +83,7 @@ def sort_keys(ctx, keys, min_keys=1):
     return out, stats
 
 
-DISTS = ["uniform", "28bit", "mult256", "lowbyte", "sorted", "reverse", "const", "two_values", "max_keys",
+DISTS = ["uniform", "28bit", "mult256", "lowbyte", "16bit", "sorted", "reverse", "const", "two_values", "max_keys",
          "skewed_stream", "clustered"]
 
 
@@ -80,11 +95,13 @@ def test_one_read_sort_equals_std_sort(gpu_context, oracle, n, dist):
     assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
     # the one-read form really ran: one counting read, and every pass is either a look-back scatter or a contract pass
     assert stats["digit_tables"] == 1
-    assert stats["lookback_scatter"] + stats["scatter"] == 4 and stats["histogram"] == stats["scatter"]
+    assert stats["lookback_scatter"] + stats["scatter"] == 4 - identity_passes(keys) and stats["histogram"] == stats["scatter"]
     if dist in ("uniform", "28bit", "sorted", "reverse"):
         assert stats["lookback_scatter"] == 4
-    if dist in ("mult256", "const", "skewed_stream"):
+    if dist in ("mult256", "skewed_stream", "two_values"):
         assert stats["scatter"] >= 1  # unbalanced streams -> contract pass
+    if dist in ("const", "lowbyte"):
+        assert stats["lookback_scatter"] == 1 and stats["scatter"] == 0  # passes 1-3 are the identity: left out
 
 
 @pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 8191, (1 << 22) - 1, 5000000, (1 << 23) + 12345])
@@ -106,7 +123,7 @@ def test_threshold_selects_the_form(gpu_context):
         gpu_context.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, -1)
 
 
-@pytest.mark.parametrize("dist", ["uniform", "mult256", "two_values", "sorted"])
+@pytest.mark.parametrize("dist", ["uniform", "mult256", "two_values", "sorted", "lowbyte", "16bit"])
 def test_one_read_pairs_are_stable(gpu_context, oracle, dist):
     ctx, lib, n = gpu_context, gpu_context.lib, 2500003
     keys = make_keys(n, dist) if dist != "uniform" else (make_keys(n, "uniform") & np.uint32(0x00FFFFFF))
@@ -235,11 +252,11 @@ def test_one_read_sort_u64(gpu_context, n, dist):
     ctx.check(lib.vrs_buffer_download(ctx.handle, big.handle, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
     assert host[0] == 0x1111111111111111 and host[-1] == 0x2222222222222222
     assert np.array_equal(host[1:-1], np.sort(keys))
-    assert stats["digit_tables"] == 2 and stats["lookback_scatter"] + stats["scatter"] == 8
+    assert stats["digit_tables"] == 2 and stats["lookback_scatter"] + stats["scatter"] == 8 - identity_passes(keys)
     if dist in ("uniform", "sorted"):
         assert stats["lookback_scatter"] == 8
     if dist in ("low32", "high32"):
-        assert stats["scatter"] >= 3
+        assert stats["lookback_scatter"] + stats["scatter"] == 5  # three identity passes in the constant word
     for b in (view, big, tmp):
         b.release()
 

@@ -57,7 +57,8 @@ struct vrs_context_t {
     bool os_misplace = false;            // test hook, VRS_TUNE_DEBUG_MISPLACE_STREAMS
     bool xcc_map_valid = false;          // the probe found block b on an XCC that depends on b % 8 only
     unsigned long long xcc_map = 0;      // byte x = that XCC for b % 8 == x
-    uint64_t os_fallback_passes = 0;     // passes the one-call sort ran through the contract path (unbalanced streams)
+    uint64_t os_fallback_passes = 0;
+    uint64_t os_skipped_passes = 0;      // identity passes (one digit value holds every key) the one-call sort left out     // passes the one-call sort ran through the contract path (unbalanced streams)
 };
 
 struct vrs_buffer_t {
@@ -606,15 +607,12 @@ static int ensure_sort_hist(vrs_context ctx, uint32_t workgroups) {
 }
 
 // one contract pass (stage 0 + stage 1) of the one-call forms
-static int contract_pass(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values, vrs_buffer values_tmp,
-                         vrs_push_constants *pc, uint32_t i, int key_bytes) {
-    pc->g_shift = 8 * i;
-    vrs_buffer kin = (i & 1u) ? keys_tmp : keys, kout = (i & 1u) ? keys : keys_tmp;
+static int contract_pass(vrs_context ctx, vrs_buffer kin, vrs_buffer kout, vrs_buffer vin, vrs_buffer vout,
+                         vrs_push_constants *pc, uint32_t shift, int key_bytes) {
+    pc->g_shift = shift;
     int rc = run_histogram_stage(ctx, kin, ctx->sort_hist, pc, key_bytes);
     if (rc) return rc;
-    return run_sort_stage(ctx, kin, kout, values ? ((i & 1u) ? values_tmp : values) : nullptr,
-                          values ? ((i & 1u) ? values : values_tmp) : nullptr, ctx->sort_hist, pc, values != nullptr,
-                          key_bytes);
+    return run_sort_stage(ctx, kin, kout, vin, vout, ctx->sort_hist, pc, vin != nullptr, key_bytes);
 }
 
 // Large-N form of the one-call sort (K5): ONE counting read of the keys per group of four passes, then four scatter
@@ -633,7 +631,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_tables), vrs::kDigitTableWords * sizeof(uint32_t)));
         VRS_HIP(ctx, hipMemsetAsync(ctx->os_tables, 0, vrs::kDigitTableWords * sizeof(uint32_t), ctx->stream));
         VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_plan), sizeof(vrs::OnesweepPlan)));
-        VRS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->os_host_max_tiles), 4 * sizeof(uint32_t)));
+        VRS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->os_host_max_tiles), 8 * sizeof(uint32_t)));
         VRS_HIP(ctx, hipEventCreateWithFlags(&ctx->os_plan_ready, hipEventDisableTiming));
     }
     const size_t pass_rows = static_cast<size_t>(S) * tile_cap;  // status rows of one pass
@@ -662,40 +660,57 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
             if (armed) (void)hipMemsetAsync(ctx->os_tables, 0, vrs::kDigitTableWords * sizeof(uint32_t), ctx->stream);
         }
     } guard{ctx};
+    // where the data lives: buffers[0] = caller's keys / values, buffers[1] = the ping-pong partners.  A pass whose digit
+    // is the same for every key is the identity and is skipped (not the first pass of a group: it is enqueued before
+    // the plan is back), so the result may end in the partner and is copied home at the end.
+    vrs_buffer kbuf[2] = {keys, keys_tmp}, vbuf[2] = {values, values_tmp};
+    uint32_t cur = 0;
     for (uint32_t group = 0; group < static_cast<uint32_t>(key_bytes) / 4u; ++group) {
-        // the group's input is in `keys`: every group is four passes long
         if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
         guard.armed = true;
-        VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, keys->ptr, n, key_bytes, 32u * group, stream_len, ctx->os_tables,
-                                              ctx->os_status, rows * VRS_RADIX_SORT_BINS, ev));
+        VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, stream_len,
+                                              ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS, ev));
         VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, n, stream_len, T));
         guard.armed = false;
-        VRS_HIP(ctx, hipMemcpyAsync(ctx->os_host_max_tiles, ctx->os_plan->max_tiles, 4 * sizeof(uint32_t),
-                                    hipMemcpyDeviceToHost, ctx->stream));
+        VRS_HIP(ctx, hipMemcpyAsync(ctx->os_host_max_tiles, ctx->os_plan->max_tiles, 8 * sizeof(uint32_t),
+                                    hipMemcpyDeviceToHost, ctx->stream));  // max_tiles[4] + constant[4]
         VRS_HIP(ctx, hipEventRecord(ctx->os_plan_ready, ctx->stream));
         for (uint32_t i = 0; i < 4; ++i) {
-            const uint32_t pass = 4u * group + i;  // == shift / 8
+            const uint32_t shift = 32u * group + 8u * i;
             // pass 0's streams are slices of the input (known here); the others come back from the plan while it runs
             uint32_t max_tiles = tiles0;
             if (i == 1) VRS_HIP(ctx, hipEventSynchronize(ctx->os_plan_ready));
-            if (i > 0) max_tiles = ctx->os_host_max_tiles[i];
+            if (i > 0) {
+                max_tiles = ctx->os_host_max_tiles[i];
+                if (ctx->os_host_max_tiles[4 + i]) {
+                    ctx->os_skipped_passes++;
+                    continue;
+                }
+            }
+            vrs_buffer kin = kbuf[cur], kout = kbuf[cur ^ 1u];
+            vrs_buffer vin = values ? vbuf[cur] : nullptr, vout = values ? vbuf[cur ^ 1u] : nullptr;
+            cur ^= 1u;
             if (max_tiles > tile_cap) {
                 ctx->os_fallback_passes++;
                 if ((rc = ensure_sort_hist(ctx, pc.g_num_workgroups))) return rc;
-                if ((rc = contract_pass(ctx, keys, keys_tmp, values, values_tmp, &pc, pass, key_bytes))) return rc;
+                if ((rc = contract_pass(ctx, kin, kout, vin, vout, &pc, shift, key_bytes))) return rc;
                 continue;
             }
-            vrs_buffer kin = (pass & 1u) ? keys_tmp : keys, kout = (pass & 1u) ? keys : keys_tmp;
-            vrs_buffer vin = values ? ((pass & 1u) ? values_tmp : values) : nullptr;
-            vrs_buffer vout = values ? ((pass & 1u) ? values : values_tmp) : nullptr;
             if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
             VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kin->ptr, kout->ptr,
                                                       vin ? static_cast<const uint32_t *>(vin->ptr) : nullptr,
                                                       vout ? static_cast<uint32_t *>(vout->ptr) : nullptr, ctx->os_plan, i,
-                                                      8u * pass, ctx->os_status + i * pass_rows * VRS_RADIX_SORT_BINS,
-                                                      max_tiles, ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes, ev,
+                                                      shift, ctx->os_status + i * pass_rows * VRS_RADIX_SORT_BINS, max_tiles,
+                                                      ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes, ev,
                                                       ctx->os_misplace));
         }
+    }
+    if (cur) {  // an odd number of passes ran
+        VRS_HIP(ctx, hipMemcpyAsync(keys->ptr, keys_tmp->ptr, static_cast<size_t>(n) * key_bytes, hipMemcpyDeviceToDevice,
+                                    ctx->stream));
+        if (values)
+            VRS_HIP(ctx, hipMemcpyAsync(values->ptr, values_tmp->ptr, static_cast<size_t>(n) * sizeof(uint32_t),
+                                        hipMemcpyDeviceToDevice, ctx->stream));
     }
     return VRS_OK;
 }
@@ -728,7 +743,10 @@ static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp
         return sort_one_read(ctx, keys, keys_tmp, values, values_tmp, n, key_bytes);
     if ((rc = ensure_sort_hist(ctx, pc.g_num_workgroups))) return rc;
     for (uint32_t i = 0; i < static_cast<uint32_t>(key_bytes); ++i) {  // one pass per key byte: 4 or 8 (even either way)
-        if ((rc = contract_pass(ctx, keys, keys_tmp, values, values_tmp, &pc, i, key_bytes))) return rc;
+        const bool odd = (i & 1u) != 0;
+        if ((rc = contract_pass(ctx, odd ? keys_tmp : keys, odd ? keys : keys_tmp, values ? (odd ? values_tmp : values) : nullptr,
+                                values ? (odd ? values : values_tmp) : nullptr, &pc, 8 * i, key_bytes)))
+            return rc;
     }
     return VRS_OK;
 }

@@ -71,6 +71,7 @@ struct OnesweepPlan {
     uint32_t start[4][kStreams];      // first key of the stream in the pass's input
     uint32_t len[4][kStreams];
     uint32_t max_tiles[4];            // tiles of the longest stream of each pass
+    uint32_t constant[4];             // 1: every key has the same digit in this pass (the pass is the identity)
 };
 constexpr size_t kDigitTableWords = 4u * kStreams * 256u;
 // keys per look-back tile: 8192 uint32 or 4096 uint64 (32 KiB either way)

@@ -966,7 +966,7 @@ __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ 
                                                         uint32_t n, uint32_t stream_len, uint32_t tile) {
     __shared__ uint32_t s_prefix[4][kBins + 1];
     __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_max[4];
+    __shared__ uint32_t s_max[4], s_const[4];
     const uint32_t tid = threadIdx.x, p = tid >> 8, d = tid & 255u, lane = tid & 63u, wave = tid >> 6;
     uint32_t before[kStreams];
     uint32_t total = 0;
@@ -986,8 +986,12 @@ __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ 
         if (lane >= static_cast<uint32_t>(o)) incl += x;
     }
     if (lane == 63u) s_wave[wave] = incl;
-    if (tid < 4) s_max[tid] = 0;
+    if (tid < 4) {
+        s_max[tid] = 0;
+        s_const[tid] = 0;
+    }
     __syncthreads();
+    if (total == n) s_const[p] = 1;  // one digit value holds every key
     uint32_t base = 0;
     for (uint32_t j = p * 4u; j < wave; ++j) base += s_wave[j];
     const uint32_t digit_start = base + incl - total;
@@ -1012,7 +1016,10 @@ __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ 
         atomicMax(&s_max[q], (end - start + tile - 1u) / tile);
     }
     __syncthreads();
-    if (tid < 4) plan->max_tiles[tid] = s_max[tid];
+    if (tid < 4) {
+        plan->max_tiles[tid] = s_max[tid];
+        plan->constant[tid] = s_const[tid];
+    }
 }
 
 // grid = kStreams * T workgroups (T = tiles of the longest stream); block b -> XCD b % 8 -> stream b%8 + 8*((b/8) % (kStreams/8)),
