@@ -272,14 +272,16 @@ def test_config2_1e8_keys_roofline_size(gpu_context, oracle):
     assert oracle.test_sort(ref, out) == -1
 
 
-def test_config3_1e8_pairs(gpu_context):
+@pytest.mark.parametrize("one_call", [False, True], ids=["stages", "one_call"])
+def test_config3_1e8_pairs(gpu_context, one_call):
     # BASELINE.json configs[3]: 10^8 key+payload pairs; payload[i] = i; verified by properties:
     # keys sorted, keys[payload] reproduces the output keys (payload is a permutation that follows its key),
-    # and equal keys keep increasing payloads (stability)
+    # and equal keys keep increasing payloads (stability).  Both ways to run the four passes.
     n = 10 ** 8
     keys = rand_keys(n, 2)
     vals = np.arange(n, dtype=np.uint32)
     m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=32, keys=keys, values=vals, quiet=True)
+    m.m_oneCallSort = one_call
     m.setup(gpu_context)
     m.enqueueSort()
     gpu_context.waitIdle()
