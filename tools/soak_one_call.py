@@ -1,0 +1,67 @@
+"""Soak of the one-call sort's look-back path: many large sorts, verified ON the device (ascending + the same
+order-independent fingerprint as the input), so timing-dependent faults of the inter-workgroup hand-off would show.
+   python tools/soak_one_call.py [seconds] [seed]"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import vkradixsort_amd as vrs  # noqa: E402
+from vkradixsort_amd import capi  # noqa: E402
+
+
+def fingerprint(t):
+    u = t.to(torch.int64) & 0xFFFFFFFF
+    return int(u.sum().item()), int(((u & 0xFFFF) * (u >> 16)).sum().item()), int((u * 2654435761 & 0xFFFFFFFF).sum().item())
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    torch.manual_seed(seed)
+    rs = np.random.RandomState(seed)
+    dev = torch.device("cuda", 0)
+    S = vrs.Buffer.BufferSettings
+    flip = torch.tensor(-2 ** 31, dtype=torch.int32, device=dev)
+    cases = keys_sorted = 0
+    t_end = time.time() + budget
+    with vrs.GPUContext(0, stream=torch.cuda.current_stream().cuda_stream) as gpu:
+        while time.time() < t_end:
+            n = int(rs.choice([rs.randint(1 << 20, 1 << 23), rs.randint(1 << 23, 6 * 10 ** 7), 10 ** 8]))
+            kind = rs.randint(0, 6)
+            k = torch.randint(-2 ** 31, 2 ** 31, (n,), dtype=torch.int64, device=dev).to(torch.int32)
+            if kind == 1:
+                k = k >> int(rs.randint(1, 20))  # arithmetic shift: sign-extended clusters at both ends
+            elif kind == 2:
+                k = torch.sort(k)[0]
+            elif kind == 3:
+                k = k & int(rs.choice([0x00FFFFFF, 0x0FFFFFFF, 0x7FFFFF00, 0x7FF0FFFF]))
+            elif kind == 4:
+                k = (k & 0x7FFF07FF) | 0x2000  # one heavy stream in pass 2
+            tmp = torch.empty_like(k)
+            before = fingerprint(k)
+            torch.cuda.synchronize()
+            k0 = vrs.Buffer(gpu, S(4 * n), device_ptr=k.data_ptr())
+            k1 = vrs.Buffer(gpu, S(4 * n), device_ptr=tmp.data_ptr())
+            reps = int(rs.randint(1, 4))
+            for r in range(reps):  # re-sorting sorted output is a legal (and differently timed) input
+                gpu.check(gpu.lib.vrs_sort_keys_u32(gpu.handle, k0.handle, k1.handle, n))
+            gpu.waitIdle()
+            u = k ^ flip
+            ok = bool((u[1:] >= u[:-1]).all().item()) and fingerprint(k) == before
+            k0.release()
+            k1.release()
+            cases += 1
+            keys_sorted += n * reps
+            if not ok:
+                print(f"SOAK MISMATCH n={n} kind={kind} seed={seed} case={cases}")
+                sys.exit(1)
+            del k, tmp, u
+    print(f"soak ok: {cases} sorts, {keys_sorted / 1e9:.1f} G keys in {budget:.0f} s (seed {seed})")
+
+
+if __name__ == "__main__":
+    main()
