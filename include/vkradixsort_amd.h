@@ -178,6 +178,9 @@ int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uin
 int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
                        vrs_buffer values_tmp, uint32_t num_elements);
 int vrs_sort_keys_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements); /* 8 passes */
+/* uint64 keys with uint32 payloads: always the eight contract passes (no look-back form). */
+int vrs_sort_pairs_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
+                       vrs_buffer values_tmp, uint32_t num_elements);
 
 /*
  * Key preprocessing the reference leaves to the integrator ("you have to preprocess negative numbers",

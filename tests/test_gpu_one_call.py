@@ -141,6 +141,24 @@ def test_one_read_pairs_are_stable(gpu_context, oracle, dist):
         b.release()
 
 
+def test_one_call_pairs_u64(gpu_context):
+    """uint64 keys + uint32 payloads in one call: the eight contract passes, stable."""
+    ctx, lib, n = gpu_context, gpu_context.lib, 1300001
+    keys = make_keys64(n, "uniform") >> np.uint64(40)  # 24-bit values: plenty of ties
+    vals = np.arange(n, dtype=np.uint32)
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(8 * n), keys)
+    v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
+    k1, v1 = vrs.Buffer(ctx, S(8 * n)), vrs.Buffer(ctx, S(4 * n))
+    ctx.check(lib.vrs_sort_pairs_u64(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+    ok, ov = np.empty(n, np.uint64), np.empty(n, np.uint32)
+    k0.downloadWithStagingBuffer(ok)
+    v0.downloadWithStagingBuffer(ov)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ok, keys[order]) and np.array_equal(ov, vals[order])
+    for b in (k0, k1, v0, v1):
+        b.release()
+
+
 @pytest.mark.parametrize("kind", ["keys", "pairs", "u64"])
 def test_engine_mirror_one_call_flag(gpu_context, kind):
     """engine.MultiRadixSort.m_oneCallSort (C++: engine::MultiRadixSort::m_oneCallSort): same execute(), same checks."""

@@ -88,6 +88,7 @@ _SIGNATURES = [
     ("vrs_single_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_sort_keys_u32", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_sort_pairs_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
+    ("vrs_sort_pairs_u64", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_sort_keys_u64", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_transform_keys", c_int, [c_void_p, c_void_p, c_uint32, c_int]),
     ("vrs_profile_enable", c_int, [c_void_p, c_int]),

@@ -765,6 +765,12 @@ int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vr
     return sort_all_passes(ctx, keys, keys_tmp, values, values_tmp, num_elements);
 }
 
+int vrs_sort_pairs_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
+                       vrs_buffer values_tmp, uint32_t num_elements) {
+    if (!values || !values_tmp) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "values buffers are NULL");
+    return sort_all_passes(ctx, keys, keys_tmp, values, values_tmp, num_elements, 8);
+}
+
 int vrs_transform_keys(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, int mode) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     if (mode < VRS_KEYS_INT32 || mode > VRS_KEYS_SORTABLE_TO_FLOAT32)

@@ -408,11 +408,12 @@ class MultiRadixSort:
 
     def enqueueSort(self) -> None:  # the hot loop, MultiRadixSort.cpp:50-61 (no blocking call inside)
         ctx = self.m_gpuContext
-        if self.m_oneCallSort and not (self.m_pass.m_pairs and self.KEY_BYTES == 8):
+        if self.m_oneCallSort:
             k0, k1 = self.m_buffers[0].handle, self.m_buffers[1].handle
             if self.m_pass.m_pairs:
-                ctx.check(ctx.lib.vrs_sort_pairs_u32(ctx.handle, k0, k1, self.m_valueBuffers[0].handle,
-                                                     self.m_valueBuffers[1].handle, self.NUM_ELEMENTS))
+                fn = ctx.lib.vrs_sort_pairs_u64 if self.KEY_BYTES == 8 else ctx.lib.vrs_sort_pairs_u32
+                ctx.check(fn(ctx.handle, k0, k1, self.m_valueBuffers[0].handle, self.m_valueBuffers[1].handle,
+                             self.NUM_ELEMENTS))
             elif self.KEY_BYTES == 8:
                 ctx.check(ctx.lib.vrs_sort_keys_u64(ctx.handle, k0, k1, self.NUM_ELEMENTS))
             else:
