@@ -127,6 +127,9 @@ int vrs_multi_radixsort_pairs(vrs_context ctx, vrs_buffer keys_in, vrs_buffer ke
  * extension) to cut the locally grouped shard into per-rank slices.
  */
 int vrs_multi_radixsort_digit_offsets(vrs_context ctx, void *host_u32x256);
+/* The same 256 words copied into a device buffer, asynchronously (no host round trip: the multi-GPU step feeds
+ * them straight into its count all-gather). */
+int vrs_multi_radixsort_digit_offsets_device(vrs_context ctx, vrs_buffer out_u32x256);
 /*
  * 64-bit keys: the reference's SORT_64_BIT switch (MultiRadixSort.h:10-18; NUM_ITERATIONS = 8,
  * MultiRadixSort.cpp:51-55), which it leaves as a stub ("requires changes in the two shaders").  Same two

@@ -84,6 +84,7 @@ _SIGNATURES = [
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(PushConstants)]),
     ("vrs_range_partition", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_uint32]),
     ("vrs_multi_radixsort_digit_offsets", c_int, [c_void_p, c_void_p]),
+    ("vrs_multi_radixsort_digit_offsets_device", c_int, [c_void_p, c_void_p]),
     ("vrs_queue_wait_idle", c_int, [c_void_p]),
     ("vrs_single_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_sort_keys_u32", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),

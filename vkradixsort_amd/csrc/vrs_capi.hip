@@ -888,6 +888,18 @@ int vrs_multi_radixsort_digit_offsets(vrs_context ctx, void *host_u32x256) {
     return VRS_OK;
 }
 
+int vrs_multi_radixsort_digit_offsets_device(vrs_context ctx, vrs_buffer out_u32x256) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (ctx->last_offsets_workgroups == 0)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "no RADIX_SORT stage has run on this context yet");
+    int rc = check_buffer(ctx, out_u32x256, VRS_RADIX_SORT_BINS * sizeof(uint32_t), "digit offsets");
+    if (rc) return rc;
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    VRS_HIP(ctx, hipMemcpyAsync(out_u32x256->ptr, ctx->scratch.offsets, VRS_RADIX_SORT_BINS * sizeof(uint32_t),
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    return VRS_OK;
+}
+
 int vrs_debug_download_offsets(vrs_context ctx, void *host_data, size_t size_bytes) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     const size_t row = VRS_RADIX_SORT_BINS * sizeof(uint32_t);

@@ -63,7 +63,8 @@ class LocalSortBackend:
     """Device work of steps 1 and 4 on one rank."""
 
     def group_by_top_byte(self, keys, n: int):
-        """-> (grouped keys tensor (len >= n), digit_base uint32[256])"""
+        """-> (grouped keys tensor (len >= n), digit_base[256]: first position of every top byte in it -- a host
+        uint32 array, or a device int32 tensor when the backend can hand it over without a host round trip)"""
         raise NotImplementedError
 
     def partition_by_splitters(self, keys, n: int, splitters: np.ndarray):
@@ -104,6 +105,7 @@ class HipLocalSortBackend(LocalSortBackend):
         self.scratch = torch.empty(self.capacity, dtype=torch.int32, device=self.device)  # ping-pong partner of the local sorts
         w_max = self.ctx.lib.vrs_workgroup_count(self.capacity, self.B)
         self.hist = torch.empty(max(w_max, 1) * RADIX_SORT_BINS, dtype=torch.int32, device=self.device)
+        self.digit_base = torch.empty(RADIX_SORT_BINS, dtype=torch.int32, device=self.device)
         self._wrapped = {}
 
     def close(self):
@@ -135,10 +137,9 @@ class HipLocalSortBackend(LocalSortBackend):
         if n > self.capacity:
             raise ValueError("shard larger than the backend capacity")
         self._pass(keys, self.grouped, n, 24)
-        digit_base = np.empty(RADIX_SORT_BINS, dtype=np.uint32)
-        self.ctx.check(self.ctx.lib.vrs_multi_radixsort_digit_offsets(self.ctx.handle,
-                                                                     digit_base.ctypes.data_as(ctypes.c_void_p)))
-        return self.grouped, digit_base
+        # stays on the device: the step feeds it into its count all-gather and synchronises once, after that
+        self.ctx.check(self.ctx.lib.vrs_multi_radixsort_digit_offsets_device(self.ctx.handle, self._buf(self.digit_base).handle))
+        return self.grouped, self.digit_base
 
     def partition_by_splitters(self, keys, n, splitters):
         if n > self.capacity:
@@ -224,14 +225,17 @@ class RangeShardedSort:
             return self._step_small(keys, n, all_sz.cpu().numpy())
         # 1. local step
         grouped, digit_base = self.backend.group_by_top_byte(keys, n)
-        base = np.concatenate([digit_base.astype(np.int64), [n]])
-        local_counts = np.diff(base)
         # 2. ONE small collective: everybody learns everybody's 256 top-byte counts (world x 2 KiB), from which
         #    each rank derives the same splitters, its send counts and its receive counts without further traffic
-        mine = torch.from_numpy(local_counts.copy()).to(self.device)
+        if torch.is_tensor(digit_base):  # device-resident prefix: counts by differencing on the device, one host sync below
+            b64 = digit_base.to(torch.int64) & 0xFFFFFFFF
+            mine = torch.cat([b64[1:], torch.tensor([n], dtype=torch.int64, device=self.device)]) - b64
+        else:
+            mine = torch.from_numpy(np.diff(np.concatenate([digit_base.astype(np.int64), [n]]))).to(self.device)
         table = torch.empty(world * RADIX_SORT_BINS, dtype=mine.dtype, device=self.device)
-        dist.all_gather_into_tensor(table, mine, group=self.group)
+        dist.all_gather_into_tensor(table, mine.contiguous(), group=self.group)
         all_counts = table.cpu().numpy().reshape(world, RADIX_SORT_BINS)
+        base = np.concatenate([[0], np.cumsum(all_counts[me])]).astype(np.int64)  # my own prefix, back from the table
         # world*R parts of (almost) equal size; part q*R + r = rank q, round r
         parts = plan_splitters(all_counts.sum(axis=0), world * R)
         bounds = parts[::R]
