@@ -229,7 +229,9 @@ class RangeShardedSort:
         #    each rank derives the same splitters, its send counts and its receive counts without further traffic
         if torch.is_tensor(digit_base):  # device-resident prefix: counts by differencing on the device, one host sync below
             b64 = digit_base.to(torch.int64) & 0xFFFFFFFF
-            mine = torch.cat([b64[1:], torch.tensor([n], dtype=torch.int64, device=self.device)]) - b64
+            mine = torch.empty(RADIX_SORT_BINS, dtype=torch.int64, device=self.device)
+            mine[:-1] = b64[1:] - b64[:-1]
+            mine[-1] = n - b64[-1]  # scalar operand: no host-to-device copy
         else:
             mine = torch.from_numpy(np.diff(np.concatenate([digit_base.astype(np.int64), [n]]))).to(self.device)
         table = torch.empty(world * RADIX_SORT_BINS, dtype=mine.dtype, device=self.device)
