@@ -1,5 +1,5 @@
 """GPU parity tests of the one-call sort's large-N form (K5 in vrs_kernels.hip): ONE counting read of the keys
-(digit_tables_kernel), then four scatter passes that find their offsets by decoupled look-back along 32 streams.
+(digit_tables_kernel), then four scatter passes that find their offsets by decoupled look-back along 8 streams (one per XCD).
 The reference has no such entry point (its loop is MultiRadixSort.cpp:50-61); the acceptance criterion is the
 reference's own: the output must equal std::sort (MultiRadixSort.cpp:141-161), bit for bit, and pairs must
 equal std::stable_sort by key."""
@@ -22,7 +22,7 @@ def make_keys(n, dist, seed=7):
         return k
     if dist == "28bit":  # the reference's own generator, MultiRadixSort.cpp:121-133
         return k >> np.uint32(4)
-    if dist == "mult256":  # digit 0 constant: every key of pass 1 falls into stream 0 -> that pass must fall back
+    if dist == "mult256":  # digit 0 constant: every key of pass 1 falls into one group -> that pass must fall back
         return k & np.uint32(0xFFFFFF00)
     if dist == "lowbyte":  # passes 1-3 are the identity: one pass runs, the result is copied home
         return k & np.uint32(0xFF)
@@ -38,7 +38,7 @@ def make_keys(n, dist, seed=7):
         return np.where(k & 1, np.uint32(0xFFFFFFFF), np.uint32(0)).astype(np.uint32)
     if dist == "max_keys":  # the padding value of a ragged tile is a legal key
         return np.where(k % 3 == 0, np.uint32(0xFFFFFFFF), k).astype(np.uint32)
-    if dist == "skewed_stream":  # 40 % of the keys share digit-1 stream 5: more than the 25 % slack of pass 2's grid
+    if dist == "skewed_stream":  # 40 % of the keys share one digit-1 group: no cut between groups balances pass 2
         heavy = (k % 5) < 2
         return np.where(heavy, (k & np.uint32(0xFFFF07FF)) | np.uint32(0x2800), k).astype(np.uint32)
     if dist == "clustered":  # few distinct top bytes, long runs
@@ -237,7 +237,7 @@ def make_keys64(n, dist, seed=11):
         return k
     if dist == "44bit":  # the reference's SORT_64_BIT generator, MultiRadixSort.cpp:128
         return k >> np.uint64(20)
-    if dist == "low32":  # upper word zero: passes 5-7 have every key in stream 0 -> contract passes
+    if dist == "low32":  # upper word zero: passes 5-7 are the identity
         return k & np.uint64(0xFFFFFFFF)
     if dist == "high32":
         return k & np.uint64(0xFFFFFFFF00000000)

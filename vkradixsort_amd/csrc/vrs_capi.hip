@@ -621,12 +621,21 @@ static int contract_pass(vrs_context ctx, vrs_buffer kin, vrs_buffer kout, vrs_b
 // follow the data) runs as a contract pass instead.
 static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values, vrs_buffer values_tmp,
                          uint32_t n, int key_bytes) {
-    constexpr uint32_t S = vrs::kStreams;
+    constexpr uint32_t S = vrs::kStreams, G = vrs::kGroups;
     const uint32_t T = vrs::onesweep_tile_keys(key_bytes);
     const uint32_t tiles_total = (n + T - 1) / T;
-    const uint32_t tiles0 = (tiles_total + S - 1) / S;  // tiles per pass-0 stream
-    const uint32_t stream_len = tiles0 * T;              // < 2^30 + 8192
-    const uint32_t tile_cap = tiles0 + tiles0 / 4 + 2;   // streams of later passes may be up to 25 % longer
+    const uint32_t group_tiles = (tiles_total + G - 1) / G;  // tiles per pass-0 group (slice of the input)
+    const uint32_t group_len = group_tiles * T;              // < 2^30 / 32 + 8192
+    // pass 0's streams are made here (the pass is enqueued before the plan is back): neighbouring slices merged
+    const vrs::StreamCuts cuts0 = vrs::pass0_stream_cuts(n, group_len);
+    uint32_t tiles0 = 0;  // tiles of the longest pass-0 stream
+    for (uint32_t k = 0; k < S; ++k) {
+        const uint64_t a = std::min<uint64_t>(static_cast<uint64_t>(cuts0.first_group[k]) * group_len, n);
+        const uint64_t b = std::min<uint64_t>(static_cast<uint64_t>(cuts0.first_group[k + 1]) * group_len, n);
+        tiles0 = std::max<uint32_t>(tiles0, static_cast<uint32_t>((b - a + T - 1) / T));
+    }
+    const uint32_t even = (tiles_total + S - 1) / S;        // tiles of a perfectly even stream
+    const uint32_t tile_cap = std::max(tiles0, even + even / 4 + 2);  // later passes: streams up to 25 % longer
     if (!ctx->os_tables) {
         VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_tables), vrs::kDigitTableWords * sizeof(uint32_t)));
         VRS_HIP(ctx, hipMemsetAsync(ctx->os_tables, 0, vrs::kDigitTableWords * sizeof(uint32_t), ctx->stream));
@@ -668,9 +677,9 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
     for (uint32_t group = 0; group < static_cast<uint32_t>(key_bytes) / 4u; ++group) {
         if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
         guard.armed = true;
-        VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, stream_len,
+        VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, group_len,
                                               ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS, ev));
-        VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, n, stream_len, T));
+        VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, n, group_len, T, cuts0));
         guard.armed = false;
         VRS_HIP(ctx, hipMemcpyAsync(ctx->os_host_max_tiles, ctx->os_plan->max_tiles, 8 * sizeof(uint32_t),
                                     hipMemcpyDeviceToHost, ctx->stream));  // max_tiles[4] + constant[4]

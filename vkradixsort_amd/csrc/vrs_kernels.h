@@ -61,11 +61,15 @@ hipError_t launch_atomic_rank_selftest(hipStream_t stream, uint32_t rounds, uint
 hipError_t launch_transform_keys(hipStream_t stream, uint32_t *keys, uint32_t n, int mode);
 
 // ---- one-call sort for large N (K5): one counting read, four look-back scatter passes
+// The counting read sorts every key into one of kGroups GROUPS per pass (pass 0: slice of the input, pass p > 0:
+// digit p-1 / 8); plan_kernel merges neighbouring groups into kStreams balanced STREAMS, one per XCD (fewer streams =
+// fewer open write fronts per pass: 2048 instead of 8192, which is what the next pass's write drain pays for)
 #ifndef VRS_STREAMS
-#define VRS_STREAMS 32
+#define VRS_STREAMS 8
 #endif
-constexpr int kStreams = VRS_STREAMS;    // independent look-back streams per pass (a multiple of 8: stream s runs on XCD s % 8)
-constexpr int kTableSlices = 8;          // digit_tables workgroups per pass-0 stream
+constexpr int kGroups = 32;
+constexpr int kStreams = VRS_STREAMS;    // a multiple of 8 that divides kGroups: stream s runs on XCD s % 8
+constexpr int kTableSlices = 8;          // digit_tables workgroups per pass-0 group
 struct OnesweepPlan {
     uint32_t seed[4][kStreams][256];  // global offset of digit d at the start of stream s of pass p
     uint32_t start[4][kStreams];      // first key of the stream in the pass's input
@@ -73,16 +77,37 @@ struct OnesweepPlan {
     uint32_t max_tiles[4];            // tiles of the longest stream of each pass
     uint32_t constant[4];             // 1: every key has the same digit in this pass (the pass is the identity)
 };
-constexpr size_t kDigitTableWords = 4u * kStreams * 256u;
+constexpr size_t kDigitTableWords = 4u * kGroups * 256u;
+// first group of every stream (first_group[kStreams] == kGroups)
+struct StreamCuts {
+    uint32_t first_group[kStreams + 1];
+};
+// Cuts the kGroups groups (group g = keys [starts[g], starts[g + 1]) of the pass's input, starts[kGroups] == n) into
+// kStreams contiguous streams of nearly equal length: stream k ends at the group boundary closest to (k + 1) * n / kStreams.
+// One definition for the host (pass 0) and the plan kernel (passes 1-3).
+__host__ __device__ inline void balanced_cuts(const uint32_t (&starts)[kGroups + 1], uint32_t n, uint32_t (&first_group)[kStreams + 1]) {
+    first_group[0] = 0;
+    uint32_t g = 0;
+    for (uint32_t k = 1; k < static_cast<uint32_t>(kStreams); ++k) {
+        const uint64_t target = static_cast<uint64_t>(n) * k / kStreams;
+        while (g < static_cast<uint32_t>(kGroups) && starts[g] < target) ++g;
+        if (g > first_group[k - 1] && target - starts[g - 1] < starts[g] - target) --g;  // the boundary before is closer
+        first_group[k] = g;
+    }
+    first_group[kStreams] = kGroups;
+}
+// pass 0: the groups are slices of group_len keys
+StreamCuts pass0_stream_cuts(uint32_t n, uint32_t group_len);
 // keys per look-back tile: 8192 uint32 or 4096 uint64 (32 KiB either way)
 uint32_t onesweep_tile_keys(int key_bytes);
 // counts the four digits at bits [base_shift, base_shift + 32) of every key; also zeroes status[0, status_words)
 // (a multiple of 4 words, 16-byte aligned): the look-back words of the four passes
+// group_len: keys per pass-0 group (whole tiles)
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
-                               uint32_t stream_len, uint32_t *tables, uint32_t *status, size_t status_words,
+                               uint32_t group_len, uint32_t *tables, uint32_t *status, size_t status_words,
                                LaunchEvents ev = {});
-hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t stream_len,
-                       uint32_t tile);
+hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t group_len,
+                       uint32_t tile, const StreamCuts &cuts0);
 // pass = 0..3 inside the group the plan was made for, shift = the pass's absolute bit position; status: kStreams *
 // max_tiles rows of 256 words, zeroed
 hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,

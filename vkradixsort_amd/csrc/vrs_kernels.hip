@@ -529,7 +529,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_w(uint32_t v, uint32_t 
 // neither reads status words (it re-counts its stream's earlier tiles from the keys) nor publishes L2-resident
 // ones (it stores write-through, which the agent-scope polls of the others do see).
 constexpr uint32_t kLbAggregate = 1u << 30, kLbInclusive = 2u << 30, kLbValue = (1u << 30) - 1u;
-constexpr int kLbBatch = 4;  // status rows fetched per round trip
+constexpr int kLbBatch = 4;  // status rows fetched per round trip (2-4 measure the same, 8 and 16 slower)
 
 __device__ __forceinline__ uint32_t lb_load(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load sc1: L1 bypassed, L2 served
@@ -802,20 +802,22 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
 // reference's interface.  When the library owns all four passes it can count ONCE, before the first pass, and let
 // every scatter pass find its offsets by decoupled look-back.  A single look-back chain over all tiles does not
 // fit this chip (tiles must stay in XCD-contiguous order for the L2s to merge their partial lines, and 500-750
-// resident tiles finish 12 ns apart while a hand-off between workgroups takes 1-3 us under load), so the tiles of a pass are cut
-// into kStreams independent STREAMS whose starting offsets are known before the pass starts:
-//   pass 0   stream s = the s-th slice of the input (whole tiles of 8192 uint32 / 4096 uint64 keys);
-//   pass p>0 stream s = the keys whose digit p-1 lies in [8s, 8s+8): after pass p-1 they are the contiguous range
-//            [P_{p-1}[8s], P_{p-1}[8s+8]) of its output (P = exclusive digit prefix), whatever their order inside.
-// digit_tables_kernel counts, in one read of the keys, H[p][s][d] = #keys of stream s of pass p with digit p == d
-// (97 KiB of LDS counters per workgroup); plan_kernel turns H into stream ranges and seeds
-// seed[p][s][d] = P_p[d] + sum_{s'<s} H[p][s'][d]; onesweep_scatter_kernel walks stream s in tile order on XCD
-// s % 8 (tiles of one stream are neighbours in that L2) and looks back only along its own stream.
-// Streams follow the data: a pass whose streams are too unequal (keys that are all multiples of 256, say) is run
-// through the contract path instead (the host reads max_tiles).
+// resident tiles finish 12 ns apart while a hand-off between workgroups takes 1-3 us under load), so the tiles of a
+// pass are cut into kStreams independent STREAMS -- one per XCD -- whose starting offsets are known before the pass
+// starts.  A stream is a run of neighbouring GROUPS; a key's group is a function of the key alone:
+//   pass 0   group g = the g-th slice of the input (whole tiles of 8192 uint32 / 4096 uint64 keys);
+//   pass p>0 group g = the keys whose digit p-1 lies in [8g, 8g+8): after pass p-1 they are the contiguous range
+//            [P_{p-1}[8g], P_{p-1}[8g+8]) of its output (P = exclusive digit prefix), whatever their order inside.
+// digit_tables_kernel counts, in one read of the keys, H[p][g][d] = #keys of group g of pass p with digit p == d
+// (97 KiB of LDS counters per workgroup); plan_kernel merges the kGroups groups of each pass into kStreams streams of
+// nearly equal length and turns H into their ranges and seeds seed[p][s][d] = P_p[d] + (keys with digit d in the
+// groups before stream s); onesweep_scatter_kernel walks stream s in tile order on XCD s % 8 (tiles of one stream
+// are neighbours in that L2) and looks back only along its own stream.
+// Streams follow the data: a pass whose streams cannot be balanced (one group holds far more than 1/kStreams of the
+// keys: keys that are all multiples of 256, say) is run through the contract path instead (the host reads max_tiles).
 constexpr int kTableThreads = 1024;
 constexpr int kTableUnroll = 4;
-constexpr int kStreamDigits = kBins / kStreams;  // digits of pass p-1 per stream of pass p
+constexpr int kGroupDigits = kBins / kGroups;  // digit values of pass p-1 per group of pass p
 // LDS row of one stream's 256 counters, padded by one word: keys that share the counted digit but not the stream
 // (sorted input) would otherwise hit one LDS bank from every lane
 constexpr int kTableRow = kBins + 1;
@@ -823,9 +825,9 @@ constexpr int kTableRow = kBins + 1;
 __device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t key) {
     const uint32_t d0 = key & 255u, d1 = (key >> 8) & 255u, d2 = (key >> 16) & 255u, d3 = key >> 24;
     atomicAdd(&t0[d0], 1u);
-    atomicAdd(&t1[(d0 / kStreamDigits) * kTableRow + d1], 1u);
-    atomicAdd(&t2[(d1 / kStreamDigits) * kTableRow + d2], 1u);
-    atomicAdd(&t3[(d2 / kStreamDigits) * kTableRow + d3], 1u);
+    atomicAdd(&t1[(d0 / kGroupDigits) * kTableRow + d1], 1u);
+    atomicAdd(&t2[(d1 / kGroupDigits) * kTableRow + d2], 1u);
+    atomicAdd(&t3[(d2 / kGroupDigits) * kTableRow + d3], 1u);
 }
 
 // V counters per lane (one 16-byte vector of keys).  Same-address lanes of one LDS atomic are served one after the
@@ -876,9 +878,9 @@ __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t
         const uint32_t w = digit_word(KeyVec<K>::get(q, j), base_shift);
         const uint32_t d0 = w & 255u, d1 = (w >> 8) & 255u, d2 = (w >> 16) & 255u, d3 = w >> 24;
         i0[j] = d0;
-        i1[j] = (d0 / kStreamDigits) * kTableRow + d1;
-        i2[j] = (d1 / kStreamDigits) * kTableRow + d2;
-        i3[j] = (d2 / kStreamDigits) * kTableRow + d3;
+        i1[j] = (d0 / kGroupDigits) * kTableRow + d1;
+        i2[j] = (d1 / kGroupDigits) * kTableRow + d2;
+        i3[j] = (d2 / kGroupDigits) * kTableRow + d3;
     }
     table_add<V>(t0, i0, lane);
     table_add<V>(t1, i1, lane);
@@ -886,8 +888,9 @@ __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t
     table_add<V>(t3, i3, lane);
 }
 
-// grid = kStreams * slices workgroups; workgroup (s, g) counts the g-th part of pass-0 stream s and zeroes its share
-// of the look-back status words of all four passes.  stream_len is a multiple of 4 * slices.  One workgroup per CU
+// grid = kGroups * slices workgroups; workgroup (s, g) counts the g-th part of pass-0 group s and zeroes its share
+// of the look-back status words of all four passes.  stream_len (the length of a pass-0 group) is a multiple of
+// 4 * slices.  One workgroup per CU
 // (97 KiB of LDS), so the loads of step k+1 are issued before step k is counted.  64-bit keys are sorted in two groups
 // of four passes, each with its own counting read: base_shift = 0, then 32.
 template <typename K>
@@ -898,9 +901,9 @@ __global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const K *__
     using Vec = typename KeyVec<K>::type;
     constexpr uint32_t V = KeyVec<K>::kKeys;
     __shared__ uint32_t t0[kBins];
-    __shared__ uint32_t t[3][kStreams * kTableRow];
+    __shared__ uint32_t t[3][kGroups * kTableRow];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t c = tid; c < 3u * kStreams * kTableRow; c += kTableThreads) (&t[0][0])[c] = 0;
+    for (uint32_t c = tid; c < 3u * kGroups * kTableRow; c += kTableThreads) (&t[0][0])[c] = 0;
     if (tid < kBins) t0[tid] = 0;
     {
         const uint4 zero = make_uint4(0, 0, 0, 0);
@@ -955,29 +958,32 @@ __global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const K *__
     if (tid < kBins && t0[tid])
         __hip_atomic_fetch_add(&tables[static_cast<size_t>(s) * kBins + tid], t0[tid], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-    for (uint32_t c = tid; c < 3u * kStreams * kBins; c += kTableThreads) {  // c = (pass - 1, stream, digit)
+    for (uint32_t c = tid; c < 3u * kGroups * kBins; c += kTableThreads) {  // c = (pass - 1, group, digit)
         const uint32_t x = (&t[0][0])[(c >> 8) * kTableRow + (c & 255u)];
-        if (x) __hip_atomic_fetch_add(&tables[kStreams * kBins + c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x) __hip_atomic_fetch_add(&tables[kGroups * kBins + c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// one workgroup; thread (p, d).  Leaves `tables` zeroed for the next sort.
+// one workgroup; thread (p, d).  Merges the kGroups groups of every pass into kStreams streams of (nearly) equal
+// length -- cuts only between groups, so a stream is still a contiguous range of the pass's input and its seed is a
+// prefix over whole groups -- and leaves `tables` zeroed for the next sort.
 __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ tables, OnesweepPlan *__restrict__ plan,
-                                                        uint32_t n, uint32_t stream_len, uint32_t tile) {
+                                                        uint32_t n, uint32_t group_len, uint32_t tile, StreamCuts cuts0) {
     __shared__ uint32_t s_prefix[4][kBins + 1];
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max[4], s_const[4];
+    __shared__ uint32_t s_cut[4][kStreams + 1];  // first group of every stream
     const uint32_t tid = threadIdx.x, p = tid >> 8, d = tid & 255u, lane = tid & 63u, wave = tid >> 6;
-    uint32_t before[kStreams];
+    uint32_t before[kGroups];
     uint32_t total = 0;
 #pragma unroll
-    for (int s = 0; s < kStreams; ++s) before[s] = tables[(static_cast<size_t>(p) * kStreams + s) * kBins + d];
+    for (int g = 0; g < kGroups; ++g) before[g] = tables[(static_cast<size_t>(p) * kGroups + g) * kBins + d];
 #pragma unroll
-    for (int s = 0; s < kStreams; ++s) {
-        const uint32_t c = before[s];
-        before[s] = total;
+    for (int g = 0; g < kGroups; ++g) {
+        const uint32_t c = before[g];
+        before[g] = total;
         total += c;
-        tables[(static_cast<size_t>(p) * kStreams + s) * kBins + d] = 0;
+        tables[(static_cast<size_t>(p) * kGroups + g) * kBins + d] = 0;
     }
     uint32_t incl = total;
 #pragma unroll
@@ -997,20 +1003,44 @@ __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ 
     const uint32_t digit_start = base + incl - total;
     s_prefix[p][d] = digit_start;
     if (d == 255u) s_prefix[p][kBins] = n;
-#pragma unroll
-    for (int s = 0; s < kStreams; ++s) plan->seed[p][s][d] = digit_start + before[s];
     __syncthreads();
+    // where group g of pass q starts in the pass's input
+    const auto group_start = [&](uint32_t q, uint32_t g) -> uint32_t {
+        if (q == 0) {
+            const uint64_t a = static_cast<uint64_t>(g) * group_len;
+            return static_cast<uint32_t>(a < n ? a : n);
+        }
+        return s_prefix[q - 1][g * kGroupDigits];  // g == kGroups -> n
+    };
+    if (tid < 4) {
+        const uint32_t q = tid;
+        if (q == 0) {  // slices of the input: the host made these cuts (it launches pass 0 before this plan is back)
+            for (int k = 0; k <= kStreams; ++k) s_cut[0][k] = cuts0.first_group[k];
+        } else {
+            uint32_t starts[kGroups + 1];
+            for (int g = 0; g <= kGroups; ++g) starts[g] = s_prefix[q - 1][g * kGroupDigits];  // [kGroups] == n
+            balanced_cuts(starts, n, s_cut[q]);
+        }
+    }
+    __syncthreads();
+    {
+        // seed of stream s = digit start + the keys of this digit in all groups before the stream's first one
+        uint32_t s = 0;
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            while (s < static_cast<uint32_t>(kStreams) && s_cut[p][s] == static_cast<uint32_t>(g)) {
+                plan->seed[p][s][d] = digit_start + before[g];
+                ++s;
+            }
+        }
+        while (s < static_cast<uint32_t>(kStreams)) {  // streams that start past the last group are empty
+            plan->seed[p][s][d] = digit_start + total;
+            ++s;
+        }
+    }
     if (tid < 4u * kStreams) {
         const uint32_t q = tid / kStreams, s = tid % kStreams;
-        uint32_t start, end;
-        if (q == 0) {
-            const uint64_t a = static_cast<uint64_t>(s) * stream_len, b = a + stream_len;
-            start = static_cast<uint32_t>(a < n ? a : n);
-            end = static_cast<uint32_t>(b < n ? b : n);
-        } else {
-            start = s_prefix[q - 1][s * kStreamDigits];
-            end = s_prefix[q - 1][(s + 1) * kStreamDigits];
-        }
+        const uint32_t start = group_start(q, s_cut[q][s]), end = group_start(q, s_cut[q][s + 1]);
         plan->start[q][s] = start;
         plan->len[q][s] = end - start;
         atomicMax(&s_max[q], (end - start + tile - 1u) / tile);
@@ -1350,7 +1380,7 @@ uint32_t onesweep_tile_keys(int key_bytes) { return key_bytes == 8 ? 4096u : 819
 
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
                                uint32_t stream_len, uint32_t *tables, uint32_t *status, size_t status_words, LaunchEvents ev) {
-    const dim3 grid(kStreams * kTableSlices), block(kTableThreads);
+    const dim3 grid(kGroups * kTableSlices), block(kTableThreads);
     const uint32_t slices = kTableSlices, vecs = static_cast<uint32_t>(status_words / 4);
     if (key_bytes == 8)
         VRS_LAUNCH(digit_tables_kernel<uint64_t>, grid, block, stream, ev, static_cast<const uint64_t *>(keys), n, base_shift,
@@ -1361,9 +1391,20 @@ hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n,
     return hipGetLastError();
 }
 
-hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t stream_len,
-                       uint32_t tile) {
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(4 * kBins), 0, stream, tables, plan, n, stream_len, tile);
+StreamCuts pass0_stream_cuts(uint32_t n, uint32_t group_len) {
+    uint32_t starts[kGroups + 1];
+    for (int g = 0; g <= kGroups; ++g) {
+        const uint64_t a = static_cast<uint64_t>(g) * group_len;
+        starts[g] = static_cast<uint32_t>(a < n ? a : n);
+    }
+    StreamCuts c;
+    balanced_cuts(starts, n, c.first_group);
+    return c;
+}
+
+hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t group_len,
+                       uint32_t tile, const StreamCuts &cuts0) {
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(4 * kBins), 0, stream, tables, plan, n, group_len, tile, cuts0);
     return hipGetLastError();
 }
 
