@@ -71,7 +71,8 @@ constexpr int kGroups = 32;
 constexpr int kStreams = VRS_STREAMS;    // a multiple of 8 that divides kGroups: stream s runs on XCD s % 8
 constexpr int kTableSlices = 8;          // digit_tables workgroups per pass-0 group
 struct OnesweepPlan {
-    uint32_t seed[4][kStreams][256];  // global offset of digit d at the start of stream s of pass p
+    uint32_t group_seed[4][kGroups + 1][256];  // global offset of digit d at the start of group g of pass p
+    uint32_t first_group[4][kStreams];         // stream s starts with this group: its seed row is group_seed[p][that]
     uint32_t start[4][kStreams];      // first key of the stream in the pass's input
     uint32_t len[4][kStreams];
     uint32_t max_tiles[4];            // tiles of the longest stream of each pass
@@ -82,19 +83,16 @@ constexpr size_t kDigitTableWords = 4u * kGroups * 256u;
 struct StreamCuts {
     uint32_t first_group[kStreams + 1];
 };
-// Cuts the kGroups groups (group g = keys [starts[g], starts[g + 1]) of the pass's input, starts[kGroups] == n) into
-// kStreams contiguous streams of nearly equal length: stream k ends at the group boundary closest to (k + 1) * n / kStreams.
-// One definition for the host (pass 0) and the plan kernel (passes 1-3).
-__host__ __device__ inline void balanced_cuts(const uint32_t (&starts)[kGroups + 1], uint32_t n, uint32_t (&first_group)[kStreams + 1]) {
-    first_group[0] = 0;
+// Cut k (0 < k < kStreams) between streams k-1 and k: the group boundary closest to k * n / kStreams, where group g
+// of the pass's input is keys [start_of(g), start_of(g + 1)) and start_of(kGroups) == n.  Non-decreasing in k.  One
+// definition for the host (pass 0) and the plan kernel (passes 1-3).
+template <typename StartOf>
+__host__ __device__ inline uint32_t balanced_cut(const StartOf &start_of, uint32_t n, uint32_t k) {
+    const uint64_t target = static_cast<uint64_t>(n) * k / kStreams;
     uint32_t g = 0;
-    for (uint32_t k = 1; k < static_cast<uint32_t>(kStreams); ++k) {
-        const uint64_t target = static_cast<uint64_t>(n) * k / kStreams;
-        while (g < static_cast<uint32_t>(kGroups) && starts[g] < target) ++g;
-        if (g > first_group[k - 1] && target - starts[g - 1] < starts[g] - target) --g;  // the boundary before is closer
-        first_group[k] = g;
-    }
-    first_group[kStreams] = kGroups;
+    while (g < static_cast<uint32_t>(kGroups) && start_of(g) < target) ++g;
+    if (g > 0 && target - start_of(g - 1) < start_of(g) - target) --g;  // the boundary before is closer
+    return g;
 }
 // pass 0: the groups are slices of group_len keys
 StreamCuts pass0_stream_cuts(uint32_t n, uint32_t group_len);

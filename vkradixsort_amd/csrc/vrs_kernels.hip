@@ -810,8 +810,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
 //            [P_{p-1}[8g], P_{p-1}[8g+8]) of its output (P = exclusive digit prefix), whatever their order inside.
 // digit_tables_kernel counts, in one read of the keys, H[p][g][d] = #keys of group g of pass p with digit p == d
 // (97 KiB of LDS counters per workgroup); plan_kernel merges the kGroups groups of each pass into kStreams streams of
-// nearly equal length and turns H into their ranges and seeds seed[p][s][d] = P_p[d] + (keys with digit d in the
-// groups before stream s); onesweep_scatter_kernel walks stream s in tile order on XCD s % 8 (tiles of one stream
+// nearly equal length and turns H into their ranges and seeds (P_p[d] + the keys with digit d in the groups before
+// the stream's first group); onesweep_scatter_kernel walks stream s in tile order on XCD s % 8 (tiles of one stream
 // are neighbours in that L2) and looks back only along its own stream.
 // Streams follow the data: a pass whose streams cannot be balanced (one group holds far more than 1/kStreams of the
 // keys: keys that are all multiples of 256, say) is run through the contract path instead (the host reads max_tiles).
@@ -1012,35 +1012,25 @@ __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ 
         }
         return s_prefix[q - 1][g * kGroupDigits];  // g == kGroups -> n
     };
-    if (tid < 4) {
-        const uint32_t q = tid;
-        if (q == 0) {  // slices of the input: the host made these cuts (it launches pass 0 before this plan is back)
-            for (int k = 0; k <= kStreams; ++k) s_cut[0][k] = cuts0.first_group[k];
-        } else {
-            uint32_t starts[kGroups + 1];
-            for (int g = 0; g <= kGroups; ++g) starts[g] = s_prefix[q - 1][g * kGroupDigits];  // [kGroups] == n
-            balanced_cuts(starts, n, s_cut[q]);
-        }
+    if (tid < 4u * kStreams) {  // thread (q, k): the cut between streams k-1 and k of pass q
+        const uint32_t q = tid / kStreams, k = tid % kStreams;
+        uint32_t cut = 0;
+        if (q == 0)  // slices of the input: the host made these cuts (it launches pass 0 before this plan is back)
+            cut = cuts0.first_group[k];
+        else if (k > 0)
+            cut = balanced_cut([&](uint32_t g) { return s_prefix[q - 1][g * kGroupDigits]; }, n, k);  // [kGroups] -> n
+        s_cut[q][k] = cut;
+        if (k == 0) s_cut[q][kStreams] = kGroups;
     }
-    __syncthreads();
-    {
-        // seed of stream s = digit start + the keys of this digit in all groups before the stream's first one
-        uint32_t s = 0;
+    // where digit d of every group starts in the pass's output; a stream's seed is the row of its first group
 #pragma unroll
-        for (int g = 0; g < kGroups; ++g) {
-            while (s < static_cast<uint32_t>(kStreams) && s_cut[p][s] == static_cast<uint32_t>(g)) {
-                plan->seed[p][s][d] = digit_start + before[g];
-                ++s;
-            }
-        }
-        while (s < static_cast<uint32_t>(kStreams)) {  // streams that start past the last group are empty
-            plan->seed[p][s][d] = digit_start + total;
-            ++s;
-        }
-    }
+    for (int g = 0; g < kGroups; ++g) plan->group_seed[p][g][d] = digit_start + before[g];
+    plan->group_seed[p][kGroups][d] = digit_start + total;
+    __syncthreads();
     if (tid < 4u * kStreams) {
         const uint32_t q = tid / kStreams, s = tid % kStreams;
         const uint32_t start = group_start(q, s_cut[q][s]), end = group_start(q, s_cut[q][s + 1]);
+        plan->first_group[q][s] = s_cut[q][s];
         plan->start[q][s] = start;
         plan->len[q][s] = end - start;
         atomicMax(&s_max[q], (end - start + tile - 1u) / tile);
@@ -1093,7 +1083,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     lb.col = status + static_cast<size_t>(s) * kBins + (threadIdx.x & 255u);
     lb.stride = static_cast<size_t>(kStreams) * kBins;
     lb.index = static_cast<int>(i);
-    lb.seed = threadIdx.x < kBins ? plan->seed[pass][s][threadIdx.x] : 0u;
+    lb.seed = threadIdx.x < kBins ? plan->group_seed[pass][plan->first_group[pass][s]][threadIdx.x] : 0u;
     uint32_t unused = 0;
     const uint32_t *vin = PAIRS ? values_in + begin : nullptr;
     if (valid == kTile)
@@ -1392,13 +1382,14 @@ hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n,
 }
 
 StreamCuts pass0_stream_cuts(uint32_t n, uint32_t group_len) {
-    uint32_t starts[kGroups + 1];
-    for (int g = 0; g <= kGroups; ++g) {
+    const auto start_of = [&](uint32_t g) -> uint32_t {
         const uint64_t a = static_cast<uint64_t>(g) * group_len;
-        starts[g] = static_cast<uint32_t>(a < n ? a : n);
-    }
+        return static_cast<uint32_t>(a < n ? a : n);
+    };
     StreamCuts c;
-    balanced_cuts(starts, n, c.first_group);
+    c.first_group[0] = 0;
+    for (uint32_t k = 1; k < static_cast<uint32_t>(kStreams); ++k) c.first_group[k] = balanced_cut(start_of, n, k);
+    c.first_group[kStreams] = kGroups;
     return c;
 }
 
