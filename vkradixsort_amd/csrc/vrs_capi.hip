@@ -52,7 +52,7 @@ struct vrs_context_t {
     vrs::OnesweepPlan *os_plan = nullptr;
     uint32_t *os_status = nullptr;       // look-back status rows
     size_t os_status_rows = 0;
-    uint32_t *os_host_max_tiles = nullptr;  // pinned copy of plan->max_tiles
+    vrs::OnesweepPlanHead *os_host_head = nullptr;  // pinned copy of the plan's head
     hipEvent_t os_plan_ready = nullptr;
     bool os_misplace = false;            // test hook, VRS_TUNE_DEBUG_MISPLACE_STREAMS
     bool xcc_map_valid = false;          // the probe found block b on an XCC that depends on b % 8 only
@@ -368,7 +368,7 @@ int vrs_context_destroy(vrs_context ctx) {
     if (ctx->os_tables) (void)hipFree(ctx->os_tables);
     if (ctx->os_plan) (void)hipFree(ctx->os_plan);
     if (ctx->os_status) (void)hipFree(ctx->os_status);
-    if (ctx->os_host_max_tiles) (void)hipHostFree(ctx->os_host_max_tiles);
+    if (ctx->os_host_head) (void)hipHostFree(ctx->os_host_head);
     if (ctx->os_plan_ready) (void)hipEventDestroy(ctx->os_plan_ready);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -628,10 +628,14 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
     const uint32_t group_len = group_tiles * T;              // < 2^30 / 32 + 8192
     // pass 0's streams are made here (the pass is enqueued before the plan is back): neighbouring slices merged
     const vrs::StreamCuts cuts0 = vrs::pass0_stream_cuts(n, group_len);
-    uint32_t tiles0 = 0;  // tiles of the longest pass-0 stream
+    vrs::StreamRanges ranges0{};  // pass 0's streams
+    uint32_t tiles0 = 0;          // tiles of the longest of them
     for (uint32_t k = 0; k < S; ++k) {
         const uint64_t a = std::min<uint64_t>(static_cast<uint64_t>(cuts0.first_group[k]) * group_len, n);
         const uint64_t b = std::min<uint64_t>(static_cast<uint64_t>(cuts0.first_group[k + 1]) * group_len, n);
+        ranges0.first_group[k] = cuts0.first_group[k];
+        ranges0.start[k] = static_cast<uint32_t>(a);
+        ranges0.len[k] = static_cast<uint32_t>(b - a);
         tiles0 = std::max<uint32_t>(tiles0, static_cast<uint32_t>((b - a + T - 1) / T));
     }
     const uint32_t even = (tiles_total + S - 1) / S;        // tiles of a perfectly even stream
@@ -640,7 +644,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_tables), vrs::kDigitTableWords * sizeof(uint32_t)));
         VRS_HIP(ctx, hipMemsetAsync(ctx->os_tables, 0, vrs::kDigitTableWords * sizeof(uint32_t), ctx->stream));
         VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_plan), sizeof(vrs::OnesweepPlan)));
-        VRS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->os_host_max_tiles), 8 * sizeof(uint32_t)));
+        VRS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->os_host_head), sizeof(vrs::OnesweepPlanHead)));
         VRS_HIP(ctx, hipEventCreateWithFlags(&ctx->os_plan_ready, hipEventDisableTiming));
     }
     const size_t pass_rows = static_cast<size_t>(S) * tile_cap;  // status rows of one pass
@@ -681,19 +685,26 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
                                               ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS, ev));
         VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, n, group_len, T, cuts0));
         guard.armed = false;
-        VRS_HIP(ctx, hipMemcpyAsync(ctx->os_host_max_tiles, ctx->os_plan->max_tiles, 8 * sizeof(uint32_t),
-                                    hipMemcpyDeviceToHost, ctx->stream));  // max_tiles[4] + constant[4]
+        VRS_HIP(ctx, hipMemcpyAsync(ctx->os_host_head, &ctx->os_plan->head, sizeof(vrs::OnesweepPlanHead), hipMemcpyDeviceToHost,
+                                    ctx->stream));
         VRS_HIP(ctx, hipEventRecord(ctx->os_plan_ready, ctx->stream));
         for (uint32_t i = 0; i < 4; ++i) {
             const uint32_t shift = 32u * group + 8u * i;
             // pass 0's streams are slices of the input (known here); the others come back from the plan while it runs
             uint32_t max_tiles = tiles0;
             if (i == 1) VRS_HIP(ctx, hipEventSynchronize(ctx->os_plan_ready));
+            vrs::StreamRanges ranges = ranges0;
             if (i > 0) {
-                max_tiles = ctx->os_host_max_tiles[i];
-                if (ctx->os_host_max_tiles[4 + i]) {
+                const vrs::OnesweepPlanHead &head = *ctx->os_host_head;
+                max_tiles = head.max_tiles[i];
+                if (head.constant[i]) {
                     ctx->os_skipped_passes++;
                     continue;
+                }
+                for (uint32_t k = 0; k < S; ++k) {
+                    ranges.first_group[k] = head.first_group[i][k];
+                    ranges.start[k] = head.start[i][k];
+                    ranges.len[k] = head.len[i][k];
                 }
             }
             vrs_buffer kin = kbuf[cur], kout = kbuf[cur ^ 1u];
@@ -709,8 +720,8 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
             VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kin->ptr, kout->ptr,
                                                       vin ? static_cast<const uint32_t *>(vin->ptr) : nullptr,
                                                       vout ? static_cast<uint32_t *>(vout->ptr) : nullptr, ctx->os_plan, i,
-                                                      shift, ctx->os_status + i * pass_rows * VRS_RADIX_SORT_BINS, max_tiles,
-                                                      ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes, ev,
+                                                      shift, ranges, ctx->os_status + i * pass_rows * VRS_RADIX_SORT_BINS,
+                                                      max_tiles, ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes, ev,
                                                       ctx->os_misplace));
         }
     }

@@ -70,13 +70,22 @@ hipError_t launch_transform_keys(hipStream_t stream, uint32_t *keys, uint32_t n,
 constexpr int kGroups = 32;
 constexpr int kStreams = VRS_STREAMS;    // a multiple of 8 that divides kGroups: stream s runs on XCD s % 8
 constexpr int kTableSlices = 8;          // digit_tables workgroups per pass-0 group
-struct OnesweepPlan {
-    uint32_t group_seed[4][kGroups + 1][256];  // global offset of digit d at the start of group g of pass p
-    uint32_t first_group[4][kStreams];         // stream s starts with this group: its seed row is group_seed[p][that]
-    uint32_t start[4][kStreams];      // first key of the stream in the pass's input
+// the part of the plan the host reads back (one small copy) before it launches passes 1-3
+struct OnesweepPlanHead {
+    uint32_t first_group[4][kStreams];  // stream s of pass p starts with this group: its seed row is group_seed[p][that]
+    uint32_t start[4][kStreams];        // first key of the stream in the pass's input
     uint32_t len[4][kStreams];
-    uint32_t max_tiles[4];            // tiles of the longest stream of each pass
-    uint32_t constant[4];             // 1: every key has the same digit in this pass (the pass is the identity)
+    uint32_t max_tiles[4];              // tiles of the longest stream of each pass
+    uint32_t constant[4];               // 1: every key has the same digit in this pass (the pass is the identity)
+};
+struct OnesweepPlan {
+    OnesweepPlanHead head;
+    uint32_t group_seed[4][kGroups + 1][256];  // global offset of digit d at the start of group g of pass p
+};
+// The streams of ONE pass, handed to the scatter kernel by value: a tile must not wait for a load from the plan before
+// it can issue the loads of its keys.
+struct StreamRanges {
+    uint32_t first_group[kStreams], start[kStreams], len[kStreams];
 };
 constexpr size_t kDigitTableWords = 4u * kGroups * 256u;
 // first group of every stream (first_group[kStreams] == kGroups)
@@ -106,12 +115,13 @@ hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n,
                                LaunchEvents ev = {});
 hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t group_len,
                        uint32_t tile, const StreamCuts &cuts0);
-// pass = 0..3 inside the group the plan was made for, shift = the pass's absolute bit position; status: kStreams *
-// max_tiles rows of 256 words, zeroed
+// pass = 0..3 inside the group of four the plan was made for, shift = the pass's absolute bit position, ranges = the
+// pass's streams (from the plan's head, or made by the host for pass 0); status: kStreams * max_tiles rows of 256
+// words, zeroed
 hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                                    uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
-                                   uint32_t *status, uint32_t max_tiles, bool atomic_rank, unsigned long long xcc_map,
-                                   int key_bytes, LaunchEvents ev = {}, bool misplace = false);
+                                   const StreamRanges &ranges, uint32_t *status, uint32_t max_tiles, bool atomic_rank,
+                                   unsigned long long xcc_map, int key_bytes, LaunchEvents ev = {}, bool misplace = false);
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups
 hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks);
 

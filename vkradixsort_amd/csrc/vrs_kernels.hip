@@ -1030,15 +1030,15 @@ __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ 
     if (tid < 4u * kStreams) {
         const uint32_t q = tid / kStreams, s = tid % kStreams;
         const uint32_t start = group_start(q, s_cut[q][s]), end = group_start(q, s_cut[q][s + 1]);
-        plan->first_group[q][s] = s_cut[q][s];
-        plan->start[q][s] = start;
-        plan->len[q][s] = end - start;
+        plan->head.first_group[q][s] = s_cut[q][s];
+        plan->head.start[q][s] = start;
+        plan->head.len[q][s] = end - start;
         atomicMax(&s_max[q], (end - start + tile - 1u) / tile);
     }
     __syncthreads();
     if (tid < 4) {
-        plan->max_tiles[tid] = s_max[tid];
-        plan->constant[tid] = s_const[tid];
+        plan->head.max_tiles[tid] = s_max[tid];
+        plan->head.constant[tid] = s_const[tid];
     }
 }
 
@@ -1049,8 +1049,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
                                                                        K *__restrict__ keys_out,
                                                                        const uint32_t *__restrict__ values_in,
                                                                        uint32_t *__restrict__ values_out,
-                                                                       const OnesweepPlan *__restrict__ plan,
-                                                                       uint32_t pass, uint32_t shift,
+                                                                       const uint32_t *__restrict__ group_seed,
+                                                                       StreamRanges ranges, uint32_t shift,
                                                                        uint32_t *__restrict__ status,
                                                                        unsigned long long xcc_map, int misplace) {
     constexpr uint32_t kTile = ITEMS * WAVES * 64;  // the tile the plan counted with (onesweep_tile_keys)
@@ -1059,10 +1059,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     // misplace (test hook): odd tiles of every stream run on the neighbouring XCD, so the look-back has to work
     // through the write-through copies instead of one L2
     const uint32_t s = ((blockIdx.x + (misplace ? (i & 1u) : 0u)) & 7u) + 8u * (k % (kStreams / 8));
-    const uint32_t len = plan->len[pass][s];
+    // start and length come with the launch (kernel arguments), not from memory: nothing delays the key loads
+    const uint32_t len = ranges.len[s];
     if (static_cast<uint64_t>(i) * kTile >= len) return;  // uniform per workgroup
     const uint32_t done = i * kTile;
-    const uint32_t begin = plan->start[pass][s] + done;
+    const uint32_t begin = ranges.start[s] + done;
     const uint32_t valid = min(kTile, len - done);
     RadixDigit<K> dg;
     dg.shift = shift;
@@ -1074,7 +1075,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
         uint32_t *cnt = sm.whist[0];
         if (threadIdx.x < kBins) cnt[threadIdx.x] = 0;
         __syncthreads();
-        const K *k0 = keys_in + plan->start[pass][s];
+        const K *k0 = keys_in + ranges.start[s];
         for (uint32_t j = threadIdx.x; j < done; j += WAVES * 64) atomicAdd(&cnt[dg(k0[j])], 1u);
         __syncthreads();
         if (threadIdx.x < kBins) lb.recounted = cnt[threadIdx.x];
@@ -1083,7 +1084,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     lb.col = status + static_cast<size_t>(s) * kBins + (threadIdx.x & 255u);
     lb.stride = static_cast<size_t>(kStreams) * kBins;
     lb.index = static_cast<int>(i);
-    lb.seed = threadIdx.x < kBins ? plan->group_seed[pass][plan->first_group[pass][s]][threadIdx.x] : 0u;
+    lb.seed = threadIdx.x < kBins ? group_seed[static_cast<size_t>(ranges.first_group[s]) * kBins + threadIdx.x] : 0u;
     uint32_t unused = 0;
     const uint32_t *vin = PAIRS ? values_in + begin : nullptr;
     if (valid == kTile)
@@ -1401,15 +1402,16 @@ hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan,
 
 hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                                    uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
-                                   uint32_t *status, uint32_t max_tiles, bool atomic_rank, unsigned long long xcc_map,
-                                   int key_bytes, LaunchEvents ev, bool misplace) {
+                                   const StreamRanges &ranges, uint32_t *status, uint32_t max_tiles, bool atomic_rank,
+                                   unsigned long long xcc_map, int key_bytes, LaunchEvents ev, bool misplace) {
     const int mis = misplace ? 1 : 0;
+    const uint32_t *group_seed = &plan->group_seed[pass][0][0];  // address arithmetic on the device pointer only
     const dim3 grid(kStreams * max_tiles), block(512);
     const bool pairs = values_in != nullptr;
 #define VRS_ONESWEEP(K, ITEMS, PAIRS, RANK)                                                                           \
     VRS_LAUNCH((onesweep_scatter_kernel<K, ITEMS, 8, PAIRS, RANK, 4>), grid, block, stream, ev,                       \
-               static_cast<const K *>(keys_in), static_cast<K *>(keys_out), values_in, values_out, plan, pass, shift, \
-               status, xcc_map, mis)
+               static_cast<const K *>(keys_in), static_cast<K *>(keys_out), values_in, values_out, group_seed, ranges, \
+               shift, status, xcc_map, mis)
     if (key_bytes == 8) {
         if (pairs) return hipErrorInvalidValue;  // no one-call pairs entry point for 64-bit keys
         if (atomic_rank) VRS_ONESWEEP(uint64_t, 8, false, RANK_ATOMIC); else VRS_ONESWEEP(uint64_t, 8, false, RANK_BALLOT);
