@@ -718,10 +718,11 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) sm.vals[rank[i]] = val[i];
     }
+    uint32_t lb_inclusive = 0;
     if constexpr (LB::kEnabled) {
         if (tid < kBins) {
             const uint32_t before = lb.foreign ? lb.recounted : lb.resolve(lb_rows);
-            lb.publish(kLbInclusive | (before + lb_total));
+            lb_inclusive = kLbInclusive | (before + lb_total);  // published below, after the LDS reads of the write-out
             sm.gbase[tid] = lb.seed + before - lb_excl;
         }
     }
@@ -734,6 +735,13 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     uint32_t dst[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) dst[i] = sm.gbase[dg(key[i])] + (i * THREADS + tid);
+    if constexpr (LB::kEnabled) {
+        // The inclusive count goes out HERE, as the first store of the write-out, not right after the look-back: the
+        // registers the status loads landed in are reused by the LDS reads above, so the compiler waits for vmcnt(0)
+        // before them -- and loads and stores retire on one in-order counter, so with the store already issued that
+        // wait would hold the whole write-out back until the store is acknowledged.
+        if (tid < kBins) lb.publish(lb_inclusive);
+    }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         if (FULL || i * THREADS + tid < valid) kout[dst[i]] = key[i];
