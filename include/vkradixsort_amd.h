@@ -230,6 +230,10 @@ int vrs_debug_download_offsets(vrs_context ctx, void *host_data, size_t size_byt
  * number of lanes whose rank differs from the __ballot-based rank over `rounds` rounds per wave. */
 int vrs_debug_atomic_rank_selftest(vrs_context ctx, uint32_t rounds, uint32_t seed, uint64_t *mismatches);
 
+/* What the large-N form of the one-call sorts did on this context so far (cumulative): passes run as look-back
+ * scatters, passes that fell back to a contract pass (streams too unequal), identity passes left out. */
+int vrs_one_call_stats(vrs_context ctx, uint64_t *lookback_passes, uint64_t *fallback_passes, uint64_t *skipped_passes);
+
 /* Ranking method in effect: 1 = __ballot match-any, 2 = returning LDS atomics. */
 int vrs_rank_mode(vrs_context ctx);
 

@@ -113,6 +113,26 @@ def test_one_read_and_contract_passes_agree(gpu_context, n):
     assert np.array_equal(a, b) and np.array_equal(a, np.sort(keys))
 
 
+def test_one_call_stats_count_what_happened(gpu_context):
+    ctx = gpu_context
+
+    def stats():
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        ctx.check(ctx.lib.vrs_one_call_stats(ctx.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return np.array([a.value, b.value, c.value], dtype=np.int64)
+
+    s0 = stats()
+    sort_keys(ctx, make_keys(1 << 21, "uniform"))
+    s1 = stats()
+    assert (s1 - s0).tolist() == [4, 0, 0]
+    sort_keys(ctx, make_keys(1 << 21, "lowbyte"))  # passes 1-3 are the identity
+    s2 = stats()
+    assert (s2 - s1).tolist() == [1, 0, 3]
+    sort_keys(ctx, make_keys(1 << 21, "mult256"))  # pass 1's keys all sit in one group
+    s3 = stats()
+    assert (s3 - s2).tolist() == [3, 1, 0]
+
+
 def test_threshold_selects_the_form(gpu_context):
     keys = make_keys(600000, "uniform")
     _, below = sort_keys(gpu_context, keys, min_keys=1 << 20)

@@ -97,6 +97,7 @@ _SIGNATURES = [
     ("vrs_profile_reset", c_int, [c_void_p]),
     ("vrs_profile_query", c_int, [c_void_p, c_int, POINTER(c_uint64), POINTER(c_double)]),
     ("vrs_profile_query_launch", c_int, [c_void_p, c_int, c_uint64, POINTER(c_double)]),
+    ("vrs_one_call_stats", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
     ("vrs_debug_download_offsets", c_int, [c_void_p, c_void_p, c_size_t]),
     ("vrs_debug_atomic_rank_selftest", c_int, [c_void_p, c_uint32, c_uint32, POINTER(c_uint64)]),
     ("vrs_rank_mode", c_int, [c_void_p]),

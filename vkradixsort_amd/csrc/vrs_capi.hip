@@ -57,6 +57,7 @@ struct vrs_context_t {
     bool os_misplace = false;            // test hook, VRS_TUNE_DEBUG_MISPLACE_STREAMS
     bool xcc_map_valid = false;          // the probe found block b on an XCC that depends on b % 8 only
     unsigned long long xcc_map = 0;      // byte x = that XCC for b % 8 == x
+    uint64_t os_lookback_passes = 0;
     uint64_t os_fallback_passes = 0;
     uint64_t os_skipped_passes = 0;      // identity passes (one digit value holds every key) the one-call sort left out     // passes the one-call sort ran through the contract path (unbalanced streams)
 };
@@ -717,6 +718,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
                 continue;
             }
             if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+            ctx->os_lookback_passes++;
             VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kin->ptr, kout->ptr,
                                                       vin ? static_cast<const uint32_t *>(vin->ptr) : nullptr,
                                                       vout ? static_cast<uint32_t *>(vout->ptr) : nullptr, ctx->os_plan, i,
@@ -938,6 +940,14 @@ int vrs_debug_atomic_rank_selftest(vrs_context ctx, uint32_t rounds, uint32_t se
     if (!ctx || !mismatches) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or mismatches is NULL");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
     return atomic_rank_selftest(ctx, rounds, seed, mismatches);
+}
+
+int vrs_one_call_stats(vrs_context ctx, uint64_t *lookback_passes, uint64_t *fallback_passes, uint64_t *skipped_passes) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (lookback_passes) *lookback_passes = ctx->os_lookback_passes;
+    if (fallback_passes) *fallback_passes = ctx->os_fallback_passes;
+    if (skipped_passes) *skipped_passes = ctx->os_skipped_passes;
+    return VRS_OK;
 }
 
 int vrs_rank_mode(vrs_context ctx) { return ctx && ctx->scatter.atomic_rank ? 2 : 1; }
