@@ -829,10 +829,15 @@ constexpr int kGroupDigits = kBins / kGroups;  // digit values of pass p-1 per g
 // LDS row of one stream's 256 counters, padded by one word: keys that share the counted digit but not the stream
 // (sorted input) would otherwise hit one LDS bank from every lane
 constexpr int kTableRow = kBins + 1;
+// The pass-0 table has only 256 counters, hit by every key of the workgroup: it is kept in kT0Copies copies, lane l
+// adding to copy l % kT0Copies (word d0 * kT0Copies + copy, so the 32 lanes of a half wave sit in 32 different banks
+// whatever their digits).  Four random LDS adds per key are what bounds this kernel (bank conflicts); this one is
+// conflict-free.
+constexpr int kT0Copies = 32;
 
 __device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t key) {
     const uint32_t d0 = key & 255u, d1 = (key >> 8) & 255u, d2 = (key >> 16) & 255u, d3 = key >> 24;
-    atomicAdd(&t0[d0], 1u);
+    atomicAdd(&t0[d0 * kT0Copies + (lane_id() % kT0Copies)], 1u);
     atomicAdd(&t1[(d0 / kGroupDigits) * kTableRow + d1], 1u);
     atomicAdd(&t2[(d1 / kGroupDigits) * kTableRow + d2], 1u);
     atomicAdd(&t3[(d2 / kGroupDigits) * kTableRow + d3], 1u);
@@ -885,7 +890,7 @@ __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t
     for (int j = 0; j < V; ++j) {
         const uint32_t w = digit_word(KeyVec<K>::get(q, j), base_shift);
         const uint32_t d0 = w & 255u, d1 = (w >> 8) & 255u, d2 = (w >> 16) & 255u, d3 = w >> 24;
-        i0[j] = d0;
+        i0[j] = d0 * kT0Copies + (lane % kT0Copies);
         i1[j] = (d0 / kGroupDigits) * kTableRow + d1;
         i2[j] = (d1 / kGroupDigits) * kTableRow + d2;
         i3[j] = (d2 / kGroupDigits) * kTableRow + d3;
@@ -908,11 +913,11 @@ __global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const K *__
                                                                      uint4 *__restrict__ status, uint32_t status_vecs) {
     using Vec = typename KeyVec<K>::type;
     constexpr uint32_t V = KeyVec<K>::kKeys;
-    __shared__ uint32_t t0[kBins];
+    __shared__ uint32_t t0[kBins * kT0Copies];
     __shared__ uint32_t t[3][kGroups * kTableRow];
     const uint32_t tid = threadIdx.x;
     for (uint32_t c = tid; c < 3u * kGroups * kTableRow; c += kTableThreads) (&t[0][0])[c] = 0;
-    if (tid < kBins) t0[tid] = 0;
+    for (uint32_t c = tid; c < static_cast<uint32_t>(kBins * kT0Copies); c += kTableThreads) t0[c] = 0;
     {
         const uint4 zero = make_uint4(0, 0, 0, 0);
         const uint32_t per = (status_vecs + gridDim.x - 1) / gridDim.x;
@@ -963,9 +968,14 @@ __global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const K *__
         if (tail < len) digit_tables_count(t0, t[0], t[1], t[2], digit_word(keys[begin + tail], base_shift));
     }
     __syncthreads();
-    if (tid < kBins && t0[tid])
-        __hip_atomic_fetch_add(&tables[static_cast<size_t>(s) * kBins + tid], t0[tid], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < kBins) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int r = 0; r < kT0Copies; ++r) sum += t0[tid * kT0Copies + ((r + tid) % kT0Copies)];  // skewed: no bank conflicts
+        if (sum)
+            __hip_atomic_fetch_add(&tables[static_cast<size_t>(s) * kBins + tid], sum, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    }
     for (uint32_t c = tid; c < 3u * kGroups * kBins; c += kTableThreads) {  // c = (pass - 1, group, digit)
         const uint32_t x = (&t[0][0])[(c >> 8) * kTableRow + (c & 255u)];
         if (x) __hip_atomic_fetch_add(&tables[kGroups * kBins + c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
