@@ -16,7 +16,7 @@ The reference is single-GPU; this is the build's multi-GPU path.  One process pe
                   the sub-ranges are disjoint and ascending, so their concatenation is the sorted range -- no merge
 
 Rank g ends up holding range g in ascending order; the global result is the concatenation of ranks 0..W-1.
-HBM bytes per key: 12 (step 1) + 48 (step 4) = 60, plus one trip over xGMI for (world-1)/world of the keys; only the
+HBM bytes per key: 12 (step 1) + 36 (step 4: the one-call sort, one counting read + four look-back scatters) = 48, plus one trip over xGMI for (world-1)/world of the keys; only the
 first round's transfer and the last round's sort are not overlapped.
 
 The device work is behind `LocalSortBackend`; the product backend drives the C ABI on torch's current stream.
