@@ -168,14 +168,16 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * library picks NUM_BLOCKS_PER_WORKGROUP (32) and owns the histogram table.  Result in `keys`.
  * The pairs form is stable (== std::stable_sort by key); `values` follow their keys.
  *
- * Below VRS_TUNE_ONE_CALL_MIN_KEYS elements (default 2^20) these are the four (eight) contract passes,
- * fully asynchronous.  From there on -- the library owns all passes, so the per-pass [W][256] table of the
+ * Up to VRS_TUNE_SINGLE_MAX_KEYS uint32 keys (default 4096) the whole sort is one single_radixsort launch (the
+ * reference's guidance for small inputs, README.md:18-21).  Below VRS_TUNE_ONE_CALL_MIN_KEYS elements (default 2^20)
+ * these are the four (eight) contract passes, fully asynchronous.  From there on -- the library owns all passes, so the per-pass [W][256] table of the
  * reference's interface is not needed -- the keys are read ONCE to count all four digits of a 32-bit word
  * and every pass is a stable scatter that finds its offsets by decoupled look-back (36 instead of 48 bytes
- * per 32-bit key, 136 instead of 192 per 64-bit key; DESIGN.md "K5").  That form waits on the host ONCE per
- * four passes for a 16-byte plan read-back while the first pass already runs; it never waits for the sort
- * itself, which still completes asynchronously on the context's stream.  Passes whose digit is the same for every
- * key (small keys, constant bytes) are the identity and are left out.  Same result, bit for bit.
+ * per 32-bit key, 136 instead of 192 per 64-bit key; DESIGN.md "K5").  That form enqueues everything, then waits on
+ * the host ONCE per four passes until the plan kernel has written the plan's head (a few hundred bytes) into pinned
+ * host memory -- i.e. until the counting read has run; it never waits for the sort itself, which still completes
+ * asynchronously on the context's stream.  Passes whose digit is the same for every key (small keys, constant bytes)
+ * are the identity and are left out.  Same result, bit for bit.
  */
 int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements);
 int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
@@ -247,8 +249,16 @@ typedef enum vrs_tuning_key {
     VRS_TUNE_ONE_CALL_MIN_KEYS = 4, /* vrs_sort_keys_u32 / _u64 / vrs_sort_pairs_u32 count all four digits in ONE read
                                      and scatter with decoupled look-back (36 instead of 48 bytes per key) from this many
                                      keys on; 0 = never (always the contract passes).  Default 2^20. */
-    VRS_TUNE_DEBUG_MISPLACE_STREAMS = 5 /* test hook (default 0): run every other tile of a look-back stream behind a
+    VRS_TUNE_DEBUG_MISPLACE_STREAMS = 5, /* test hook (default 0): run every other tile of a look-back stream behind a
                                      different XCD's L2, i.e. without the placement the fast hand-off relies on */
+    VRS_TUNE_LOOKBACK_SPIN_BUDGET = 6, /* polls of a predecessor's unpublished look-back row before a tile stops waiting
+                                     and counts its stream's earlier keys itself (default 4096, about 2-4 ms) */
+    VRS_TUNE_DEBUG_HOLD_TILE = 7,  /* test hook (default -1 = off): this tile of every look-back stream never publishes
+                                     its counts, so its successors must run out of spin budget and recount */
+    VRS_TUNE_DIGIT_TABLE_GROUPS = 8, /* groups per pass of the one-call sort's counting read: 8, 16 or 32 */
+    VRS_TUNE_SINGLE_MAX_KEYS = 9   /* vrs_sort_keys_u32 runs up to this many keys as ONE single_radixsort launch (one
+                                     workgroup, four passes) instead of twelve launch-bound multi-block launches;
+                                     0 = never.  Default 4096 (measured crossover, profiles/r02_small_n_crossover.csv) */
 } vrs_tuning_key;
 int vrs_set_tuning(vrs_context ctx, int key, int value);
 

@@ -51,13 +51,11 @@ def launches(ctx, kid):
 
 
 def identity_passes(keys):
-    """Passes the one-call sort may leave out: every key has the same digit there (not the first pass of a group of
-    four -- that one is enqueued before the plan is back on the host)."""
+    """Passes the one-call sort leaves out: every key has the same digit there, so the pass is the identity (the
+    plan marks it; the workgroups of the speculatively enqueued pass leave at once)."""
     nbytes = keys.dtype.itemsize
     skipped = 0
     for p in range(nbytes):
-        if p % 4 == 0:
-            continue
         d = (keys >> keys.dtype.type(8 * p)) & keys.dtype.type(255)
         skipped += int(d.min() == d.max())
     return skipped
@@ -100,8 +98,10 @@ def test_one_read_sort_equals_std_sort(gpu_context, oracle, n, dist):
         assert stats["lookback_scatter"] == 4
     if dist in ("mult256", "skewed_stream", "two_values"):
         assert stats["scatter"] >= 1  # unbalanced streams -> contract pass
-    if dist in ("const", "lowbyte"):
+    if dist == "lowbyte":
         assert stats["lookback_scatter"] == 1 and stats["scatter"] == 0  # passes 1-3 are the identity: left out
+    if dist == "const":
+        assert stats["lookback_scatter"] == 0 and stats["scatter"] == 0  # every pass is the identity
 
 
 @pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 8191, (1 << 22) - 1, 5000000, (1 << 23) + 12345])
@@ -128,9 +128,9 @@ def test_one_call_stats_count_what_happened(gpu_context):
     sort_keys(ctx, make_keys(1 << 21, "lowbyte"))  # passes 1-3 are the identity
     s2 = stats()
     assert (s2 - s1).tolist() == [1, 0, 3]
-    sort_keys(ctx, make_keys(1 << 21, "mult256"))  # pass 1's keys all sit in one group
+    sort_keys(ctx, make_keys(1 << 21, "mult256"))  # pass 0 is the identity, pass 1's keys all sit in one group
     s3 = stats()
-    assert (s3 - s2).tolist() == [3, 1, 0]
+    assert (s3 - s2).tolist() == [2, 1, 1]
 
 
 def test_threshold_selects_the_form(gpu_context):
@@ -223,6 +223,82 @@ def test_look_back_does_not_depend_on_xcd_placement(gpu_context):
     assert np.array_equal(out, np.sort(keys))
 
 
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 1000, 4095, 4096, 4097, 5000, 10000, 70000])
+def test_small_n_goes_to_the_single_workgroup_kernel(gpu_context, oracle, n):
+    """f1 of SURVEY section 8: vrs_sort_keys_u32 runs small inputs as ONE single_radixsort launch (the reference's
+    guidance, README.md:18-21) and larger ones through the multi-block passes; same result on both sides of the
+    threshold (default 4096 keys), bit-equal to std::sort and to the oracle's single_radixsort restatement."""
+    keys = make_keys(n, "uniform", seed=n)
+    out, stats = sort_keys(gpu_context, keys, min_keys=1 << 20)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    assert np.array_equal(out, oracle.single_radixsort(keys))
+    if n <= 4096:
+        assert stats.get("single", 0) == 1 and stats.get("scatter", 0) == 0
+    else:
+        assert stats.get("single", 0) == 0 and stats["scatter"] == 4
+    # the threshold is a tuning knob: 0 switches the single-launch form off
+    gpu_context.setTuning(capi.VRS_TUNE_SINGLE_MAX_KEYS, 0)
+    try:
+        out2, stats2 = sort_keys(gpu_context, keys, min_keys=1 << 20)
+    finally:
+        gpu_context.setTuning(capi.VRS_TUNE_SINGLE_MAX_KEYS, 4096)
+    assert stats2.get("single", 0) == 0 and np.array_equal(out2, out)
+
+
+@pytest.mark.parametrize("budget", [16, None])
+@pytest.mark.parametrize("dist", ["uniform", "sorted"])
+def test_look_back_never_waits_forever(gpu_context, dist, budget):
+    """Bounded spin: a tile whose predecessor never publishes its look-back row (the test hook withholds tile 3 of
+    every stream in every pass) must run out of budget, count its stream's earlier keys itself and carry on --
+    same result, no hang.  budget None = the default (a few milliseconds per pass here)."""
+    ctx = gpu_context
+    n = (1 << 22) + 77
+    keys = make_keys(n, dist, seed=13)
+    ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, 3)
+    if budget is not None:
+        ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, budget)
+    try:
+        out, stats = sort_keys(ctx, keys)
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, -1)
+        ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 4096)
+    assert stats["lookback_scatter"] == 4
+    assert np.array_equal(out, np.sort(keys))
+
+
+@pytest.mark.parametrize("groups", [8, 16, 32])
+def test_digit_table_group_counts_agree(gpu_context, groups):
+    """The counting read's group count (8 / 16 / 32 per pass) only changes how finely the streams can follow the
+    data, never the result."""
+    ctx = gpu_context
+    ctx.setTuning(capi.VRS_TUNE_DIGIT_TABLE_GROUPS, groups)
+    try:
+        for n, dist in [((1 << 21) + 5, "uniform"), (3000001, "skewed_stream"), ((1 << 20) + 1, "mult256"), (2500000, "clustered")]:
+            keys = make_keys(n, dist, seed=groups)
+            out, stats = sort_keys(ctx, keys)
+            assert stats["digit_tables"] == 1
+            assert np.array_equal(out, np.sort(keys)), (groups, n, dist)
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_DIGIT_TABLE_GROUPS, 32)
+    with pytest.raises(vrs.VrsError):
+        ctx.setTuning(capi.VRS_TUNE_DIGIT_TABLE_GROUPS, 12)
+
+
+@pytest.mark.parametrize("mode", ["keys", "pairs"])
+def test_soak_cut(mode):
+    """A 12-second cut of tools/soak_one_call.py: back-to-back large sorts of varying size and distribution on a
+    borrowed torch stream, each verified on the device (ascending + fingerprint / payload order).  The inter-workgroup
+    hand-off of the look-back is the one timing-dependent part of the path."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("soak_one_call", Path(__file__).resolve().parent.parent / "tools" / "soak_one_call.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cases, keys_sorted, bad = mod.soak(12.0, seed=5, mode=mode, max_keys=3 * 10 ** 7)
+    assert bad is None, bad
+    assert cases >= 5
+
+
 @pytest.mark.parametrize("offset_keys", [1, 2, 3])
 def test_unaligned_keys(gpu_context, offset_keys):
     """The counting read uses 16-byte loads: a wrapped pointer that is only 4-byte aligned (a sub-range of a larger
@@ -294,7 +370,7 @@ def test_one_read_sort_u64(gpu_context, n, dist):
     if dist in ("uniform", "sorted"):
         assert stats["lookback_scatter"] == 8
     if dist in ("low32", "high32"):
-        assert stats["lookback_scatter"] + stats["scatter"] == 5  # three identity passes in the constant word
+        assert stats["lookback_scatter"] + stats["scatter"] == 4  # four identity passes in the constant word
     for b in (view, big, tmp):
         b.release()
 

@@ -338,12 +338,19 @@ def test_cpp_host_examples_run_and_verify():
     _, exes = build.build_host()
     multi, single = exes
     for args in (["1000000"], ["1000", "1"], ["100003", "7", "5"], ["2000000", "32", "2", "3", "28bit"],
-                 ["3000000", "32", "1", "2", "full", "32bit", "onecall"]):  # m_oneCallSort: the library runs the passes
+                 ["3000000", "32", "1", "2", "full", "32bit", "onecall"],  # m_oneCallSort: the library runs the passes
+                 # BASELINE.json configs[3] through the C++ drop-in (m_sortPairs): payloads ride at bindings (1,3)/(1,4),
+                 # keys and payloads verified against std::stable_sort -- stage by stage and one-call
+                 ["2500003", "32", "4", "2", "28bit", "32bit", "stages", "pairs"],
+                 ["2500003", "32", "5", "1", "full", "32bit", "onecall", "pairs"],
+                 ["300000", "64", "6", "1", "28bit", "64bit", "stages", "pairs"]):
         p = subprocess.run([str(multi), *args], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stdout + p.stderr
-        assert "[MultiRadixSort] Sorting " + str(int(float(args[0]))) + " 32bit numbers." in p.stdout
+        bits = "64" if len(args) > 5 and args[5] == "64bit" else "32"
+        assert "[MultiRadixSort] Sorting " + str(int(float(args[0]))) + " " + bits + "bit numbers." in p.stdout
         assert "GPU sort finished in" in p.stdout and "CPU sort finished in" in p.stdout
         assert "[MultiRadixSort] Test passed." in p.stdout
+        assert ("Payloads follow their keys (stable)." in p.stdout) == ("pairs" in args)
     p = subprocess.run([str(single), "1000"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "[SingleRadixSort] Test passed." in p.stdout, p.stdout + p.stderr
 

@@ -1,0 +1,8 @@
+#!/bin/bash
+# lab builds of the library with extra -D flags: tools/lab/build_variant.sh NAME [-DVRS_X=..]...  -> tools/lab/libs/libvrs_NAME.so
+set -e
+cd "$(dirname "$0")/../.."
+name=$1; shift
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -Ivkradixsort_amd/csrc "$@" \
+    vkradixsort_amd/csrc/vrs_kernels.hip vkradixsort_amd/csrc/vrs_capi.hip -o tools/lab/libs/libvrs_$name.so
+echo built tools/lab/libs/libvrs_$name.so "$@"

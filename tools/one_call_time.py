@@ -51,7 +51,9 @@ def main():
             vsrc = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S, vals)
             v0, v1 = vrs.Buffer(gpu, S), vrs.Buffer(gpu, S)
         gpu.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, int(os.environ.get("VRS_MISPLACE", "0")))
-        for min_keys in (0, 1):
+        if os.environ.get("VRS_GROUPS"):
+            gpu.setTuning(capi.VRS_TUNE_DIGIT_TABLE_GROUPS, int(os.environ["VRS_GROUPS"]))
+        for min_keys in ((1,) if os.environ.get("VRS_ONLY_ONE_READ") else (0, 1)):
             gpu.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, min_keys)
             times = []
             for r in range(reps + 2):
@@ -83,7 +85,8 @@ def main():
                 v0.downloadWithStagingBuffer(vo)
                 ok = ok and bool(np.array_equal(vo, np.argsort(keys, kind="stable").astype(np.uint32)))
             t = min(times)
-            line = f"N={n} {dist} {'pairs' if pairs else 'u64 keys' if u64 else 'keys'} one_read={'on' if min_keys else 'off'} exact={ok} min={t*1e3:.3f}ms med={np.median(times)*1e3:.3f}ms {n/t/1e9:.2f} G/s"
+            tag = os.environ.get("VRS_TAG", "")
+            line = f"{tag} N={n} {dist} {'pairs' if pairs else 'u64 keys' if u64 else 'keys'} one_read={'on' if min_keys else 'off'} exact={ok} min={t*1e3:.3f}ms med={np.median(times)*1e3:.3f}ms {n/t/1e9:.2f} G/s"
             for kid, name in capi.KERNEL_NAMES.items():
                 cnt, ms = gpu.profileQuery(kid)
                 if cnt:

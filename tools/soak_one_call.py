@@ -22,6 +22,15 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     mode = sys.argv[3] if len(sys.argv) > 3 else "keys"
+    cases, keys_sorted, bad = soak(budget, seed, mode)
+    if bad:
+        print(bad)
+        sys.exit(1)
+    print(f"soak ok ({mode}): {cases} sorts, {keys_sorted / 1e9:.1f} G keys in {budget:.0f} s (seed {seed})")
+
+
+def soak(budget, seed=1, mode="keys", max_keys=10 ** 8):
+    """Sorts for `budget` seconds; returns (sorts, keys sorted, None or a description of the first mismatch)."""
     torch.manual_seed(seed)
     rs = np.random.RandomState(seed)
     dev = torch.device("cuda", 0)
@@ -33,6 +42,7 @@ def main():
         gpu.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 1 if mode == "misplaced" else 0)
         while time.time() < t_end:
             n = int(rs.choice([rs.randint(1 << 20, 1 << 23), rs.randint(1 << 23, 6 * 10 ** 7), 10 ** 8]))
+            n = min(n, max_keys)
             if mode == "misplaced":
                 n = int(rs.randint(1 << 20, 1 << 22))  # every other tile re-counts its stream's prefix: slow
             if mode in ("pairs", "u64"):
@@ -57,8 +67,7 @@ def main():
                 cases += 1
                 keys_sorted += n
                 if not ok:
-                    print(f"SOAK MISMATCH u64 n={n} seed={seed} case={cases}")
-                    sys.exit(1)
+                    return cases, keys_sorted, f"SOAK MISMATCH u64 n={n} seed={seed} case={cases}"
                 del k, tmp, u, hi, lo
                 continue
             kind = rs.randint(0, 6)
@@ -91,8 +100,7 @@ def main():
                 cases += 1
                 keys_sorted += n
                 if not ok:
-                    print(f"SOAK MISMATCH pairs n={n} kind={kind} seed={seed} case={cases}")
-                    sys.exit(1)
+                    return cases, keys_sorted, f"SOAK MISMATCH pairs n={n} kind={kind} seed={seed} case={cases}"
                 del k, tmp, v, vt, src, u, vl, same
                 continue
             torch.cuda.synchronize()
@@ -109,10 +117,9 @@ def main():
             cases += 1
             keys_sorted += n * reps
             if not ok:
-                print(f"SOAK MISMATCH n={n} kind={kind} seed={seed} case={cases}")
-                sys.exit(1)
+                return cases, keys_sorted, f"SOAK MISMATCH n={n} kind={kind} seed={seed} case={cases}"
             del k, tmp, u
-    print(f"soak ok ({mode}): {cases} sorts, {keys_sorted / 1e9:.1f} G keys in {budget:.0f} s (seed {seed})")
+    return cases, keys_sorted, None
 
 
 if __name__ == "__main__":

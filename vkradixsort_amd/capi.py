@@ -37,6 +37,10 @@ VRS_TUNE_FUSED_PREFIX = 2
 VRS_TUNE_RANK_MODE = 3
 VRS_TUNE_ONE_CALL_MIN_KEYS = 4
 VRS_TUNE_DEBUG_MISPLACE_STREAMS = 5
+VRS_TUNE_LOOKBACK_SPIN_BUDGET = 6
+VRS_TUNE_DEBUG_HOLD_TILE = 7
+VRS_TUNE_DIGIT_TABLE_GROUPS = 8
+VRS_TUNE_SINGLE_MAX_KEYS = 9
 
 
 class PushConstants(Structure):

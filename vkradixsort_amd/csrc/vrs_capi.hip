@@ -48,12 +48,17 @@ struct vrs_context_t {
     size_t events_used[VRS_KERNEL_COUNT] = {};
     // one-call sort for large N (K5 in vrs_kernels.hip)
     uint32_t one_call_min_keys = 1u << 20;
+    uint32_t single_max_keys = 4096;     // one-call uint32 key sorts up to this size run as ONE single_radixsort launch
     uint32_t *os_tables = nullptr;       // [4][kStreams][256] digit tables, zero between sorts
     vrs::OnesweepPlan *os_plan = nullptr;
     uint32_t *os_status = nullptr;       // look-back status rows
     size_t os_status_rows = 0;
-    vrs::OnesweepPlanHead *os_host_head = nullptr;  // pinned copy of the plan's head
-    hipEvent_t os_plan_ready = nullptr;
+    vrs::OnesweepPlanHead *os_host_head = nullptr;      // pinned host copy of the plan's head (the plan kernel writes it)
+    vrs::OnesweepPlanHead *os_host_head_dev = nullptr;  // the same memory as the device sees it
+    uint32_t os_stamp = 0;               // stamp of the most recent plan (never 0)
+    uint32_t os_groups = 32;             // groups per pass of the counting read (8, 16 or 32), VRS_TUNE_DIGIT_TABLE_GROUPS
+    uint32_t os_spin_budget = 4096;      // polls of an unpublished look-back row before a tile recounts, VRS_TUNE_LOOKBACK_SPIN_BUDGET
+    int os_hold_tile = -1;               // test hook, VRS_TUNE_DEBUG_HOLD_TILE
     bool os_misplace = false;            // test hook, VRS_TUNE_DEBUG_MISPLACE_STREAMS
     bool xcc_map_valid = false;          // the probe found block b on an XCC that depends on b % 8 only
     unsigned long long xcc_map = 0;      // byte x = that XCC for b % 8 == x
@@ -370,7 +375,6 @@ int vrs_context_destroy(vrs_context ctx) {
     if (ctx->os_plan) (void)hipFree(ctx->os_plan);
     if (ctx->os_status) (void)hipFree(ctx->os_status);
     if (ctx->os_host_head) (void)hipHostFree(ctx->os_host_head);
-    if (ctx->os_plan_ready) (void)hipEventDestroy(ctx->os_plan_ready);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VRS_OK;
@@ -616,40 +620,74 @@ static int contract_pass(vrs_context ctx, vrs_buffer kin, vrs_buffer kout, vrs_b
     return run_sort_stage(ctx, kin, kout, vin, vout, ctx->sort_hist, pc, vin != nullptr, key_bytes);
 }
 
+// The plan kernel writes the head of the plan straight into pinned host memory and stamps it last; wait for the stamp.
+// Spins (the plan is at most a counting read away), looking at the stream now and then so that a faulted queue
+// surfaces as an error instead of an endless wait.
+static int wait_for_plan(vrs_context ctx, uint32_t stamp) {
+    volatile uint32_t *ready = &ctx->os_host_head->ready;
+    for (uint64_t spins = 0;; ++spins) {
+        if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == stamp) return VRS_OK;
+        if ((spins & 0xFFFu) == 0xFFFu) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {  // everything enqueued has run: the stamp must be there
+                if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == stamp) return VRS_OK;
+                return fail(ctx, VRS_ERROR_HIP, "the one-call sort's plan never arrived on the host");
+            }
+            if (q != hipErrorNotReady) return fail_hip(ctx, "hipStreamQuery (waiting for the sort plan)", q);
+        }
+        __builtin_ia32_pause();
+    }
+}
+
 // Large-N form of the one-call sort (K5): ONE counting read of the keys per group of four passes, then four scatter
 // passes that find their offsets by look-back along kStreams independent streams -- 36 instead of 48 bytes per key
-// (64-bit keys: two groups, 136 instead of 192).  A pass whose streams are too unequal for the fixed grid (they
-// follow the data) runs as a contract pass instead.
+// (64-bit keys: two groups, 136 instead of 192).  All of it -- counting read, plan, four look-back passes -- is
+// enqueued before the host knows the plan; the passes read their streams from the plan in device memory.  The host
+// then waits for the plan's head (never for the sort): usually there is nothing left to do.  If the plan marks a pass
+// as the identity (one digit value holds every key) or its streams as too unequal for the grid, that pass and the
+// ones after it left at once on the device, and the host enqueues them again in the form they need.
 static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values, vrs_buffer values_tmp,
                          uint32_t n, int key_bytes) {
-    constexpr uint32_t S = vrs::kStreams, G = vrs::kGroups;
+    constexpr uint32_t S = vrs::kStreams;
+    const uint32_t G = ctx->os_groups;
     const uint32_t T = vrs::onesweep_tile_keys(key_bytes);
     const uint32_t tiles_total = (n + T - 1) / T;
     const uint32_t group_tiles = (tiles_total + G - 1) / G;  // tiles per pass-0 group (slice of the input)
-    const uint32_t group_len = group_tiles * T;              // < 2^30 / 32 + 8192
-    // pass 0's streams are made here (the pass is enqueued before the plan is back): neighbouring slices merged
-    const vrs::StreamCuts cuts0 = vrs::pass0_stream_cuts(n, group_len);
-    vrs::StreamRanges ranges0{};  // pass 0's streams
-    uint32_t tiles0 = 0;          // tiles of the longest of them
+    const uint32_t group_len = group_tiles * T;              // < 2^30 / 8 + 8192
+    // pass 0's streams are neighbouring slices merged (the plan kernel gets the same cuts)
+    const vrs::StreamCuts cuts0 = vrs::pass0_stream_cuts(n, group_len, G);
+    uint32_t tiles0 = 0;  // tiles of the longest of them
     for (uint32_t k = 0; k < S; ++k) {
         const uint64_t a = std::min<uint64_t>(static_cast<uint64_t>(cuts0.first_group[k]) * group_len, n);
         const uint64_t b = std::min<uint64_t>(static_cast<uint64_t>(cuts0.first_group[k + 1]) * group_len, n);
-        ranges0.first_group[k] = cuts0.first_group[k];
-        ranges0.start[k] = static_cast<uint32_t>(a);
-        ranges0.len[k] = static_cast<uint32_t>(b - a);
         tiles0 = std::max<uint32_t>(tiles0, static_cast<uint32_t>((b - a + T - 1) / T));
     }
     const uint32_t even = (tiles_total + S - 1) / S;        // tiles of a perfectly even stream
     const uint32_t tile_cap = std::max(tiles0, even + even / 4 + 2);  // later passes: streams up to 25 % longer
     if (!ctx->os_tables) {
-        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_tables), vrs::kDigitTableWords * sizeof(uint32_t)));
-        VRS_HIP(ctx, hipMemsetAsync(ctx->os_tables, 0, vrs::kDigitTableWords * sizeof(uint32_t), ctx->stream));
-        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_plan), sizeof(vrs::OnesweepPlan)));
-        VRS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->os_host_head), sizeof(vrs::OnesweepPlanHead)));
-        VRS_HIP(ctx, hipEventCreateWithFlags(&ctx->os_plan_ready, hipEventDisableTiming));
+        uint32_t *tables = nullptr;
+        vrs::OnesweepPlan *plan = nullptr;
+        vrs::OnesweepPlanHead *host = nullptr, *host_dev = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&tables), vrs::kDigitTableWords * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(tables, 0, vrs::kDigitTableWords * sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&plan), sizeof(vrs::OnesweepPlan));
+        if (e == hipSuccess)
+            e = hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(vrs::OnesweepPlanHead),
+                              hipHostMallocMapped | hipHostMallocCoherent);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&host_dev), host, 0);
+        if (e != hipSuccess) {  // all or nothing: a half-made set would be dereferenced by the next call
+            if (host) (void)hipHostFree(host);
+            if (plan) (void)hipFree(plan);
+            if (tables) (void)hipFree(tables);
+            return fail_hip(ctx, "one-call sort scratch allocation", e);
+        }
+        std::memset(host, 0, sizeof *host);
+        ctx->os_tables = tables;
+        ctx->os_plan = plan;
+        ctx->os_host_head = host;
+        ctx->os_host_head_dev = host_dev;
     }
-    const size_t pass_rows = static_cast<size_t>(S) * tile_cap;  // status rows of one pass
-    const size_t rows = 4 * pass_rows;
+    const size_t rows = static_cast<size_t>(S) * tile_cap;  // status rows: one region for all four passes (tagged words)
     if (rows > ctx->os_status_rows) {
         if (ctx->os_status) {
             VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -675,56 +713,63 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         }
     } guard{ctx};
     // where the data lives: buffers[0] = caller's keys / values, buffers[1] = the ping-pong partners.  A pass whose digit
-    // is the same for every key is the identity and is skipped (not the first pass of a group: it is enqueued before
-    // the plan is back), so the result may end in the partner and is copied home at the end.
+    // is the same for every key is the identity and is left out, so the result may end in the partner and is copied
+    // home at the end.
     vrs_buffer kbuf[2] = {keys, keys_tmp}, vbuf[2] = {values, values_tmp};
     uint32_t cur = 0;
+    const auto lookback_pass = [&](uint32_t i, uint32_t shift, uint32_t grid_tiles, bool forced) -> int {
+        vrs_buffer kin = kbuf[cur], kout = kbuf[cur ^ 1u];
+        vrs_buffer vin = values ? vbuf[cur] : nullptr, vout = values ? vbuf[cur ^ 1u] : nullptr;
+        cur ^= 1u;
+        int r = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev);
+        if (r) return r;
+        VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kin->ptr, kout->ptr,
+                                                  vin ? static_cast<const uint32_t *>(vin->ptr) : nullptr,
+                                                  vout ? static_cast<uint32_t *>(vout->ptr) : nullptr, ctx->os_plan, i, shift,
+                                                  ctx->os_status, grid_tiles, forced, ctx->scatter.atomic_rank, ctx->xcc_map,
+                                                  key_bytes, ctx->os_spin_budget, ctx->os_hold_tile, ev, ctx->os_misplace));
+        return VRS_OK;
+    };
     for (uint32_t group = 0; group < static_cast<uint32_t>(key_bytes) / 4u; ++group) {
         if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
+        if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
+        const uint32_t stamp = ctx->os_stamp;
         guard.armed = true;
-        VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, group_len,
-                                              ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS, ev));
-        VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, n, group_len, T, cuts0));
+        VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, group_len, G,
+                                              ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS,
+                                              ctx->scatter.compute_units, ev));
+        VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, ctx->os_host_head_dev, stamp, n, group_len, G,
+                                      T, tile_cap, cuts0));
         guard.armed = false;
-        VRS_HIP(ctx, hipMemcpyAsync(ctx->os_host_head, &ctx->os_plan->head, sizeof(vrs::OnesweepPlanHead), hipMemcpyDeviceToHost,
-                                    ctx->stream));
-        VRS_HIP(ctx, hipEventRecord(ctx->os_plan_ready, ctx->stream));
-        for (uint32_t i = 0; i < 4; ++i) {
+        // all four passes at once, before the plan is known here; pass 0's streams are the host's own cuts
+        const uint32_t cur_at_start = cur;
+        const size_t events_before = ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER];
+        for (uint32_t i = 0; i < 4; ++i)
+            if ((rc = lookback_pass(i, 32u * group + 8u * i, i == 0 ? tiles0 : tile_cap, false))) return rc;
+        if ((rc = wait_for_plan(ctx, stamp))) return rc;
+        const vrs::OnesweepPlanHead &head = *ctx->os_host_head;
+        const uint32_t q = std::min<uint32_t>(head.first_abnormal, 4u);
+        ctx->os_lookback_passes += q;
+        if (q == 4) continue;  // four look-back passes: the data is back where it started (cur unchanged)
+        // passes q..3 left at once on the device: take back their (untouched) buffers and timing events, enqueue them again
+        cur = cur_at_start ^ (q & 1u);
+        if (ctx->profile_mask & (1u << VRS_KERNEL_LOOKBACK_SCATTER))
+            ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + q;
+        for (uint32_t i = q; i < 4; ++i) {
             const uint32_t shift = 32u * group + 8u * i;
-            // pass 0's streams are slices of the input (known here); the others come back from the plan while it runs
-            uint32_t max_tiles = tiles0;
-            if (i == 1) VRS_HIP(ctx, hipEventSynchronize(ctx->os_plan_ready));
-            vrs::StreamRanges ranges = ranges0;
-            if (i > 0) {
-                const vrs::OnesweepPlanHead &head = *ctx->os_host_head;
-                max_tiles = head.max_tiles[i];
-                if (head.constant[i]) {
-                    ctx->os_skipped_passes++;
-                    continue;
-                }
-                for (uint32_t k = 0; k < S; ++k) {
-                    ranges.first_group[k] = head.first_group[i][k];
-                    ranges.start[k] = head.start[i][k];
-                    ranges.len[k] = head.len[i][k];
-                }
-            }
-            vrs_buffer kin = kbuf[cur], kout = kbuf[cur ^ 1u];
-            vrs_buffer vin = values ? vbuf[cur] : nullptr, vout = values ? vbuf[cur ^ 1u] : nullptr;
-            cur ^= 1u;
-            if (max_tiles > tile_cap) {
+            if (head.mode[i] == vrs::kPassIdentity) {
+                ctx->os_skipped_passes++;
+            } else if (head.mode[i] == vrs::kPassUnbalanced) {
+                vrs_buffer kin = kbuf[cur], kout = kbuf[cur ^ 1u];
+                vrs_buffer vin = values ? vbuf[cur] : nullptr, vout = values ? vbuf[cur ^ 1u] : nullptr;
+                cur ^= 1u;
                 ctx->os_fallback_passes++;
                 if ((rc = ensure_sort_hist(ctx, pc.g_num_workgroups))) return rc;
                 if ((rc = contract_pass(ctx, kin, kout, vin, vout, &pc, shift, key_bytes))) return rc;
-                continue;
+            } else {
+                ctx->os_lookback_passes++;
+                if ((rc = lookback_pass(i, shift, head.max_tiles[i], true))) return rc;
             }
-            if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
-            ctx->os_lookback_passes++;
-            VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kin->ptr, kout->ptr,
-                                                      vin ? static_cast<const uint32_t *>(vin->ptr) : nullptr,
-                                                      vout ? static_cast<uint32_t *>(vout->ptr) : nullptr, ctx->os_plan, i,
-                                                      shift, ranges, ctx->os_status + i * pass_rows * VRS_RADIX_SORT_BINS,
-                                                      max_tiles, ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes, ev,
-                                                      ctx->os_misplace));
         }
     }
     if (cur) {  // an odd number of passes ran
@@ -759,7 +804,16 @@ static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp
         }
     }
     VRS_HIP(ctx, hipSetDevice(ctx->device));
-    // the look-back status words carry 30-bit counts; there is no one-call pairs entry point for 64-bit keys
+    // small N: the whole sort in ONE launch of the single-workgroup kernel instead of twelve launch-bound ones (the
+    // reference's own guidance: its single_radixsort is the faster path for small inputs, README.md:18-21)
+    if (key_bytes == 4 && !values && n <= ctx->single_max_keys) {
+        vrs::LaunchEvents ev;
+        if ((rc = profile_events(ctx, VRS_KERNEL_SINGLE, &ev))) return rc;
+        VRS_HIP(ctx, vrs::launch_single(ctx->stream, static_cast<uint32_t *>(keys->ptr), static_cast<uint32_t *>(keys_tmp->ptr),
+                                        n, ev));
+        return VRS_OK;
+    }
+    // the look-back status words carry 28-bit stream counts; there is no one-call pairs entry point for 64-bit keys
     if (ctx->xcc_map_valid && ctx->one_call_min_keys != 0 && n >= ctx->one_call_min_keys && n < (1u << 30) &&
         (key_bytes == 4 || !values))
         return sort_one_read(ctx, keys, keys_tmp, values, values_tmp, n, key_bytes);
@@ -982,6 +1036,24 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             return VRS_OK;
         case VRS_TUNE_DEBUG_MISPLACE_STREAMS:
             ctx->os_misplace = value != 0;
+            return VRS_OK;
+        case VRS_TUNE_SINGLE_MAX_KEYS:
+            if (value < 0) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "single-launch threshold must be >= 0");
+            ctx->single_max_keys = static_cast<uint32_t>(value);
+            return VRS_OK;
+        case VRS_TUNE_LOOKBACK_SPIN_BUDGET:
+            if (value < 0) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "spin budget must be >= 0");
+            ctx->os_spin_budget = static_cast<uint32_t>(value);
+            return VRS_OK;
+        case VRS_TUNE_DEBUG_HOLD_TILE:
+            ctx->os_hold_tile = value;
+            return VRS_OK;
+        case VRS_TUNE_DIGIT_TABLE_GROUPS:
+            if (value != 8 && value != 16 && value != 32)
+                return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "digit table groups must be 8, 16 or 32");
+            if (static_cast<uint32_t>(value) % vrs::kStreams != 0)
+                return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "digit table groups must be a multiple of the stream count");
+            ctx->os_groups = static_cast<uint32_t>(value);
             return VRS_OK;
         default:
             return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "unknown tuning key");

@@ -61,67 +61,81 @@ hipError_t launch_atomic_rank_selftest(hipStream_t stream, uint32_t rounds, uint
 hipError_t launch_transform_keys(hipStream_t stream, uint32_t *keys, uint32_t n, int mode);
 
 // ---- one-call sort for large N (K5): one counting read, four look-back scatter passes
-// The counting read sorts every key into one of kGroups GROUPS per pass (pass 0: slice of the input, pass p > 0:
-// digit p-1 / 8); plan_kernel merges neighbouring groups into kStreams balanced STREAMS, one per XCD (fewer streams =
-// fewer open write fronts per pass: 2048 instead of 8192, which is what the next pass's write drain pays for)
+// The counting read sorts every key into one of `groups` GROUPS per pass (pass 0: slice of the input, pass p > 0:
+// digit p-1 / (256 / groups)); plan_kernel merges neighbouring groups into kStreams balanced STREAMS, one per XCD
+// (fewer streams = fewer open write fronts per pass: 2048 instead of 8192, which is what the next pass's write drain
+// pays for).  groups is 8, 16 or 32 (a tuning choice: more groups = streams that follow skewed data better, fewer =
+// a cheaper counting read).
 #ifndef VRS_STREAMS
 #define VRS_STREAMS 8
 #endif
-constexpr int kGroups = 32;
-constexpr int kStreams = VRS_STREAMS;    // a multiple of 8 that divides kGroups: stream s runs on XCD s % 8
-constexpr int kTableSlices = 8;          // digit_tables workgroups per pass-0 group
-// the part of the plan the host reads back (one small copy) before it launches passes 1-3
+constexpr int kMaxGroups = 32;
+constexpr int kStreams = VRS_STREAMS;    // a multiple of 8 that divides the group count: stream s runs on XCD s % 8
+// one stream of one pass: a contiguous range of the pass's input
+struct StreamDesc {
+    uint32_t start;        // first key of the stream in the pass's input
+    uint32_t len;
+    uint32_t first_group;  // the stream starts with this group: its seed row is group_seed[p][that]
+    uint32_t tiles;        // ceil(len / tile)
+};
+// what the plan says about one pass
+enum : uint32_t { kPassLookback = 0, kPassIdentity = 1, kPassUnbalanced = 2 };
+// The part of the plan the scatter workgroups read (scalar loads) and the host reads back.  The host enqueues all
+// four look-back passes BEFORE it knows the plan; a pass p >= first_abnormal leaves at once (its workgroups read the
+// word and exit) and the host, once the head has arrived, enqueues passes first_abnormal..3 in the form they need.
 struct OnesweepPlanHead {
-    uint32_t first_group[4][kStreams];  // stream s of pass p starts with this group: its seed row is group_seed[p][that]
-    uint32_t start[4][kStreams];        // first key of the stream in the pass's input
-    uint32_t len[4][kStreams];
-    uint32_t max_tiles[4];              // tiles of the longest stream of each pass
-    uint32_t constant[4];               // 1: every key has the same digit in this pass (the pass is the identity)
+    StreamDesc stream[4][kStreams];
+    uint32_t max_tiles[4];      // tiles of the longest stream of each pass
+    uint32_t mode[4];           // kPassLookback / kPassIdentity (one digit value holds every key) / kPassUnbalanced
+    uint32_t first_abnormal;    // smallest p with mode[p] != kPassLookback, 4 if there is none
+    uint32_t ready;             // host copy only: the sort's stamp, written after everything else
 };
 struct OnesweepPlan {
     OnesweepPlanHead head;
-    uint32_t group_seed[4][kGroups + 1][256];  // global offset of digit d at the start of group g of pass p
+    uint32_t group_seed[4][kMaxGroups + 1][256];  // global offset of digit d at the start of group g of pass p
 };
-// The streams of ONE pass, handed to the scatter kernel by value: a tile must not wait for a load from the plan before
-// it can issue the loads of its keys.
-struct StreamRanges {
-    uint32_t first_group[kStreams], start[kStreams], len[kStreams];
-};
-constexpr size_t kDigitTableWords = 4u * kGroups * 256u;
-// first group of every stream (first_group[kStreams] == kGroups)
+constexpr size_t kDigitTableWords = 4u * kMaxGroups * 256u;  // [4][groups][256], zero between sorts
+// first group of every stream (first_group[kStreams] == groups)
 struct StreamCuts {
     uint32_t first_group[kStreams + 1];
 };
 // Cut k (0 < k < kStreams) between streams k-1 and k: the group boundary closest to k * n / kStreams, where group g
-// of the pass's input is keys [start_of(g), start_of(g + 1)) and start_of(kGroups) == n.  Non-decreasing in k.  One
+// of the pass's input is keys [start_of(g), start_of(g + 1)) and start_of(groups) == n.  Non-decreasing in k.  One
 // definition for the host (pass 0) and the plan kernel (passes 1-3).
 template <typename StartOf>
-__host__ __device__ inline uint32_t balanced_cut(const StartOf &start_of, uint32_t n, uint32_t k) {
+__host__ __device__ inline uint32_t balanced_cut(const StartOf &start_of, uint32_t n, uint32_t k, uint32_t groups) {
     const uint64_t target = static_cast<uint64_t>(n) * k / kStreams;
     uint32_t g = 0;
-    while (g < static_cast<uint32_t>(kGroups) && start_of(g) < target) ++g;
+    while (g < groups && start_of(g) < target) ++g;
     if (g > 0 && target - start_of(g - 1) < start_of(g) - target) --g;  // the boundary before is closer
     return g;
 }
 // pass 0: the groups are slices of group_len keys
-StreamCuts pass0_stream_cuts(uint32_t n, uint32_t group_len);
+StreamCuts pass0_stream_cuts(uint32_t n, uint32_t group_len, uint32_t groups);
 // keys per look-back tile: 8192 uint32 or 4096 uint64 (32 KiB either way)
 uint32_t onesweep_tile_keys(int key_bytes);
-// counts the four digits at bits [base_shift, base_shift + 32) of every key; also zeroes status[0, status_words)
-// (a multiple of 4 words, 16-byte aligned): the look-back words of the four passes
-// group_len: keys per pass-0 group (whole tiles)
+// Look-back status words: ONE region of kStreams * tile_cap rows of 256 words serves all four passes of a group --
+// a word carries the pass's tag, so only the counting read zeroes it (once per group of four passes).
+// Counts the four digits at bits [base_shift, base_shift + 32) of every key into tables[4][groups][256]; also zeroes
+// status[0, status_words) (a multiple of 4 words, 16-byte aligned).  group_len: keys per pass-0 group (whole tiles).
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
-                               uint32_t group_len, uint32_t *tables, uint32_t *status, size_t status_words,
-                               LaunchEvents ev = {});
-hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t group_len,
-                       uint32_t tile, const StreamCuts &cuts0);
-// pass = 0..3 inside the group of four the plan was made for, shift = the pass's absolute bit position, ranges = the
-// pass's streams (from the plan's head, or made by the host for pass 0); status: kStreams * max_tiles rows of 256
-// words, zeroed
+                               uint32_t group_len, uint32_t groups, uint32_t *tables, uint32_t *status,
+                               size_t status_words, int compute_units, LaunchEvents ev = {});
+// host_head: device-visible address of a pinned host copy of the head (written with system-scope stores, `stamp` last)
+hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, OnesweepPlanHead *host_head,
+                       uint32_t stamp, uint32_t n, uint32_t group_len, uint32_t groups, uint32_t tile, uint32_t tile_cap,
+                       const StreamCuts &cuts0);
+// pass = 0..3 inside the group of four the plan was made for, shift = the pass's absolute bit position; the streams
+// come from plan->head (device memory).  grid_tiles: rows of workgroups to launch (>= the pass's max_tiles, which the
+// host may not know yet: tile_cap).  forced: run even if the plan marks an earlier pass abnormal (the host's second
+// enqueue).  status: kStreams * grid_tiles rows of 256 tagged words.  spin_budget: polls of an unpublished row before
+// a tile stops waiting and counts its stream's earlier keys itself; hold_tile >= 0: test hook, that tile of every
+// stream never publishes.
 hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                                    uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
-                                   const StreamRanges &ranges, uint32_t *status, uint32_t max_tiles, bool atomic_rank,
-                                   unsigned long long xcc_map, int key_bytes, LaunchEvents ev = {}, bool misplace = false);
+                                   uint32_t *status, uint32_t grid_tiles, bool forced, bool atomic_rank,
+                                   unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, int hold_tile,
+                                   LaunchEvents ev = {}, bool misplace = false);
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups
 hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks);
 

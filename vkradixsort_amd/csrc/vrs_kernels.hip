@@ -22,6 +22,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef VRS_DT_UNROLL
+#define VRS_DT_UNROLL 8  // 16-byte loads in flight per lane in the counting read
+#endif
+
 // Launch with optional timing events bound to the dispatch packet itself (hipExtLaunchKernel): unlike
 // hipEventRecord brackets this adds no barrier packets between dependent kernels.
 #define VRS_LAUNCH(kernel, grid, block, stream, ev, ...)                                                        \
@@ -36,6 +40,12 @@
 #ifndef VRS_MARK
 #define VRS_MARK(i)
 #define VRS_MARK_FLUSH()
+#endif
+#ifndef VRS_LB_STAT
+#define VRS_LB_STAT(polls, rows, trips)
+#endif
+#ifndef VRS_LB_BATCH
+#define VRS_LB_BATCH 4
 #endif
 
 namespace vrs {
@@ -480,6 +490,7 @@ struct ChunkSmem {
     uint32_t whist[WAVES][kBins];       // per-wave digit counters -> per-wave digit start positions
     uint32_t gbase[kBins];              // global offset of digit d minus its start inside the chunk
     uint32_t scan_tmp[WAVES];
+    uint32_t lb_gave_up;                // look-back only: some digit's wait ran out of budget
 };
 
 // 64-bit mask of the lanes whose 8-bit digit equals mine ("match-any"), 4 VALU per digit bit:
@@ -518,18 +529,27 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_w(uint32_t v, uint32_t 
 
 // ---------------------------------------------------------------------------------------------
 // Decoupled look-back along a STREAM of tiles (the one-call sort, see "K5" below).  One 32-bit status word per
-// (tile, digit): bits 31:30 = 0 not published / 1 the tile's own count / 2 inclusive count of the stream up to
-// and including the tile; bits 29:0 the count.  The word carries its own flag, so no fence is needed.
+// (tile, digit):  bits 31:29 = tag of the pass that wrote it (pass + 1; 0 = never written: the counting read zeroes
+// the region once per group of four passes, and a word left by an earlier pass simply reads as "not published"),
+// bit 28 = 0 the tile's own count / 1 the inclusive count of the stream up to and including the tile,
+// bits 27:0 the count (a stream is shorter than 2^28 keys: N < 2^30 and no stream is longer than 1.25 N / 8 + a tile).
+// The word carries its own flag, so no fence is needed.
 //
 // All tiles of a stream are meant to run behind ONE XCD's L2 (block b -> XCD b % 8: observed, probed at context
 // creation, not promised by HIP), so the words are published with L2-resident stores and polled with loads that
 // bypass only the CU's L1: a hand-off costs an L2 round trip instead of a trip through the fabric (measured: 181
-// vs 223 us per pass; writing every word through as well costs 30 us per pass).  Placement is speed only: every
-// workgroup compares HW_REG_XCC_ID with its stream's XCD, and one that finds itself behind another L2 ("foreign")
-// neither reads status words (it re-counts its stream's earlier tiles from the keys) nor publishes L2-resident
-// ones (it stores write-through, which the agent-scope polls of the others do see).
-constexpr uint32_t kLbAggregate = 1u << 30, kLbInclusive = 2u << 30, kLbValue = (1u << 30) - 1u;
-constexpr int kLbBatch = 4;  // status rows fetched per round trip (2-4 measure the same, 8 and 16 slower)
+// vs 223 us per pass; writing every word through as well costs 30 us per pass).  That store is a workgroup-scope
+// atomic store (global_store sc0: the line stays dirty in this XCD's L2) read by ANOTHER workgroup with an agent-scope
+// load (global_load sc1: bypasses the reader's L1, served by the same L2) -- outside what the HSA memory model
+// promises for inter-workgroup data, correct on gfx950 because the vector L1 is write-through and both workgroups sit
+// behind the one L2 that holds the line (MI355X_MICROARCH.md, "stores of each flavour").  Placement is therefore never
+// trusted: every workgroup compares HW_REG_XCC_ID with its stream's XCD, and one that finds itself behind another L2
+// ("foreign") neither reads status words (it re-counts its stream's earlier tiles from the keys) nor publishes
+// L2-resident ones (it stores write-through, sc1, which the agent-scope polls of the others do see).
+// Progress never depends on another workgroup either: a tile polls an unpublished row at most `budget` times, then
+// stops waiting and counts the digits of its stream's earlier keys itself (same result; the guide's "bound every spin").
+constexpr uint32_t kLbInclusive = 1u << 28, kLbValue = (1u << 28) - 1u, kLbTagShift = 29;
+constexpr int kLbBatch = VRS_LB_BATCH;  // status rows fetched per round trip (2-4 measure the same, 8 and 16 slower)
 
 __device__ __forceinline__ uint32_t lb_load(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load sc1: L1 bypassed, L2 served
@@ -549,51 +569,75 @@ __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(
 struct StreamLookback {
     static constexpr bool kEnabled = true;
     bool foreign = false;     // this workgroup is not behind its stream's L2 (workgroup-uniform)
+    bool hold = false;        // test hook: this tile never publishes (its successors must stop waiting)
     uint32_t recounted = 0;   // foreign only: exclusive count of my digit over the stream's earlier tiles
     uint32_t *col = nullptr;  // status word of (tile 0 of my stream, digit == my thread)
     size_t stride = 0;        // words between consecutive tiles of the stream
     int index = 0;            // this tile's position in its stream
     uint32_t seed = 0;        // global offset of my digit at the start of the stream
+    uint32_t tag = 0;         // (pass + 1) << kLbTagShift
+    uint32_t budget = 0;      // polls of an unpublished row before giving up
+    const void *stream_keys = nullptr;  // first key of the stream in the pass's input
+    uint32_t done = 0;        // keys of the stream before this tile
 
     __device__ __forceinline__ void publish(uint32_t v) const {
+        if (hold) return;
         uint32_t *p = col + static_cast<size_t>(index) * stride;
-        if (foreign) lb_store_through(p, v); else lb_store_l2(p, v);
+        if (foreign) lb_store_through(p, tag | v); else lb_store_l2(p, tag | v);
     }
     // rows first, first-1, ...: the row before the stream's first tile reads as "inclusive, 0"
     __device__ __forceinline__ void fetch(int first, uint32_t (&v)[kLbBatch]) const {
 #pragma unroll
         for (int r = 0; r < kLbBatch; ++r)
-            v[r] = first - r >= 0 ? lb_load(col + static_cast<size_t>(first - r) * stride) : kLbInclusive;
+            v[r] = first - r >= 0 ? lb_load(col + static_cast<size_t>(first - r) * stride) : (tag | kLbInclusive);
     }
     // exclusive count of my digit over the tiles before mine; v = fetch(index - 1) issued earlier.
     // Every round trip consumes all rows that are published; at the first unpublished one the REST of the batch is
-    // fetched again in one go (re-polling row by row would serialise one round trip per row).
-    __device__ __forceinline__ uint32_t resolve(uint32_t (&v)[kLbBatch]) const {
-        uint32_t acc = 0;
+    // fetched again in one go (re-polling row by row would serialise one round trip per row).  gave_up: the budget
+    // ran out on an unpublished row (the caller then counts the stream's earlier keys itself).
+    __device__ __forceinline__ uint32_t resolve(uint32_t (&v)[kLbBatch], bool &gave_up) const {
+        uint32_t acc = 0, polls = 0;
+        [[maybe_unused]] uint32_t trips = 1;
         int first = index - 1;
         for (;;) {
-            bool done = false, blocked = false;
+            bool done_ = false, blocked = false;
             int consumed = 0;
 #pragma unroll
             for (int r = 0; r < kLbBatch; ++r) {
-                if (!done && !blocked) {
+                if (!done_ && !blocked) {
                     const uint32_t x = v[r];
-                    if ((x >> 30) == 0u) {
-                        blocked = true;  // the tile is resident (dispatched before mine) and will publish
+                    if ((x >> kLbTagShift) != (tag >> kLbTagShift)) {
+                        blocked = true;  // not published in this pass (yet)
                     } else {
                         acc += x & kLbValue;
                         consumed = r + 1;
-                        done = (x >> 30) == 2u;
+                        done_ = (x & kLbInclusive) != 0u;
                     }
                 }
             }
-            if (done) return acc;
+            if (done_) {
+                VRS_LB_STAT(polls, static_cast<uint32_t>(index - first + consumed - 1), trips);
+                return acc;
+            }
             first -= consumed;
-            if (blocked) __builtin_amdgcn_s_sleep(4);
+            ++trips;
+            if (blocked) {
+                if (++polls > budget) {
+                    gave_up = true;
+                    return 0u;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
             fetch(first, v);
         }
     }
 };
+
+// cnt[0..256) += digit counts of keys[0, count) (all threads of the workgroup; barriers are the caller's)
+template <typename K, typename DG>
+__device__ __forceinline__ void recount_keys(uint32_t *cnt, const K *keys, uint32_t count, const DG &dg) {
+    for (uint32_t j = threadIdx.x; j < count; j += blockDim.x) atomicAdd(&cnt[dg(keys[j])], 1u);
+}
 
 // `run_off`: thread t (< 256) holds the running global offset of digit t, advanced by this chunk's
 // count of t.  `valid`: number of real keys in the chunk (the rest is padding that sorts last).
@@ -639,6 +683,9 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
         uint32_t *z = &sm.whist[0][0];
 #pragma unroll
         for (int v = 0; v < 4; ++v) z[v * THREADS + tid] = 0;  // WAVES*256 words / THREADS = 4 each
+        if constexpr (LB::kEnabled) {
+            if (tid == 0) sm.lb_gave_up = 0;
+        }
     }
     __syncthreads();
     VRS_MARK(1);
@@ -685,6 +732,14 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
                 total += c[v];
             }
         }
+        if constexpr (LB::kEnabled) {
+            // publish my count at once (successors can add it without waiting for my look-back) and put the first
+            // batch of predecessor rows in flight: the scan and the re-bucketing below hide their latency
+            if (tid < kBins) {
+                lb.publish(total);
+                if (!lb.foreign) lb.fetch(lb.index - 1, lb_rows);
+            }
+        }
         const uint32_t excl = block_exclusive_scan_w<WAVES>(total, sm.scan_tmp, lane, wave);
         if (tid < kBins) {
             uint32_t acc = excl;
@@ -694,10 +749,6 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
                 acc += c[v];
             }
             if constexpr (LB::kEnabled) {
-                // publish my count first (successors can add it without waiting for my look-back), then put the
-                // first batch of predecessor rows in flight: the re-bucketing below hides their latency
-                lb.publish(kLbAggregate | total);
-                if (!lb.foreign) lb.fetch(lb.index - 1, lb_rows);
                 lb_total = total;
                 lb_excl = excl;
             } else {
@@ -721,13 +772,31 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     uint32_t lb_inclusive = 0;
     if constexpr (LB::kEnabled) {
         if (tid < kBins) {
-            const uint32_t before = lb.foreign ? lb.recounted : lb.resolve(lb_rows);
+            bool gave_up = false;
+            const uint32_t before = lb.foreign ? lb.recounted : lb.resolve(lb_rows, gave_up);
+            if (gave_up) sm.lb_gave_up = 1;
             lb_inclusive = kLbInclusive | (before + lb_total);  // published below, after the LDS reads of the write-out
             sm.gbase[tid] = lb.seed + before - lb_excl;
         }
     }
     __syncthreads();
     VRS_MARK(4);
+    if constexpr (LB::kEnabled) {
+        if (sm.lb_gave_up) {  // workgroup-uniform, never in a healthy run: a predecessor did not publish in time
+            uint32_t *cnt = sm.whist[0];  // the per-wave counters are dead from here on
+            __syncthreads();
+            if (tid < kBins) cnt[tid] = 0;
+            __syncthreads();
+            recount_keys(cnt, static_cast<const K *>(lb.stream_keys), lb.done, dg);
+            __syncthreads();
+            if (tid < kBins) {
+                const uint32_t before = cnt[tid];
+                lb_inclusive = kLbInclusive | (before + lb_total);
+                sm.gbase[tid] = lb.seed + before - lb_excl;
+            }
+            __syncthreads();
+        }
+    }
 
     // ---- write out: position p of the chunk goes to gbase[digit] + p; reads batched before stores
 #pragma unroll
@@ -814,52 +883,59 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
 // pass are cut into kStreams independent STREAMS -- one per XCD -- whose starting offsets are known before the pass
 // starts.  A stream is a run of neighbouring GROUPS; a key's group is a function of the key alone:
 //   pass 0   group g = the g-th slice of the input (whole tiles of 8192 uint32 / 4096 uint64 keys);
-//   pass p>0 group g = the keys whose digit p-1 lies in [8g, 8g+8): after pass p-1 they are the contiguous range
-//            [P_{p-1}[8g], P_{p-1}[8g+8]) of its output (P = exclusive digit prefix), whatever their order inside.
-// digit_tables_kernel counts, in one read of the keys, H[p][g][d] = #keys of group g of pass p with digit p == d
-// (97 KiB of LDS counters per workgroup); plan_kernel merges the kGroups groups of each pass into kStreams streams of
-// nearly equal length and turns H into their ranges and seeds (P_p[d] + the keys with digit d in the groups before
-// the stream's first group); onesweep_scatter_kernel walks stream s in tile order on XCD s % 8 (tiles of one stream
-// are neighbours in that L2) and looks back only along its own stream.
+//   pass p>0 group g = the keys whose digit p-1 lies in [g * 256/G, (g+1) * 256/G): after pass p-1 they are the
+//            contiguous range [P_{p-1}[g * 256/G], P_{p-1}[(g+1) * 256/G]) of its output (P = exclusive digit prefix),
+//            whatever their order inside.
+// digit_tables_kernel counts, in one read of the keys, H[p][g][d] = #keys of group g of pass p with digit p == d;
+// plan_kernel merges the G groups of each pass into kStreams streams of nearly equal length and turns H into their
+// ranges and seeds (P_p[d] + the keys with digit d in the groups before the stream's first group);
+// onesweep_scatter_kernel walks stream s in tile order on XCD s % 8 (tiles of one stream are neighbours in that L2)
+// and looks back only along its own stream.
 // Streams follow the data: a pass whose streams cannot be balanced (one group holds far more than 1/kStreams of the
-// keys: keys that are all multiples of 256, say) is run through the contract path instead (the host reads max_tiles).
-constexpr int kTableThreads = 1024;
-constexpr int kTableUnroll = 4;
-constexpr int kGroupDigits = kBins / kGroups;  // digit values of pass p-1 per group of pass p
-// LDS row of one stream's 256 counters, padded by one word: keys that share the counted digit but not the stream
+// keys: keys that are all multiples of 256, say) is marked in the plan and run through the contract path instead.
+
+// LDS row of one group's 256 counters, padded by one word: keys that share the counted digit but not the group
 // (sorted input) would otherwise hit one LDS bank from every lane
 constexpr int kTableRow = kBins + 1;
-// The pass-0 table has only 256 counters, hit by every key of the workgroup: it is kept in kT0Copies copies, lane l
-// adding to copy l % kT0Copies (word d0 * kT0Copies + copy, so the 32 lanes of a half wave sit in 32 different banks
-// whatever their digits).  Four random LDS adds per key are what bounds this kernel (bank conflicts); this one is
-// conflict-free.
-constexpr int kT0Copies = 32;
-
-__device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t key) {
-    const uint32_t d0 = key & 255u, d1 = (key >> 8) & 255u, d2 = (key >> 16) & 255u, d3 = key >> 24;
-    atomicAdd(&t0[d0 * kT0Copies + (lane_id() % kT0Copies)], 1u);
-    atomicAdd(&t1[(d0 / kGroupDigits) * kTableRow + d1], 1u);
-    atomicAdd(&t2[(d1 / kGroupDigits) * kTableRow + d2], 1u);
-    atomicAdd(&t3[(d2 / kGroupDigits) * kTableRow + d3], 1u);
-}
+// The pass-0 table has only 256 counters, hit by every key of the workgroup: it is kept in COPIES copies, lane l
+// adding to copy l % COPIES (word d0 * COPIES + copy, so the lanes of a half wave spread over COPIES banks whatever
+// their digits; 32 copies = conflict-free).
+template <int GROUPS, int COPIES>
+struct TableIndex {
+    static constexpr int kShift = GROUPS == 32 ? 3 : GROUPS == 16 ? 4 : 5;  // log2(256 / GROUPS)
+    // word of pass-0 digit / of the joint (group of digit p-1, digit p) counter
+    static __device__ __forceinline__ uint32_t t0(uint32_t w, uint32_t lane) { return (w & 255u) * COPIES + (lane % COPIES); }
+    static __device__ __forceinline__ uint32_t t1(uint32_t w) { return ((w & 255u) >> kShift) * kTableRow + ((w >> 8) & 255u); }
+    static __device__ __forceinline__ uint32_t t2(uint32_t w) { return (((w >> 8) & 255u) >> kShift) * kTableRow + ((w >> 16) & 255u); }
+    static __device__ __forceinline__ uint32_t t3(uint32_t w) { return (((w >> 16) & 255u) >> kShift) * kTableRow + (w >> 24); }
+};
 
 // V counters per lane (one 16-byte vector of keys).  Same-address lanes of one LDS atomic are served one after the
 // other, so input with few distinct counters per wave (constant bytes, sorted or clustered keys) would crawl.  When
 // (nearly) every lane's keys share a counter -- the signature of such input -- the wave adds once per RUN of equal
 // counters across its lanes instead of once per key; uniform-random keys fail the vote at once and take the plain path.
+// clustered: the vote, taken by the caller on the first vector of a step (it is a speed heuristic only: both forms
+// count every key exactly once).
 template <int V>
-__device__ __forceinline__ void table_add(uint32_t *t, const uint32_t (&idx)[V], uint32_t lane) {
+__device__ __forceinline__ bool table_vote(const uint32_t (&idx)[V]) {
     bool same = true;
 #pragma unroll
     for (int j = 1; j < V; ++j) same = same && idx[j] == idx[0];
-    const uint64_t clustered = __ballot(same);
-    if (__popcll(clustered) >= 48) {  // wave-uniform
+    return __popcll(__ballot(same)) >= 48;  // wave-uniform
+}
+template <int V>
+__device__ __forceinline__ void table_add(uint32_t *t, const uint32_t (&idx)[V], uint32_t lane, bool clustered) {
+    if (clustered) {  // wave-uniform
         // run-length aggregation across the lanes: the first lane of every run of equal counters adds the whole run.
         // (Equal counters in different runs just add twice: always correct, best on sorted / clustered input.)
+        bool same = true;
+#pragma unroll
+        for (int j = 1; j < V; ++j) same = same && idx[j] == idx[0];
+        const uint64_t uniform_lanes = __ballot(same);
         const uint32_t mine = same ? idx[0] : 0xFFFFFFFFu;  // lanes that straddle two counters break the runs
         const uint32_t prev = __shfl_up(mine, 1);
         const bool head = same && (lane == 0u || prev != mine);
-        const uint64_t breaks = __ballot(head) | ~clustered;
+        const uint64_t breaks = __ballot(head) | ~uniform_lanes;
         const uint64_t after = lane == 63u ? 0ull : breaks >> (lane + 1u);
         const uint32_t run = after ? static_cast<uint32_t>(__ffsll(static_cast<long long>(after))) : 64u - lane;
         if (head) atomicAdd(&t[idx[0]], static_cast<uint32_t>(V) * run);
@@ -879,55 +955,66 @@ __device__ __forceinline__ uint32_t digit_word(uint64_t key, uint32_t base_shift
     return static_cast<uint32_t>(key >> base_shift);
 }
 
-// one 16-byte vector of keys per lane: 4 uint32 or 2 uint64
-template <typename K>
+template <typename TI>
+__device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t w) {
+    atomicAdd(&t0[TI::t0(w, lane_id())], 1u);
+    atomicAdd(&t1[TI::t1(w)], 1u);
+    atomicAdd(&t2[TI::t2(w)], 1u);
+    atomicAdd(&t3[TI::t3(w)], 1u);
+}
+
+// one 16-byte vector of keys per lane: 4 uint32 or 2 uint64.  vote: bit t = table t takes the run-length form
+template <typename K, typename TI, bool VOTE>
 __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3,
-                                                       const typename KeyVec<K>::type &q, uint32_t base_shift) {
+                                                       const typename KeyVec<K>::type &q, uint32_t base_shift,
+                                                       uint32_t lane, uint32_t &vote) {
     constexpr int V = KeyVec<K>::kKeys;
-    const uint32_t lane = lane_id();
     uint32_t i0[V], i1[V], i2[V], i3[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         const uint32_t w = digit_word(KeyVec<K>::get(q, j), base_shift);
-        const uint32_t d0 = w & 255u, d1 = (w >> 8) & 255u, d2 = (w >> 16) & 255u, d3 = w >> 24;
-        i0[j] = d0 * kT0Copies + (lane % kT0Copies);
-        i1[j] = (d0 / kGroupDigits) * kTableRow + d1;
-        i2[j] = (d1 / kGroupDigits) * kTableRow + d2;
-        i3[j] = (d2 / kGroupDigits) * kTableRow + d3;
+        i0[j] = TI::t0(w, lane);
+        i1[j] = TI::t1(w);
+        i2[j] = TI::t2(w);
+        i3[j] = TI::t3(w);
     }
-    table_add<V>(t0, i0, lane);
-    table_add<V>(t1, i1, lane);
-    table_add<V>(t2, i2, lane);
-    table_add<V>(t3, i3, lane);
+    if constexpr (VOTE)
+        vote = (table_vote<V>(i0) ? 1u : 0u) | (table_vote<V>(i1) ? 2u : 0u) | (table_vote<V>(i2) ? 4u : 0u) |
+               (table_vote<V>(i3) ? 8u : 0u);
+    table_add<V>(t0, i0, lane, (vote & 1u) != 0u);
+    table_add<V>(t1, i1, lane, (vote & 2u) != 0u);
+    table_add<V>(t2, i2, lane, (vote & 4u) != 0u);
+    table_add<V>(t3, i3, lane, (vote & 8u) != 0u);
 }
 
-// grid = kGroups * slices workgroups; workgroup (s, g) counts the g-th part of pass-0 group s and zeroes its share
-// of the look-back status words of all four passes.  stream_len (the length of a pass-0 group) is a multiple of
-// 4 * slices.  One workgroup per CU
-// (97 KiB of LDS), so the loads of step k+1 are issued before step k is counted.  64-bit keys are sorted in two groups
-// of four passes, each with its own counting read: base_shift = 0, then 32.
-template <typename K>
-__global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const K *__restrict__ keys, uint32_t n,
-                                                                     uint32_t base_shift, uint32_t stream_len,
-                                                                     uint32_t slices, uint32_t *__restrict__ tables,
-                                                                     uint4 *__restrict__ status, uint32_t status_vecs) {
+// grid = GROUPS * slices workgroups; workgroup (s, g) counts the g-th part of pass-0 group s and zeroes its share
+// of the look-back status words.  group_len (the length of a pass-0 group) is a multiple of 4 * slices.
+// The loads run one step ahead of the counting, vector by vector (a vector's register is refilled for the next step
+// as soon as it has been consumed), so UNROLL 16-byte loads per lane are in flight all the time.  64-bit keys are sorted
+// in two groups of four passes, each with its own counting read: base_shift = 0, then 32.
+template <typename K, int GROUPS, int THREADS, int COPIES, int UNROLL, int OCC>
+__global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__restrict__ keys, uint32_t n,
+                                                                    uint32_t base_shift, uint32_t group_len,
+                                                                    uint32_t slices, uint32_t *__restrict__ tables,
+                                                                    uint4 *__restrict__ status, uint32_t status_vecs) {
     using Vec = typename KeyVec<K>::type;
+    using TI = TableIndex<GROUPS, COPIES>;
     constexpr uint32_t V = KeyVec<K>::kKeys;
-    __shared__ uint32_t t0[kBins * kT0Copies];
-    __shared__ uint32_t t[3][kGroups * kTableRow];
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t c = tid; c < 3u * kGroups * kTableRow; c += kTableThreads) (&t[0][0])[c] = 0;
-    for (uint32_t c = tid; c < static_cast<uint32_t>(kBins * kT0Copies); c += kTableThreads) t0[c] = 0;
+    __shared__ uint32_t t0[kBins * COPIES];
+    __shared__ uint32_t t[3][GROUPS * kTableRow];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (uint32_t c = tid; c < 3u * GROUPS * kTableRow; c += THREADS) (&t[0][0])[c] = 0;
+    for (uint32_t c = tid; c < static_cast<uint32_t>(kBins * COPIES); c += THREADS) t0[c] = 0;
     {
         const uint4 zero = make_uint4(0, 0, 0, 0);
         const uint32_t per = (status_vecs + gridDim.x - 1) / gridDim.x;
         const uint32_t z0 = blockIdx.x * per, z1 = min(z0 + per, status_vecs);
-        for (uint32_t c = z0 + tid; c < z1; c += kTableThreads) status[c] = zero;
+        for (uint32_t c = z0 + tid; c < z1; c += THREADS) status[c] = zero;
     }
     __syncthreads();
     const uint32_t s = blockIdx.x / slices, g = blockIdx.x % slices;
-    const uint32_t part = stream_len / slices;
-    const uint64_t begin64 = static_cast<uint64_t>(s) * stream_len + static_cast<uint64_t>(g) * part;
+    const uint32_t part = group_len / slices;
+    const uint64_t begin64 = static_cast<uint64_t>(s) * group_len + static_cast<uint64_t>(g) * part;
     if (begin64 < n) {
         const uint32_t begin = static_cast<uint32_t>(begin64);
         const uint32_t len = min(part, n - begin);
@@ -935,73 +1022,79 @@ __global__ __launch_bounds__(kTableThreads) void digit_tables_kernel(const K *__
         // allocation; every slice starts a multiple of V keys after it)
         const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) / sizeof(K)) % V);
         const uint32_t head = min((V - mis) % V, len);
-        if (tid < head) digit_tables_count(t0, t[0], t[1], t[2], digit_word(keys[begin + tid], base_shift));
+        if (tid < head) digit_tables_count<TI>(t0, t[0], t[1], t[2], digit_word(keys[begin + tid], base_shift));
         const Vec *v = reinterpret_cast<const Vec *>(keys + begin + head);
         const uint32_t nvec = (len - head) / V;
-        constexpr uint32_t kStep = kTableThreads * kTableUnroll;
+        constexpr uint32_t kStep = THREADS * UNROLL;
         uint32_t i0 = 0;
-        Vec cur[kTableUnroll], nxt[kTableUnroll];
+        Vec cur[UNROLL];
         if (kStep <= nvec) {
 #pragma unroll
-            for (int r = 0; r < kTableUnroll; ++r) cur[r] = v[r * kTableThreads + tid];
+            for (int r = 0; r < UNROLL; ++r) cur[r] = v[r * THREADS + tid];
         }
         for (; i0 + kStep <= nvec; i0 += kStep) {
             const bool more = i0 + 2u * kStep <= nvec;  // workgroup-uniform
-            if (more) {
+            uint32_t vote = 0;
 #pragma unroll
-                for (int r = 0; r < kTableUnroll; ++r) nxt[r] = v[i0 + kStep + r * kTableThreads + tid];
-            }
-#pragma unroll
-            for (int r = 0; r < kTableUnroll; ++r) digit_tables_count_vec<K>(t0, t[0], t[1], t[2], cur[r], base_shift);
-            if (more) {
-#pragma unroll
-                for (int r = 0; r < kTableUnroll; ++r) cur[r] = nxt[r];
+            for (int r = 0; r < UNROLL; ++r) {
+                const Vec x = cur[r];
+                if (more) cur[r] = v[i0 + kStep + r * THREADS + tid];
+                if (r == 0)
+                    digit_tables_count_vec<K, TI, true>(t0, t[0], t[1], t[2], x, base_shift, lane, vote);
+                else
+                    digit_tables_count_vec<K, TI, false>(t0, t[0], t[1], t[2], x, base_shift, lane, vote);
             }
         }
-        for (uint32_t i = i0 + tid; i < nvec; i += kTableThreads) {
+        for (uint32_t i = i0 + tid; i < nvec; i += THREADS) {
             const Vec q = v[i];
 #pragma unroll
             for (int j = 0; j < static_cast<int>(V); ++j)
-                digit_tables_count(t0, t[0], t[1], t[2], digit_word(KeyVec<K>::get(q, j), base_shift));
+                digit_tables_count<TI>(t0, t[0], t[1], t[2], digit_word(KeyVec<K>::get(q, j), base_shift));
         }
         const uint32_t tail = head + nvec * V + tid;  // at most V - 1 keys
-        if (tail < len) digit_tables_count(t0, t[0], t[1], t[2], digit_word(keys[begin + tail], base_shift));
+        if (tail < len) digit_tables_count<TI>(t0, t[0], t[1], t[2], digit_word(keys[begin + tail], base_shift));
     }
     __syncthreads();
-    if (tid < kBins) {
+    for (uint32_t d = tid; d < static_cast<uint32_t>(kBins); d += THREADS) {
         uint32_t sum = 0;
 #pragma unroll
-        for (int r = 0; r < kT0Copies; ++r) sum += t0[tid * kT0Copies + ((r + tid) % kT0Copies)];  // skewed: no bank conflicts
+        for (int r = 0; r < COPIES; ++r) sum += t0[d * COPIES + ((r + d) % COPIES)];  // skewed: no bank conflicts
         if (sum)
-            __hip_atomic_fetch_add(&tables[static_cast<size_t>(s) * kBins + tid], sum, __ATOMIC_RELAXED,
+            __hip_atomic_fetch_add(&tables[static_cast<size_t>(s) * kBins + d], sum, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
     }
-    for (uint32_t c = tid; c < 3u * kGroups * kBins; c += kTableThreads) {  // c = (pass - 1, group, digit)
+    for (uint32_t c = tid; c < 3u * GROUPS * kBins; c += THREADS) {  // c = (pass - 1, group, digit)
         const uint32_t x = (&t[0][0])[(c >> 8) * kTableRow + (c & 255u)];
-        if (x) __hip_atomic_fetch_add(&tables[kGroups * kBins + c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x) __hip_atomic_fetch_add(&tables[GROUPS * kBins + c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// one workgroup; thread (p, d).  Merges the kGroups groups of every pass into kStreams streams of (nearly) equal
+// one workgroup; thread (p, d).  Merges the GROUPS groups of every pass into kStreams streams of (nearly) equal
 // length -- cuts only between groups, so a stream is still a contiguous range of the pass's input and its seed is a
-// prefix over whole groups -- and leaves `tables` zeroed for the next sort.
+// prefix over whole groups -- and leaves `tables` zeroed for the next sort.  The head goes to device memory (the
+// scatter workgroups read their stream from it) and, with system-scope stores, to the pinned host copy (stamp last).
+template <int GROUPS>
 __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ tables, OnesweepPlan *__restrict__ plan,
-                                                        uint32_t n, uint32_t group_len, uint32_t tile, StreamCuts cuts0) {
+                                                        OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n,
+                                                        uint32_t group_len, uint32_t tile, uint32_t tile_cap,
+                                                        StreamCuts cuts0) {
+    constexpr uint32_t kGroupDigits = kBins / GROUPS;  // digit values of pass p-1 per group of pass p
     __shared__ uint32_t s_prefix[4][kBins + 1];
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max[4], s_const[4];
     __shared__ uint32_t s_cut[4][kStreams + 1];  // first group of every stream
+    __shared__ OnesweepPlanHead s_head;
     const uint32_t tid = threadIdx.x, p = tid >> 8, d = tid & 255u, lane = tid & 63u, wave = tid >> 6;
-    uint32_t before[kGroups];
+    uint32_t before[GROUPS];
     uint32_t total = 0;
 #pragma unroll
-    for (int g = 0; g < kGroups; ++g) before[g] = tables[(static_cast<size_t>(p) * kGroups + g) * kBins + d];
+    for (int g = 0; g < GROUPS; ++g) before[g] = tables[(static_cast<size_t>(p) * GROUPS + g) * kBins + d];
 #pragma unroll
-    for (int g = 0; g < kGroups; ++g) {
+    for (int g = 0; g < GROUPS; ++g) {
         const uint32_t c = before[g];
         before[g] = total;
         total += c;
-        tables[(static_cast<size_t>(p) * kGroups + g) * kBins + d] = 0;
+        tables[(static_cast<size_t>(p) * GROUPS + g) * kBins + d] = 0;
     }
     uint32_t incl = total;
 #pragma unroll
@@ -1028,73 +1121,100 @@ __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ 
             const uint64_t a = static_cast<uint64_t>(g) * group_len;
             return static_cast<uint32_t>(a < n ? a : n);
         }
-        return s_prefix[q - 1][g * kGroupDigits];  // g == kGroups -> n
+        return s_prefix[q - 1][g * kGroupDigits];  // g == GROUPS -> n
     };
     if (tid < 4u * kStreams) {  // thread (q, k): the cut between streams k-1 and k of pass q
         const uint32_t q = tid / kStreams, k = tid % kStreams;
         uint32_t cut = 0;
-        if (q == 0)  // slices of the input: the host made these cuts (it launches pass 0 before this plan is back)
+        if (q == 0)  // slices of the input: the host made these cuts (it sizes pass 0's grid from them)
             cut = cuts0.first_group[k];
         else if (k > 0)
-            cut = balanced_cut([&](uint32_t g) { return s_prefix[q - 1][g * kGroupDigits]; }, n, k);  // [kGroups] -> n
+            cut = balanced_cut([&](uint32_t g) { return s_prefix[q - 1][g * kGroupDigits]; }, n, k, GROUPS);  // [GROUPS] -> n
         s_cut[q][k] = cut;
-        if (k == 0) s_cut[q][kStreams] = kGroups;
+        if (k == 0) s_cut[q][kStreams] = GROUPS;
     }
     // where digit d of every group starts in the pass's output; a stream's seed is the row of its first group
 #pragma unroll
-    for (int g = 0; g < kGroups; ++g) plan->group_seed[p][g][d] = digit_start + before[g];
-    plan->group_seed[p][kGroups][d] = digit_start + total;
+    for (int g = 0; g < GROUPS; ++g) plan->group_seed[p][g][d] = digit_start + before[g];
+    plan->group_seed[p][GROUPS][d] = digit_start + total;
     __syncthreads();
     if (tid < 4u * kStreams) {
         const uint32_t q = tid / kStreams, s = tid % kStreams;
         const uint32_t start = group_start(q, s_cut[q][s]), end = group_start(q, s_cut[q][s + 1]);
-        plan->head.first_group[q][s] = s_cut[q][s];
-        plan->head.start[q][s] = start;
-        plan->head.len[q][s] = end - start;
-        atomicMax(&s_max[q], (end - start + tile - 1u) / tile);
+        const uint32_t tiles = (end - start + tile - 1u) / tile;
+        s_head.stream[q][s] = StreamDesc{start, end - start, s_cut[q][s], tiles};
+        atomicMax(&s_max[q], tiles);
     }
     __syncthreads();
-    if (tid < 4) {
-        plan->head.max_tiles[tid] = s_max[tid];
-        plan->head.constant[tid] = s_const[tid];
+    if (tid == 0) {
+        uint32_t first = 4;
+        for (int q = 3; q >= 0; --q) {
+            const uint32_t mode = s_const[q] ? kPassIdentity : (s_max[q] > tile_cap ? kPassUnbalanced : kPassLookback);
+            s_head.max_tiles[q] = s_max[q];
+            s_head.mode[q] = mode;
+            if (mode != kPassLookback) first = static_cast<uint32_t>(q);
+        }
+        s_head.first_abnormal = first;
+        s_head.ready = 0;
+    }
+    __syncthreads();
+    constexpr uint32_t kHeadWords = sizeof(OnesweepPlanHead) / sizeof(uint32_t);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&s_head);
+    for (uint32_t i = tid; i < kHeadWords - 1u; i += 4 * kBins) {  // every word but `ready` (the last one)
+        reinterpret_cast<uint32_t *>(&plan->head)[i] = src[i];
+        if (host_head)
+            __hip_atomic_store(reinterpret_cast<uint32_t *>(host_head) + i, src[i], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (host_head) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-// grid = kStreams * T workgroups (T = tiles of the longest stream); block b -> XCD b % 8 -> stream b%8 + 8*((b/8) % (kStreams/8)),
+// grid = kStreams * grid_tiles workgroups; block b -> XCD b % 8 -> stream b%8 + 8*((b/8) % (kStreams/8)),
 // tile (b/8) / (kStreams/8): every tile's predecessors in its stream sit in lower-numbered blocks of the same XCD.
+// The stream's range comes from the plan in device memory (three scalar loads): the host launches the pass before it
+// has seen the plan, with room for the longest stream the plan may accept (tile_cap tiles); surplus workgroups leave.
 template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, int OCC>
 __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const K *__restrict__ keys_in,
                                                                        K *__restrict__ keys_out,
                                                                        const uint32_t *__restrict__ values_in,
                                                                        uint32_t *__restrict__ values_out,
-                                                                       const uint32_t *__restrict__ group_seed,
-                                                                       StreamRanges ranges, uint32_t shift,
+                                                                       const OnesweepPlan *__restrict__ plan,
+                                                                       uint32_t pass, int forced, uint32_t shift,
                                                                        uint32_t *__restrict__ status,
-                                                                       unsigned long long xcc_map, int misplace) {
+                                                                       unsigned long long xcc_map, int misplace,
+                                                                       uint32_t spin_budget, int hold_tile) {
     constexpr uint32_t kTile = ITEMS * WAVES * 64;  // the tile the plan counted with (onesweep_tile_keys)
     __shared__ ChunkSmem<K, ITEMS, WAVES, PAIRS> sm;
     const uint32_t k = blockIdx.x >> 3, i = k / (kStreams / 8);
     // misplace (test hook): odd tiles of every stream run on the neighbouring XCD, so the look-back has to work
     // through the write-through copies instead of one L2
     const uint32_t s = ((blockIdx.x + (misplace ? (i & 1u) : 0u)) & 7u) + 8u * (k % (kStreams / 8));
-    // start and length come with the launch (kernel arguments), not from memory: nothing delays the key loads
-    const uint32_t len = ranges.len[s];
-    if (static_cast<uint64_t>(i) * kTile >= len) return;  // uniform per workgroup
+    // the host enqueued this pass before it knew the plan: a pass at or after the first one that needs another form
+    // (identity, unbalanced streams) leaves at once and the host enqueues it again, `forced`, in the right order
+    if (!forced && plan->head.first_abnormal <= pass) return;
+    const StreamDesc sd = plan->head.stream[pass][s];
+    if (i >= sd.tiles) return;  // uniform per workgroup
     const uint32_t done = i * kTile;
-    const uint32_t begin = ranges.start[s] + done;
-    const uint32_t valid = min(kTile, len - done);
+    const uint32_t begin = sd.start + done;
+    const uint32_t valid = min(kTile, sd.len - done);
     RadixDigit<K> dg;
     dg.shift = shift;
     StreamLookback lb;
     // byte x of xcc_map = XCC of the blocks with blockIdx % 8 == x (probed); my stream's tiles sit in blocks = s (mod 8)
     lb.foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * (s & 7u))) & 0xFFu);
+    lb.hold = hold_tile >= 0 && i == static_cast<uint32_t>(hold_tile);
+    lb.stream_keys = keys_in + sd.start;
+    lb.done = done;
     if (lb.foreign) {
         // the earlier tiles of the stream are all full: count their digits from the keys themselves
         uint32_t *cnt = sm.whist[0];
         if (threadIdx.x < kBins) cnt[threadIdx.x] = 0;
         __syncthreads();
-        const K *k0 = keys_in + ranges.start[s];
-        for (uint32_t j = threadIdx.x; j < done; j += WAVES * 64) atomicAdd(&cnt[dg(k0[j])], 1u);
+        recount_keys(cnt, keys_in + sd.start, done, dg);
         __syncthreads();
         if (threadIdx.x < kBins) lb.recounted = cnt[threadIdx.x];
         __syncthreads();
@@ -1102,7 +1222,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     lb.col = status + static_cast<size_t>(s) * kBins + (threadIdx.x & 255u);
     lb.stride = static_cast<size_t>(kStreams) * kBins;
     lb.index = static_cast<int>(i);
-    lb.seed = threadIdx.x < kBins ? group_seed[static_cast<size_t>(ranges.first_group[s]) * kBins + threadIdx.x] : 0u;
+    lb.tag = (pass + 1u) << kLbTagShift;
+    lb.budget = spin_budget;
+    lb.seed = threadIdx.x < kBins ? plan->group_seed[pass][sd.first_group][threadIdx.x] : 0u;
     uint32_t unused = 0;
     const uint32_t *vin = PAIRS ? values_in + begin : nullptr;
     if (valid == kTile)
@@ -1110,6 +1232,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     else
         scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused,
                                                           lb);
+    VRS_MARK_FLUSH();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1387,49 +1510,88 @@ hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks) 
 
 uint32_t onesweep_tile_keys(int key_bytes) { return key_bytes == 8 ? 4096u : 8192u; }
 
+// largest power of two <= x (x >= 1)
+static uint32_t floor_pow2(uint32_t x) {
+    uint32_t p = 1;
+    while (p * 2u <= x) p *= 2u;
+    return p;
+}
+
+template <typename K, int GROUPS, int THREADS, int COPIES, int UNROLL, int OCC>
+static void launch_digit_tables_variant(hipStream_t stream, const void *keys, uint32_t n, uint32_t base_shift,
+                                        uint32_t group_len, uint32_t *tables, uint32_t *status, size_t status_words,
+                                        int compute_units, LaunchEvents ev) {
+    // one workgroup per (pass-0 group, slice): a power-of-two number of slices that fills the chip once
+    const uint32_t wgs = static_cast<uint32_t>(compute_units) * (OCC * 256 / THREADS);
+    const uint32_t slices = floor_pow2(wgs / GROUPS > 0 ? wgs / GROUPS : 1u);
+    const dim3 grid(GROUPS * slices), block(THREADS);
+    const uint32_t vecs = static_cast<uint32_t>(status_words / 4);
+    VRS_LAUNCH((digit_tables_kernel<K, GROUPS, THREADS, COPIES, UNROLL, OCC>), grid, block, stream, ev,
+               static_cast<const K *>(keys), n, base_shift, group_len, slices, tables, reinterpret_cast<uint4 *>(status), vecs);
+}
+
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
-                               uint32_t stream_len, uint32_t *tables, uint32_t *status, size_t status_words, LaunchEvents ev) {
-    const dim3 grid(kGroups * kTableSlices), block(kTableThreads);
-    const uint32_t slices = kTableSlices, vecs = static_cast<uint32_t>(status_words / 4);
-    if (key_bytes == 8)
-        VRS_LAUNCH(digit_tables_kernel<uint64_t>, grid, block, stream, ev, static_cast<const uint64_t *>(keys), n, base_shift,
-                   stream_len, slices, tables, reinterpret_cast<uint4 *>(status), vecs);
-    else
-        VRS_LAUNCH(digit_tables_kernel<uint32_t>, grid, block, stream, ev, static_cast<const uint32_t *>(keys), n, base_shift,
-                   stream_len, slices, tables, reinterpret_cast<uint4 *>(status), vecs);
+                               uint32_t group_len, uint32_t groups, uint32_t *tables, uint32_t *status,
+                               size_t status_words, int compute_units, LaunchEvents ev) {
+#define VRS_DT(K, G, T, C, U, O) \
+    launch_digit_tables_variant<K, G, T, C, U, O>(stream, keys, n, base_shift, group_len, tables, status, status_words, compute_units, ev)
+    // (THREADS, COPIES, UNROLL, OCC): 32 groups fill a CU's LDS with one 1024-thread workgroup (131 KiB); 8 groups
+    // leave room for two 512-thread workgroups (57 KiB each)
+    if (key_bytes == 8) {
+        if (groups == 32) VRS_DT(uint64_t, 32, 1024, 32, VRS_DT_UNROLL, 4);
+        else if (groups == 16) VRS_DT(uint64_t, 16, 1024, 32, VRS_DT_UNROLL, 4);
+        else if (groups == 8) VRS_DT(uint64_t, 8, 512, 32, VRS_DT_UNROLL, 4);
+        else return hipErrorInvalidValue;
+    } else {
+        if (groups == 32) VRS_DT(uint32_t, 32, 1024, 32, VRS_DT_UNROLL, 4);
+        else if (groups == 16) VRS_DT(uint32_t, 16, 1024, 32, VRS_DT_UNROLL, 4);
+        else if (groups == 8) VRS_DT(uint32_t, 8, 512, 32, VRS_DT_UNROLL, 4);
+        else return hipErrorInvalidValue;
+    }
+#undef VRS_DT
     return hipGetLastError();
 }
 
-StreamCuts pass0_stream_cuts(uint32_t n, uint32_t group_len) {
+StreamCuts pass0_stream_cuts(uint32_t n, uint32_t group_len, uint32_t groups) {
     const auto start_of = [&](uint32_t g) -> uint32_t {
         const uint64_t a = static_cast<uint64_t>(g) * group_len;
         return static_cast<uint32_t>(a < n ? a : n);
     };
     StreamCuts c;
     c.first_group[0] = 0;
-    for (uint32_t k = 1; k < static_cast<uint32_t>(kStreams); ++k) c.first_group[k] = balanced_cut(start_of, n, k);
-    c.first_group[kStreams] = kGroups;
+    for (uint32_t k = 1; k < static_cast<uint32_t>(kStreams); ++k) c.first_group[k] = balanced_cut(start_of, n, k, groups);
+    c.first_group[kStreams] = groups;
     return c;
 }
 
-hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, uint32_t n, uint32_t group_len,
-                       uint32_t tile, const StreamCuts &cuts0) {
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(4 * kBins), 0, stream, tables, plan, n, group_len, tile, cuts0);
+hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, OnesweepPlanHead *host_head,
+                       uint32_t stamp, uint32_t n, uint32_t group_len, uint32_t groups, uint32_t tile, uint32_t tile_cap,
+                       const StreamCuts &cuts0) {
+    const dim3 grid(1), block(4 * kBins);
+    if (groups == 32)
+        hipLaunchKernelGGL(plan_kernel<32>, grid, block, 0, stream, tables, plan, host_head, stamp, n, group_len, tile, tile_cap, cuts0);
+    else if (groups == 16)
+        hipLaunchKernelGGL(plan_kernel<16>, grid, block, 0, stream, tables, plan, host_head, stamp, n, group_len, tile, tile_cap, cuts0);
+    else if (groups == 8)
+        hipLaunchKernelGGL(plan_kernel<8>, grid, block, 0, stream, tables, plan, host_head, stamp, n, group_len, tile, tile_cap, cuts0);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                                    uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
-                                   const StreamRanges &ranges, uint32_t *status, uint32_t max_tiles, bool atomic_rank,
-                                   unsigned long long xcc_map, int key_bytes, LaunchEvents ev, bool misplace) {
-    const int mis = misplace ? 1 : 0;
-    const uint32_t *group_seed = &plan->group_seed[pass][0][0];  // address arithmetic on the device pointer only
-    const dim3 grid(kStreams * max_tiles), block(512);
+                                   uint32_t *status, uint32_t grid_tiles, bool forced, bool atomic_rank,
+                                   unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, int hold_tile,
+                                   LaunchEvents ev, bool misplace) {
+    const int mis = misplace ? 1 : 0, force = forced ? 1 : 0;
+    if (grid_tiles == 0) return hipSuccess;
+    const dim3 grid(kStreams * grid_tiles), block(512);
     const bool pairs = values_in != nullptr;
 #define VRS_ONESWEEP(K, ITEMS, PAIRS, RANK)                                                                           \
     VRS_LAUNCH((onesweep_scatter_kernel<K, ITEMS, 8, PAIRS, RANK, 4>), grid, block, stream, ev,                       \
-               static_cast<const K *>(keys_in), static_cast<K *>(keys_out), values_in, values_out, group_seed, ranges, \
-               shift, status, xcc_map, mis)
+               static_cast<const K *>(keys_in), static_cast<K *>(keys_out), values_in, values_out, plan, pass, force,  \
+               shift, status, xcc_map, mis, spin_budget, hold_tile)
     if (key_bytes == 8) {
         if (pairs) return hipErrorInvalidValue;  // no one-call pairs entry point for 64-bit keys
         if (atomic_rank) VRS_ONESWEEP(uint64_t, 8, false, RANK_ATOMIC); else VRS_ONESWEEP(uint64_t, 8, false, RANK_BALLOT);

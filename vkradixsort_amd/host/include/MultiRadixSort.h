@@ -34,6 +34,12 @@ public:
     // 48 bytes per key.  Same buffers, same result in buffer 0.
     bool m_oneCallSort = false;
 
+    // Build extension (BASELINE.json configs[3]): every key carries a uint32 payload (its input index).  execute()
+    // binds the payload ping-pong pair at (RADIX_SORT, 3) / (RADIX_SORT, 4) beside the keys' (RADIX_SORT, 0) / (1),
+    // runs the same passes (MultiRadixSortPass::m_sortPairs) and verifies keys AND payloads against
+    // std::stable_sort by key -- the sort is stable, so the payloads are the stable permutation.
+    bool m_sortPairs = false;
+
     // results of the last execute() for programmatic callers / the sweep harness
     [[nodiscard]] double gpuSortTimeMs() const { return m_gpuSortTime; }
     [[nodiscard]] double cpuSortTimeMs() const { return m_cpuSortTime; }
@@ -42,6 +48,8 @@ public:
     static void generateRandomNumbers(std::vector<SORT_TYPE> &buffer, uint32_t numElements, uint32_t seed,
                                       bool reference28BitKeys);
     static double sort(std::vector<SORT_TYPE> &buffer);
+    // CPU reference of the pairs extension: std::stable_sort by key; values follow their keys
+    static double sortPairs(std::vector<SORT_TYPE> &keys, std::vector<uint32_t> &values);
     static bool testSort(std::vector<SORT_TYPE> &reference, std::vector<SORT_TYPE> &outBuffer,
                          const char *printPrefix = PRINT_PREFIX);
 
@@ -58,7 +66,9 @@ private:
     const uint32_t m_timedRepetitions;
 
     std::vector<std::shared_ptr<Buffer>> m_buffers = std::vector<std::shared_ptr<Buffer>>(3);
+    std::vector<std::shared_ptr<Buffer>> m_valueBuffers = std::vector<std::shared_ptr<Buffer>>(2);  // pairs only
     std::vector<SORT_TYPE> m_elementsIn;
+    std::vector<uint32_t> m_valuesIn;  // pairs only: 0, 1, ..., N-1
     double m_gpuSortTime = 0.0, m_cpuSortTime = 0.0;
 
     void prepareBuffers();

@@ -4,6 +4,7 @@
 #include <cassert>
 #include <chrono>
 #include <iostream>
+#include <numeric>
 #include <random>
 #include <stdexcept>
 
@@ -62,19 +63,36 @@ void BasicMultiRadixSort<T>::execute(GPUContext *gpuContext) {
     m_pass->setStorageBuffer(odd, R, 1, m_buffers[0].get());   // ... and write buffer0
     m_pass->setStorageBuffer(H, 1, m_buffers[2].get());
     m_pass->setStorageBuffer(R, 2, m_buffers[2].get());
+    if (m_sortPairs) {  // payloads ping-pong with their keys
+        m_pass->m_sortPairs = true;
+        m_pass->setStorageBuffer(even, R, 3, m_valueBuffers[0].get());
+        m_pass->setStorageBuffer(even, R, 4, m_valueBuffers[1].get());
+        m_pass->setStorageBuffer(odd, R, 3, m_valueBuffers[1].get());
+        m_pass->setStorageBuffer(odd, R, 4, m_valueBuffers[0].get());
+    }
 
     // timed region, as in the reference: first pass enqueue -> queue idle; data already resident
-    std::shared_ptr<Buffer> pristine;
-    if (m_timedRepetitions > 1)
+    std::shared_ptr<Buffer> pristine, pristineValues;
+    if (m_timedRepetitions > 1) {
         pristine = Buffer::fillDeviceWithStagingBuffer(m_gpuContext, {.m_sizeBytes = NUM_ELEMENTS_BYTES}, m_elementsIn.data());
+        if (m_sortPairs)
+            pristineValues = Buffer::fillDeviceWithStagingBuffer(
+                m_gpuContext, {.m_sizeBytes = static_cast<size_t>(NUM_ELEMENTS) * sizeof(uint32_t)}, m_valuesIn.data());
+    }
     double best = 0.0;
     for (uint32_t rep = 0; rep < m_timedRepetitions; rep++) {
         if (rep > 0) {
             m_buffers[0]->copyFrom(*pristine);
+            if (m_sortPairs) m_valueBuffers[0]->copyFrom(*pristineValues);
             m_gpuContext->waitIdle();
         }
         const auto begin = std::chrono::steady_clock::now();
-        if (m_oneCallSort) {
+        if (m_oneCallSort && m_sortPairs) {
+            const auto sortPairsFn = sizeof(T) == 8 ? vrs_sort_pairs_u64 : vrs_sort_pairs_u32;
+            m_gpuContext->check(sortPairsFn(m_gpuContext->handle(), m_buffers[0]->getBuffer(), m_buffers[1]->getBuffer(),
+                                            m_valueBuffers[0]->getBuffer(), m_valueBuffers[1]->getBuffer(), NUM_ELEMENTS),
+                                "Failed to enqueue the one-call sort");
+        } else if (m_oneCallSort) {
             const auto sortKeys = sizeof(T) == 8 ? vrs_sort_keys_u64 : vrs_sort_keys_u32;
             m_gpuContext->check(sortKeys(m_gpuContext->handle(), m_buffers[0]->getBuffer(), m_buffers[1]->getBuffer(), NUM_ELEMENTS),
                                 "Failed to enqueue the one-call sort");
@@ -94,7 +112,7 @@ void BasicMultiRadixSort<T>::execute(GPUContext *gpuContext) {
     m_gpuSortTime = best;
     std::cout << PRINT_PREFIX << "GPU sort finished in " << m_gpuSortTime << "[ms]." << std::endl;
 
-    m_cpuSortTime = sort(m_elementsIn);
+    m_cpuSortTime = m_sortPairs ? sortPairs(m_elementsIn, m_valuesIn) : sort(m_elementsIn);
     std::cout << PRINT_PREFIX << "CPU sort finished in " << m_cpuSortTime << "[ms]." << std::endl;
 
     verify(m_elementsIn);
@@ -115,6 +133,15 @@ void BasicMultiRadixSort<T>::prepareBuffers() {
                                   RADIX_SORT_BINS * sizeof(uint32_t);
     m_buffers[2] = std::make_shared<Buffer>(
         m_gpuContext, Buffer::BufferSettings{.m_sizeBytes = histogramBytes, .m_name = "radixSort.histogramsBuffer"});
+    if (m_sortPairs) {
+        m_valuesIn.resize(NUM_ELEMENTS);
+        std::iota(m_valuesIn.begin(), m_valuesIn.end(), 0u);
+        const size_t valueBytes = static_cast<size_t>(NUM_ELEMENTS) * sizeof(uint32_t);
+        m_valueBuffers[0] = Buffer::fillDeviceWithStagingBuffer(
+            m_gpuContext, {.m_sizeBytes = valueBytes, .m_name = "radixSort.valueBuffer0"}, m_valuesIn.data());
+        m_valueBuffers[1] = std::make_shared<Buffer>(
+            m_gpuContext, Buffer::BufferSettings{.m_sizeBytes = valueBytes, .m_name = "radixSort.valueBuffer1"});
+    }
 }
 
 template <typename T>
@@ -122,12 +149,29 @@ void BasicMultiRadixSort<T>::verify(std::vector<T> &reference) {
     std::vector<T> data(NUM_ELEMENTS);
     m_buffers[0]->downloadWithStagingBuffer(data.data());  // an even number of passes: the result is back in buffer0
     testSort(reference, data);
+    if (m_sortPairs) {  // payloads: element for element equal to std::stable_sort's
+        std::vector<uint32_t> values(NUM_ELEMENTS);
+        m_valueBuffers[0]->downloadWithStagingBuffer(values.data());
+        const auto mismatch = std::mismatch(m_valuesIn.begin(), m_valuesIn.end(), values.begin());
+        if (mismatch.first != m_valuesIn.end()) {
+            const auto i = mismatch.first - m_valuesIn.begin();
+            std::cerr << PRINT_PREFIX << *mismatch.first << " = referenceValues[" << i << "] != outValues[" << i
+                      << "] = " << *mismatch.second << std::endl;
+            throw std::runtime_error("TEST FAILED.");
+        }
+        std::cout << PRINT_PREFIX << "Payloads follow their keys (stable)." << std::endl;
+    }
 }
 
 template <typename T>
 void BasicMultiRadixSort<T>::releaseBuffers() {
     for (const auto &buffer : m_buffers)
         if (buffer) buffer->release();
+    for (auto &buffer : m_valueBuffers)
+        if (buffer) {
+            buffer->release();
+            buffer.reset();
+        }
 }
 
 template <typename T>
@@ -152,6 +196,23 @@ template <typename T>
 double BasicMultiRadixSort<T>::sort(std::vector<T> &buffer) {
     const auto begin = std::chrono::steady_clock::now();
     std::sort(buffer.begin(), buffer.end());
+    return elapsedMs(begin, std::chrono::steady_clock::now());
+}
+
+template <typename T>
+double BasicMultiRadixSort<T>::sortPairs(std::vector<T> &keys, std::vector<uint32_t> &values) {
+    const auto begin = std::chrono::steady_clock::now();
+    std::vector<uint32_t> order(keys.size());
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+    std::vector<T> sortedKeys(keys.size());
+    std::vector<uint32_t> sortedValues(values.size());
+    for (size_t i = 0; i < order.size(); i++) {
+        sortedKeys[i] = keys[order[i]];
+        sortedValues[i] = values[order[i]];
+    }
+    keys.swap(sortedKeys);
+    values.swap(sortedValues);
     return elapsedMs(begin, std::chrono::steady_clock::now());
 }
 
