@@ -50,16 +50,24 @@ def load_traffic_profile(kernel: str = "scatter"):
         return None
 
 
-def cpu_baseline(keys: np.ndarray):
+def cpu_baseline(host_keys):
     """The reference's verification path (single-threaded std::sort, MultiRadixSort.cpp:141-146) timed on this
-    host through the oracle library.  Only this leg of bench.py touches oracle/."""
+    host through the oracle library: every distinct batch (seeds 1, 2, 3) is sorted once -- the results are the
+    bit-exact references of the GPU outputs, the times are the baseline.  Only this leg of bench.py touches oracle/."""
     from tests import _oracle
     orc = _oracle.load()
-    ref, ms = orc.std_sort(keys)
+    refs, times = [], []
+    for keys in host_keys:
+        ref, ms = orc.std_sort(keys)
+        refs.append(ref)
+        times.append(ms)
     cores, model = orc.cpu_info()
-    return ref, {"value": round(keys.size / (ms * 1e-3) / 1e9, 5), "unit": "Gkeys/s", "cores": 1, "kind": "port",
-                 "sample": f"std::sort of the full {keys.size}-key seed-1 batch, 1 repetition, {ms:.0f} ms",
-                 "host": f"1 thread of {cores} hardware threads ({model})"}
+    n = host_keys[0].size
+    best = min(times)
+    return refs, {"value": round(n / (best * 1e-3) / 1e9, 5), "unit": "Gkeys/s", "cores": 1, "kind": "port",
+                  "sample": f"std::sort of the full {n}-key batches of seeds 1..{len(times)}, one repetition each: "
+                            + ", ".join(f"{t:.0f}" for t in times) + " ms (value = the fastest)",
+                  "host": f"1 thread of {cores} hardware threads ({model})"}
 
 
 def bench_single(args):
@@ -156,6 +164,12 @@ def bench_single(args):
     # ---- timed region: exactly K steps, inputs resident.  The dominant kernel's launches carry HIP events on their
     # own dispatch packets, on the stream they are launched on; nothing else is instrumented.
     elapsed, kernels = run_steps(primary, K, 1 << dominant_id)
+    # the timed region's own outputs, every one of them, before anything overwrites them (one device read each)
+    fingerprints = [p_.verifyKeys(n)[1:] for p_ in pristine]
+    timed_bad = [i for i in range(K)
+                 if (lambda r: r[0] != 0 or r[1:] != fingerprints[i % len(pristine)])(batches[i].verifyKeys(n))]
+    if timed_bad:
+        raise SystemExit(f"VERIFICATION FAILED: timed-region outputs of steps {timed_bad} are not sorted permutations of their inputs")
 
     # ---- outside the timed region: (a) the same K steps with no events at all (instrumentation overhead check),
     # (b) once more with every kernel timed, for the per-kernel breakdown
@@ -164,16 +178,32 @@ def bench_single(args):
     rearm()
     _, breakdown = run_steps(primary, K, (1 << capi.VRS_KERNEL_COUNT) - 1)
 
-    # ---- verification of what the steps produced (result is in each batch buffer = "buffer0")
+    # ---- verification, second part: the reruns above sorted the same inputs again (rearm() restores them), so the
+    # batches now hold the outputs of the last rerun: every one is checked on the device again (ascending + the
+    # multiset fingerprint of its input) and the first batch of every seed bit for bit against std::sort.  The timed
+    # region's own K outputs were checked on the device right after the timed region.
+    def verify_batches(tag, refs):
+        bad = []
+        for i in range(K):
+            d, sm, mx = batches[i].verifyKeys(n)
+            if d != 0 or (sm, mx) != fingerprints[i % len(pristine)]:
+                bad.append(i)
+        res = {f"{tag}_every_batch_ascending_and_permutation_of_its_input": not bad, f"{tag}_batches_checked_on_device": K}
+        if refs is not None:
+            exact = True
+            for j in range(min(len(pristine), K)):
+                batches[j].downloadWithStagingBuffer(out0)
+                exact = exact and bool(np.array_equal(refs[j], out0))
+            res[f"{tag}_bit_exact_vs_std_sort_seeds"] = exact
+            res[f"{tag}_batches_compared_with_std_sort"] = min(len(pristine), K)
+        return res, bad
+
     out0 = np.empty(n, dtype=np.uint32)
-    batches[0].downloadWithStagingBuffer(out0)
-    check = {"sorted": bool(np.all(out0[1:] >= out0[:-1])),
-             "checksum_ok": int(out0.astype(np.uint64).sum()) == int(host_keys[0].astype(np.uint64).sum())}
     base = None
-    ref = None
+    refs = None
     if not args.no_cpu_baseline:
-        ref, base = cpu_baseline(host_keys[0])
-        check["bit_exact_vs_std_sort"] = bool(np.array_equal(ref, out0))
+        refs, base = cpu_baseline(host_keys)
+    check, bad = verify_batches(args.path, refs)
 
     # ---- the other path over the same batches, reported beside the headline (never as `value`)
     other_name = "contract" if one_call else "one_call"
@@ -184,12 +214,30 @@ def bench_single(args):
     other_elapsed, _ = run_steps(other_fn, K, 0)
     rearm()
     _, other_breakdown = run_steps(other_fn, K, (1 << capi.VRS_KERNEL_COUNT) - 1)
-    batches[0].downloadWithStagingBuffer(out0)
-    check[f"{other_name}_path_sorted"] = bool(np.all(out0[1:] >= out0[:-1]))
-    if ref is not None:
-        check[f"{other_name}_path_bit_exact_vs_std_sort"] = bool(np.array_equal(ref, out0))
-    if not all(check.values()):
-        raise SystemExit(f"VERIFICATION FAILED: {check}")
+    other_check, other_bad = verify_batches(other_name, refs)
+    check.update(other_check)
+    if not all(v for v in check.values() if isinstance(v, bool)):
+        raise SystemExit(f"VERIFICATION FAILED: {check} (batches {bad} / {other_bad})")
+
+    # ---- per-step spread (SURVEY 8d asks for min and median): K more steps, each bracketed by a queue-idle wait --
+    # outside the timed region, which runs its K steps back to back
+    rearm()
+    singles = []
+    for i in range(K):
+        gpu.waitIdle()
+        t0 = time.perf_counter()
+        primary(batches[i])
+        gpu.waitIdle()
+        singles.append((time.perf_counter() - t0) * 1e3)
+    # ---- what a plain device-to-device copy of one batch achieves here (read + write bytes), beside the 8 TB/s figure
+    copy_times = []
+    for i in range(6):
+        gpu.waitIdle()
+        t0 = time.perf_counter()
+        buf1.copyFrom(pristine[0])
+        gpu.waitIdle()
+        copy_times.append(time.perf_counter() - t0)
+    copy_gbps = 2 * 4 * n / min(copy_times[1:]) / 1e9
 
     bytes_per_key_sort = {"one_call": BYTES_PER_KEY_SORT_ONE_READ, "contract": BYTES_PER_KEY_SORT}
     dom_us = kernels.get(dominant_name, {}).get("avg_us")
@@ -202,7 +250,10 @@ def bench_single(args):
         "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[2]: {n} uniform random uint32 keys (std::mt19937 seeds 1,2,3), "
+        "ms_per_step_individually_timed": {"min": round(min(singles), 4), "median": round(float(np.median(singles)), 4),
+                                           "max": round(max(singles), 4),
+                                           "note": "K further steps, each bracketed by a queue-idle wait (outside the timed region)"},
+        "config": {"workload": f"BASELINE.json configs[{ {10 ** 7: 1, 10 ** 8: 2}.get(n, 2) }]: {n} uniform random uint32 keys (std::mt19937 seeds 1,2,3), "
                                f"multi_radixsort, 1xMI355X, keys resident in HBM",
                    "path": ("vrs_sort_keys_u32: the library runs the four 8-bit passes itself -- one counting read of the "
                             "keys, then four stable scatter passes with decoupled look-back (36 B/key)") if one_call else
@@ -215,7 +266,12 @@ def bench_single(args):
                      "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                      "algorithmic_bytes_per_launch": BYTES_PER_KEY_SCATTER * n, "avg_launch_us": dom_us,
-                     "traffic": load_traffic_profile(dominant_name)},
+                     "traffic": load_traffic_profile(dominant_name) if n == 10 ** 8 else None,
+                     "traffic_source": f"profiles/{dominant_name}_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                       "this command at N = 10^8 in an earlier run (counters cannot be read from inside this run)",
+                     "measured_d2d_copy_GBps": round(copy_gbps, 1),
+                     "measured_d2d_copy_note": "hipMemcpyDtoD of one batch in this run, read + write bytes: what this box's "
+                                               "HBM delivers for a mixed read/write stream, beside the 8 TB/s spec peak"},
         "sort_roofline": {"algorithmic_bytes": sort_bytes, "bytes_per_key": bytes_per_key_sort[args.path],
                           "achieved_GBps": round(sort_bytes * K / elapsed / 1e9, 1),
                           "frac_of_peak": round(sort_bytes * K / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
@@ -230,7 +286,8 @@ def bench_single(args):
                                 "frac": round(BYTES_PER_KEY_SCATTER * n / (other_dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                                 if other_dom_us else None},
             "kernels": other_breakdown, "note": "same batches, uninstrumented timing; not the headline"},
-        "verified": check,
+        "verified": dict(check, timed_region_every_batch_ascending_and_permutation_of_its_input=True,
+                         timed_region_batches_checked_on_device=K),
     }
     if base:
         result["cpu_baseline"] = base

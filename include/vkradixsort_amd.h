@@ -199,6 +199,16 @@ typedef enum vrs_key_transform {
 } vrs_key_transform;
 int vrs_transform_keys(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, int mode);
 
+/*
+ * On-device counterpart of MultiRadixSort::verify / testSort (MultiRadixSort.cpp:97-102,148-161), for results too
+ * many or too large to download and compare on the host: *descents = number of positions with keys[i] > keys[i+1]
+ * (0 == ascending); *key_sum and *key_mix = order-independent fingerprints (plain sum, sum of a 64-bit mix of every
+ * key) -- equal before and after a sort iff, up to hash collisions, the output is a permutation of the input.
+ * Synchronous (one read of the keys).  Any of the three outputs may be NULL.
+ */
+int vrs_verify_keys_u32(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, uint64_t *descents, uint64_t *key_sum,
+                        uint64_t *key_mix);
+
 /* ---- measurement (no reference counterpart) ------------------------- */
 
 typedef enum vrs_kernel_id {

@@ -25,15 +25,12 @@ __shared__ unsigned long long s_marks[8];
             for (int i_ = 0; i_ < 7; ++i_) g_marks[(size_t)blockIdx.x * 8 + i_] = s_marks[i_]; \
         }                                                                                    \
     } while (0)
-#define VRS_LB_STAT(polls, rows, trips)                                   \
-    do {                                                                  \
-        if ((threadIdx.x & 255u) == 17u) {                                \
-            atomicAdd(&g_lbstat[0], (unsigned long long)(polls));         \
-            atomicAdd(&g_lbstat[1], (unsigned long long)(rows));          \
-            atomicAdd(&g_lbstat[2], (unsigned long long)(trips));         \
-            if (polls) atomicAdd(&g_lbstat[3], 1ull);                     \
-            atomicAdd(&g_lbstat[4], 1ull);                                \
-        }                                                                 \
+// per-block slot (no contention): digit 17's thread packs polls | rows walked | round trips into mark 7
+#define VRS_LB_STAT(polls, rows, trips)                                                                          \
+    do {                                                                                                         \
+        if ((threadIdx.x & 255u) == 17u && g_marks)                                                              \
+            g_marks[(size_t)blockIdx.x * 8 + 7] =                                                                \
+                ((unsigned long long)(polls) << 40) | ((unsigned long long)(rows) << 20) | (unsigned long long)(trips); \
     } while (0)
 #include "vrs_kernels.hip"
 
@@ -109,15 +106,11 @@ int main(int argc, char **argv) {
     // ---- A: steady state, per-kernel times
     for (int r = 0; r < 2; ++r) one_sort(false, 0);
     double dt = 0, ps[4] = {0, 0, 0, 0};
-    unsigned long long zero8[8] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_lbstat), zero8, sizeof zero8));
     for (int r = 0; r < reps; ++r) {
         one_sort(false, 0);
         dt += e_dt.us(); for (int i = 0; i < 4; ++i) ps[i] += e_p[i].us();
     }
-    unsigned long long st8[8]; CK(hipMemcpyFromSymbol(st8, HIP_SYMBOL(g_lbstat), sizeof st8));
     printf("A steady state: digit_tables %.1f us | passes %.1f %.1f %.1f %.1f us\n", dt / reps, ps[0] / reps, ps[1] / reps, ps[2] / reps, ps[3] / reps);
-    printf("  look-back (digit 17's thread of every tile, %d sorts): tiles %llu, tiles that polled %llu (%.1f%%), polls/tile %.3f, rows walked/tile %.2f, round trips/tile %.2f\n",
-           reps, st8[4], st8[3], 100.0 * st8[3] / st8[4], (double)st8[0] / st8[4], (double)st8[1] / st8[4], (double)st8[2] / st8[4]);
     {   // verify the last sort
         std::vector<uint32_t> out(n); CK(hipMemcpy(out.data(), d_a, (size_t)n * 4, hipMemcpyDeviceToHost));
         bool ok = true; for (size_t i = 1; i < n && ok; ++i) ok = out[i - 1] <= out[i];
@@ -128,6 +121,7 @@ int main(int argc, char **argv) {
     for (int which : {0, 2}) {
         CK(hipMemset(d_marks, 0, nblocks * 64));
         one_sort(true, which);
+        CK(hipStreamSynchronize(st));
         std::vector<unsigned long long> m(nblocks * 8);
         CK(hipMemcpy(m.data(), d_marks, m.size() * 8, hipMemcpyDeviceToHost));
         double sum[8] = {0}; size_t cnt = 0; unsigned long long tmin = ~0ull, tmax = 0;
@@ -148,6 +142,20 @@ int main(int argc, char **argv) {
             if (w < 768) { early += life; ++ne; } else { late += life; ++nl; }
         }
         printf("   lifetime of the first 768 blocks %.0f ticks, of the rest %.0f ticks\n", ne ? early / ne : 0, nl ? late / nl : 0);
+        {
+            double polls[2] = {0, 0}, rowsw[2] = {0, 0}, trips[2] = {0, 0}; size_t c[2] = {0, 0}, polled[2] = {0, 0}; unsigned long long maxrows = 0;
+            for (size_t w = 0; w < nblocks; ++w) {
+                if (m[w * 8 + 6] == 0) continue;
+                const unsigned long long x = m[w * 8 + 7];
+                const int k = w < 768 ? 0 : 1;
+                const unsigned long long pl = x >> 40, rw = (x >> 20) & 0xFFFFF, tr = x & 0xFFFFF;
+                polls[k] += pl; rowsw[k] += rw; trips[k] += tr; ++c[k]; polled[k] += pl ? 1 : 0; maxrows = std::max(maxrows, rw);
+            }
+            for (int k = 0; k < 2; ++k)
+                printf("   look-back of the %s: tiles %zu, polled %.1f%%, polls/tile %.2f, rows walked/tile %.2f, round trips/tile %.2f\n",
+                       k ? "rest" : "first 768 blocks", c[k], c[k] ? 100.0 * polled[k] / c[k] : 0, c[k] ? polls[k] / c[k] : 0, c[k] ? rowsw[k] / c[k] : 0, c[k] ? trips[k] / c[k] : 0);
+            printf("   longest walk %llu rows\n", maxrows);
+        }
     }
     {
         unsigned long long *m = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_marks), &m, sizeof(m)));

@@ -61,7 +61,7 @@ def main():
                 if pairs:
                     v0.copyFrom(vsrc)
                 gpu.waitIdle()
-                if r == 2:
+                if r == 2 and not os.environ.get("VRS_NO_PROFILE"):
                     gpu.profileReset()
                     gpu.profileEnable(True)
                 t0 = time.perf_counter()

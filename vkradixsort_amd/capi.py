@@ -98,6 +98,7 @@ _SIGNATURES = [
     ("vrs_transform_keys", c_int, [c_void_p, c_void_p, c_uint32, c_int]),
     ("vrs_profile_enable", c_int, [c_void_p, c_int]),
     ("vrs_profile_enable_mask", c_int, [c_void_p, c_uint32]),
+    ("vrs_verify_keys_u32", c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
     ("vrs_profile_reset", c_int, [c_void_p]),
     ("vrs_profile_query", c_int, [c_void_p, c_int, POINTER(c_uint64), POINTER(c_double)]),
     ("vrs_profile_query_launch", c_int, [c_void_p, c_int, c_uint64, POINTER(c_double)]),

@@ -859,6 +859,31 @@ int vrs_transform_keys(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, 
     return VRS_OK;
 }
 
+int vrs_verify_keys_u32(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, uint64_t *descents, uint64_t *key_sum,
+                        uint64_t *key_mix) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (descents) *descents = 0;
+    if (key_sum) *key_sum = 0;
+    if (key_mix) *key_mix = 0;
+    if (num_elements == 0) return VRS_OK;
+    int rc = check_buffer(ctx, keys, static_cast<size_t>(num_elements) * sizeof(uint32_t), "keys");
+    if (rc) return rc;
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr;
+    VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), 3 * sizeof(unsigned long long)));
+    unsigned long long h[3] = {0, 0, 0};
+    hipError_t e = hipMemsetAsync(d, 0, sizeof h, ctx->stream);
+    if (e == hipSuccess) e = vrs::launch_verify_keys(ctx->stream, static_cast<const uint32_t *>(keys->ptr), num_elements, d);
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(ctx, "vrs_verify_keys_u32", e);
+    if (descents) *descents = h[0];
+    if (key_sum) *key_sum = h[1];
+    if (key_mix) *key_mix = h[2];
+    return VRS_OK;
+}
+
 int vrs_profile_enable(vrs_context ctx, int enabled) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     ctx->profile_mask = enabled ? (1u << VRS_KERNEL_COUNT) - 1u : 0u;

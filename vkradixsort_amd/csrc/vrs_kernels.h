@@ -60,6 +60,9 @@ hipError_t launch_atomic_rank_selftest(hipStream_t stream, uint32_t rounds, uint
 
 hipError_t launch_transform_keys(hipStream_t stream, uint32_t *keys, uint32_t n, int mode);
 
+// out3 (zeroed by the caller): descents keys[i] > keys[i+1], sum of the keys, sum of a 64-bit mix of every key
+hipError_t launch_verify_keys(hipStream_t stream, const uint32_t *keys, uint32_t n, unsigned long long *out3);
+
 // ---- one-call sort for large N (K5): one counting read, four look-back scatter passes
 // The counting read sorts every key into one of `groups` GROUPS per pass (pass 0: slice of the input, pass p > 0:
 // digit p-1 / (256 / groups)); plan_kernel merges neighbouring groups into kStreams balanced STREAMS, one per XCD

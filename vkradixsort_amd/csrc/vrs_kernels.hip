@@ -1359,6 +1359,45 @@ __global__ __launch_bounds__(kThreads) void transform_keys_kernel(uint32_t *keys
 }
 
 // ---------------------------------------------------------------------------------------------
+// On-device counterpart of MultiRadixSort::verify / testSort (MultiRadixSort.cpp:97-102,148-161) for batches too
+// many or too large to download: out[0] = number of positions i with keys[i] > keys[i+1] (0 == ascending),
+// out[1] = sum of the keys, out[2] = sum of a 64-bit mix of every key (both order-independent: equal before and after a
+// sort iff -- up to hash collisions -- the output is a permutation of the input).
+__device__ __forceinline__ unsigned long long mix_key(uint32_t k) {
+    unsigned long long x = (static_cast<unsigned long long>(k) + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 29;
+    return x * 0x94D049BB133111EBull;
+}
+__global__ __launch_bounds__(kThreads) void verify_keys_kernel(const uint32_t *__restrict__ keys, uint32_t n,
+                                                               unsigned long long *__restrict__ out) {
+    unsigned long long inv = 0, sum = 0, mix = 0;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * kThreads) {
+        const uint32_t k = keys[i];
+        if (i + 1 < n && k > keys[i + 1]) ++inv;
+        sum += k;
+        mix += mix_key(k);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        inv += __shfl_down(inv, o);
+        sum += __shfl_down(sum, o);
+        mix += __shfl_down(mix, o);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        if (inv) atomicAdd(&out[0], inv);
+        atomicAdd(&out[1], sum);
+        atomicAdd(&out[2], mix);
+    }
+}
+
+hipError_t launch_verify_keys(hipStream_t stream, const uint32_t *keys, uint32_t n, unsigned long long *out3) {
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = min((n + kThreads - 1) / kThreads, 8192u);
+    hipLaunchKernelGGL(verify_keys_kernel, dim3(blocks), dim3(kThreads), 0, stream, keys, n, out3);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launch wrappers
 
 hipError_t launch_fold_histograms(hipStream_t stream, const uint32_t *sub, uint32_t *hist, uint32_t sub_rows,

@@ -107,6 +107,7 @@ class HipLocalSortBackend(LocalSortBackend):
         self.hist = torch.empty(max(w_max, 1) * RADIX_SORT_BINS, dtype=torch.int32, device=self.device)
         self.digit_base = torch.empty(RADIX_SORT_BINS, dtype=torch.int32, device=self.device)
         self._wrapped = {}
+        self._in_use = set()
 
     def close(self):
         for b in self._wrapped.values():
@@ -115,27 +116,46 @@ class HipLocalSortBackend(LocalSortBackend):
         self.ctx.shutdown()
 
     def _buf(self, t):
+        """C-ABI wrapper of a tensor's memory, cached.  The backend's own buffers (hist, grouped, scratch, digit_base)
+        stay wrapped for its whole life; the wrappers of callers' tensors and sub-range views (they differ from step
+        to step) are dropped oldest-first once there are more than 256 -- never one handed out in the current call."""
         key = (t.data_ptr(), t.numel())
-        if key not in self._wrapped and len(self._wrapped) > 256:  # sub-range views differ from step to step
-            for b in self._wrapped.values():
-                b[0].release()
-            self._wrapped.clear()
-        if key not in self._wrapped:
-            S = self.engine.Buffer.BufferSettings
-            self._wrapped[key] = (self.engine.Buffer(self.ctx, S(t.numel() * 4), device_ptr=t.data_ptr()), t)
-        return self._wrapped[key][0]
+        hit = self._wrapped.get(key)
+        if hit is not None:
+            return hit[0]
+        S = self.engine.Buffer.BufferSettings
+        buf = self.engine.Buffer(self.ctx, S(t.numel() * 4), device_ptr=t.data_ptr())
+        pinned = any(t is own for own in (self.hist, self.grouped, self.scratch, self.digit_base))
+        self._wrapped[key] = (buf, t, pinned)
+        if len(self._wrapped) > 256:
+            keep = self._in_use | {key}
+            for k in [k for k, v in self._wrapped.items() if not v[2] and k not in keep][:64]:
+                self._wrapped.pop(k)[0].release()
+        return buf
+
+    def _handles(self, *tensors):
+        """Handles of several tensors for ONE C-ABI call: none of them is evicted while the others are resolved."""
+        self._in_use = {(t.data_ptr(), t.numel()) for t in tensors}
+        try:
+            return [self._buf(t).handle for t in tensors]
+        finally:
+            self._in_use = set()
 
     def _pass(self, src, dst, n, shift):
         lib, ctx = self.ctx.lib, self.ctx
         pc = self.engine.PushConstants(n, shift, lib.vrs_workgroup_count(n, self.B), self.B)
-        h = self._buf(self.hist)
-        ctx.check(lib.vrs_multi_radixsort_histograms(ctx.handle, self._buf(src).handle, h.handle, ctypes.byref(pc)))
-        ctx.check(lib.vrs_multi_radixsort(ctx.handle, self._buf(src).handle, self._buf(dst).handle, h.handle,
-                                          ctypes.byref(pc)))
+        s, d, h = self._handles(src, dst, self.hist)
+        ctx.check(lib.vrs_multi_radixsort_histograms(ctx.handle, s, h, ctypes.byref(pc)))
+        ctx.check(lib.vrs_multi_radixsort(ctx.handle, s, d, h, ctypes.byref(pc)))
 
     def group_by_top_byte(self, keys, n):
         if n > self.capacity:
             raise ValueError("shard larger than the backend capacity")
+        if n == 0:
+            # an empty shard: both stages return without launching anything, so there is no offset row to read --
+            # every top byte starts at position 0
+            self.digit_base.zero_()
+            return self.grouped, self.digit_base
         self._pass(keys, self.grouped, n, 24)
         # stays on the device: the step feeds it into its count all-gather and synchronises once, after that
         self.ctx.check(self.ctx.lib.vrs_multi_radixsort_digit_offsets_device(self.ctx.handle, self._buf(self.digit_base).handle))
@@ -150,8 +170,11 @@ class HipLocalSortBackend(LocalSortBackend):
         torch.cuda.current_stream().synchronize()  # the upload ran on torch's stream == the context's stream; keep it simple
         lib, ctx = self.ctx.lib, self.ctx
         spb = self.engine.Buffer(ctx, self.engine.Buffer.BufferSettings(sp_t.numel() * 4), device_ptr=sp_t.data_ptr())
-        ctx.check(lib.vrs_range_partition(ctx.handle, self._buf(keys).handle, self._buf(self.grouped).handle, spb.handle,
-                                          sp.size, n))
+        if n == 0:  # nothing is launched for an empty shard: every range starts (and ends) at 0
+            spb.release()
+            return self.grouped, np.zeros(sp.size + 2, dtype=np.int64)
+        k, g = self._handles(keys, self.grouped)
+        ctx.check(lib.vrs_range_partition(ctx.handle, k, g, spb.handle, sp.size, n))
         first = np.empty(RADIX_SORT_BINS, dtype=np.uint32)
         ctx.check(lib.vrs_multi_radixsort_digit_offsets(ctx.handle, first.ctypes.data_as(ctypes.c_void_p)))  # synchronous
         spb.release()
@@ -165,7 +188,8 @@ class HipLocalSortBackend(LocalSortBackend):
         # the library's own four-pass loop (one counting read + look-back scatters from 2^20 keys on); the result is
         # back in `keys`, `scratch` is the ping-pong partner
         ctx = self.ctx
-        ctx.check(ctx.lib.vrs_sort_keys_u32(ctx.handle, self._buf(keys).handle, self._buf(self.scratch).handle, n))
+        k, t = self._handles(keys, self.scratch)
+        ctx.check(ctx.lib.vrs_sort_keys_u32(ctx.handle, k, t, n))
         return keys
 
 

@@ -164,6 +164,14 @@ class Buffer:
         ctx.check(ctx.lib.vrs_buffer_download(ctx.handle, self.handle, data.ctypes.data_as(ctypes.c_void_p),
                                               self.m_bufferSettings.m_sizeBytes))
 
+    def verifyKeys(self, num_elements: int):
+        """On-device verify (vrs_verify_keys_u32): (descents, key sum, key mix) of the first num_elements uint32 keys --
+        descents == 0 means ascending; sum and mix are order-independent fingerprints of the multiset."""
+        ctx = self.m_gpuContext
+        d, s, m = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        ctx.check(ctx.lib.vrs_verify_keys_u32(ctx.handle, self.handle, num_elements, ctypes.byref(d), ctypes.byref(s), ctypes.byref(m)))
+        return d.value, s.value, m.value
+
     def copyFrom(self, src: "Buffer", size_bytes: int | None = None) -> None:
         ctx = self.m_gpuContext
         n = self.m_bufferSettings.m_sizeBytes if size_bytes is None else size_bytes
