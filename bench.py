@@ -377,6 +377,9 @@ def bench_multi(args):
         sorter.rounds = min(tried, key=tried.get)
     torch.cuda.synchronize()
     rearm()
+    from vkradixsort_amd import capi
+    backend.ctx.profileReset()
+    backend.ctx.profileEnableMask(1 << capi.VRS_KERNEL_LOOKBACK_SCATTER)  # events ride on the dominant kernel's own launches
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -386,6 +389,8 @@ def bench_multi(args):
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    backend.ctx.profileEnable(False)
+    lb_launches, lb_ms = backend.ctx.profileQuery(capi.VRS_KERNEL_LOOKBACK_SCATTER)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -415,6 +420,21 @@ def bench_multi(args):
         if not all(check.values()):
             raise SystemExit(f"VERIFICATION FAILED: {check}")
         value = n * world * K / elapsed / 1e9
+        # dominant kernel: the look-back scatter of the local sorts (one launch per pass per received sub-range); a launch
+        # over m keys moves 8 m algorithmic bytes; rank 0's launches of the timed region
+        recv_keys = int(g[0][2])
+        lb_bytes = 8 * 4 * recv_keys * K  # 4 passes over every received key, K steps
+        lb_achieved = lb_bytes / (lb_ms * 1e-3) / 1e9 if lb_ms > 0 else None
+        base = None
+        if not args.no_cpu_baseline:
+            from tests import _oracle
+            orc = _oracle.load()
+            sample = shard[:min(n, 2 * 10 ** 7)]
+            _, ms = orc.std_sort(sample)
+            cores, model = orc.cpu_info()
+            base = {"value": round(sample.size / (ms * 1e-3) / 1e9, 5), "unit": "Gkeys/s", "cores": 1, "kind": "port",
+                    "sample": f"std::sort of the first {sample.size} keys of rank 0's shard, 1 repetition, {ms:.0f} ms",
+                    "host": f"1 thread of {cores} hardware threads ({model})"}
         result = {
             "metric": "Gkeys/s sorting 10^8 uint32 at 1/2/4/8 MI355X; % of HBM roofline",
             "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -424,14 +444,24 @@ def bench_multi(args):
                                    f"range: top-byte partition pass, RCCL all-to-all over xGMI, local 4-pass multi_radixsort (one-call form)",
                        "num_elements_per_gpu": n, "num_blocks_per_workgroup": B, "parallelism": f"range-sharded x{world}",
                        "exchange_rounds": sorter.rounds, "rounds_tried_in_warmup_ms": {str(k): round(v * 1e3, 3) for k, v in tried.items()},
-                       "hbm_bytes_per_key": 48},
-            "roofline": {"bound": "hbm", "achieved": round(48 * n * K / elapsed / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(48 * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "note": "per GPU, whole step incl. the xGMI exchange: 12 B/key partition pass + 36 B/key local "
-                                 "sorts (one counting read + four look-back scatter passes per received sub-range)"},
+                       "hbm_bytes_per_key": 48,
+                       "hbm_bytes_per_key_breakdown": {"partition_pass_histogram_read": 4, "partition_pass_scatter": 8,
+                                                       "local_sorts_counting_read": 4, "local_sorts_four_lookback_scatters": 32}},
+            "roofline": {"bound": "hbm", "kernel": "lookback_scatter of the local sorts (rank 0's launches in the timed region)",
+                         "achieved": round(lb_achieved, 1) if lb_achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(lb_achieved / HBM_PEAK_GBS, 4) if lb_achieved else None,
+                         "launches": lb_launches, "avg_launch_us": round(lb_ms / lb_launches * 1e3, 2) if lb_launches else None,
+                         "algorithmic_bytes_per_launch": round(lb_bytes / lb_launches) if lb_launches else None,
+                         "traffic": None},
+            "step_roofline": {"bytes_per_key": 48, "achieved_GBps_per_gpu": round(48 * n * K / elapsed / 1e9, 1),
+                              "frac_of_peak": round(48 * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+                              "note": "per GPU, whole step incl. the xGMI exchange: 12 B/key partition pass + 36 B/key "
+                                      "local sorts (one counting read + four look-back scatter passes per received sub-range)"},
             "shard_sizes": [x[2] for x in g],
             "verified": check,
         }
+        if base:
+            result["cpu_baseline"] = base
     backend.close()
     dist.destroy_process_group()
     return result

@@ -245,6 +245,10 @@ int vrs_debug_atomic_rank_selftest(vrs_context ctx, uint32_t rounds, uint32_t se
 /* What the large-N form of the one-call sorts did on this context so far (cumulative): passes run as look-back
  * scatters, passes that fell back to a contract pass (streams too unequal), identity passes left out. */
 int vrs_one_call_stats(vrs_context ctx, uint64_t *lookback_passes, uint64_t *fallback_passes, uint64_t *skipped_passes);
+/* Look-back passes the one-call sort enqueued a second time: the speculative enqueue (made before the plan was known)
+ * left at once because an earlier pass needed another form or because the pass's longest stream did not fit the
+ * speculative grid.  Cumulative; diagnostics only. */
+int vrs_one_call_relaunched_passes(vrs_context ctx, uint64_t *relaunched_passes);
 
 /* Ranking method in effect: 1 = __ballot match-any, 2 = returning LDS atomics. */
 int vrs_rank_mode(vrs_context ctx);
@@ -265,7 +269,11 @@ typedef enum vrs_tuning_key {
                                      and counts its stream's earlier keys itself (default 4096, about 2-4 ms) */
     VRS_TUNE_DEBUG_HOLD_TILE = 7,  /* test hook (default -1 = off): this tile of every look-back stream never publishes
                                      its counts, so its successors must run out of spin budget and recount */
-    VRS_TUNE_DIGIT_TABLE_GROUPS = 8, /* groups per pass of the one-call sort's counting read: 8, 16 or 32 */
+    VRS_TUNE_DIGIT_TABLE_GROUPS = 8, /* groups per pass of the one-call sort's counting read: 8, 16, 32, or 0 (default):
+                                     8 below 2^26 keys, 32 from there on */
+    VRS_TUNE_FUSED_PLAN = 10,      /* 1: the last workgroup of the one-call sort's counting read turns the digit tables
+                                     into the plan; 0 (default): a separate single-workgroup plan kernel (measured a
+                                     tie at 10^7 and 10^8 keys) */
     VRS_TUNE_SINGLE_MAX_KEYS = 9   /* vrs_sort_keys_u32 runs up to this many keys as ONE single_radixsort launch (one
                                      workgroup, four passes) instead of twelve launch-bound multi-block launches;
                                      0 = never.  Default 4096 (measured crossover, profiles/r02_small_n_crossover.csv) */

@@ -133,6 +133,30 @@ def test_one_call_stats_count_what_happened(gpu_context):
     assert (s3 - s2).tolist() == [2, 1, 1]
 
 
+def test_mildly_unbalanced_streams_take_the_relaunch_path(gpu_context):
+    """Passes 1-3 are enqueued before the plan is known, with grids sized for (nearly) even streams.  Keys whose
+    digit 0 is a little skewed make pass 1's longest stream ~12 % longer than even: too long for the speculative
+    grid, well within what a look-back pass handles -- that pass (and the ones after it) must leave at once and be
+    enqueued again with their exact grids.  Same result, four look-back passes, no contract pass."""
+    ctx = gpu_context
+    n = 6000007
+    rs = np.random.RandomState(77)
+    k = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    extra = rs.rand(n) < 0.017  # 1.7 % more keys with digit 0 in [0, 8): stream 0 of pass 1 = groups 0-3 grows by ~13 %
+    k = np.where(extra, (k & np.uint32(0xFFFFFF07)), k).astype(np.uint32)
+    r0, s0 = ctypes.c_uint64(), [ctypes.c_uint64() for _ in range(3)]
+    ctx.check(ctx.lib.vrs_one_call_relaunched_passes(ctx.handle, ctypes.byref(r0)))
+    ctx.check(ctx.lib.vrs_one_call_stats(ctx.handle, *[ctypes.byref(x) for x in s0]))
+    out, stats = sort_keys(ctx, k)
+    r1, s1 = ctypes.c_uint64(), [ctypes.c_uint64() for _ in range(3)]
+    ctx.check(ctx.lib.vrs_one_call_relaunched_passes(ctx.handle, ctypes.byref(r1)))
+    ctx.check(ctx.lib.vrs_one_call_stats(ctx.handle, *[ctypes.byref(x) for x in s1]))
+    assert np.array_equal(out, np.sort(k))
+    assert stats["lookback_scatter"] == 4 and stats["scatter"] == 0
+    assert [b.value - a.value for a, b in zip(s0, s1)] == [4, 0, 0]
+    assert r1.value - r0.value == 3  # passes 1, 2, 3 went out twice
+
+
 def test_threshold_selects_the_form(gpu_context):
     keys = make_keys(600000, "uniform")
     _, below = sort_keys(gpu_context, keys, min_keys=1 << 20)
@@ -278,8 +302,15 @@ def test_digit_table_group_counts_agree(gpu_context, groups):
             out, stats = sort_keys(ctx, keys)
             assert stats["digit_tables"] == 1
             assert np.array_equal(out, np.sort(keys)), (groups, n, dist)
+            # the fused form (the counting read's last workgroup makes the plan) gives the same plan
+            ctx.setTuning(capi.VRS_TUNE_FUSED_PLAN, 1)
+            try:
+                out2, stats2 = sort_keys(ctx, keys)
+            finally:
+                ctx.setTuning(capi.VRS_TUNE_FUSED_PLAN, 0)
+            assert np.array_equal(out2, out) and stats2["lookback_scatter"] == stats["lookback_scatter"], (groups, n, dist)
     finally:
-        ctx.setTuning(capi.VRS_TUNE_DIGIT_TABLE_GROUPS, 32)
+        ctx.setTuning(capi.VRS_TUNE_DIGIT_TABLE_GROUPS, 0)
     with pytest.raises(vrs.VrsError):
         ctx.setTuning(capi.VRS_TUNE_DIGIT_TABLE_GROUPS, 12)
 

@@ -496,6 +496,72 @@ def test_sort_stage_accepts_a_caller_filled_histogram_table(gpu_context, oracle,
             b.release()
 
 
+@pytest.mark.parametrize("B", [64, 256])
+def test_kept_sub_tile_table_never_outlives_its_keys(gpu_context, oracle, B):
+    """For NUM_BLOCKS_PER_WORKGROUP > 32 the histogram stage keeps an 8192-key sub-tile table for the sort stage.  It must
+    be dropped as soon as the keys it describes may have changed (upload, device copy, key transform, a one-call sort)
+    or another table is bound: the sort stage then reads the table it is GIVEN, as the reference's does
+    (multi_radixsort.comp:56-63)."""
+    ctx, lib = gpu_context, gpu_context.lib
+    n = 400003
+    a, b = rand_keys(n, 11), rand_keys(n, 12)
+    W = oracle.workgroup_count(n, B)
+    pc = vrs.PushConstants(n, 8, W, B)
+    b0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), a)
+    b1 = vrs.Buffer(ctx, S(4 * n))
+    h = vrs.Buffer(ctx, S(W * 1024))
+    out = np.empty(n, np.uint32)
+    # (1) keys rewritten in place between the two stages, table refilled by the caller for the NEW keys
+    ctx.check(lib.vrs_multi_radixsort_histograms(ctx.handle, b0.handle, h.handle, ctypes.byref(pc)))
+    ctx.check(lib.vrs_buffer_upload(ctx.handle, b0.handle, b.ctypes.data_as(ctypes.c_void_p), b.nbytes))
+    hb = oracle.histograms(b, 8, W, B)
+    ctx.check(lib.vrs_buffer_upload(ctx.handle, h.handle, hb.ctypes.data_as(ctypes.c_void_p), hb.nbytes))
+    ctx.check(lib.vrs_multi_radixsort(ctx.handle, b0.handle, b1.handle, h.handle, ctypes.byref(pc)))
+    b1.downloadWithStagingBuffer(out)
+    assert np.array_equal(out, oracle.scatter(b, hb, 8, W, B)), "stale sub-tile table after an upload"
+    # (2) same keys, but the sort stage is handed ANOTHER table buffer (filled by the caller)
+    ctx.check(lib.vrs_multi_radixsort_histograms(ctx.handle, b0.handle, h.handle, ctypes.byref(pc)))
+    h2 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(W * 1024), hb)
+    ctx.check(lib.vrs_multi_radixsort(ctx.handle, b0.handle, b1.handle, h2.handle, ctypes.byref(pc)))
+    b1.downloadWithStagingBuffer(out)
+    assert np.array_equal(out, oracle.scatter(b, hb, 8, W, B)), "another table bound to the sort stage"
+    # (3) a device copy over the keys between the stages
+    src = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), a)
+    ctx.check(lib.vrs_multi_radixsort_histograms(ctx.handle, b0.handle, h.handle, ctypes.byref(pc)))  # table of b
+    b0.copyFrom(src)  # keys are a again
+    ha = oracle.histograms(a, 8, W, B)
+    ctx.check(lib.vrs_buffer_upload(ctx.handle, h.handle, ha.ctypes.data_as(ctypes.c_void_p), ha.nbytes))
+    ctx.check(lib.vrs_multi_radixsort(ctx.handle, b0.handle, b1.handle, h.handle, ctypes.byref(pc)))
+    b1.downloadWithStagingBuffer(out)
+    assert np.array_equal(out, oracle.scatter(a, ha, 8, W, B)), "stale sub-tile table after a device copy"
+    for x in (b0, b1, h, h2, src):
+        x.release()
+
+
+def test_verify_keys_on_device(gpu_context):
+    """vrs_verify_keys_u32, the on-device form of MultiRadixSort::verify / testSort (MultiRadixSort.cpp:97-102,148-161):
+    descents == 0 iff ascending; the two fingerprints do not depend on the order and change with the multiset."""
+    ctx = gpu_context
+    n = 1000003
+    keys = rand_keys(n, 5)
+    kb = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)
+    d, sm, mx = kb.verifyKeys(n)
+    assert d == int(np.count_nonzero(keys[:-1] > keys[1:]))
+    assert sm == int(keys.astype(np.uint64).sum())
+    sb = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), np.sort(keys))
+    d2, sm2, mx2 = sb.verifyKeys(n)
+    assert d2 == 0 and (sm2, mx2) == (sm, mx)
+    tampered = np.sort(keys)
+    tampered[1234] += 1  # still ascending or not, the multiset changed: the fingerprints must notice
+    tampered[1235] -= 1 if tampered[1235] > 0 else 0
+    tb = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), tampered)
+    _, sm3, mx3 = tb.verifyKeys(n)
+    assert mx3 != mx
+    assert kb.verifyKeys(0) == (0, 0, 0)
+    for x in (kb, sb, tb):
+        x.release()
+
+
 @pytest.mark.parametrize("B", [1, 2, 4, 8, 16, 64, 128, 512, 4096, 16384])
 def test_every_block_count_of_the_reference_sweeps(gpu_context, oracle, B):
     """NUM_BLOCKS_PER_WORKGROUP values of the reference's timing plots (README.md:253-265): tables and outputs per stage."""

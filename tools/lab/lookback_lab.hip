@@ -85,12 +85,12 @@ int main(int argc, char **argv) {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_marks), &null_marks, sizeof(null_marks)));
     Ev e_dt, e_p[4], e_x;
     uint32_t stamp = 0;
-    printf("n=%u groups=%u tile_cap=%u tiles0=%u kLbBatch=%d\n", n, G, tile_cap, tiles0, vrs::kLbBatch);
+    printf("n=%u groups=%u tile_cap=%u tiles0=%u cooperative look-back\n", n, G, tile_cap, tiles0);
 
     auto one_sort = [&](bool marks_pass, int which) {
         CK(hipMemcpyAsync(d_a, d_src, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         CK(vrs::launch_digit_tables(st, d_a, n, 4, 0, group_len, G, tables, status, rows * 256, cus, e_dt.le()));
-        CK(vrs::launch_plan(st, tables, plan, host_dev, ++stamp, n, group_len, G, T, tile_cap, cuts0));
+        CK(vrs::launch_plan(st, tables, plan, host_dev, ++stamp, n, group_len, G, T, tile_cap, tile_cap, cuts0));
         uint32_t *in = d_a, *out = d_b;
         for (uint32_t i = 0; i < 4; ++i) {
             if (marks_pass) {

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -30,6 +31,7 @@ struct vrs_context_t {
     uint32_t sub_hist_rows = 0;
     struct {
         const void *keys = nullptr;
+        const void *hist = nullptr;  // the caller's table the sub-tile table was folded into
         uint32_t n = 0, shift = 0, blocks = 0;
         int key_bytes = 4;
         bool valid = false;
@@ -56,13 +58,16 @@ struct vrs_context_t {
     vrs::OnesweepPlanHead *os_host_head = nullptr;      // pinned host copy of the plan's head (the plan kernel writes it)
     vrs::OnesweepPlanHead *os_host_head_dev = nullptr;  // the same memory as the device sees it
     uint32_t os_stamp = 0;               // stamp of the most recent plan (never 0)
-    uint32_t os_groups = 32;             // groups per pass of the counting read (8, 16 or 32), VRS_TUNE_DIGIT_TABLE_GROUPS
+    uint32_t *os_ticket = nullptr;       // fused plan: ticket word of the counting read's workgroups (zero between launches)
+    bool os_fused_plan = false;          // the counting read's last workgroup makes the plan (VRS_TUNE_FUSED_PLAN)
+    uint32_t os_groups = 0;              // groups per pass of the counting read: 8, 16, 32 or 0 = by size, VRS_TUNE_DIGIT_TABLE_GROUPS
     uint32_t os_spin_budget = 4096;      // polls of an unpublished look-back row before a tile recounts, VRS_TUNE_LOOKBACK_SPIN_BUDGET
     int os_hold_tile = -1;               // test hook, VRS_TUNE_DEBUG_HOLD_TILE
     bool os_misplace = false;            // test hook, VRS_TUNE_DEBUG_MISPLACE_STREAMS
     bool xcc_map_valid = false;          // the probe found block b on an XCC that depends on b % 8 only
     unsigned long long xcc_map = 0;      // byte x = that XCC for b % 8 == x
     uint64_t os_lookback_passes = 0;
+    uint64_t os_relaunched_passes = 0;   // look-back passes enqueued a second time (first enqueue left at once: see sort_one_read)
     uint64_t os_fallback_passes = 0;
     uint64_t os_skipped_passes = 0;      // identity passes (one digit value holds every key) the one-call sort left out     // passes the one-call sort ran through the contract path (unbalanced streams)
 };
@@ -296,8 +301,8 @@ int run_sort_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs
     const uint32_t kLaunchTileBlocks = launch_tile_blocks(key_bytes);
     uint32_t launch_W = W, launch_B = B, row_stride = 1, rows_per_contract_tile = 1;
     if (B > kLaunchTileBlocks && B % kLaunchTileBlocks == 0 && ctx->sub_cache.valid &&
-        ctx->sub_cache.keys == keys_in->ptr && ctx->sub_cache.n == n && ctx->sub_cache.shift == pc->g_shift &&
-        ctx->sub_cache.blocks == B && ctx->sub_cache.key_bytes == key_bytes) {
+        ctx->sub_cache.keys == keys_in->ptr && ctx->sub_cache.hist == histograms->ptr && ctx->sub_cache.n == n &&
+        ctx->sub_cache.shift == pc->g_shift && ctx->sub_cache.blocks == B && ctx->sub_cache.key_bytes == key_bytes) {
         // large contract tiles: prefix + scatter at 8192-key sub-tile granularity from the table the histogram
         // stage kept (the caller's table is its fold, so both describe the same keys)
         launch_B = kLaunchTileBlocks;
@@ -452,6 +457,7 @@ int vrs_buffer_upload(vrs_context ctx, vrs_buffer buf, const void *host_data, si
     if (size_bytes == 0) return VRS_OK;
     if (!host_data) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "host_data is NULL");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->sub_cache.valid = false;  // a buffer is rewritten: the kept sub-tile table may no longer describe its keys
     VRS_HIP(ctx, hipMemcpyAsync(buf->ptr, host_data, size_bytes, hipMemcpyHostToDevice, ctx->stream));
     VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VRS_OK;
@@ -476,6 +482,7 @@ int vrs_buffer_copy(vrs_context ctx, vrs_buffer dst, vrs_buffer src, size_t size
     if ((rc = check_buffer(ctx, src, size_bytes, "copy src"))) return rc;
     if (size_bytes == 0) return VRS_OK;
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->sub_cache.valid = false;  // a buffer is rewritten: the kept sub-tile table may no longer describe its keys
     VRS_HIP(ctx, hipMemcpyAsync(dst->ptr, src->ptr, size_bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return VRS_OK;
 }
@@ -532,6 +539,7 @@ static int run_histogram_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer h
         VRS_HIP(ctx, vrs::launch_fold_histograms(ctx->stream, ctx->sub_hist, static_cast<uint32_t *>(histograms->ptr),
                                                  sub_rows, pc->g_num_workgroups, S, vrs::LaunchEvents{nullptr, ev.stop}));
         ctx->sub_cache.keys = keys_in->ptr;
+        ctx->sub_cache.hist = histograms->ptr;
         ctx->sub_cache.n = n;
         ctx->sub_cache.shift = pc->g_shift;
         ctx->sub_cache.blocks = B;
@@ -649,7 +657,10 @@ static int wait_for_plan(vrs_context ctx, uint32_t stamp) {
 static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values, vrs_buffer values_tmp,
                          uint32_t n, int key_bytes) {
     constexpr uint32_t S = vrs::kStreams;
-    const uint32_t G = ctx->os_groups;
+    // groups per pass: 32 let the streams follow skewed data more closely, but every workgroup of the counting read
+    // flushes 3 * G * 256 counters -- a fixed cost that only large inputs amortise (10^7 keys: 20 vs 34 us for the
+    // counting read, 3 * 10^7: 47 vs 61, 10^8: a tie; profiles/labs/r02_groups_and_fused_plan.txt)
+    const uint32_t G = ctx->os_groups ? ctx->os_groups : (n < (1u << 26) ? 8u : 32u);
     const uint32_t T = vrs::onesweep_tile_keys(key_bytes);
     const uint32_t tiles_total = (n + T - 1) / T;
     const uint32_t group_tiles = (tiles_total + G - 1) / G;  // tiles per pass-0 group (slice of the input)
@@ -668,8 +679,9 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         uint32_t *tables = nullptr;
         vrs::OnesweepPlan *plan = nullptr;
         vrs::OnesweepPlanHead *host = nullptr, *host_dev = nullptr;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&tables), vrs::kDigitTableWords * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemsetAsync(tables, 0, vrs::kDigitTableWords * sizeof(uint32_t), ctx->stream);
+        // one allocation: the digit tables and, behind them, the ticket word of the fused plan
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&tables), (vrs::kDigitTableWords + 64) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(tables, 0, (vrs::kDigitTableWords + 64) * sizeof(uint32_t), ctx->stream);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&plan), sizeof(vrs::OnesweepPlan));
         if (e == hipSuccess)
             e = hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(vrs::OnesweepPlanHead),
@@ -683,10 +695,16 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         }
         std::memset(host, 0, sizeof *host);
         ctx->os_tables = tables;
+        ctx->os_ticket = tables + vrs::kDigitTableWords;
         ctx->os_plan = plan;
         ctx->os_host_head = host;
         ctx->os_host_head_dev = host_dev;
     }
+    // Passes 1-3 are enqueued before the plan is known: their grids have room for streams a little longer than even ones
+    // (uniform keys: the longest stream is within a tile or two of N / 8).  Surplus workgroups are not free (3 000 of
+    // them cost 3-4 us per pass, profiles/labs/r02_blind_grid.txt), so the slack is small; a pass whose longest stream
+    // needs more -- but no more than tile_cap -- leaves at once and is launched again with its exact grid.
+    const uint32_t blind_cap = std::min(tile_cap, even + even / 64 + 2);
     const size_t rows = static_cast<size_t>(S) * tile_cap;  // status rows: one region for all four passes (tagged words)
     if (rows > ctx->os_status_rows) {
         if (ctx->os_status) {
@@ -709,7 +727,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         vrs_context ctx;
         bool armed = false;
         ~TablesGuard() {
-            if (armed) (void)hipMemsetAsync(ctx->os_tables, 0, vrs::kDigitTableWords * sizeof(uint32_t), ctx->stream);
+            if (armed) (void)hipMemsetAsync(ctx->os_tables, 0, (vrs::kDigitTableWords + 64) * sizeof(uint32_t), ctx->stream);
         }
     } guard{ctx};
     // where the data lives: buffers[0] = caller's keys / values, buffers[1] = the ping-pong partners.  A pass whose digit
@@ -735,17 +753,19 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
         const uint32_t stamp = ctx->os_stamp;
         guard.armed = true;
+        const vrs::FusedPlan fused{ctx->os_plan, ctx->os_host_head_dev, ctx->os_ticket, stamp, T, tile_cap, blind_cap, cuts0};
         VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, group_len, G,
                                               ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS,
-                                              ctx->scatter.compute_units, ev));
-        VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, ctx->os_host_head_dev, stamp, n, group_len, G,
-                                      T, tile_cap, cuts0));
+                                              ctx->scatter.compute_units, ev, ctx->os_fused_plan ? &fused : nullptr));
+        if (!ctx->os_fused_plan)
+            VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, ctx->os_host_head_dev, stamp, n,
+                                          group_len, G, T, tile_cap, blind_cap, cuts0));
         guard.armed = false;
         // all four passes at once, before the plan is known here; pass 0's streams are the host's own cuts
         const uint32_t cur_at_start = cur;
         const size_t events_before = ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER];
         for (uint32_t i = 0; i < 4; ++i)
-            if ((rc = lookback_pass(i, 32u * group + 8u * i, i == 0 ? tiles0 : tile_cap, false))) return rc;
+            if ((rc = lookback_pass(i, 32u * group + 8u * i, i == 0 ? tiles0 : blind_cap, false))) return rc;
         if ((rc = wait_for_plan(ctx, stamp))) return rc;
         const vrs::OnesweepPlanHead &head = *ctx->os_host_head;
         const uint32_t q = std::min<uint32_t>(head.first_abnormal, 4u);
@@ -768,6 +788,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
                 if ((rc = contract_pass(ctx, kin, kout, vin, vout, &pc, shift, key_bytes))) return rc;
             } else {
                 ctx->os_lookback_passes++;
+                ctx->os_relaunched_passes++;
                 if ((rc = lookback_pass(i, shift, head.max_tiles[i], true))) return rc;
             }
         }
@@ -804,6 +825,7 @@ static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp
         }
     }
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->sub_cache.valid = false;  // the keys are rewritten in place
     // small N: the whole sort in ONE launch of the single-workgroup kernel instead of twelve launch-bound ones (the
     // reference's own guidance: its single_radixsort is the faster path for small inputs, README.md:18-21)
     if (key_bytes == 4 && !values && n <= ctx->single_max_keys) {
@@ -855,6 +877,7 @@ int vrs_transform_keys(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, 
     int rc = check_buffer(ctx, keys, static_cast<size_t>(num_elements) * sizeof(uint32_t), "keys");
     if (rc) return rc;
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->sub_cache.valid = false;  // a buffer is rewritten: the kept sub-tile table may no longer describe its keys
     VRS_HIP(ctx, vrs::launch_transform_keys(ctx->stream, static_cast<uint32_t *>(keys->ptr), num_elements, mode));
     return VRS_OK;
 }
@@ -1029,6 +1052,12 @@ int vrs_one_call_stats(vrs_context ctx, uint64_t *lookback_passes, uint64_t *fal
     return VRS_OK;
 }
 
+int vrs_one_call_relaunched_passes(vrs_context ctx, uint64_t *relaunched_passes) {
+    if (!ctx || !relaunched_passes) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or output is NULL");
+    *relaunched_passes = ctx->os_relaunched_passes;
+    return VRS_OK;
+}
+
 int vrs_rank_mode(vrs_context ctx) { return ctx && ctx->scatter.atomic_rank ? 2 : 1; }
 
 int vrs_set_tuning(vrs_context ctx, int key, int value) {
@@ -1062,6 +1091,9 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
         case VRS_TUNE_DEBUG_MISPLACE_STREAMS:
             ctx->os_misplace = value != 0;
             return VRS_OK;
+        case VRS_TUNE_FUSED_PLAN:
+            ctx->os_fused_plan = value != 0;
+            return VRS_OK;
         case VRS_TUNE_SINGLE_MAX_KEYS:
             if (value < 0) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "single-launch threshold must be >= 0");
             ctx->single_max_keys = static_cast<uint32_t>(value);
@@ -1074,8 +1106,8 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             ctx->os_hold_tile = value;
             return VRS_OK;
         case VRS_TUNE_DIGIT_TABLE_GROUPS:
-            if (value != 8 && value != 16 && value != 32)
-                return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "digit table groups must be 8, 16 or 32");
+            if (value != 0 && value != 8 && value != 16 && value != 32)
+                return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "digit table groups must be 0 (by size), 8, 16 or 32");
             if (static_cast<uint32_t>(value) % vrs::kStreams != 0)
                 return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "digit table groups must be a multiple of the stream count");
             ctx->os_groups = static_cast<uint32_t>(value);

@@ -82,14 +82,17 @@ struct StreamDesc {
     uint32_t tiles;        // ceil(len / tile)
 };
 // what the plan says about one pass
-enum : uint32_t { kPassLookback = 0, kPassIdentity = 1, kPassUnbalanced = 2 };
+enum : uint32_t { kPassLookback = 0, kPassIdentity = 1, kPassUnbalanced = 2, kPassLookbackWide = 3 };
 // The part of the plan the scatter workgroups read (scalar loads) and the host reads back.  The host enqueues all
 // four look-back passes BEFORE it knows the plan; a pass p >= first_abnormal leaves at once (its workgroups read the
 // word and exit) and the host, once the head has arrived, enqueues passes first_abnormal..3 in the form they need.
 struct OnesweepPlanHead {
     StreamDesc stream[4][kStreams];
+    StreamDesc blind[4][kStreams];  // the same with tiles = 0 for every pass >= first_abnormal
     uint32_t max_tiles[4];      // tiles of the longest stream of each pass
-    uint32_t mode[4];           // kPassLookback / kPassIdentity (one digit value holds every key) / kPassUnbalanced
+    uint32_t mode[4];           // kPassLookback / kPassIdentity (one digit value holds every key) / kPassUnbalanced (a
+                                // stream longer than tile_cap tiles: contract pass) / kPassLookbackWide (a stream longer
+                                // than the speculative grid but within tile_cap: look-back pass, launched again)
     uint32_t first_abnormal;    // smallest p with mode[p] != kPassLookback, 4 if there is none
     uint32_t ready;             // host copy only: the sort's stamp, written after everything else
 };
@@ -121,13 +124,24 @@ uint32_t onesweep_tile_keys(int key_bytes);
 // a word carries the pass's tag, so only the counting read zeroes it (once per group of four passes).
 // Counts the four digits at bits [base_shift, base_shift + 32) of every key into tables[4][groups][256]; also zeroes
 // status[0, status_words) (a multiple of 4 words, 16-byte aligned).  group_len: keys per pass-0 group (whole tiles).
+// fused: the counting read's last workgroup also makes the plan (what launch_plan would do in a launch of its own);
+// done = a zero-initialised ticket word the launches share
+struct FusedPlan {
+    OnesweepPlan *plan;
+    OnesweepPlanHead *host_head;
+    uint32_t *done;
+    uint32_t stamp, tile, tile_cap, blind_cap;
+    StreamCuts cuts0;
+};
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
                                uint32_t group_len, uint32_t groups, uint32_t *tables, uint32_t *status,
-                               size_t status_words, int compute_units, LaunchEvents ev = {});
+                               size_t status_words, int compute_units, LaunchEvents ev = {},
+                               const FusedPlan *fused = nullptr);
 // host_head: device-visible address of a pinned host copy of the head (written with system-scope stores, `stamp` last)
+// blind_cap: rows of workgroups of the speculatively enqueued passes 1-3 (<= tile_cap)
 hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, OnesweepPlanHead *host_head,
                        uint32_t stamp, uint32_t n, uint32_t group_len, uint32_t groups, uint32_t tile, uint32_t tile_cap,
-                       const StreamCuts &cuts0);
+                       uint32_t blind_cap, const StreamCuts &cuts0);
 // pass = 0..3 inside the group of four the plan was made for, shift = the pass's absolute bit position; the streams
 // come from plan->head (device memory).  grid_tiles: rows of workgroups to launch (>= the pass's max_tiles, which the
 // host may not know yet: tile_cap).  forced: run even if the plan marks an earlier pass abnormal (the host's second

@@ -732,14 +732,6 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
                 total += c[v];
             }
         }
-        if constexpr (LB::kEnabled) {
-            // publish my count at once (successors can add it without waiting for my look-back) and put the first
-            // batch of predecessor rows in flight: the scan and the re-bucketing below hide their latency
-            if (tid < kBins) {
-                lb.publish(total);
-                if (!lb.foreign) lb.fetch(lb.index - 1, lb_rows);
-            }
-        }
         const uint32_t excl = block_exclusive_scan_w<WAVES>(total, sm.scan_tmp, lane, wave);
         if (tid < kBins) {
             uint32_t acc = excl;
@@ -749,6 +741,11 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
                 acc += c[v];
             }
             if constexpr (LB::kEnabled) {
+                // publish my count first (successors can add it without waiting for my look-back), then put the
+                // first batch of predecessor rows in flight: the re-bucketing below hides their latency.  (Both AFTER
+                // the scan: issuing them before it measured 4 us per pass slower, profiles/labs/r02_lookback_order.txt)
+                lb.publish(total);
+                if (!lb.foreign) lb.fetch(lb.index - 1, lb_rows);
                 lb_total = total;
                 lb_excl = excl;
             } else {
@@ -894,6 +891,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
 // Streams follow the data: a pass whose streams cannot be balanced (one group holds far more than 1/kStreams of the
 // keys: keys that are all multiples of 256, say) is marked in the plan and run through the contract path instead.
 
+// fused form of the counting read: the last workgroup to finish also makes the plan (plan == nullptr: separate kernel)
+struct FusedPlanArgs {
+    OnesweepPlan *plan;
+    OnesweepPlanHead *host_head;
+    uint32_t *done;  // ticket counter, zero between launches
+    uint32_t stamp, tile, tile_cap, blind_cap;
+    StreamCuts cuts0;
+};
+
 // LDS row of one group's 256 counters, padded by one word: keys that share the counted digit but not the group
 // (sorted input) would otherwise hit one LDS bank from every lane
 constexpr int kTableRow = kBins + 1;
@@ -987,6 +993,131 @@ __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t
     table_add<V>(t3, i3, lane, (vote & 8u) != 0u);
 }
 
+// one workgroup; thread (p, d).  Merges the GROUPS groups of every pass into kStreams streams of (nearly) equal
+// length -- cuts only between groups, so a stream is still a contiguous range of the pass's input and its seed is a
+// prefix over whole groups -- and leaves `tables` zeroed for the next sort.  The head goes to device memory (the
+// scatter workgroups read their stream from it) and, with system-scope stores, to the pinned host copy (stamp last).
+// A device function of one 1024-thread workgroup: the standalone plan kernel, or the tail of the counting read's LAST
+// workgroup (fused form: no kernel of its own).  The tables are read with agent-scope loads -- in the fused form they
+// were written by other workgroups' atomics in the same launch.
+template <int GROUPS>
+__device__ __forceinline__ void plan_body(uint32_t *__restrict__ tables, OnesweepPlan *__restrict__ plan,
+                                          OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t group_len,
+                                          uint32_t tile, uint32_t tile_cap, uint32_t blind_cap, const StreamCuts &cuts0) {
+    constexpr uint32_t kGroupDigits = kBins / GROUPS;  // digit values of pass p-1 per group of pass p
+    __shared__ uint32_t s_prefix[4][kBins + 1];
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_max[4], s_const[4];
+    __shared__ uint32_t s_cut[4][kStreams + 1];  // first group of every stream
+    __shared__ OnesweepPlanHead s_head;
+    const uint32_t tid = threadIdx.x, p = tid >> 8, d = tid & 255u, lane = tid & 63u, wave = tid >> 6;
+    uint32_t before[GROUPS];
+    uint32_t total = 0;
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g)
+        before[g] = __hip_atomic_load(&tables[(static_cast<size_t>(p) * GROUPS + g) * kBins + d], __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+        const uint32_t c = before[g];
+        before[g] = total;
+        total += c;
+        tables[(static_cast<size_t>(p) * GROUPS + g) * kBins + d] = 0;
+    }
+    uint32_t incl = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t x = __shfl_up(incl, o);
+        if (lane >= static_cast<uint32_t>(o)) incl += x;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    if (tid < 4) {
+        s_max[tid] = 0;
+        s_const[tid] = 0;
+    }
+    __syncthreads();
+    if (total == n) s_const[p] = 1;  // one digit value holds every key
+    uint32_t base = 0;
+    for (uint32_t j = p * 4u; j < wave; ++j) base += s_wave[j];
+    const uint32_t digit_start = base + incl - total;
+    s_prefix[p][d] = digit_start;
+    if (d == 255u) s_prefix[p][kBins] = n;
+    __syncthreads();
+    // where group g of pass q starts in the pass's input
+    const auto group_start = [&](uint32_t q, uint32_t g) -> uint32_t {
+        if (q == 0) {
+            const uint64_t a = static_cast<uint64_t>(g) * group_len;
+            return static_cast<uint32_t>(a < n ? a : n);
+        }
+        return s_prefix[q - 1][g * kGroupDigits];  // g == GROUPS -> n
+    };
+    if (tid < 4u * kStreams) {  // thread (q, k): the cut between streams k-1 and k of pass q
+        const uint32_t q = tid / kStreams, k = tid % kStreams;
+        uint32_t cut = 0;
+        if (q == 0)  // slices of the input: the host made these cuts (it sizes pass 0's grid from them)
+            cut = cuts0.first_group[k];
+        else if (k > 0)
+            cut = balanced_cut([&](uint32_t g) { return s_prefix[q - 1][g * kGroupDigits]; }, n, k, GROUPS);  // [GROUPS] -> n
+        s_cut[q][k] = cut;
+        if (k == 0) s_cut[q][kStreams] = GROUPS;
+    }
+    // where digit d of every group starts in the pass's output; a stream's seed is the row of its first group
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) plan->group_seed[p][g][d] = digit_start + before[g];
+    plan->group_seed[p][GROUPS][d] = digit_start + total;
+    __syncthreads();
+    if (tid < 4u * kStreams) {
+        const uint32_t q = tid / kStreams, s = tid % kStreams;
+        const uint32_t start = group_start(q, s_cut[q][s]), end = group_start(q, s_cut[q][s + 1]);
+        const uint32_t tiles = (end - start + tile - 1u) / tile;
+        s_head.stream[q][s] = StreamDesc{start, end - start, s_cut[q][s], tiles};
+        atomicMax(&s_max[q], tiles);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t first = 4;
+        for (int q = 3; q >= 0; --q) {
+            // pass 0's grid is sized by the host from its own cuts; passes 1-3 were enqueued with blind_cap rows
+            const uint32_t mode = s_const[q]                       ? kPassIdentity
+                                  : s_max[q] > tile_cap            ? kPassUnbalanced
+                                  : (q > 0 && s_max[q] > blind_cap) ? kPassLookbackWide
+                                                                    : kPassLookback;
+            s_head.max_tiles[q] = s_max[q];
+            s_head.mode[q] = mode;
+            if (mode != kPassLookback) first = static_cast<uint32_t>(q);
+        }
+        s_head.first_abnormal = first;
+        s_head.ready = 0;
+    }
+    __syncthreads();
+    if (tid < 4u * kStreams) {  // what a speculatively enqueued pass sees: no tiles from the first abnormal pass on
+        const uint32_t q = tid / kStreams, k = tid % kStreams;
+        StreamDesc d = s_head.stream[q][k];
+        if (q >= s_head.first_abnormal) d.tiles = 0;
+        s_head.blind[q][k] = d;
+    }
+    __syncthreads();
+    constexpr uint32_t kHeadWords = sizeof(OnesweepPlanHead) / sizeof(uint32_t);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&s_head);
+    for (uint32_t i = tid; i < kHeadWords - 1u; i += 4 * kBins)  // every word but `ready` (the last one)
+        reinterpret_cast<uint32_t *>(&plan->head)[i] = src[i];
+    if (host_head && tid < 64u) {  // ONE wave writes the host copy, so one wave's fence orders it before the stamp
+        for (uint32_t i = tid; i < kHeadWords - 1u; i += 64u)
+            __hip_atomic_store(reinterpret_cast<uint32_t *>(host_head) + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        if (tid == 0) __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <int GROUPS>
+__global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ tables, OnesweepPlan *__restrict__ plan,
+                                                        OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n,
+                                                        uint32_t group_len, uint32_t tile, uint32_t tile_cap,
+                                                        uint32_t blind_cap, StreamCuts cuts0) {
+    plan_body<GROUPS>(tables, plan, host_head, stamp, n, group_len, tile, tile_cap, blind_cap, cuts0);
+}
+
+
 // grid = GROUPS * slices workgroups; workgroup (s, g) counts the g-th part of pass-0 group s and zeroes its share
 // of the look-back status words.  group_len (the length of a pass-0 group) is a multiple of 4 * slices.
 // The loads run one step ahead of the counting, vector by vector (a vector's register is refilled for the next step
@@ -996,7 +1127,8 @@ template <typename K, int GROUPS, int THREADS, int COPIES, int UNROLL, int OCC>
 __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__restrict__ keys, uint32_t n,
                                                                     uint32_t base_shift, uint32_t group_len,
                                                                     uint32_t slices, uint32_t *__restrict__ tables,
-                                                                    uint4 *__restrict__ status, uint32_t status_vecs) {
+                                                                    uint4 *__restrict__ status, uint32_t status_vecs,
+                                                                    FusedPlanArgs fp) {
     using Vec = typename KeyVec<K>::type;
     using TI = TableIndex<GROUPS, COPIES>;
     constexpr uint32_t V = KeyVec<K>::kKeys;
@@ -1067,109 +1199,26 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
         const uint32_t x = (&t[0][0])[(c >> 8) * kTableRow + (c & 255u)];
         if (x) __hip_atomic_fetch_add(&tables[GROUPS * kBins + c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-// one workgroup; thread (p, d).  Merges the GROUPS groups of every pass into kStreams streams of (nearly) equal
-// length -- cuts only between groups, so a stream is still a contiguous range of the pass's input and its seed is a
-// prefix over whole groups -- and leaves `tables` zeroed for the next sort.  The head goes to device memory (the
-// scatter workgroups read their stream from it) and, with system-scope stores, to the pinned host copy (stamp last).
-template <int GROUPS>
-__global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ tables, OnesweepPlan *__restrict__ plan,
-                                                        OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n,
-                                                        uint32_t group_len, uint32_t tile, uint32_t tile_cap,
-                                                        StreamCuts cuts0) {
-    constexpr uint32_t kGroupDigits = kBins / GROUPS;  // digit values of pass p-1 per group of pass p
-    __shared__ uint32_t s_prefix[4][kBins + 1];
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_max[4], s_const[4];
-    __shared__ uint32_t s_cut[4][kStreams + 1];  // first group of every stream
-    __shared__ OnesweepPlanHead s_head;
-    const uint32_t tid = threadIdx.x, p = tid >> 8, d = tid & 255u, lane = tid & 63u, wave = tid >> 6;
-    uint32_t before[GROUPS];
-    uint32_t total = 0;
-#pragma unroll
-    for (int g = 0; g < GROUPS; ++g) before[g] = tables[(static_cast<size_t>(p) * GROUPS + g) * kBins + d];
-#pragma unroll
-    for (int g = 0; g < GROUPS; ++g) {
-        const uint32_t c = before[g];
-        before[g] = total;
-        total += c;
-        tables[(static_cast<size_t>(p) * GROUPS + g) * kBins + d] = 0;
-    }
-    uint32_t incl = total;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t x = __shfl_up(incl, o);
-        if (lane >= static_cast<uint32_t>(o)) incl += x;
-    }
-    if (lane == 63u) s_wave[wave] = incl;
-    if (tid < 4) {
-        s_max[tid] = 0;
-        s_const[tid] = 0;
-    }
-    __syncthreads();
-    if (total == n) s_const[p] = 1;  // one digit value holds every key
-    uint32_t base = 0;
-    for (uint32_t j = p * 4u; j < wave; ++j) base += s_wave[j];
-    const uint32_t digit_start = base + incl - total;
-    s_prefix[p][d] = digit_start;
-    if (d == 255u) s_prefix[p][kBins] = n;
-    __syncthreads();
-    // where group g of pass q starts in the pass's input
-    const auto group_start = [&](uint32_t q, uint32_t g) -> uint32_t {
-        if (q == 0) {
-            const uint64_t a = static_cast<uint64_t>(g) * group_len;
-            return static_cast<uint32_t>(a < n ? a : n);
+    if constexpr (THREADS == 4 * kBins) {
+        if (fp.plan != nullptr) {  // fused form: the workgroup that finishes LAST turns the tables into the plan
+            __shared__ uint32_t s_last;
+            // every lane's atomics above must have been performed before this workgroup's ticket is drawn
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint32_t ticket = __hip_atomic_fetch_add(fp.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = ticket == gridDim.x - 1u ? 1u : 0u;
+                if (s_last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    __hip_atomic_store(fp.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+                }
+            }
+            __syncthreads();
+            if (s_last)
+                plan_body<GROUPS>(tables, fp.plan, fp.host_head, fp.stamp, n, group_len, fp.tile, fp.tile_cap, fp.blind_cap, fp.cuts0);
         }
-        return s_prefix[q - 1][g * kGroupDigits];  // g == GROUPS -> n
-    };
-    if (tid < 4u * kStreams) {  // thread (q, k): the cut between streams k-1 and k of pass q
-        const uint32_t q = tid / kStreams, k = tid % kStreams;
-        uint32_t cut = 0;
-        if (q == 0)  // slices of the input: the host made these cuts (it sizes pass 0's grid from them)
-            cut = cuts0.first_group[k];
-        else if (k > 0)
-            cut = balanced_cut([&](uint32_t g) { return s_prefix[q - 1][g * kGroupDigits]; }, n, k, GROUPS);  // [GROUPS] -> n
-        s_cut[q][k] = cut;
-        if (k == 0) s_cut[q][kStreams] = GROUPS;
-    }
-    // where digit d of every group starts in the pass's output; a stream's seed is the row of its first group
-#pragma unroll
-    for (int g = 0; g < GROUPS; ++g) plan->group_seed[p][g][d] = digit_start + before[g];
-    plan->group_seed[p][GROUPS][d] = digit_start + total;
-    __syncthreads();
-    if (tid < 4u * kStreams) {
-        const uint32_t q = tid / kStreams, s = tid % kStreams;
-        const uint32_t start = group_start(q, s_cut[q][s]), end = group_start(q, s_cut[q][s + 1]);
-        const uint32_t tiles = (end - start + tile - 1u) / tile;
-        s_head.stream[q][s] = StreamDesc{start, end - start, s_cut[q][s], tiles};
-        atomicMax(&s_max[q], tiles);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t first = 4;
-        for (int q = 3; q >= 0; --q) {
-            const uint32_t mode = s_const[q] ? kPassIdentity : (s_max[q] > tile_cap ? kPassUnbalanced : kPassLookback);
-            s_head.max_tiles[q] = s_max[q];
-            s_head.mode[q] = mode;
-            if (mode != kPassLookback) first = static_cast<uint32_t>(q);
-        }
-        s_head.first_abnormal = first;
-        s_head.ready = 0;
-    }
-    __syncthreads();
-    constexpr uint32_t kHeadWords = sizeof(OnesweepPlanHead) / sizeof(uint32_t);
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&s_head);
-    for (uint32_t i = tid; i < kHeadWords - 1u; i += 4 * kBins) {  // every word but `ready` (the last one)
-        reinterpret_cast<uint32_t *>(&plan->head)[i] = src[i];
-        if (host_head)
-            __hip_atomic_store(reinterpret_cast<uint32_t *>(host_head) + i, src[i], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (host_head) {
-        __threadfence_system();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1195,8 +1244,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     const uint32_t s = ((blockIdx.x + (misplace ? (i & 1u) : 0u)) & 7u) + 8u * (k % (kStreams / 8));
     // the host enqueued this pass before it knew the plan: a pass at or after the first one that needs another form
     // (identity, unbalanced streams) leaves at once and the host enqueues it again, `forced`, in the right order
-    if (!forced && plan->head.first_abnormal <= pass) return;
-    const StreamDesc sd = plan->head.stream[pass][s];
+    // (the plan keeps a second copy of the streams in which such a pass has no tiles: ONE scalar load decides)
+    const StreamDesc sd = forced ? plan->head.stream[pass][s] : plan->head.blind[pass][s];
     if (i >= sd.tiles) return;  // uniform per workgroup
     const uint32_t done = i * kTile;
     const uint32_t begin = sd.start + done;
@@ -1559,32 +1608,43 @@ static uint32_t floor_pow2(uint32_t x) {
 template <typename K, int GROUPS, int THREADS, int COPIES, int UNROLL, int OCC>
 static void launch_digit_tables_variant(hipStream_t stream, const void *keys, uint32_t n, uint32_t base_shift,
                                         uint32_t group_len, uint32_t *tables, uint32_t *status, size_t status_words,
-                                        int compute_units, LaunchEvents ev) {
+                                        int compute_units, LaunchEvents ev, const FusedPlanArgs &fp) {
     // one workgroup per (pass-0 group, slice): a power-of-two number of slices that fills the chip once
     const uint32_t wgs = static_cast<uint32_t>(compute_units) * (OCC * 256 / THREADS);
     const uint32_t slices = floor_pow2(wgs / GROUPS > 0 ? wgs / GROUPS : 1u);
     const dim3 grid(GROUPS * slices), block(THREADS);
     const uint32_t vecs = static_cast<uint32_t>(status_words / 4);
     VRS_LAUNCH((digit_tables_kernel<K, GROUPS, THREADS, COPIES, UNROLL, OCC>), grid, block, stream, ev,
-               static_cast<const K *>(keys), n, base_shift, group_len, slices, tables, reinterpret_cast<uint4 *>(status), vecs);
+               static_cast<const K *>(keys), n, base_shift, group_len, slices, tables, reinterpret_cast<uint4 *>(status), vecs,
+               fp);
 }
 
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
                                uint32_t group_len, uint32_t groups, uint32_t *tables, uint32_t *status,
-                               size_t status_words, int compute_units, LaunchEvents ev) {
+                               size_t status_words, int compute_units, LaunchEvents ev, const FusedPlan *fused) {
+    FusedPlanArgs fp{};
+    if (fused) {
+        fp.plan = fused->plan;
+        fp.host_head = fused->host_head;
+        fp.done = fused->done;
+        fp.stamp = fused->stamp;
+        fp.tile = fused->tile;
+        fp.tile_cap = fused->tile_cap;
+        fp.blind_cap = fused->blind_cap;
+        fp.cuts0 = fused->cuts0;
+    }
 #define VRS_DT(K, G, T, C, U, O) \
-    launch_digit_tables_variant<K, G, T, C, U, O>(stream, keys, n, base_shift, group_len, tables, status, status_words, compute_units, ev)
-    // (THREADS, COPIES, UNROLL, OCC): 32 groups fill a CU's LDS with one 1024-thread workgroup (131 KiB); 8 groups
-    // leave room for two 512-thread workgroups (57 KiB each)
+    launch_digit_tables_variant<K, G, T, C, U, O>(stream, keys, n, base_shift, group_len, tables, status, status_words, compute_units, ev, fp)
+    // (THREADS, COPIES, UNROLL, OCC): one 1024-thread workgroup per CU (32 groups: 131 KiB of LDS counters, 8 groups: 57)
     if (key_bytes == 8) {
         if (groups == 32) VRS_DT(uint64_t, 32, 1024, 32, VRS_DT_UNROLL, 4);
         else if (groups == 16) VRS_DT(uint64_t, 16, 1024, 32, VRS_DT_UNROLL, 4);
-        else if (groups == 8) VRS_DT(uint64_t, 8, 512, 32, VRS_DT_UNROLL, 4);
+        else if (groups == 8) VRS_DT(uint64_t, 8, 1024, 32, VRS_DT_UNROLL, 4);
         else return hipErrorInvalidValue;
     } else {
         if (groups == 32) VRS_DT(uint32_t, 32, 1024, 32, VRS_DT_UNROLL, 4);
         else if (groups == 16) VRS_DT(uint32_t, 16, 1024, 32, VRS_DT_UNROLL, 4);
-        else if (groups == 8) VRS_DT(uint32_t, 8, 512, 32, VRS_DT_UNROLL, 4);
+        else if (groups == 8) VRS_DT(uint32_t, 8, 1024, 32, VRS_DT_UNROLL, 4);
         else return hipErrorInvalidValue;
     }
 #undef VRS_DT
@@ -1605,14 +1665,14 @@ StreamCuts pass0_stream_cuts(uint32_t n, uint32_t group_len, uint32_t groups) {
 
 hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan, OnesweepPlanHead *host_head,
                        uint32_t stamp, uint32_t n, uint32_t group_len, uint32_t groups, uint32_t tile, uint32_t tile_cap,
-                       const StreamCuts &cuts0) {
+                       uint32_t blind_cap, const StreamCuts &cuts0) {
     const dim3 grid(1), block(4 * kBins);
     if (groups == 32)
-        hipLaunchKernelGGL(plan_kernel<32>, grid, block, 0, stream, tables, plan, host_head, stamp, n, group_len, tile, tile_cap, cuts0);
+        hipLaunchKernelGGL(plan_kernel<32>, grid, block, 0, stream, tables, plan, host_head, stamp, n, group_len, tile, tile_cap, blind_cap, cuts0);
     else if (groups == 16)
-        hipLaunchKernelGGL(plan_kernel<16>, grid, block, 0, stream, tables, plan, host_head, stamp, n, group_len, tile, tile_cap, cuts0);
+        hipLaunchKernelGGL(plan_kernel<16>, grid, block, 0, stream, tables, plan, host_head, stamp, n, group_len, tile, tile_cap, blind_cap, cuts0);
     else if (groups == 8)
-        hipLaunchKernelGGL(plan_kernel<8>, grid, block, 0, stream, tables, plan, host_head, stamp, n, group_len, tile, tile_cap, cuts0);
+        hipLaunchKernelGGL(plan_kernel<8>, grid, block, 0, stream, tables, plan, host_head, stamp, n, group_len, tile, tile_cap, blind_cap, cuts0);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
