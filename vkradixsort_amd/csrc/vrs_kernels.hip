@@ -1160,17 +1160,29 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
         constexpr uint32_t kStep = THREADS * UNROLL;
         uint32_t i0 = 0;
         Vec cur[UNROLL];
+        // The loads of a lane return in issue order, and the compiler's wait before vector r is consumed must hold for
+        // every way into the loop: the scheduling barriers keep the issue order r = 0, 1, ... in the prologue and in the
+        // loop alike, so that wait is "all but the UNROLL - 1 youngest loads" (s_waitcnt vmcnt(UNROLL - 1) before every
+        // vector) instead of one "all but one" at the top of the step.  It measures the same (the kernel runs at the
+        // HBM rate of its 400 MB read plus the write-back of the previous kernel's dirty lines),
+        // but the loads are what the comment above says they are.
         if (kStep <= nvec) {
 #pragma unroll
-            for (int r = 0; r < UNROLL; ++r) cur[r] = v[r * THREADS + tid];
+            for (int r = 0; r < UNROLL; ++r) {
+                cur[r] = v[r * THREADS + tid];
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         for (; i0 + kStep <= nvec; i0 += kStep) {
-            const bool more = i0 + 2u * kStep <= nvec;  // workgroup-uniform
+            // the refill is unconditional (the last step re-reads its own vectors, which nobody consumes): a
+            // conditional load would force the waits to cover the path on which it was not issued
+            const uint32_t refill = i0 + 2u * kStep <= nvec ? i0 + kStep : i0;  // workgroup-uniform
             uint32_t vote = 0;
 #pragma unroll
             for (int r = 0; r < UNROLL; ++r) {
                 const Vec x = cur[r];
-                if (more) cur[r] = v[i0 + kStep + r * THREADS + tid];
+                cur[r] = v[refill + r * THREADS + tid];
+                __builtin_amdgcn_sched_barrier(0);
                 if (r == 0)
                     digit_tables_count_vec<K, TI, true>(t0, t[0], t[1], t[2], x, base_shift, lane, vote);
                 else
