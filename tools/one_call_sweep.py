@@ -41,7 +41,7 @@ def main():
             print(f"{n},{res[0]*1e3:.4f},{res[1]*1e3:.4f},{n/res[0]/1e9:.2f},{n/res[1]/1e9:.2f},{res[0]/res[1]:.3f}", flush=True)
             for b in (src, k0, k1):
                 b.release()
-        gpu.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, 1 << 20)
+        gpu.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, capi.ONE_CALL_MIN_KEYS_DEFAULT)
 
 
 if __name__ == "__main__":

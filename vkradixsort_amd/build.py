@@ -17,7 +17,7 @@ HOST = PKG_DIR / "host"
 INCLUDE = REPO_ROOT / "include"
 LIB_PATH = PKG_DIR / "libvkradixsort_amd.so"
 
-HIP_SOURCES = [CSRC / "vrs_kernels.hip", CSRC / "vrs_capi.hip"]
+HIP_SOURCES = [CSRC / "vrs_kernels.hip", CSRC / "vrs_capi.hip", CSRC / "vrs_dist.hip"]
 HIP_HEADERS = [CSRC / "vrs_kernels.h", INCLUDE / "vkradixsort_amd.h"]
 ARCH = "gfx950"
 
@@ -46,7 +46,7 @@ def build_library(force: bool = False) -> Path:
     """hipcc --offload-arch=gfx950 -> vkradixsort_amd/libvkradixsort_amd.so (kernels + C ABI)."""
     if force or _stale(LIB_PATH, HIP_SOURCES + HIP_HEADERS):
         _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-              f"-I{INCLUDE}", f"-I{CSRC}", *HIP_SOURCES, "-o", LIB_PATH])
+              f"-I{INCLUDE}", f"-I{CSRC}", *HIP_SOURCES, "-ldl", "-o", LIB_PATH])
     return LIB_PATH
 
 

@@ -36,6 +36,7 @@ VRS_TUNE_SCATTER_VARIANT = 1
 VRS_TUNE_FUSED_PREFIX = 2
 VRS_TUNE_RANK_MODE = 3
 VRS_TUNE_ONE_CALL_MIN_KEYS = 4
+ONE_CALL_MIN_KEYS_DEFAULT = 1 << 13  # the library's default for VRS_TUNE_ONE_CALL_MIN_KEYS
 VRS_TUNE_DEBUG_MISPLACE_STREAMS = 5
 VRS_TUNE_LOOKBACK_SPIN_BUDGET = 6
 VRS_TUNE_DEBUG_HOLD_TILE = 7
@@ -100,6 +101,11 @@ _SIGNATURES = [
     ("vrs_profile_enable", c_int, [c_void_p, c_int]),
     ("vrs_profile_enable_mask", c_int, [c_void_p, c_uint32]),
     ("vrs_verify_keys_u32", c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
+    ("vrs_dist_create", c_int, [c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, POINTER(c_void_p)]),
+    ("vrs_dist_destroy", c_int, [c_void_p]),
+    ("vrs_dist_sort_keys_u32", c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_void_p), POINTER(c_uint32)]),
+    ("vrs_dist_plan_splitters", c_int, [POINTER(c_uint64), c_int, POINTER(c_uint32)]),
+    ("vrs_dist_last_error", c_char_p, [c_void_p]),
     ("vrs_profile_reset", c_int, [c_void_p]),
     ("vrs_profile_query", c_int, [c_void_p, c_int, POINTER(c_uint64), POINTER(c_double)]),
     ("vrs_profile_query_launch", c_int, [c_void_p, c_int, c_uint64, POINTER(c_double)]),

@@ -49,7 +49,7 @@ struct vrs_context_t {
     std::vector<EventPair> events[VRS_KERNEL_COUNT];
     size_t events_used[VRS_KERNEL_COUNT] = {};
     // one-call sort for large N (K5 in vrs_kernels.hip)
-    uint32_t one_call_min_keys = 1u << 20;
+    uint32_t one_call_min_keys = 1u << 13;  // measured: the one-read form wins from the single-launch threshold on (profiles/r02_one_call_crossover.csv)
     uint32_t single_max_keys = 4096;     // one-call uint32 key sorts up to this size run as ONE single_radixsort launch
     uint32_t *os_tables = nullptr;       // [4][kStreams][256] digit tables, zero between sorts
     vrs::OnesweepPlan *os_plan = nullptr;

@@ -1432,9 +1432,30 @@ __device__ __forceinline__ unsigned long long mix_key(uint32_t k) {
 __global__ __launch_bounds__(kThreads) void verify_keys_kernel(const uint32_t *__restrict__ keys, uint32_t n,
                                                                unsigned long long *__restrict__ out) {
     unsigned long long inv = 0, sum = 0, mix = 0;
-    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * kThreads) {
-        const uint32_t k = keys[i];
-        if (i + 1 < n && k > keys[i + 1]) ++inv;
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads, t = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x;
+    // 16-byte loads behind a scalar head (the buffer may be a 4-byte aligned sub-range); the element after a vector
+    // is one extra cached 4-byte load
+    const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys) / 4u) % 4u);
+    const uint32_t head = min(mis ? 4u - mis : 0u, n);
+    if (t < head) {
+        const uint32_t k = keys[t];
+        if (t + 1 < n && k > keys[t + 1]) ++inv;
+        sum += k;
+        mix += mix_key(k);
+    }
+    const uint4 *v = reinterpret_cast<const uint4 *>(keys + head);
+    const size_t nvec = (n - head) / 4u;
+    for (size_t i = t; i < nvec; i += stride) {
+        const uint4 q = v[i];
+        const size_t next = head + 4u * i + 4u;
+        inv += (q.x > q.y) + (q.y > q.z) + (q.z > q.w) + (next < n && q.w > keys[next] ? 1u : 0u);
+        sum += static_cast<unsigned long long>(q.x) + q.y + q.z + q.w;
+        mix += mix_key(q.x) + mix_key(q.y) + mix_key(q.z) + mix_key(q.w);
+    }
+    const size_t tail = head + 4u * nvec + t;  // at most 3 keys
+    if (tail < n) {
+        const uint32_t k = keys[tail];
+        if (tail + 1 < n && k > keys[tail + 1]) ++inv;
         sum += k;
         mix += mix_key(k);
     }
@@ -1453,7 +1474,7 @@ __global__ __launch_bounds__(kThreads) void verify_keys_kernel(const uint32_t *_
 
 hipError_t launch_verify_keys(hipStream_t stream, const uint32_t *keys, uint32_t n, unsigned long long *out3) {
     if (n == 0) return hipSuccess;
-    const uint32_t blocks = min((n + kThreads - 1) / kThreads, 8192u);
+    const uint32_t blocks = min((n / 4u + kThreads - 1) / kThreads + 1u, 4096u);
     hipLaunchKernelGGL(verify_keys_kernel, dim3(blocks), dim3(kThreads), 0, stream, keys, n, out3);
     return hipGetLastError();
 }
