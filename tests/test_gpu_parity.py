@@ -788,6 +788,27 @@ def test_range_sharded_sort_small_keys_take_the_sampled_splitter_path(oracle):
         dist.destroy_process_group()
 
 
+def test_product_backend_handles_an_empty_shard():
+    """a rank may hold no keys.  Both C-ABI stages launch nothing for N == 0, so the backend must not read
+    an offset row that was never written: every top byte starts at position 0."""
+    torch = pytest.importorskip("torch")
+    from vkradixsort_amd.distributed import HipLocalSortBackend
+    backend = HipLocalSortBackend(0, capacity=1 << 20)
+    try:
+        keys = torch.from_numpy(rand_keys(300000, 3).view(np.int32)).cuda()
+        grouped, base = backend.group_by_top_byte(keys, 300000)  # leaves a non-trivial offset row behind
+        torch.cuda.synchronize()
+        assert int(base[-1].item()) > 0
+        grouped, base = backend.group_by_top_byte(keys[:0], 0)
+        torch.cuda.synchronize()
+        assert int(base.abs().sum().item()) == 0
+        g2, first = backend.partition_by_splitters(keys[:0], 0, np.array([10, 20, 30], dtype=np.uint32))
+        assert first.tolist() == [0, 0, 0, 0, 0]
+        assert backend.sort(keys[:0], 0).numel() == 0
+    finally:
+        backend.close()
+
+
 def _dist_step(ctx, comm, keys, rounds, capacity=None):
     """one vrs_dist_sort_keys_u32 step at world size 1 -> (sorted range as numpy, count)"""
     lib = ctx.lib

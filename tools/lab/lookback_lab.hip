@@ -85,7 +85,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_marks), &null_marks, sizeof(null_marks)));
     Ev e_dt, e_p[4], e_x;
     uint32_t stamp = 0;
-    printf("n=%u groups=%u tile_cap=%u tiles0=%u cooperative look-back\n", n, G, tile_cap, tiles0);
+    printf("n=%u groups=%u tile_cap=%u tiles0=%u\n", n, G, tile_cap, tiles0);
 
     auto one_sort = [&](bool marks_pass, int which) {
         CK(hipMemcpyAsync(d_a, d_src, (size_t)n * 4, hipMemcpyDeviceToDevice, st));

@@ -1629,7 +1629,7 @@ hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks) 
     return hipGetLastError();
 }
 
-uint32_t onesweep_tile_keys(int key_bytes) { return key_bytes == 8 ? 4096u : 8192u; }
+uint32_t onesweep_tile_keys(int key_bytes) { return key_bytes == 8 ? 4096u : VRS_LB_ITEMS * 512u; }
 
 // largest power of two <= x (x >= 1)
 static uint32_t floor_pow2(uint32_t x) {
@@ -1728,9 +1728,9 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
         if (pairs) return hipErrorInvalidValue;  // no one-call pairs entry point for 64-bit keys
         if (atomic_rank) VRS_ONESWEEP(uint64_t, 8, false, RANK_ATOMIC); else VRS_ONESWEEP(uint64_t, 8, false, RANK_BALLOT);
     } else if (pairs) {
-        if (atomic_rank) VRS_ONESWEEP(uint32_t, 16, true, RANK_ATOMIC); else VRS_ONESWEEP(uint32_t, 16, true, RANK_BALLOT);
+        if (atomic_rank) VRS_ONESWEEP(uint32_t, VRS_LB_ITEMS, true, RANK_ATOMIC); else VRS_ONESWEEP(uint32_t, VRS_LB_ITEMS, true, RANK_BALLOT);
     } else {
-        if (atomic_rank) VRS_ONESWEEP(uint32_t, 16, false, RANK_ATOMIC); else VRS_ONESWEEP(uint32_t, 16, false, RANK_BALLOT);
+        if (atomic_rank) VRS_ONESWEEP(uint32_t, VRS_LB_ITEMS, false, RANK_ATOMIC); else VRS_ONESWEEP(uint32_t, VRS_LB_ITEMS, false, RANK_BALLOT);
     }
 #undef VRS_ONESWEEP
     return hipGetLastError();

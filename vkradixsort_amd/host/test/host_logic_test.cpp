@@ -69,6 +69,20 @@ int main() {
     }
     CHECK(threw);
 
+    // sortPairs(): the CPU reference of the pairs extension -- std::stable_sort by key, payloads follow their keys
+    {
+        std::vector<uint32_t> pk = {5u, 1u, 5u, 0u, 1u, 5u};
+        std::vector<uint32_t> pv = {0u, 1u, 2u, 3u, 4u, 5u};
+        const double pms = MultiRadixSort::sortPairs(pk, pv);
+        CHECK(pms >= 0.0);
+        CHECK((pk == std::vector<uint32_t>{0u, 1u, 1u, 5u, 5u, 5u}));
+        CHECK((pv == std::vector<uint32_t>{3u, 1u, 4u, 0u, 2u, 5u}));  // ties keep their input order
+        std::vector<uint64_t> pk64 = {9ull << 40, 3ull, 9ull << 40};
+        std::vector<uint32_t> pv64 = {7u, 8u, 9u};
+        MultiRadixSort64::sortPairs(pk64, pv64);
+        CHECK(pk64[0] == 3ull && pv64[0] == 8u && pv64[1] == 7u && pv64[2] == 9u);
+    }
+
     // push-constant blocks stay the reference's 16-byte layout
     static_assert(sizeof(engine::MultiRadixSortPass::PushConstants) == 16, "PushConstants");
     static_assert(sizeof(engine::MultiRadixSortPass::PushConstantsHistograms) == 16, "PushConstantsHistograms");
