@@ -291,7 +291,8 @@ typedef enum vrs_tuning_key {
                                      context creation, else __ballot ranking; 1 force ballot; 2 force atomic */
     VRS_TUNE_ONE_CALL_MIN_KEYS = 4, /* vrs_sort_keys_u32 / _u64 / vrs_sort_pairs_u32 count all four digits in ONE read
                                      and scatter with decoupled look-back (36 instead of 48 bytes per key) from this many
-                                     keys on; 0 = never (always the contract passes).  Default 2^20. */
+                                     keys on; 0 = never (always the contract passes).  Default 2^13: it is the faster form at every
+                                     size above the single-launch threshold (profiles/r02_one_call_crossover.csv). */
     VRS_TUNE_DEBUG_MISPLACE_STREAMS = 5, /* test hook (default 0): run every other tile of a look-back stream behind a
                                      different XCD's L2, i.e. without the placement the fast hand-off relies on */
     VRS_TUNE_LOOKBACK_SPIN_BUDGET = 6, /* polls of a predecessor's unpublished look-back row before a tile stops waiting

@@ -185,7 +185,7 @@ class HipLocalSortBackend(LocalSortBackend):
             return keys
         if n > self.capacity or keys.numel() < n:
             raise ValueError("received more keys than the backend capacity")
-        # the library's own four-pass loop (one counting read + look-back scatters from 2^20 keys on); the result is
+        # the library's own four-pass loop (one counting read + look-back scatters from 2^13 keys on); the result is
         # back in `keys`, `scratch` is the ping-pong partner
         ctx = self.ctx
         k, t = self._handles(keys, self.scratch)
@@ -275,9 +275,12 @@ class RangeShardedSort:
             mine_s = keys[:n][idx] if n else torch.zeros(S, dtype=keys.dtype, device=self.device)
             pool = torch.empty(world * S, dtype=keys.dtype, device=self.device)
             dist.all_gather_into_tensor(pool, mine_s.contiguous(), group=self.group)
-            sample = np.sort(pool.cpu().numpy().view(np.uint32))
+            # sort the pooled sample where it is (unsigned order on int32 storage: flip the sign bit), bring back only
+            # the P - 1 splitters
             P = world * R
-            splitters = sample[(np.arange(1, P) * sample.size) // P]
+            flipped = torch.sort(pool.to(torch.int32) ^ (-2 ** 31)).values
+            picks = torch.from_numpy((np.arange(1, P) * pool.numel()) // P).to(self.device)
+            splitters = (flipped[picks] ^ (-2 ** 31)).cpu().numpy().view(np.uint32)
             grouped, base = self.backend.partition_by_splitters(keys, n, splitters)
             local = np.diff(base)  # P ranges
             mine2 = torch.from_numpy(local.astype(np.int64)).to(self.device)

@@ -345,7 +345,7 @@ class MultiRadixSort:
         self.quiet = quiet
         # False (default): enqueueSort() drives the two stages pass by pass like the reference's loop.  True: the
         # library runs the passes itself (vrs_sort_keys_u32 / _u64 / vrs_sort_pairs_u32: one counting read + look-back
-        # scatter passes from 2^20 keys on).  Same buffers, same result in buffer 0.  (C++: m_oneCallSort.)
+        # scatter passes from 2^13 keys on).  Same buffers, same result in buffer 0.  (C++: m_oneCallSort.)
         self.m_oneCallSort = False
         self.gpuSortTime = None
         self.cpuSortTime = None

@@ -30,7 +30,7 @@ public:
 
     // false (default): execute() drives the two stages pass by pass, exactly like the reference's loop
     // (MultiRadixSort.cpp:50-61).  true: the library runs the passes itself (vrs_sort_keys_u32 / _u64) -- for 32-bit
-    // keys from 2^20 elements on that is ONE counting read plus four look-back scatter passes, 36 instead of
+    // keys from 2^13 elements on that is ONE counting read plus four look-back scatter passes, 36 instead of
     // 48 bytes per key.  Same buffers, same result in buffer 0.
     bool m_oneCallSort = false;
 
