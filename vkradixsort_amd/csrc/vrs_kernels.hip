@@ -44,6 +44,9 @@
 #ifndef VRS_LB_STAT
 #define VRS_LB_STAT(polls, rows, trips)
 #endif
+#ifndef VRS_LB_ITEMS
+#define VRS_LB_ITEMS 16  // keys per thread of a look-back tile of uint32 keys: 8192-key tiles (labs: 12 / 20 / 24 measure the same or worse)
+#endif
 #ifndef VRS_LB_BATCH
 #define VRS_LB_BATCH 4
 #endif
