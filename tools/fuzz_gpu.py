@@ -72,7 +72,15 @@ def main():
             keys, kind = make_keys(rs, n, bits64)
             vals = rs.randint(0, 2 ** 32, n, dtype=np.uint32) if pairs else None
             if one_call:
-                ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, int(rs.choice([0, 1, n, max(1, n // 2), 1 << 20])))
+                ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, int(rs.choice([0, 1, n, max(1, n // 2), 1 << 20, capi.ONE_CALL_MIN_KEYS_DEFAULT])))
+                # round 2 knobs: group count of the counting read, fused plan, single-launch threshold, and (rarely) a
+                # withheld look-back tile with a small spin budget -- none of them may change a result
+                ctx.setTuning(capi.VRS_TUNE_DIGIT_TABLE_GROUPS, int(rs.choice([0, 8, 16, 32])))
+                ctx.setTuning(capi.VRS_TUNE_FUSED_PLAN, int(rs.randint(0, 2)))
+                ctx.setTuning(capi.VRS_TUNE_SINGLE_MAX_KEYS, int(rs.choice([0, 4096, 4096, 20000])))
+                hold = rs.randint(0, 8) == 0
+                ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, int(rs.randint(0, 6)) if hold else -1)
+                ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, int(rs.choice([0, 3, 40])) if hold else 4096)
                 kb = keys.itemsize
                 off = int(rs.randint(0, 16 // kb))
                 g0, g1 = keys.dtype.type(0x11111111), keys.dtype.type(0x22222222)
@@ -101,7 +109,9 @@ def main():
                     v1.release()
                 for b in (k0, k1, big):
                     b.release()
-                ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, 1 << 20)
+                ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, capi.ONE_CALL_MIN_KEYS_DEFAULT)
+                ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, -1)
+                ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 4096)
                 cases += 1
                 if not ok:
                     print(f"MISMATCH one-call n={n} bits64={bits64} pairs={pairs} kind={kind} mode={mode} off={off} seed={seed} case={cases}")
