@@ -247,7 +247,8 @@ typedef enum vrs_kernel_id {
     VRS_KERNEL_SINGLE = 3,    /* single_radixsort */
     VRS_KERNEL_DIGIT_TABLES = 4,     /* one-call sort, large N: the single counting read of all four digits */
     VRS_KERNEL_LOOKBACK_SCATTER = 5, /* one-call sort, large N: stable scatter with decoupled look-back */
-    VRS_KERNEL_COUNT = 6
+    VRS_KERNEL_LOCAL_SORT = 6,       /* one-call sort, hybrid form: every top-14-bit bucket sorted inside LDS */
+    VRS_KERNEL_COUNT = 7
 } vrs_kernel_id;
 
 /* When enabled, every kernel launch carries a (start, stop) hipEvent pair on its own dispatch packet
@@ -278,6 +279,8 @@ int vrs_one_call_stats(vrs_context ctx, uint64_t *lookback_passes, uint64_t *fal
  * left at once because an earlier pass needed another form or because the pass's longest stream did not fit the
  * speculative grid.  Cumulative; diagnostics only. */
 int vrs_one_call_relaunched_passes(vrs_context ctx, uint64_t *relaunched_passes);
+/* One-call sorts that took the hybrid form (VRS_TUNE_HYBRID).  Cumulative; diagnostics only. */
+int vrs_one_call_hybrid_sorts(vrs_context ctx, uint64_t *hybrid_sorts);
 
 /* Ranking method in effect: 1 = __ballot match-any, 2 = returning LDS atomics. */
 int vrs_rank_mode(vrs_context ctx);
@@ -301,6 +304,11 @@ typedef enum vrs_tuning_key {
                                      its counts, so its successors must run out of spin budget and recount */
     VRS_TUNE_DIGIT_TABLE_GROUPS = 8, /* groups per pass of the one-call sort's counting read: 8, 16, 32, or 0 (default):
                                      8 below 2^26 keys, 32 from there on */
+    VRS_TUNE_HYBRID = 11,          /* vrs_sort_keys_u32 of large inputs: 1 (default) = the 28-byte-per-key hybrid form (MSD
+                                     partition by the top 14 bits in two look-back passes + an LDS-local sort of every
+                                     bucket) whenever every bucket fits a workgroup's LDS, else the four LSD passes (decided
+                                     on the device from the same counting read); 0 = always the LSD passes */
+    VRS_TUNE_HYBRID_MIN_KEYS = 12, /* the hybrid form is considered from this many keys on (default 2^26; at least 2^22) */
     VRS_TUNE_FUSED_PLAN = 10,      /* 1: the last workgroup of the one-call sort's counting read turns the digit tables
                                      into the plan; 0 (default): a separate single-workgroup plan kernel (measured a
                                      tie at 10^7 and 10^8 keys) */

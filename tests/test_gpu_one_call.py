@@ -437,9 +437,115 @@ def test_one_read_sort_u64(gpu_context, n, dist):
 
 
 def test_one_read_sort_1e8_equals_std_sort(gpu_context, oracle):
-    """BASELINE.json config 3 through the one-call entry point."""
+    """BASELINE.json config 3 through the one-call entry point, in both of its large-N forms: the hybrid one (MSD
+    partition by the top 14 bits in two look-back passes + an LDS-local sort of every bucket, 28 B/key: the default at this
+    size) and the four LSD look-back passes (36 B/key)."""
     n = 10 ** 8
     keys = np.random.RandomState(1).randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    ref = oracle.std_sort(keys)[0]
     out, stats = sort_keys(gpu_context, keys)
-    assert stats["lookback_scatter"] == 4 and stats["digit_tables"] == 1
+    assert stats["digit_tables"] == 1 and stats["lookback_scatter"] == 2 and stats["local_sort"] == 1
+    assert oracle.test_sort(ref, out) == -1
+    gpu_context.setTuning(capi.VRS_TUNE_HYBRID, 0)
+    try:
+        out, stats = sort_keys(gpu_context, keys)
+    finally:
+        gpu_context.setTuning(capi.VRS_TUNE_HYBRID, 1)
+    assert stats["lookback_scatter"] == 4 and stats["digit_tables"] == 1 and stats["local_sort"] == 0
+    assert oracle.test_sort(ref, out) == -1
+
+
+def hybrid_sorts(ctx):
+    h = ctypes.c_uint64()
+    ctx.check(ctx.lib.vrs_one_call_hybrid_sorts(ctx.handle, ctypes.byref(h)))
+    return h.value
+
+
+HYBRID_DISTS = ["uniform", "sorted", "reverse", "28bit", "16bit", "const", "max_keys", "clustered", "two_values", "mult256",
+                "low18_const", "one_hot_bucket"]
+
+
+def make_hybrid_keys(n, dist, seed):
+    if dist == "low18_const":  # every bucket holds one distinct key: the local sort sees one digit value in both passes
+        return make_keys(n, "uniform", seed) & np.uint32(0xFFFC0000)
+    if dist == "one_hot_bucket":  # one top-14-bit bucket with far more keys than a workgroup can hold: must fall back
+        k = make_keys(n, "uniform", seed)
+        k[: n // 20] = (k[: n // 20] & np.uint32(0x3FFFF)) | np.uint32(0x56780000)
+        return k
+    return make_keys(n, dist, seed)
+
+
+@pytest.mark.parametrize("dist", HYBRID_DISTS)
+@pytest.mark.parametrize("n", [(1 << 22) + 1, 9000001])
+def test_hybrid_form_equals_std_sort(gpu_context, oracle, n, dist):
+    """The hybrid form at sizes a test can afford (VRS_TUNE_HYBRID_MIN_KEYS lowered to 2^22): buckets of a few hundred
+    keys, ragged tiles in every top-byte bucket of the second pass, empty buckets, and distributions whose buckets cannot
+    fit a workgroup (the plan must say no and the four LSD passes must run from the SAME counting read)."""
+    ctx = gpu_context
+    keys = make_hybrid_keys(n, dist, seed=n % 313)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    h0 = hybrid_sorts(ctx)
+    try:
+        out, stats = sort_keys(ctx, keys)
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+    took = hybrid_sorts(ctx) - h0
     assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    assert stats["digit_tables"] == 1
+    top14 = np.bincount(keys >> np.uint32(18), minlength=1 << 14)
+    fits = int(top14.max()) <= 6656
+    assert took == (1 if fits else 0), (dist, int(top14.max()))
+    if fits:
+        assert stats["lookback_scatter"] == 2 and stats["local_sort"] == 1 and stats["scatter"] == 0
+    else:
+        assert stats["local_sort"] == 0 and stats["lookback_scatter"] + stats["scatter"] == 4 - identity_passes(keys)
+
+
+@pytest.mark.parametrize("hook", ["misplace", "hold", "ballot"])
+def test_hybrid_form_under_the_look_back_hooks(gpu_context, hook):
+    """The first MSD pass is the ordinary look-back kernel: XCD misplacement and a withheld tile must be survived there;
+    with ballot ranking forced the hybrid form is off (its local sort ranks with returning LDS atomics)."""
+    ctx = gpu_context
+    n = (1 << 23) + 4321
+    keys = make_keys(n, "uniform", seed=91)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    if hook == "misplace":
+        ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 1)
+    elif hook == "hold":
+        ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, 2)
+        ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 8)
+    else:
+        ctx.setTuning(capi.VRS_TUNE_RANK_MODE, 1)
+    h0 = hybrid_sorts(ctx)
+    try:
+        out, stats = sort_keys(ctx, keys)
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+        ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 0)
+        ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, -1)
+        ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 4096)
+        ctx.setTuning(capi.VRS_TUNE_RANK_MODE, 0)
+    assert np.array_equal(out, np.sort(keys))
+    assert hybrid_sorts(ctx) - h0 == (0 if hook == "ballot" else 1)
+
+
+def test_hybrid_form_leaves_pairs_and_wide_keys_to_the_lsd_passes(gpu_context, oracle):
+    ctx, lib, n = gpu_context, gpu_context.lib, (1 << 22) + 99
+    keys = make_keys(n, "uniform", seed=17) & np.uint32(0xFFFFFF)
+    vals = np.arange(n, dtype=np.uint32)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    h0 = hybrid_sorts(ctx)
+    try:
+        k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)
+        v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
+        k1, v1 = vrs.Buffer(ctx, S(4 * n)), vrs.Buffer(ctx, S(4 * n))
+        ctx.check(lib.vrs_sort_pairs_u32(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+        ok, ov = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        k0.downloadWithStagingBuffer(ok)
+        v0.downloadWithStagingBuffer(ov)
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+    rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
+    assert np.array_equal(ok, rk) and np.array_equal(ov, rv) and hybrid_sorts(ctx) == h0
+    for b in (k0, k1, v0, v1):
+        b.release()

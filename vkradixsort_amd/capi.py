@@ -24,8 +24,10 @@ VRS_KERNEL_SCATTER = 2
 VRS_KERNEL_SINGLE = 3
 VRS_KERNEL_DIGIT_TABLES = 4
 VRS_KERNEL_LOOKBACK_SCATTER = 5
-VRS_KERNEL_COUNT = 6
-KERNEL_NAMES = {0: "histogram", 1: "prefix", 2: "scatter", 3: "single", 4: "digit_tables", 5: "lookback_scatter"}
+VRS_KERNEL_LOCAL_SORT = 6
+VRS_KERNEL_COUNT = 7
+KERNEL_NAMES = {0: "histogram", 1: "prefix", 2: "scatter", 3: "single", 4: "digit_tables", 5: "lookback_scatter",
+                6: "local_sort"}
 
 VRS_KEYS_INT32 = 0
 VRS_KEYS_FLOAT32_TO_SORTABLE = 1
@@ -43,6 +45,8 @@ VRS_TUNE_DEBUG_HOLD_TILE = 7
 VRS_TUNE_DIGIT_TABLE_GROUPS = 8
 VRS_TUNE_SINGLE_MAX_KEYS = 9
 VRS_TUNE_FUSED_PLAN = 10
+VRS_TUNE_HYBRID = 11
+VRS_TUNE_HYBRID_MIN_KEYS = 12
 
 
 class PushConstants(Structure):
@@ -111,6 +115,7 @@ _SIGNATURES = [
     ("vrs_profile_query_launch", c_int, [c_void_p, c_int, c_uint64, POINTER(c_double)]),
     ("vrs_one_call_stats", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
     ("vrs_one_call_relaunched_passes", c_int, [c_void_p, POINTER(c_uint64)]),
+    ("vrs_one_call_hybrid_sorts", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_debug_download_offsets", c_int, [c_void_p, c_void_p, c_size_t]),
     ("vrs_debug_atomic_rank_selftest", c_int, [c_void_p, c_uint32, c_uint32, POINTER(c_uint64)]),
     ("vrs_rank_mode", c_int, [c_void_p]),

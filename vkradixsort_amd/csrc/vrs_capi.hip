@@ -67,7 +67,14 @@ struct vrs_context_t {
     bool xcc_map_valid = false;          // the probe found block b on an XCC that depends on b % 8 only
     unsigned long long xcc_map = 0;      // byte x = that XCC for b % 8 == x
     uint64_t os_lookback_passes = 0;
-    uint64_t os_relaunched_passes = 0;   // look-back passes enqueued a second time (first enqueue left at once: see sort_one_read)
+    uint64_t os_relaunched_passes = 0;
+    // hybrid form (K5b): uint32 keys from 2^24 on
+    bool os_hybrid = true;               // VRS_TUNE_HYBRID
+    uint32_t os_hybrid_min_keys = 1u << 26;  // VRS_TUNE_HYBRID_MIN_KEYS
+    uint32_t *os_msd_counts = nullptr;   // [16384] top-14-bit histogram + [8][256] top-byte counts per pass-0 group, zero between sorts
+    vrs::MsdPlan *os_msd_plan = nullptr;
+    vrs::OnesweepPlan *os_plan_a = nullptr;  // seeds and streams of the first MSD pass
+    uint64_t os_hybrid_sorts = 0;   // look-back passes enqueued a second time (first enqueue left at once: see sort_one_read)
     uint64_t os_fallback_passes = 0;
     uint64_t os_skipped_passes = 0;      // identity passes (one digit value holds every key) the one-call sort left out     // passes the one-call sort ran through the contract path (unbalanced streams)
 };
@@ -380,6 +387,9 @@ int vrs_context_destroy(vrs_context ctx) {
     if (ctx->os_plan) (void)hipFree(ctx->os_plan);
     if (ctx->os_status) (void)hipFree(ctx->os_status);
     if (ctx->os_host_head) (void)hipHostFree(ctx->os_host_head);
+    if (ctx->os_msd_counts) (void)hipFree(ctx->os_msd_counts);
+    if (ctx->os_msd_plan) (void)hipFree(ctx->os_msd_plan);
+    if (ctx->os_plan_a) (void)hipFree(ctx->os_plan_a);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VRS_OK;
@@ -660,7 +670,16 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
     // groups per pass: 32 let the streams follow skewed data more closely, but every workgroup of the counting read
     // flushes 3 * G * 256 counters -- a fixed cost that only large inputs amortise (10^7 keys: 20 vs 34 us for the
     // counting read, 3 * 10^7: 47 vs 61, 10^8: a tie; profiles/labs/r02_groups_and_fused_plan.txt)
-    const uint32_t G = ctx->os_groups ? ctx->os_groups : (n < (1u << 26) ? 8u : 32u);
+    // Hybrid form (K5b): uint32 keys only, from os_hybrid_min_keys on (default 2^26: the 16384 buckets are then at least
+    // 60 % full -- below, the fixed cost per bucket workgroup outweighs the saved pass: measured crossover 6-7 * 10^7
+    // keys); above about 1.03 * 10^8 uniform keys the largest bucket no longer fits a workgroup's LDS and the plan says
+    // no.  Its local sort ranks with returning LDS atomics, so the lane-order self-test must have passed.  The counting
+    // read then also fills the top-14-bit histogram, which needs the 8-group tables to fit beside it in LDS.
+    const bool msd_capable = key_bytes == 4 && !values && ctx->os_hybrid && ctx->atomic_rank_verified &&
+                             ctx->scatter.atomic_rank && n >= ctx->os_hybrid_min_keys && n >= (1u << 22) &&
+                             static_cast<uint64_t>(n) <= 2ull * vrs::kMsdBucketCount * vrs::msd_local_capacity() &&
+                             (ctx->os_groups == 0 || ctx->os_groups == 8);
+    const uint32_t G = msd_capable ? 8u : ctx->os_groups ? ctx->os_groups : (n < (1u << 26) ? 8u : 32u);
     const uint32_t T = vrs::onesweep_tile_keys(key_bytes);
     const uint32_t tiles_total = (n + T - 1) / T;
     const uint32_t group_tiles = (tiles_total + G - 1) / G;  // tiles per pass-0 group (slice of the input)
@@ -705,7 +724,27 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
     // them cost 3-4 us per pass, profiles/labs/r02_blind_grid.txt), so the slack is small; a pass whose longest stream
     // needs more -- but no more than tile_cap -- leaves at once and is launched again with its exact grid.
     const uint32_t blind_cap = std::min(tile_cap, even + even / 64 + 2);
-    const size_t rows = static_cast<size_t>(S) * tile_cap;  // status rows: one region for all four passes (tagged words)
+    // second MSD pass: every XCD walks 32 top-byte buckets, each rounded up to whole tiles
+    const uint32_t tiles_b_cap = even + even / 4 + 40;
+    const size_t rows = static_cast<size_t>(S) * std::max(tile_cap, msd_capable ? tiles_b_cap : 0u);  // status rows: one region for all passes (tagged words)
+    if (msd_capable && !ctx->os_msd_counts) {
+        uint32_t *counts = nullptr;
+        vrs::MsdPlan *mp = nullptr;
+        vrs::OnesweepPlan *pa = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&counts), vrs::kMsdCountWords * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(counts, 0, vrs::kMsdCountWords * sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&mp), sizeof(vrs::MsdPlan));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pa), sizeof(vrs::OnesweepPlan));
+        if (e != hipSuccess) {
+            if (pa) (void)hipFree(pa);
+            if (mp) (void)hipFree(mp);
+            if (counts) (void)hipFree(counts);
+            return fail_hip(ctx, "hybrid sort scratch allocation", e);
+        }
+        ctx->os_msd_counts = counts;
+        ctx->os_msd_plan = mp;
+        ctx->os_plan_a = pa;
+    }
     if (rows > ctx->os_status_rows) {
         if (ctx->os_status) {
             VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -728,6 +767,8 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         bool armed = false;
         ~TablesGuard() {
             if (armed) (void)hipMemsetAsync(ctx->os_tables, 0, (vrs::kDigitTableWords + 64) * sizeof(uint32_t), ctx->stream);
+            if (armed && ctx->os_msd_counts)
+                (void)hipMemsetAsync(ctx->os_msd_counts, 0, vrs::kMsdCountWords * sizeof(uint32_t), ctx->stream);
         }
     } guard{ctx};
     // where the data lives: buffers[0] = caller's keys / values, buffers[1] = the ping-pong partners.  A pass whose digit
@@ -754,21 +795,62 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         const uint32_t stamp = ctx->os_stamp;
         guard.armed = true;
         const vrs::FusedPlan fused{ctx->os_plan, ctx->os_host_head_dev, ctx->os_ticket, stamp, T, tile_cap, blind_cap, cuts0};
-        VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, group_len, G,
-                                              ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS,
-                                              ctx->scatter.compute_units, ev, ctx->os_fused_plan ? &fused : nullptr));
-        if (!ctx->os_fused_plan)
-            VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, ctx->os_host_head_dev, stamp, n,
-                                          group_len, G, T, tile_cap, blind_cap, cuts0));
+        if (msd_capable) {
+            // hybrid: the same read also fills the top-14-bit histogram; the LSD plan is made as always (without the
+            // stamp), then msd_plan_kernel decides which form runs, arms exactly one of the two first passes and stamps
+            VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, kbuf[cur]->ptr, n, group_len, ctx->os_tables, ctx->os_status,
+                                                      rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts, ev));
+            VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, ctx->os_host_head_dev, 0u, n, group_len, G, T,
+                                          tile_cap, blind_cap, cuts0));
+            VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
+                                              ctx->os_host_head_dev, stamp, n, T, tiles_b_cap, 1u));
+        } else {
+            VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, group_len, G,
+                                                  ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS,
+                                                  ctx->scatter.compute_units, ev, ctx->os_fused_plan ? &fused : nullptr));
+            if (!ctx->os_fused_plan)
+                VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, ctx->os_host_head_dev, stamp, n,
+                                              group_len, G, T, tile_cap, blind_cap, cuts0));
+        }
         guard.armed = false;
-        // all four passes at once, before the plan is known here; pass 0's streams are the host's own cuts
+        // speculative launches, before the plan is known here.  LSD form: all four passes (pass 0's streams are the host's
+        // own cuts).  Hybrid-capable sort: only the two candidate FIRST passes -- the LSD pass 0 and the first MSD pass
+        // (same buffers; the plan arms exactly one, the other leaves at once) -- the rest follows once the head is here,
+        // while that first pass runs.
         const uint32_t cur_at_start = cur;
         const size_t events_before = ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER];
-        for (uint32_t i = 0; i < 4; ++i)
+        const uint32_t blind_passes = msd_capable ? 1u : 4u;
+        for (uint32_t i = 0; i < blind_passes; ++i)
             if ((rc = lookback_pass(i, 32u * group + 8u * i, i == 0 ? tiles0 : blind_cap, false))) return rc;
+        if (msd_capable) {
+            if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+            VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kbuf[cur_at_start]->ptr, kbuf[cur_at_start ^ 1u]->ptr, nullptr,
+                                                      nullptr, ctx->os_plan_a, 0, 24, ctx->os_status, tiles0, false,
+                                                      ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes, ctx->os_spin_budget,
+                                                      ctx->os_hold_tile, ev, ctx->os_misplace));
+        }
         if ((rc = wait_for_plan(ctx, stamp))) return rc;
         const vrs::OnesweepPlanHead &head = *ctx->os_host_head;
-        const uint32_t q = std::min<uint32_t>(head.first_abnormal, 4u);
+        const bool timed = (ctx->profile_mask & (1u << VRS_KERNEL_LOOKBACK_SCATTER)) != 0;
+        if (msd_capable && head.msd_ok) {
+            // hybrid form: the first MSD pass is running (keys -> partner); second pass back, then the buckets in place
+            if (timed) {  // the LSD pass 0 left at once: hand its events back, keep the MSD pass's
+                std::swap(ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][events_before], ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][events_before + 1]);
+                ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + 1;
+            }
+            if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+            VRS_HIP(ctx, vrs::launch_msd_pass_b(ctx->stream, static_cast<const uint32_t *>(kbuf[cur_at_start ^ 1u]->ptr),
+                                                static_cast<uint32_t *>(kbuf[cur_at_start]->ptr), ctx->os_msd_plan, ctx->os_status,
+                                                head.msd_tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map, ctx->os_spin_budget, ev));
+            if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
+            VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(kbuf[cur_at_start]->ptr), ctx->os_msd_plan, ev));
+            cur = cur_at_start;
+            ctx->os_hybrid_sorts++;
+            continue;
+        }
+        if (msd_capable && timed)  // the first MSD pass left at once: hand its events back
+            ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + 1;
+        const uint32_t q = std::min<uint32_t>(head.first_abnormal, blind_passes);
         ctx->os_lookback_passes += q;
         if (q == 4) continue;  // four look-back passes: the data is back where it started (cur unchanged)
         // passes q..3 left at once on the device: take back their (untouched) buffers and timing events, enqueue them again
@@ -788,7 +870,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
                 if ((rc = contract_pass(ctx, kin, kout, vin, vout, &pc, shift, key_bytes))) return rc;
             } else {
                 ctx->os_lookback_passes++;
-                ctx->os_relaunched_passes++;
+                if (i < blind_passes) ctx->os_relaunched_passes++;
                 if ((rc = lookback_pass(i, shift, head.max_tiles[i], true))) return rc;
             }
         }
@@ -1058,6 +1140,12 @@ int vrs_one_call_relaunched_passes(vrs_context ctx, uint64_t *relaunched_passes)
     return VRS_OK;
 }
 
+int vrs_one_call_hybrid_sorts(vrs_context ctx, uint64_t *hybrid_sorts) {
+    if (!ctx || !hybrid_sorts) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or output is NULL");
+    *hybrid_sorts = ctx->os_hybrid_sorts;
+    return VRS_OK;
+}
+
 int vrs_rank_mode(vrs_context ctx) { return ctx && ctx->scatter.atomic_rank ? 2 : 1; }
 
 int vrs_set_tuning(vrs_context ctx, int key, int value) {
@@ -1090,6 +1178,13 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             return VRS_OK;
         case VRS_TUNE_DEBUG_MISPLACE_STREAMS:
             ctx->os_misplace = value != 0;
+            return VRS_OK;
+        case VRS_TUNE_HYBRID:
+            ctx->os_hybrid = value != 0;
+            return VRS_OK;
+        case VRS_TUNE_HYBRID_MIN_KEYS:
+            if (value < 0) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "hybrid threshold must be >= 0");
+            ctx->os_hybrid_min_keys = static_cast<uint32_t>(value);
             return VRS_OK;
         case VRS_TUNE_FUSED_PLAN:
             ctx->os_fused_plan = value != 0;

@@ -94,6 +94,9 @@ struct OnesweepPlanHead {
                                 // stream longer than tile_cap tiles: contract pass) / kPassLookbackWide (a stream longer
                                 // than the speculative grid but within tile_cap: look-back pass, launched again)
     uint32_t first_abnormal;    // smallest p with mode[p] != kPassLookback, 4 if there is none
+    uint32_t msd_ok;            // hybrid form (K5b): 1 = the MSD passes and the local sort take over (set by msd_plan_kernel)
+    uint32_t msd_tiles_b;       // rows of workgroups of the second MSD pass
+    uint32_t msd_max_bucket;    // keys in the largest top-14-bit bucket
     uint32_t ready;             // host copy only: the sort's stamp, written after everything else
 };
 struct OnesweepPlan {
@@ -153,6 +156,35 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
                                    uint32_t *status, uint32_t grid_tiles, bool forced, bool atomic_rank,
                                    unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, int hold_tile,
                                    LaunchEvents ev = {}, bool misplace = false);
+// ---- hybrid form of the one-call sort (K5b, uint32 keys): MSD partition by the top 14 bits in two look-back passes,
+// then one workgroup per bucket sorts the low 18 bits inside LDS.
+constexpr uint32_t kMsdBucketCount = 1u << 14;
+struct MsdPlan {
+    uint32_t xcd_tiles[8][33];            // XCD x walks top-byte buckets x, x+8, ...: exclusive prefix of their tile counts
+    uint32_t base[kMsdBucketCount + 1];   // exclusive prefix of the bucket sizes = where bucket b starts when sorted
+};
+// words the hybrid's counting needs beside the digit tables: the 16384-bin histogram + 8 x 256 top-byte counts per
+// pass-0 group, zero between sorts
+constexpr size_t kMsdCountWords = kMsdBucketCount + 8u * 256u;
+// same as launch_digit_tables with 8 groups, and fills msd_counts (uint32 keys only)
+hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *tables,
+                                   uint32_t *status, size_t status_words, int compute_units, uint32_t *msd_counts,
+                                   LaunchEvents ev = {});
+// after launch_plan(..., stamp = 0): bucket offsets, the first MSD pass's seeds (into plan_a->group_seed[0]) and streams,
+// the second pass's tile tables; decides msd_ok (largest bucket <= the local sort's capacity, XCD tile counts <=
+// tiles_b_cap), arms exactly one of the two speculative first passes (plan_a's or plan_lsd's blind descriptors), writes
+// the msd_* words of the host head and stamps it
+hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
+                           OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
+                           uint32_t tiles_b_cap, uint32_t enabled);
+// second MSD pass: bits [18, 24) inside every top-byte bucket; grid of 8 * tiles_b workgroups; status rows: 8 * tiles_b
+hipError_t launch_msd_pass_b(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const MsdPlan *msd,
+                             uint32_t *status, uint32_t tiles_b, bool atomic_rank, unsigned long long xcc_map,
+                             uint32_t spin_budget, LaunchEvents ev = {});
+// every bucket sorted by its low 18 bits, in place
+hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, const MsdPlan *msd, LaunchEvents ev = {});
+uint32_t msd_local_capacity();
+
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups
 hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks);
 

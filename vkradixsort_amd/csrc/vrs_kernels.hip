@@ -698,9 +698,22 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     uint32_t *my_hist = sm.whist[wave];
     if constexpr (RANK == RANK_ATOMIC) {
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i)
-            rank[i] = __hip_atomic_fetch_add(&my_hist[dg(key[i])], 1u, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t d = dg(key[i]);
+#ifndef VRS_NO_UNIFORM_GUARD
+            // Skew guard: 64 lanes on ONE counter are served one after the other (28 instead of 9 cycles per wave
+            // instruction) -- input whose 64 consecutive keys share the digit (sorted keys under an MSD digit, constant
+            // bytes) would crawl.  A wave-uniform digit needs no atomic per lane: lane 0 adds 64, rank = old + lane.
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+            if (__ballot(d == d0) == ~0ull) {  // wave-uniform branch
+                uint32_t old = 0;
+                if (lane == 0u)
+                    old = __hip_atomic_fetch_add(&my_hist[d0], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rank[i] = __builtin_amdgcn_readfirstlane(old) + lane;
+            } else
+#endif
+                rank[i] = __hip_atomic_fetch_add(&my_hist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -894,6 +907,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
 // Streams follow the data: a pass whose streams cannot be balanced (one group holds far more than 1/kStreams of the
 // keys: keys that are all multiples of 256, say) is marked in the plan and run through the contract path instead.
 
+// ---- K5b, hybrid form of the one-call sort for uint32 keys (28 instead of 36 bytes per key): an MSD partition by the top
+// kMsdBits bits in two look-back scatter passes (8 + 6 bits), then every bucket (about N / 16384 keys) is sorted by its
+// low 18 bits inside ONE workgroup's LDS and written back once.
+constexpr uint32_t kMsdBits = 14, kMsdShift = 32 - kMsdBits, kMsdBuckets = 1u << kMsdBits;
+constexpr uint32_t kMsdSubBits = kMsdBits - 8, kMsdSub = 1u << kMsdSubBits;  // buckets per top byte: 64
+constexpr int kLocalThreads = 256, kLocalItems = 26;                          // local sort: capacity 6656 keys per bucket
+constexpr uint32_t kLocalCap = kLocalThreads * kLocalItems;
+
 // fused form of the counting read: the last workgroup to finish also makes the plan (plan == nullptr: separate kernel)
 struct FusedPlanArgs {
     OnesweepPlan *plan;
@@ -964,21 +985,24 @@ __device__ __forceinline__ uint32_t digit_word(uint64_t key, uint32_t base_shift
     return static_cast<uint32_t>(key >> base_shift);
 }
 
+// hm: the 16384-bin histogram of the key's top 14 bits (hybrid form, K5b), or nullptr
 template <typename TI>
-__device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t w) {
+__device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t *hm,
+                                                   uint32_t w) {
     atomicAdd(&t0[TI::t0(w, lane_id())], 1u);
     atomicAdd(&t1[TI::t1(w)], 1u);
     atomicAdd(&t2[TI::t2(w)], 1u);
     atomicAdd(&t3[TI::t3(w)], 1u);
+    if (hm) atomicAdd(&hm[w >> kMsdShift], 1u);
 }
 
 // one 16-byte vector of keys per lane: 4 uint32 or 2 uint64.  vote: bit t = table t takes the run-length form
-template <typename K, typename TI, bool VOTE>
-__device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3,
+template <typename K, typename TI, bool VOTE, bool MSD>
+__device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t *hm,
                                                        const typename KeyVec<K>::type &q, uint32_t base_shift,
                                                        uint32_t lane, uint32_t &vote) {
     constexpr int V = KeyVec<K>::kKeys;
-    uint32_t i0[V], i1[V], i2[V], i3[V];
+    uint32_t i0[V], i1[V], i2[V], i3[V], im[MSD ? V : 1];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         const uint32_t w = digit_word(KeyVec<K>::get(q, j), base_shift);
@@ -986,14 +1010,18 @@ __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t
         i1[j] = TI::t1(w);
         i2[j] = TI::t2(w);
         i3[j] = TI::t3(w);
+        if constexpr (MSD) im[j] = w >> kMsdShift;
     }
-    if constexpr (VOTE)
+    if constexpr (VOTE) {
         vote = (table_vote<V>(i0) ? 1u : 0u) | (table_vote<V>(i1) ? 2u : 0u) | (table_vote<V>(i2) ? 4u : 0u) |
                (table_vote<V>(i3) ? 8u : 0u);
+        if constexpr (MSD) vote |= table_vote<V>(im) ? 16u : 0u;
+    }
     table_add<V>(t0, i0, lane, (vote & 1u) != 0u);
     table_add<V>(t1, i1, lane, (vote & 2u) != 0u);
     table_add<V>(t2, i2, lane, (vote & 4u) != 0u);
     table_add<V>(t3, i3, lane, (vote & 8u) != 0u);
+    if constexpr (MSD) table_add<V>(hm, im, lane, (vote & 16u) != 0u);
 }
 
 // one workgroup; thread (p, d).  Merges the GROUPS groups of every pass into kStreams streams of (nearly) equal
@@ -1108,7 +1136,8 @@ __device__ __forceinline__ void plan_body(uint32_t *__restrict__ tables, Oneswee
         for (uint32_t i = tid; i < kHeadWords - 1u; i += 64u)
             __hip_atomic_store(reinterpret_cast<uint32_t *>(host_head) + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __threadfence_system();
-        if (tid == 0) __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // stamp == 0: another kernel (msd_plan_kernel) completes the head and stamps it
+        if (tid == 0 && stamp != 0u) __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1126,18 +1155,26 @@ __global__ __launch_bounds__(4 * kBins) void plan_kernel(uint32_t *__restrict__ 
 // The loads run one step ahead of the counting, vector by vector (a vector's register is refilled for the next step
 // as soon as it has been consumed), so UNROLL 16-byte loads per lane are in flight all the time.  64-bit keys are sorted
 // in two groups of four passes, each with its own counting read: base_shift = 0, then 32.
-template <typename K, int GROUPS, int THREADS, int COPIES, int UNROLL, int OCC>
+// MSD (hybrid form, K5b; uint32 keys, GROUPS == 8): the same read also fills a 16384-bin histogram of the top 14 bits
+// (msd_hist) and, per pass-0 group, the 256 top-byte counts the MSD pass needs as its streams' seeds (msd_slices).
+template <typename K, int GROUPS, int THREADS, int COPIES, int UNROLL, int OCC, bool MSD = false>
 __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__restrict__ keys, uint32_t n,
                                                                     uint32_t base_shift, uint32_t group_len,
                                                                     uint32_t slices, uint32_t *__restrict__ tables,
                                                                     uint4 *__restrict__ status, uint32_t status_vecs,
-                                                                    FusedPlanArgs fp) {
+                                                                    FusedPlanArgs fp, uint32_t *__restrict__ msd_hist,
+                                                                    uint32_t *__restrict__ msd_slices) {
     using Vec = typename KeyVec<K>::type;
     using TI = TableIndex<GROUPS, COPIES>;
     constexpr uint32_t V = KeyVec<K>::kKeys;
     __shared__ uint32_t t0[kBins * COPIES];
     __shared__ uint32_t t[3][GROUPS * kTableRow];
+    __shared__ uint32_t s_msd[MSD ? kMsdBuckets : 1];
+    uint32_t *const hm = MSD ? s_msd : nullptr;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if constexpr (MSD) {
+        for (uint32_t c = tid; c < kMsdBuckets; c += THREADS) s_msd[c] = 0;
+    }
     for (uint32_t c = tid; c < 3u * GROUPS * kTableRow; c += THREADS) (&t[0][0])[c] = 0;
     for (uint32_t c = tid; c < static_cast<uint32_t>(kBins * COPIES); c += THREADS) t0[c] = 0;
     {
@@ -1157,7 +1194,7 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
         // allocation; every slice starts a multiple of V keys after it)
         const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) / sizeof(K)) % V);
         const uint32_t head = min((V - mis) % V, len);
-        if (tid < head) digit_tables_count<TI>(t0, t[0], t[1], t[2], digit_word(keys[begin + tid], base_shift));
+        if (tid < head) digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, digit_word(keys[begin + tid], base_shift));
         const Vec *v = reinterpret_cast<const Vec *>(keys + begin + head);
         const uint32_t nvec = (len - head) / V;
         constexpr uint32_t kStep = THREADS * UNROLL;
@@ -1187,19 +1224,19 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
                 cur[r] = v[refill + r * THREADS + tid];
                 __builtin_amdgcn_sched_barrier(0);
                 if (r == 0)
-                    digit_tables_count_vec<K, TI, true>(t0, t[0], t[1], t[2], x, base_shift, lane, vote);
+                    digit_tables_count_vec<K, TI, true, MSD>(t0, t[0], t[1], t[2], hm, x, base_shift, lane, vote);
                 else
-                    digit_tables_count_vec<K, TI, false>(t0, t[0], t[1], t[2], x, base_shift, lane, vote);
+                    digit_tables_count_vec<K, TI, false, MSD>(t0, t[0], t[1], t[2], hm, x, base_shift, lane, vote);
             }
         }
         for (uint32_t i = i0 + tid; i < nvec; i += THREADS) {
             const Vec q = v[i];
 #pragma unroll
             for (int j = 0; j < static_cast<int>(V); ++j)
-                digit_tables_count<TI>(t0, t[0], t[1], t[2], digit_word(KeyVec<K>::get(q, j), base_shift));
+                digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, digit_word(KeyVec<K>::get(q, j), base_shift));
         }
         const uint32_t tail = head + nvec * V + tid;  // at most V - 1 keys
-        if (tail < len) digit_tables_count<TI>(t0, t[0], t[1], t[2], digit_word(keys[begin + tail], base_shift));
+        if (tail < len) digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, digit_word(keys[begin + tail], base_shift));
     }
     __syncthreads();
     for (uint32_t d = tid; d < static_cast<uint32_t>(kBins); d += THREADS) {
@@ -1213,6 +1250,20 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
     for (uint32_t c = tid; c < 3u * GROUPS * kBins; c += THREADS) {  // c = (pass - 1, group, digit)
         const uint32_t x = (&t[0][0])[(c >> 8) * kTableRow + (c & 255u)];
         if (x) __hip_atomic_fetch_add(&tables[GROUPS * kBins + c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if constexpr (MSD) {
+        // top-14-bit histogram; the top-byte counts of this workgroup's pass-0 group are the sums of 64 sub-bins each
+        for (uint32_t c = tid; c < kMsdBuckets; c += THREADS) {
+            const uint32_t x = s_msd[c];
+            if (x) __hip_atomic_fetch_add(&msd_hist[c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < kBins) {
+            uint32_t sum = 0;
+            for (uint32_t j = 0; j < kMsdBuckets / kBins; ++j) sum += s_msd[tid * (kMsdBuckets / kBins) + ((j + tid) % (kMsdBuckets / kBins))];
+            if (sum)
+                __hip_atomic_fetch_add(&msd_slices[static_cast<size_t>(s) * kBins + tid], sum, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if constexpr (THREADS == 4 * kBins) {
         if (fp.plan != nullptr) {  // fused form: the workgroup that finishes LAST turns the tables into the plan
@@ -1297,6 +1348,280 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
         scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused,
                                                           lb);
     VRS_MARK_FLUSH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5b: the hybrid form's own kernels (the counting read is digit_tables_kernel<..., MSD = true>, the first MSD pass is
+// onesweep_scatter_kernel on bits 24-31 with the eight input slices as streams).
+
+// a digit of fewer than 8 bits: (key >> shift) & mask
+struct BitsDigit {
+    uint32_t shift, mask;
+    __device__ __forceinline__ uint32_t operator()(uint32_t key) const { return (key >> shift) & mask; }
+};
+
+// One 1024-thread workgroup, after plan_kernel.  counts = [16384] top-14-bit histogram, then [8][256] top-byte counts per
+// pass-0 group (both left zeroed for the next sort).
+__global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ counts, MsdPlan *__restrict__ msd,
+                                                       OnesweepPlan *__restrict__ plan_a, OnesweepPlan *__restrict__ plan_lsd,
+                                                       OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
+                                                       uint32_t tiles_b_cap, uint32_t enabled) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_start[kBins + 1];  // where top byte a starts
+    __shared__ uint32_t s_tiles[kBins];
+    __shared__ uint32_t s_max, s_tiles_b, s_ok;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    constexpr uint32_t kPer = kMsdBuckets / 1024u;  // 16 buckets per thread
+    if (tid == 0) {
+        s_max = 0;
+        s_tiles_b = 0;
+    }
+    // (1) exclusive prefix over the 16384 buckets
+    uint32_t c[kPer], sum = 0, mx = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) {
+        c[j] = counts[tid * kPer + j];
+        counts[tid * kPer + j] = 0;
+        sum += c[j];
+        mx = max(mx, c[j]);
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= static_cast<uint32_t>(o)) incl += t;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    atomicMax(&s_max, mx);
+    uint32_t run = incl - sum;
+    for (uint32_t j = 0; j < wave; ++j) run += s_wave[j];
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) {
+        const uint32_t b = tid * kPer + j;
+        msd->base[b] = run;
+        if ((b & (kMsdSub - 1u)) == 0u) s_start[b >> kMsdSubBits] = run;
+        run += c[j];
+    }
+    if (tid == 1023u) {
+        msd->base[kMsdBuckets] = run;  // == n
+        s_start[kBins] = run;
+    }
+    __syncthreads();
+    // (2) seeds of the first MSD pass: where top byte a of pass-0 group g goes = start of a + its keys in earlier groups
+    uint32_t *slices = counts + kMsdBuckets;
+    if (tid < kBins) {
+        uint32_t before = s_start[tid];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            plan_a->group_seed[0][g][tid] = before;
+            before += slices[g * kBins + tid];
+            slices[g * kBins + tid] = 0;
+        }
+        plan_a->group_seed[0][8][tid] = before;
+        // (3) tiles of top-byte bucket a in the second pass
+        s_tiles[tid] = (s_start[tid + 1] - s_start[tid] + tile - 1u) / tile;
+    }
+    __syncthreads();
+    if (tid < 8u) {  // XCD tid walks buckets tid, tid + 8, ...
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < 32u; ++k) {
+            msd->xcd_tiles[tid][k] = acc;
+            acc += s_tiles[tid + 8u * k];
+        }
+        msd->xcd_tiles[tid][32] = acc;
+        atomicMax(&s_tiles_b, acc);
+    }
+    __syncthreads();
+    if (tid == 0) s_ok = (enabled != 0u && s_max <= kLocalCap && s_tiles_b <= tiles_b_cap) ? 1u : 0u;
+    __syncthreads();
+    // (4) the first MSD pass's streams are pass 0's (slices of the input); exactly one of the two speculatively enqueued
+    //     first passes is armed
+    if (tid < static_cast<uint32_t>(kStreams)) {
+        StreamDesc d = plan_lsd->head.stream[0][tid];
+        plan_a->head.stream[0][tid] = d;
+        if (!s_ok) d.tiles = 0;
+        plan_a->head.blind[0][tid] = d;
+        if (s_ok) plan_lsd->head.blind[0][tid].tiles = 0;
+    }
+    if (tid == 0) {
+        plan_a->head.first_abnormal = 4;
+        plan_lsd->head.msd_ok = s_ok;
+        plan_lsd->head.msd_tiles_b = s_tiles_b;
+        plan_lsd->head.msd_max_bucket = s_max;
+        if (host_head) {
+            __hip_atomic_store(&host_head->msd_ok, s_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_head->msd_tiles_b, s_tiles_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_head->msd_max_bucket, s_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// Second MSD pass: inside every top-byte bucket (a contiguous range of the first pass's output) a stable scatter by bits
+// 18-23 -- the look-back machinery with one chain per bucket.  Block b -> XCD b % 8, which walks its 32 buckets in order;
+// status row of (XCD x, its j-th tile) = j * 8 + x, so a bucket's tiles are 8 rows apart like a stream's.
+template <int RANK>
+__global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out,
+                                                            const MsdPlan *__restrict__ msd, uint32_t *__restrict__ status,
+                                                            unsigned long long xcc_map, uint32_t spin_budget) {
+    constexpr uint32_t kTile = 16 * 8 * 64;
+    __shared__ ChunkSmem<uint32_t, 16, 8, false> sm;
+    const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const uint32_t *pt = msd->xcd_tiles[x];
+    if (j >= pt[32]) return;  // uniform per workgroup
+    uint32_t k = 0;           // the bucket whose tiles contain j: largest k with pt[k] <= j
+#pragma unroll
+    for (uint32_t step = 16; step >= 1; step >>= 1)
+        if (pt[k + step] <= j) k += step;
+    const uint32_t a = x + 8u * k, i = j - pt[k];
+    const uint32_t first = msd->base[a << kMsdSubBits], last = msd->base[(a + 1u) << kMsdSubBits];
+    const uint32_t done = i * kTile;
+    const uint32_t begin = first + done;
+    const uint32_t valid = min(kTile, last - begin);
+    BitsDigit dg{kMsdShift, kMsdSub - 1u};
+    StreamLookback lb;
+    lb.foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * x)) & 0xFFu);
+    lb.stream_keys = keys_in + first;
+    lb.done = done;
+    if (lb.foreign) {
+        uint32_t *cnt = sm.whist[0];
+        if (threadIdx.x < kBins) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        recount_keys(cnt, keys_in + first, done, dg);
+        __syncthreads();
+        if (threadIdx.x < kBins) lb.recounted = cnt[threadIdx.x];
+        __syncthreads();
+    }
+    lb.col = status + (static_cast<size_t>(pt[k]) * 8u + x) * kBins + (threadIdx.x & 255u);
+    lb.stride = static_cast<size_t>(8) * kBins;
+    lb.index = static_cast<int>(i);
+    lb.tag = 6u << kLbTagShift;
+    lb.budget = spin_budget;
+    lb.seed = threadIdx.x < kMsdSub ? msd->base[(a << kMsdSubBits) + threadIdx.x] : 0u;
+    uint32_t unused = 0;
+    if (valid == kTile)
+        scatter_chunk<uint32_t, 16, 8, false, RANK, true>(sm, keys_in + begin, nullptr, keys_out, nullptr, valid, dg, unused, lb);
+    else
+        scatter_chunk<uint32_t, 16, 8, false, RANK, false>(sm, keys_in + begin, nullptr, keys_out, nullptr, valid, dg, unused, lb);
+}
+
+// One stable LSD pass over the keys a workgroup holds in registers (wave-striped: wave v owns ITEMS * 64 consecutive
+// positions, item i of lane l is position v * ITEMS * 64 + i * 64 + l), through LDS: per-wave counters fed by returning
+// LDS atomics (lane order: the RANK_ATOMIC property), a scan over bins and waves, re-bucketing, striped read-back.
+template <int THREADS, int ITEMS, int BITS>
+__device__ __forceinline__ void local_pass(uint32_t (&key)[ITEMS], uint32_t *s_keys, uint32_t *s_hist, uint32_t *s_tmp,
+                                           uint32_t shift) {
+    constexpr int WAVES = THREADS / 64, BINS = 1 << BITS;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t c = tid; c < WAVES * BINS; c += THREADS) s_hist[c] = 0;
+    if (tid == 0) s_tmp[0] = 0;
+    __syncthreads();
+    uint32_t *my = s_hist + wave * BINS;
+    uint32_t rank[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t d = (key[i] >> shift) & (BINS - 1);
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__ballot(d == d0) == ~0ull) {  // wave-uniform digit (padding, constant bits): one add instead of 64 on one counter
+            uint32_t old = 0;
+            if (lane == 0u) old = __hip_atomic_fetch_add(&my[d0], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            rank[i] = __builtin_amdgcn_readfirstlane(old) + lane;
+        } else {
+            rank[i] = __hip_atomic_fetch_add(&my[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < BINS; b0 += THREADS) {  // THREADS bins per stride
+        const uint32_t b = b0 + tid;
+        uint32_t c[WAVES], total = 0;
+        if (b < BINS) {
+#pragma unroll
+            for (int v = 0; v < WAVES; ++v) {
+                c[v] = s_hist[v * BINS + b];
+                total += c[v];
+            }
+        }
+        uint32_t incl = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= static_cast<uint32_t>(o)) incl += t;
+        }
+        if (lane == 63u) s_tmp[1 + wave] = incl;
+        __syncthreads();
+        uint32_t base = s_tmp[0];  // keys in the earlier strides
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) base += (static_cast<uint32_t>(v) < wave) ? s_tmp[1 + v] : 0u;
+        if (b < BINS) {
+            uint32_t acc = base + incl - total;
+#pragma unroll
+            for (int v = 0; v < WAVES; ++v) {
+                s_hist[v * BINS + b] = acc;
+                acc += c[v];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t t = s_tmp[0];
+            for (int v = 0; v < WAVES; ++v) t += s_tmp[1 + v];
+            s_tmp[0] = t;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) rank[i] += my[(key[i] >> shift) & (BINS - 1)];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) s_keys[rank[i]] = key[i];
+    __syncthreads();
+    const uint32_t seg = wave * (ITEMS * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) key[i] = s_keys[seg + i * 64];
+    __syncthreads();
+}
+
+// the bucket with ITEMS keys per thread (n <= ITEMS * kLocalThreads): read once, two stable 9-bit passes, written back
+template <int ITEMS>
+__device__ __forceinline__ void local_sort_bucket(uint32_t *bucket, uint32_t n, uint32_t *s_keys, uint32_t *s_hist, uint32_t *s_tmp) {
+    constexpr int BITS = 9;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t key[ITEMS];
+    const uint32_t seg = wave * (ITEMS * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t idx = seg + i * 64;
+        const uint32_t k = bucket[idx < n ? idx : n - 1u];
+        key[i] = idx < n ? k : 0xFFFFFFFFu;  // padding sorts behind every real key of the bucket and is not written
+    }
+    local_pass<kLocalThreads, ITEMS, BITS>(key, s_keys, s_hist, s_tmp, 0);
+    local_pass<kLocalThreads, ITEMS, BITS>(key, s_keys, s_hist, s_tmp, BITS);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t idx = seg + i * 64;
+        if (idx < n) bucket[idx] = key[i];
+    }
+}
+
+// One workgroup per bucket of the MSD partition (<= kLocalCap keys, guaranteed by the plan), sorted by its low 18 bits
+// inside LDS, in place.  The keys-per-thread count is picked per bucket (workgroup-uniform), so the work follows the
+// bucket's size, not the capacity.
+__global__ __launch_bounds__(kLocalThreads, 4) void msd_local_sort_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd) {
+    constexpr int WAVES = kLocalThreads / 64;
+    __shared__ uint32_t s_keys[kLocalCap];
+    __shared__ uint32_t s_hist[WAVES << 9];
+    __shared__ uint32_t s_tmp[1 + WAVES];
+    const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
+    if (n == 0 || n > kLocalCap) return;  // uniform; n > capacity cannot happen (the plan would have refused)
+    uint32_t *bucket = keys + begin;
+    const uint32_t used = (n + kLocalThreads - 1u) / kLocalThreads;
+    if (used <= 4) local_sort_bucket<4>(bucket, n, s_keys, s_hist, s_tmp);
+    else if (used <= 8) local_sort_bucket<8>(bucket, n, s_keys, s_hist, s_tmp);
+    else if (used <= 12) local_sort_bucket<12>(bucket, n, s_keys, s_hist, s_tmp);
+    else if (used <= 16) local_sort_bucket<16>(bucket, n, s_keys, s_hist, s_tmp);
+    else if (used <= 20) local_sort_bucket<20>(bucket, n, s_keys, s_hist, s_tmp);
+    else if (used <= 24) local_sort_bucket<24>(bucket, n, s_keys, s_hist, s_tmp);
+    else local_sort_bucket<kLocalItems>(bucket, n, s_keys, s_hist, s_tmp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1641,19 +1966,56 @@ static uint32_t floor_pow2(uint32_t x) {
     return p;
 }
 
-template <typename K, int GROUPS, int THREADS, int COPIES, int UNROLL, int OCC>
+template <typename K, int GROUPS, int THREADS, int COPIES, int UNROLL, int OCC, bool MSD = false>
 static void launch_digit_tables_variant(hipStream_t stream, const void *keys, uint32_t n, uint32_t base_shift,
                                         uint32_t group_len, uint32_t *tables, uint32_t *status, size_t status_words,
-                                        int compute_units, LaunchEvents ev, const FusedPlanArgs &fp) {
+                                        int compute_units, LaunchEvents ev, const FusedPlanArgs &fp,
+                                        uint32_t *msd_counts = nullptr) {
     // one workgroup per (pass-0 group, slice): a power-of-two number of slices that fills the chip once
     const uint32_t wgs = static_cast<uint32_t>(compute_units) * (OCC * 256 / THREADS);
     const uint32_t slices = floor_pow2(wgs / GROUPS > 0 ? wgs / GROUPS : 1u);
     const dim3 grid(GROUPS * slices), block(THREADS);
     const uint32_t vecs = static_cast<uint32_t>(status_words / 4);
-    VRS_LAUNCH((digit_tables_kernel<K, GROUPS, THREADS, COPIES, UNROLL, OCC>), grid, block, stream, ev,
+    VRS_LAUNCH((digit_tables_kernel<K, GROUPS, THREADS, COPIES, UNROLL, OCC, MSD>), grid, block, stream, ev,
                static_cast<const K *>(keys), n, base_shift, group_len, slices, tables, reinterpret_cast<uint4 *>(status), vecs,
-               fp);
+               fp, msd_counts, msd_counts ? msd_counts + kMsdBuckets : nullptr);
 }
+
+hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *tables,
+                                   uint32_t *status, size_t status_words, int compute_units, uint32_t *msd_counts,
+                                   LaunchEvents ev) {
+    launch_digit_tables_variant<uint32_t, 8, 1024, 32, VRS_DT_UNROLL, 4, true>(stream, keys, n, 0, group_len, tables, status,
+                                                                               status_words, compute_units, ev,
+                                                                               FusedPlanArgs{}, msd_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
+                           OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
+                           uint32_t tiles_b_cap, uint32_t enabled) {
+    hipLaunchKernelGGL(msd_plan_kernel, dim3(1), dim3(1024), 0, stream, msd_counts, msd, plan_a, plan_lsd, host_head, stamp, n,
+                       tile, tiles_b_cap, enabled);
+    return hipGetLastError();
+}
+
+hipError_t launch_msd_pass_b(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const MsdPlan *msd,
+                             uint32_t *status, uint32_t tiles_b, bool atomic_rank, unsigned long long xcc_map,
+                             uint32_t spin_budget, LaunchEvents ev) {
+    if (tiles_b == 0) return hipSuccess;
+    const dim3 grid(8 * tiles_b), block(512);
+    if (atomic_rank)
+        VRS_LAUNCH(msd_pass_b_kernel<RANK_ATOMIC>, grid, block, stream, ev, keys_in, keys_out, msd, status, xcc_map, spin_budget);
+    else
+        VRS_LAUNCH(msd_pass_b_kernel<RANK_BALLOT>, grid, block, stream, ev, keys_in, keys_out, msd, status, xcc_map, spin_budget);
+    return hipGetLastError();
+}
+
+hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, const MsdPlan *msd, LaunchEvents ev) {
+    VRS_LAUNCH(msd_local_sort_kernel, dim3(kMsdBuckets), dim3(kLocalThreads), stream, ev, keys, msd);
+    return hipGetLastError();
+}
+
+uint32_t msd_local_capacity() { return kLocalCap; }
 
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
                                uint32_t group_len, uint32_t groups, uint32_t *tables, uint32_t *status,
