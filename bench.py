@@ -31,6 +31,7 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 BYTES_PER_KEY_SORT = 48  # 4 passes x (histogram read 4 + scatter read 4 + scatter write 4)   SURVEY.md section 8d
 BYTES_PER_KEY_SORT_ONE_READ = 36  # one counting read 4 + 4 passes x (scatter read 4 + scatter write 4): SURVEY.md section 8d's rule
+BYTES_PER_KEY_SORT_HYBRID = 28  # one counting read 4 + 2 MSD scatter passes x 8 + the LDS-local bucket sort (read 4 + write 4)
 BYTES_PER_KEY_SCATTER = 8  # the dominant kernel of either path, per launch: read 4 + write 4
 
 
@@ -128,8 +129,14 @@ def bench_single(args):
             gpu.incrementActiveIndex()
 
     def sort_one_call(b0):
-        # the library's own loop over the four passes: one counting read + four look-back scatter passes (K5)
+        # the library's own loop over the passes: one counting read, then either four LSD look-back scatter passes (K5) or
+        # -- large inputs whose top-14-bit buckets fit a workgroup -- two MSD look-back passes + the LDS-local sort (K5b)
         gpu.check(gpu.lib.vrs_sort_keys_u32(gpu.handle, b0.handle, buf1.handle, n))
+
+    def hybrid_sorts():
+        h = ctypes.c_uint64()
+        gpu.check(gpu.lib.vrs_one_call_hybrid_sorts(gpu.handle, ctypes.byref(h)))
+        return h.value
 
     one_call = args.path == "one_call"
     paths = {"one_call": (sort_one_call, capi.VRS_KERNEL_LOOKBACK_SCATTER, "lookback_scatter"),
@@ -163,7 +170,9 @@ def bench_single(args):
 
     # ---- timed region: exactly K steps, inputs resident.  The dominant kernel's launches carry HIP events on their
     # own dispatch packets, on the stream they are launched on; nothing else is instrumented.
+    hybrid_before = hybrid_sorts()
     elapsed, kernels = run_steps(primary, K, 1 << dominant_id)
+    hybrid_steps = hybrid_sorts() - hybrid_before  # K if every timed one-call sort took the hybrid form, 0 if none did
     # the timed region's own outputs, every one of them, before anything overwrites them (one device read each)
     fingerprints = [p_.verifyKeys(n)[1:] for p_ in pristine]
     timed_bad = [i for i in range(K)
@@ -211,7 +220,9 @@ def bench_single(args):
     rearm()
     run_steps(other_fn, 1, 0)
     rearm()
+    hybrid_before_other = hybrid_sorts()
     other_elapsed, _ = run_steps(other_fn, K, 0)
+    other_hybrid = (not one_call) and hybrid_sorts() - hybrid_before_other == K
     rearm()
     _, other_breakdown = run_steps(other_fn, K, (1 << capi.VRS_KERNEL_COUNT) - 1)
     other_check, other_bad = verify_batches(other_name, refs)
@@ -239,7 +250,11 @@ def bench_single(args):
         copy_times.append(time.perf_counter() - t0)
     copy_gbps = 2 * 4 * n / min(copy_times[1:]) / 1e9
 
-    bytes_per_key_sort = {"one_call": BYTES_PER_KEY_SORT_ONE_READ, "contract": BYTES_PER_KEY_SORT}
+    if one_call and hybrid_steps not in (0, K):
+        raise SystemExit(f"the timed steps mixed the two forms of the one-call sort ({hybrid_steps} of {K} hybrid)")
+    hybrid = one_call and hybrid_steps == K
+    bytes_per_key_sort = {"one_call": BYTES_PER_KEY_SORT_HYBRID if (hybrid or other_hybrid) else BYTES_PER_KEY_SORT_ONE_READ,
+                          "contract": BYTES_PER_KEY_SORT}
     dom_us = kernels.get(dominant_name, {}).get("avg_us")
     achieved = (BYTES_PER_KEY_SCATTER * n / (dom_us * 1e-6) / 1e9) if dom_us else None
     value = n * K / elapsed / 1e9
@@ -255,14 +270,19 @@ def bench_single(args):
                                            "note": "K further steps, each bracketed by a queue-idle wait (outside the timed region)"},
         "config": {"workload": f"BASELINE.json configs[{ {10 ** 7: 1, 10 ** 8: 2}.get(n, 2) }]: {n} uniform random uint32 keys (std::mt19937 seeds 1,2,3), "
                                f"multi_radixsort, 1xMI355X, keys resident in HBM",
-                   "path": ("vrs_sort_keys_u32: the library runs the four 8-bit passes itself -- one counting read of the "
-                            "keys, then four stable scatter passes with decoupled look-back (36 B/key)") if one_call else
+                   "path": (("vrs_sort_keys_u32, hybrid form: one counting read of the keys, an MSD partition by the top 14 bits in "
+                             "two stable scatter passes with decoupled look-back (8 + 6 bits), then every bucket sorted by its "
+                             "low 18 bits inside one workgroup's LDS (28 B/key)") if hybrid else
+                            ("vrs_sort_keys_u32: the library runs the four 8-bit passes itself -- one counting read of the "
+                             "keys, then four stable scatter passes with decoupled look-back (36 B/key)")) if one_call else
                            ("MultiRadixSortPass stages, as MultiRadixSort::execute drives them: 4 x [histograms, prefix, "
                             "scatter] with the caller-visible [W][256] table (48 B/key)"),
-                   "num_elements": n, "num_blocks_per_workgroup": B, "num_workgroups": Wg, "passes": 4,
+                   "num_elements": n, "num_blocks_per_workgroup": B, "num_workgroups": Wg,
+                   "passes": "2 MSD scatter passes + 1 LDS-local sort pass" if hybrid else 4,
                    "rank_mode": {1: "ballot", 2: "lds_atomic"}[gpu.lib.vrs_rank_mode(gpu.handle)], "device": dev_name,
                    "compute_units": cus},
-        "roofline": {"bound": "hbm", "kernel": f"{dominant_name} (one launch per pass: reads and writes every key once)",
+        "roofline": {"bound": "hbm", "kernel": f"{dominant_name} (one launch per scatter pass: reads and writes every key once"
+                                               + ("; two launches per sort in the hybrid form, 44 % of the step" if hybrid else "") + ")",
                      "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                      "algorithmic_bytes_per_launch": BYTES_PER_KEY_SCATTER * n, "avg_launch_us": dom_us,

@@ -462,12 +462,18 @@ def hybrid_sorts(ctx):
 
 
 HYBRID_DISTS = ["uniform", "sorted", "reverse", "28bit", "16bit", "const", "max_keys", "clustered", "two_values", "mult256",
-                "low18_const", "one_hot_bucket"]
+                "low18_const", "one_hot_bucket", "24bit", "rare_high_bit"]
 
 
 def make_hybrid_keys(n, dist, seed):
     if dist == "low18_const":  # every bucket holds one distinct key: the local sort sees one digit value in both passes
         return make_keys(n, "uniform", seed) & np.uint32(0xFFFC0000)
+    if dist == "24bit":
+        return make_keys(n, "uniform", seed) >> np.uint32(8)
+    if dist == "rare_high_bit":  # 20-bit keys except three that use bit 31: the range probe's sample misses them, the counting
+        k = make_keys(n, "uniform", seed) >> np.uint32(12)  # read must notice and the four LSD passes must run
+        k[[5, n // 2 + 1, n - 2]] |= np.uint32(0x80000000)
+        return k
     if dist == "one_hot_bucket":  # one top-14-bit bucket with far more keys than a workgroup can hold: must fall back
         k = make_keys(n, "uniform", seed)
         k[: n // 20] = (k[: n // 20] & np.uint32(0x3FFFF)) | np.uint32(0x56780000)
@@ -492,9 +498,12 @@ def test_hybrid_form_equals_std_sort(gpu_context, oracle, n, dist):
     took = hybrid_sorts(ctx) - h0
     assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
     assert stats["digit_tables"] == 1
-    top14 = np.bincount(keys >> np.uint32(18), minlength=1 << 14)
-    fits = int(top14.max()) <= 6656
-    assert took == (1 if fits else 0), (dist, int(top14.max()))
+    # the buckets are the top 14 bits of the key RANGE (32-bit keys: bits 18-31, the reference's 28-bit keys: bits 14-27);
+    # ranges below 27 bits are left to the LSD passes, which then drop an identity pass
+    bits = int(keys.max()).bit_length()
+    shift = bits - 14
+    fits = 13 <= shift <= 18 and int(np.bincount(keys >> np.uint32(shift), minlength=1 << 14).max()) <= 6656
+    assert took == (1 if fits else 0), (dist, bits)
     if fits:
         assert stats["lookback_scatter"] == 2 and stats["local_sort"] == 1 and stats["scatter"] == 0
     else:

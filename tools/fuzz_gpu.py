@@ -68,7 +68,7 @@ def main():
             ctx.setTuning(capi.VRS_TUNE_XCD_REMAP, int(rs.randint(0, 2)))
             one_call = rs.randint(0, 3) == 0 and not (bits64 and pairs)  # no one-call pairs entry point for 64-bit keys
             if one_call:
-                n = int(rs.choice([rs.randint(1, 20000), rs.randint(1, 3000000), rs.randint(1000000, 9000000)]))
+                n = int(rs.choice([rs.randint(1, 20000), rs.randint(1, 3000000), rs.randint(1000000, 9000000), rs.randint(4200000, 12000000)]))
             keys, kind = make_keys(rs, n, bits64)
             vals = rs.randint(0, 2 ** 32, n, dtype=np.uint32) if pairs else None
             if one_call:
@@ -78,6 +78,8 @@ def main():
                 ctx.setTuning(capi.VRS_TUNE_DIGIT_TABLE_GROUPS, int(rs.choice([0, 8, 16, 32])))
                 ctx.setTuning(capi.VRS_TUNE_FUSED_PLAN, int(rs.randint(0, 2)))
                 ctx.setTuning(capi.VRS_TUNE_SINGLE_MAX_KEYS, int(rs.choice([0, 4096, 4096, 20000])))
+                ctx.setTuning(capi.VRS_TUNE_HYBRID, int(rs.randint(0, 4) != 0))
+                ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, int(rs.choice([1 << 22, 1 << 22, 1 << 26])))
                 hold = rs.randint(0, 8) == 0
                 ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, int(rs.randint(0, 6)) if hold else -1)
                 ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, int(rs.choice([0, 3, 40])) if hold else 4096)

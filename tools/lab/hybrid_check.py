@@ -22,6 +22,8 @@ def make(n, dist, rs):
         k = np.sort(k)[::-1].copy()
     elif dist == "28bit":
         k >>= 4
+    elif dist == "24bit":
+        k >>= 8
     elif dist == "max_keys":
         k = np.where(k % 3 == 0, np.uint32(0xFFFFFFFF), k).astype(np.uint32)
     elif dist == "dups":
@@ -41,7 +43,7 @@ def main():
         if quick:
             cases = [(40000000, "uniform"), (50000000, "uniform"), (60000000, "uniform"), (70000000, "uniform"), (80000000, "uniform"),
                      (90000000, "uniform"), (10 ** 8, "uniform"), (10 ** 8, "sorted"), (10 ** 8, "reverse"), (10 ** 8, "28bit"),
-                     (10 ** 8, "dups"), (102000000, "uniform")]
+                     (10 ** 8, "dups"), (102000000, "uniform"), (10 ** 8, "24bit"), (10 ** 8, "hot_bucket")]
         for n, dist in cases:
             keys = make(n, dist, rs)
             ref = np.sort(keys)

@@ -796,14 +796,15 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         guard.armed = true;
         const vrs::FusedPlan fused{ctx->os_plan, ctx->os_host_head_dev, ctx->os_ticket, stamp, T, tile_cap, blind_cap, cuts0};
         if (msd_capable) {
-            // hybrid: the same read also fills the top-14-bit histogram; the LSD plan is made as always (without the
-            // stamp), then msd_plan_kernel decides which form runs, arms exactly one of the two first passes and stamps
+            // hybrid: a probe of the key range, then the same read also fills the histogram of the range's top 14 bits; ONE
+            // plan kernel makes the LSD plan as always, decides which form runs, arms exactly one of the two first passes
+            // and stamps the head
+            VRS_HIP(ctx, vrs::launch_range_probe(ctx->stream, static_cast<const uint32_t *>(kbuf[cur]->ptr), n, ctx->os_msd_counts));
             VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, kbuf[cur]->ptr, n, group_len, ctx->os_tables, ctx->os_status,
                                                       rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts, ev));
-            VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, ctx->os_host_head_dev, 0u, n, group_len, G, T,
-                                          tile_cap, blind_cap, cuts0));
             VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
-                                              ctx->os_host_head_dev, stamp, n, T, tiles_b_cap, 1u));
+                                              ctx->os_host_head_dev, stamp, n, T, tiles_b_cap, 1u, ctx->os_tables, group_len,
+                                              tile_cap, blind_cap, cuts0));
         } else {
             VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, group_len, G,
                                                   ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS,
@@ -825,7 +826,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         if (msd_capable) {
             if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
             VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kbuf[cur_at_start]->ptr, kbuf[cur_at_start ^ 1u]->ptr, nullptr,
-                                                      nullptr, ctx->os_plan_a, 0, 24, ctx->os_status, tiles0, false,
+                                                      nullptr, ctx->os_plan_a, 0, vrs::kShiftFromPlan, ctx->os_status, tiles0, false,
                                                       ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes, ctx->os_spin_budget,
                                                       ctx->os_hold_tile, ev, ctx->os_misplace));
         }

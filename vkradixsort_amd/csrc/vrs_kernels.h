@@ -97,6 +97,7 @@ struct OnesweepPlanHead {
     uint32_t msd_ok;            // hybrid form (K5b): 1 = the MSD passes and the local sort take over (set by msd_plan_kernel)
     uint32_t msd_tiles_b;       // rows of workgroups of the second MSD pass
     uint32_t msd_max_bucket;    // keys in the largest top-14-bit bucket
+    uint32_t msd_shift_a;       // the first MSD pass's digit shift (top 8 bits of the key range)
     uint32_t ready;             // host copy only: the sort's stamp, written after everything else
 };
 struct OnesweepPlan {
@@ -160,23 +161,30 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
 // then one workgroup per bucket sorts the low 18 bits inside LDS.
 constexpr uint32_t kMsdBucketCount = 1u << 14;
 struct MsdPlan {
+    uint32_t shift;                       // bucket = key >> shift (the top 14 bits of the key range)
+    uint32_t pad[3];
     uint32_t xcd_tiles[8][33];            // XCD x walks top-byte buckets x, x+8, ...: exclusive prefix of their tile counts
     uint32_t base[kMsdBucketCount + 1];   // exclusive prefix of the bucket sizes = where bucket b starts when sorted
 };
 // words the hybrid's counting needs beside the digit tables: the 16384-bin histogram + 8 x 256 top-byte counts per
 // pass-0 group, zero between sorts
-constexpr size_t kMsdCountWords = kMsdBucketCount + 8u * 256u;
+constexpr size_t kMsdCountWords = kMsdBucketCount + 8u * 256u + 64u;  // + the probed shift and the out-of-range flag
+constexpr uint32_t kShiftFromPlan = 0xFFFFFFFFu;  // launch_onesweep_scatter: take the shift from plan->head.msd_shift_a
+// ORs a strided sample of the keys and writes the bucket shift their range suggests into msd_counts
+hipError_t launch_range_probe(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t *msd_counts);
 // same as launch_digit_tables with 8 groups, and fills msd_counts (uint32 keys only)
 hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *tables,
                                    uint32_t *status, size_t status_words, int compute_units, uint32_t *msd_counts,
                                    LaunchEvents ev = {});
-// after launch_plan(..., stamp = 0): bucket offsets, the first MSD pass's seeds (into plan_a->group_seed[0]) and streams,
-// the second pass's tile tables; decides msd_ok (largest bucket <= the local sort's capacity, XCD tile counts <=
-// tiles_b_cap), arms exactly one of the two speculative first passes (plan_a's or plan_lsd's blind descriptors), writes
-// the msd_* words of the host head and stamps it
+// ONE workgroup: the plan of the four LSD passes (what launch_plan does, 8 groups), then the hybrid form's: bucket
+// offsets, the first MSD pass's seeds (into plan_a->group_seed[0]) and streams, the second pass's tile tables; decides
+// msd_ok (key range 27-32 bits and fully probed, largest bucket <= the local sort's capacity, XCD tile counts <=
+// tiles_b_cap), arms exactly one of the two speculative first passes (plan_a's or plan_lsd's blind descriptors), writes the
+// host head and stamps it
 hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
-                           uint32_t tiles_b_cap, uint32_t enabled);
+                           uint32_t tiles_b_cap, uint32_t enabled, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
+                           uint32_t blind_cap, const StreamCuts &cuts0);
 // second MSD pass: bits [18, 24) inside every top-byte bucket; grid of 8 * tiles_b workgroups; status rows: 8 * tiles_b
 hipError_t launch_msd_pass_b(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const MsdPlan *msd,
                              uint32_t *status, uint32_t tiles_b, bool atomic_rank, unsigned long long xcc_map,

@@ -910,7 +910,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
 // ---- K5b, hybrid form of the one-call sort for uint32 keys (28 instead of 36 bytes per key): an MSD partition by the top
 // kMsdBits bits in two look-back scatter passes (8 + 6 bits), then every bucket (about N / 16384 keys) is sorted by its
 // low 18 bits inside ONE workgroup's LDS and written back once.
-constexpr uint32_t kMsdBits = 14, kMsdShift = 32 - kMsdBits, kMsdBuckets = 1u << kMsdBits;
+constexpr uint32_t kMsdBits = 14, kMsdBuckets = 1u << kMsdBits;
+// words behind the counts ([16384] histogram + [8][256] slice counts): the probed bucket shift and the "a key lies above
+// the probed range" flag
+constexpr uint32_t kMsdProbeWord = kMsdBuckets + 8u * 256u, kMsdOverWord = kMsdProbeWord + 1u;
 constexpr uint32_t kMsdSubBits = kMsdBits - 8, kMsdSub = 1u << kMsdSubBits;  // buckets per top byte: 64
 constexpr int kLocalThreads = 256, kLocalItems = 26;                          // local sort: capacity 6656 keys per bucket
 constexpr uint32_t kLocalCap = kLocalThreads * kLocalItems;
@@ -988,17 +991,22 @@ __device__ __forceinline__ uint32_t digit_word(uint64_t key, uint32_t base_shift
 // hm: the 16384-bin histogram of the key's top 14 bits (hybrid form, K5b), or nullptr
 template <typename TI>
 __device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t *hm,
-                                                   uint32_t w) {
+                                                   uint32_t msd_shift, uint32_t &msd_over, uint32_t w) {
     atomicAdd(&t0[TI::t0(w, lane_id())], 1u);
     atomicAdd(&t1[TI::t1(w)], 1u);
     atomicAdd(&t2[TI::t2(w)], 1u);
     atomicAdd(&t3[TI::t3(w)], 1u);
-    if (hm) atomicAdd(&hm[w >> kMsdShift], 1u);
+    if (hm) {
+        const uint32_t b = w >> msd_shift;
+        msd_over |= b >> kMsdBits;  // a key above the probed range: the plan will refuse the hybrid form
+        atomicAdd(&hm[min(b, kMsdBuckets - 1u)], 1u);
+    }
 }
 
 // one 16-byte vector of keys per lane: 4 uint32 or 2 uint64.  vote: bit t = table t takes the run-length form
 template <typename K, typename TI, bool VOTE, bool MSD>
 __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t *hm,
+                                                       uint32_t msd_shift, uint32_t &msd_over,
                                                        const typename KeyVec<K>::type &q, uint32_t base_shift,
                                                        uint32_t lane, uint32_t &vote) {
     constexpr int V = KeyVec<K>::kKeys;
@@ -1010,7 +1018,11 @@ __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t
         i1[j] = TI::t1(w);
         i2[j] = TI::t2(w);
         i3[j] = TI::t3(w);
-        if constexpr (MSD) im[j] = w >> kMsdShift;
+        if constexpr (MSD) {
+            const uint32_t b = w >> msd_shift;
+            msd_over |= b >> kMsdBits;
+            im[j] = min(b, kMsdBuckets - 1u);
+        }
     }
     if constexpr (VOTE) {
         vote = (table_vote<V>(i0) ? 1u : 0u) | (table_vote<V>(i1) ? 2u : 0u) | (table_vote<V>(i2) ? 4u : 0u) |
@@ -1171,6 +1183,10 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
     __shared__ uint32_t t[3][GROUPS * kTableRow];
     __shared__ uint32_t s_msd[MSD ? kMsdBuckets : 1];
     uint32_t *const hm = MSD ? s_msd : nullptr;
+    // the hybrid form's buckets are the top 14 bits of the key RANGE: msd_hist[kMsdProbeWord] holds the shift a probe of
+    // the input suggested (range_probe_kernel); a key above that range sets msd_hist[kMsdOverWord]
+    uint32_t msd_shift = 0, msd_over = 0;
+    if constexpr (MSD) msd_shift = min(msd_hist[kMsdProbeWord], 31u);
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if constexpr (MSD) {
         for (uint32_t c = tid; c < kMsdBuckets; c += THREADS) s_msd[c] = 0;
@@ -1194,7 +1210,7 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
         // allocation; every slice starts a multiple of V keys after it)
         const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) / sizeof(K)) % V);
         const uint32_t head = min((V - mis) % V, len);
-        if (tid < head) digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, digit_word(keys[begin + tid], base_shift));
+        if (tid < head) digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, msd_shift, msd_over, digit_word(keys[begin + tid], base_shift));
         const Vec *v = reinterpret_cast<const Vec *>(keys + begin + head);
         const uint32_t nvec = (len - head) / V;
         constexpr uint32_t kStep = THREADS * UNROLL;
@@ -1224,19 +1240,19 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
                 cur[r] = v[refill + r * THREADS + tid];
                 __builtin_amdgcn_sched_barrier(0);
                 if (r == 0)
-                    digit_tables_count_vec<K, TI, true, MSD>(t0, t[0], t[1], t[2], hm, x, base_shift, lane, vote);
+                    digit_tables_count_vec<K, TI, true, MSD>(t0, t[0], t[1], t[2], hm, msd_shift, msd_over, x, base_shift, lane, vote);
                 else
-                    digit_tables_count_vec<K, TI, false, MSD>(t0, t[0], t[1], t[2], hm, x, base_shift, lane, vote);
+                    digit_tables_count_vec<K, TI, false, MSD>(t0, t[0], t[1], t[2], hm, msd_shift, msd_over, x, base_shift, lane, vote);
             }
         }
         for (uint32_t i = i0 + tid; i < nvec; i += THREADS) {
             const Vec q = v[i];
 #pragma unroll
             for (int j = 0; j < static_cast<int>(V); ++j)
-                digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, digit_word(KeyVec<K>::get(q, j), base_shift));
+                digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, msd_shift, msd_over, digit_word(KeyVec<K>::get(q, j), base_shift));
         }
         const uint32_t tail = head + nvec * V + tid;  // at most V - 1 keys
-        if (tail < len) digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, digit_word(keys[begin + tail], base_shift));
+        if (tail < len) digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, msd_shift, msd_over, digit_word(keys[begin + tail], base_shift));
     }
     __syncthreads();
     for (uint32_t d = tid; d < static_cast<uint32_t>(kBins); d += THREADS) {
@@ -1252,6 +1268,8 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
         if (x) __hip_atomic_fetch_add(&tables[GROUPS * kBins + c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (MSD) {
+        if (__ballot(msd_over != 0u) != 0ull && lane == 0u)
+            __hip_atomic_fetch_or(&msd_hist[kMsdOverWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // top-14-bit histogram; the top-byte counts of this workgroup's pass-0 group are the sums of 64 sub-bins each
         for (uint32_t c = tid; c < kMsdBuckets; c += THREADS) {
             const uint32_t x = s_msd[c];
@@ -1317,7 +1335,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     const uint32_t begin = sd.start + done;
     const uint32_t valid = min(kTile, sd.len - done);
     RadixDigit<K> dg;
-    dg.shift = shift;
+    dg.shift = shift == kShiftFromPlan ? plan->head.msd_shift_a : shift;  // first MSD pass of the hybrid form: set by msd_plan_kernel
     StreamLookback lb;
     // byte x of xcc_map = XCC of the blocks with blockIdx % 8 == x (probed); my stream's tiles sit in blocks = s (mod 8)
     lb.foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * (s & 7u))) & 0xFFu);
@@ -1360,12 +1378,43 @@ struct BitsDigit {
     __device__ __forceinline__ uint32_t operator()(uint32_t key) const { return (key >> shift) & mask; }
 };
 
+// The hybrid form buckets the keys by the top 14 bits of their RANGE (32-bit keys: bits 18-31; the reference's 28-bit
+// keys: bits 14-27; ...).  One workgroup ORs a strided sample of 4096 keys and writes the bucket shift that range
+// suggests; the counting read flags every key above it, so a wrong guess costs the hybrid form, never the result.
+__global__ __launch_bounds__(1024) void range_probe_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t s_or;
+    if (threadIdx.x == 0) s_or = 0;
+    __syncthreads();
+    const uint32_t samples = min(n, 4096u);  // four independent loads per thread: one memory round trip
+    const uint64_t stride = n / samples;     // >= 1
+    uint32_t acc = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        const uint32_t i = threadIdx.x + j * 1024u;
+        acc |= i < samples ? keys[static_cast<uint64_t>(i) * stride] : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc |= __shfl_down(acc, o);
+    if ((threadIdx.x & 63u) == 0u) atomicOr(&s_or, acc);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t bits = s_or ? 32u - static_cast<uint32_t>(__clz(static_cast<int>(s_or))) : 0u;  // keys < 2^bits (sampled)
+        counts[kMsdProbeWord] = bits > kMsdBits ? bits - kMsdBits : 0u;
+        counts[kMsdOverWord] = 0;
+    }
+}
+
 // One 1024-thread workgroup, after plan_kernel.  counts = [16384] top-14-bit histogram, then [8][256] top-byte counts per
 // pass-0 group (both left zeroed for the next sort).
 __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ counts, MsdPlan *__restrict__ msd,
                                                        OnesweepPlan *__restrict__ plan_a, OnesweepPlan *__restrict__ plan_lsd,
                                                        OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
-                                                       uint32_t tiles_b_cap, uint32_t enabled) {
+                                                       uint32_t tiles_b_cap, uint32_t enabled, uint32_t *__restrict__ tables,
+                                                       uint32_t group_len, uint32_t tile_cap, uint32_t blind_cap,
+                                                       StreamCuts cuts0) {
+    // first the plan of the four LSD passes (the same workgroup, no launch of its own; the head is stamped at the end)
+    plan_body<8>(tables, plan_lsd, host_head, 0u, n, group_len, tile, tile_cap, blind_cap, cuts0);
+    __syncthreads();
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_start[kBins + 1];  // where top byte a starts
     __shared__ uint32_t s_tiles[kBins];
@@ -1433,7 +1482,12 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
         atomicMax(&s_tiles_b, acc);
     }
     __syncthreads();
-    if (tid == 0) s_ok = (enabled != 0u && s_max <= kLocalCap && s_tiles_b <= tiles_b_cap) ? 1u : 0u;
+    // the probed range must hold every key and be 27 to 32 bits wide: a narrower range leaves the four LSD passes an
+    // identity pass to drop (they then move 28 bytes per key too, without the local sort's LDS work: 24-bit keys measured
+    // 0.80 ms LSD vs 0.89 ms hybrid at 10^8 keys), a wider one cannot occur; at most 18 low bits go to the local sort
+    const uint32_t shift = counts[kMsdProbeWord], over = counts[kMsdOverWord];
+    if (tid == 0)
+        s_ok = (enabled != 0u && over == 0u && shift >= 13u && shift <= 18u && s_max <= kLocalCap && s_tiles_b <= tiles_b_cap) ? 1u : 0u;
     __syncthreads();
     // (4) the first MSD pass's streams are pass 0's (slices of the input); exactly one of the two speculatively enqueued
     //     first passes is armed
@@ -1445,7 +1499,9 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
         if (s_ok) plan_lsd->head.blind[0][tid].tiles = 0;
     }
     if (tid == 0) {
+        msd->shift = shift;
         plan_a->head.first_abnormal = 4;
+        plan_a->head.msd_shift_a = shift + kMsdSubBits;  // the first MSD pass's digit: the top 8 bits of the range
         plan_lsd->head.msd_ok = s_ok;
         plan_lsd->head.msd_tiles_b = s_tiles_b;
         plan_lsd->head.msd_max_bucket = s_max;
@@ -1480,7 +1536,7 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const uint32_t *__re
     const uint32_t done = i * kTile;
     const uint32_t begin = first + done;
     const uint32_t valid = min(kTile, last - begin);
-    BitsDigit dg{kMsdShift, kMsdSub - 1u};
+    BitsDigit dg{msd->shift, kMsdSub - 1u};
     StreamLookback lb;
     lb.foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * x)) & 0xFFu);
     lb.stream_keys = keys_in + first;
@@ -1990,11 +2046,17 @@ hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_
     return hipGetLastError();
 }
 
+hipError_t launch_range_probe(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t *msd_counts) {
+    hipLaunchKernelGGL(range_probe_kernel, dim3(1), dim3(1024), 0, stream, keys, n, msd_counts);
+    return hipGetLastError();
+}
+
 hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
-                           uint32_t tiles_b_cap, uint32_t enabled) {
+                           uint32_t tiles_b_cap, uint32_t enabled, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
+                           uint32_t blind_cap, const StreamCuts &cuts0) {
     hipLaunchKernelGGL(msd_plan_kernel, dim3(1), dim3(1024), 0, stream, msd_counts, msd, plan_a, plan_lsd, host_head, stamp, n,
-                       tile, tiles_b_cap, enabled);
+                       tile, tiles_b_cap, enabled, tables, group_len, tile_cap, blind_cap, cuts0);
     return hipGetLastError();
 }
 
