@@ -179,6 +179,11 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * host memory -- i.e. until the counting read has run; it never waits for the sort itself, which still completes
  * asynchronously on the context's stream.  Passes whose digit is the same for every key (small keys, constant bytes)
  * are the identity and are left out.  Same result, bit for bit.
+ * uint32 keys without payload, from 2^26 keys on (VRS_TUNE_HYBRID, VRS_TUNE_HYBRID_MIN_KEYS): the same counting read also
+ * histograms the top 14 bits of the key range, and when every such bucket fits one workgroup's LDS (uniform keys: up to
+ * about 1.03 * 10^8) the four LSD passes are replaced by an MSD partition in two look-back scatter passes (8 + 6 bits)
+ * plus one pass in which every bucket is sorted inside LDS -- 28 bytes per key (DESIGN.md "K5b").  The choice is made on
+ * the device from that one read; either form gives the same bits.
  */
 int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements);
 int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
