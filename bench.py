@@ -443,7 +443,9 @@ def bench_multi(args):
         # dominant kernel: the look-back scatter of the local sorts (one launch per pass per received sub-range); a launch
         # over m keys moves 8 m algorithmic bytes; rank 0's launches of the timed region
         recv_keys = int(g[0][2])
-        lb_bytes = 8 * 4 * recv_keys * K  # 4 passes over every received key, K steps
+        # every launch of the look-back scatter reads and writes one received sub-range once (the LSD form launches it four
+        # times per sub-range, the hybrid form twice)
+        lb_bytes = 8 * (recv_keys / max(sorter.rounds, 1)) * lb_launches
         lb_achieved = lb_bytes / (lb_ms * 1e-3) / 1e9 if lb_ms > 0 else None
         base = None
         if not args.no_cpu_baseline:
@@ -466,7 +468,9 @@ def bench_multi(args):
                        "exchange_rounds": sorter.rounds, "rounds_tried_in_warmup_ms": {str(k): round(v * 1e3, 3) for k, v in tried.items()},
                        "hbm_bytes_per_key": 48,
                        "hbm_bytes_per_key_breakdown": {"partition_pass_histogram_read": 4, "partition_pass_scatter": 8,
-                                                       "local_sorts_counting_read": 4, "local_sorts_four_lookback_scatters": 32}},
+                                                       "local_sorts_counting_read": 4, "local_sorts_four_lookback_scatters": 32,
+                                                       "note": "sub-ranges of 2^26 keys or more take the 28-byte hybrid form "
+                                                               "(two look-back scatters + the LDS-local bucket sort): 40 in total"}},
             "roofline": {"bound": "hbm", "kernel": "lookback_scatter of the local sorts (rank 0's launches in the timed region)",
                          "achieved": round(lb_achieved, 1) if lb_achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(lb_achieved / HBM_PEAK_GBS, 4) if lb_achieved else None,

@@ -796,10 +796,9 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         guard.armed = true;
         const vrs::FusedPlan fused{ctx->os_plan, ctx->os_host_head_dev, ctx->os_ticket, stamp, T, tile_cap, blind_cap, cuts0};
         if (msd_capable) {
-            // hybrid: a probe of the key range, then the same read also fills the histogram of the range's top 14 bits; ONE
+            // hybrid: the same read (after probing the key range on a sample) also fills the histogram of the range's top 14 bits; ONE
             // plan kernel makes the LSD plan as always, decides which form runs, arms exactly one of the two first passes
             // and stamps the head
-            VRS_HIP(ctx, vrs::launch_range_probe(ctx->stream, static_cast<const uint32_t *>(kbuf[cur]->ptr), n, ctx->os_msd_counts));
             VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, kbuf[cur]->ptr, n, group_len, ctx->os_tables, ctx->os_status,
                                                       rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts, ev));
             VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
@@ -821,24 +820,21 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         const uint32_t cur_at_start = cur;
         const size_t events_before = ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER];
         const uint32_t blind_passes = msd_capable ? 1u : 4u;
-        for (uint32_t i = 0; i < blind_passes; ++i)
-            if ((rc = lookback_pass(i, 32u * group + 8u * i, i == 0 ? tiles0 : blind_cap, false))) return rc;
-        if (msd_capable) {
+        if (msd_capable) {  // the first MSD pass goes first: it is the one that usually runs, the other then leaves behind it
             if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
             VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kbuf[cur_at_start]->ptr, kbuf[cur_at_start ^ 1u]->ptr, nullptr,
                                                       nullptr, ctx->os_plan_a, 0, vrs::kShiftFromPlan, ctx->os_status, tiles0, false,
                                                       ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes, ctx->os_spin_budget,
                                                       ctx->os_hold_tile, ev, ctx->os_misplace));
         }
+        for (uint32_t i = 0; i < blind_passes; ++i)
+            if ((rc = lookback_pass(i, 32u * group + 8u * i, i == 0 ? tiles0 : blind_cap, false))) return rc;
         if ((rc = wait_for_plan(ctx, stamp))) return rc;
         const vrs::OnesweepPlanHead &head = *ctx->os_host_head;
         const bool timed = (ctx->profile_mask & (1u << VRS_KERNEL_LOOKBACK_SCATTER)) != 0;
         if (msd_capable && head.msd_ok) {
             // hybrid form: the first MSD pass is running (keys -> partner); second pass back, then the buckets in place
-            if (timed) {  // the LSD pass 0 left at once: hand its events back, keep the MSD pass's
-                std::swap(ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][events_before], ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][events_before + 1]);
-                ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + 1;
-            }
+            if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + 1;  // the LSD pass 0 left at once: hand its events back
             if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
             VRS_HIP(ctx, vrs::launch_msd_pass_b(ctx->stream, static_cast<const uint32_t *>(kbuf[cur_at_start ^ 1u]->ptr),
                                                 static_cast<uint32_t *>(kbuf[cur_at_start]->ptr), ctx->os_msd_plan, ctx->os_status,
@@ -849,8 +845,10 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
             ctx->os_hybrid_sorts++;
             continue;
         }
-        if (msd_capable && timed)  // the first MSD pass left at once: hand its events back
+        if (msd_capable && timed) {  // the first MSD pass left at once: hand its events back, keep the LSD pass 0's
+            std::swap(ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][events_before], ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][events_before + 1]);
             ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + 1;
+        }
         const uint32_t q = std::min<uint32_t>(head.first_abnormal, blind_passes);
         ctx->os_lookback_passes += q;
         if (q == 4) continue;  // four look-back passes: the data is back where it started (cur unchanged)

@@ -170,8 +170,7 @@ struct MsdPlan {
 // pass-0 group, zero between sorts
 constexpr size_t kMsdCountWords = kMsdBucketCount + 8u * 256u + 64u;  // + the probed shift and the out-of-range flag
 constexpr uint32_t kShiftFromPlan = 0xFFFFFFFFu;  // launch_onesweep_scatter: take the shift from plan->head.msd_shift_a
-// ORs a strided sample of the keys and writes the bucket shift their range suggests into msd_counts
-hipError_t launch_range_probe(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t *msd_counts);
+
 // same as launch_digit_tables with 8 groups, and fills msd_counts (uint32 keys only)
 hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *tables,
                                    uint32_t *status, size_t status_words, int compute_units, uint32_t *msd_counts,

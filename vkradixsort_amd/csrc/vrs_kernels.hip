@@ -911,6 +911,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
 // kMsdBits bits in two look-back scatter passes (8 + 6 bits), then every bucket (about N / 16384 keys) is sorted by its
 // low 18 bits inside ONE workgroup's LDS and written back once.
 constexpr uint32_t kMsdBits = 14, kMsdBuckets = 1u << kMsdBits;
+constexpr uint32_t kMsdMinShift = 13, kMsdMaxShift = 18;  // bucket shift of a 27 ... 32-bit key range
 // words behind the counts ([16384] histogram + [8][256] slice counts): the probed bucket shift and the "a key lies above
 // the probed range" flag
 constexpr uint32_t kMsdProbeWord = kMsdBuckets + 8u * 256u, kMsdOverWord = kMsdProbeWord + 1u;
@@ -1027,13 +1028,17 @@ __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t
     if constexpr (VOTE) {
         vote = (table_vote<V>(i0) ? 1u : 0u) | (table_vote<V>(i1) ? 2u : 0u) | (table_vote<V>(i2) ? 4u : 0u) |
                (table_vote<V>(i3) ? 8u : 0u);
-        if constexpr (MSD) vote |= table_vote<V>(im) ? 16u : 0u;
+        if constexpr (MSD) {
+            if (hm) vote |= table_vote<V>(im) ? 16u : 0u;
+        }
     }
     table_add<V>(t0, i0, lane, (vote & 1u) != 0u);
     table_add<V>(t1, i1, lane, (vote & 2u) != 0u);
     table_add<V>(t2, i2, lane, (vote & 4u) != 0u);
     table_add<V>(t3, i3, lane, (vote & 8u) != 0u);
-    if constexpr (MSD) table_add<V>(hm, im, lane, (vote & 16u) != 0u);
+    if constexpr (MSD) {
+        if (hm) table_add<V>(hm, im, lane, (vote & 16u) != 0u);  // workgroup-uniform: nullptr when the key range is too narrow
+    }
 }
 
 // one workgroup; thread (p, d).  Merges the GROUPS groups of every pass into kStreams streams of (nearly) equal
@@ -1182,12 +1187,33 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
     __shared__ uint32_t t0[kBins * COPIES];
     __shared__ uint32_t t[3][GROUPS * kTableRow];
     __shared__ uint32_t s_msd[MSD ? kMsdBuckets : 1];
-    uint32_t *const hm = MSD ? s_msd : nullptr;
+    uint32_t *hm = MSD ? s_msd : nullptr;
     // the hybrid form's buckets are the top 14 bits of the key RANGE: msd_hist[kMsdProbeWord] holds the shift a probe of
     // the input suggested (range_probe_kernel); a key above that range sets msd_hist[kMsdOverWord]
     uint32_t msd_shift = 0, msd_over = 0;
-    if constexpr (MSD) msd_shift = min(msd_hist[kMsdProbeWord], 31u);
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if constexpr (MSD) {
+        // The hybrid form buckets the keys by the top 14 bits of their RANGE (32-bit keys: bits 18-31; the reference's
+        // 28-bit keys: bits 14-27; ...).  Every workgroup ORs the SAME strided sample of 4096 keys (16 KB: served by L2
+        // after the first few) and derives the same bucket shift; every key above the sampled range is flagged below, so
+        // a wrong guess costs the hybrid form, never the result.
+        __shared__ uint32_t s_or;
+        if (tid == 0) s_or = 0;
+        __syncthreads();
+        const uint32_t samples = min(n, 4096u);
+        const uint64_t stride = n / samples;  // >= 1
+        uint32_t acc = 0;
+        for (uint32_t i = tid; i < samples; i += THREADS) acc |= digit_word(keys[static_cast<uint64_t>(i) * stride], base_shift);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc |= __shfl_down(acc, o);
+        if (lane == 0u && acc) atomicOr(&s_or, acc);
+        __syncthreads();
+        const uint32_t bits = s_or ? 32u - static_cast<uint32_t>(__clz(static_cast<int>(s_or))) : 0u;  // sampled keys < 2^bits
+        msd_shift = bits > kMsdBits ? bits - kMsdBits : 0u;
+        if (blockIdx.x == 0 && tid == 0) msd_hist[kMsdProbeWord] = msd_shift;  // for the plan
+        // a key range below 27 bits is left to the LSD passes (the plan will say so): do not pay for the histogram
+        if (msd_shift < kMsdMinShift) hm = nullptr;
+    }
     if constexpr (MSD) {
         for (uint32_t c = tid; c < kMsdBuckets; c += THREADS) s_msd[c] = 0;
     }
@@ -1268,6 +1294,7 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
         if (x) __hip_atomic_fetch_add(&tables[GROUPS * kBins + c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (MSD) {
+      if (hm != nullptr) {
         if (__ballot(msd_over != 0u) != 0ull && lane == 0u)
             __hip_atomic_fetch_or(&msd_hist[kMsdOverWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // top-14-bit histogram; the top-byte counts of this workgroup's pass-0 group are the sums of 64 sub-bins each
@@ -1282,6 +1309,7 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
                 __hip_atomic_fetch_add(&msd_slices[static_cast<size_t>(s) * kBins + tid], sum, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
         }
+      }
     }
     if constexpr (THREADS == 4 * kBins) {
         if (fp.plan != nullptr) {  // fused form: the workgroup that finishes LAST turns the tables into the plan
@@ -1378,32 +1406,6 @@ struct BitsDigit {
     __device__ __forceinline__ uint32_t operator()(uint32_t key) const { return (key >> shift) & mask; }
 };
 
-// The hybrid form buckets the keys by the top 14 bits of their RANGE (32-bit keys: bits 18-31; the reference's 28-bit
-// keys: bits 14-27; ...).  One workgroup ORs a strided sample of 4096 keys and writes the bucket shift that range
-// suggests; the counting read flags every key above it, so a wrong guess costs the hybrid form, never the result.
-__global__ __launch_bounds__(1024) void range_probe_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ counts) {
-    __shared__ uint32_t s_or;
-    if (threadIdx.x == 0) s_or = 0;
-    __syncthreads();
-    const uint32_t samples = min(n, 4096u);  // four independent loads per thread: one memory round trip
-    const uint64_t stride = n / samples;     // >= 1
-    uint32_t acc = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 4u; ++j) {
-        const uint32_t i = threadIdx.x + j * 1024u;
-        acc |= i < samples ? keys[static_cast<uint64_t>(i) * stride] : 0u;
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) acc |= __shfl_down(acc, o);
-    if ((threadIdx.x & 63u) == 0u) atomicOr(&s_or, acc);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t bits = s_or ? 32u - static_cast<uint32_t>(__clz(static_cast<int>(s_or))) : 0u;  // keys < 2^bits (sampled)
-        counts[kMsdProbeWord] = bits > kMsdBits ? bits - kMsdBits : 0u;
-        counts[kMsdOverWord] = 0;
-    }
-}
-
 // One 1024-thread workgroup, after plan_kernel.  counts = [16384] top-14-bit histogram, then [8][256] top-byte counts per
 // pass-0 group (both left zeroed for the next sort).
 __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ counts, MsdPlan *__restrict__ msd,
@@ -1487,7 +1489,7 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
     // 0.80 ms LSD vs 0.89 ms hybrid at 10^8 keys), a wider one cannot occur; at most 18 low bits go to the local sort
     const uint32_t shift = counts[kMsdProbeWord], over = counts[kMsdOverWord];
     if (tid == 0)
-        s_ok = (enabled != 0u && over == 0u && shift >= 13u && shift <= 18u && s_max <= kLocalCap && s_tiles_b <= tiles_b_cap) ? 1u : 0u;
+        s_ok = (enabled != 0u && over == 0u && shift >= kMsdMinShift && shift <= kMsdMaxShift && s_max <= kLocalCap && s_tiles_b <= tiles_b_cap) ? 1u : 0u;
     __syncthreads();
     // (4) the first MSD pass's streams are pass 0's (slices of the input); exactly one of the two speculatively enqueued
     //     first passes is armed
@@ -1499,6 +1501,7 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
         if (s_ok) plan_lsd->head.blind[0][tid].tiles = 0;
     }
     if (tid == 0) {
+        counts[kMsdOverWord] = 0;  // re-armed for the next sort (the shift word is rewritten by every counting read)
         msd->shift = shift;
         plan_a->head.first_abnormal = 4;
         plan_a->head.msd_shift_a = shift + kMsdSubBits;  // the first MSD pass's digit: the top 8 bits of the range
@@ -2043,11 +2046,6 @@ hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_
     launch_digit_tables_variant<uint32_t, 8, 1024, 32, VRS_DT_UNROLL, 4, true>(stream, keys, n, 0, group_len, tables, status,
                                                                                status_words, compute_units, ev,
                                                                                FusedPlanArgs{}, msd_counts);
-    return hipGetLastError();
-}
-
-hipError_t launch_range_probe(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t *msd_counts) {
-    hipLaunchKernelGGL(range_probe_kernel, dim3(1), dim3(1024), 0, stream, keys, n, msd_counts);
     return hipGetLastError();
 }
 
