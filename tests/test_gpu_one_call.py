@@ -502,7 +502,7 @@ def test_hybrid_form_equals_std_sort(gpu_context, oracle, n, dist):
     # ranges below 27 bits are left to the LSD passes, which then drop an identity pass
     bits = int(keys.max()).bit_length()
     shift = bits - 14
-    fits = 13 <= shift <= 18 and int(np.bincount(keys >> np.uint32(shift), minlength=1 << 14).max()) <= 6656
+    fits = 13 <= shift <= 18 and int(np.bincount(keys >> np.uint32(shift), minlength=1 << 14).max()) <= 13312
     assert took == (1 if fits else 0), (dist, bits)
     if fits:
         assert stats["lookback_scatter"] == 2 and stats["local_sort"] == 1 and stats["scatter"] == 0
@@ -538,23 +538,88 @@ def test_hybrid_form_under_the_look_back_hooks(gpu_context, hook):
     assert hybrid_sorts(ctx) - h0 == (0 if hook == "ballot" else 1)
 
 
-def test_hybrid_form_leaves_pairs_and_wide_keys_to_the_lsd_passes(gpu_context, oracle):
-    ctx, lib, n = gpu_context, gpu_context.lib, (1 << 22) + 99
-    keys = make_keys(n, "uniform", seed=17) & np.uint32(0xFFFFFF)
-    vals = np.arange(n, dtype=np.uint32)
-    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
-    h0 = hybrid_sorts(ctx)
+def sort_pairs_once(ctx, keys, vals):
+    lib, n = ctx.lib, keys.size
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)
+    v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
+    k1, v1 = vrs.Buffer(ctx, S(4 * n)), vrs.Buffer(ctx, S(4 * n))
     try:
-        k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)
-        v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
-        k1, v1 = vrs.Buffer(ctx, S(4 * n)), vrs.Buffer(ctx, S(4 * n))
         ctx.check(lib.vrs_sort_pairs_u32(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
         ok, ov = np.empty(n, np.uint32), np.empty(n, np.uint32)
         k0.downloadWithStagingBuffer(ok)
         v0.downloadWithStagingBuffer(ov)
     finally:
+        for b in (k0, k1, v0, v1):
+            b.release()
+    return ok, ov
+
+
+@pytest.mark.parametrize("dist", ["uniform", "sorted", "low18_const", "28bit", "ties", "one_hot_bucket", "24bit"])
+@pytest.mark.parametrize("n", [(1 << 22) + 77, 7000003])
+def test_hybrid_form_pairs_are_stable(gpu_context, oracle, n, dist):
+    """Key + payload pairs through the hybrid form: both partition passes and the two local passes are stable, so payloads
+    of equal keys must come out in input order (the reference's LSD passes guarantee exactly that,
+    multi_radixsort.comp:130-141); distributions that cannot take the form fall back to the LSD passes, payloads and all."""
+    ctx = gpu_context
+    if dist == "28bit":
+        keys = make_keys(n, "uniform", seed=5) >> np.uint32(4)
+    elif dist == "ties":  # 2^16 distinct keys spread over the whole range: long runs of equal keys inside every bucket
+        keys = (make_keys(n, "uniform", seed=6) & np.uint32(0xFFFF)) * np.uint32(65537)
+    else:
+        keys = make_hybrid_keys(n, dist, seed=n % 311)
+    vals = make_keys(n, "uniform", seed=8)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    h0 = hybrid_sorts(ctx)
+    try:
+        ok, ov = sort_pairs_once(ctx, keys, vals)
+    finally:
         ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+    took = hybrid_sorts(ctx) - h0
     rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
-    assert np.array_equal(ok, rk) and np.array_equal(ov, rv) and hybrid_sorts(ctx) == h0
-    for b in (k0, k1, v0, v1):
-        b.release()
+    assert np.array_equal(ok, rk) and np.array_equal(ov, rv)
+    shift = int(keys.max()).bit_length() - 14
+    fits = 13 <= shift <= 18 and int(np.bincount(keys >> np.uint32(shift), minlength=1 << 14).max()) <= 6656
+    assert took == (1 if fits else 0), (dist, shift)
+
+
+@pytest.mark.parametrize("mode", ["keys", "pairs"])
+def test_hybrid_form_with_buckets_beyond_the_small_local_sort(gpu_context, mode):
+    """Buckets of 6657-13312 keys take the 512-thread local sort (keys only; pairs of that size fall back to the LSD
+    passes).  Three of four top-14-bit buckets are empty here, so 3.6e7 keys fill the others with about 8800 each."""
+    ctx, n = gpu_context, 36000001
+    keys = make_keys(n, "uniform", seed=23) & np.uint32(0xFFF3FFFF)
+    assert 6656 < int(np.bincount(keys >> np.uint32(18), minlength=1 << 14).max()) <= 13312
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    h0 = hybrid_sorts(ctx)
+    try:
+        if mode == "keys":
+            out, stats = sort_keys(ctx, keys)
+            assert np.array_equal(out, np.sort(keys))
+            assert stats["local_sort"] == 1 and stats["lookback_scatter"] == 2
+        else:
+            vals = np.arange(n, dtype=np.uint32)
+            ok, ov = sort_pairs_once(ctx, keys, vals)
+            order = np.argsort(keys, kind="stable")
+            assert np.array_equal(ok, keys[order]) and np.array_equal(ov, vals[order])
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+    assert hybrid_sorts(ctx) - h0 == (1 if mode == "keys" else 0)
+
+
+def test_hybrid_form_leaves_wide_keys_to_the_lsd_passes(gpu_context):
+    ctx, lib, n = gpu_context, gpu_context.lib, (1 << 22) + 99
+    rs = np.random.RandomState(3)
+    keys = rs.randint(0, 2 ** 63, size=n, dtype=np.uint64)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    h0 = hybrid_sorts(ctx)
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(8 * n), keys)
+    k1 = vrs.Buffer(ctx, S(8 * n))
+    try:
+        ctx.check(lib.vrs_sort_keys_u64(ctx.handle, k0.handle, k1.handle, n))
+        out = np.empty(n, np.uint64)
+        k0.downloadWithStagingBuffer(out)
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+        k0.release()
+        k1.release()
+    assert np.array_equal(out, np.sort(keys)) and hybrid_sorts(ctx) == h0

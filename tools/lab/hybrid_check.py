@@ -1,5 +1,5 @@
 """Hybrid form of vrs_sort_keys_u32 (MSD partition + LDS-local sort): correctness vs numpy over sizes / distributions, which
-form ran, and time against the LSD form.   usage: hybrid_check.py [quick]"""
+form ran, and time against the LSD form.   usage: hybrid_check.py [quick | sizes n,n,... [dist,dist,...]]"""
 import ctypes
 import sys
 import time
@@ -34,7 +34,9 @@ def make(n, dist, rs):
 
 
 def main():
-    quick = len(sys.argv) > 1
+    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    sizes = [int(float(x)) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 and sys.argv[1] == "sizes" else None
+    dists = sys.argv[3].split(",") if len(sys.argv) > 3 else ["uniform"]
     rs = np.random.RandomState(3)
     with vrs.GPUContext(0) as gpu:
         lib = gpu.lib
@@ -44,6 +46,8 @@ def main():
             cases = [(40000000, "uniform"), (50000000, "uniform"), (60000000, "uniform"), (70000000, "uniform"), (80000000, "uniform"),
                      (90000000, "uniform"), (10 ** 8, "uniform"), (10 ** 8, "sorted"), (10 ** 8, "reverse"), (10 ** 8, "28bit"),
                      (10 ** 8, "dups"), (102000000, "uniform"), (10 ** 8, "24bit"), (10 ** 8, "hot_bucket")]
+        if sizes:
+            cases = [(n, d) for n in sizes for d in dists]
         for n, dist in cases:
             keys = make(n, dist, rs)
             ref = np.sort(keys)

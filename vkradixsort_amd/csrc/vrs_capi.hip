@@ -670,14 +670,17 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
     // groups per pass: 32 let the streams follow skewed data more closely, but every workgroup of the counting read
     // flushes 3 * G * 256 counters -- a fixed cost that only large inputs amortise (10^7 keys: 20 vs 34 us for the
     // counting read, 3 * 10^7: 47 vs 61, 10^8: a tie; profiles/labs/r02_groups_and_fused_plan.txt)
-    // Hybrid form (K5b): uint32 keys only, from os_hybrid_min_keys on (default 2^26: the 16384 buckets are then at least
+    // Hybrid form (K5b): uint32 keys, with or without uint32 payloads, from os_hybrid_min_keys on (default 2^26: the 16384 buckets are then at least
     // 60 % full -- below, the fixed cost per bucket workgroup outweighs the saved pass: measured crossover 6-7 * 10^7
     // keys); above about 1.03 * 10^8 uniform keys the largest bucket no longer fits a workgroup's LDS and the plan says
     // no.  Its local sort ranks with returning LDS atomics, so the lane-order self-test must have passed.  The counting
     // read then also fills the top-14-bit histogram, which needs the 8-group tables to fit beside it in LDS.
-    const bool msd_capable = key_bytes == 4 && !values && ctx->os_hybrid && ctx->atomic_rank_verified &&
-                             ctx->scatter.atomic_rank && n >= ctx->os_hybrid_min_keys && n >= (1u << 22) &&
-                             static_cast<uint64_t>(n) <= 2ull * vrs::kMsdBucketCount * vrs::msd_local_capacity() &&
+    // payloads double what the hybrid form saves per key: measured crossover 3e7 pairs vs 6-7e7 keys (profiles/labs/r02_hybrid_pairs.txt)
+    const uint32_t hybrid_min = values ? ctx->os_hybrid_min_keys / 2u : ctx->os_hybrid_min_keys;
+    const uint32_t local_cap = vrs::msd_local_capacity(values != nullptr);
+    const bool msd_capable = key_bytes == 4 && ctx->os_hybrid && ctx->atomic_rank_verified &&
+                             ctx->scatter.atomic_rank && n >= hybrid_min && n >= (1u << 22) &&
+                             static_cast<uint64_t>(n) <= 2ull * vrs::kMsdBucketCount * local_cap &&
                              (ctx->os_groups == 0 || ctx->os_groups == 8);
     const uint32_t G = msd_capable ? 8u : ctx->os_groups ? ctx->os_groups : (n < (1u << 26) ? 8u : 32u);
     const uint32_t T = vrs::onesweep_tile_keys(key_bytes);
@@ -802,7 +805,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
             VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, kbuf[cur]->ptr, n, group_len, ctx->os_tables, ctx->os_status,
                                                       rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts, ev));
             VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
-                                              ctx->os_host_head_dev, stamp, n, T, tiles_b_cap, 1u, ctx->os_tables, group_len,
+                                              ctx->os_host_head_dev, stamp, n, T, tiles_b_cap, local_cap, ctx->os_tables, group_len,
                                               tile_cap, blind_cap, cuts0));
         } else {
             VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, group_len, G,
@@ -822,8 +825,10 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         const uint32_t blind_passes = msd_capable ? 1u : 4u;
         if (msd_capable) {  // the first MSD pass goes first: it is the one that usually runs, the other then leaves behind it
             if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
-            VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kbuf[cur_at_start]->ptr, kbuf[cur_at_start ^ 1u]->ptr, nullptr,
-                                                      nullptr, ctx->os_plan_a, 0, vrs::kShiftFromPlan, ctx->os_status, tiles0, false,
+            VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kbuf[cur_at_start]->ptr, kbuf[cur_at_start ^ 1u]->ptr,
+                                                      values ? static_cast<const uint32_t *>(vbuf[cur_at_start]->ptr) : nullptr,
+                                                      values ? static_cast<uint32_t *>(vbuf[cur_at_start ^ 1u]->ptr) : nullptr,
+                                                      ctx->os_plan_a, 0, vrs::kShiftFromPlan, ctx->os_status, tiles0, false,
                                                       ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes, ctx->os_spin_budget,
                                                       ctx->os_hold_tile, ev, ctx->os_misplace));
         }
@@ -837,10 +842,15 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
             if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + 1;  // the LSD pass 0 left at once: hand its events back
             if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
             VRS_HIP(ctx, vrs::launch_msd_pass_b(ctx->stream, static_cast<const uint32_t *>(kbuf[cur_at_start ^ 1u]->ptr),
-                                                static_cast<uint32_t *>(kbuf[cur_at_start]->ptr), ctx->os_msd_plan, ctx->os_status,
-                                                head.msd_tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map, ctx->os_spin_budget, ev));
+                                                static_cast<uint32_t *>(kbuf[cur_at_start]->ptr),
+                                                values ? static_cast<const uint32_t *>(vbuf[cur_at_start ^ 1u]->ptr) : nullptr,
+                                                values ? static_cast<uint32_t *>(vbuf[cur_at_start]->ptr) : nullptr, ctx->os_msd_plan,
+                                                ctx->os_status, head.msd_tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map,
+                                                ctx->os_spin_budget, ev));
             if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
-            VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(kbuf[cur_at_start]->ptr), ctx->os_msd_plan, ev));
+            VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(kbuf[cur_at_start]->ptr),
+                                                    values ? static_cast<uint32_t *>(vbuf[cur_at_start]->ptr) : nullptr,
+                                                    ctx->os_msd_plan, head.msd_max_bucket, ev));
             cur = cur_at_start;
             ctx->os_hybrid_sorts++;
             continue;

@@ -182,15 +182,19 @@ hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_
 // host head and stamps it
 hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
-                           uint32_t tiles_b_cap, uint32_t enabled, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
+                           uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
                            uint32_t blind_cap, const StreamCuts &cuts0);
 // second MSD pass: bits [18, 24) inside every top-byte bucket; grid of 8 * tiles_b workgroups; status rows: 8 * tiles_b
-hipError_t launch_msd_pass_b(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const MsdPlan *msd,
-                             uint32_t *status, uint32_t tiles_b, bool atomic_rank, unsigned long long xcc_map,
-                             uint32_t spin_budget, LaunchEvents ev = {});
-// every bucket sorted by its low 18 bits, in place
-hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, const MsdPlan *msd, LaunchEvents ev = {});
-uint32_t msd_local_capacity();
+// values_in / values_out: uint32 payloads that follow their keys (nullptr: keys only)
+hipError_t launch_msd_pass_b(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *values_in,
+                             uint32_t *values_out, const MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
+                             unsigned long long xcc_map, uint32_t spin_budget, LaunchEvents ev = {});
+// every bucket sorted by its low 18 bits, in place (stable; values, if any, follow their keys)
+// max_bucket: the plan's msd_max_bucket (picks the workgroup shape: 256 x 26 keys up to 6656, else 512 x 26)
+hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *values, const MsdPlan *msd, uint32_t max_bucket,
+                                 LaunchEvents ev = {});
+// keys the local sort of one bucket can hold (the plan refuses the hybrid form when a bucket has more)
+uint32_t msd_local_capacity(bool pairs);
 
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups
 hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks);

@@ -1411,7 +1411,7 @@ struct BitsDigit {
 __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ counts, MsdPlan *__restrict__ msd,
                                                        OnesweepPlan *__restrict__ plan_a, OnesweepPlan *__restrict__ plan_lsd,
                                                        OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
-                                                       uint32_t tiles_b_cap, uint32_t enabled, uint32_t *__restrict__ tables,
+                                                       uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *__restrict__ tables,
                                                        uint32_t group_len, uint32_t tile_cap, uint32_t blind_cap,
                                                        StreamCuts cuts0) {
     // first the plan of the four LSD passes (the same workgroup, no launch of its own; the head is stamped at the end)
@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
     // 0.80 ms LSD vs 0.89 ms hybrid at 10^8 keys), a wider one cannot occur; at most 18 low bits go to the local sort
     const uint32_t shift = counts[kMsdProbeWord], over = counts[kMsdOverWord];
     if (tid == 0)
-        s_ok = (enabled != 0u && over == 0u && shift >= kMsdMinShift && shift <= kMsdMaxShift && s_max <= kLocalCap && s_tiles_b <= tiles_b_cap) ? 1u : 0u;
+        s_ok = (over == 0u && shift >= kMsdMinShift && shift <= kMsdMaxShift && s_max <= local_cap && s_tiles_b <= tiles_b_cap) ? 1u : 0u;
     __syncthreads();
     // (4) the first MSD pass's streams are pass 0's (slices of the input); exactly one of the two speculatively enqueued
     //     first passes is armed
@@ -1521,12 +1521,13 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
 // Second MSD pass: inside every top-byte bucket (a contiguous range of the first pass's output) a stable scatter by bits
 // 18-23 -- the look-back machinery with one chain per bucket.  Block b -> XCD b % 8, which walks its 32 buckets in order;
 // status row of (XCD x, its j-th tile) = j * 8 + x, so a bucket's tiles are 8 rows apart like a stream's.
-template <int RANK>
+template <int RANK, bool PAIRS>
 __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out,
+                                                            const uint32_t *__restrict__ values_in, uint32_t *__restrict__ values_out,
                                                             const MsdPlan *__restrict__ msd, uint32_t *__restrict__ status,
                                                             unsigned long long xcc_map, uint32_t spin_budget) {
     constexpr uint32_t kTile = 16 * 8 * 64;
-    __shared__ ChunkSmem<uint32_t, 16, 8, false> sm;
+    __shared__ ChunkSmem<uint32_t, 16, 8, PAIRS> sm;
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
     const uint32_t *pt = msd->xcd_tiles[x];
     if (j >= pt[32]) return;  // uniform per workgroup
@@ -1560,18 +1561,19 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const uint32_t *__re
     lb.budget = spin_budget;
     lb.seed = threadIdx.x < kMsdSub ? msd->base[(a << kMsdSubBits) + threadIdx.x] : 0u;
     uint32_t unused = 0;
+    const uint32_t *vin = PAIRS ? values_in + begin : nullptr;
     if (valid == kTile)
-        scatter_chunk<uint32_t, 16, 8, false, RANK, true>(sm, keys_in + begin, nullptr, keys_out, nullptr, valid, dg, unused, lb);
+        scatter_chunk<uint32_t, 16, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     else
-        scatter_chunk<uint32_t, 16, 8, false, RANK, false>(sm, keys_in + begin, nullptr, keys_out, nullptr, valid, dg, unused, lb);
+        scatter_chunk<uint32_t, 16, 8, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
 }
 
 // One stable LSD pass over the keys a workgroup holds in registers (wave-striped: wave v owns ITEMS * 64 consecutive
 // positions, item i of lane l is position v * ITEMS * 64 + i * 64 + l), through LDS: per-wave counters fed by returning
 // LDS atomics (lane order: the RANK_ATOMIC property), a scan over bins and waves, re-bucketing, striped read-back.
-template <int THREADS, int ITEMS, int BITS>
-__device__ __forceinline__ void local_pass(uint32_t (&key)[ITEMS], uint32_t *s_keys, uint32_t *s_hist, uint32_t *s_tmp,
-                                           uint32_t shift) {
+template <int THREADS, int ITEMS, int BITS, bool PAIRS>
+__device__ __forceinline__ void local_pass(uint32_t (&key)[ITEMS], uint32_t (&val)[PAIRS ? ITEMS : 1], uint32_t *s_keys,
+                                           uint32_t *s_vals, uint32_t *s_hist, uint32_t *s_tmp, uint32_t shift) {
     constexpr int WAVES = THREADS / 64, BINS = 1 << BITS;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t c = tid; c < WAVES * BINS; c += THREADS) s_hist[c] = 0;
@@ -1633,19 +1635,28 @@ __device__ __forceinline__ void local_pass(uint32_t (&key)[ITEMS], uint32_t *s_k
     for (int i = 0; i < ITEMS; ++i) rank[i] += my[(key[i] >> shift) & (BINS - 1)];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) s_keys[rank[i]] = key[i];
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) s_vals[rank[i]] = val[i];
+    }
     __syncthreads();
     const uint32_t seg = wave * (ITEMS * 64) + lane;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) key[i] = s_keys[seg + i * 64];
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) val[i] = s_vals[seg + i * 64];
+    }
     __syncthreads();
 }
 
-// the bucket with ITEMS keys per thread (n <= ITEMS * kLocalThreads): read once, two stable 9-bit passes, written back
-template <int ITEMS>
-__device__ __forceinline__ void local_sort_bucket(uint32_t *bucket, uint32_t n, uint32_t *s_keys, uint32_t *s_hist, uint32_t *s_tmp) {
+// the bucket with ITEMS keys per thread (n <= ITEMS * THREADS): read once, two stable 9-bit passes, written back
+template <int THREADS, int ITEMS, bool PAIRS>
+__device__ __forceinline__ void local_sort_bucket(uint32_t *bucket, uint32_t *bucket_vals, uint32_t n, uint32_t *s_keys,
+                                                  uint32_t *s_vals, uint32_t *s_hist, uint32_t *s_tmp) {
     constexpr int BITS = 9;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t key[ITEMS];
+    uint32_t key[ITEMS], val[PAIRS ? ITEMS : 1];
     const uint32_t seg = wave * (ITEMS * 64) + lane;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -1653,18 +1664,32 @@ __device__ __forceinline__ void local_sort_bucket(uint32_t *bucket, uint32_t n, 
         const uint32_t k = bucket[idx < n ? idx : n - 1u];
         key[i] = idx < n ? k : 0xFFFFFFFFu;  // padding sorts behind every real key of the bucket and is not written
     }
-    local_pass<kLocalThreads, ITEMS, BITS>(key, s_keys, s_hist, s_tmp, 0);
-    local_pass<kLocalThreads, ITEMS, BITS>(key, s_keys, s_hist, s_tmp, BITS);
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t idx = seg + i * 64;
+            val[i] = bucket_vals[idx < n ? idx : n - 1u];
+        }
+    }
+    local_pass<THREADS, ITEMS, BITS, PAIRS>(key, val, s_keys, s_vals, s_hist, s_tmp, 0);
+    local_pass<THREADS, ITEMS, BITS, PAIRS>(key, val, s_keys, s_vals, s_hist, s_tmp, BITS);
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t idx = seg + i * 64;
         if (idx < n) bucket[idx] = key[i];
     }
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t idx = seg + i * 64;
+            if (idx < n) bucket_vals[idx] = val[i];
+        }
+    }
 }
 
 // One workgroup per bucket of the MSD partition (<= kLocalCap keys, guaranteed by the plan), sorted by its low 18 bits
 // inside LDS, in place.  The keys-per-thread count is picked per bucket (workgroup-uniform), so the work follows the
-// bucket's size, not the capacity.
+// bucket's size, not the capacity.  Keys only: 256 threads x up to 26 keys, four workgroups per CU.
 __global__ __launch_bounds__(kLocalThreads, 4) void msd_local_sort_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd) {
     constexpr int WAVES = kLocalThreads / 64;
     __shared__ uint32_t s_keys[kLocalCap];
@@ -1674,13 +1699,62 @@ __global__ __launch_bounds__(kLocalThreads, 4) void msd_local_sort_kernel(uint32
     if (n == 0 || n > kLocalCap) return;  // uniform; n > capacity cannot happen (the plan would have refused)
     uint32_t *bucket = keys + begin;
     const uint32_t used = (n + kLocalThreads - 1u) / kLocalThreads;
-    if (used <= 4) local_sort_bucket<4>(bucket, n, s_keys, s_hist, s_tmp);
-    else if (used <= 8) local_sort_bucket<8>(bucket, n, s_keys, s_hist, s_tmp);
-    else if (used <= 12) local_sort_bucket<12>(bucket, n, s_keys, s_hist, s_tmp);
-    else if (used <= 16) local_sort_bucket<16>(bucket, n, s_keys, s_hist, s_tmp);
-    else if (used <= 20) local_sort_bucket<20>(bucket, n, s_keys, s_hist, s_tmp);
-    else if (used <= 24) local_sort_bucket<24>(bucket, n, s_keys, s_hist, s_tmp);
-    else local_sort_bucket<kLocalItems>(bucket, n, s_keys, s_hist, s_tmp);
+    if (used <= 4) local_sort_bucket<kLocalThreads, 4, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 8) local_sort_bucket<kLocalThreads, 8, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 12) local_sort_bucket<kLocalThreads, 12, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 16) local_sort_bucket<kLocalThreads, 16, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 20) local_sort_bucket<kLocalThreads, 20, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 24) local_sort_bucket<kLocalThreads, 24, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else local_sort_bucket<kLocalThreads, kLocalItems, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+}
+
+// The same for sorts whose largest bucket holds more than kLocalCap keys (uniform keys: N above 1.05e8): 512 threads x up
+// to 26 keys, capacity 13312, 69 KB of LDS -- two workgroups per CU, the same 16 waves.
+constexpr int kLocalBigThreads = 512;
+constexpr uint32_t kLocalBigCap = kLocalBigThreads * kLocalItems;
+__global__ __launch_bounds__(kLocalBigThreads, 2) void msd_local_sort_big_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd) {
+    constexpr int WAVES = kLocalBigThreads / 64;
+    __shared__ uint32_t s_keys[kLocalBigCap];
+    __shared__ uint32_t s_hist[WAVES << 9];
+    __shared__ uint32_t s_tmp[1 + WAVES];
+    const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
+    if (n == 0 || n > kLocalBigCap) return;
+    uint32_t *bucket = keys + begin;
+    const uint32_t used = (n + kLocalBigThreads - 1u) / kLocalBigThreads;
+    if (used <= 4) local_sort_bucket<kLocalBigThreads, 4, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 8) local_sort_bucket<kLocalBigThreads, 8, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 12) local_sort_bucket<kLocalBigThreads, 12, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 14) local_sort_bucket<kLocalBigThreads, 14, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 16) local_sort_bucket<kLocalBigThreads, 16, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 18) local_sort_bucket<kLocalBigThreads, 18, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 20) local_sort_bucket<kLocalBigThreads, 20, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 22) local_sort_bucket<kLocalBigThreads, 22, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else if (used <= 24) local_sort_bucket<kLocalBigThreads, 24, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    else local_sort_bucket<kLocalBigThreads, kLocalItems, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+}
+
+// Key + payload pairs: the payload doubles a bucket's LDS footprint (53 + 16 KB), so two workgroups of 512 threads x up
+// to 13 pairs share a CU.
+constexpr int kLocalPairThreads = 512, kLocalPairItems = kLocalCap / kLocalPairThreads;  // 13
+__global__ __launch_bounds__(kLocalPairThreads, 4) void msd_local_sort_pairs_kernel(uint32_t *__restrict__ keys,
+                                                                                   uint32_t *__restrict__ values,
+                                                                                   const MsdPlan *__restrict__ msd) {
+    constexpr int WAVES = kLocalPairThreads / 64;
+    __shared__ uint32_t s_keys[kLocalCap];
+    __shared__ uint32_t s_vals[kLocalCap];
+    __shared__ uint32_t s_hist[WAVES << 9];
+    __shared__ uint32_t s_tmp[1 + WAVES];
+    const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
+    if (n == 0 || n > kLocalCap) return;
+    uint32_t *bucket = keys + begin, *bvals = values + begin;
+    const uint32_t used = (n + kLocalPairThreads - 1u) / kLocalPairThreads;
+    if (used <= 2) local_sort_bucket<kLocalPairThreads, 2, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 4) local_sort_bucket<kLocalPairThreads, 4, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 6) local_sort_bucket<kLocalPairThreads, 6, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 8) local_sort_bucket<kLocalPairThreads, 8, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 10) local_sort_bucket<kLocalPairThreads, 10, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 12) local_sort_bucket<kLocalPairThreads, 12, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else local_sort_bucket<kLocalPairThreads, kLocalPairItems, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2051,31 +2125,42 @@ hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_
 
 hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
-                           uint32_t tiles_b_cap, uint32_t enabled, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
+                           uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
                            uint32_t blind_cap, const StreamCuts &cuts0) {
     hipLaunchKernelGGL(msd_plan_kernel, dim3(1), dim3(1024), 0, stream, msd_counts, msd, plan_a, plan_lsd, host_head, stamp, n,
-                       tile, tiles_b_cap, enabled, tables, group_len, tile_cap, blind_cap, cuts0);
+                       tile, tiles_b_cap, local_cap, tables, group_len, tile_cap, blind_cap, cuts0);
     return hipGetLastError();
 }
 
-hipError_t launch_msd_pass_b(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const MsdPlan *msd,
-                             uint32_t *status, uint32_t tiles_b, bool atomic_rank, unsigned long long xcc_map,
-                             uint32_t spin_budget, LaunchEvents ev) {
+hipError_t launch_msd_pass_b(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *values_in,
+                             uint32_t *values_out, const MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
+                             unsigned long long xcc_map, uint32_t spin_budget, LaunchEvents ev) {
     if (tiles_b == 0) return hipSuccess;
     const dim3 grid(8 * tiles_b), block(512);
-    if (atomic_rank)
-        VRS_LAUNCH(msd_pass_b_kernel<RANK_ATOMIC>, grid, block, stream, ev, keys_in, keys_out, msd, status, xcc_map, spin_budget);
+#define VRS_PASS_B(RANK, PAIRS) \
+    VRS_LAUNCH((msd_pass_b_kernel<RANK, PAIRS>), grid, block, stream, ev, keys_in, keys_out, values_in, values_out, msd, status, xcc_map, spin_budget)
+    if (values_in != nullptr) {
+        if (atomic_rank) VRS_PASS_B(RANK_ATOMIC, true); else VRS_PASS_B(RANK_BALLOT, true);
+    } else {
+        if (atomic_rank) VRS_PASS_B(RANK_ATOMIC, false); else VRS_PASS_B(RANK_BALLOT, false);
+    }
+#undef VRS_PASS_B
+    return hipGetLastError();
+}
+
+hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *values, const MsdPlan *msd, uint32_t max_bucket,
+                                 LaunchEvents ev) {
+    if (max_bucket > msd_local_capacity(values != nullptr)) return hipErrorInvalidValue;  // the plan would have refused
+    if (values != nullptr)
+        VRS_LAUNCH(msd_local_sort_pairs_kernel, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, keys, values, msd);
+    else if (max_bucket > kLocalCap)
+        VRS_LAUNCH(msd_local_sort_big_kernel, dim3(kMsdBuckets), dim3(kLocalBigThreads), stream, ev, keys, msd);
     else
-        VRS_LAUNCH(msd_pass_b_kernel<RANK_BALLOT>, grid, block, stream, ev, keys_in, keys_out, msd, status, xcc_map, spin_budget);
+        VRS_LAUNCH(msd_local_sort_kernel, dim3(kMsdBuckets), dim3(kLocalThreads), stream, ev, keys, msd);
     return hipGetLastError();
 }
 
-hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, const MsdPlan *msd, LaunchEvents ev) {
-    VRS_LAUNCH(msd_local_sort_kernel, dim3(kMsdBuckets), dim3(kLocalThreads), stream, ev, keys, msd);
-    return hipGetLastError();
-}
-
-uint32_t msd_local_capacity() { return kLocalCap; }
+uint32_t msd_local_capacity(bool pairs) { return pairs ? kLocalCap : kLocalBigCap; }
 
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
                                uint32_t group_len, uint32_t groups, uint32_t *tables, uint32_t *status,
