@@ -179,11 +179,12 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * host memory -- i.e. until the counting read has run; it never waits for the sort itself, which still completes
  * asynchronously on the context's stream.  Passes whose digit is the same for every key (small keys, constant bytes)
  * are the identity and are left out.  Same result, bit for bit.
- * uint32 keys without payload, from 2^26 keys on (VRS_TUNE_HYBRID, VRS_TUNE_HYBRID_MIN_KEYS): the same counting read also
- * histograms the top 14 bits of the key range, and when every such bucket fits one workgroup's LDS (uniform keys: up to
- * about 1.03 * 10^8) the four LSD passes are replaced by an MSD partition in two look-back scatter passes (8 + 6 bits)
- * plus one pass in which every bucket is sorted inside LDS -- 28 bytes per key (DESIGN.md "K5b").  The choice is made on
- * the device from that one read; either form gives the same bits.
+ * uint32 keys from 2^26 keys on, uint32 key + payload pairs from 2^25 pairs on (VRS_TUNE_HYBRID, VRS_TUNE_HYBRID_MIN_KEYS):
+ * the same counting read also histograms the top 14 bits of the key range, and when every such bucket fits one workgroup's
+ * LDS (13312 keys or 6656 pairs; uniform keys: up to about 2.1 * 10^8 keys, 1.03 * 10^8 pairs) the four LSD passes are
+ * replaced by an MSD partition in two look-back scatter passes (8 + 6 bits) plus one pass in which every bucket is sorted
+ * inside LDS -- 28 bytes per key instead of 36, 52 per pair instead of 68 (DESIGN.md "K5b").  The choice is made on the
+ * device from that one read; either form gives the same bits, payloads of equal keys in input order included.
  */
 int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements);
 int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
@@ -309,11 +310,12 @@ typedef enum vrs_tuning_key {
                                      its counts, so its successors must run out of spin budget and recount */
     VRS_TUNE_DIGIT_TABLE_GROUPS = 8, /* groups per pass of the one-call sort's counting read: 8, 16, 32, or 0 (default):
                                      8 below 2^26 keys, 32 from there on */
-    VRS_TUNE_HYBRID = 11,          /* vrs_sort_keys_u32 of large inputs: 1 (default) = the 28-byte-per-key hybrid form (MSD
+    VRS_TUNE_HYBRID = 11,          /* vrs_sort_keys_u32 / vrs_sort_pairs_u32 of large inputs: 1 (default) = the 28-byte-per-key hybrid form (MSD
                                      partition by the top 14 bits in two look-back passes + an LDS-local sort of every
                                      bucket) whenever every bucket fits a workgroup's LDS, else the four LSD passes (decided
                                      on the device from the same counting read); 0 = always the LSD passes */
-    VRS_TUNE_HYBRID_MIN_KEYS = 12, /* the hybrid form is considered from this many keys on (default 2^26; at least 2^22) */
+    VRS_TUNE_HYBRID_MIN_KEYS = 12, /* the hybrid form is considered from this many keys on, and from half as many pairs
+                                     (default 2^26; never below 2^22 elements) */
     VRS_TUNE_FUSED_PLAN = 10,      /* 1: the last workgroup of the one-call sort's counting read turns the digit tables
                                      into the plan; 0 (default): a separate single-workgroup plan kernel (measured a
                                      tie at 10^7 and 10^8 keys) */
