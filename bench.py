@@ -138,6 +138,11 @@ def bench_single(args):
         gpu.check(gpu.lib.vrs_one_call_hybrid_sorts(gpu.handle, ctypes.byref(h)))
         return h.value
 
+    def hybrid_recounts():  # sorts that needed a second counting read (fast count, then a refused hybrid form)
+        h = ctypes.c_uint64()
+        gpu.check(gpu.lib.vrs_one_call_hybrid_recounts(gpu.handle, ctypes.byref(h)))
+        return h.value
+
     one_call = args.path == "one_call"
     paths = {"one_call": (sort_one_call, capi.VRS_KERNEL_LOOKBACK_SCATTER, "lookback_scatter"),
              "contract": (sort_batch, capi.VRS_KERNEL_SCATTER, "scatter")}
@@ -170,9 +175,10 @@ def bench_single(args):
 
     # ---- timed region: exactly K steps, inputs resident.  The dominant kernel's launches carry HIP events on their
     # own dispatch packets, on the stream they are launched on; nothing else is instrumented.
-    hybrid_before = hybrid_sorts()
+    hybrid_before, recounts_before = hybrid_sorts(), hybrid_recounts()
     elapsed, kernels = run_steps(primary, K, 1 << dominant_id)
     hybrid_steps = hybrid_sorts() - hybrid_before  # K if every timed one-call sort took the hybrid form, 0 if none did
+    recount_steps = hybrid_recounts() - recounts_before
     # the timed region's own outputs, every one of them, before anything overwrites them (one device read each)
     fingerprints = [p_.verifyKeys(n)[1:] for p_ in pristine]
     timed_bad = [i for i in range(K)
@@ -272,7 +278,8 @@ def bench_single(args):
                                f"multi_radixsort, 1xMI355X, keys resident in HBM",
                    "path": (("vrs_sort_keys_u32, hybrid form: one counting read of the keys, an MSD partition by the top 14 bits in "
                              "two stable scatter passes with decoupled look-back (8 + 6 bits), then every bucket sorted by its "
-                             "low 18 bits inside one workgroup's LDS (28 B/key)") if hybrid else
+                             "low 18 bits inside one workgroup's LDS (28 B/key); " + str(recount_steps) + " of the timed sorts "
+                             "needed a second counting read") if hybrid else
                             ("vrs_sort_keys_u32: the library runs the four 8-bit passes itself -- one counting read of the "
                              "keys, then four stable scatter passes with decoupled look-back (36 B/key)")) if one_call else
                            ("MultiRadixSortPass stages, as MultiRadixSort::execute drives them: 4 x [histograms, prefix, "

@@ -287,6 +287,9 @@ int vrs_one_call_stats(vrs_context ctx, uint64_t *lookback_passes, uint64_t *fal
 int vrs_one_call_relaunched_passes(vrs_context ctx, uint64_t *relaunched_passes);
 /* One-call sorts that took the hybrid form (VRS_TUNE_HYBRID).  Cumulative; diagnostics only. */
 int vrs_one_call_hybrid_sorts(vrs_context ctx, uint64_t *hybrid_sorts);
+/* One-call sorts that, after a fast count (VRS_TUNE_HYBRID_FAST_COUNT) and a plan that refused the hybrid form, started over
+ * as LSD sorts with a second counting read.  Cumulative; diagnostics only. */
+int vrs_one_call_hybrid_recounts(vrs_context ctx, uint64_t *recounts);
 
 /* Ranking method in effect: 1 = __ballot match-any, 2 = returning LDS atomics. */
 int vrs_rank_mode(vrs_context ctx);
@@ -316,6 +319,12 @@ typedef enum vrs_tuning_key {
                                      on the device from the same counting read); 0 = always the LSD passes */
     VRS_TUNE_HYBRID_MIN_KEYS = 12, /* the hybrid form is considered from this many keys on, and from half as many pairs
                                      (default 2^26; never below 2^22 elements) */
+    VRS_TUNE_HYBRID_FAST_COUNT = 13, /* the counting read of a sort the hybrid form may take: 0 = always counts the LSD
+                                     tables beside the bucket histogram (a refusal costs nothing extra); 2 = counts only
+                                     the bucket histogram when the probed key range allows the hybrid form (1 LDS add per
+                                     key instead of 5: about 20 us at 10^8 keys) and starts over as an LSD sort, with a second
+                                     counting read, if the plan refuses; 1 (default) = adaptive: like 2 while the context's
+                                     previous hybrid-capable sort took the hybrid form, like 0 after a refusal */
     VRS_TUNE_FUSED_PLAN = 10,      /* 1: the last workgroup of the one-call sort's counting read turns the digit tables
                                      into the plan; 0 (default): a separate single-workgroup plan kernel (measured a
                                      tie at 10^7 and 10^8 keys) */

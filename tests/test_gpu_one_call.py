@@ -481,33 +481,75 @@ def make_hybrid_keys(n, dist, seed):
     return make_keys(n, dist, seed)
 
 
+def probed_shift(keys):
+    """The bucket shift the counting read derives from its strided sample of 4096 keys (digit_tables_kernel)."""
+    samples = min(keys.size, 4096)
+    acc = int(np.bitwise_or.reduce(keys[:: keys.size // samples][:samples]))
+    return max(acc.bit_length() - 14, 0)
+
+
+def hybrid_recounts(ctx):
+    import ctypes
+    r = ctypes.c_uint64()
+    ctx.check(ctx.lib.vrs_one_call_hybrid_recounts(ctx.handle, ctypes.byref(r)))
+    return r.value
+
+
+@pytest.mark.parametrize("fast_count", [0, 2])
 @pytest.mark.parametrize("dist", HYBRID_DISTS)
 @pytest.mark.parametrize("n", [(1 << 22) + 1, 9000001])
-def test_hybrid_form_equals_std_sort(gpu_context, oracle, n, dist):
+def test_hybrid_form_equals_std_sort(gpu_context, oracle, n, dist, fast_count):
     """The hybrid form at sizes a test can afford (VRS_TUNE_HYBRID_MIN_KEYS lowered to 2^22): buckets of a few hundred
     keys, ragged tiles in every top-byte bucket of the second pass, empty buckets, and distributions whose buckets cannot
-    fit a workgroup (the plan must say no and the four LSD passes must run from the SAME counting read)."""
+    fit a workgroup (the plan must say no and the four LSD passes must run -- from the SAME counting read when it counted
+    everything, VRS_TUNE_HYBRID_FAST_COUNT = 0, from a second one when it counted only the bucket histogram, = 2)."""
     ctx = gpu_context
     keys = make_hybrid_keys(n, dist, seed=n % 313)
     ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
-    h0 = hybrid_sorts(ctx)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_FAST_COUNT, fast_count)
+    h0, r0 = hybrid_sorts(ctx), hybrid_recounts(ctx)
     try:
         out, stats = sort_keys(ctx, keys)
     finally:
         ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
-    took = hybrid_sorts(ctx) - h0
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_FAST_COUNT, 1)
+    took, recounts = hybrid_sorts(ctx) - h0, hybrid_recounts(ctx) - r0
     assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
-    assert stats["digit_tables"] == 1
     # the buckets are the top 14 bits of the key RANGE (32-bit keys: bits 18-31, the reference's 28-bit keys: bits 14-27);
     # ranges below 27 bits are left to the LSD passes, which then drop an identity pass
     bits = int(keys.max()).bit_length()
     shift = bits - 14
     fits = 13 <= shift <= 18 and int(np.bincount(keys >> np.uint32(shift), minlength=1 << 14).max()) <= 13312
     assert took == (1 if fits else 0), (dist, bits)
+    # a fast count leaves the LSD tables out when the SAMPLED range allows the hybrid form: a refusal then counts again
+    recount = fast_count == 2 and not fits and probed_shift(keys) >= 13
+    assert recounts == (1 if recount else 0)
+    assert stats["digit_tables"] == (2 if recount else 1)
     if fits:
         assert stats["lookback_scatter"] == 2 and stats["local_sort"] == 1 and stats["scatter"] == 0
     else:
         assert stats["local_sort"] == 0 and stats["lookback_scatter"] + stats["scatter"] == 4 - identity_passes(keys)
+
+
+def test_fast_count_is_armed_by_a_hybrid_sort_and_disarmed_by_a_refusal(gpu_context):
+    """VRS_TUNE_HYBRID_FAST_COUNT = 1 (default): the counting read leaves the LSD tables out only while the context's last
+    hybrid-capable sort took the hybrid form.  uniform, uniform, hot, hot, uniform, uniform -> one recount (the first hot
+    sort), and every output sorted."""
+    ctx, n = gpu_context, (1 << 22) + 4097
+    uniform = make_keys(n, "uniform", seed=41)
+    hot = make_hybrid_keys(n, "one_hot_bucket", seed=42)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_FAST_COUNT, 1)  # also disarms
+    seen = []
+    try:
+        for keys in (uniform, uniform, hot, hot, uniform, uniform):
+            h0, r0 = hybrid_sorts(ctx), hybrid_recounts(ctx)
+            out, stats = sort_keys(ctx, keys)
+            assert np.array_equal(out, np.sort(keys))
+            seen.append((hybrid_sorts(ctx) - h0, hybrid_recounts(ctx) - r0, stats["digit_tables"]))
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+    assert seen == [(1, 0, 1), (1, 0, 1), (0, 1, 2), (0, 0, 1), (1, 0, 1), (1, 0, 1)]
 
 
 @pytest.mark.parametrize("hook", ["misplace", "hold", "ballot"])

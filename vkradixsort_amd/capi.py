@@ -47,6 +47,7 @@ VRS_TUNE_SINGLE_MAX_KEYS = 9
 VRS_TUNE_FUSED_PLAN = 10
 VRS_TUNE_HYBRID = 11
 VRS_TUNE_HYBRID_MIN_KEYS = 12
+VRS_TUNE_HYBRID_FAST_COUNT = 13
 
 
 class PushConstants(Structure):
@@ -116,6 +117,7 @@ _SIGNATURES = [
     ("vrs_one_call_stats", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
     ("vrs_one_call_relaunched_passes", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_one_call_hybrid_sorts", c_int, [c_void_p, POINTER(c_uint64)]),
+    ("vrs_one_call_hybrid_recounts", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_debug_download_offsets", c_int, [c_void_p, c_void_p, c_size_t]),
     ("vrs_debug_atomic_rank_selftest", c_int, [c_void_p, c_uint32, c_uint32, POINTER(c_uint64)]),
     ("vrs_rank_mode", c_int, [c_void_p]),

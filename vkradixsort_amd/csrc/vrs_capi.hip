@@ -68,13 +68,16 @@ struct vrs_context_t {
     unsigned long long xcc_map = 0;      // byte x = that XCC for b % 8 == x
     uint64_t os_lookback_passes = 0;
     uint64_t os_relaunched_passes = 0;
-    // hybrid form (K5b): uint32 keys from 2^24 on
+    // hybrid form (K5b)
     bool os_hybrid = true;               // VRS_TUNE_HYBRID
+    int os_fast_count = 1;               // VRS_TUNE_HYBRID_FAST_COUNT: 0 never, 1 adaptive, 2 always
+    bool os_fast_count_armed = false;    // adaptive: the last hybrid-capable sort of this context took the hybrid form
+    uint64_t os_hybrid_recounts = 0;     // sorts that started over as LSD sorts after a fast count and a refusal
     uint32_t os_hybrid_min_keys = 1u << 26;  // VRS_TUNE_HYBRID_MIN_KEYS
     uint32_t *os_msd_counts = nullptr;   // [16384] top-14-bit histogram + [8][256] top-byte counts per pass-0 group, zero between sorts
     vrs::MsdPlan *os_msd_plan = nullptr;
     vrs::OnesweepPlan *os_plan_a = nullptr;  // seeds and streams of the first MSD pass
-    uint64_t os_hybrid_sorts = 0;   // look-back passes enqueued a second time (first enqueue left at once: see sort_one_read)
+    uint64_t os_hybrid_sorts = 0;        // one-call sorts that took the hybrid form
     uint64_t os_fallback_passes = 0;
     uint64_t os_skipped_passes = 0;      // identity passes (one digit value holds every key) the one-call sort left out     // passes the one-call sort ran through the contract path (unbalanced streams)
 };
@@ -682,6 +685,11 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
                              ctx->scatter.atomic_rank && n >= hybrid_min && n >= (1u << 22) &&
                              static_cast<uint64_t>(n) <= 2ull * vrs::kMsdBucketCount * local_cap &&
                              (ctx->os_groups == 0 || ctx->os_groups == 8);
+    // Fast count: the counting read of a hybrid-capable sort fills only the bucket histogram (1 LDS add per key instead of
+    // 5).  If the plan then refuses the hybrid form, nothing has been moved and the sort starts over as an LSD sort -- a
+    // second counting read.  Adaptive (default): fast only while the context's last hybrid-capable sort took the hybrid
+    // form; after a refusal the next ones count everything again (a refusal then costs nothing extra) until one is taken.
+    const bool fast_count = msd_capable && (ctx->os_fast_count == 2 || (ctx->os_fast_count == 1 && ctx->os_fast_count_armed));
     const uint32_t G = msd_capable ? 8u : ctx->os_groups ? ctx->os_groups : (n < (1u << 26) ? 8u : 32u);
     const uint32_t T = vrs::onesweep_tile_keys(key_bytes);
     const uint32_t tiles_total = (n + T - 1) / T;
@@ -803,10 +811,11 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
             // plan kernel makes the LSD plan as always, decides which form runs, arms exactly one of the two first passes
             // and stamps the head
             VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, kbuf[cur]->ptr, n, group_len, ctx->os_tables, ctx->os_status,
-                                                      rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts, ev));
+                                                      rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts,
+                                                      fast_count, ev));
             VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
                                               ctx->os_host_head_dev, stamp, n, T, tiles_b_cap, local_cap, ctx->os_tables, group_len,
-                                              tile_cap, blind_cap, cuts0));
+                                              tile_cap, blind_cap, cuts0, fast_count));
         } else {
             VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, group_len, G,
                                                   ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS,
@@ -837,6 +846,19 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         if ((rc = wait_for_plan(ctx, stamp))) return rc;
         const vrs::OnesweepPlanHead &head = *ctx->os_host_head;
         const bool timed = (ctx->profile_mask & (1u << VRS_KERNEL_LOOKBACK_SCATTER)) != 0;
+        if (msd_capable && !head.msd_ok && head.lsd_missing) {
+            // fast count, and the plan refused the hybrid form: both speculative first passes left at once, no key has
+            // moved.  Start over as an LSD sort (its own counting read).
+            if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before;
+            ctx->os_fast_count_armed = false;
+            ctx->os_hybrid_recounts++;
+            const bool saved = ctx->os_hybrid;
+            ctx->os_hybrid = false;
+            rc = sort_one_read(ctx, keys, keys_tmp, values, values_tmp, n, key_bytes);
+            ctx->os_hybrid = saved;
+            return rc;
+        }
+        if (msd_capable) ctx->os_fast_count_armed = head.msd_ok != 0u;
         if (msd_capable && head.msd_ok) {
             // hybrid form: the first MSD pass is running (keys -> partner); second pass back, then the buckets in place
             if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + 1;  // the LSD pass 0 left at once: hand its events back
@@ -1155,6 +1177,12 @@ int vrs_one_call_hybrid_sorts(vrs_context ctx, uint64_t *hybrid_sorts) {
     return VRS_OK;
 }
 
+int vrs_one_call_hybrid_recounts(vrs_context ctx, uint64_t *recounts) {
+    if (!ctx || !recounts) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or output is NULL");
+    *recounts = ctx->os_hybrid_recounts;
+    return VRS_OK;
+}
+
 int vrs_rank_mode(vrs_context ctx) { return ctx && ctx->scatter.atomic_rank ? 2 : 1; }
 
 int vrs_set_tuning(vrs_context ctx, int key, int value) {
@@ -1194,6 +1222,11 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
         case VRS_TUNE_HYBRID_MIN_KEYS:
             if (value < 0) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "hybrid threshold must be >= 0");
             ctx->os_hybrid_min_keys = static_cast<uint32_t>(value);
+            return VRS_OK;
+        case VRS_TUNE_HYBRID_FAST_COUNT:
+            if (value < 0 || value > 2) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "fast count mode must be 0, 1 or 2");
+            ctx->os_fast_count = value;
+            ctx->os_fast_count_armed = false;
             return VRS_OK;
         case VRS_TUNE_FUSED_PLAN:
             ctx->os_fused_plan = value != 0;

@@ -98,6 +98,7 @@ struct OnesweepPlanHead {
     uint32_t msd_tiles_b;       // rows of workgroups of the second MSD pass
     uint32_t msd_max_bucket;    // keys in the largest top-14-bit bucket
     uint32_t msd_shift_a;       // the first MSD pass's digit shift (top 8 bits of the key range)
+    uint32_t lsd_missing;       // 1 = the counting read counted only the bucket histogram (fast count): no LSD plan exists
     uint32_t ready;             // host copy only: the sort's stamp, written after everything else
 };
 struct OnesweepPlan {
@@ -171,19 +172,21 @@ struct MsdPlan {
 constexpr size_t kMsdCountWords = kMsdBucketCount + 8u * 256u + 64u;  // + the probed shift and the out-of-range flag
 constexpr uint32_t kShiftFromPlan = 0xFFFFFFFFu;  // launch_onesweep_scatter: take the shift from plan->head.msd_shift_a
 
-// same as launch_digit_tables with 8 groups, and fills msd_counts (uint32 keys only)
+// same as launch_digit_tables with 8 groups, and fills msd_counts (uint32 keys only); msd_only (fast count): a key range
+// the hybrid form can take gets ONLY the bucket histogram -- launch_msd_plan must be told the same
 hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *tables,
                                    uint32_t *status, size_t status_words, int compute_units, uint32_t *msd_counts,
-                                   LaunchEvents ev = {});
+                                   bool msd_only, LaunchEvents ev = {});
 // ONE workgroup: the plan of the four LSD passes (what launch_plan does, 8 groups), then the hybrid form's: bucket
 // offsets, the first MSD pass's seeds (into plan_a->group_seed[0]) and streams, the second pass's tile tables; decides
 // msd_ok (key range 27-32 bits and fully probed, largest bucket <= the local sort's capacity, XCD tile counts <=
 // tiles_b_cap), arms exactly one of the two speculative first passes (plan_a's or plan_lsd's blind descriptors), writes the
-// host head and stamps it
+// host head and stamps it.  msd_only: without LSD tables there is no LSD plan -- if msd_ok is 0 then, head.lsd_missing is 1
+// and neither first pass is armed (the caller counts again, for the LSD passes)
 hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                            uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
-                           uint32_t blind_cap, const StreamCuts &cuts0);
+                           uint32_t blind_cap, const StreamCuts &cuts0, bool msd_only);
 // second MSD pass: bits [18, 24) inside every top-byte bucket; grid of 8 * tiles_b workgroups; status rows: 8 * tiles_b
 // values_in / values_out: uint32 payloads that follow their keys (nullptr: keys only)
 hipError_t launch_msd_pass_b(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *values_in,

@@ -989,14 +989,16 @@ __device__ __forceinline__ uint32_t digit_word(uint64_t key, uint32_t base_shift
     return static_cast<uint32_t>(key >> base_shift);
 }
 
-// hm: the 16384-bin histogram of the key's top 14 bits (hybrid form, K5b), or nullptr
+// hm: the 16384-bin histogram of the key's top 14 bits (hybrid form, K5b), or nullptr; t0: nullptr = no LSD tables
 template <typename TI>
 __device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t *hm,
                                                    uint32_t msd_shift, uint32_t &msd_over, uint32_t w) {
-    atomicAdd(&t0[TI::t0(w, lane_id())], 1u);
-    atomicAdd(&t1[TI::t1(w)], 1u);
-    atomicAdd(&t2[TI::t2(w)], 1u);
-    atomicAdd(&t3[TI::t3(w)], 1u);
+    if (t0) {  // workgroup-uniform: nullptr when only the bucket histogram is counted (hybrid form, fast count)
+        atomicAdd(&t0[TI::t0(w, lane_id())], 1u);
+        atomicAdd(&t1[TI::t1(w)], 1u);
+        atomicAdd(&t2[TI::t2(w)], 1u);
+        atomicAdd(&t3[TI::t3(w)], 1u);
+    }
     if (hm) {
         const uint32_t b = w >> msd_shift;
         msd_over |= b >> kMsdBits;  // a key above the probed range: the plan will refuse the hybrid form
@@ -1011,6 +1013,20 @@ __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t
                                                        const typename KeyVec<K>::type &q, uint32_t base_shift,
                                                        uint32_t lane, uint32_t &vote) {
     constexpr int V = KeyVec<K>::kKeys;
+    if constexpr (MSD) {
+        if (t0 == nullptr) {  // only the bucket histogram (workgroup-uniform; hm != nullptr then)
+            uint32_t im[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const uint32_t b = digit_word(KeyVec<K>::get(q, j), base_shift) >> msd_shift;
+                msd_over |= b >> kMsdBits;
+                im[j] = min(b, kMsdBuckets - 1u);
+            }
+            if constexpr (VOTE) vote = table_vote<V>(im) ? 16u : 0u;
+            table_add<V>(hm, im, lane, (vote & 16u) != 0u);
+            return;
+        }
+    }
     uint32_t i0[V], i1[V], i2[V], i3[V], im[MSD ? V : 1];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -1135,6 +1151,7 @@ __device__ __forceinline__ void plan_body(uint32_t *__restrict__ tables, Oneswee
             if (mode != kPassLookback) first = static_cast<uint32_t>(q);
         }
         s_head.first_abnormal = first;
+        s_head.lsd_missing = 0;
         s_head.ready = 0;
     }
     __syncthreads();
@@ -1180,12 +1197,13 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
                                                                     uint32_t slices, uint32_t *__restrict__ tables,
                                                                     uint4 *__restrict__ status, uint32_t status_vecs,
                                                                     FusedPlanArgs fp, uint32_t *__restrict__ msd_hist,
-                                                                    uint32_t *__restrict__ msd_slices) {
+                                                                    uint32_t *__restrict__ msd_slices, uint32_t msd_only) {
     using Vec = typename KeyVec<K>::type;
     using TI = TableIndex<GROUPS, COPIES>;
     constexpr uint32_t V = KeyVec<K>::kKeys;
-    __shared__ uint32_t t0[kBins * COPIES];
+    __shared__ uint32_t t0_[kBins * COPIES];
     __shared__ uint32_t t[3][GROUPS * kTableRow];
+    uint32_t *t0 = t0_;
     __shared__ uint32_t s_msd[MSD ? kMsdBuckets : 1];
     uint32_t *hm = MSD ? s_msd : nullptr;
     // the hybrid form's buckets are the top 14 bits of the key RANGE: msd_hist[kMsdProbeWord] holds the shift a probe of
@@ -1213,12 +1231,15 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
         if (blockIdx.x == 0 && tid == 0) msd_hist[kMsdProbeWord] = msd_shift;  // for the plan
         // a key range below 27 bits is left to the LSD passes (the plan will say so): do not pay for the histogram
         if (msd_shift < kMsdMinShift) hm = nullptr;
+        // fast count (msd_only): a range the hybrid form takes gets ONLY the bucket histogram -- 1 LDS add per key instead
+        // of 5; should the plan then refuse (a bucket too large), the host counts again for the LSD passes
+        else if (msd_only) t0 = nullptr;
     }
     if constexpr (MSD) {
         for (uint32_t c = tid; c < kMsdBuckets; c += THREADS) s_msd[c] = 0;
     }
     for (uint32_t c = tid; c < 3u * GROUPS * kTableRow; c += THREADS) (&t[0][0])[c] = 0;
-    for (uint32_t c = tid; c < static_cast<uint32_t>(kBins * COPIES); c += THREADS) t0[c] = 0;
+    for (uint32_t c = tid; c < static_cast<uint32_t>(kBins * COPIES); c += THREADS) t0_[c] = 0;
     {
         const uint4 zero = make_uint4(0, 0, 0, 0);
         const uint32_t per = (status_vecs + gridDim.x - 1) / gridDim.x;
@@ -1281,10 +1302,11 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
         if (tail < len) digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, msd_shift, msd_over, digit_word(keys[begin + tail], base_shift));
     }
     __syncthreads();
+    if (t0 != nullptr) {
     for (uint32_t d = tid; d < static_cast<uint32_t>(kBins); d += THREADS) {
         uint32_t sum = 0;
 #pragma unroll
-        for (int r = 0; r < COPIES; ++r) sum += t0[d * COPIES + ((r + d) % COPIES)];  // skewed: no bank conflicts
+        for (int r = 0; r < COPIES; ++r) sum += t0_[d * COPIES + ((r + d) % COPIES)];  // skewed: no bank conflicts
         if (sum)
             __hip_atomic_fetch_add(&tables[static_cast<size_t>(s) * kBins + d], sum, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -1292,6 +1314,7 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
     for (uint32_t c = tid; c < 3u * GROUPS * kBins; c += THREADS) {  // c = (pass - 1, group, digit)
         const uint32_t x = (&t[0][0])[(c >> 8) * kTableRow + (c & 255u)];
         if (x) __hip_atomic_fetch_add(&tables[GROUPS * kBins + c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     }
     if constexpr (MSD) {
       if (hm != nullptr) {
@@ -1413,9 +1436,24 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
                                                        OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                                                        uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *__restrict__ tables,
                                                        uint32_t group_len, uint32_t tile_cap, uint32_t blind_cap,
-                                                       StreamCuts cuts0) {
+                                                       StreamCuts cuts0, uint32_t msd_only) {
+    // Fast count (msd_only): the counting read left the LSD tables out unless the probed key range was too narrow for
+    // the hybrid form anyway -- then there is no LSD plan to make (and none is needed if the hybrid form is taken).
+    const bool have_tables = msd_only == 0u || counts[kMsdProbeWord] < kMsdMinShift;  // workgroup-uniform
     // first the plan of the four LSD passes (the same workgroup, no launch of its own; the head is stamped at the end)
-    plan_body<8>(tables, plan_lsd, host_head, 0u, n, group_len, tile, tile_cap, blind_cap, cuts0);
+    if (have_tables) {
+        plan_body<8>(tables, plan_lsd, host_head, 0u, n, group_len, tile, tile_cap, blind_cap, cuts0);
+    } else if (threadIdx.x < static_cast<uint32_t>(kStreams)) {
+        // pass 0's streams are slices of the input (the first MSD pass uses them): the same arithmetic as plan_body's
+        const uint32_t k = threadIdx.x;
+        const uint64_t a64 = static_cast<uint64_t>(cuts0.first_group[k]) * group_len, b64 = static_cast<uint64_t>(cuts0.first_group[k + 1]) * group_len;
+        const uint32_t a = static_cast<uint32_t>(a64 < n ? a64 : n), b = static_cast<uint32_t>(b64 < n ? b64 : n);
+        const StreamDesc d{a, b - a, cuts0.first_group[k], (b - a + tile - 1u) / tile};
+        plan_lsd->head.stream[0][k] = d;
+        StreamDesc none = d;
+        none.tiles = 0;
+        plan_lsd->head.blind[0][k] = none;  // the speculatively enqueued LSD pass 0 has no plan: it leaves at once
+    }
     __syncthreads();
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_start[kBins + 1];  // where top byte a starts
@@ -1508,7 +1546,9 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
         plan_lsd->head.msd_ok = s_ok;
         plan_lsd->head.msd_tiles_b = s_tiles_b;
         plan_lsd->head.msd_max_bucket = s_max;
+        plan_lsd->head.lsd_missing = have_tables ? 0u : 1u;
         if (host_head) {
+            __hip_atomic_store(&host_head->lsd_missing, have_tables ? 0u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_head->msd_ok, s_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_head->msd_tiles_b, s_tiles_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_head->msd_max_bucket, s_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2103,7 +2143,7 @@ template <typename K, int GROUPS, int THREADS, int COPIES, int UNROLL, int OCC, 
 static void launch_digit_tables_variant(hipStream_t stream, const void *keys, uint32_t n, uint32_t base_shift,
                                         uint32_t group_len, uint32_t *tables, uint32_t *status, size_t status_words,
                                         int compute_units, LaunchEvents ev, const FusedPlanArgs &fp,
-                                        uint32_t *msd_counts = nullptr) {
+                                        uint32_t *msd_counts = nullptr, uint32_t msd_only = 0) {
     // one workgroup per (pass-0 group, slice): a power-of-two number of slices that fills the chip once
     const uint32_t wgs = static_cast<uint32_t>(compute_units) * (OCC * 256 / THREADS);
     const uint32_t slices = floor_pow2(wgs / GROUPS > 0 ? wgs / GROUPS : 1u);
@@ -2111,24 +2151,24 @@ static void launch_digit_tables_variant(hipStream_t stream, const void *keys, ui
     const uint32_t vecs = static_cast<uint32_t>(status_words / 4);
     VRS_LAUNCH((digit_tables_kernel<K, GROUPS, THREADS, COPIES, UNROLL, OCC, MSD>), grid, block, stream, ev,
                static_cast<const K *>(keys), n, base_shift, group_len, slices, tables, reinterpret_cast<uint4 *>(status), vecs,
-               fp, msd_counts, msd_counts ? msd_counts + kMsdBuckets : nullptr);
+               fp, msd_counts, msd_counts ? msd_counts + kMsdBuckets : nullptr, msd_only);
 }
 
 hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *tables,
                                    uint32_t *status, size_t status_words, int compute_units, uint32_t *msd_counts,
-                                   LaunchEvents ev) {
+                                   bool msd_only, LaunchEvents ev) {
     launch_digit_tables_variant<uint32_t, 8, 1024, 32, VRS_DT_UNROLL, 4, true>(stream, keys, n, 0, group_len, tables, status,
                                                                                status_words, compute_units, ev,
-                                                                               FusedPlanArgs{}, msd_counts);
+                                                                               FusedPlanArgs{}, msd_counts, msd_only ? 1u : 0u);
     return hipGetLastError();
 }
 
 hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                            uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
-                           uint32_t blind_cap, const StreamCuts &cuts0) {
+                           uint32_t blind_cap, const StreamCuts &cuts0, bool msd_only) {
     hipLaunchKernelGGL(msd_plan_kernel, dim3(1), dim3(1024), 0, stream, msd_counts, msd, plan_a, plan_lsd, host_head, stamp, n,
-                       tile, tiles_b_cap, local_cap, tables, group_len, tile_cap, blind_cap, cuts0);
+                       tile, tiles_b_cap, local_cap, tables, group_len, tile_cap, blind_cap, cuts0, msd_only ? 1u : 0u);
     return hipGetLastError();
 }
 
