@@ -476,7 +476,7 @@ def bench_multi(args):
                        "hbm_bytes_per_key": 48,
                        "hbm_bytes_per_key_breakdown": {"partition_pass_histogram_read": 4, "partition_pass_scatter": 8,
                                                        "local_sorts_counting_read": 4, "local_sorts_four_lookback_scatters": 32,
-                                                       "note": "sub-ranges of 2^26 keys or more take the 28-byte hybrid form "
+                                                       "note": "sub-ranges of 4e7 keys or more take the 28-byte hybrid form "
                                                                "(two look-back scatters + the LDS-local bucket sort): 40 in total"}},
             "roofline": {"bound": "hbm", "kernel": "lookback_scatter of the local sorts (rank 0's launches in the timed region)",
                          "achieved": round(lb_achieved, 1) if lb_achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -179,7 +179,8 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * host memory -- i.e. until the counting read has run; it never waits for the sort itself, which still completes
  * asynchronously on the context's stream.  Passes whose digit is the same for every key (small keys, constant bytes)
  * are the identity and are left out.  Same result, bit for bit.
- * uint32 keys from 2^26 keys on, uint32 key + payload pairs from 2^25 pairs on (VRS_TUNE_HYBRID, VRS_TUNE_HYBRID_MIN_KEYS):
+ * uint32 keys from 4 * 10^7 keys on, uint32 key + payload pairs from 2.5 * 10^7 pairs on (VRS_TUNE_HYBRID,
+ * VRS_TUNE_HYBRID_MIN_KEYS):
  * the same counting read also histograms the top 14 bits of the key range, and when every such bucket fits one workgroup's
  * LDS (13312 keys or 6656 pairs; uniform keys: up to about 2.1 * 10^8 keys, 1.03 * 10^8 pairs) the four LSD passes are
  * replaced by an MSD partition in two look-back scatter passes (8 + 6 bits) plus one pass in which every bucket is sorted
@@ -317,8 +318,8 @@ typedef enum vrs_tuning_key {
                                      partition by the top 14 bits in two look-back passes + an LDS-local sort of every
                                      bucket) whenever every bucket fits a workgroup's LDS, else the four LSD passes (decided
                                      on the device from the same counting read); 0 = always the LSD passes */
-    VRS_TUNE_HYBRID_MIN_KEYS = 12, /* the hybrid form is considered from this many keys on, and from half as many pairs
-                                     (default 2^26; never below 2^22 elements) */
+    VRS_TUNE_HYBRID_MIN_KEYS = 12, /* the hybrid form is considered from this many keys on, and from 5/8 as many pairs
+                                     (default 4 * 10^7; never below 2^22 elements) */
     VRS_TUNE_HYBRID_FAST_COUNT = 13, /* the counting read of a sort the hybrid form may take: 0 = always counts the LSD
                                      tables beside the bucket histogram (a refusal costs nothing extra); 2 = counts only
                                      the bucket histogram when the probed key range allows the hybrid form (1 LDS add per

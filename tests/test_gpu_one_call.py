@@ -511,7 +511,7 @@ def test_hybrid_form_equals_std_sort(gpu_context, oracle, n, dist, fast_count):
     try:
         out, stats = sort_keys(ctx, keys)
     finally:
-        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
         ctx.setTuning(capi.VRS_TUNE_HYBRID_FAST_COUNT, 1)
     took, recounts = hybrid_sorts(ctx) - h0, hybrid_recounts(ctx) - r0
     assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
@@ -548,7 +548,7 @@ def test_fast_count_is_armed_by_a_hybrid_sort_and_disarmed_by_a_refusal(gpu_cont
             assert np.array_equal(out, np.sort(keys))
             seen.append((hybrid_sorts(ctx) - h0, hybrid_recounts(ctx) - r0, stats["digit_tables"]))
     finally:
-        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
     assert seen == [(1, 0, 1), (1, 0, 1), (0, 1, 2), (0, 0, 1), (1, 0, 1), (1, 0, 1)]
 
 
@@ -571,7 +571,7 @@ def test_hybrid_form_under_the_look_back_hooks(gpu_context, hook):
     try:
         out, stats = sort_keys(ctx, keys)
     finally:
-        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
         ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 0)
         ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, -1)
         ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 4096)
@@ -615,7 +615,7 @@ def test_hybrid_form_pairs_are_stable(gpu_context, oracle, n, dist):
     try:
         ok, ov = sort_pairs_once(ctx, keys, vals)
     finally:
-        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
     took = hybrid_sorts(ctx) - h0
     rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
     assert np.array_equal(ok, rk) and np.array_equal(ov, rv)
@@ -644,7 +644,7 @@ def test_hybrid_form_with_buckets_beyond_the_small_local_sort(gpu_context, mode)
             order = np.argsort(keys, kind="stable")
             assert np.array_equal(ok, keys[order]) and np.array_equal(ov, vals[order])
     finally:
-        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
     assert hybrid_sorts(ctx) - h0 == (1 if mode == "keys" else 0)
 
 
@@ -661,7 +661,7 @@ def test_hybrid_form_leaves_wide_keys_to_the_lsd_passes(gpu_context):
         out = np.empty(n, np.uint64)
         k0.downloadWithStagingBuffer(out)
     finally:
-        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 26)
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
         k0.release()
         k1.release()
     assert np.array_equal(out, np.sort(keys)) and hybrid_sorts(ctx) == h0

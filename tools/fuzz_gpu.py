@@ -79,7 +79,7 @@ def main():
                 ctx.setTuning(capi.VRS_TUNE_FUSED_PLAN, int(rs.randint(0, 2)))
                 ctx.setTuning(capi.VRS_TUNE_SINGLE_MAX_KEYS, int(rs.choice([0, 4096, 4096, 20000])))
                 ctx.setTuning(capi.VRS_TUNE_HYBRID, int(rs.randint(0, 4) != 0))
-                ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, int(rs.choice([1 << 22, 1 << 22, 1 << 26])))
+                ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, int(rs.choice([1 << 22, 1 << 22, capi.HYBRID_MIN_KEYS_DEFAULT])))
                 ctx.setTuning(capi.VRS_TUNE_HYBRID_FAST_COUNT, int(rs.randint(0, 3)))
                 hold = rs.randint(0, 8) == 0
                 ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, int(rs.randint(0, 6)) if hold else -1)

@@ -1,5 +1,5 @@
 """Hybrid form of vrs_sort_keys_u32 (MSD partition + LDS-local sort): correctness vs numpy over sizes / distributions, which
-form ran, and time against the LSD form.   usage: hybrid_check.py [quick | sizes n,n,... [dist,dist,...]]"""
+form ran, and time against the LSD form.   usage: hybrid_check.py [quick | sizes n,n,... [dist,dist,...] [hybrid_min_keys]]"""
 import ctypes
 import sys
 import time
@@ -37,9 +37,12 @@ def main():
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     sizes = [int(float(x)) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 and sys.argv[1] == "sizes" else None
     dists = sys.argv[3].split(",") if len(sys.argv) > 3 else ["uniform"]
+    min_keys = int(float(sys.argv[4])) if len(sys.argv) > 4 else None
     rs = np.random.RandomState(3)
     with vrs.GPUContext(0) as gpu:
         lib = gpu.lib
+        if min_keys is not None:
+            gpu.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, min_keys)
         cases = [((1 << 24), "uniform"), ((1 << 24) + 12345, "uniform"), (30000001, "uniform"), (30000001, "sorted"), (30000001, "reverse"),
                  (20000003, "28bit"), (25000000, "max_keys"), (25000000, "dups"), (25000000, "hot_bucket"), (10 ** 8, "uniform"), (2 * 10 ** 8 + 77, "uniform")]
         if quick:

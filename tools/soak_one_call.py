@@ -40,7 +40,7 @@ def soak(budget, seed=1, mode="keys", max_keys=10 ** 8):
     t_end = time.time() + budget
     with vrs.GPUContext(0, stream=torch.cuda.current_stream().cuda_stream) as gpu:
         gpu.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 1 if mode == "misplaced" else 0)
-        gpu.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)  # the hybrid form wherever its buckets fit, not only from 2^26 keys on
+        gpu.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)  # the hybrid form wherever its buckets fit, not only from 4e7 keys on
         while time.time() < t_end:
             n = int(rs.choice([rs.randint(1 << 20, 1 << 23), rs.randint(1 << 23, 6 * 10 ** 7), 10 ** 8]))
             n = min(n, max_keys)

@@ -48,6 +48,7 @@ VRS_TUNE_FUSED_PLAN = 10
 VRS_TUNE_HYBRID = 11
 VRS_TUNE_HYBRID_MIN_KEYS = 12
 VRS_TUNE_HYBRID_FAST_COUNT = 13
+HYBRID_MIN_KEYS_DEFAULT = 40_000_000  # vrs_capi.hip: os_hybrid_min_keys
 
 
 class PushConstants(Structure):

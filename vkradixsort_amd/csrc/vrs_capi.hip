@@ -73,7 +73,7 @@ struct vrs_context_t {
     int os_fast_count = 1;               // VRS_TUNE_HYBRID_FAST_COUNT: 0 never, 1 adaptive, 2 always
     bool os_fast_count_armed = false;    // adaptive: the last hybrid-capable sort of this context took the hybrid form
     uint64_t os_hybrid_recounts = 0;     // sorts that started over as LSD sorts after a fast count and a refusal
-    uint32_t os_hybrid_min_keys = 1u << 26;  // VRS_TUNE_HYBRID_MIN_KEYS
+    uint32_t os_hybrid_min_keys = 40000000u;  // VRS_TUNE_HYBRID_MIN_KEYS (measured crossover with the fast count: 3.5-4e7 keys)
     uint32_t *os_msd_counts = nullptr;   // [16384] top-14-bit histogram + [8][256] top-byte counts per pass-0 group, zero between sorts
     vrs::MsdPlan *os_msd_plan = nullptr;
     vrs::OnesweepPlan *os_plan_a = nullptr;  // seeds and streams of the first MSD pass
@@ -673,13 +673,14 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
     // groups per pass: 32 let the streams follow skewed data more closely, but every workgroup of the counting read
     // flushes 3 * G * 256 counters -- a fixed cost that only large inputs amortise (10^7 keys: 20 vs 34 us for the
     // counting read, 3 * 10^7: 47 vs 61, 10^8: a tie; profiles/labs/r02_groups_and_fused_plan.txt)
-    // Hybrid form (K5b): uint32 keys, with or without uint32 payloads, from os_hybrid_min_keys on (default 2^26: the 16384 buckets are then at least
-    // 60 % full -- below, the fixed cost per bucket workgroup outweighs the saved pass: measured crossover 6-7 * 10^7
-    // keys); above about 1.03 * 10^8 uniform keys the largest bucket no longer fits a workgroup's LDS and the plan says
-    // no.  Its local sort ranks with returning LDS atomics, so the lane-order self-test must have passed.  The counting
+    // Hybrid form (K5b): uint32 keys, with or without uint32 payloads, from os_hybrid_min_keys on (default 4e7 keys, 2.5e7
+    // pairs: below, the fixed cost per bucket workgroup outweighs the saved pass -- measured crossover 3.5-4e7 keys with the
+    // fast count, 6-7e7 without); above about 2.1 * 10^8 uniform keys (1.03 * 10^8 pairs) the largest bucket no longer fits
+    // a workgroup's LDS and the plan says no.  Its local sort ranks with returning LDS atomics, so the lane-order self-test
+    // must have passed.  The counting
     // read then also fills the top-14-bit histogram, which needs the 8-group tables to fit beside it in LDS.
-    // payloads double what the hybrid form saves per key: measured crossover 3e7 pairs vs 6-7e7 keys (profiles/labs/r02_hybrid_pairs.txt)
-    const uint32_t hybrid_min = values ? ctx->os_hybrid_min_keys / 2u : ctx->os_hybrid_min_keys;
+    // payloads double what the hybrid form saves per key: measured crossover 2.5e7 pairs vs 3.5-4e7 keys (profiles/labs/r02_hybrid_pairs.txt)
+    const uint32_t hybrid_min = values ? ctx->os_hybrid_min_keys / 8u * 5u : ctx->os_hybrid_min_keys;
     const uint32_t local_cap = vrs::msd_local_capacity(values != nullptr);
     const bool msd_capable = key_bytes == 4 && ctx->os_hybrid && ctx->atomic_rank_verified &&
                              ctx->scatter.atomic_rank && n >= hybrid_min && n >= (1u << 22) &&
@@ -831,7 +832,9 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         // while that first pass runs.
         const uint32_t cur_at_start = cur;
         const size_t events_before = ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER];
-        const uint32_t blind_passes = msd_capable ? 1u : 4u;
+        // (after a fast count the LSD pass 0 is not enqueued at all: that sort is expected to take the hybrid form; if the
+        // key range turns out too narrow for it, the four LSD passes follow the plan's head, one host round trip late)
+        const uint32_t blind_passes = msd_capable ? (fast_count ? 0u : 1u) : 4u;
         if (msd_capable) {  // the first MSD pass goes first: it is the one that usually runs, the other then leaves behind it
             if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
             VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kbuf[cur_at_start]->ptr, kbuf[cur_at_start ^ 1u]->ptr,
@@ -877,9 +880,10 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
             ctx->os_hybrid_sorts++;
             continue;
         }
-        if (msd_capable && timed) {  // the first MSD pass left at once: hand its events back, keep the LSD pass 0's
-            std::swap(ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][events_before], ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][events_before + 1]);
-            ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + 1;
+        if (msd_capable && timed) {  // the first MSD pass left at once: hand its events back, keep the LSD pass 0's (if any)
+            if (blind_passes)
+                std::swap(ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][events_before], ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][events_before + 1]);
+            ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + blind_passes;
         }
         const uint32_t q = std::min<uint32_t>(head.first_abnormal, blind_passes);
         ctx->os_lookback_passes += q;
