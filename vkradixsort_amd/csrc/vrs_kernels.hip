@@ -1608,40 +1608,58 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const uint32_t *__re
         scatter_chunk<uint32_t, 16, 8, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
 }
 
-// One stable LSD pass over the keys a workgroup holds in registers (wave-striped: wave v owns ITEMS * 64 consecutive
-// positions, item i of lane l is position v * ITEMS * 64 + i * 64 + l), through LDS: per-wave counters fed by returning
-// LDS atomics (lane order: the RANK_ATOMIC property), a scan over bins and waves, re-bucketing, striped read-back.
-template <int THREADS, int ITEMS, int BITS, bool PAIRS>
+// One LSD pass over the keys a workgroup holds in registers (wave-striped: wave v owns ITEMS * 64 consecutive positions,
+// item i of lane l is position v * ITEMS * 64 + i * 64 + l; positions >= n hold nothing and stay where they are), through
+// LDS: counters fed by returning LDS atomics, a scan over the bins, re-bucketing, striped read-back.
+// STABLE: one counter table per wave (lane order inside an instruction is the RANK_ATOMIC property, item order and wave order
+// come from the tables' prefix) -- equal digits keep their order.  Not STABLE: ONE table for the workgroup, a quarter of the
+// zeroing and scanning; equal digits come out in any order -- enough for the FIRST pass over bare keys (keys that tie in
+// this digit are told apart by the later pass or are equal), never for payloads.
+template <int THREADS, int ITEMS, int BITS, bool PAIRS, bool STABLE>
 __device__ __forceinline__ void local_pass(uint32_t (&key)[ITEMS], uint32_t (&val)[PAIRS ? ITEMS : 1], uint32_t *s_keys,
-                                           uint32_t *s_vals, uint32_t *s_hist, uint32_t *s_tmp, uint32_t shift) {
-    constexpr int WAVES = THREADS / 64, BINS = 1 << BITS;
+                                           uint32_t *s_vals, uint32_t *s_hist, uint32_t *s_tmp, uint32_t shift, uint32_t n) {
+    constexpr int WAVES = THREADS / 64, BINS = 1 << BITS, TABLES = STABLE ? WAVES : 1, PER = BINS / THREADS;
+    static_assert(PER >= 1 && PER * THREADS == BINS, "every thread scans PER whole bins");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t c = tid; c < WAVES * BINS; c += THREADS) s_hist[c] = 0;
-    if (tid == 0) s_tmp[0] = 0;
+    for (uint32_t c = tid; c < TABLES * BINS; c += THREADS) s_hist[c] = 0;
     __syncthreads();
-    uint32_t *my = s_hist + wave * BINS;
+    uint32_t *my = s_hist + (STABLE ? wave * BINS : 0u);
+    const uint32_t seg = wave * (ITEMS * 64) + lane;
     uint32_t rank[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t d = (key[i] >> shift) & (BINS - 1);
-        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-        if (__ballot(d == d0) == ~0ull) {  // wave-uniform digit (padding, constant bits): one add instead of 64 on one counter
-            uint32_t old = 0;
-            if (lane == 0u) old = __hip_atomic_fetch_add(&my[d0], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            rank[i] = __builtin_amdgcn_readfirstlane(old) + lane;
-        } else {
-            rank[i] = __hip_atomic_fetch_add(&my[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        rank[i] = seg + i * 64;
+        if (rank[i] < n) {
+            const uint32_t d = (key[i] >> shift) & (BINS - 1);
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+            const uint64_t active = __ballot(1);
+            if (__ballot(d == d0) == active) {  // one digit value for the whole instruction: one add instead of up to 64 on one counter
+                uint32_t old = 0;
+                if (__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(active >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(active), 0u)) == 0u)
+                    old = __hip_atomic_fetch_add(&my[d0], static_cast<uint32_t>(__popcll(active)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rank[i] = __builtin_amdgcn_readfirstlane(old) +
+                          __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(active >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(active), 0u));
+            } else {
+                rank[i] = __hip_atomic_fetch_add(&my[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     }
     __syncthreads();
-    for (uint32_t b0 = 0; b0 < BINS; b0 += THREADS) {  // THREADS bins per stride
-        const uint32_t b = b0 + tid;
-        uint32_t c[WAVES], total = 0;
-        if (b < BINS) {
+    {   // exclusive prefix over (bin, table): thread t owns bins [t * PER, (t + 1) * PER)
+        uint32_t c[TABLES][PER], total = 0;
 #pragma unroll
-            for (int v = 0; v < WAVES; ++v) {
-                c[v] = s_hist[v * BINS + b];
-                total += c[v];
+        for (int v = 0; v < TABLES; ++v) {
+            if constexpr (PER == 2) {
+                const uint2 q = reinterpret_cast<const uint2 *>(s_hist + v * BINS)[tid];
+                c[v][0] = q.x;
+                c[v][1] = q.y;
+                total += q.x + q.y;
+            } else {
+#pragma unroll
+                for (int p_ = 0; p_ < PER; ++p_) {
+                    c[v][p_] = s_hist[v * BINS + tid * PER + p_];
+                    total += c[v][p_];
+                }
             }
         }
         uint32_t incl = total;
@@ -1650,37 +1668,43 @@ __device__ __forceinline__ void local_pass(uint32_t (&key)[ITEMS], uint32_t (&va
             const uint32_t t = __shfl_up(incl, o);
             if (lane >= static_cast<uint32_t>(o)) incl += t;
         }
-        if (lane == 63u) s_tmp[1 + wave] = incl;
+        if (lane == 63u) s_tmp[wave] = incl;
         __syncthreads();
-        uint32_t base = s_tmp[0];  // keys in the earlier strides
+        uint32_t acc = incl - total;
 #pragma unroll
-        for (int v = 0; v < WAVES; ++v) base += (static_cast<uint32_t>(v) < wave) ? s_tmp[1 + v] : 0u;
-        if (b < BINS) {
-            uint32_t acc = base + incl - total;
+        for (int v = 0; v < WAVES; ++v) acc += (static_cast<uint32_t>(v) < wave) ? s_tmp[v] : 0u;
+        uint32_t out[TABLES][PER];
 #pragma unroll
-            for (int v = 0; v < WAVES; ++v) {
-                s_hist[v * BINS + b] = acc;
-                acc += c[v];
+        for (int p_ = 0; p_ < PER; ++p_) {
+#pragma unroll
+            for (int v = 0; v < TABLES; ++v) {
+                out[v][p_] = acc;
+                acc += c[v][p_];
             }
         }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t t = s_tmp[0];
-            for (int v = 0; v < WAVES; ++v) t += s_tmp[1 + v];
-            s_tmp[0] = t;
+#pragma unroll
+        for (int v = 0; v < TABLES; ++v) {
+            if constexpr (PER == 2) {
+                reinterpret_cast<uint2 *>(s_hist + v * BINS)[tid] = make_uint2(out[v][0], out[v][1]);
+            } else {
+#pragma unroll
+                for (int p_ = 0; p_ < PER; ++p_) s_hist[v * BINS + tid * PER + p_] = out[v][p_];
+            }
         }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) rank[i] += my[(key[i] >> shift) & (BINS - 1)];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) s_keys[rank[i]] = key[i];
-    if constexpr (PAIRS) {
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) s_vals[rank[i]] = val[i];
     }
     __syncthreads();
-    const uint32_t seg = wave * (ITEMS * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (seg + i * 64 < n) rank[i] += my[(key[i] >> shift) & (BINS - 1)];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (seg + i * 64 < n) s_keys[rank[i]] = key[i];
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if (seg + i * 64 < n) s_vals[rank[i]] = val[i];
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) key[i] = s_keys[seg + i * 64];
     if constexpr (PAIRS) {
@@ -1702,7 +1726,7 @@ __device__ __forceinline__ void local_sort_bucket(uint32_t *bucket, uint32_t *bu
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t idx = seg + i * 64;
         const uint32_t k = bucket[idx < n ? idx : n - 1u];
-        key[i] = idx < n ? k : 0xFFFFFFFFu;  // padding sorts behind every real key of the bucket and is not written
+        key[i] = k;  // positions >= n hold nothing: the passes leave them alone and they are not written
     }
     if constexpr (PAIRS) {
 #pragma unroll
@@ -1711,8 +1735,8 @@ __device__ __forceinline__ void local_sort_bucket(uint32_t *bucket, uint32_t *bu
             val[i] = bucket_vals[idx < n ? idx : n - 1u];
         }
     }
-    local_pass<THREADS, ITEMS, BITS, PAIRS>(key, val, s_keys, s_vals, s_hist, s_tmp, 0);
-    local_pass<THREADS, ITEMS, BITS, PAIRS>(key, val, s_keys, s_vals, s_hist, s_tmp, BITS);
+    local_pass<THREADS, ITEMS, BITS, PAIRS, PAIRS>(key, val, s_keys, s_vals, s_hist, s_tmp, 0, n);  // bare keys: any order of ties
+    local_pass<THREADS, ITEMS, BITS, PAIRS, true>(key, val, s_keys, s_vals, s_hist, s_tmp, BITS, n);
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t idx = seg + i * 64;
