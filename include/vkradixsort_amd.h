@@ -186,11 +186,13 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * replaced by an MSD partition in two look-back scatter passes (8 + 6 bits) plus one pass in which every bucket is sorted
  * inside LDS -- 28 bytes per key instead of 36, 52 per pair instead of 68 (DESIGN.md "K5b").  The choice is made on the
  * device from that one read; either form gives the same bits, payloads of equal keys in input order included.
+ * vrs_sort_keys_u64 takes the same form from 2 * 10^7 keys on (56 instead of 144 bytes per key; the local sort then needs
+ * ceil(low bits / 9) LDS passes, up to six); its counting read never makes LSD tables, so a refused sort starts over.
  */
 int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements);
 int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
                        vrs_buffer values_tmp, uint32_t num_elements);
-int vrs_sort_keys_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements); /* 8 passes */
+int vrs_sort_keys_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements); /* 8 LSD passes, or the hybrid form */
 /* uint64 keys with uint32 payloads: always the eight contract passes (no look-back form). */
 int vrs_sort_pairs_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
                        vrs_buffer values_tmp, uint32_t num_elements);
@@ -314,12 +316,12 @@ typedef enum vrs_tuning_key {
                                      its counts, so its successors must run out of spin budget and recount */
     VRS_TUNE_DIGIT_TABLE_GROUPS = 8, /* groups per pass of the one-call sort's counting read: 8, 16, 32, or 0 (default):
                                      8 below 2^26 keys, 32 from there on */
-    VRS_TUNE_HYBRID = 11,          /* vrs_sort_keys_u32 / vrs_sort_pairs_u32 of large inputs: 1 (default) = the 28-byte-per-key hybrid form (MSD
+    VRS_TUNE_HYBRID = 11,          /* vrs_sort_keys_u32 / vrs_sort_pairs_u32 / vrs_sort_keys_u64 of large inputs: 1 (default) = the 28-byte-per-key hybrid form (MSD
                                      partition by the top 14 bits in two look-back passes + an LDS-local sort of every
                                      bucket) whenever every bucket fits a workgroup's LDS, else the four LSD passes (decided
                                      on the device from the same counting read); 0 = always the LSD passes */
-    VRS_TUNE_HYBRID_MIN_KEYS = 12, /* the hybrid form is considered from this many keys on, and from 5/8 as many pairs
-                                     (default 4 * 10^7; never below 2^22 elements) */
+    VRS_TUNE_HYBRID_MIN_KEYS = 12, /* the hybrid form is considered from this many keys on, from 5/8 as many pairs and from
+                                     half as many 64-bit keys (default 4 * 10^7; never below 2^22 elements) */
     VRS_TUNE_HYBRID_FAST_COUNT = 13, /* the counting read of a sort the hybrid form may take: 0 = always counts the LSD
                                      tables beside the bucket histogram (a refusal costs nothing extra); 2 = counts only
                                      the bucket histogram when the probed key range allows the hybrid form (1 LDS add per

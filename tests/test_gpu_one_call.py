@@ -648,11 +648,28 @@ def test_hybrid_form_with_buckets_beyond_the_small_local_sort(gpu_context, mode)
     assert hybrid_sorts(ctx) - h0 == (1 if mode == "keys" else 0)
 
 
-def test_hybrid_form_leaves_wide_keys_to_the_lsd_passes(gpu_context):
-    ctx, lib, n = gpu_context, gpu_context.lib, (1 << 22) + 99
-    rs = np.random.RandomState(3)
-    keys = rs.randint(0, 2 ** 63, size=n, dtype=np.uint64)
+def make_hybrid_keys64(n, dist, seed):
+    if dist == "narrow":  # 20-bit keys: the range is too narrow for the form, the LSD passes drop their identity passes
+        return make_keys64(n, "uniform", seed) >> np.uint64(44)
+    if dist == "one_hot_bucket":  # a bucket no workgroup can hold
+        k = make_keys64(n, "uniform", seed)
+        k[: n // 20] = (k[: n // 20] & np.uint64((1 << 50) - 1)) | np.uint64(0x1234 << 50)
+        return k
+    if dist == "ties":  # 2^12 distinct keys spread over 64 bits: one value per bucket, six passes over equal keys
+        return (make_keys64(n, "uniform", seed) >> np.uint64(52)) * np.uint64(0x0010000100001001)
+    return make_keys64(n, dist, seed)
+
+
+@pytest.mark.parametrize("dist", ["uniform", "44bit", "low32", "high32", "sorted", "max_keys", "narrow", "one_hot_bucket", "ties"])
+@pytest.mark.parametrize("n", [(1 << 22) + 99, 6000001])
+def test_hybrid_form_u64(gpu_context, n, dist):
+    """64-bit keys through the hybrid form: buckets = the top 14 bits of the key range, the local sort takes the remaining
+    low bits in ceil(bits / 9) LDS passes (44-bit keys: four, full 64-bit keys: six, upper word zero: two).  Ranges below 27
+    bits and buckets that do not fit are refused -- nothing has moved by then -- and the eight LSD passes run."""
+    ctx, lib = gpu_context, gpu_context.lib
+    keys = make_hybrid_keys64(n, dist, seed=n % 211)
     ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID, 1)  # also forgets an earlier refusal (after one, only every 16th 64-bit sort tries again)
     h0 = hybrid_sorts(ctx)
     k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(8 * n), keys)
     k1 = vrs.Buffer(ctx, S(8 * n))
@@ -664,4 +681,8 @@ def test_hybrid_form_leaves_wide_keys_to_the_lsd_passes(gpu_context):
         ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
         k0.release()
         k1.release()
-    assert np.array_equal(out, np.sort(keys)) and hybrid_sorts(ctx) == h0
+    assert np.array_equal(out, np.sort(keys))
+    bits = int(keys.max()).bit_length()
+    shift = bits - 14
+    fits = shift >= 13 and int(np.bincount((keys >> np.uint64(shift)).astype(np.int64), minlength=1 << 14).max()) <= 6656
+    assert hybrid_sorts(ctx) - h0 == (1 if fits else 0), (dist, bits)

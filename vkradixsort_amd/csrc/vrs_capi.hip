@@ -72,6 +72,8 @@ struct vrs_context_t {
     bool os_hybrid = true;               // VRS_TUNE_HYBRID
     int os_fast_count = 1;               // VRS_TUNE_HYBRID_FAST_COUNT: 0 never, 1 adaptive, 2 always
     bool os_fast_count_armed = false;    // adaptive: the last hybrid-capable sort of this context took the hybrid form
+    bool os_wide_refused = false;        // 64-bit keys: the last attempt at the hybrid form was refused
+    uint32_t os_wide_skipped = 0;        //   ... sorts since (every 16th tries again)
     uint64_t os_hybrid_recounts = 0;     // sorts that started over as LSD sorts after a fast count and a refusal
     uint32_t os_hybrid_min_keys = 40000000u;  // VRS_TUNE_HYBRID_MIN_KEYS (measured crossover with the fast count: 3.5-4e7 keys)
     uint32_t *os_msd_counts = nullptr;   // [16384] top-14-bit histogram + [8][256] top-byte counts per pass-0 group, zero between sorts
@@ -680,9 +682,17 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
     // must have passed.  The counting
     // read then also fills the top-14-bit histogram, which needs the 8-group tables to fit beside it in LDS.
     // payloads double what the hybrid form saves per key: measured crossover 2.5e7 pairs vs 3.5-4e7 keys (profiles/labs/r02_hybrid_pairs.txt)
-    const uint32_t hybrid_min = values ? ctx->os_hybrid_min_keys / 8u * 5u : ctx->os_hybrid_min_keys;
-    const uint32_t local_cap = vrs::msd_local_capacity(values != nullptr);
-    const bool msd_capable = key_bytes == 4 && ctx->os_hybrid && ctx->atomic_rank_verified &&
+    // 64-bit keys (no payload) take the form too: the local sort then runs ceil(low bits / 9) LDS passes (up to six) instead of
+    // two, still 8 + 3 * 16 = 56 bytes per key against the LSD form's 2 * (8 + 4 * 16) = 144.  Their counting read never makes
+    // LSD tables (the LSD form of 64-bit keys counts twice anyway), so a refusal always starts over; after one, only every
+    // 16th such sort of the context tries again.
+    const bool wide = key_bytes == 8;
+    // measured crossovers: 3.5-4e7 uint32 keys, 2.5e7 pairs, 1.5-2e7 64-bit keys (profiles/labs/r02_hybrid_u64.txt)
+    const uint32_t hybrid_min = wide ? ctx->os_hybrid_min_keys / 2u : values ? ctx->os_hybrid_min_keys / 8u * 5u : ctx->os_hybrid_min_keys;
+    const uint32_t local_cap = vrs::msd_local_capacity(values != nullptr || wide);
+    bool wide_try = wide && !values;
+    if (wide_try && ctx->os_wide_refused && (++ctx->os_wide_skipped % 16u) != 0u) wide_try = false;
+    const bool msd_capable = (key_bytes == 4 || wide_try) && ctx->os_hybrid && ctx->atomic_rank_verified &&
                              ctx->scatter.atomic_rank && n >= hybrid_min && n >= (1u << 22) &&
                              static_cast<uint64_t>(n) <= 2ull * vrs::kMsdBucketCount * local_cap &&
                              (ctx->os_groups == 0 || ctx->os_groups == 8);
@@ -690,7 +700,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
     // 5).  If the plan then refuses the hybrid form, nothing has been moved and the sort starts over as an LSD sort -- a
     // second counting read.  Adaptive (default): fast only while the context's last hybrid-capable sort took the hybrid
     // form; after a refusal the next ones count everything again (a refusal then costs nothing extra) until one is taken.
-    const bool fast_count = msd_capable && (ctx->os_fast_count == 2 || (ctx->os_fast_count == 1 && ctx->os_fast_count_armed));
+    const bool fast_count = msd_capable && (wide || ctx->os_fast_count == 2 || (ctx->os_fast_count == 1 && ctx->os_fast_count_armed));
     const uint32_t G = msd_capable ? 8u : ctx->os_groups ? ctx->os_groups : (n < (1u << 26) ? 8u : 32u);
     const uint32_t T = vrs::onesweep_tile_keys(key_bytes);
     const uint32_t tiles_total = (n + T - 1) / T;
@@ -811,12 +821,16 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
             // hybrid: the same read (after probing the key range on a sample) also fills the histogram of the range's top 14 bits; ONE
             // plan kernel makes the LSD plan as always, decides which form runs, arms exactly one of the two first passes
             // and stamps the head
-            VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, kbuf[cur]->ptr, n, group_len, ctx->os_tables, ctx->os_status,
-                                                      rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts,
-                                                      fast_count, ev));
+            if (wide)
+                VRS_HIP(ctx, vrs::launch_msd_count_u64(ctx->stream, kbuf[cur]->ptr, n, group_len, ctx->os_status,
+                                                       rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts, ev));
+            else
+                VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, kbuf[cur]->ptr, n, group_len, ctx->os_tables, ctx->os_status,
+                                                          rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units,
+                                                          ctx->os_msd_counts, fast_count, ev));
             VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
                                               ctx->os_host_head_dev, stamp, n, T, tiles_b_cap, local_cap, ctx->os_tables, group_len,
-                                              tile_cap, blind_cap, cuts0, fast_count));
+                                              tile_cap, blind_cap, cuts0, wide ? 2u : fast_count ? 1u : 0u, wide ? 50u : 18u));
         } else {
             VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, group_len, G,
                                                   ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS,
@@ -853,7 +867,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
             // fast count, and the plan refused the hybrid form: both speculative first passes left at once, no key has
             // moved.  Start over as an LSD sort (its own counting read).
             if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before;
-            ctx->os_fast_count_armed = false;
+            if (wide) ctx->os_wide_refused = true; else ctx->os_fast_count_armed = false;
             ctx->os_hybrid_recounts++;
             const bool saved = ctx->os_hybrid;
             ctx->os_hybrid = false;
@@ -861,24 +875,28 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
             ctx->os_hybrid = saved;
             return rc;
         }
-        if (msd_capable) ctx->os_fast_count_armed = head.msd_ok != 0u;
+        if (msd_capable && !wide) ctx->os_fast_count_armed = head.msd_ok != 0u;
+        if (msd_capable && wide && head.msd_ok) ctx->os_wide_refused = false;
         if (msd_capable && head.msd_ok) {
             // hybrid form: the first MSD pass is running (keys -> partner); second pass back, then the buckets in place
             if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + 1;  // the LSD pass 0 left at once: hand its events back
             if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
-            VRS_HIP(ctx, vrs::launch_msd_pass_b(ctx->stream, static_cast<const uint32_t *>(kbuf[cur_at_start ^ 1u]->ptr),
-                                                static_cast<uint32_t *>(kbuf[cur_at_start]->ptr),
+            VRS_HIP(ctx, vrs::launch_msd_pass_b(ctx->stream, kbuf[cur_at_start ^ 1u]->ptr, kbuf[cur_at_start]->ptr,
                                                 values ? static_cast<const uint32_t *>(vbuf[cur_at_start ^ 1u]->ptr) : nullptr,
                                                 values ? static_cast<uint32_t *>(vbuf[cur_at_start]->ptr) : nullptr, ctx->os_msd_plan,
-                                                ctx->os_status, head.msd_tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map,
+                                                ctx->os_status, head.msd_tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes,
                                                 ctx->os_spin_budget, ev));
             if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
-            VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(kbuf[cur_at_start]->ptr),
-                                                    values ? static_cast<uint32_t *>(vbuf[cur_at_start]->ptr) : nullptr,
-                                                    ctx->os_msd_plan, head.msd_max_bucket, ev));
+            if (wide)
+                VRS_HIP(ctx, vrs::launch_msd_local_sort_u64(ctx->stream, kbuf[cur_at_start]->ptr, ctx->os_msd_plan,
+                                                            head.msd_max_bucket, ev));
+            else
+                VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(kbuf[cur_at_start]->ptr),
+                                                        values ? static_cast<uint32_t *>(vbuf[cur_at_start]->ptr) : nullptr,
+                                                        ctx->os_msd_plan, head.msd_max_bucket, ev));
             cur = cur_at_start;
             ctx->os_hybrid_sorts++;
-            continue;
+            break;  // the whole key is sorted (64-bit keys: no second group of passes)
         }
         if (msd_capable && timed) {  // the first MSD pass left at once: hand its events back, keep the LSD pass 0's (if any)
             if (blind_passes)
@@ -1222,6 +1240,8 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             return VRS_OK;
         case VRS_TUNE_HYBRID:
             ctx->os_hybrid = value != 0;
+            ctx->os_wide_refused = false;  // 64-bit keys: forget an earlier refusal
+            ctx->os_wide_skipped = 0;
             return VRS_OK;
         case VRS_TUNE_HYBRID_MIN_KEYS:
             if (value < 0) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "hybrid threshold must be >= 0");

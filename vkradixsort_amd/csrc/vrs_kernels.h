@@ -181,23 +181,28 @@ hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_
 // offsets, the first MSD pass's seeds (into plan_a->group_seed[0]) and streams, the second pass's tile tables; decides
 // msd_ok (key range 27-32 bits and fully probed, largest bucket <= the local sort's capacity, XCD tile counts <=
 // tiles_b_cap), arms exactly one of the two speculative first passes (plan_a's or plan_lsd's blind descriptors), writes the
-// host head and stamps it.  msd_only: without LSD tables there is no LSD plan -- if msd_ok is 0 then, head.lsd_missing is 1
+// host head and stamps it.  max_shift: the most low bits the local sort takes (18; 64-bit keys: 50).  msd_only (1: as the
+// counting read was told; 2: 64-bit keys, never any tables): without LSD tables there is no LSD plan -- if msd_ok is 0 then, head.lsd_missing is 1
 // and neither first pass is armed (the caller counts again, for the LSD passes)
 hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                            uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
-                           uint32_t blind_cap, const StreamCuts &cuts0, bool msd_only);
+                           uint32_t blind_cap, const StreamCuts &cuts0, uint32_t msd_only, uint32_t max_shift);
 // second MSD pass: bits [18, 24) inside every top-byte bucket; grid of 8 * tiles_b workgroups; status rows: 8 * tiles_b
 // values_in / values_out: uint32 payloads that follow their keys (nullptr: keys only)
-hipError_t launch_msd_pass_b(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *values_in,
+hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                              uint32_t *values_out, const MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
-                             unsigned long long xcc_map, uint32_t spin_budget, LaunchEvents ev = {});
-// every bucket sorted by its low 18 bits, in place (stable; values, if any, follow their keys)
+                             unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev = {});
+// 64-bit keys: the counting read of the hybrid form (bucket histogram + top-byte counts of the 8 input slices only; zeroes
+// the status words) and the local sort of every bucket by its low msd->shift bits (ceil(shift / 9) LDS passes)
+hipError_t launch_msd_count_u64(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *status,
+                                size_t status_words, int compute_units, uint32_t *msd_counts, LaunchEvents ev = {});
+hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, const MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev = {});
 // max_bucket: the plan's msd_max_bucket (picks the workgroup shape: 256 x 26 keys up to 6656, else 512 x 26)
 hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *values, const MsdPlan *msd, uint32_t max_bucket,
                                  LaunchEvents ev = {});
 // keys the local sort of one bucket can hold (the plan refuses the hybrid form when a bucket has more)
-uint32_t msd_local_capacity(bool pairs);
+uint32_t msd_local_capacity(bool pairs_or_wide);  // pairs and 64-bit keys: 6656, uint32 keys: 13312
 
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups
 hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks);

@@ -1427,7 +1427,92 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
 struct BitsDigit {
     uint32_t shift, mask;
     __device__ __forceinline__ uint32_t operator()(uint32_t key) const { return (key >> shift) & mask; }
+    __device__ __forceinline__ uint32_t operator()(uint64_t key) const { return static_cast<uint32_t>(key >> shift) & mask; }
 };
+
+// Hybrid form for 64-bit keys: the counting read.  Same workgroup -> slice mapping as digit_tables_kernel with 8 groups; ONLY
+// the bucket histogram (the top 14 bits of the probed key range) and the top-byte counts of the 8 input slices are
+// counted -- the LSD form of 64-bit keys makes its own tables (two counting reads) if the plan refuses.  Zeroes its share
+// of the look-back status words like digit_tables_kernel.
+__global__ __launch_bounds__(1024) void msd_count_u64_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint32_t group_len,
+                                                            uint32_t slices, uint4 *__restrict__ status, uint32_t status_vecs,
+                                                            uint32_t *__restrict__ msd_hist, uint32_t *__restrict__ msd_slices) {
+    constexpr uint32_t THREADS = 1024, UNROLL = 4;
+    __shared__ uint32_t s_msd[kMsdBuckets];
+    __shared__ unsigned long long s_or;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (tid == 0) s_or = 0;
+    for (uint32_t c = tid; c < kMsdBuckets; c += THREADS) s_msd[c] = 0;
+    {
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        const uint32_t per = (status_vecs + gridDim.x - 1) / gridDim.x;
+        const uint32_t z0 = blockIdx.x * per, z1 = min(z0 + per, status_vecs);
+        for (uint32_t c = z0 + tid; c < z1; c += THREADS) status[c] = zero;
+    }
+    __syncthreads();
+    {   // every workgroup ORs the same strided sample of 4096 keys and derives the same bucket shift
+        const uint32_t samples = min(n, 4096u);
+        const uint64_t stride = n / samples;
+        unsigned long long acc = 0;
+        for (uint32_t i = tid; i < samples; i += THREADS) acc |= keys[static_cast<uint64_t>(i) * stride];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc |= __shfl_down(acc, o);
+        if (lane == 0u && acc) atomicOr(&s_or, acc);
+    }
+    __syncthreads();
+    const uint32_t bits = s_or ? 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(s_or))) : 0u;
+    const uint32_t shift = bits > kMsdBits ? bits - kMsdBits : 0u;
+    if (blockIdx.x == 0 && tid == 0) msd_hist[kMsdProbeWord] = shift;
+    uint32_t over = 0;
+    const auto count = [&](uint64_t key) {
+        const uint64_t b = key >> shift;
+        over |= (b >> kMsdBits) != 0ull ? 1u : 0u;
+        atomicAdd(&s_msd[static_cast<uint32_t>(b < kMsdBuckets ? b : kMsdBuckets - 1u)], 1u);
+    };
+    const uint32_t s = blockIdx.x / slices, g = blockIdx.x % slices;
+    const uint32_t part = group_len / slices;
+    const uint64_t begin64 = static_cast<uint64_t>(s) * group_len + static_cast<uint64_t>(g) * part;
+    if (begin64 < n) {
+        const uint32_t begin = static_cast<uint32_t>(begin64);
+        const uint32_t len = min(part, n - begin);
+        // 16-byte loads need a 16-byte aligned address: peel one key if the slice starts on an odd one
+        const uint32_t head = min(static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) / sizeof(uint64_t)) & 1u), len);
+        if (tid < head) count(keys[begin + tid]);
+        const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(keys + begin + head);
+        const uint32_t nvec = (len - head) / 2u;
+        uint32_t i0 = 0;
+        for (; i0 + THREADS * UNROLL <= nvec; i0 += THREADS * UNROLL) {
+            ulonglong2 q[UNROLL];
+#pragma unroll
+            for (uint32_t r = 0; r < UNROLL; ++r) q[r] = v[i0 + r * THREADS + tid];
+#pragma unroll
+            for (uint32_t r = 0; r < UNROLL; ++r) {
+                count(q[r].x);
+                count(q[r].y);
+            }
+        }
+        for (uint32_t i = i0 + tid; i < nvec; i += THREADS) {
+            const ulonglong2 q = v[i];
+            count(q.x);
+            count(q.y);
+        }
+        const uint32_t tail = head + nvec * 2u + tid;  // at most one key
+        if (tail < len) count(keys[begin + tail]);
+    }
+    __syncthreads();
+    if (__ballot(over != 0u) != 0ull && lane == 0u)
+        __hip_atomic_fetch_or(&msd_hist[kMsdOverWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t c = tid; c < kMsdBuckets; c += THREADS) {
+        const uint32_t x = s_msd[c];
+        if (x) __hip_atomic_fetch_add(&msd_hist[c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < kBins) {
+        uint32_t sum = 0;
+        for (uint32_t j = 0; j < kMsdBuckets / kBins; ++j) sum += s_msd[tid * (kMsdBuckets / kBins) + ((j + tid) % (kMsdBuckets / kBins))];
+        if (sum)
+            __hip_atomic_fetch_add(&msd_slices[static_cast<size_t>(s) * kBins + tid], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // One 1024-thread workgroup, after plan_kernel.  counts = [16384] top-14-bit histogram, then [8][256] top-byte counts per
 // pass-0 group (both left zeroed for the next sort).
@@ -1436,10 +1521,11 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
                                                        OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                                                        uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *__restrict__ tables,
                                                        uint32_t group_len, uint32_t tile_cap, uint32_t blind_cap,
-                                                       StreamCuts cuts0, uint32_t msd_only) {
+                                                       StreamCuts cuts0, uint32_t msd_only, uint32_t max_shift) {
     // Fast count (msd_only): the counting read left the LSD tables out unless the probed key range was too narrow for
     // the hybrid form anyway -- then there is no LSD plan to make (and none is needed if the hybrid form is taken).
-    const bool have_tables = msd_only == 0u || counts[kMsdProbeWord] < kMsdMinShift;  // workgroup-uniform
+    // (msd_only == 2: 64-bit keys -- their LSD form makes its own tables, two counting reads, if it has to run)
+    const bool have_tables = msd_only == 0u || (msd_only == 1u && counts[kMsdProbeWord] < kMsdMinShift);  // workgroup-uniform
     // first the plan of the four LSD passes (the same workgroup, no launch of its own; the head is stamped at the end)
     if (have_tables) {
         plan_body<8>(tables, plan_lsd, host_head, 0u, n, group_len, tile, tile_cap, blind_cap, cuts0);
@@ -1527,7 +1613,7 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
     // 0.80 ms LSD vs 0.89 ms hybrid at 10^8 keys), a wider one cannot occur; at most 18 low bits go to the local sort
     const uint32_t shift = counts[kMsdProbeWord], over = counts[kMsdOverWord];
     if (tid == 0)
-        s_ok = (over == 0u && shift >= kMsdMinShift && shift <= kMsdMaxShift && s_max <= local_cap && s_tiles_b <= tiles_b_cap) ? 1u : 0u;
+        s_ok = (over == 0u && shift >= kMsdMinShift && shift <= max_shift && s_max <= local_cap && s_tiles_b <= tiles_b_cap) ? 1u : 0u;
     __syncthreads();
     // (4) the first MSD pass's streams are pass 0's (slices of the input); exactly one of the two speculatively enqueued
     //     first passes is armed
@@ -1561,13 +1647,13 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
 // Second MSD pass: inside every top-byte bucket (a contiguous range of the first pass's output) a stable scatter by bits
 // 18-23 -- the look-back machinery with one chain per bucket.  Block b -> XCD b % 8, which walks its 32 buckets in order;
 // status row of (XCD x, its j-th tile) = j * 8 + x, so a bucket's tiles are 8 rows apart like a stream's.
-template <int RANK, bool PAIRS>
-__global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out,
+template <typename K, int ITEMS, int RANK, bool PAIRS>
+__global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                             const uint32_t *__restrict__ values_in, uint32_t *__restrict__ values_out,
                                                             const MsdPlan *__restrict__ msd, uint32_t *__restrict__ status,
                                                             unsigned long long xcc_map, uint32_t spin_budget) {
-    constexpr uint32_t kTile = 16 * 8 * 64;
-    __shared__ ChunkSmem<uint32_t, 16, 8, PAIRS> sm;
+    constexpr uint32_t kTile = ITEMS * 8 * 64;  // the tile the plan counted with (onesweep_tile_keys)
+    __shared__ ChunkSmem<K, ITEMS, 8, PAIRS> sm;
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
     const uint32_t *pt = msd->xcd_tiles[x];
     if (j >= pt[32]) return;  // uniform per workgroup
@@ -1603,9 +1689,9 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const uint32_t *__re
     uint32_t unused = 0;
     const uint32_t *vin = PAIRS ? values_in + begin : nullptr;
     if (valid == kTile)
-        scatter_chunk<uint32_t, 16, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
+        scatter_chunk<K, ITEMS, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     else
-        scatter_chunk<uint32_t, 16, 8, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
+        scatter_chunk<K, ITEMS, 8, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
 }
 
 // One LSD pass over the keys a workgroup holds in registers (wave-striped: wave v owns ITEMS * 64 consecutive positions,
@@ -1615,8 +1701,8 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const uint32_t *__re
 // come from the tables' prefix) -- equal digits keep their order.  Not STABLE: ONE table for the workgroup, a quarter of the
 // zeroing and scanning; equal digits come out in any order -- enough for the FIRST pass over bare keys (keys that tie in
 // this digit are told apart by the later pass or are equal), never for payloads.
-template <int THREADS, int ITEMS, int BITS, bool PAIRS, bool STABLE>
-__device__ __forceinline__ void local_pass(uint32_t (&key)[ITEMS], uint32_t (&val)[PAIRS ? ITEMS : 1], uint32_t *s_keys,
+template <int THREADS, int ITEMS, int BITS, bool PAIRS, bool STABLE, typename K = uint32_t>
+__device__ __forceinline__ void local_pass(K (&key)[ITEMS], uint32_t (&val)[PAIRS ? ITEMS : 1], K *s_keys,
                                            uint32_t *s_vals, uint32_t *s_hist, uint32_t *s_tmp, uint32_t shift, uint32_t n) {
     constexpr int WAVES = THREADS / 64, BINS = 1 << BITS, TABLES = STABLE ? WAVES : 1, PER = BINS / THREADS;
     static_assert(PER >= 1 && PER * THREADS == BINS, "every thread scans PER whole bins");
@@ -1630,7 +1716,7 @@ __device__ __forceinline__ void local_pass(uint32_t (&key)[ITEMS], uint32_t (&va
     for (int i = 0; i < ITEMS; ++i) {
         rank[i] = seg + i * 64;
         if (rank[i] < n) {
-            const uint32_t d = (key[i] >> shift) & (BINS - 1);
+            const uint32_t d = static_cast<uint32_t>(key[i] >> shift) & (BINS - 1);
             const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
             const uint64_t active = __ballot(1);
             if (__ballot(d == d0) == active) {  // one digit value for the whole instruction: one add instead of up to 64 on one counter
@@ -1695,7 +1781,7 @@ __device__ __forceinline__ void local_pass(uint32_t (&key)[ITEMS], uint32_t (&va
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
-        if (seg + i * 64 < n) rank[i] += my[(key[i] >> shift) & (BINS - 1)];
+        if (seg + i * 64 < n) rank[i] += my[static_cast<uint32_t>(key[i] >> shift) & (BINS - 1)];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
         if (seg + i * 64 < n) s_keys[rank[i]] = key[i];
@@ -1819,6 +1905,52 @@ __global__ __launch_bounds__(kLocalPairThreads, 4) void msd_local_sort_pairs_ker
     else if (used <= 10) local_sort_bucket<kLocalPairThreads, 10, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
     else if (used <= 12) local_sort_bucket<kLocalPairThreads, 12, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
     else local_sort_bucket<kLocalPairThreads, kLocalPairItems, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+}
+
+// 64-bit keys: the bucket's keys differ only in their low `shift` bits (up to 50): ceil(shift / 9) LDS passes, the first in any
+// order of ties, the others stable.  512 threads x up to 13 keys (8 bytes each: the footprint of the pairs kernel).
+template <int ITEMS>
+__device__ __forceinline__ void local_sort_bucket_u64(uint64_t *bucket, uint32_t n, uint32_t passes, uint64_t *s_keys,
+                                                      uint32_t *s_hist, uint32_t *s_tmp) {
+    constexpr int BITS = 9;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint64_t key[ITEMS];
+    uint32_t none[1];
+    const uint32_t seg = wave * (ITEMS * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t idx = seg + i * 64;
+        key[i] = bucket[idx < n ? idx : n - 1u];
+    }
+    if (passes > 0u) local_pass<kLocalPairThreads, ITEMS, BITS, false, false, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, 0, n);
+    for (uint32_t p_ = 1; p_ < passes; ++p_)
+        local_pass<kLocalPairThreads, ITEMS, BITS, false, true, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, BITS * p_, n);
+    if (passes == 0u) return;  // one distinct key per bucket
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t idx = seg + i * 64;
+        if (idx < n) bucket[idx] = key[i];
+    }
+}
+
+__global__ __launch_bounds__(kLocalPairThreads, 4) void msd_local_sort_u64_kernel(uint64_t *__restrict__ keys,
+                                                                                 const MsdPlan *__restrict__ msd) {
+    constexpr int WAVES = kLocalPairThreads / 64;
+    __shared__ uint64_t s_keys[kLocalCap];
+    __shared__ uint32_t s_hist[WAVES << 9];
+    __shared__ uint32_t s_tmp[1 + WAVES];
+    const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
+    if (n == 0 || n > kLocalCap) return;
+    const uint32_t passes = (msd->shift + 8u) / 9u;
+    uint64_t *bucket = keys + begin;
+    const uint32_t used = (n + kLocalPairThreads - 1u) / kLocalPairThreads;
+    if (used <= 2) local_sort_bucket_u64<2>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    else if (used <= 4) local_sort_bucket_u64<4>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    else if (used <= 6) local_sort_bucket_u64<6>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    else if (used <= 8) local_sort_bucket_u64<8>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    else if (used <= 10) local_sort_bucket_u64<10>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    else if (used <= 12) local_sort_bucket_u64<12>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    else local_sort_bucket_u64<kLocalPairItems>(bucket, n, passes, s_keys, s_hist, s_tmp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2190,25 +2322,45 @@ hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_
 hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                            uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
-                           uint32_t blind_cap, const StreamCuts &cuts0, bool msd_only) {
+                           uint32_t blind_cap, const StreamCuts &cuts0, uint32_t msd_only, uint32_t max_shift) {
     hipLaunchKernelGGL(msd_plan_kernel, dim3(1), dim3(1024), 0, stream, msd_counts, msd, plan_a, plan_lsd, host_head, stamp, n,
-                       tile, tiles_b_cap, local_cap, tables, group_len, tile_cap, blind_cap, cuts0, msd_only ? 1u : 0u);
+                       tile, tiles_b_cap, local_cap, tables, group_len, tile_cap, blind_cap, cuts0, msd_only, max_shift);
     return hipGetLastError();
 }
 
-hipError_t launch_msd_pass_b(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *values_in,
+hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                              uint32_t *values_out, const MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
-                             unsigned long long xcc_map, uint32_t spin_budget, LaunchEvents ev) {
+                             unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev) {
     if (tiles_b == 0) return hipSuccess;
+    if (key_bytes == 8 && values_in != nullptr) return hipErrorInvalidValue;
     const dim3 grid(8 * tiles_b), block(512);
-#define VRS_PASS_B(RANK, PAIRS) \
-    VRS_LAUNCH((msd_pass_b_kernel<RANK, PAIRS>), grid, block, stream, ev, keys_in, keys_out, values_in, values_out, msd, status, xcc_map, spin_budget)
-    if (values_in != nullptr) {
-        if (atomic_rank) VRS_PASS_B(RANK_ATOMIC, true); else VRS_PASS_B(RANK_BALLOT, true);
+#define VRS_PASS_B(K, ITEMS, RANK, PAIRS)                                                                                  \
+    VRS_LAUNCH((msd_pass_b_kernel<K, ITEMS, RANK, PAIRS>), grid, block, stream, ev, static_cast<const K *>(keys_in),         \
+               static_cast<K *>(keys_out), values_in, values_out, msd, status, xcc_map, spin_budget)
+    if (key_bytes == 8) {
+        if (atomic_rank) VRS_PASS_B(uint64_t, 8, RANK_ATOMIC, false); else VRS_PASS_B(uint64_t, 8, RANK_BALLOT, false);
+    } else if (values_in != nullptr) {
+        if (atomic_rank) VRS_PASS_B(uint32_t, 16, RANK_ATOMIC, true); else VRS_PASS_B(uint32_t, 16, RANK_BALLOT, true);
     } else {
-        if (atomic_rank) VRS_PASS_B(RANK_ATOMIC, false); else VRS_PASS_B(RANK_BALLOT, false);
+        if (atomic_rank) VRS_PASS_B(uint32_t, 16, RANK_ATOMIC, false); else VRS_PASS_B(uint32_t, 16, RANK_BALLOT, false);
     }
 #undef VRS_PASS_B
+    return hipGetLastError();
+}
+
+hipError_t launch_msd_count_u64(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *status,
+                                size_t status_words, int compute_units, uint32_t *msd_counts, LaunchEvents ev) {
+    const uint32_t wgs = static_cast<uint32_t>(compute_units);
+    const uint32_t slices = floor_pow2(wgs / 8u > 0 ? wgs / 8u : 1u);
+    VRS_LAUNCH(msd_count_u64_kernel, dim3(8 * slices), dim3(1024), stream, ev, static_cast<const uint64_t *>(keys), n, group_len,
+               slices, reinterpret_cast<uint4 *>(status), static_cast<uint32_t>(status_words / 4), msd_counts,
+               msd_counts + kMsdBuckets);
+    return hipGetLastError();
+}
+
+hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, const MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev) {
+    if (max_bucket > kLocalCap) return hipErrorInvalidValue;  // the plan would have refused
+    VRS_LAUNCH(msd_local_sort_u64_kernel, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, static_cast<uint64_t *>(keys), msd);
     return hipGetLastError();
 }
 
@@ -2224,7 +2376,7 @@ hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *v
     return hipGetLastError();
 }
 
-uint32_t msd_local_capacity(bool pairs) { return pairs ? kLocalCap : kLocalBigCap; }
+uint32_t msd_local_capacity(bool pairs_or_wide) { return pairs_or_wide ? kLocalCap : kLocalBigCap; }
 
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
                                uint32_t group_len, uint32_t groups, uint32_t *tables, uint32_t *status,
