@@ -655,12 +655,15 @@ def make_hybrid_keys64(n, dist, seed):
         k = make_keys64(n, "uniform", seed)
         k[: n // 20] = (k[: n // 20] & np.uint64((1 << 50) - 1)) | np.uint64(0x1234 << 50)
         return k
+    if dist == "low14_only":  # inside a bucket the keys differ ONLY in their low 14 bits: the top-four-digits shortcut of the
+        k = make_keys64(n, "uniform", seed)  # local sort finds them out of order and all six passes run
+        return (k & np.uint64(0xFFFC000000003FFF)) | np.uint64(0x0000123456784000)
     if dist == "ties":  # 2^12 distinct keys spread over 64 bits: one value per bucket, six passes over equal keys
         return (make_keys64(n, "uniform", seed) >> np.uint64(52)) * np.uint64(0x0010000100001001)
     return make_keys64(n, dist, seed)
 
 
-@pytest.mark.parametrize("dist", ["uniform", "44bit", "low32", "high32", "sorted", "max_keys", "narrow", "one_hot_bucket", "ties"])
+@pytest.mark.parametrize("dist", ["uniform", "44bit", "low32", "high32", "sorted", "max_keys", "narrow", "one_hot_bucket", "ties", "low14_only"])
 @pytest.mark.parametrize("n", [(1 << 22) + 99, 6000001])
 def test_hybrid_form_u64(gpu_context, n, dist):
     """64-bit keys through the hybrid form: buckets = the top 14 bits of the key range, the local sort takes the remaining

@@ -1908,7 +1908,7 @@ __global__ __launch_bounds__(kLocalPairThreads, 4) void msd_local_sort_pairs_ker
 }
 
 // 64-bit keys: the bucket's keys differ only in their low `shift` bits (up to 50): ceil(shift / 9) LDS passes, the first in any
-// order of ties, the others stable -- or, when that is more than three, the top three and a check (see below).  512 threads x up to 13 keys (8 bytes each: the footprint of the pairs kernel).
+// order of ties, the others stable -- or, when that is more than four, the top four and a check (see below).  512 threads x up to 13 keys (8 bytes each: the footprint of the pairs kernel).
 template <int ITEMS>
 __device__ __forceinline__ void local_sort_bucket_u64(uint64_t *bucket, uint32_t n, uint32_t passes, uint64_t *s_keys,
                                                       uint32_t *s_hist, uint32_t *s_tmp) {
@@ -1922,13 +1922,14 @@ __device__ __forceinline__ void local_sort_bucket_u64(uint64_t *bucket, uint32_t
         const uint32_t idx = seg + i * 64;
         key[i] = bucket[idx < n ? idx : n - 1u];
     }
-    if (passes > 3u) {
-        // More than 27 low bits: sort by the TOP three digits first -- with a few thousand keys per bucket nearly all of them
-        // differ there -- and look whether that already is the order of the whole keys (neighbours compared in LDS).  Only a
-        // bucket with a pair still out of order (keys that tie in those digits) runs all the passes, from the bottom.
-        local_pass<kLocalPairThreads, ITEMS, BITS, false, false, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, BITS * (passes - 3u), n);
-        local_pass<kLocalPairThreads, ITEMS, BITS, false, true, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, BITS * (passes - 2u), n);
-        local_pass<kLocalPairThreads, ITEMS, BITS, false, true, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, BITS * (passes - 1u), n);
+    if (passes > 4u) {
+        // More than 36 low bits: sort by the TOP four digits first -- with a few thousand keys per bucket hardly any two tie in
+        // 36 bits (three digits are not enough: 23 bits below the bucket's own, two ties per bucket of 6000 uniform keys) -- and
+        // look whether that already is the order of the whole keys (neighbours compared in LDS).  Only a bucket with a pair
+        // still out of order runs all the passes, from the bottom.
+        local_pass<kLocalPairThreads, ITEMS, BITS, false, false, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, BITS * (passes - 4u), n);
+        for (uint32_t p_ = passes - 3u; p_ < passes; ++p_)
+            local_pass<kLocalPairThreads, ITEMS, BITS, false, true, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, BITS * p_, n);
         int bad = 0;
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
