@@ -1522,41 +1522,65 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
                                                        uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *__restrict__ tables,
                                                        uint32_t group_len, uint32_t tile_cap, uint32_t blind_cap,
                                                        StreamCuts cuts0, uint32_t msd_only, uint32_t max_shift) {
-    // Fast count (msd_only): the counting read left the LSD tables out unless the probed key range was too narrow for
-    // the hybrid form anyway -- then there is no LSD plan to make (and none is needed if the hybrid form is taken).
-    // (msd_only == 2: 64-bit keys -- their LSD form makes its own tables, two counting reads, if it has to run)
-    const bool have_tables = msd_only == 0u || (msd_only == 1u && counts[kMsdProbeWord] < kMsdMinShift);  // workgroup-uniform
-    // first the plan of the four LSD passes (the same workgroup, no launch of its own; the head is stamped at the end)
-    if (have_tables) {
-        plan_body<8>(tables, plan_lsd, host_head, 0u, n, group_len, tile, tile_cap, blind_cap, cuts0);
-    } else if (threadIdx.x < static_cast<uint32_t>(kStreams)) {
-        // pass 0's streams are slices of the input (the first MSD pass uses them): the same arithmetic as plan_body's
-        const uint32_t k = threadIdx.x;
-        const uint64_t a64 = static_cast<uint64_t>(cuts0.first_group[k]) * group_len, b64 = static_cast<uint64_t>(cuts0.first_group[k + 1]) * group_len;
-        const uint32_t a = static_cast<uint32_t>(a64 < n ? a64 : n), b = static_cast<uint32_t>(b64 < n ? b64 : n);
-        const StreamDesc d{a, b - a, cuts0.first_group[k], (b - a + tile - 1u) / tile};
-        plan_lsd->head.stream[0][k] = d;
-        StreamDesc none = d;
-        none.tiles = 0;
-        plan_lsd->head.blind[0][k] = none;  // the speculatively enqueued LSD pass 0 has no plan: it leaves at once
-    }
-    __syncthreads();
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_start[kBins + 1];  // where top byte a starts
     __shared__ uint32_t s_tiles[kBins];
     __shared__ uint32_t s_max, s_tiles_b, s_ok;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     constexpr uint32_t kPer = kMsdBuckets / 1024u;  // 16 buckets per thread
+    // Everything this workgroup reads from memory is asked for at once, up front (the kernel sits between the counting read
+    // and the first scatter pass: every dependent round trip here is a microsecond of the sort): the probed shift and the
+    // out-of-range flag, 16 bucket counts per thread, the slices' top-byte counts.
+    const uint32_t shift = counts[kMsdProbeWord], over = counts[kMsdOverWord];
+    uint32_t c[kPer], sl[8];
+    {
+        const uint4 *cv = reinterpret_cast<const uint4 *>(counts + tid * kPer);
+#pragma unroll
+        for (uint32_t j = 0; j < kPer / 4u; ++j) {
+            const uint4 q = cv[j];
+            c[4 * j] = q.x;
+            c[4 * j + 1] = q.y;
+            c[4 * j + 2] = q.z;
+            c[4 * j + 3] = q.w;
+        }
+    }
+    uint32_t *slices = counts + kMsdBuckets;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) sl[g] = tid < kBins ? slices[g * kBins + tid] : 0u;
+    // Fast count (msd_only): the counting read left the LSD tables out unless the probed key range was too narrow for
+    // the hybrid form anyway -- then there is no LSD plan to make (and none is needed if the hybrid form is taken).
+    // (msd_only == 2: 64-bit keys -- their LSD form makes its own tables, two counting reads, if it has to run)
+    const bool have_tables = msd_only == 0u || (msd_only == 1u && shift < kMsdMinShift);  // workgroup-uniform
+    StreamDesc mine{};  // pass 0's stream tid (tid < kStreams)
+    // first the plan of the four LSD passes (the same workgroup, no launch of its own; the head is stamped at the end)
+    if (have_tables) {
+        plan_body<8>(tables, plan_lsd, host_head, 0u, n, group_len, tile, tile_cap, blind_cap, cuts0);
+        __syncthreads();
+        if (tid < static_cast<uint32_t>(kStreams)) mine = plan_lsd->head.stream[0][tid];
+    } else if (tid < static_cast<uint32_t>(kStreams)) {
+        // pass 0's streams are slices of the input (the first MSD pass uses them): the same arithmetic as plan_body's
+        const uint32_t k = tid;
+        const uint64_t a64 = static_cast<uint64_t>(cuts0.first_group[k]) * group_len, b64 = static_cast<uint64_t>(cuts0.first_group[k + 1]) * group_len;
+        const uint32_t a = static_cast<uint32_t>(a64 < n ? a64 : n), b = static_cast<uint32_t>(b64 < n ? b64 : n);
+        mine = StreamDesc{a, b - a, cuts0.first_group[k], (b - a + tile - 1u) / tile};
+        plan_lsd->head.stream[0][k] = mine;
+        StreamDesc none = mine;
+        none.tiles = 0;
+        plan_lsd->head.blind[0][k] = none;  // the speculatively enqueued LSD pass 0 has no plan: it leaves at once
+    }
     if (tid == 0) {
         s_max = 0;
         s_tiles_b = 0;
     }
-    // (1) exclusive prefix over the 16384 buckets
-    uint32_t c[kPer], sum = 0, mx = 0;
+    // (1) exclusive prefix over the 16384 buckets (the counters are left zeroed for the next sort)
+    uint32_t sum = 0, mx = 0;
+    {
+        uint4 *cv = reinterpret_cast<uint4 *>(counts + tid * kPer);
+#pragma unroll
+        for (uint32_t j = 0; j < kPer / 4u; ++j) cv[j] = make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
     for (uint32_t j = 0; j < kPer; ++j) {
-        c[j] = counts[tid * kPer + j];
-        counts[tid * kPer + j] = 0;
         sum += c[j];
         mx = max(mx, c[j]);
     }
@@ -1584,13 +1608,12 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
     }
     __syncthreads();
     // (2) seeds of the first MSD pass: where top byte a of pass-0 group g goes = start of a + its keys in earlier groups
-    uint32_t *slices = counts + kMsdBuckets;
     if (tid < kBins) {
         uint32_t before = s_start[tid];
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             plan_a->group_seed[0][g][tid] = before;
-            before += slices[g * kBins + tid];
+            before += sl[g];
             slices[g * kBins + tid] = 0;
         }
         plan_a->group_seed[0][8][tid] = before;
@@ -1611,14 +1634,13 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
     // the probed range must hold every key and be 27 to 32 bits wide: a narrower range leaves the four LSD passes an
     // identity pass to drop (they then move 28 bytes per key too, without the local sort's LDS work: 24-bit keys measured
     // 0.80 ms LSD vs 0.89 ms hybrid at 10^8 keys), a wider one cannot occur; at most 18 low bits go to the local sort
-    const uint32_t shift = counts[kMsdProbeWord], over = counts[kMsdOverWord];
     if (tid == 0)
         s_ok = (over == 0u && shift >= kMsdMinShift && shift <= max_shift && s_max <= local_cap && s_tiles_b <= tiles_b_cap) ? 1u : 0u;
     __syncthreads();
     // (4) the first MSD pass's streams are pass 0's (slices of the input); exactly one of the two speculatively enqueued
     //     first passes is armed
     if (tid < static_cast<uint32_t>(kStreams)) {
-        StreamDesc d = plan_lsd->head.stream[0][tid];
+        StreamDesc d = mine;
         plan_a->head.stream[0][tid] = d;
         if (!s_ok) d.tiles = 0;
         plan_a->head.blind[0][tid] = d;
