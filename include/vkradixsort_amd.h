@@ -327,7 +327,8 @@ typedef enum vrs_tuning_key {
                                      the bucket histogram when the probed key range allows the hybrid form (1 LDS add per
                                      key instead of 5: about 20 us at 10^8 keys) and starts over as an LSD sort, with a second
                                      counting read, if the plan refuses; 1 (default) = adaptive: like 2 while the context's
-                                     previous hybrid-capable sort took the hybrid form, like 0 after a refusal */
+                                     previous hybrid-capable sort of the same kind (keys / pairs) took the hybrid form, like 0 after a
+                                     refusal (64-bit keys: always 2; after a refusal every 16th such sort tries again) */
     VRS_TUNE_FUSED_PLAN = 10,      /* 1: the last workgroup of the one-call sort's counting read turns the digit tables
                                      into the plan; 0 (default): a separate single-workgroup plan kernel (measured a
                                      tie at 10^7 and 10^8 keys) */

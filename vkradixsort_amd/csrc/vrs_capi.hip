@@ -71,7 +71,7 @@ struct vrs_context_t {
     // hybrid form (K5b)
     bool os_hybrid = true;               // VRS_TUNE_HYBRID
     int os_fast_count = 1;               // VRS_TUNE_HYBRID_FAST_COUNT: 0 never, 1 adaptive, 2 always
-    bool os_fast_count_armed = false;    // adaptive: the last hybrid-capable sort of this context took the hybrid form
+    bool os_fast_count_armed[2] = {false, false};  // adaptive: the context's last hybrid-capable sort of keys [0] / pairs [1] took the hybrid form
     bool os_wide_refused = false;        // 64-bit keys: the last attempt at the hybrid form was refused
     uint32_t os_wide_skipped = 0;        //   ... sorts since (every 16th tries again)
     uint64_t os_hybrid_recounts = 0;     // sorts that started over as LSD sorts after a fast count and a refusal
@@ -700,7 +700,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
     // 5).  If the plan then refuses the hybrid form, nothing has been moved and the sort starts over as an LSD sort -- a
     // second counting read.  Adaptive (default): fast only while the context's last hybrid-capable sort took the hybrid
     // form; after a refusal the next ones count everything again (a refusal then costs nothing extra) until one is taken.
-    const bool fast_count = msd_capable && (wide || ctx->os_fast_count == 2 || (ctx->os_fast_count == 1 && ctx->os_fast_count_armed));
+    const bool fast_count = msd_capable && (wide || ctx->os_fast_count == 2 || (ctx->os_fast_count == 1 && ctx->os_fast_count_armed[values ? 1 : 0]));
     const uint32_t G = msd_capable ? 8u : ctx->os_groups ? ctx->os_groups : (n < (1u << 26) ? 8u : 32u);
     const uint32_t T = vrs::onesweep_tile_keys(key_bytes);
     const uint32_t tiles_total = (n + T - 1) / T;
@@ -867,7 +867,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
             // fast count, and the plan refused the hybrid form: both speculative first passes left at once, no key has
             // moved.  Start over as an LSD sort (its own counting read).
             if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before;
-            if (wide) ctx->os_wide_refused = true; else ctx->os_fast_count_armed = false;
+            if (wide) ctx->os_wide_refused = true; else ctx->os_fast_count_armed[values ? 1 : 0] = false;
             ctx->os_hybrid_recounts++;
             const bool saved = ctx->os_hybrid;
             ctx->os_hybrid = false;
@@ -875,7 +875,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
             ctx->os_hybrid = saved;
             return rc;
         }
-        if (msd_capable && !wide) ctx->os_fast_count_armed = head.msd_ok != 0u;
+        if (msd_capable && !wide) ctx->os_fast_count_armed[values ? 1 : 0] = head.msd_ok != 0u;
         if (msd_capable && wide && head.msd_ok) ctx->os_wide_refused = false;
         if (msd_capable && head.msd_ok) {
             // hybrid form: the first MSD pass is running (keys -> partner); second pass back, then the buckets in place
@@ -1250,7 +1250,7 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
         case VRS_TUNE_HYBRID_FAST_COUNT:
             if (value < 0 || value > 2) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "fast count mode must be 0, 1 or 2");
             ctx->os_fast_count = value;
-            ctx->os_fast_count_armed = false;
+            ctx->os_fast_count_armed[0] = ctx->os_fast_count_armed[1] = false;
             return VRS_OK;
         case VRS_TUNE_FUSED_PLAN:
             ctx->os_fused_plan = value != 0;
