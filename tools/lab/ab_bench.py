@@ -12,6 +12,10 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from vkradixsort_amd import capi  # noqa: E402
 if os.environ.get("VRS_LIB"):
     capi.LIB_PATH = Path(os.environ["VRS_LIB"]).resolve()
+if os.environ.get("VRS_LIB_LENIENT"):  # timing an older build of the library: drop the entry points it does not have yet
+    import ctypes
+    _probe = ctypes.CDLL(str(capi.LIB_PATH))
+    capi._SIGNATURES[:] = [sig for sig in capi._SIGNATURES if hasattr(_probe, sig[0])]
 import vkradixsort_amd as vrs  # noqa: E402
 
 tag = sys.argv[1]

@@ -162,10 +162,7 @@ def load_library() -> ctypes.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
     _preload_torch_hip_runtime()
     lib = ctypes.CDLL(str(LIB_PATH))
-    import os
     for name, restype, argtypes in _SIGNATURES:
-        if os.environ.get("VRS_LIB_LENIENT") and not hasattr(lib, name):
-            continue  # lab only: timing an older build of the library against the current one
         fn = getattr(lib, name)  # AttributeError if the header and the library ever diverge
         fn.restype = restype
         fn.argtypes = argtypes
