@@ -519,7 +519,7 @@ def test_hybrid_form_equals_std_sort(gpu_context, oracle, n, dist, fast_count):
     # ranges below 27 bits are left to the LSD passes, which then drop an identity pass
     bits = int(keys.max()).bit_length()
     shift = bits - 14
-    fits = 13 <= shift <= 18 and int(np.bincount(keys >> np.uint32(shift), minlength=1 << 14).max()) <= 13312
+    fits = 13 <= shift <= 18 and int(np.bincount(keys >> np.uint32(shift), minlength=1 << 14).max()) <= capi.LOCAL_SORT_MAX_KEYS
     assert took == (1 if fits else 0), (dist, bits)
     # a fast count leaves the LSD tables out when the SAMPLED range allows the hybrid form: a refusal then counts again
     recount = fast_count == 2 and not fits and probed_shift(keys) >= 13
@@ -620,17 +620,17 @@ def test_hybrid_form_pairs_are_stable(gpu_context, oracle, n, dist):
     rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
     assert np.array_equal(ok, rk) and np.array_equal(ov, rv)
     shift = int(keys.max()).bit_length() - 14
-    fits = 13 <= shift <= 18 and int(np.bincount(keys >> np.uint32(shift), minlength=1 << 14).max()) <= 6656
+    fits = 13 <= shift <= 18 and int(np.bincount(keys >> np.uint32(shift), minlength=1 << 14).max()) <= capi.LOCAL_SORT_MAX_PAIRS
     assert took == (1 if fits else 0), (dist, shift)
 
 
 @pytest.mark.parametrize("mode", ["keys", "pairs"])
 def test_hybrid_form_with_buckets_beyond_the_small_local_sort(gpu_context, mode):
-    """Buckets of 6657-13312 keys take the 512-thread local sort (keys only; pairs of that size fall back to the LSD
+    """Buckets of 7166-14333 keys take the 512-thread local sort (keys only; pairs of that size fall back to the LSD
     passes).  Three of four top-14-bit buckets are empty here, so 3.6e7 keys fill the others with about 8800 each."""
     ctx, n = gpu_context, 36000001
     keys = make_keys(n, "uniform", seed=23) & np.uint32(0xFFF3FFFF)
-    assert 6656 < int(np.bincount(keys >> np.uint32(18), minlength=1 << 14).max()) <= 13312
+    assert capi.LOCAL_SORT_SMALL_KEYS < int(np.bincount(keys >> np.uint32(18), minlength=1 << 14).max()) <= capi.LOCAL_SORT_MAX_KEYS
     ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
     h0 = hybrid_sorts(ctx)
     try:
@@ -687,5 +687,5 @@ def test_hybrid_form_u64(gpu_context, n, dist):
     assert np.array_equal(out, np.sort(keys))
     bits = int(keys.max()).bit_length()
     shift = bits - 14
-    fits = shift >= 13 and int(np.bincount((keys >> np.uint64(shift)).astype(np.int64), minlength=1 << 14).max()) <= 6656
+    fits = shift >= 13 and int(np.bincount((keys >> np.uint64(shift)).astype(np.int64), minlength=1 << 14).max()) <= capi.LOCAL_SORT_MAX_PAIRS
     assert hybrid_sorts(ctx) - h0 == (1 if fits else 0), (dist, bits)

@@ -48,6 +48,8 @@ VRS_TUNE_FUSED_PLAN = 10
 VRS_TUNE_HYBRID = 11
 VRS_TUNE_HYBRID_MIN_KEYS = 12
 VRS_TUNE_HYBRID_FAST_COUNT = 13
+# keys the local sort of one top-14-bit bucket can hold (msd_local_capacity): uint32 keys with the 256- / 512-thread workgroup, pairs and 64-bit keys
+LOCAL_SORT_SMALL_KEYS, LOCAL_SORT_MAX_KEYS, LOCAL_SORT_MAX_PAIRS = 7165, 14333, 6656
 HYBRID_MIN_KEYS_DEFAULT = 40_000_000  # vrs_capi.hip: os_hybrid_min_keys
 
 

@@ -198,11 +198,11 @@ hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys
 hipError_t launch_msd_count_u64(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *status,
                                 size_t status_words, int compute_units, uint32_t *msd_counts, LaunchEvents ev = {});
 hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, const MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev = {});
-// max_bucket: the plan's msd_max_bucket (picks the workgroup shape: 256 x 26 keys up to 6656, else 512 x 26)
+// max_bucket: the plan's msd_max_bucket (picks the workgroup shape: 256 threads up to 7165 keys, else 512)
 hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *values, const MsdPlan *msd, uint32_t max_bucket,
                                  LaunchEvents ev = {});
 // keys the local sort of one bucket can hold (the plan refuses the hybrid form when a bucket has more)
-uint32_t msd_local_capacity(bool pairs_or_wide);  // pairs and 64-bit keys: 6656, uint32 keys: 13312
+uint32_t msd_local_capacity(bool pairs_or_wide);  // pairs and 64-bit keys: 6656, uint32 keys: 14333
 
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups
 hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks);

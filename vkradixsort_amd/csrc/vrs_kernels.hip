@@ -1859,51 +1859,271 @@ __device__ __forceinline__ void local_sort_bucket(uint32_t *bucket, uint32_t *bu
     }
 }
 
-// One workgroup per bucket of the MSD partition (<= kLocalCap keys, guaranteed by the plan), sorted by its low 18 bits
-// inside LDS, in place.  The keys-per-thread count is picked per bucket (workgroup-uniform), so the work follows the
-// bucket's size, not the capacity.  Keys only: 256 threads x up to 26 keys, four workgroups per CU.
-__global__ __launch_bounds__(kLocalThreads, 4) void msd_local_sort_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd) {
-    constexpr int WAVES = kLocalThreads / 64;
-    __shared__ uint32_t s_keys[kLocalCap];
-    __shared__ uint32_t s_hist[WAVES << 9];
-    __shared__ uint32_t s_tmp[1 + WAVES];
-    const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
-    if (n == 0 || n > kLocalCap) return;  // uniform; n > capacity cannot happen (the plan would have refused)
-    uint32_t *bucket = keys + begin;
-    const uint32_t used = (n + kLocalThreads - 1u) / kLocalThreads;
-    if (used <= 4) local_sort_bucket<kLocalThreads, 4, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 8) local_sort_bucket<kLocalThreads, 8, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 12) local_sort_bucket<kLocalThreads, 12, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 16) local_sort_bucket<kLocalThreads, 16, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 20) local_sort_bucket<kLocalThreads, 20, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 24) local_sort_bucket<kLocalThreads, 24, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else local_sort_bucket<kLocalThreads, kLocalItems, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+// ---- the local sort of bare uint32 keys (round 3 form).  One workgroup per bucket of the MSD partition, the bucket sorted by its
+// low 18 bits inside LDS in two 9-bit passes and written back in place -- the algorithm of local_pass above (returning LDS
+// atomics rank the keys; pass 1 over bare keys in any order of ties with ONE counter table, pass 2 stable with one table per
+// wave), laid out for the LDS pipe, which is what bounds this kernel (rocprofv3: LDS array busy 80 % of the kernel, 60 % of
+// that bank conflicts of the three random accesses per key and pass; profiles/labs/r03_local_sort_variants.txt):
+//  * the bucket is moved in 16-byte vectors: global_load_dwordx4 from the bucket's first 16-byte boundary (slot q = key index
+//    minus that boundary; the first `mis` slots belong to the bucket before), ds_read_b128, global_store_dwordx4;
+//  * pass 1 writes position L (the order pass 2 must see) to LDS word (L & ~255) | ((L & 63) << 2) | ((L >> 6) & 3), so that ONE
+//    ds_read_b128 per lane returns the lane's four wave-striped items of pass 2 (item 4g + c of lane t is L = seg + (4g + c) 64 + t);
+//    pass 2 writes slot mis + position, so the final read is a ds_read_b128 of whole 16-byte global vectors;
+//  * no item is predicated: a slot that holds no key (before the bucket's first key, behind its last) takes part with a dummy
+//    counter of its own -- one per LANE: 64 lanes returning from ONE counter are served one after the other, 115 instead of 10
+//    cycles per instruction -- and a position fixed by arithmetic (it keeps its place behind the keys); the selects are compiled
+//    into the first and last vector row of pass 1 and the last 17 items of a wave in pass 2 only;
+//  * counters count BYTES (add 4): every rank is an LDS byte offset, pass 2's prefix starts at 4 mis;
+//  * the same-counter guard of local_pass (a whole instruction on one counter: constant digits) costs 16 us at 10^8 uniform
+//    keys when compiled into every item, so it is switched per bucket and pass: every wave looks at its first vector row, and
+//    only a bucket in which some instruction has half its lanes on one counter runs the guarded form.
+constexpr int kLeanRow = 512 + 64;  // words per counter table: 512 digits + one dummy per lane for slots without a key
+constexpr int kLeanMaxVec = 7;      // 16-byte vectors per thread: capacity THREADS * 28 slots
+template <int THREADS, int VEC>
+__device__ __forceinline__ void lean_sort_bucket(uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *s_hist2,
+                                                 uint32_t *s_tmp) {
+    constexpr int WAVES = THREADS / 64, ITEMS = 4 * VEC, PER = 512 / THREADS;
+    static_assert(THREADS == 256 || THREADS == 512, "the scans give every thread 2 or 1 bins");
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t end = mis + n;  // slots [mis, end) hold keys
+    const uint32_t nvec = (end + 3u) / 4u;
+    uint32_t k[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        uint32_t v = j * THREADS + tid;
+        if (j == VEC - 1) v = v < nvec ? v : nvec - 1u;  // only the last row can reach behind the bucket
+        const uint4 t = reinterpret_cast<const uint4 *>(abase)[v];
+        k[4 * j] = t.x;
+        k[4 * j + 1] = t.y;
+        k[4 * j + 2] = t.z;
+        k[4 * j + 3] = t.w;
+    }
+    // every table zeroed here: WAVES tables of pass 2, then pass 1's
+    uint32_t *s_hist = s_hist2 + WAVES * kLeanRow;
+    {
+        constexpr uint32_t kVecs = (WAVES + 1) * kLeanRow / 4;
+        for (uint32_t c = tid; c < kVecs; c += THREADS) reinterpret_cast<uint4 *>(s_hist2)[c] = make_uint4(0, 0, 0, 0);
+    }
+    {   // does some instruction of this wave's first row put half its lanes on one counter?  bit 0: pass 1, bit 1: pass 2
+        uint32_t skew = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t a1 = k[c] & 511u, a2 = (k[c] >> 9) & 511u;
+            skew |= __popcll(__ballot(a1 == __builtin_amdgcn_readfirstlane(a1))) >= 32 ? 1u : 0u;
+            skew |= __popcll(__ballot(a2 == __builtin_amdgcn_readfirstlane(a2))) >= 32 ? 2u : 0u;
+        }
+        if (lane == 0u) s_tmp[16 + wave] = skew;
+    }
+    __syncthreads();
+    uint32_t guards = 0;
+#pragma unroll
+    for (int v = 0; v < WAVES; ++v) guards |= s_tmp[16 + v];
+    const bool guard1 = (__builtin_amdgcn_readfirstlane(guards) & 1u) != 0u, guard2 = (__builtin_amdgcn_readfirstlane(guards) & 2u) != 0u;
+    // ---- pass 1: low 9 bits, one table, ties in any order; byte address of counter d = 4 d
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t a = (k[4 * j + c] << 2) & 0x7FCu;
+            if (j == 0 || j == VEC - 1) {
+                const uint32_t q = 4u * (j * THREADS + tid) + c;
+                a = (q - mis < n) ? a : 2048u + 4u * lane;
+            }
+            uint32_t *counter = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_hist) + a);
+            if (guard1) {  // workgroup-uniform
+                const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
+                if (__ballot(a == a0) == ~0ull) {  // one counter for the whole instruction: lane 0 adds the 64 keys
+                    uint32_t old = 0;
+                    if (lane == 0u) old = __hip_atomic_fetch_add(counter, 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    rank[4 * j + c] = __builtin_amdgcn_readfirstlane(old) + 4u * lane;
+                    continue;
+                }
+            }
+            rank[4 * j + c] = __hip_atomic_fetch_add(counter, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    __syncthreads();
+    {   // exclusive prefix over the 512 bins
+        uint32_t c[PER], total = 0;
+        if constexpr (PER == 2) {
+            const uint2 q = reinterpret_cast<const uint2 *>(s_hist)[tid];
+            c[0] = q.x;
+            c[1] = q.y;
+            total = q.x + q.y;
+        } else {
+            c[0] = s_hist[tid];
+            total = c[0];
+        }
+        uint32_t incl = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= static_cast<uint32_t>(o)) incl += t;
+        }
+        if (lane == 63u) s_tmp[wave] = incl;
+        __syncthreads();
+        uint32_t acc = incl - total;
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) acc += (static_cast<uint32_t>(v) < wave) ? s_tmp[v] : 0u;
+        if constexpr (PER == 2) reinterpret_cast<uint2 *>(s_hist)[tid] = make_uint2(acc, acc + c[0]);
+        else s_hist[tid] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t a = (k[4 * j + c] << 2) & 0x7FCu;
+            if (j == 0 || j == VEC - 1) {
+                // a slot behind the bucket keeps its place (position q: mis + n slots lie before the first of them, mis of those
+                // without a key), the ones before the bucket follow the keys (position n + q)
+                const uint32_t q = 4u * (j * THREADS + tid) + c;
+                const bool valid = q - mis < n;
+                a = valid ? a : 2048u + 4u * lane;
+                const uint32_t r = rank[4 * j + c] + *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_hist) + a);
+                rank[4 * j + c] = valid ? r : 4u * (q < mis ? n + q : q);
+                continue;
+            }
+            rank[4 * j + c] += *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_hist) + a);
+        }
+    // byte offset Lb = 4 L of position L goes to byte (Lb & ~1023) | ((Lb & 252) << 2) | ((Lb >> 6) & 12)
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t Lb = rank[i];
+        const uint32_t ph = (Lb & ~1023u) | ((Lb & 252u) << 2) | ((Lb >> 6) & 12u);
+        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_keys) + ph) = k[i];
+    }
+    __syncthreads();
+    // ---- pass 2: high 9 bits, one table per wave, stable
+    const uint32_t seg = wave * (ITEMS * 64);
+#pragma unroll
+    for (int g = 0; g < VEC; ++g) {
+        const uint4 t = reinterpret_cast<const uint4 *>(s_keys + seg + g * 256)[lane];
+        k[4 * g] = t.x;
+        k[4 * g + 1] = t.y;
+        k[4 * g + 2] = t.z;
+        k[4 * g + 3] = t.w;
+    }
+    char *my = reinterpret_cast<char *>(s_hist2 + wave * kLeanRow);
+    // fewer than a row (4 THREADS slots) + 3 slots hold no key, all at the end of the position space: with 256 threads and five
+    // rows or more that is the last 17 items of the last wave, otherwise it may be any item of any wave
+    constexpr int kEmptyItems = (4 * THREADS + 3 + 63) / 64;
+    constexpr int kFirstMaybeEmpty = ITEMS >= kEmptyItems ? ITEMS - kEmptyItems : 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        uint32_t a = (k[i] >> 7) & 0x7FCu;
+        if (i >= kFirstMaybeEmpty) a = (seg + i * 64 + lane < n) ? a : 2048u + 4u * lane;
+        uint32_t *counter = reinterpret_cast<uint32_t *>(my + a);
+        if (guard2) {
+            const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
+            if (__ballot(a == a0) == ~0ull) {
+                uint32_t old = 0;
+                if (lane == 0u) old = __hip_atomic_fetch_add(counter, 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rank[i] = __builtin_amdgcn_readfirstlane(old) + 4u * lane;
+                continue;
+            }
+        }
+        rank[i] = __hip_atomic_fetch_add(counter, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    {   // exclusive prefix over (bin, wave); starts at the bucket's misalignment: pass 2 writes slot = mis + position
+        uint32_t c[WAVES][PER], total = 0;
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) {
+            if constexpr (PER == 2) {
+                const uint2 q = reinterpret_cast<const uint2 *>(s_hist2 + v * kLeanRow)[tid];
+                c[v][0] = q.x;
+                c[v][1] = q.y;
+                total += q.x + q.y;
+            } else {
+                c[v][0] = s_hist2[v * kLeanRow + tid];
+                total += c[v][0];
+            }
+        }
+        uint32_t incl = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= static_cast<uint32_t>(o)) incl += t;
+        }
+        if (lane == 63u) s_tmp[wave] = incl;
+        __syncthreads();
+        uint32_t acc = incl - total + 4u * mis;
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) acc += (static_cast<uint32_t>(v) < wave) ? s_tmp[v] : 0u;
+        uint32_t out[WAVES][PER];
+#pragma unroll
+        for (int p_ = 0; p_ < PER; ++p_)
+#pragma unroll
+            for (int v = 0; v < WAVES; ++v) {
+                out[v][p_] = acc;
+                acc += c[v][p_];
+            }
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) {
+            if constexpr (PER == 2) reinterpret_cast<uint2 *>(s_hist2 + v * kLeanRow)[tid] = make_uint2(out[v][0], out[v][1]);
+            else s_hist2[v * kLeanRow + tid] = out[v][0];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        uint32_t a = (k[i] >> 7) & 0x7FCu;
+        if (i >= kFirstMaybeEmpty) {  // a slot without a key stays where it is: slot mis + L
+            const uint32_t L = seg + i * 64 + lane;
+            a = L < n ? a : 2048u + 4u * lane;
+            const uint32_t r = rank[i] + *reinterpret_cast<const uint32_t *>(my + a);
+            rank[i] = L < n ? r : 4u * (mis + L);
+            continue;
+        }
+        rank[i] += *reinterpret_cast<const uint32_t *>(my + a);
+    }
+    // (every wave read its pass-2 keys out of s_keys before its atomics, and two barriers lie behind those: s_keys is free)
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_keys) + rank[i]) = k[i];
+    __syncthreads();
+    // ---- store: slot q = 4 v + c holds sorted position q - mis
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const uint32_t v = j * THREADS + tid;
+        if (j > 0 && j < VEC - 1) {
+            reinterpret_cast<uint4 *>(abase)[v] = reinterpret_cast<const uint4 *>(s_keys)[v];
+        } else if (v < nvec) {
+            const uint4 q4 = reinterpret_cast<const uint4 *>(s_keys)[v];
+            const uint32_t q = 4u * v;
+            if (q >= mis && q + 4u <= end) {
+                reinterpret_cast<uint4 *>(abase)[v] = q4;
+            } else {  // the two ends of the bucket: the neighbours' keys in the same 16 bytes are not ours to write
+                if (q + 0u - mis < n) abase[q + 0u] = q4.x;
+                if (q + 1u - mis < n) abase[q + 1u] = q4.y;
+                if (q + 2u - mis < n) abase[q + 2u] = q4.z;
+                if (q + 3u - mis < n) abase[q + 3u] = q4.w;
+            }
+        }
+    }
 }
 
-// The same for sorts whose largest bucket holds more than kLocalCap keys (uniform keys: N above 1.05e8): 512 threads x up
-// to 26 keys, capacity 13312, 69 KB of LDS -- two workgroups per CU, the same 16 waves.
-constexpr int kLocalBigThreads = 512;
-constexpr uint32_t kLocalBigCap = kLocalBigThreads * kLocalItems;
-__global__ __launch_bounds__(kLocalBigThreads, 2) void msd_local_sort_big_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd) {
-    constexpr int WAVES = kLocalBigThreads / 64;
-    __shared__ uint32_t s_keys[kLocalBigCap];
-    __shared__ uint32_t s_hist[WAVES << 9];
-    __shared__ uint32_t s_tmp[1 + WAVES];
+// THREADS = 256: up to 7165 keys per bucket (uniform keys: N <= 1.05e8), 38 KB of LDS, four workgroups per CU;
+// THREADS = 512: up to 14333 keys (N <= 2.1e8), 78 KB, two per CU -- the same 16 waves
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void msd_local_sort_keys_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * kLeanMaxVec + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
+    __shared__ uint32_t s_tmp[32];
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
-    if (n == 0 || n > kLocalBigCap) return;
-    uint32_t *bucket = keys + begin;
-    const uint32_t used = (n + kLocalBigThreads - 1u) / kLocalBigThreads;
-    if (used <= 4) local_sort_bucket<kLocalBigThreads, 4, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 8) local_sort_bucket<kLocalBigThreads, 8, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 12) local_sort_bucket<kLocalBigThreads, 12, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 14) local_sort_bucket<kLocalBigThreads, 14, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 16) local_sort_bucket<kLocalBigThreads, 16, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 18) local_sort_bucket<kLocalBigThreads, 18, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 20) local_sort_bucket<kLocalBigThreads, 20, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 22) local_sort_bucket<kLocalBigThreads, 22, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else if (used <= 24) local_sort_bucket<kLocalBigThreads, 24, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
-    else local_sort_bucket<kLocalBigThreads, kLocalItems, false>(bucket, nullptr, n, s_keys, nullptr, s_hist, s_tmp);
+    const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
+    if (n == 0 || mis + n > THREADS * 4u * kLeanMaxVec) return;  // uniform; above the capacity cannot happen (the plan would have refused)
+    uint32_t *abase = keys + begin - mis;
+    switch ((mis + n + 4u * THREADS - 1u) / (4u * THREADS)) {  // rows of THREADS vectors the bucket touches
+        case 1: lean_sort_bucket<THREADS, 1>(abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 2: lean_sort_bucket<THREADS, 2>(abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 3: lean_sort_bucket<THREADS, 3>(abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 4: lean_sort_bucket<THREADS, 4>(abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 5: lean_sort_bucket<THREADS, 5>(abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 6: lean_sort_bucket<THREADS, 6>(abase, mis, n, s_keys, s_hist, s_tmp); break;
+        default: lean_sort_bucket<THREADS, 7>(abase, mis, n, s_keys, s_hist, s_tmp); break;
+    }
 }
+constexpr uint32_t kLeanCap = 256u * 4u * kLeanMaxVec - 3u, kLeanBigCap = 512u * 4u * kLeanMaxVec - 3u;  // whatever the misalignment
 
 // Key + payload pairs: the payload doubles a bucket's LDS footprint (53 + 16 KB), so two workgroups of 512 threads x up
 // to 13 pairs share a CU.
@@ -2414,14 +2634,14 @@ hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *v
     if (max_bucket > msd_local_capacity(values != nullptr)) return hipErrorInvalidValue;  // the plan would have refused
     if (values != nullptr)
         VRS_LAUNCH(msd_local_sort_pairs_kernel, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, keys, values, msd);
-    else if (max_bucket > kLocalCap)
-        VRS_LAUNCH(msd_local_sort_big_kernel, dim3(kMsdBuckets), dim3(kLocalBigThreads), stream, ev, keys, msd);
+    else if (max_bucket > kLeanCap)
+        VRS_LAUNCH(msd_local_sort_keys_kernel<512>, dim3(kMsdBuckets), dim3(512), stream, ev, keys, msd);
     else
-        VRS_LAUNCH(msd_local_sort_kernel, dim3(kMsdBuckets), dim3(kLocalThreads), stream, ev, keys, msd);
+        VRS_LAUNCH(msd_local_sort_keys_kernel<256>, dim3(kMsdBuckets), dim3(256), stream, ev, keys, msd);
     return hipGetLastError();
 }
 
-uint32_t msd_local_capacity(bool pairs_or_wide) { return pairs_or_wide ? kLocalCap : kLocalBigCap; }
+uint32_t msd_local_capacity(bool pairs_or_wide) { return pairs_or_wide ? kLocalCap : kLeanBigCap; }
 
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
                                uint32_t group_len, uint32_t groups, uint32_t *tables, uint32_t *status,
