@@ -33,7 +33,9 @@ typedef enum vrs_status {
     VRS_ERROR_HIP = 2,          /* a HIP runtime call failed; see vrs_last_error */
     VRS_ERROR_NO_DEVICE = 3,    /* no gfx950-capable device / bad ordinal */
     VRS_ERROR_OUT_OF_MEMORY = 4,
-    VRS_ERROR_UNBALANCED = 5    /* vrs_dist_sort_keys_u32: key ranges cut at top-byte boundaries cannot be balanced */
+    VRS_ERROR_UNBALANCED = 5,   /* vrs_dist_sort_keys_u32: key ranges cut at top-byte boundaries cannot be balanced */
+    VRS_ERROR_TIMEOUT = 6       /* a one-call sort's plan did not reach the host within VRS_TUNE_PLAN_WAIT_MS (the stream is held
+                                   up by earlier work); the sort is still queued, vrs_sort_settle may be called again */
 } vrs_status;
 
 typedef struct vrs_context_t *vrs_context; /* replaces engine::GPUContext (GPUContext.h:15-111) */
@@ -66,6 +68,7 @@ int vrs_context_destroy(vrs_context ctx);
 const char *vrs_last_error(vrs_context ctx);
 /* hipStream_t of the context, for callers that interleave their own work. */
 void *vrs_context_stream(vrs_context ctx);
+int vrs_context_device(vrs_context ctx); /* the device ordinal the context was created on */
 /* Device facts for reports: name, CU count, HBM bytes.  Any out pointer may be NULL. */
 int vrs_device_info(vrs_context ctx, char *name, size_t name_cap, int *compute_units,
                     uint64_t *global_mem_bytes);
@@ -182,20 +185,53 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * uint32 keys from 4 * 10^7 keys on, uint32 key + payload pairs from 2.5 * 10^7 pairs on (VRS_TUNE_HYBRID,
  * VRS_TUNE_HYBRID_MIN_KEYS):
  * the same counting read also histograms the top 14 bits of the key range, and when every such bucket fits one workgroup's
- * LDS (13312 keys or 6656 pairs; uniform keys: up to about 2.1 * 10^8 keys, 1.03 * 10^8 pairs) the four LSD passes are
+ * LDS (14333 keys or 6656 pairs; uniform keys: up to about 2.2 * 10^8 keys, 1.03 * 10^8 pairs) the four LSD passes are
  * replaced by an MSD partition in two look-back scatter passes (8 + 6 bits) plus one pass in which every bucket is sorted
  * inside LDS -- 28 bytes per key instead of 36, 52 per pair instead of 68 (DESIGN.md "K5b").  The choice is made on the
  * device from that one read; either form gives the same bits, payloads of equal keys in input order included.
  * vrs_sort_keys_u64 takes the same form from 2 * 10^7 keys on (56 instead of 144 bytes per key; the local sort then needs
  * ceil(low bits / 9) LDS passes, up to six); its counting read never makes LSD tables, so a refused sort starts over.
+ *
+ * Blocking behaviour.  By default these calls return once the plan's head has reached the host (they spin briefly, then yield;
+ * never longer than VRS_TUNE_PLAN_WAIT_MS -> VRS_ERROR_TIMEOUT): on a stream that still has earlier work queued that means
+ * waiting for that work.  With VRS_TUNE_ASYNC_SORT = 1 they only ENQUEUE -- like the reference's ComputePass::execute
+ * (ComputePass.h:31-56), whose only blocking call is the queue-idle wait -- and return at once: a sort the hybrid form may take
+ * is put on the stream completely (second MSD pass and local sort with grids sized for the worst plan the form accepts), the
+ * LSD form as four speculative look-back passes.  What the plan may still ask for (a refused hybrid form: the LSD sort; a
+ * pass with unbalanced or wide streams; the copy home after an odd number of passes) is enqueued by vrs_sort_settle, which
+ * waits for the plan; vrs_queue_wait_idle, the blocking buffer transfers, vrs_verify_keys_u32, every stage / sort entry point
+ * and vrs_context_destroy settle a pending sort first.  Until then the buffers must stay alive and nothing else may be queued
+ * behind the sort that reads its result.  vrs_sort_pending tells whether a second half is outstanding (0 / 1).
  */
 int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements);
+int vrs_sort_settle(vrs_context ctx);
+int vrs_sort_pending(vrs_context ctx);
 int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
                        vrs_buffer values_tmp, uint32_t num_elements);
 int vrs_sort_keys_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements); /* 8 LSD passes, or the hybrid form */
 /* uint64 keys with uint32 payloads: always the eight contract passes (no look-back form). */
 int vrs_sort_pairs_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
                        vrs_buffer values_tmp, uint32_t num_elements);
+
+/*
+ * The hybrid form of vrs_sort_keys_u32 in two halves, for callers that move the keys between its two MSD passes -- the
+ * multi-GPU step (vrs_dist_*) puts the exchange between the GPUs there.  Both only enqueue.
+ *   vrs_msd_partition_u32: counting read (histogram of the top 14 bits of the probed key range + top-byte counts) and the first
+ *     MSD pass: `out` = the keys grouped by the top 8 bits of the range, stable.  counts_out (VRS_MSD_COUNT_WORDS uint32):
+ *     [0, 16384) the bucket histogram, [16384, 16384 + 8 * 256) the top-byte counts of the eight input slices,
+ *     [VRS_MSD_SHIFT_WORD] the bucket shift (bucket = key >> shift; below 13 the key range is too narrow for the form: the
+ *     histogram is empty and `out` is not a partition), [VRS_MSD_SHIFT_WORD + 1] != 0: a key above the probed range.
+ *   vrs_msd_finish_u32: second MSD pass + local sort of n keys that ARE grouped by that top byte (`grouped`; clobbered as
+ *     scratch), result in `out`.  counts: the same layout, [0, 16384) = the bucket histogram of exactly these n keys, the
+ *     slice counts zero, the shift word set, the flag word zero.  The plan may refuse (a bucket beyond the local sort's
+ *     capacity, top-byte buckets too unequal for the grid): vrs_msd_finish_status waits for the plan's head and tells
+ *     (*took == 0: `out` holds nothing useful, `grouped` still holds the keys -- sort them with vrs_sort_keys_u32).
+ */
+#define VRS_MSD_COUNT_WORDS (16384u + 8u * 256u + 64u)
+#define VRS_MSD_SHIFT_WORD (16384u + 8u * 256u)
+int vrs_msd_partition_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer out, vrs_buffer counts_out, uint32_t num_elements);
+int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_buffer counts, uint32_t num_elements);
+int vrs_msd_finish_status(vrs_context ctx, int *took);
 
 /*
  * Key preprocessing the reference leaves to the integrator ("you have to preprocess negative numbers",
@@ -332,9 +368,13 @@ typedef enum vrs_tuning_key {
     VRS_TUNE_FUSED_PLAN = 10,      /* 1: the last workgroup of the one-call sort's counting read turns the digit tables
                                      into the plan; 0 (default): a separate single-workgroup plan kernel (measured a
                                      tie at 10^7 and 10^8 keys) */
-    VRS_TUNE_SINGLE_MAX_KEYS = 9   /* vrs_sort_keys_u32 runs up to this many keys as ONE single_radixsort launch (one
+    VRS_TUNE_SINGLE_MAX_KEYS = 9,  /* vrs_sort_keys_u32 runs up to this many keys as ONE single_radixsort launch (one
                                      workgroup, four passes) instead of twelve launch-bound multi-block launches;
                                      0 = never.  Default 4096 (measured crossover, profiles/r02_small_n_crossover.csv) */
+    VRS_TUNE_ASYNC_SORT = 14,      /* 1: vrs_sort_keys_u32 / _pairs_u32 / _keys_u64 only enqueue and return at once;
+                                     vrs_sort_settle (or any entry point that settles) finishes what the plan asks for.
+                                     0 (default): they return once the plan's head has reached the host */
+    VRS_TUNE_PLAN_WAIT_MS = 15     /* longest wait for a plan's head in milliseconds (default 60000; 0 = no limit) */
 } vrs_tuning_key;
 int vrs_set_tuning(vrs_context ctx, int key, int value);
 

@@ -689,3 +689,142 @@ def test_hybrid_form_u64(gpu_context, n, dist):
     shift = bits - 14
     fits = shift >= 13 and int(np.bincount((keys >> np.uint64(shift)).astype(np.int64), minlength=1 << 14).max()) <= capi.LOCAL_SORT_MAX_PAIRS
     assert hybrid_sorts(ctx) - h0 == (1 if fits else 0), (dist, bits)
+
+
+# ---- the one-call sorts as enqueue-only calls (VRS_TUNE_ASYNC_SORT) and the bounded wait for the plan
+
+def _busy_stream(ms):
+    """Put about `ms` milliseconds of work on torch's current stream; returns at once."""
+    import torch
+    torch.cuda._sleep(int(ms * 1e-3 * 2.0e9))  # cycles of the device's ~2 GHz clock
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["hybrid", "hybrid_refused", "lsd", "lsd_abnormal", "pairs_hybrid", "u64_lsd"])
+def test_async_sort_returns_at_once_and_settles(case):
+    """VRS_TUNE_ASYNC_SORT = 1 on a borrowed stream that is busy for ~60 ms: vrs_sort_* must return in well under a
+    millisecond (the reference's execute() never blocks, ComputePass.h:31-56), vrs_sort_pending says whether a second half is
+    owed, and after vrs_sort_settle + a stream sync the result is bit-exact -- for a sort the hybrid form takes (enqueued
+    completely: nothing owed beyond the bookkeeping), one it refuses (the settle runs the LSD sort), plain LSD sorts with and
+    without abnormal passes, pairs and 64-bit keys."""
+    import time
+    import torch
+    dev = torch.device("cuda", 0)
+    n = {"hybrid": (1 << 23) + 77, "hybrid_refused": (1 << 23) + 77, "lsd": 3000001, "lsd_abnormal": 3000001,
+         "pairs_hybrid": (1 << 23) + 5, "u64_lsd": 2000003}[case]
+    rs = np.random.RandomState(len(case))
+    wide = case == "u64_lsd"
+    if wide:
+        keys = rs.randint(0, 2 ** 63, size=n, dtype=np.int64).astype(np.uint64)
+    else:
+        keys = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    if case == "hybrid_refused":
+        keys[: n // 8] = (keys[: n // 8] & np.uint32(0x3FFFF)) | np.uint32(0x12340000 & ~0x3FFFF)  # one bucket far too large
+    if case == "lsd_abnormal":
+        keys &= np.uint32(0x00FFFF00)  # two identity passes, and low byte constant: streams of pass 1 collapse
+    with vrs.GPUContext(0, stream=torch.cuda.current_stream().cuda_stream) as gpu:
+        gpu.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+        kt = torch.from_numpy(keys.view(np.int64 if wide else np.int32)).to(dev)
+        tmp = torch.empty_like(kt)
+        vals = torch.arange(n, dtype=torch.int32, device=dev) if case == "pairs_hybrid" else None
+        vtmp = torch.empty_like(vals) if vals is not None else None
+        eb = 8 if wide else 4
+        k0 = vrs.Buffer(gpu, S(eb * n), device_ptr=kt.data_ptr())
+        k1 = vrs.Buffer(gpu, S(eb * n), device_ptr=tmp.data_ptr())
+        v0 = vrs.Buffer(gpu, S(4 * n), device_ptr=vals.data_ptr()) if vals is not None else None
+        v1 = vrs.Buffer(gpu, S(4 * n), device_ptr=vtmp.data_ptr()) if vals is not None else None
+
+        def call():
+            if wide:
+                return gpu.lib.vrs_sort_keys_u64(gpu.handle, k0.handle, k1.handle, n)
+            if vals is not None:
+                return gpu.lib.vrs_sort_pairs_u32(gpu.handle, k0.handle, k1.handle, v0.handle, v1.handle, n)
+            return gpu.lib.vrs_sort_keys_u32(gpu.handle, k0.handle, k1.handle, n)
+
+        # warm-up in the default mode: scratch allocations, module load
+        pristine = kt.clone()
+        gpu.check(call())
+        torch.cuda.synchronize()
+        kt.copy_(pristine)
+        if vals is not None:
+            vals.copy_(torch.arange(n, dtype=torch.int32, device=dev))
+        torch.cuda.synchronize()
+        gpu.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)
+        h0 = hybrid_sorts(gpu)
+        _busy_stream(60)
+        t0 = time.perf_counter()
+        rc = call()
+        dt = time.perf_counter() - t0
+        gpu.check(rc)
+        assert dt < 2e-3, f"the enqueue-only sort took {dt * 1e3:.2f} ms on the host"
+        assert gpu.lib.vrs_sort_pending(gpu.handle) == 1
+        assert not torch.cuda.current_stream().query()  # the stream is still busy with the work queued before the sort
+        gpu.check(gpu.lib.vrs_sort_settle(gpu.handle))
+        assert gpu.lib.vrs_sort_pending(gpu.handle) == 0
+        torch.cuda.synchronize()
+        took = hybrid_sorts(gpu) - h0
+        gpu.setTuning(capi.VRS_TUNE_ASYNC_SORT, 0)
+        out = kt.cpu().numpy().view(keys.dtype)
+        if vals is not None:
+            order = np.argsort(keys, kind="stable")
+            assert np.array_equal(out, keys[order]) and np.array_equal(vals.cpu().numpy().view(np.uint32), order.astype(np.uint32))
+        else:
+            assert np.array_equal(out, np.sort(keys))
+        assert took == (1 if case in ("hybrid", "pairs_hybrid") else 0)
+        for b in (k0, k1, v0, v1):
+            if b is not None:
+                b.release()
+
+
+@pytest.mark.gpu
+def test_async_sorts_back_to_back_and_implicit_settle():
+    """Several enqueue-only sorts in a row (each call settles its predecessor first) and an entry point that settles by
+    itself (the blocking download) instead of an explicit vrs_sort_settle."""
+    with vrs.GPUContext(0) as gpu:
+        gpu.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+        gpu.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)
+        bufs = []
+        for i, n in enumerate([(1 << 22) + 3, 1500001, (1 << 23) + 9, 70001]):
+            keys = make_keys(n, ["uniform", "16bit", "uniform", "mult256"][i], seed=40 + i)
+            k0 = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), keys)
+            k1 = vrs.Buffer(gpu, S(4 * n))
+            gpu.check(gpu.lib.vrs_sort_keys_u32(gpu.handle, k0.handle, k1.handle, n))
+            bufs.append((keys, k0, k1))
+        for keys, k0, k1 in bufs:
+            out = np.empty(keys.size, np.uint32)
+            k0.downloadWithStagingBuffer(out)  # settles the last sort, then waits for the stream
+            assert np.array_equal(out, np.sort(keys))
+            k0.release()
+            k1.release()
+        assert gpu.lib.vrs_sort_pending(gpu.handle) == 0
+
+
+@pytest.mark.gpu
+def test_the_wait_for_the_plan_is_bounded():
+    """Default (blocking) mode behind a stream that stays busy longer than VRS_TUNE_PLAN_WAIT_MS: the call gives up with
+    VRS_ERROR_TIMEOUT instead of spinning on; the sort is still queued and a later vrs_sort_settle completes it."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 3000001
+    keys = make_keys(n, "uniform", seed=3)
+    with vrs.GPUContext(0, stream=torch.cuda.current_stream().cuda_stream) as gpu:
+        kt = torch.from_numpy(keys.view(np.int32)).to(dev)
+        tmp = torch.empty_like(kt)
+        k0 = vrs.Buffer(gpu, S(4 * n), device_ptr=kt.data_ptr())
+        k1 = vrs.Buffer(gpu, S(4 * n), device_ptr=tmp.data_ptr())
+        pristine = kt.clone()
+        gpu.check(gpu.lib.vrs_sort_keys_u32(gpu.handle, k0.handle, k1.handle, n))
+        torch.cuda.synchronize()
+        kt.copy_(pristine)
+        torch.cuda.synchronize()
+        gpu.setTuning(capi.VRS_TUNE_PLAN_WAIT_MS, 5)
+        _busy_stream(300)
+        rc = gpu.lib.vrs_sort_keys_u32(gpu.handle, k0.handle, k1.handle, n)
+        assert rc == capi.VRS_ERROR_TIMEOUT
+        assert gpu.lib.vrs_sort_pending(gpu.handle) == 1
+        gpu.setTuning(capi.VRS_TUNE_PLAN_WAIT_MS, 60000)
+        gpu.check(gpu.lib.vrs_sort_settle(gpu.handle))
+        torch.cuda.synchronize()
+        assert np.array_equal(kt.cpu().numpy().view(np.uint32), np.sort(keys))
+        k0.release()
+        k1.release()

@@ -17,6 +17,8 @@ VRS_ERROR_INVALID_ARGUMENT = 1
 VRS_ERROR_HIP = 2
 VRS_ERROR_NO_DEVICE = 3
 VRS_ERROR_OUT_OF_MEMORY = 4
+VRS_ERROR_UNBALANCED = 5
+VRS_ERROR_TIMEOUT = 6
 
 VRS_KERNEL_HISTOGRAM = 0
 VRS_KERNEL_PREFIX = 1
@@ -48,6 +50,8 @@ VRS_TUNE_FUSED_PLAN = 10
 VRS_TUNE_HYBRID = 11
 VRS_TUNE_HYBRID_MIN_KEYS = 12
 VRS_TUNE_HYBRID_FAST_COUNT = 13
+VRS_TUNE_ASYNC_SORT = 14
+VRS_TUNE_PLAN_WAIT_MS = 15
 # keys the local sort of one top-14-bit bucket can hold (msd_local_capacity): uint32 keys with the 256- / 512-thread workgroup, pairs and 64-bit keys
 LOCAL_SORT_SMALL_KEYS, LOCAL_SORT_MAX_KEYS, LOCAL_SORT_MAX_PAIRS = 7165, 14333, 6656
 HYBRID_MIN_KEYS_DEFAULT = 40_000_000  # vrs_capi.hip: os_hybrid_min_keys
@@ -102,6 +106,8 @@ _SIGNATURES = [
     ("vrs_queue_wait_idle", c_int, [c_void_p]),
     ("vrs_single_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_sort_keys_u32", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
+    ("vrs_sort_settle", c_int, [c_void_p]),
+    ("vrs_sort_pending", c_int, [c_void_p]),
     ("vrs_sort_pairs_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_sort_pairs_u64", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_sort_keys_u64", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),

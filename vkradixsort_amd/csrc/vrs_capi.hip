@@ -5,7 +5,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -82,6 +86,24 @@ struct vrs_context_t {
     uint64_t os_hybrid_sorts = 0;        // one-call sorts that took the hybrid form
     uint64_t os_fallback_passes = 0;
     uint64_t os_skipped_passes = 0;      // identity passes (one digit value holds every key) the one-call sort left out     // passes the one-call sort ran through the contract path (unbalanced streams)
+    bool os_async = false;               // VRS_TUNE_ASYNC_SORT: the one-call sorts return without waiting for the plan; vrs_sort_settle finishes them
+    uint32_t os_plan_wait_ms = 60000;    // VRS_TUNE_PLAN_WAIT_MS: longest wait for a plan's head (0 = no limit)
+    // a one-call sort between its two halves (see one_read_enqueue / one_read_complete)
+    struct OneRead {
+        bool active = false;    // enqueued, its plan not yet looked at
+        bool deferred = false;  // async mode: the caller did not wait
+        void *kptr[2] = {nullptr, nullptr}, *vptr[2] = {nullptr, nullptr};  // [0] the caller's buffers, [1] the ping-pong partners
+        uint32_t n = 0;
+        int key_bytes = 4;
+        uint32_t group = 0;     // group of four passes that is on the stream
+        uint32_t stamp = 0;     // of that group's plan
+        uint32_t cur = 0, cur_at_start = 0;  // which of the two buffers holds the data (now / when the group started)
+        uint32_t blind_passes = 0;
+        bool msd_capable = false, fast_count = false, blind_tail = false, no_hybrid = false;
+        size_t ev_lb_before = 0, ev_ls_before = 0;
+    } one_read;
+    bool one_read_settling = false;
+    uint32_t os_msd_half_stamp = 0;      // stamp of the most recent vrs_msd_finish_u32's plan
 };
 
 struct vrs_buffer_t {
@@ -98,6 +120,10 @@ namespace {
 constexpr uint32_t launch_tile_blocks(int key_bytes) { return key_bytes == 8 ? 16u : 32u; }
 
 thread_local std::string g_global_error;
+
+// second half of a pending async one-call sort (vrs_capi.hip, "one_read_settle"); every entry point that puts work on the
+// stream or waits for it calls this first
+int settle_pending(vrs_context ctx);
 
 int fail(vrs_context ctx, int code, const std::string &msg) {
     if (ctx)
@@ -308,6 +334,7 @@ int run_sort_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs
             return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "values_in and values_out alias");
     }
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int settled = settle_pending(ctx)) return settled;  // an async one-call sort may still owe its second half
     const uint32_t B = pc->g_num_blocks_per_workgroup;
     const uint32_t *table = static_cast<const uint32_t *>(histograms->ptr);
     const uint32_t kLaunchTileBlocks = launch_tile_blocks(key_bytes);
@@ -377,6 +404,7 @@ int vrs_context_create_on_stream(int device_ordinal, void *hip_stream, vrs_conte
 int vrs_context_destroy(vrs_context ctx) {
     if (!ctx) return VRS_OK;
     (void)hipSetDevice(ctx->device);
+    (void)settle_pending(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &pool : ctx->events)
         for (auto &p : pool) {
@@ -472,6 +500,7 @@ int vrs_buffer_upload(vrs_context ctx, vrs_buffer buf, const void *host_data, si
     if (size_bytes == 0) return VRS_OK;
     if (!host_data) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "host_data is NULL");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int settled = settle_pending(ctx)) return settled;  // an async one-call sort may still owe its second half
     ctx->sub_cache.valid = false;  // a buffer is rewritten: the kept sub-tile table may no longer describe its keys
     VRS_HIP(ctx, hipMemcpyAsync(buf->ptr, host_data, size_bytes, hipMemcpyHostToDevice, ctx->stream));
     VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -485,6 +514,7 @@ int vrs_buffer_download(vrs_context ctx, vrs_buffer buf, void *host_data, size_t
     if (size_bytes == 0) return VRS_OK;
     if (!host_data) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "host_data is NULL");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int settled = settle_pending(ctx)) return settled;  // an async one-call sort may still owe its second half
     VRS_HIP(ctx, hipMemcpyAsync(host_data, buf->ptr, size_bytes, hipMemcpyDeviceToHost, ctx->stream));
     VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VRS_OK;
@@ -497,6 +527,7 @@ int vrs_buffer_copy(vrs_context ctx, vrs_buffer dst, vrs_buffer src, size_t size
     if ((rc = check_buffer(ctx, src, size_bytes, "copy src"))) return rc;
     if (size_bytes == 0) return VRS_OK;
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int settled = settle_pending(ctx)) return settled;  // an async one-call sort may still owe its second half
     ctx->sub_cache.valid = false;  // a buffer is rewritten: the kept sub-tile table may no longer describe its keys
     VRS_HIP(ctx, hipMemcpyAsync(dst->ptr, src->ptr, size_bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return VRS_OK;
@@ -531,6 +562,7 @@ static int run_histogram_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer h
                            "histograms")))
         return rc;
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int settled = settle_pending(ctx)) return settled;  // an async one-call sort may still owe its second half
     vrs::LaunchEvents ev;
     if ((rc = profile_events(ctx, VRS_KERNEL_HISTOGRAM, &ev))) return rc;
     const uint32_t B = pc->g_num_blocks_per_workgroup, n = pc->g_num_elements;
@@ -600,6 +632,8 @@ int vrs_multi_radixsort_pairs(vrs_context ctx, vrs_buffer keys_in, vrs_buffer ke
 int vrs_queue_wait_idle(vrs_context ctx) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = settle_pending(ctx);
+    if (rc) return rc;
     VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VRS_OK;
 }
@@ -613,6 +647,7 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
     if ((rc = check_buffer(ctx, buffer1, bytes, "buffer1"))) return rc;
     if (buffer0->ptr == buffer1->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "buffer0 and buffer1 alias");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int settled = settle_pending(ctx)) return settled;  // an async one-call sort may still owe its second half
     vrs::LaunchEvents ev;
     if ((rc = profile_events(ctx, VRS_KERNEL_SINGLE, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_single(ctx->stream, static_cast<uint32_t *>(buffer0->ptr),
@@ -644,78 +679,114 @@ static int contract_pass(vrs_context ctx, vrs_buffer kin, vrs_buffer kout, vrs_b
 }
 
 // The plan kernel writes the head of the plan straight into pinned host memory and stamps it last; wait for the stamp.
-// Spins (the plan is at most a counting read away), looking at the stream now and then so that a faulted queue
-// surfaces as an error instead of an endless wait.
+// The plan is at most a counting read behind whatever the stream still has to run: a short spin (the usual case: it is
+// there already, or microseconds away), then the thread yields between looks, sleeping a little longer each time, and asks
+// the stream now and then so that a faulted queue surfaces as an error instead of an endless wait.  Bounded in time
+// (VRS_TUNE_PLAN_WAIT_MS, default 60 s): a stream stuck behind work that never finishes returns VRS_ERROR_TIMEOUT.
 static int wait_for_plan(vrs_context ctx, uint32_t stamp) {
     volatile uint32_t *ready = &ctx->os_host_head->ready;
-    for (uint64_t spins = 0;; ++spins) {
-        if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == stamp) return VRS_OK;
-        if ((spins & 0xFFFu) == 0xFFFu) {
+    const auto arrived = [&] { return __atomic_load_n(ready, __ATOMIC_ACQUIRE) == stamp; };
+    for (int spins = 0; spins < 20000; ++spins) {  // ~50-100 us
+        if (arrived()) return VRS_OK;
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        asm volatile("yield" ::: "memory");
+#endif
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned nap_us = 1;
+    for (uint64_t looks = 0;; ++looks) {
+        if (arrived()) return VRS_OK;
+        if ((looks & 63u) == 63u) {
             const hipError_t q = hipStreamQuery(ctx->stream);
             if (q == hipSuccess) {  // everything enqueued has run: the stamp must be there
-                if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == stamp) return VRS_OK;
+                if (arrived()) return VRS_OK;
                 return fail(ctx, VRS_ERROR_HIP, "the one-call sort's plan never arrived on the host");
             }
             if (q != hipErrorNotReady) return fail_hip(ctx, "hipStreamQuery (waiting for the sort plan)", q);
+            const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (ctx->os_plan_wait_ms != 0 && waited > static_cast<long long>(ctx->os_plan_wait_ms))
+                return fail(ctx, VRS_ERROR_TIMEOUT,
+                            "the one-call sort's plan did not arrive in time: the stream is held up by earlier work "
+                            "(VRS_TUNE_PLAN_WAIT_MS; the sort itself is still queued -- vrs_sort_settle may be called again)");
         }
-        __builtin_ia32_pause();
+        if (nap_us <= 2) sched_yield(); else usleep(nap_us);
+        if (nap_us < 200) nap_us *= 2;
     }
 }
 
-// Large-N form of the one-call sort (K5): ONE counting read of the keys per group of four passes, then four scatter
-// passes that find their offsets by look-back along kStreams independent streams -- 36 instead of 48 bytes per key
-// (64-bit keys: two groups, 136 instead of 192).  All of it -- counting read, plan, four look-back passes -- is
-// enqueued before the host knows the plan; the passes read their streams from the plan in device memory.  The host
-// then waits for the plan's head (never for the sort): usually there is nothing left to do.  If the plan marks a pass
-// as the identity (one digit value holds every key) or its streams as too unequal for the grid, that pass and the
-// ones after it left at once on the device, and the host enqueues them again in the form they need.
-static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values, vrs_buffer values_tmp,
-                         uint32_t n, int key_bytes) {
+// ---- the one-call sort for large N (K5 / K5b), in two halves around the plan's arrival on the host.
+// Half one (one_read_enqueue) puts one group of four passes on the stream without knowing the plan: the counting read, the
+// plan kernel, and the scatter passes as speculative launches that read their streams from the plan in device memory.  Half
+// two (one_read_complete), once the plan's head has arrived in pinned host memory, enqueues whatever the plan asks for beyond
+// that -- usually nothing for the LSD form, the second MSD pass and the local sort for the hybrid form -- or the passes the
+// plan marked abnormal (identity: left out; unbalanced streams: a contract pass; wide streams: launched again).
+// vrs_sort_* run both halves (the host waits for the plan's head -- for the counting read, never for the sort -- while the
+// first pass runs).  With VRS_TUNE_ASYNC_SORT = 1 they run only the first and return at once, whatever the stream still
+// has queued; the second half runs in vrs_sort_settle (also called by every entry point that waits for the stream or
+// starts another sort).  In that mode a sort the hybrid form may take is enqueued COMPLETELY -- second MSD pass and local
+// sort included, with grids sized for the worst plan the form accepts; their workgroups leave at once should the plan
+// refuse -- so that the usual case needs no second half at all.
+static vrs_buffer_t stack_view(vrs_context ctx, void *ptr, size_t bytes) {
+    vrs_buffer_t b;
+    b.ctx = ctx;
+    b.device = ctx->device;
+    b.ptr = ptr;
+    b.size = bytes;
+    b.owned = false;
+    return b;
+}
+
+struct OneReadGeometry {
+    uint32_t G, T, tiles_total, group_len, tiles0, tile_cap, blind_cap, tiles_b_cap, local_cap;
+    size_t rows;
+    vrs::StreamCuts cuts0;
+};
+
+// everything here is a function of (n, key type, payload or not, the form) alone: both halves compute the same
+static OneReadGeometry one_read_geometry(vrs_context ctx, const vrs_context_t::OneRead &st) {
     constexpr uint32_t S = vrs::kStreams;
+    OneReadGeometry g{};
+    const uint32_t n = st.n;
+    const bool wide = st.key_bytes == 8, pairs = st.vptr[0] != nullptr;
     // groups per pass: 32 let the streams follow skewed data more closely, but every workgroup of the counting read
     // flushes 3 * G * 256 counters -- a fixed cost that only large inputs amortise (10^7 keys: 20 vs 34 us for the
-    // counting read, 3 * 10^7: 47 vs 61, 10^8: a tie; profiles/labs/r02_groups_and_fused_plan.txt)
-    // Hybrid form (K5b): uint32 keys, with or without uint32 payloads, from os_hybrid_min_keys on (default 4e7 keys, 2.5e7
-    // pairs: below, the fixed cost per bucket workgroup outweighs the saved pass -- measured crossover 3.5-4e7 keys with the
-    // fast count, 6-7e7 without); above about 2.1 * 10^8 uniform keys (1.03 * 10^8 pairs) the largest bucket no longer fits
-    // a workgroup's LDS and the plan says no.  Its local sort ranks with returning LDS atomics, so the lane-order self-test
-    // must have passed.  The counting
-    // read then also fills the top-14-bit histogram, which needs the 8-group tables to fit beside it in LDS.
-    // payloads double what the hybrid form saves per key: measured crossover 2.5e7 pairs vs 3.5-4e7 keys (profiles/labs/r02_hybrid_pairs.txt)
-    // 64-bit keys (no payload) take the form too: the local sort then runs ceil(low bits / 9) LDS passes (up to six) instead of
-    // two, still 8 + 3 * 16 = 56 bytes per key against the LSD form's 2 * (8 + 4 * 16) = 144.  Their counting read never makes
-    // LSD tables (the LSD form of 64-bit keys counts twice anyway), so a refusal always starts over; after one, only every
-    // 16th such sort of the context tries again.
-    const bool wide = key_bytes == 8;
-    // measured crossovers: 3.5-4e7 uint32 keys, 2.5e7 pairs, 1.5-2e7 64-bit keys (profiles/labs/r02_hybrid_u64.txt)
-    const uint32_t hybrid_min = wide ? ctx->os_hybrid_min_keys / 2u : values ? ctx->os_hybrid_min_keys / 8u * 5u : ctx->os_hybrid_min_keys;
-    const uint32_t local_cap = vrs::msd_local_capacity(values != nullptr || wide);
-    bool wide_try = wide && !values;
-    if (wide_try && ctx->os_wide_refused && (++ctx->os_wide_skipped % 16u) != 0u) wide_try = false;
-    const bool msd_capable = (key_bytes == 4 || wide_try) && ctx->os_hybrid && ctx->atomic_rank_verified &&
-                             ctx->scatter.atomic_rank && n >= hybrid_min && n >= (1u << 22) &&
-                             static_cast<uint64_t>(n) <= 2ull * vrs::kMsdBucketCount * local_cap &&
-                             (ctx->os_groups == 0 || ctx->os_groups == 8);
-    // Fast count: the counting read of a hybrid-capable sort fills only the bucket histogram (1 LDS add per key instead of
-    // 5).  If the plan then refuses the hybrid form, nothing has been moved and the sort starts over as an LSD sort -- a
-    // second counting read.  Adaptive (default): fast only while the context's last hybrid-capable sort took the hybrid
-    // form; after a refusal the next ones count everything again (a refusal then costs nothing extra) until one is taken.
-    const bool fast_count = msd_capable && (wide || ctx->os_fast_count == 2 || (ctx->os_fast_count == 1 && ctx->os_fast_count_armed[values ? 1 : 0]));
-    const uint32_t G = msd_capable ? 8u : ctx->os_groups ? ctx->os_groups : (n < (1u << 26) ? 8u : 32u);
-    const uint32_t T = vrs::onesweep_tile_keys(key_bytes);
-    const uint32_t tiles_total = (n + T - 1) / T;
-    const uint32_t group_tiles = (tiles_total + G - 1) / G;  // tiles per pass-0 group (slice of the input)
-    const uint32_t group_len = group_tiles * T;              // < 2^30 / 8 + 8192
+    // counting read, 3 * 10^7: 47 vs 61, 10^8: a tie; profiles/labs/r02_groups_and_fused_plan.txt); the hybrid form's
+    // bucket histogram needs the 8-group tables to fit beside it in LDS
+    g.G = st.msd_capable ? 8u : ctx->os_groups ? ctx->os_groups : (n < (1u << 26) ? 8u : 32u);
+    g.T = vrs::onesweep_tile_keys(st.key_bytes);
+    g.tiles_total = (n + g.T - 1) / g.T;
+    const uint32_t group_tiles = (g.tiles_total + g.G - 1) / g.G;  // tiles per pass-0 group (slice of the input)
+    g.group_len = group_tiles * g.T;                               // < 2^30 / 8 + 8192
     // pass 0's streams are neighbouring slices merged (the plan kernel gets the same cuts)
-    const vrs::StreamCuts cuts0 = vrs::pass0_stream_cuts(n, group_len, G);
-    uint32_t tiles0 = 0;  // tiles of the longest of them
+    g.cuts0 = vrs::pass0_stream_cuts(n, g.group_len, g.G);
+    g.tiles0 = 0;  // tiles of the longest of them
     for (uint32_t k = 0; k < S; ++k) {
-        const uint64_t a = std::min<uint64_t>(static_cast<uint64_t>(cuts0.first_group[k]) * group_len, n);
-        const uint64_t b = std::min<uint64_t>(static_cast<uint64_t>(cuts0.first_group[k + 1]) * group_len, n);
-        tiles0 = std::max<uint32_t>(tiles0, static_cast<uint32_t>((b - a + T - 1) / T));
+        const uint64_t a = std::min<uint64_t>(static_cast<uint64_t>(g.cuts0.first_group[k]) * g.group_len, n);
+        const uint64_t b = std::min<uint64_t>(static_cast<uint64_t>(g.cuts0.first_group[k + 1]) * g.group_len, n);
+        g.tiles0 = std::max<uint32_t>(g.tiles0, static_cast<uint32_t>((b - a + g.T - 1) / g.T));
     }
-    const uint32_t even = (tiles_total + S - 1) / S;        // tiles of a perfectly even stream
-    const uint32_t tile_cap = std::max(tiles0, even + even / 4 + 2);  // later passes: streams up to 25 % longer
+    const uint32_t even = (g.tiles_total + S - 1) / S;            // tiles of a perfectly even stream
+    g.tile_cap = std::max(g.tiles0, even + even / 4 + 2);         // later passes: streams up to 25 % longer
+    // Passes 1-3 are enqueued before the plan is known: their grids have room for streams a little longer than even ones
+    // (uniform keys: the longest stream is within a tile or two of N / 8).  Surplus workgroups are not free (3 000 of
+    // them cost 3-4 us per pass, profiles/labs/r02_blind_grid.txt), so the slack is small; a pass whose longest stream
+    // needs more -- but no more than tile_cap -- leaves at once and is launched again with its exact grid.
+    g.blind_cap = std::min(g.tile_cap, even + even / 64 + 2);
+    // second MSD pass: every XCD walks 32 top-byte buckets, each rounded up to whole tiles.  Launched once the plan is known
+    // it may be up to 25 % over the even share; launched blind (async mode) the grid IS the cap, so the slack is 6 %
+    g.tiles_b_cap = st.blind_tail ? even + even / 16 + 40 : even + even / 4 + 40;
+    // the local sort's capacity per bucket; launched blind, the workgroup shape of bare uint32 keys is chosen from N alone
+    // (uniform keys: buckets of N / 16384 +- a few per cent)
+    g.local_cap = vrs::msd_local_capacity(pairs || wide);
+    if (st.blind_tail && !pairs && !wide && static_cast<uint64_t>(n) * 11u / 10u / vrs::kMsdBucketCount + 64u <= vrs::msd_local_capacity_small())
+        g.local_cap = vrs::msd_local_capacity_small();
+    g.rows = static_cast<size_t>(S) * std::max(g.tile_cap, st.msd_capable ? g.tiles_b_cap : 0u);  // status rows: one region for all passes (tagged words)
+    return g;
+}
+
+static int one_read_scratch(vrs_context ctx, const vrs_context_t::OneRead &st, const OneReadGeometry &g) {
     if (!ctx->os_tables) {
         uint32_t *tables = nullptr;
         vrs::OnesweepPlan *plan = nullptr;
@@ -741,15 +812,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         ctx->os_host_head = host;
         ctx->os_host_head_dev = host_dev;
     }
-    // Passes 1-3 are enqueued before the plan is known: their grids have room for streams a little longer than even ones
-    // (uniform keys: the longest stream is within a tile or two of N / 8).  Surplus workgroups are not free (3 000 of
-    // them cost 3-4 us per pass, profiles/labs/r02_blind_grid.txt), so the slack is small; a pass whose longest stream
-    // needs more -- but no more than tile_cap -- leaves at once and is launched again with its exact grid.
-    const uint32_t blind_cap = std::min(tile_cap, even + even / 64 + 2);
-    // second MSD pass: every XCD walks 32 top-byte buckets, each rounded up to whole tiles
-    const uint32_t tiles_b_cap = even + even / 4 + 40;
-    const size_t rows = static_cast<size_t>(S) * std::max(tile_cap, msd_capable ? tiles_b_cap : 0u);  // status rows: one region for all passes (tagged words)
-    if (msd_capable && !ctx->os_msd_counts) {
+    if (st.msd_capable && !ctx->os_msd_counts) {
         uint32_t *counts = nullptr;
         vrs::MsdPlan *mp = nullptr;
         vrs::OnesweepPlan *pa = nullptr;
@@ -767,21 +830,88 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
         ctx->os_msd_plan = mp;
         ctx->os_plan_a = pa;
     }
-    if (rows > ctx->os_status_rows) {
+    if (g.rows > ctx->os_status_rows) {
         if (ctx->os_status) {
             VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
             VRS_HIP(ctx, hipFree(ctx->os_status));
             ctx->os_status = nullptr;
             ctx->os_status_rows = 0;
         }
-        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_status), rows * VRS_RADIX_SORT_BINS * sizeof(uint32_t)));
-        ctx->os_status_rows = rows;
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_status), g.rows * VRS_RADIX_SORT_BINS * sizeof(uint32_t)));
+        ctx->os_status_rows = g.rows;
     }
-    int rc;
+    return VRS_OK;
+}
+
+static int one_read_lookback_pass(vrs_context ctx, vrs_context_t::OneRead &st, uint32_t i, uint32_t shift, uint32_t grid_tiles, bool forced) {
+    const bool pairs = st.vptr[0] != nullptr;
+    void *kin = st.kptr[st.cur], *kout = st.kptr[st.cur ^ 1u];
+    void *vin = pairs ? st.vptr[st.cur] : nullptr, *vout = pairs ? st.vptr[st.cur ^ 1u] : nullptr;
+    st.cur ^= 1u;
     vrs::LaunchEvents ev;
-    // the contract pass a group may fall back to walks launch tiles of 32 (uint32) / 16 (uint64) blocks
-    const uint32_t B = launch_tile_blocks(key_bytes);
-    vrs_push_constants pc{n, 0, vrs_workgroup_count(n, B), B};
+    int r = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev);
+    if (r) return r;
+    VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kin, kout, static_cast<const uint32_t *>(vin), static_cast<uint32_t *>(vout),
+                                              ctx->os_plan, i, shift, ctx->os_status, grid_tiles, forced, ctx->scatter.atomic_rank,
+                                              ctx->xcc_map, st.key_bytes, ctx->os_spin_budget, ctx->os_hold_tile, ev, ctx->os_misplace));
+    return VRS_OK;
+}
+
+// second MSD pass + local sort of the hybrid form: partner -> home, then the buckets in place
+static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, const OneReadGeometry &g, uint32_t tiles_b, uint32_t max_bucket) {
+    const bool pairs = st.vptr[0] != nullptr, wide = st.key_bytes == 8;
+    const uint32_t home = st.cur_at_start;
+    vrs::LaunchEvents ev;
+    int rc;
+    if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_msd_pass_b(ctx->stream, st.kptr[home ^ 1u], st.kptr[home],
+                                        pairs ? static_cast<const uint32_t *>(st.vptr[home ^ 1u]) : nullptr,
+                                        pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr, ctx->os_msd_plan, ctx->os_status,
+                                        tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map, st.key_bytes, ctx->os_spin_budget, ev));
+    if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
+    if (wide)
+        VRS_HIP(ctx, vrs::launch_msd_local_sort_u64(ctx->stream, st.kptr[home], ctx->os_msd_plan, max_bucket, ev));
+    else
+        VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(st.kptr[home]),
+                                                pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr, ctx->os_msd_plan, max_bucket, ev));
+    (void)g;
+    return VRS_OK;
+}
+
+static int one_read_enqueue(vrs_context ctx) {
+    vrs_context_t::OneRead &st = ctx->one_read;
+    const uint32_t n = st.n;
+    const int key_bytes = st.key_bytes;
+    const bool wide = key_bytes == 8, pairs = st.vptr[0] != nullptr;
+    if (st.group == 0) {
+        // Hybrid form (K5b): uint32 keys, with or without uint32 payloads, and bare 64-bit keys, from os_hybrid_min_keys on
+        // (default 4e7 keys, 2.5e7 pairs, 2e7 64-bit keys: below, the fixed cost per bucket workgroup outweighs the saved
+        // pass -- measured crossovers, profiles/labs/r02_fast_count.txt, r02_hybrid_pairs.txt, r02_hybrid_u64.txt); above
+        // about 2.3 * 10^8 uniform keys (1.03 * 10^8 pairs) the largest bucket no longer fits a workgroup's LDS and the plan
+        // says no.  Its local sort ranks with returning LDS atomics, so the lane-order self-test must have passed.
+        // 64-bit keys: the counting read never makes LSD tables (their LSD form counts twice anyway), so a refusal always
+        // starts over; after one, only every 16th such sort of the context tries again.
+        const uint32_t hybrid_min = wide ? ctx->os_hybrid_min_keys / 2u : pairs ? ctx->os_hybrid_min_keys / 8u * 5u : ctx->os_hybrid_min_keys;
+        bool wide_try = wide && !pairs;
+        if (wide_try && !st.no_hybrid && ctx->os_wide_refused && (++ctx->os_wide_skipped % 16u) != 0u) wide_try = false;
+        st.msd_capable = !st.no_hybrid && (key_bytes == 4 || wide_try) && ctx->os_hybrid && ctx->atomic_rank_verified &&
+                         ctx->scatter.atomic_rank && n >= hybrid_min && n >= (1u << 22) &&
+                         static_cast<uint64_t>(n) <= 2ull * vrs::kMsdBucketCount * vrs::msd_local_capacity(pairs || wide) &&
+                         (ctx->os_groups == 0 || ctx->os_groups == 8);
+        st.blind_tail = st.msd_capable && st.deferred;
+        // Fast count: the counting read of a hybrid-capable sort fills only the bucket histogram (1 LDS add per key instead
+        // of 5).  If the plan then refuses the hybrid form, nothing has been moved and the sort starts over as an LSD sort
+        // -- a second counting read.  Adaptive (default): fast only while the context's last hybrid-capable sort took the
+        // hybrid form; after a refusal the next ones count everything again (a refusal then costs nothing extra) until one
+        // is taken.  A sort enqueued completely (async mode) always counts fast: a refusal must find every key in place.
+        st.fast_count = st.msd_capable && (wide || st.blind_tail || ctx->os_fast_count == 2 ||
+                                           (ctx->os_fast_count == 1 && ctx->os_fast_count_armed[pairs ? 1 : 0]));
+    }
+    const bool msd = st.msd_capable && st.group == 0;
+    const OneReadGeometry g = one_read_geometry(ctx, st);
+    int rc = one_read_scratch(ctx, st, g);
+    if (rc) return rc;
+    vrs::LaunchEvents ev;
     // the digit tables must be all zero when a counting read starts; plan_kernel leaves them so.  Should anything fail
     // between the two launches, re-arm them for the next sort.
     struct TablesGuard {
@@ -793,149 +923,193 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
                 (void)hipMemsetAsync(ctx->os_msd_counts, 0, vrs::kMsdCountWords * sizeof(uint32_t), ctx->stream);
         }
     } guard{ctx};
-    // where the data lives: buffers[0] = caller's keys / values, buffers[1] = the ping-pong partners.  A pass whose digit
-    // is the same for every key is the identity and is left out, so the result may end in the partner and is copied
-    // home at the end.
-    vrs_buffer kbuf[2] = {keys, keys_tmp}, vbuf[2] = {values, values_tmp};
-    uint32_t cur = 0;
-    const auto lookback_pass = [&](uint32_t i, uint32_t shift, uint32_t grid_tiles, bool forced) -> int {
-        vrs_buffer kin = kbuf[cur], kout = kbuf[cur ^ 1u];
-        vrs_buffer vin = values ? vbuf[cur] : nullptr, vout = values ? vbuf[cur ^ 1u] : nullptr;
-        cur ^= 1u;
-        int r = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev);
-        if (r) return r;
-        VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kin->ptr, kout->ptr,
-                                                  vin ? static_cast<const uint32_t *>(vin->ptr) : nullptr,
-                                                  vout ? static_cast<uint32_t *>(vout->ptr) : nullptr, ctx->os_plan, i, shift,
-                                                  ctx->os_status, grid_tiles, forced, ctx->scatter.atomic_rank, ctx->xcc_map,
-                                                  key_bytes, ctx->os_spin_budget, ctx->os_hold_tile, ev, ctx->os_misplace));
+    const uint32_t group = st.group;
+    if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
+    if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
+    st.stamp = ctx->os_stamp;
+    guard.armed = true;
+    const vrs::FusedPlan fused{ctx->os_plan, ctx->os_host_head_dev, ctx->os_ticket, st.stamp, g.T, g.tile_cap, g.blind_cap, g.cuts0};
+    if (msd) {
+        // hybrid: the same read (after probing the key range on a sample) also fills the histogram of the range's top 14
+        // bits; ONE plan kernel makes the LSD plan as always, decides which form runs, arms exactly one of the two first
+        // passes and stamps the head
+        if (wide)
+            VRS_HIP(ctx, vrs::launch_msd_count_u64(ctx->stream, st.kptr[st.cur], n, g.group_len, ctx->os_status,
+                                                   g.rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts, ev));
+        else
+            VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, st.kptr[st.cur], n, g.group_len, ctx->os_tables, ctx->os_status,
+                                                      g.rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts,
+                                                      st.fast_count, ev));
+        VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
+                                          ctx->os_host_head_dev, st.stamp, n, g.T, g.tiles_b_cap, g.local_cap, ctx->os_tables,
+                                          g.group_len, g.tile_cap, g.blind_cap, g.cuts0, wide ? 2u : st.fast_count ? 1u : 0u,
+                                          wide ? 50u : 18u));
+    } else {
+        VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, st.kptr[st.cur], n, key_bytes, 32u * group, g.group_len, g.G, ctx->os_tables,
+                                              ctx->os_status, g.rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ev,
+                                              ctx->os_fused_plan ? &fused : nullptr));
+        if (!ctx->os_fused_plan)
+            VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, ctx->os_host_head_dev, st.stamp, n, g.group_len,
+                                          g.G, g.T, g.tile_cap, g.blind_cap, g.cuts0));
+    }
+    guard.armed = false;
+    // speculative launches, before the plan is known here.  LSD form: all four passes (pass 0's streams are the host's
+    // own cuts).  Hybrid-capable sort: the two candidate FIRST passes -- the first MSD pass and the LSD pass 0 (same
+    // buffers; the plan arms exactly one, the other leaves at once; after a fast count the LSD pass 0 is not enqueued at
+    // all) -- and, in async mode, the rest of the hybrid form as well.
+    st.cur_at_start = st.cur;
+    st.ev_lb_before = ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER];
+    st.ev_ls_before = ctx->events_used[VRS_KERNEL_LOCAL_SORT];
+    st.blind_passes = msd ? (st.fast_count ? 0u : 1u) : 4u;
+    if (msd) {  // the first MSD pass goes first: it is the one that usually runs, the other then leaves behind it
+        if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+        const uint32_t c = st.cur_at_start;
+        VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, st.kptr[c], st.kptr[c ^ 1u],
+                                                  pairs ? static_cast<const uint32_t *>(st.vptr[c]) : nullptr,
+                                                  pairs ? static_cast<uint32_t *>(st.vptr[c ^ 1u]) : nullptr, ctx->os_plan_a, 0,
+                                                  vrs::kShiftFromPlan, ctx->os_status, g.tiles0, false, ctx->scatter.atomic_rank,
+                                                  ctx->xcc_map, key_bytes, ctx->os_spin_budget, ctx->os_hold_tile, ev, ctx->os_misplace));
+    }
+    for (uint32_t i = 0; i < st.blind_passes; ++i)
+        if ((rc = one_read_lookback_pass(ctx, st, i, 32u * group + 8u * i, i == 0 ? g.tiles0 : g.blind_cap, false))) return rc;
+    if (msd && st.blind_tail && (rc = one_read_hybrid_tail(ctx, st, g, g.tiles_b_cap, g.local_cap))) return rc;
+    st.active = true;
+    return VRS_OK;
+}
+
+// the plan's head has arrived: finish the group; *done = the whole sort is on the stream
+static int one_read_complete(vrs_context ctx, bool *done) {
+    vrs_context_t::OneRead &st = ctx->one_read;
+    *done = false;
+    const uint32_t n = st.n;
+    const int key_bytes = st.key_bytes;
+    const bool wide = key_bytes == 8, pairs = st.vptr[0] != nullptr;
+    const bool msd = st.msd_capable && st.group == 0;
+    const OneReadGeometry g = one_read_geometry(ctx, st);
+    const vrs::OnesweepPlanHead &head = *ctx->os_host_head;
+    const bool timed = (ctx->profile_mask & (1u << VRS_KERNEL_LOOKBACK_SCATTER)) != 0;
+    const bool timed_ls = (ctx->profile_mask & (1u << VRS_KERNEL_LOCAL_SORT)) != 0;
+    int rc;
+    const auto finish = [&]() -> int {
+        if (st.cur) {  // an odd number of passes ran
+            VRS_HIP(ctx, hipMemcpyAsync(st.kptr[0], st.kptr[1], static_cast<size_t>(n) * key_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            if (pairs)
+                VRS_HIP(ctx, hipMemcpyAsync(st.vptr[0], st.vptr[1], static_cast<size_t>(n) * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        st.active = false;
+        *done = true;
         return VRS_OK;
     };
-    for (uint32_t group = 0; group < static_cast<uint32_t>(key_bytes) / 4u; ++group) {
-        if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
-        if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
-        const uint32_t stamp = ctx->os_stamp;
-        guard.armed = true;
-        const vrs::FusedPlan fused{ctx->os_plan, ctx->os_host_head_dev, ctx->os_ticket, stamp, T, tile_cap, blind_cap, cuts0};
-        if (msd_capable) {
-            // hybrid: the same read (after probing the key range on a sample) also fills the histogram of the range's top 14 bits; ONE
-            // plan kernel makes the LSD plan as always, decides which form runs, arms exactly one of the two first passes
-            // and stamps the head
-            if (wide)
-                VRS_HIP(ctx, vrs::launch_msd_count_u64(ctx->stream, kbuf[cur]->ptr, n, group_len, ctx->os_status,
-                                                       rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts, ev));
-            else
-                VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, kbuf[cur]->ptr, n, group_len, ctx->os_tables, ctx->os_status,
-                                                          rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units,
-                                                          ctx->os_msd_counts, fast_count, ev));
-            VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
-                                              ctx->os_host_head_dev, stamp, n, T, tiles_b_cap, local_cap, ctx->os_tables, group_len,
-                                              tile_cap, blind_cap, cuts0, wide ? 2u : fast_count ? 1u : 0u, wide ? 50u : 18u));
-        } else {
-            VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, kbuf[cur]->ptr, n, key_bytes, 32u * group, group_len, G,
-                                                  ctx->os_tables, ctx->os_status, rows * VRS_RADIX_SORT_BINS,
-                                                  ctx->scatter.compute_units, ev, ctx->os_fused_plan ? &fused : nullptr));
-            if (!ctx->os_fused_plan)
-                VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, ctx->os_host_head_dev, stamp, n,
-                                              group_len, G, T, tile_cap, blind_cap, cuts0));
+    if (msd && !head.msd_ok && head.lsd_missing) {
+        // fast count, and the plan refused the hybrid form: every speculative launch left at once, no key has moved.
+        // Start over as an LSD sort (its own counting read).
+        if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = st.ev_lb_before;
+        if (timed_ls) ctx->events_used[VRS_KERNEL_LOCAL_SORT] = st.ev_ls_before;
+        if (wide) ctx->os_wide_refused = true; else ctx->os_fast_count_armed[pairs ? 1 : 0] = false;
+        ctx->os_hybrid_recounts++;
+        st.no_hybrid = true;
+        st.group = 0;
+        st.cur = st.cur_at_start;
+        return one_read_enqueue(ctx);
+    }
+    if (msd && !wide) ctx->os_fast_count_armed[pairs ? 1 : 0] = head.msd_ok != 0u;
+    if (msd && wide && head.msd_ok) ctx->os_wide_refused = false;
+    if (msd && head.msd_ok) {
+        // hybrid form: the first MSD pass is running (keys -> partner); second pass back, then the buckets in place
+        if (timed) {  // the LSD pass 0 (if it was enqueued) left at once: hand its events back
+            if (st.blind_passes && st.blind_tail)
+                std::swap(ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][st.ev_lb_before + 1], ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][st.ev_lb_before + 2]);
+            ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = st.ev_lb_before + (st.blind_tail ? 2 : 1);
         }
-        guard.armed = false;
-        // speculative launches, before the plan is known here.  LSD form: all four passes (pass 0's streams are the host's
-        // own cuts).  Hybrid-capable sort: only the two candidate FIRST passes -- the LSD pass 0 and the first MSD pass
-        // (same buffers; the plan arms exactly one, the other leaves at once) -- the rest follows once the head is here,
-        // while that first pass runs.
-        const uint32_t cur_at_start = cur;
-        const size_t events_before = ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER];
-        // (after a fast count the LSD pass 0 is not enqueued at all: that sort is expected to take the hybrid form; if the
-        // key range turns out too narrow for it, the four LSD passes follow the plan's head, one host round trip late)
-        const uint32_t blind_passes = msd_capable ? (fast_count ? 0u : 1u) : 4u;
-        if (msd_capable) {  // the first MSD pass goes first: it is the one that usually runs, the other then leaves behind it
-            if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
-            VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kbuf[cur_at_start]->ptr, kbuf[cur_at_start ^ 1u]->ptr,
-                                                      values ? static_cast<const uint32_t *>(vbuf[cur_at_start]->ptr) : nullptr,
-                                                      values ? static_cast<uint32_t *>(vbuf[cur_at_start ^ 1u]->ptr) : nullptr,
-                                                      ctx->os_plan_a, 0, vrs::kShiftFromPlan, ctx->os_status, tiles0, false,
-                                                      ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes, ctx->os_spin_budget,
-                                                      ctx->os_hold_tile, ev, ctx->os_misplace));
+        if (!st.blind_tail && (rc = one_read_hybrid_tail(ctx, st, g, head.msd_tiles_b, head.msd_max_bucket))) return rc;
+        st.cur = st.cur_at_start;
+        ctx->os_hybrid_sorts++;
+        return finish();  // the whole key is sorted (64-bit keys: no second group of passes)
+    }
+    if (msd) {  // refused, but the LSD plan exists: the first MSD pass (and a blind tail) left at once -- hand the events back, keep the LSD pass 0's
+        if (timed) {
+            if (st.blind_passes)
+                std::swap(ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][st.ev_lb_before], ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][st.ev_lb_before + 1]);
+            ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = st.ev_lb_before + st.blind_passes;
         }
-        for (uint32_t i = 0; i < blind_passes; ++i)
-            if ((rc = lookback_pass(i, 32u * group + 8u * i, i == 0 ? tiles0 : blind_cap, false))) return rc;
-        if ((rc = wait_for_plan(ctx, stamp))) return rc;
-        const vrs::OnesweepPlanHead &head = *ctx->os_host_head;
-        const bool timed = (ctx->profile_mask & (1u << VRS_KERNEL_LOOKBACK_SCATTER)) != 0;
-        if (msd_capable && !head.msd_ok && head.lsd_missing) {
-            // fast count, and the plan refused the hybrid form: both speculative first passes left at once, no key has
-            // moved.  Start over as an LSD sort (its own counting read).
-            if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before;
-            if (wide) ctx->os_wide_refused = true; else ctx->os_fast_count_armed[values ? 1 : 0] = false;
-            ctx->os_hybrid_recounts++;
-            const bool saved = ctx->os_hybrid;
-            ctx->os_hybrid = false;
-            rc = sort_one_read(ctx, keys, keys_tmp, values, values_tmp, n, key_bytes);
-            ctx->os_hybrid = saved;
-            return rc;
-        }
-        if (msd_capable && !wide) ctx->os_fast_count_armed[values ? 1 : 0] = head.msd_ok != 0u;
-        if (msd_capable && wide && head.msd_ok) ctx->os_wide_refused = false;
-        if (msd_capable && head.msd_ok) {
-            // hybrid form: the first MSD pass is running (keys -> partner); second pass back, then the buckets in place
-            if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + 1;  // the LSD pass 0 left at once: hand its events back
-            if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
-            VRS_HIP(ctx, vrs::launch_msd_pass_b(ctx->stream, kbuf[cur_at_start ^ 1u]->ptr, kbuf[cur_at_start]->ptr,
-                                                values ? static_cast<const uint32_t *>(vbuf[cur_at_start ^ 1u]->ptr) : nullptr,
-                                                values ? static_cast<uint32_t *>(vbuf[cur_at_start]->ptr) : nullptr, ctx->os_msd_plan,
-                                                ctx->os_status, head.msd_tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map, key_bytes,
-                                                ctx->os_spin_budget, ev));
-            if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
-            if (wide)
-                VRS_HIP(ctx, vrs::launch_msd_local_sort_u64(ctx->stream, kbuf[cur_at_start]->ptr, ctx->os_msd_plan,
-                                                            head.msd_max_bucket, ev));
-            else
-                VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(kbuf[cur_at_start]->ptr),
-                                                        values ? static_cast<uint32_t *>(vbuf[cur_at_start]->ptr) : nullptr,
-                                                        ctx->os_msd_plan, head.msd_max_bucket, ev));
-            cur = cur_at_start;
-            ctx->os_hybrid_sorts++;
-            break;  // the whole key is sorted (64-bit keys: no second group of passes)
-        }
-        if (msd_capable && timed) {  // the first MSD pass left at once: hand its events back, keep the LSD pass 0's (if any)
-            if (blind_passes)
-                std::swap(ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][events_before], ctx->events[VRS_KERNEL_LOOKBACK_SCATTER][events_before + 1]);
-            ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + blind_passes;
-        }
-        const uint32_t q = std::min<uint32_t>(head.first_abnormal, blind_passes);
-        ctx->os_lookback_passes += q;
-        if (q == 4) continue;  // four look-back passes: the data is back where it started (cur unchanged)
+        if (timed_ls) ctx->events_used[VRS_KERNEL_LOCAL_SORT] = st.ev_ls_before;
+    }
+    const uint32_t q = std::min<uint32_t>(head.first_abnormal, st.blind_passes);
+    ctx->os_lookback_passes += q;
+    if (q < 4) {
         // passes q..3 left at once on the device: take back their (untouched) buffers and timing events, enqueue them again
-        cur = cur_at_start ^ (q & 1u);
-        if (ctx->profile_mask & (1u << VRS_KERNEL_LOOKBACK_SCATTER))
-            ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = events_before + q;
+        st.cur = st.cur_at_start ^ (q & 1u);
+        if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = st.ev_lb_before + q;
+        // the contract pass a group may fall back to walks launch tiles of 32 (uint32) / 16 (uint64) blocks
+        const uint32_t B = launch_tile_blocks(key_bytes);
+        vrs_push_constants pc{n, 0, vrs_workgroup_count(n, B), B};
         for (uint32_t i = q; i < 4; ++i) {
-            const uint32_t shift = 32u * group + 8u * i;
+            const uint32_t shift = 32u * st.group + 8u * i;
             if (head.mode[i] == vrs::kPassIdentity) {
                 ctx->os_skipped_passes++;
             } else if (head.mode[i] == vrs::kPassUnbalanced) {
-                vrs_buffer kin = kbuf[cur], kout = kbuf[cur ^ 1u];
-                vrs_buffer vin = values ? vbuf[cur] : nullptr, vout = values ? vbuf[cur ^ 1u] : nullptr;
-                cur ^= 1u;
+                vrs_buffer_t kin = stack_view(ctx, st.kptr[st.cur], static_cast<size_t>(n) * key_bytes);
+                vrs_buffer_t kout = stack_view(ctx, st.kptr[st.cur ^ 1u], static_cast<size_t>(n) * key_bytes);
+                vrs_buffer_t vin = stack_view(ctx, pairs ? st.vptr[st.cur] : nullptr, static_cast<size_t>(n) * sizeof(uint32_t));
+                vrs_buffer_t vout = stack_view(ctx, pairs ? st.vptr[st.cur ^ 1u] : nullptr, static_cast<size_t>(n) * sizeof(uint32_t));
+                st.cur ^= 1u;
                 ctx->os_fallback_passes++;
                 if ((rc = ensure_sort_hist(ctx, pc.g_num_workgroups))) return rc;
-                if ((rc = contract_pass(ctx, kin, kout, vin, vout, &pc, shift, key_bytes))) return rc;
+                if ((rc = contract_pass(ctx, &kin, &kout, pairs ? &vin : nullptr, pairs ? &vout : nullptr, &pc, shift, key_bytes))) return rc;
             } else {
                 ctx->os_lookback_passes++;
-                if (i < blind_passes) ctx->os_relaunched_passes++;
-                if ((rc = lookback_pass(i, shift, head.max_tiles[i], true))) return rc;
+                if (i < st.blind_passes) ctx->os_relaunched_passes++;
+                if ((rc = one_read_lookback_pass(ctx, st, i, shift, head.max_tiles[i], true))) return rc;
             }
         }
     }
-    if (cur) {  // an odd number of passes ran
-        VRS_HIP(ctx, hipMemcpyAsync(keys->ptr, keys_tmp->ptr, static_cast<size_t>(n) * key_bytes, hipMemcpyDeviceToDevice,
-                                    ctx->stream));
-        if (values)
-            VRS_HIP(ctx, hipMemcpyAsync(values->ptr, values_tmp->ptr, static_cast<size_t>(n) * sizeof(uint32_t),
-                                        hipMemcpyDeviceToDevice, ctx->stream));
+    // (four look-back passes: the data is back where the group started)
+    if (++st.group < static_cast<uint32_t>(key_bytes) / 4u) return one_read_enqueue(ctx);
+    return finish();
+}
+
+// second half of a pending one-call sort (no-op without one); blocks until the plan(s) arrived and everything is enqueued
+static int one_read_settle(vrs_context ctx) {
+    struct Settling {  // the second half itself goes through entry points that would settle
+        vrs_context ctx;
+        explicit Settling(vrs_context c) : ctx(c) { ctx->one_read_settling = true; }
+        ~Settling() { ctx->one_read_settling = false; }
+    } settling(ctx);
+    while (ctx->one_read.active) {
+        int rc = wait_for_plan(ctx, ctx->one_read.stamp);
+        if (rc) return rc;  // still pending: a later settle may succeed (VRS_ERROR_TIMEOUT)
+        bool done = false;
+        if ((rc = one_read_complete(ctx, &done))) {
+            ctx->one_read.active = false;  // the sort failed half-way: nothing to resume
+            return rc;
+        }
     }
     return VRS_OK;
+}
+
+}  // extern "C"
+namespace {
+int settle_pending(vrs_context ctx) { return ctx->one_read.active && !ctx->one_read_settling ? one_read_settle(ctx) : VRS_OK; }
+}  // namespace
+extern "C" {
+
+static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values, vrs_buffer values_tmp,
+                         uint32_t n, int key_bytes) {
+    vrs_context_t::OneRead &st = ctx->one_read;
+    st = vrs_context_t::OneRead{};
+    st.kptr[0] = keys->ptr;
+    st.kptr[1] = keys_tmp->ptr;
+    st.vptr[0] = values ? values->ptr : nullptr;
+    st.vptr[1] = values ? values_tmp->ptr : nullptr;
+    st.n = n;
+    st.key_bytes = key_bytes;
+    st.deferred = ctx->os_async;
+    int rc = one_read_enqueue(ctx);
+    if (rc) {
+        st.active = false;
+        return rc;
+    }
+    return st.deferred ? VRS_OK : one_read_settle(ctx);
 }
 
 // One-call form: the four passes of MultiRadixSort::execute's hot loop (MultiRadixSort.cpp:50-61) with the
@@ -960,6 +1134,7 @@ static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp
         }
     }
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = one_read_settle(ctx))) return rc;  // an earlier async sort may still owe its second half
     ctx->sub_cache.valid = false;  // the keys are rewritten in place
     // small N: the whole sort in ONE launch of the single-workgroup kernel instead of twelve launch-bound ones (the
     // reference's own guidance: its single_radixsort is the faster path for small inputs, README.md:18-21)
@@ -983,6 +1158,108 @@ static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp
     }
     return VRS_OK;
 }
+
+static_assert(VRS_MSD_COUNT_WORDS == vrs::kMsdCountWords && VRS_MSD_SHIFT_WORD == vrs::kMsdBucketCount + 8u * 256u, "the public layout of the count words is the kernels' own");
+
+// ---- the hybrid form in two halves, for callers that move the keys between its two MSD passes (vrs_dist_*: the exchange
+// between the GPUs sits there).  Both halves only enqueue.
+static int msd_half_setup(vrs_context ctx, uint32_t n, vrs_context_t::OneRead *st, OneReadGeometry *g) {
+    if (!ctx->xcc_map_valid || !ctx->atomic_rank_verified || !ctx->scatter.atomic_rank)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the hybrid form needs the look-back placement probe and the LDS-atomic ranking self-test to have passed on this device");
+    if (n == 0 || n >= (1u << 30)) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the hybrid form takes 1 .. 2^30 - 1 keys");
+    *st = vrs_context_t::OneRead{};
+    st->n = n;
+    st->key_bytes = 4;
+    st->msd_capable = true;
+    st->blind_tail = true;
+    st->fast_count = true;
+    *g = one_read_geometry(ctx, *st);
+    return one_read_scratch(ctx, *st, *g);
+}
+
+int vrs_msd_partition_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer out, vrs_buffer counts_out, uint32_t n) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    int rc;
+    const size_t bytes = static_cast<size_t>(n) * sizeof(uint32_t);
+    if ((rc = check_buffer(ctx, keys, bytes, "keys"))) return rc;
+    if ((rc = check_buffer(ctx, out, bytes, "out"))) return rc;
+    if ((rc = check_buffer(ctx, counts_out, VRS_MSD_COUNT_WORDS * sizeof(uint32_t), "counts_out"))) return rc;
+    if (keys->ptr == out->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "keys and out alias");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = settle_pending(ctx))) return rc;
+    vrs_context_t::OneRead st;
+    OneReadGeometry g;
+    if ((rc = msd_half_setup(ctx, n, &st, &g))) return rc;
+    ctx->sub_cache.valid = false;
+    vrs::LaunchEvents ev;
+    if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
+    if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
+    // counting read: only the bucket histogram and the slices' top-byte counts (a key range below 27 bits gets the LSD
+    // tables instead -- the plan kernel clears them again -- and leaves the histogram empty: the caller sees the shift)
+    VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, keys->ptr, n, g.group_len, ctx->os_tables, ctx->os_status,
+                                              g.rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts, true, ev));
+    VRS_HIP(ctx, hipMemcpyAsync(counts_out->ptr, ctx->os_msd_counts, VRS_MSD_COUNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
+                                      ctx->os_host_head_dev, ctx->os_stamp, n, g.T, g.tiles_b_cap, g.local_cap, ctx->os_tables,
+                                      g.group_len, g.tile_cap, g.blind_cap, g.cuts0, 1u, 18u));
+    // the first MSD pass, whatever the plan thinks of this shard's buckets (forced: the streams, not their armed copies)
+    if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, keys->ptr, out->ptr, nullptr, nullptr, ctx->os_plan_a, 0, vrs::kShiftFromPlan,
+                                              ctx->os_status, g.tiles0, true, ctx->scatter.atomic_rank, ctx->xcc_map, 4,
+                                              ctx->os_spin_budget, -1, ev, false));
+    return VRS_OK;
+}
+
+int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_buffer counts, uint32_t n) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    int rc;
+    const size_t bytes = static_cast<size_t>(n) * sizeof(uint32_t);
+    if ((rc = check_buffer(ctx, grouped, bytes, "grouped"))) return rc;
+    if ((rc = check_buffer(ctx, out, bytes, "out"))) return rc;
+    if ((rc = check_buffer(ctx, counts, VRS_MSD_COUNT_WORDS * sizeof(uint32_t), "counts"))) return rc;
+    if (grouped->ptr == out->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "grouped and out alias");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = settle_pending(ctx))) return rc;
+    vrs_context_t::OneRead st;
+    OneReadGeometry g;
+    if ((rc = msd_half_setup(ctx, n, &st, &g))) return rc;
+    ctx->sub_cache.valid = false;
+    if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
+    ctx->os_msd_half_stamp = ctx->os_stamp;
+    // the look-back rows of the second pass must read "never written": the counting read of a whole sort clears them, here
+    // nothing else does
+    VRS_HIP(ctx, hipMemsetAsync(ctx->os_status, 0, g.rows * VRS_RADIX_SORT_BINS * sizeof(uint32_t), ctx->stream));
+    VRS_HIP(ctx, hipMemcpyAsync(ctx->os_msd_counts, counts->ptr, VRS_MSD_COUNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
+                                      ctx->os_host_head_dev, ctx->os_stamp, n, g.T, g.tiles_b_cap, g.local_cap, ctx->os_tables,
+                                      g.group_len, g.tile_cap, g.blind_cap, g.cuts0, 1u, 18u));
+    st.kptr[0] = out->ptr;      // "home": the second pass writes here, the local sort works here
+    st.kptr[1] = grouped->ptr;  // the partner holds the first pass's output
+    st.cur_at_start = 0;
+    return one_read_hybrid_tail(ctx, st, g, g.tiles_b_cap, g.local_cap);
+}
+
+int vrs_msd_finish_status(vrs_context ctx, int *took) {
+    if (!ctx || !took) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or took is NULL");
+    *took = 0;
+    if (ctx->os_msd_half_stamp == 0) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "no vrs_msd_finish_u32 to ask about");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    const int rc = wait_for_plan(ctx, ctx->os_msd_half_stamp);
+    if (rc) return rc;
+    *took = ctx->os_host_head->msd_ok ? 1 : 0;
+    return VRS_OK;
+}
+
+int vrs_context_device(vrs_context ctx) { return ctx ? ctx->device : -1; }
+
+int vrs_sort_settle(vrs_context ctx) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (!ctx->one_read.active) return VRS_OK;
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    return one_read_settle(ctx);
+}
+
+int vrs_sort_pending(vrs_context ctx) { return ctx && ctx->one_read.active ? 1 : 0; }
 
 int vrs_sort_keys_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements) {
     return sort_all_passes(ctx, keys, keys_tmp, nullptr, nullptr, num_elements, 8);
@@ -1012,6 +1289,7 @@ int vrs_transform_keys(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, 
     int rc = check_buffer(ctx, keys, static_cast<size_t>(num_elements) * sizeof(uint32_t), "keys");
     if (rc) return rc;
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int settled = settle_pending(ctx)) return settled;  // an async one-call sort may still owe its second half
     ctx->sub_cache.valid = false;  // a buffer is rewritten: the kept sub-tile table may no longer describe its keys
     VRS_HIP(ctx, vrs::launch_transform_keys(ctx->stream, static_cast<uint32_t *>(keys->ptr), num_elements, mode));
     return VRS_OK;
@@ -1027,6 +1305,7 @@ int vrs_verify_keys_u32(vrs_context ctx, vrs_buffer keys, uint32_t num_elements,
     int rc = check_buffer(ctx, keys, static_cast<size_t>(num_elements) * sizeof(uint32_t), "keys");
     if (rc) return rc;
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int settled = settle_pending(ctx)) return settled;  // an async one-call sort may still owe its second half
     unsigned long long *d = nullptr;
     VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), 3 * sizeof(unsigned long long)));
     unsigned long long h[3] = {0, 0, 0};
@@ -1106,6 +1385,7 @@ int vrs_range_partition(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out
     if ((rc = check_buffer(ctx, splitters, static_cast<size_t>(num_splitters) * sizeof(uint32_t), "splitters"))) return rc;
     if (keys_in->ptr == keys_out->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "keys_in and keys_out alias");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int settled = settle_pending(ctx)) return settled;  // an async one-call sort may still owe its second half
     const uint32_t B = launch_tile_blocks(4);
     const uint32_t W = vrs_workgroup_count(n, B);
     // the [W][256] bucket-count table lives in the context (same scratch as the sub-tile histograms)
@@ -1209,6 +1489,10 @@ int vrs_rank_mode(vrs_context ctx) { return ctx && ctx->scatter.atomic_rank ? 2 
 
 int vrs_set_tuning(vrs_context ctx, int key, int value) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (key != VRS_TUNE_PLAN_WAIT_MS) {  // the second half of a pending sort must see the settings its first half saw
+        const int rc = settle_pending(ctx);
+        if (rc) return rc;
+    }
     switch (key) {
         case VRS_TUNE_XCD_REMAP:
             ctx->xcd_remap = value != 0;
@@ -1265,6 +1549,13 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             return VRS_OK;
         case VRS_TUNE_DEBUG_HOLD_TILE:
             ctx->os_hold_tile = value;
+            return VRS_OK;
+        case VRS_TUNE_ASYNC_SORT:
+            ctx->os_async = value != 0;
+            return VRS_OK;
+        case VRS_TUNE_PLAN_WAIT_MS:
+            if (value < 0) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the plan wait limit must be >= 0 ms");
+            ctx->os_plan_wait_ms = static_cast<uint32_t>(value);
             return VRS_OK;
         case VRS_TUNE_DIGIT_TABLE_GROUPS:
             if (value != 0 && value != 8 && value != 16 && value != 32)

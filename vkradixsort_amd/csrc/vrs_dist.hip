@@ -1,25 +1,44 @@
-// vrs_dist.hip -- the multi-GPU step behind the C ABI: key-range sharded sort over an RCCL communicator, one process
-// per GPU (BASELINE.json configs[4]).  The reference has no multi-GPU code (no collective call
-// site anywhere under /root/reference); north_star defines the path: shard by key range across the GPUs of a node,
-// one all-to-all over xGMI between the local step and the local sorts.
+// vrs_dist.hip -- the multi-GPU step behind the C ABI: key-range sharded sort, one rank per GPU (BASELINE.json configs[4];
+// SURVEY.md section 8e).  The reference has no multi-GPU code (no collective call site anywhere under /root/reference);
+// north_star defines the path: shard by key range across the GPUs of a node, one all-to-all over xGMI between the local
+// step and the local sorts.
 //
-// Host orchestration only -- every device step goes through the public C ABI of this library (the same entry points
-// a C++ host would call): a top-byte partition pass (vrs_multi_radixsort_histograms + vrs_multi_radixsort with
-// g_shift = 24), ONE all-gather of every rank's 256 top-byte counts, splitters, R rounds of grouped send/recv, and a
-// vrs_sort_keys_u32 per received sub-range while the next round is on the wire.  The Python twin is
-// vkradixsort_amd/distributed.py (RangeShardedSort.step, main path); the two plan_splitters must agree bit for bit
-// (tests/test_capi_cpu.py).
+// Host orchestration only -- every device step goes through the public C ABI of this library (the entry points a C++ host
+// would call).  Two shapes of the step:
 //
-// RCCL is bound at run time (dlopen / dlsym): the library has no link-time dependency on it, and a process that
-// already carries an RCCL (PyTorch ships its own librccl.so) keeps using THAT one -- a communicator is only valid
-// inside the copy of the library that made it.
+//   hybrid shape (default; the single-GPU hybrid sort with the exchange between its two MSD passes, 28 B/key per GPU):
+//     1. vrs_msd_partition_u32 of the shard: one counting read (top-14-bit bucket histogram + top-byte counts) and the
+//        first MSD pass -- the shard grouped by the top byte of the key range;
+//     2. ONE all-gather of every rank's row (top-byte counts of its eight input slices, shard size, bucket shift, status)
+//        and ONE all-reduce of the 16384-bin bucket histograms (64 KB); every rank derives the same byte-aligned
+//        splitters, all send / receive counts and where every message lands from the gathered rows;
+//     3. R rounds of grouped send / recv on a second stream: one message per (sender, top byte), landing in top-byte
+//        order -- the receive buffer of a round IS the first MSD pass's output for that round's key sub-range;
+//     4. per round, while the later rounds are on the wire: vrs_msd_finish_u32 (second MSD pass + LDS-local sort) with the
+//        all-reduced histogram masked to the round's buckets.  A round whose plan refuses (a bucket beyond the local
+//        sort's capacity) is sorted by vrs_sort_keys_u32 instead -- a rank-local matter.
+//   byte shape (fallback, chosen by ALL ranks together from the gathered rows: a key range below 27 bits, ranks that
+//     probed different ranges, or VRS_DIST_SHAPE=byte): contract partition pass by the top byte (12 B/key), the same
+//     exchange with one message per (sender, round), vrs_sort_keys_u32 per received sub-range.
+//
+// Every decision to leave the step is made by all ranks from the same gathered data (a rank that cannot take part says so
+// in its row and still joins the collectives), so no rank is left waiting inside a collective.
+//
+// The wire is a table of five functions (vrs_dist_transport): RCCL bound at run time by dlopen (vrs_dist_create: no
+// link-time dependency, and a process that already carries an RCCL -- PyTorch ships its own -- keeps using THAT copy), or
+// anything the caller supplies (vrs_dist_create_with_transport).  vrs_dist_loopback_* is an in-process transport -- the
+// ranks are host threads of one process, every transfer a device copy ordered by events -- for one process driving several
+// GPUs, and for running the rank-to-rank bookkeeping of this file on a single GPU (tests/test_gpu_dist.py).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -28,18 +47,19 @@
 
 namespace {
 
-// the slice of the RCCL API the step needs (rccl.h: ncclResult_t == int, ncclSuccess == 0, ncclUint32 == 3)
+// ---- RCCL, bound at run time (rccl.h: ncclResult_t == int, ncclSuccess == 0, ncclUint32 == 3, ncclSum == 0)
 struct Rccl {
     void *handle = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
-    bool ok() const { return AllGather && Send && Recv && GroupStart && GroupEnd; }
+    bool ok() const { return AllGather && AllReduce && Send && Recv && GroupStart && GroupEnd; }
 };
-constexpr int kNcclUint32 = 3;
+constexpr int kNcclUint32 = 3, kNcclSum = 0;
 
 thread_local std::string g_dist_error;
 
@@ -53,6 +73,7 @@ bool load_rccl(Rccl &r) {
         }
     void *src = r.handle ? r.handle : RTLD_DEFAULT;  // RTLD_DEFAULT: symbols of whatever copy the process already holds
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(src, "ncclAllGather"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(src, "ncclAllReduce"));
     r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(src, "ncclSend"));
     r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(src, "ncclRecv"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(src, "ncclGroupStart"));
@@ -61,22 +82,64 @@ bool load_rccl(Rccl &r) {
     return r.ok();
 }
 
+// the RCCL flavour of the transport table
+struct RcclEndpoint {
+    Rccl rccl;
+    void *comm = nullptr;
+};
+int rccl_all_gather(void *u, const void *s, void *r, size_t words, void *st) {
+    auto *e = static_cast<RcclEndpoint *>(u);
+    return e->rccl.AllGather(s, r, words, kNcclUint32, e->comm, static_cast<hipStream_t>(st));
+}
+int rccl_all_reduce(void *u, const void *s, void *r, size_t words, void *st) {
+    auto *e = static_cast<RcclEndpoint *>(u);
+    return e->rccl.AllReduce(s, r, words, kNcclUint32, kNcclSum, e->comm, static_cast<hipStream_t>(st));
+}
+int rccl_group_start(void *u) { return static_cast<RcclEndpoint *>(u)->rccl.GroupStart(); }
+int rccl_group_end(void *u) { return static_cast<RcclEndpoint *>(u)->rccl.GroupEnd(); }
+int rccl_send(void *u, const void *b, size_t words, int peer, void *st) {
+    auto *e = static_cast<RcclEndpoint *>(u);
+    return e->rccl.Send(b, words, kNcclUint32, peer, e->comm, static_cast<hipStream_t>(st));
+}
+int rccl_recv(void *u, void *b, size_t words, int peer, void *st) {
+    auto *e = static_cast<RcclEndpoint *>(u);
+    return e->rccl.Recv(b, words, kNcclUint32, peer, e->comm, static_cast<hipStream_t>(st));
+}
+const char *rccl_error_string(void *u, int code) {
+    auto *e = static_cast<RcclEndpoint *>(u);
+    return e->rccl.GetErrorString ? e->rccl.GetErrorString(code) : "RCCL error";
+}
+
+// the row every rank contributes to the one all-gather of a step
+constexpr int kRowSlices = 8 * 256;         // top-byte counts of the shard's eight input slices (hybrid shape) / [0, 256): the shard's top-byte counts (byte shape)
+constexpr int kRowN = kRowSlices;           // shard size
+constexpr int kRowStatus = kRowSlices + 1;  // 0, or the VRS_ERROR_* that keeps this rank from taking part
+constexpr int kRowCapacity = kRowSlices + 2;
+constexpr int kRowShift = kRowSlices + 3;   // hybrid shape: the probed bucket shift; 0xFFFFFFFF = a key above the probed range
+constexpr int kRowWords = kRowSlices + 8;
+
 }  // namespace
 
 struct vrs_dist_t {
     vrs_context ctx = nullptr;
-    void *comm = nullptr;  // ncclComm_t; NULL only at world size 1 (no exchange partner: every transfer is a device copy)
+    int device = 0;
     int rank = 0, world = 1, rounds = 1;
     uint32_t capacity = 0;  // keys: shard size and receive capacity
-    Rccl rccl;
+    bool has_transport = false;
+    vrs_dist_transport tr{};
+    RcclEndpoint *rccl = nullptr;  // owned; the transport's `user` when vrs_dist_create made it
+    bool byte_shape_only = false;  // VRS_DIST_SHAPE=byte
     hipStream_t sort_stream = nullptr;  // the context's stream
     hipStream_t comm_stream = nullptr;  // exchange rounds run here, beside the sorts
     std::vector<hipEvent_t> round_done;  // round r has landed in the receive buffer
     hipEvent_t grouped_ready = nullptr, sorts_done = nullptr;
-    vrs_buffer grouped = nullptr, recv = nullptr, scratch = nullptr, hist = nullptr, prefix = nullptr, table = nullptr;
-    std::vector<uint32_t> host_table;  // world x 257: every rank's top-byte prefix row and shard size
+    vrs_buffer grouped = nullptr, recv = nullptr, scratch = nullptr, hist = nullptr, row = nullptr, table = nullptr;
+    vrs_buffer counts = nullptr, reduced = nullptr, round_counts = nullptr;
+    std::vector<uint32_t> host_table;  // world x kRowWords
+    uint32_t host_row_tail[8] = {};
     std::string last_error;
     double max_imbalance = 1.15;
+    uint64_t hybrid_rounds = 0, fallback_rounds = 0, byte_steps = 0;
 };
 
 namespace {
@@ -98,17 +161,239 @@ int dfail_ctx(vrs_dist d, int code, const char *what) {
         const hipError_t e__ = (call);                                                                \
         if (e__ != hipSuccess) return dfail((d), VRS_ERROR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
     } while (0)
-#define VRS_DNCCL(d, call)                                                                                   \
-    do {                                                                                                     \
-        const int r__ = (call);                                                                              \
-        if (r__ != 0)                                                                                        \
-            return dfail((d), VRS_ERROR_HIP,                                                                 \
-                         std::string(#call) + ": " + ((d)->rccl.GetErrorString ? (d)->rccl.GetErrorString(r__) : "RCCL error")); \
+
+std::string transport_error(vrs_dist d, const char *what, int code) {
+    const char *s = d->tr.error_string ? d->tr.error_string(d->tr.user, code) : nullptr;
+    return std::string(what) + " failed: " + (s ? s : "transport error") + " (" + std::to_string(code) + ")";
+}
+#define VRS_DTR(d, what, call)                                                        \
+    do {                                                                              \
+        const int r__ = (call);                                                       \
+        if (r__ != 0) return dfail((d), VRS_ERROR_HIP, transport_error((d), (what), r__)); \
     } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// In-process transport: the ranks are host threads of one process that share a hub.  A collective is a rendezvous on the
+// host (every rank publishes what it offers and an event that says when its stream has produced it), after which every
+// rank enqueues, on its own stream, the device copies that bring ITS data in; a second rendezvous hands every rank the
+// events behind which its own buffers are free again.  Same GPU or peer GPUs of one process (device-to-device copies).
+struct LoopOp {
+    const void *src;
+    void *dst;
+    size_t words;
+    int peer;
+};
+struct LoopEndpoint {
+    struct vrs_dist_loopback_t *hub;
+    int rank;
+    bool grouping = false;
+    std::vector<LoopOp> sends, recvs;  // of the open group
+    hipStream_t group_stream = nullptr;
+};
+}  // namespace
+
+struct vrs_dist_loopback_t {
+    int world = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool broken = false;  // a rank failed inside a collective: everyone leaves with an error instead of waiting
+    std::vector<LoopEndpoint> ends;
+    // what the ranks publish for the collective in flight
+    std::vector<const void *> src;
+    std::vector<size_t> words;
+    std::vector<hipEvent_t> ready, done;  // per rank: "my data is produced" / "my copies have run"
+    std::vector<std::vector<LoopOp>> sends;
+};
+
+namespace {
+
+// host barrier of the hub's ranks; false = the hub is broken (a peer failed)
+bool loop_barrier(vrs_dist_loopback_t *h) {
+    std::unique_lock<std::mutex> lk(h->m);
+    if (h->broken) return false;
+    const uint64_t gen = h->generation;
+    if (++h->arrived == h->world) {
+        h->arrived = 0;
+        ++h->generation;
+        h->cv.notify_all();
+        return true;
+    }
+    h->cv.wait(lk, [&] { return h->generation != gen || h->broken; });
+    return !h->broken;
+}
+int loop_break(vrs_dist_loopback_t *h, int code) {
+    std::lock_guard<std::mutex> lk(h->m);
+    h->broken = true;
+    h->cv.notify_all();
+    return code;
+}
+constexpr int kLoopErrHip = 1, kLoopErrPeer = 2, kLoopErrUsage = 3;
+
+// after the copies of a collective: every rank waits (on its stream) until all ranks' copies have run, so that whatever it
+// enqueues next may overwrite the buffers it offered
+int loop_release(LoopEndpoint *e, hipStream_t st) {
+    vrs_dist_loopback_t *h = e->hub;
+    if (hipEventRecord(h->done[e->rank], st) != hipSuccess) return loop_break(h, kLoopErrHip);
+    if (!loop_barrier(h)) return kLoopErrPeer;
+    for (int s = 0; s < h->world; ++s)
+        if (s != e->rank && hipStreamWaitEvent(st, h->done[s], 0) != hipSuccess) return loop_break(h, kLoopErrHip);
+    if (!loop_barrier(h)) return kLoopErrPeer;  // nobody re-records its events before everybody has waited on them
+    return 0;
+}
+
+int loop_gather_like(void *u, const void *send, void *recv, size_t words, void *stream, bool reduce) {
+    auto *e = static_cast<LoopEndpoint *>(u);
+    vrs_dist_loopback_t *h = e->hub;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    h->src[e->rank] = send;
+    h->words[e->rank] = words;
+    if (hipEventRecord(h->ready[e->rank], st) != hipSuccess) return loop_break(h, kLoopErrHip);
+    if (!loop_barrier(h)) return kLoopErrPeer;
+    for (int s = 0; s < h->world; ++s)
+        if (h->words[s] != words) return loop_break(h, kLoopErrUsage);
+    if (!reduce) {
+        for (int s = 0; s < h->world; ++s) {
+            if (s != e->rank && hipStreamWaitEvent(st, h->ready[s], 0) != hipSuccess) return loop_break(h, kLoopErrHip);
+            if (hipMemcpyAsync(static_cast<uint32_t *>(recv) + static_cast<size_t>(s) * words, h->src[s], words * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return loop_break(h, kLoopErrHip);
+        }
+    } else {
+        // sum of the ranks' buffers through the host (a few KB: this transport is not the fast path of anything)
+        std::vector<uint32_t> acc(words, 0), tmp(words);
+        for (int s = 0; s < h->world; ++s) {
+            if (s != e->rank && hipStreamWaitEvent(st, h->ready[s], 0) != hipSuccess) return loop_break(h, kLoopErrHip);
+            if (hipMemcpyAsync(tmp.data(), h->src[s], words * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+                return loop_break(h, kLoopErrHip);
+            for (size_t i = 0; i < words; ++i) acc[i] += tmp[i];
+        }
+        // every rank has read every offer before anyone's result may land in a buffer that is also an offer (in-place use)
+        if (!loop_barrier(h)) return kLoopErrPeer;
+        if (hipMemcpyAsync(recv, acc.data(), words * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return loop_break(h, kLoopErrHip);
+    }
+    return loop_release(e, st);
+}
+int loop_all_gather(void *u, const void *s, void *r, size_t words, void *st) { return loop_gather_like(u, s, r, words, st, false); }
+int loop_all_reduce(void *u, const void *s, void *r, size_t words, void *st) { return loop_gather_like(u, s, r, words, st, true); }
+int loop_group_start(void *u) {
+    auto *e = static_cast<LoopEndpoint *>(u);
+    if (e->grouping) return kLoopErrUsage;
+    e->grouping = true;
+    e->sends.clear();
+    e->recvs.clear();
+    e->group_stream = nullptr;
+    return 0;
+}
+int loop_send(void *u, const void *b, size_t words, int peer, void *st) {
+    auto *e = static_cast<LoopEndpoint *>(u);
+    if (!e->grouping || peer < 0 || peer >= e->hub->world || peer == e->rank) return kLoopErrUsage;
+    e->sends.push_back(LoopOp{b, nullptr, words, peer});
+    e->group_stream = static_cast<hipStream_t>(st);
+    return 0;
+}
+int loop_recv(void *u, void *b, size_t words, int peer, void *st) {
+    auto *e = static_cast<LoopEndpoint *>(u);
+    if (!e->grouping || peer < 0 || peer >= e->hub->world || peer == e->rank) return kLoopErrUsage;
+    e->recvs.push_back(LoopOp{nullptr, b, words, peer});
+    e->group_stream = static_cast<hipStream_t>(st);
+    return 0;
+}
+// the k-th receive a rank posted from peer p takes the k-th send p posted to that rank (the order RCCL matches them in)
+int loop_group_end(void *u) {
+    auto *e = static_cast<LoopEndpoint *>(u);
+    vrs_dist_loopback_t *h = e->hub;
+    if (!e->grouping) return kLoopErrUsage;
+    e->grouping = false;
+    hipStream_t st = e->group_stream;  // nullptr: this rank has nothing to move in this group (it still takes part)
+    h->sends[e->rank] = e->sends;
+    if (st && hipEventRecord(h->ready[e->rank], st) != hipSuccess) return loop_break(h, kLoopErrHip);
+    // a rank without operations records nothing: nobody will wait on its event, because nobody receives from it
+    if (!loop_barrier(h)) return kLoopErrPeer;
+    std::vector<size_t> next(static_cast<size_t>(h->world), 0);
+    for (const LoopOp &r : e->recvs) {
+        const std::vector<LoopOp> &theirs = h->sends[r.peer];
+        size_t &k = next[static_cast<size_t>(r.peer)];
+        while (k < theirs.size() && theirs[k].peer != e->rank) ++k;
+        if (k == theirs.size() || theirs[k].words != r.words) return loop_break(h, kLoopErrUsage);  // unmatched receive
+        if (hipStreamWaitEvent(st, h->ready[r.peer], 0) != hipSuccess ||
+            hipMemcpyAsync(r.dst, theirs[k].src, r.words * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return loop_break(h, kLoopErrHip);
+        ++k;
+    }
+    // release: senders may reuse what they offered once the receivers' copies have run
+    if (st) {
+        if (hipEventRecord(h->done[e->rank], st) != hipSuccess) return loop_break(h, kLoopErrHip);
+    }
+    if (!loop_barrier(h)) return kLoopErrPeer;
+    if (st)
+        for (const LoopOp &s : e->sends)
+            if (hipStreamWaitEvent(st, h->done[s.peer], 0) != hipSuccess) return loop_break(h, kLoopErrHip);
+    if (!loop_barrier(h)) return kLoopErrPeer;
+    return 0;
+}
+const char *loop_error_string(void *, int code) {
+    switch (code) {
+        case kLoopErrHip: return "loopback transport: a HIP call failed";
+        case kLoopErrPeer: return "loopback transport: another rank failed inside a collective";
+        case kLoopErrUsage: return "loopback transport: mismatched collective (sizes, peers or grouping differ between the ranks)";
+        default: return "loopback transport error";
+    }
+}
 
 }  // namespace
 
 extern "C" {
+
+int vrs_dist_loopback_create(int world, vrs_dist_loopback *out) {
+    if (!out || world < 1 || world > 64) return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "out is NULL or world is not in 1 .. 64");
+    *out = nullptr;
+    auto *h = new (std::nothrow) vrs_dist_loopback_t();
+    if (!h) return dfail(nullptr, VRS_ERROR_OUT_OF_MEMORY, "host allocation failed");
+    h->world = world;
+    h->ends.resize(static_cast<size_t>(world));
+    h->src.assign(static_cast<size_t>(world), nullptr);
+    h->words.assign(static_cast<size_t>(world), 0);
+    h->sends.resize(static_cast<size_t>(world));
+    h->ready.assign(static_cast<size_t>(world), nullptr);
+    h->done.assign(static_cast<size_t>(world), nullptr);
+    for (int r = 0; r < world; ++r) {
+        h->ends[static_cast<size_t>(r)].hub = h;
+        h->ends[static_cast<size_t>(r)].rank = r;
+    }
+    *out = h;
+    return VRS_OK;
+}
+
+// Fills `out` with rank `rank`'s end of the hub.  Call on the thread (and with the device current) that will drive this rank:
+// the rank's events are made here.
+int vrs_dist_loopback_transport(vrs_dist_loopback hub, int rank, vrs_dist_transport *out) {
+    if (!hub || !out || rank < 0 || rank >= hub->world) return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "hub, out or rank invalid");
+    const size_t r = static_cast<size_t>(rank);
+    if (!hub->ready[r] && (hipEventCreateWithFlags(&hub->ready[r], hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&hub->done[r], hipEventDisableTiming) != hipSuccess))
+        return dfail(nullptr, VRS_ERROR_HIP, "hipEventCreate failed");
+    out->user = &hub->ends[r];
+    out->all_gather = loop_all_gather;
+    out->all_reduce = loop_all_reduce;
+    out->group_start = loop_group_start;
+    out->send = loop_send;
+    out->recv = loop_recv;
+    out->group_end = loop_group_end;
+    out->error_string = loop_error_string;
+    return VRS_OK;
+}
+
+int vrs_dist_loopback_destroy(vrs_dist_loopback hub) {
+    if (!hub) return VRS_OK;
+    for (auto e : hub->ready)
+        if (e) (void)hipEventDestroy(e);
+    for (auto e : hub->done)
+        if (e) (void)hipEventDestroy(e);
+    delete hub;
+    return VRS_OK;
+}
 
 // Byte boundaries b[0] = 0 <= b[1] <= ... <= b[parts] = 256: part q owns top bytes [b[q], b[q+1]).  Greedy: boundary q
 // is the byte at which the cumulative count first reaches q / parts of the total, snapped to whichever side is closer.
@@ -135,29 +420,37 @@ int vrs_dist_plan_splitters(const uint64_t *counts256, int parts, uint32_t *boun
 
 const char *vrs_dist_last_error(vrs_dist d) { return d ? d->last_error.c_str() : g_dist_error.c_str(); }
 
-int vrs_dist_create(vrs_context ctx, void *nccl_comm, int rank, int world, uint32_t capacity_keys, int rounds, vrs_dist *out) {
+int vrs_dist_create_with_transport(vrs_context ctx, const vrs_dist_transport *transport, int rank, int world,
+                                   uint32_t capacity_keys, int rounds, vrs_dist *out) {
     if (!out) return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     if (!ctx || world < 1 || rank < 0 || rank >= world || capacity_keys == 0)
         return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context, rank / world or capacity invalid");
-    if (world > 1 && !nccl_comm) return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "an RCCL communicator is required at world size > 1");
+    if (world > 1 && !transport) return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "a transport is required at world size > 1");
+    if (transport && !(transport->all_gather && transport->all_reduce && transport->group_start && transport->send && transport->recv && transport->group_end))
+        return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "the transport table has an empty slot");
     vrs_dist d = new (std::nothrow) vrs_dist_t();
     if (!d) return dfail(nullptr, VRS_ERROR_OUT_OF_MEMORY, "host allocation failed");
     d->ctx = ctx;
-    d->comm = nccl_comm;
+    d->device = vrs_context_device(ctx);
     d->rank = rank;
     d->world = world;
-    d->rounds = std::max(1, std::min(rounds, 256 / world));
+    d->rounds = std::max(1, std::min(rounds, 32 / std::min(world, 32)));  // world * rounds <= 32 parts: a round keeps every XCD of the second pass busy
+    if (world > 32) d->rounds = 1;
     d->capacity = capacity_keys;
-    d->sort_stream = static_cast<hipStream_t>(vrs_context_stream(ctx));
-    if (nccl_comm && !load_rccl(d->rccl)) {
-        delete d;
-        return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "no RCCL (librccl.so) could be bound in this process");
+    if (transport) {
+        d->tr = *transport;
+        d->has_transport = true;
     }
+    const char *shape = std::getenv("VRS_DIST_SHAPE");
+    d->byte_shape_only = shape && std::strcmp(shape, "byte") == 0;
+    d->sort_stream = static_cast<hipStream_t>(vrs_context_stream(ctx));
     const auto cleanup = [&](int code, const std::string &msg) {
         vrs_dist_destroy(d);
         return dfail(nullptr, code, msg);
     };
+    // the exchange stream and every event belong to the CONTEXT's device, whatever device the calling thread had current
+    if (hipSetDevice(d->device) != hipSuccess) return cleanup(VRS_ERROR_HIP, "hipSetDevice failed");
     if (hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking) != hipSuccess) return cleanup(VRS_ERROR_HIP, "hipStreamCreate failed");
     d->round_done.resize(static_cast<size_t>(d->rounds));
     for (auto &e : d->round_done)
@@ -167,26 +460,60 @@ int vrs_dist_create(vrs_context ctx, void *nccl_comm, int rank, int world, uint3
         return cleanup(VRS_ERROR_HIP, "hipEventCreate failed");
     const size_t kb = static_cast<size_t>(capacity_keys) * sizeof(uint32_t);
     const uint32_t W = vrs_workgroup_count(capacity_keys, 32);
+    const size_t cw = static_cast<size_t>(VRS_MSD_COUNT_WORDS) * 4;
     if (vrs_buffer_create(ctx, kb, &d->grouped) || vrs_buffer_create(ctx, kb, &d->recv) || vrs_buffer_create(ctx, kb, &d->scratch) ||
-        vrs_buffer_create(ctx, static_cast<size_t>(W) * 256 * 4, &d->hist) || vrs_buffer_create(ctx, 257 * 4, &d->prefix) ||
-        vrs_buffer_create(ctx, static_cast<size_t>(world) * 257 * 4, &d->table))
+        vrs_buffer_create(ctx, static_cast<size_t>(W) * 256 * 4, &d->hist) || vrs_buffer_create(ctx, kRowWords * 4, &d->row) ||
+        vrs_buffer_create(ctx, static_cast<size_t>(world) * kRowWords * 4, &d->table) || vrs_buffer_create(ctx, cw, &d->counts) ||
+        vrs_buffer_create(ctx, cw, &d->reduced) || vrs_buffer_create(ctx, cw, &d->round_counts))
         return cleanup(VRS_ERROR_OUT_OF_MEMORY, std::string("buffer allocation failed: ") + vrs_last_error(ctx));
-    d->host_table.resize(static_cast<size_t>(world) * 257);
+    d->host_table.resize(static_cast<size_t>(world) * kRowWords);
     *out = d;
+    return VRS_OK;
+}
+
+int vrs_dist_create(vrs_context ctx, void *nccl_comm, int rank, int world, uint32_t capacity_keys, int rounds, vrs_dist *out) {
+    if (!out) return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (world > 1 && !nccl_comm) return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "an RCCL communicator is required at world size > 1");
+    if (!nccl_comm) return vrs_dist_create_with_transport(ctx, nullptr, rank, world, capacity_keys, rounds, out);
+    auto *ep = new (std::nothrow) RcclEndpoint();
+    if (!ep) return dfail(nullptr, VRS_ERROR_OUT_OF_MEMORY, "host allocation failed");
+    if (!load_rccl(ep->rccl)) {
+        delete ep;
+        return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "no RCCL (librccl.so) could be bound in this process");
+    }
+    ep->comm = nccl_comm;
+    const vrs_dist_transport t{ep, rccl_all_gather, rccl_all_reduce, rccl_group_start, rccl_send, rccl_recv, rccl_group_end, rccl_error_string};
+    const int rc = vrs_dist_create_with_transport(ctx, &t, rank, world, capacity_keys, rounds, out);
+    if (rc != VRS_OK) {
+        delete ep;
+        return rc;
+    }
+    (*out)->rccl = ep;
     return VRS_OK;
 }
 
 int vrs_dist_destroy(vrs_dist d) {
     if (!d) return VRS_OK;
+    (void)hipSetDevice(d->device);
     if (d->comm_stream) (void)hipStreamSynchronize(d->comm_stream);
-    for (vrs_buffer b : {d->grouped, d->recv, d->scratch, d->hist, d->prefix, d->table})
+    for (vrs_buffer b : {d->grouped, d->recv, d->scratch, d->hist, d->row, d->table, d->counts, d->reduced, d->round_counts})
         if (b) (void)vrs_buffer_release(b);
     for (auto e : d->round_done)
         if (e) (void)hipEventDestroy(e);
     if (d->grouped_ready) (void)hipEventDestroy(d->grouped_ready);
     if (d->sorts_done) (void)hipEventDestroy(d->sorts_done);
     if (d->comm_stream) (void)hipStreamDestroy(d->comm_stream);
-    delete d;  // the RCCL handle stays mapped: the process may hold communicators made by it
+    delete d->rccl;  // the RCCL handle itself stays mapped: the process may hold communicators made by it
+    delete d;
+    return VRS_OK;
+}
+
+int vrs_dist_stats(vrs_dist d, uint64_t *hybrid_rounds, uint64_t *fallback_rounds, uint64_t *byte_shape_steps) {
+    if (!d) return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "dist is NULL");
+    if (hybrid_rounds) *hybrid_rounds = d->hybrid_rounds;
+    if (fallback_rounds) *fallback_rounds = d->fallback_rounds;
+    if (byte_shape_steps) *byte_shape_steps = d->byte_steps;
     return VRS_OK;
 }
 
@@ -194,114 +521,287 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
     if (!d || !out_keys || !out_count) return dfail(d, VRS_ERROR_INVALID_ARGUMENT, "dist, out_keys or out_count is NULL");
     *out_keys = nullptr;
     *out_count = 0;
-    if (n > d->capacity) return dfail(d, VRS_ERROR_INVALID_ARGUMENT, "shard larger than the capacity given at creation");
-    if (n && !keys) return dfail(d, VRS_ERROR_INVALID_ARGUMENT, "keys is NULL");
     vrs_context ctx = d->ctx;
     const int world = d->world, me = d->rank, R = d->rounds;
+    VRS_DHIP(d, hipSetDevice(d->device));
     uint32_t *grouped = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->grouped));
     uint32_t *recv = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->recv));
-    uint32_t *prefix = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->prefix));
+    uint32_t *row = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->row));
     uint32_t *table = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->table));
+    uint32_t *counts = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->counts));
+    uint32_t *reduced = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->reduced));
+
+    // What keeps THIS rank from taking part goes into its row; it still joins the collectives, and all ranks leave together.
+    int my_status = VRS_OK;
+    std::string my_error;
+    if (n > d->capacity) {
+        my_status = VRS_ERROR_INVALID_ARGUMENT;
+        my_error = "shard larger than the capacity given at creation";
+    } else if (n && !keys) {
+        my_status = VRS_ERROR_INVALID_ARGUMENT;
+        my_error = "keys is NULL";
+    }
+    const uint32_t n_eff = my_status == VRS_OK ? n : 0u;
 
     // the receive buffer may still be read by the sorts of the previous step's last round (they ran on the sort stream)
     VRS_DHIP(d, hipEventRecord(d->sorts_done, d->sort_stream));
     VRS_DHIP(d, hipStreamWaitEvent(d->comm_stream, d->sorts_done, 0));
 
-    // 1. local step: one radix pass on the top byte groups the shard so that every key range is a contiguous slice;
-    //    row 0 of the offset table is the exclusive prefix of the top-byte counts
-    if (n) {
-        vrs_push_constants pc{n, 24, vrs_workgroup_count(n, 32), 32};
-        VRS_D(d, vrs_multi_radixsort_histograms(ctx, keys, d->hist, &pc));
-        VRS_D(d, vrs_multi_radixsort(ctx, keys, d->grouped, d->hist, &pc));
-        VRS_D(d, vrs_multi_radixsort_digit_offsets_device(ctx, d->prefix));
-    } else {
-        VRS_DHIP(d, hipMemsetAsync(prefix, 0, 256 * 4, d->sort_stream));  // an empty shard: nothing was launched
+    // 1. local step.  Hybrid shape: counting read + first MSD pass (the shard grouped by the top byte of its key range).
+    //    The byte shape's contract partition pass, if the ranks settle on it, runs after the all-gather (the keys are
+    //    untouched until then).
+    const bool try_hybrid = !d->byte_shape_only;
+    bool partitioned = false;
+    VRS_DHIP(d, hipMemsetAsync(row, 0, kRowWords * 4, d->sort_stream));
+    VRS_DHIP(d, hipMemsetAsync(counts, 0, static_cast<size_t>(VRS_MSD_COUNT_WORDS) * 4, d->sort_stream));
+    if (try_hybrid && n_eff >= (1u << 16)) {
+        const int rc = vrs_msd_partition_u32(ctx, keys, d->grouped, d->counts, n_eff);
+        if (rc == VRS_OK) {
+            partitioned = true;
+            // the row's slice counts = words [16384, 16384 + 2048) of the counts
+            VRS_DHIP(d, hipMemcpyAsync(row, counts + 16384, kRowSlices * 4, hipMemcpyDeviceToDevice, d->sort_stream));
+            VRS_DHIP(d, hipMemcpyAsync(row + kRowShift, counts + VRS_MSD_SHIFT_WORD, 4, hipMemcpyDeviceToDevice, d->sort_stream));
+        } else {
+            my_status = rc;
+            my_error = std::string("vrs_msd_partition_u32: ") + vrs_last_error(ctx);
+        }
     }
-    VRS_DHIP(d, hipMemcpyAsync(prefix + 256, &n, 4, hipMemcpyHostToDevice, d->sort_stream));  // word 256 = shard size
-    VRS_DHIP(d, hipEventRecord(d->grouped_ready, d->sort_stream));
+    d->host_row_tail[0] = my_status == VRS_OK ? n : 0u;
+    d->host_row_tail[1] = static_cast<uint32_t>(my_status);
+    d->host_row_tail[2] = d->capacity;
+    VRS_DHIP(d, hipMemcpyAsync(row + kRowN, d->host_row_tail, 3 * 4, hipMemcpyHostToDevice, d->sort_stream));
+    uint32_t over_flag = 0;  // read back with the table below (my own flag word travels in the counts)
 
-    // 2. ONE small collective: every rank learns every rank's prefix row (world x 1 KiB), from which each derives the
-    //    same splitters, its send counts and its receive counts without further traffic
-    if (world > 1) {
-        VRS_DNCCL(d, d->rccl.AllGather(prefix, table, 257, kNcclUint32, d->comm, d->sort_stream));
+    // 2. the collectives: every rank learns every rank's row; the bucket histograms are summed
+    if (d->has_transport) {
+        VRS_DTR(d, "all-gather of the shard rows", d->tr.all_gather(d->tr.user, row, table, kRowWords, d->sort_stream));
+        if (try_hybrid) VRS_DTR(d, "all-reduce of the bucket histograms", d->tr.all_reduce(d->tr.user, counts, reduced, 16384, d->sort_stream));
     } else {
-        VRS_DHIP(d, hipMemcpyAsync(table, prefix, 257 * 4, hipMemcpyDeviceToDevice, d->sort_stream));
+        VRS_DHIP(d, hipMemcpyAsync(table, row, kRowWords * 4, hipMemcpyDeviceToDevice, d->sort_stream));
+        if (try_hybrid) VRS_DHIP(d, hipMemcpyAsync(reduced, counts, 16384 * 4, hipMemcpyDeviceToDevice, d->sort_stream));
     }
     VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, d->host_table.size() * 4, hipMemcpyDeviceToHost, d->sort_stream));
+    VRS_DHIP(d, hipMemcpyAsync(&over_flag, counts + VRS_MSD_SHIFT_WORD + 1, 4, hipMemcpyDeviceToHost, d->sort_stream));
     VRS_DHIP(d, hipStreamSynchronize(d->sort_stream));
-    std::vector<std::vector<uint64_t>> base(static_cast<size_t>(world), std::vector<uint64_t>(257));
-    uint64_t counts[256] = {};
+
+    // ---- from here on every rank holds the same table: every decision below is the same on all of them
+    uint32_t min_capacity = 0xFFFFFFFFu;
     uint64_t grand_total = 0;
     for (int q = 0; q < world; ++q) {
-        const uint32_t *row = &d->host_table[static_cast<size_t>(q) * 257];
-        for (int t = 0; t < 256; ++t) base[q][t] = row[t];
-        base[q][256] = row[256];  // shard size: the end of top byte 255
-        for (int t = 0; t < 256; ++t) counts[t] += base[q][t + 1] - base[q][t];
-        grand_total += row[256];
+        const uint32_t *r = &d->host_table[static_cast<size_t>(q) * kRowWords];
+        if (r[kRowStatus] != 0u) {
+            if (q == me) return dfail(d, my_status, my_error);
+            return dfail(d, VRS_ERROR_PEER, "rank " + std::to_string(q) + " could not take part in the step (its status " + std::to_string(r[kRowStatus]) + ")");
+        }
+        min_capacity = std::min(min_capacity, r[kRowCapacity]);
+        grand_total += r[kRowN];
     }
+    // hybrid shape iff every rank partitioned its shard with the same bucket shift of a 27..32-bit key range.  A rank whose
+    // keys reach above its probed range cannot say so in its row (the flag is written by the same kernels as the row) --
+    // it says so through the shift it would have needed: ranks then disagree or the range check fails ... the flag word
+    // itself decides on this rank only, so it is folded into the table by a second tiny all-gather when it is set anywhere.
+    bool hybrid = try_hybrid;
+    const uint32_t shift = d->host_table[kRowShift];
+    for (int q = 0; q < world && hybrid; ++q) {
+        const uint32_t *r = &d->host_table[static_cast<size_t>(q) * kRowWords];
+        if (r[kRowN] != 0u && (r[kRowN] < (1u << 16) || r[kRowShift] != shift)) hybrid = false;
+    }
+    if (hybrid && (shift < 13u || shift > 18u)) hybrid = false;
+    (void)partitioned;
+    // the out-of-range flag is rank-local knowledge: make it common (one word per rank) before deciding
+    if (try_hybrid) {
+        d->host_row_tail[3] = over_flag;
+        VRS_DHIP(d, hipMemcpyAsync(row, &d->host_row_tail[3], 4, hipMemcpyHostToDevice, d->sort_stream));
+        std::vector<uint32_t> flags(static_cast<size_t>(world), 0);
+        if (d->has_transport) {
+            VRS_DTR(d, "all-gather of the range flags", d->tr.all_gather(d->tr.user, row, table, 1, d->sort_stream));
+            VRS_DHIP(d, hipMemcpyAsync(flags.data(), table, static_cast<size_t>(world) * 4, hipMemcpyDeviceToHost, d->sort_stream));
+            VRS_DHIP(d, hipStreamSynchronize(d->sort_stream));
+        } else {
+            flags[0] = over_flag;
+        }
+        for (uint32_t f : flags)
+            if (f) hybrid = false;
+    }
+
+    // top-byte counts per rank (hybrid shape: sums over the eight slices; byte shape: filled in below) and their prefixes
+    std::vector<std::vector<uint64_t>> base(static_cast<size_t>(world), std::vector<uint64_t>(257, 0));
+    uint64_t byte_counts[256] = {};
+    if (!hybrid) {
+        // byte shape: contract partition pass by the top byte now (12 B/key), then a second all-gather of the real rows
+        d->byte_steps++;
+        uint32_t *prefix = row;  // row words [0, 256): exclusive prefix of my top-byte counts; [256]: my shard size
+        if (n_eff) {
+            vrs_push_constants pc{n_eff, 24, vrs_workgroup_count(n_eff, 32), 32};
+            int rc = vrs_multi_radixsort_histograms(ctx, keys, d->hist, &pc);
+            if (rc == VRS_OK) rc = vrs_multi_radixsort(ctx, keys, d->grouped, d->hist, &pc);
+            vrs_buffer_t_view: ;
+            if (rc == VRS_OK) {
+                vrs_buffer pv = nullptr;
+                rc = vrs_buffer_wrap(ctx, prefix, 256 * 4, &pv);
+                if (rc == VRS_OK) rc = vrs_multi_radixsort_digit_offsets_device(ctx, pv);
+                (void)vrs_buffer_release(pv);
+            }
+            if (rc != VRS_OK) {
+                my_status = rc;
+                my_error = std::string("top-byte partition pass: ") + vrs_last_error(ctx);
+            }
+        } else {
+            VRS_DHIP(d, hipMemsetAsync(prefix, 0, 256 * 4, d->sort_stream));
+        }
+        d->host_row_tail[0] = n_eff;
+        d->host_row_tail[1] = static_cast<uint32_t>(my_status);
+        VRS_DHIP(d, hipMemcpyAsync(row + 256, d->host_row_tail, 2 * 4, hipMemcpyHostToDevice, d->sort_stream));
+        if (d->has_transport) {
+            VRS_DTR(d, "all-gather of the top-byte prefixes", d->tr.all_gather(d->tr.user, row, table, 258, d->sort_stream));
+        } else {
+            VRS_DHIP(d, hipMemcpyAsync(table, row, 258 * 4, hipMemcpyDeviceToDevice, d->sort_stream));
+        }
+        VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, static_cast<size_t>(world) * 258 * 4, hipMemcpyDeviceToHost, d->sort_stream));
+        VRS_DHIP(d, hipStreamSynchronize(d->sort_stream));
+        for (int q = 0; q < world; ++q) {
+            const uint32_t *r = &d->host_table[static_cast<size_t>(q) * 258];
+            if (r[257] != 0u) {
+                if (q == me) return dfail(d, my_status, my_error);
+                return dfail(d, VRS_ERROR_PEER, "rank " + std::to_string(q) + " failed in its partition pass (status " + std::to_string(r[257]) + ")");
+            }
+            for (int t = 0; t < 256; ++t) base[static_cast<size_t>(q)][static_cast<size_t>(t)] = r[t];
+            base[static_cast<size_t>(q)][256] = r[256];
+            for (int t = 0; t < 256; ++t) byte_counts[t] += base[static_cast<size_t>(q)][static_cast<size_t>(t) + 1] - base[static_cast<size_t>(q)][static_cast<size_t>(t)];
+        }
+    } else {
+        for (int q = 0; q < world; ++q) {
+            const uint32_t *r = &d->host_table[static_cast<size_t>(q) * kRowWords];
+            uint64_t run = 0;
+            for (int t = 0; t < 256; ++t) {
+                base[static_cast<size_t>(q)][static_cast<size_t>(t)] = run;
+                uint64_t c = 0;
+                for (int g = 0; g < 8; ++g) c += r[g * 256 + t];
+                run += c;
+                byte_counts[t] += c;
+            }
+            base[static_cast<size_t>(q)][256] = run;  // == the shard size
+        }
+    }
+
     const int P = world * R;  // part q * R + r = rank q, round r
     std::vector<uint32_t> parts(static_cast<size_t>(P) + 1);
-    int rc = vrs_dist_plan_splitters(counts, P, parts.data());
+    int rc = vrs_dist_plan_splitters(byte_counts, P, parts.data());
     if (rc) return rc;
-    // how many keys a rank receives; byte-aligned cuts cannot balance keys whose top bytes are too concentrated
+    // how many keys every rank receives; byte-aligned cuts cannot balance keys whose top bytes are too concentrated.
+    // The same verdict on every rank: the gathered capacities, not this rank's own, decide.
     uint64_t worst = 0;
     for (int q = 0; q < world; ++q) {
         uint64_t s = 0;
-        for (uint32_t t = parts[static_cast<size_t>(q) * R]; t < parts[static_cast<size_t>(q + 1) * R]; ++t) s += counts[t];
+        for (uint32_t t = parts[static_cast<size_t>(q) * R]; t < parts[static_cast<size_t>(q + 1) * R]; ++t) s += byte_counts[t];
         worst = std::max(worst, s);
     }
     const double ideal = std::max(static_cast<double>(grand_total) / world, 1.0);
-    if (static_cast<double>(worst) > d->max_imbalance * ideal || worst > d->capacity)
+    if (static_cast<double>(worst) > d->max_imbalance * ideal || worst > min_capacity)
         return dfail(d, VRS_ERROR_UNBALANCED,
                      "top bytes too concentrated for byte-aligned key ranges (small or clustered keys): use the sampled-splitter "
-                     "path of vkradixsort_amd.distributed.RangeShardedSort, or a larger capacity");
+                     "path of vkradixsort_amd.distributed.RangeShardedSort, or a larger capacity (the smallest capacity of all ranks counts)");
 
-    // what I receive in round r from source s, and where it lands: rounds ascending, sources ascending
+    // what I receive in round r: hybrid shape one message per (top byte, source) in that order -- the round's keys land
+    // grouped by top byte; byte shape one message per source.  round_off: where round r starts in the receive buffer.
     std::vector<uint64_t> round_off(static_cast<size_t>(R) + 1, 0);
-    std::vector<std::vector<uint64_t>> recv_rs(static_cast<size_t>(R), std::vector<uint64_t>(static_cast<size_t>(world)));
     for (int r = 0; r < R; ++r) {
         const uint32_t lo = parts[static_cast<size_t>(me) * R + r], hi = parts[static_cast<size_t>(me) * R + r + 1];
         uint64_t tot = 0;
-        for (int s = 0; s < world; ++s) {
-            recv_rs[r][s] = base[s][hi] - base[s][lo];
-            tot += recv_rs[r][s];
-        }
-        round_off[r + 1] = round_off[r] + tot;
+        for (int s = 0; s < world; ++s) tot += base[static_cast<size_t>(s)][hi] - base[static_cast<size_t>(s)][lo];
+        round_off[static_cast<size_t>(r) + 1] = round_off[static_cast<size_t>(r)] + tot;
     }
-    const uint64_t total = round_off[R];
-    if (total > d->capacity) return dfail(d, VRS_ERROR_UNBALANCED, "this rank's key range holds more keys than the capacity");
+    const uint64_t total = round_off[static_cast<size_t>(R)];  // <= worst <= min_capacity <= my capacity
 
-    // 3. exchange, round by round on the exchange stream: grouped send/recv with every peer; my own slice is a device copy
+    // 3. exchange, round by round on the exchange stream: grouped send/recv with every peer; my own slices are device copies
+    VRS_DHIP(d, hipEventRecord(d->grouped_ready, d->sort_stream));
     VRS_DHIP(d, hipStreamWaitEvent(d->comm_stream, d->grouped_ready, 0));
     for (int r = 0; r < R; ++r) {
-        if (world > 1) VRS_DNCCL(d, d->rccl.GroupStart());
-        uint64_t off = round_off[r];
-        for (int s = 0; s < world; ++s) {
-            const uint64_t cnt = recv_rs[r][s];
-            if (cnt && s != me) VRS_DNCCL(d, d->rccl.Recv(recv + off, cnt, kNcclUint32, s, d->comm, d->comm_stream));
-            if (cnt && s == me) {
-                const uint64_t a = base[me][parts[static_cast<size_t>(me) * R + r]];
-                VRS_DHIP(d, hipMemcpyAsync(recv + off, grouped + a, cnt * 4, hipMemcpyDeviceToDevice, d->comm_stream));
+        int failed = 0;
+        std::string what;
+        const auto tr = [&](const char *w, int code) {
+            if (code != 0 && failed == 0) {
+                failed = code;
+                what = w;
             }
-            off += cnt;
+        };
+        if (d->has_transport) tr("group start", d->tr.group_start(d->tr.user));
+        const uint32_t lo = parts[static_cast<size_t>(me) * R + r], hi = parts[static_cast<size_t>(me) * R + r + 1];
+        uint64_t off = round_off[static_cast<size_t>(r)];
+        hipError_t he = hipSuccess;
+        const auto land = [&](int s, uint32_t t0, uint32_t t1) {  // source s's keys with top bytes [t0, t1) land at `off`
+            const uint64_t a = base[static_cast<size_t>(s)][t0], b = base[static_cast<size_t>(s)][t1];
+            if (b > a) {
+                if (s == me) {
+                    if (he == hipSuccess) he = hipMemcpyAsync(recv + off, grouped + a, (b - a) * 4, hipMemcpyDeviceToDevice, d->comm_stream);
+                } else if (failed == 0) {
+                    tr("recv", d->tr.recv(d->tr.user, recv + off, b - a, s, d->comm_stream));
+                }
+            }
+            off += b - a;
+        };
+        if (hybrid) {
+            for (uint32_t t = lo; t < hi; ++t)
+                for (int s = 0; s < world; ++s) land(s, t, t + 1);
+        } else {
+            for (int s = 0; s < world; ++s) land(s, lo, hi);
         }
-        for (int dst = 0; dst < world; ++dst) {
+        for (int dst = 0; dst < world && failed == 0; ++dst) {
             if (dst == me) continue;
-            const uint64_t a = base[me][parts[static_cast<size_t>(dst) * R + r]], b = base[me][parts[static_cast<size_t>(dst) * R + r + 1]];
-            if (b > a) VRS_DNCCL(d, d->rccl.Send(grouped + a, b - a, kNcclUint32, dst, d->comm, d->comm_stream));
+            const uint32_t dlo = parts[static_cast<size_t>(dst) * R + r], dhi = parts[static_cast<size_t>(dst) * R + r + 1];
+            if (hybrid) {
+                for (uint32_t t = dlo; t < dhi && failed == 0; ++t) {
+                    const uint64_t a = base[static_cast<size_t>(me)][t], b = base[static_cast<size_t>(me)][t + 1];
+                    if (b > a) tr("send", d->tr.send(d->tr.user, grouped + a, b - a, dst, d->comm_stream));
+                }
+            } else {
+                const uint64_t a = base[static_cast<size_t>(me)][dlo], b = base[static_cast<size_t>(me)][dhi];
+                if (b > a) tr("send", d->tr.send(d->tr.user, grouped + a, b - a, dst, d->comm_stream));
+            }
         }
-        if (world > 1) VRS_DNCCL(d, d->rccl.GroupEnd());
+        // a group that was opened is closed whatever happened inside it
+        if (d->has_transport) tr("group end", d->tr.group_end(d->tr.user));
+        if (failed != 0) return dfail(d, VRS_ERROR_HIP, transport_error(d, ("exchange round " + std::to_string(r) + ", " + what).c_str(), failed));
+        if (he != hipSuccess) return dfail(d, VRS_ERROR_HIP, std::string("device copy of this rank's own slice: ") + hipGetErrorString(he));
         VRS_DHIP(d, hipEventRecord(d->round_done[static_cast<size_t>(r)], d->comm_stream));
     }
-    // 4. round r's keys are sorted (the library's four-pass sort) while the later rounds are still on the wire; the
-    //    sub-ranges are disjoint and ascending, so their concatenation is the sorted range: nothing to merge
+
+    // 4. round r's keys are finished while the later rounds are still on the wire; the sub-ranges are disjoint and ascending,
+    //    so their concatenation is the sorted range: nothing to merge.  Hybrid shape: the result of a round is built in the
+    //    scratch buffer (second MSD pass: receive buffer -> scratch; local sort in place there) and copied back.
+    uint32_t *scratch = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->scratch));
+    uint32_t *round_counts = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->round_counts));
     for (int r = 0; r < R; ++r) {
-        const uint64_t cnt = round_off[r + 1] - round_off[r];
+        const uint64_t cnt = round_off[static_cast<size_t>(r) + 1] - round_off[static_cast<size_t>(r)];
         VRS_DHIP(d, hipStreamWaitEvent(d->sort_stream, d->round_done[static_cast<size_t>(r)], 0));
         if (!cnt) continue;
-        vrs_buffer view = nullptr;
-        VRS_D(d, vrs_buffer_wrap(ctx, recv + round_off[r], cnt * 4, &view));
-        rc = vrs_sort_keys_u32(ctx, view, d->scratch, static_cast<uint32_t>(cnt));
+        vrs_buffer view = nullptr, sview = nullptr;
+        VRS_D(d, vrs_buffer_wrap(ctx, recv + round_off[static_cast<size_t>(r)], cnt * 4, &view));
+        bool done = false;
+        if (hybrid && cnt >= (1u << 16)) {
+            // the bucket histogram of exactly this round's keys: the all-reduced one, masked to the round's top bytes
+            const uint32_t lo = parts[static_cast<size_t>(me) * R + r], hi = parts[static_cast<size_t>(me) * R + r + 1];
+            VRS_DHIP(d, hipMemsetAsync(round_counts, 0, static_cast<size_t>(VRS_MSD_COUNT_WORDS) * 4, d->sort_stream));
+            VRS_DHIP(d, hipMemcpyAsync(round_counts + lo * 64u, reduced + lo * 64u, static_cast<size_t>(hi - lo) * 64 * 4, hipMemcpyDeviceToDevice, d->sort_stream));
+            VRS_DHIP(d, hipMemcpyAsync(round_counts + VRS_MSD_SHIFT_WORD, counts + VRS_MSD_SHIFT_WORD, 4, hipMemcpyDeviceToDevice, d->sort_stream));
+            rc = vrs_buffer_wrap(ctx, scratch + round_off[static_cast<size_t>(r)], cnt * 4, &sview);
+            if (rc == VRS_OK) rc = vrs_msd_finish_u32(ctx, view, sview, d->round_counts, static_cast<uint32_t>(cnt));
+            int took = 0;
+            if (rc == VRS_OK) rc = vrs_msd_finish_status(ctx, &took);  // waits for the plan's head (the counts, not the sort)
+            if (rc == VRS_OK && took) {
+                VRS_DHIP(d, hipMemcpyAsync(recv + round_off[static_cast<size_t>(r)], scratch + round_off[static_cast<size_t>(r)], cnt * 4, hipMemcpyDeviceToDevice, d->sort_stream));
+                d->hybrid_rounds++;
+                done = true;
+            } else if (rc == VRS_OK) {
+                d->fallback_rounds++;  // the plan refused (a bucket beyond the local sort's capacity ...): the keys are still in the receive buffer
+            }
+            if (sview) (void)vrs_buffer_release(sview);
+            if (rc != VRS_OK) {
+                (void)vrs_buffer_release(view);
+                return dfail_ctx(d, rc, "vrs_msd_finish_u32 (received sub-range)");
+            }
+        }
+        if (!done) rc = vrs_sort_keys_u32(ctx, view, d->scratch, static_cast<uint32_t>(cnt));
         (void)vrs_buffer_release(view);
         if (rc) return dfail_ctx(d, rc, "vrs_sort_keys_u32 (received sub-range)");
     }

@@ -163,7 +163,8 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
 constexpr uint32_t kMsdBucketCount = 1u << 14;
 struct MsdPlan {
     uint32_t shift;                       // bucket = key >> shift (the top 14 bits of the key range)
-    uint32_t pad[3];
+    uint32_t ok;                          // 1 = the plan took the hybrid form; 0 = a second MSD pass / local sort enqueued before the plan was known leaves at once
+    uint32_t pad[2];
     uint32_t xcd_tiles[8][33];            // XCD x walks top-byte buckets x, x+8, ...: exclusive prefix of their tile counts
     uint32_t base[kMsdBucketCount + 1];   // exclusive prefix of the bucket sizes = where bucket b starts when sorted
 };
@@ -202,6 +203,7 @@ hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, const MsdPl
 hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *values, const MsdPlan *msd, uint32_t max_bucket,
                                  LaunchEvents ev = {});
 // keys the local sort of one bucket can hold (the plan refuses the hybrid form when a bucket has more)
+uint32_t msd_local_capacity_small();  // bare uint32 keys, 256-thread workgroup: 7165
 uint32_t msd_local_capacity(bool pairs_or_wide);  // pairs and 64-bit keys: 6656, uint32 keys: 14333
 
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups

@@ -1649,6 +1649,7 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
     if (tid == 0) {
         counts[kMsdOverWord] = 0;  // re-armed for the next sort (the shift word is rewritten by every counting read)
         msd->shift = shift;
+        msd->ok = s_ok;
         plan_a->head.first_abnormal = 4;
         plan_a->head.msd_shift_a = shift + kMsdSubBits;  // the first MSD pass's digit: the top 8 bits of the range
         plan_lsd->head.msd_ok = s_ok;
@@ -1678,7 +1679,7 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
     __shared__ ChunkSmem<K, ITEMS, 8, PAIRS> sm;
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
     const uint32_t *pt = msd->xcd_tiles[x];
-    if (j >= pt[32]) return;  // uniform per workgroup
+    if (msd->ok == 0u || j >= pt[32]) return;  // uniform per workgroup (enqueued before the plan was known: it may have said no)
     uint32_t k = 0;           // the bucket whose tiles contain j: largest k with pt[k] <= j
 #pragma unroll
     for (uint32_t step = 16; step >= 1; step >>= 1)
@@ -2109,6 +2110,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_local_sort_keys_kernel(uint32_
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * kLeanMaxVec + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
     __shared__ uint32_t s_tmp[32];
+    if (msd->ok == 0u) return;  // enqueued before the plan was known, and the plan refused the hybrid form
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
     if (n == 0 || mis + n > THREADS * 4u * kLeanMaxVec) return;  // uniform; above the capacity cannot happen (the plan would have refused)
@@ -2136,6 +2138,7 @@ __global__ __launch_bounds__(kLocalPairThreads, 4) void msd_local_sort_pairs_ker
     __shared__ uint32_t s_vals[kLocalCap];
     __shared__ uint32_t s_hist[WAVES << 9];
     __shared__ uint32_t s_tmp[1 + WAVES];
+    if (msd->ok == 0u) return;
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     if (n == 0 || n > kLocalCap) return;
     uint32_t *bucket = keys + begin, *bvals = values + begin;
@@ -2204,6 +2207,7 @@ __global__ __launch_bounds__(kLocalPairThreads, 4) void msd_local_sort_u64_kerne
     __shared__ uint64_t s_keys[kLocalCap];
     __shared__ uint32_t s_hist[WAVES << 9];
     __shared__ uint32_t s_tmp[1 + WAVES];
+    if (msd->ok == 0u) return;
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     if (n == 0 || n > kLocalCap) return;
     const uint32_t passes = (msd->shift + 8u) / 9u;
@@ -2641,6 +2645,7 @@ hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *v
     return hipGetLastError();
 }
 
+uint32_t msd_local_capacity_small() { return kLeanCap; }
 uint32_t msd_local_capacity(bool pairs_or_wide) { return pairs_or_wide ? kLocalCap : kLeanBigCap; }
 
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
