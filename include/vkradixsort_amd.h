@@ -34,6 +34,7 @@ typedef enum vrs_status {
     VRS_ERROR_NO_DEVICE = 3,    /* no gfx950-capable device / bad ordinal */
     VRS_ERROR_OUT_OF_MEMORY = 4,
     VRS_ERROR_UNBALANCED = 5,   /* vrs_dist_sort_keys_u32: key ranges cut at top-byte boundaries cannot be balanced */
+    VRS_ERROR_PEER = 7,         /* vrs_dist_sort_keys_u32: another rank could not take part; every rank left the step together */
     VRS_ERROR_TIMEOUT = 6       /* a one-call sort's plan did not reach the host within VRS_TUNE_PLAN_WAIT_MS (the stream is held
                                    up by earlier work); the sort is still queued, vrs_sort_settle may be called again */
 } vrs_status;
@@ -255,33 +256,73 @@ int vrs_transform_keys(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, 
 int vrs_verify_keys_u32(vrs_context ctx, vrs_buffer keys, uint32_t num_elements, uint64_t *descents, uint64_t *key_sum,
                         uint64_t *key_mix);
 
-/* ---- multi-GPU: key-range sharded sort over RCCL, one process per GPU (BASELINE.json configs[4]) ---- */
+/* ---- multi-GPU: key-range sharded sort, one rank per GPU (BASELINE.json configs[4]) ---- */
 /*
  * No reference counterpart (VkRadixSort is single-GPU); north_star defines the path: shard by key range across the
- * GPUs of one node, ONE all-to-all over xGMI between the local step and the local sorts.  A step on rank g:
- *   1. top-byte partition pass of the shard (the two stages above with g_shift = 24): key ranges become slices;
- *   2. one all-gather of every rank's 256 top-byte counts; every rank derives the same byte-aligned splitters
- *      (vrs_dist_plan_splitters), its send and its receive counts;
- *   3. `rounds` rounds of grouped ncclSend / ncclRecv on a second stream (round r = the r-th sub-range of every rank);
- *   4. vrs_sort_keys_u32 of round r's keys while the later rounds are on the wire.  The sub-ranges are disjoint and
- *      ascending: their concatenation in the receive buffer is rank g's range in ascending order.
- * RCCL is bound at run time (dlopen): `nccl_comm` is an ncclComm_t of the RCCL copy already in the process; it may be
- * NULL at world size 1 (every transfer is then a device copy).  Keys whose top bytes are too concentrated for
- * byte-aligned ranges (more than 15 % over the even share) return VRS_ERROR_UNBALANCED; the Python orchestration
- * (vkradixsort_amd/distributed.py) adds sampled splitters and a gather path for small totals on top of the same
- * entry points.  Blocking only for the count exchange; the exchange and the sorts complete on the context's stream.
+ * GPUs of one node, ONE all-to-all over xGMI between the local step and the local sorts.  A step on rank g, in its
+ * default (hybrid) shape -- the single-GPU hybrid sort with the exchange between its two MSD passes, 28 B/key per GPU:
+ *   1. vrs_msd_partition_u32 of the shard: one counting read + the first MSD pass -- the shard grouped by the top byte;
+ *   2. one all-gather of every rank's row (top-byte counts, shard size, bucket shift, status) and one all-reduce of the
+ *      16384-bin bucket histograms; every rank derives the same byte-aligned splitters (vrs_dist_plan_splitters), its
+ *      send and receive counts and where every message lands;
+ *   3. `rounds` rounds of grouped send / recv on a second stream (round r = the r-th sub-range of every rank), one
+ *      message per (sender, top byte) landing in top-byte order;
+ *   4. vrs_msd_finish_u32 (second MSD pass + LDS-local sort) of round r's keys while the later rounds are on the wire.
+ *      The sub-ranges are disjoint and ascending: their concatenation is rank g's range in ascending order.
+ * Key ranges below 27 bits, shards below 2^16 keys or ranks that probed different key ranges make ALL ranks take the byte
+ * shape instead (contract partition pass by the top byte, one message per (sender, round), vrs_sort_keys_u32 per received
+ * sub-range; also forced by the environment variable VRS_DIST_SHAPE=byte, which must then be set on every rank).
+ * Every decision to leave a step is taken by all ranks from the same gathered rows: a rank that cannot take part (shard
+ * above its capacity, a failed local stage) says so in its row, still joins the collectives, and all ranks return together
+ * (that rank its own error, the others VRS_ERROR_PEER).  Keys whose top bytes are too concentrated for byte-aligned ranges
+ * (more than 15 % over the even share, or more than the SMALLEST capacity of all ranks) return VRS_ERROR_UNBALANCED on
+ * every rank; the Python orchestration (vkradixsort_amd/distributed.py) adds sampled splitters and a gather path for small
+ * totals on top of the same entry points.  Blocking for the count exchange and, per round, for the round's plan; the
+ * exchange and the sorts complete on the context's stream.
+ *
+ * The wire is a table of functions.  vrs_dist_create binds RCCL at run time (dlopen): `nccl_comm` is an ncclComm_t of the
+ * RCCL copy already in the process; NULL at world size 1 (every transfer is then a device copy).
+ * vrs_dist_create_with_transport takes any table: every function returns 0 on success, counts are in uint32 words, `peer`
+ * is a rank, `hip_stream` the stream the operation is ordered on; all_gather / all_reduce (sum) are called by every rank
+ * with equal counts (recv of all_gather: world * words, in rank order), send / recv only between group_start and
+ * group_end, matched in posting order per pair of ranks (the RCCL contract).
+ * vrs_dist_loopback_*: an in-process transport -- the ranks are host THREADS of one process sharing a hub, every transfer a
+ * device-to-device copy ordered by events (same GPU or peer GPUs of the process).  One process driving several GPUs can
+ * use it instead of RCCL; the tests use it to run two ranks on one GPU.
  */
 typedef struct vrs_dist_t *vrs_dist;
+typedef struct vrs_dist_transport {
+    void *user; /* handed back as the first argument of every call */
+    int (*all_gather)(void *user, const void *send, void *recv, size_t words, void *hip_stream);
+    int (*all_reduce)(void *user, const void *send, void *recv, size_t words, void *hip_stream);
+    int (*group_start)(void *user);
+    int (*send)(void *user, const void *buf, size_t words, int peer, void *hip_stream);
+    int (*recv)(void *user, void *buf, size_t words, int peer, void *hip_stream);
+    int (*group_end)(void *user);
+    const char *(*error_string)(void *user, int code); /* may be NULL */
+} vrs_dist_transport;
 int vrs_dist_create(vrs_context ctx, void *nccl_comm, int rank, int world, uint32_t capacity_keys, int rounds,
                     vrs_dist *out_dist);
+/* capacity_keys: shard size and receive capacity (the smallest capacity of all ranks bounds every rank's range);
+ * rounds: 1 .. 32 / world (clamped).  The table is copied; `user` must outlive the vrs_dist. */
+int vrs_dist_create_with_transport(vrs_context ctx, const vrs_dist_transport *transport, int rank, int world,
+                                   uint32_t capacity_keys, int rounds, vrs_dist *out_dist);
 int vrs_dist_destroy(vrs_dist dist);
-/* keys: this rank's shard (num_elements <= capacity_keys).  *out_keys: the library-owned receive buffer holding this
+/* keys: this rank's shard (num_elements <= capacity_keys; untouched).  *out_keys: a library-owned buffer holding this
  * rank's key range ascending in its first *out_count keys (valid until the next step or vrs_dist_destroy). */
 int vrs_dist_sort_keys_u32(vrs_dist dist, vrs_buffer keys, uint32_t num_elements, vrs_buffer *out_keys,
                            uint32_t *out_count);
 /* bounds[0] = 0 <= ... <= bounds[parts] = 256: part q owns top bytes [bounds[q], bounds[q+1]); host only */
 int vrs_dist_plan_splitters(const uint64_t *counts256, int parts, uint32_t *bounds);
 const char *vrs_dist_last_error(vrs_dist dist);
+/* cumulative: received sub-ranges finished in the hybrid shape / sorted by vrs_sort_keys_u32 after a refused plan; steps
+ * that took the byte shape.  Any pointer may be NULL. */
+int vrs_dist_stats(vrs_dist dist, uint64_t *hybrid_rounds, uint64_t *fallback_rounds, uint64_t *byte_shape_steps);
+typedef struct vrs_dist_loopback_t *vrs_dist_loopback;
+int vrs_dist_loopback_create(int world, vrs_dist_loopback *out_hub);
+/* fills *out with rank `rank`'s end of the hub; call it on the thread that drives the rank, its device current */
+int vrs_dist_loopback_transport(vrs_dist_loopback hub, int rank, vrs_dist_transport *out);
+int vrs_dist_loopback_destroy(vrs_dist_loopback hub);
 
 /* ---- measurement (no reference counterpart) ------------------------- */
 

@@ -1,0 +1,160 @@
+"""The multi-GPU step behind the C ABI (vrs_dist_*) with TWO ranks on the one GPU of the box: each rank is a host thread
+with its own context / stream, the wire is the library's in-process loopback transport (device copies ordered by events).
+This runs the rank-to-rank bookkeeping of vrs_dist.hip -- who sends what where, in which round, landing at which offset --
+with non-zero peer counts, which world size 1 cannot: the concatenation of the ranks' outputs must be std::sort of the
+concatenation of their shards, bit for bit.  (BASELINE.json configs[4]; no reference counterpart: VkRadixSort is single-GPU.)"""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+import vkradixsort_amd as vrs
+from vkradixsort_amd import capi
+
+pytestmark = pytest.mark.gpu
+S = vrs.Buffer.BufferSettings
+
+
+def keys_of(kind, n, seed):
+    rs = np.random.RandomState(seed)
+    k = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    if kind == "28bit":
+        k >>= np.uint32(4)  # the reference's own test keys (MultiRadixSort.cpp:121-133)
+    if kind == "16bit":
+        k >>= np.uint32(16)  # everything under top byte 0: no byte-aligned cut can balance two ranks
+    if kind == "clustered":  # three quarters of the keys under ONE top byte
+        m = rs.rand(n) < 0.75
+        k[m] = (k[m] & np.uint32(0x00FFFFFF)) | np.uint32(0x40000000)
+    if kind == "hot_bucket":  # one top-14-bit bucket far beyond the local sort's capacity: that round's plan must refuse
+        k[: n // 10] = (k[: n // 10] & np.uint32(0x3FFFF)) | np.uint32(0x9ABC0000 & ~0x3FFFF)
+    return k
+
+
+def run_ranks(shards, rounds, capacity=None, world=None, env_shape=None):
+    """One step with len(shards) ranks as threads; returns [(rc, sorted range or error text, stats)] per rank."""
+    world = world or len(shards)
+    lib = capi.load_library()
+    hub = ctypes.c_void_p()
+    assert lib.vrs_dist_loopback_create(world, ctypes.byref(hub)) == 0
+    cap = capacity or int(max(s.size for s in shards) * 1.3) + 70000
+    results = [None] * world
+    errors = []
+
+    def rank_main(r):
+        try:
+            with vrs.GPUContext(0) as gpu:
+                tr = capi.DistTransport()
+                assert lib.vrs_dist_loopback_transport(hub, r, ctypes.byref(tr)) == 0
+                d = ctypes.c_void_p()
+                rc = lib.vrs_dist_create_with_transport(gpu.handle, ctypes.byref(tr), r, world, cap, rounds, ctypes.byref(d))
+                assert rc == 0, lib.vrs_dist_last_error(None)
+                keys = shards[r]
+                kb = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * max(keys.size, 1)), keys) if keys.size else vrs.Buffer(gpu, S(16))
+                out_buf, out_n = ctypes.c_void_p(), ctypes.c_uint32()
+                outs = []
+                for _ in range(2):  # twice: every buffer and event of the step is reused
+                    rc = lib.vrs_dist_sort_keys_u32(d, kb.handle, keys.size, ctypes.byref(out_buf), ctypes.byref(out_n))
+                    if rc != 0:
+                        outs.append((rc, lib.vrs_dist_last_error(d).decode()))
+                        continue
+                    gpu.waitIdle()
+                    out = np.empty(out_n.value, np.uint32)
+                    if out.size:
+                        gpu.check(lib.vrs_buffer_download(gpu.handle, out_buf, out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+                    outs.append((0, out))
+                st = [ctypes.c_uint64() for _ in range(3)]
+                lib.vrs_dist_stats(d, *[ctypes.byref(x) for x in st])
+                results[r] = (outs, tuple(x.value for x in st))
+                kb.release()
+                lib.vrs_dist_destroy(d)
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    hung = [t for t in threads if t.is_alive()]
+    assert not hung, "a rank is still inside the step: the ranks did not leave it together"
+    lib.vrs_dist_loopback_destroy(hub)
+    assert not errors, errors
+    return results
+
+
+def check_sorted_ranges(shards, results):
+    allkeys = np.sort(np.concatenate(shards))
+    for step in range(2):
+        outs = [results[r][0][step] for r in range(len(shards))]
+        assert all(rc == 0 for rc, _ in outs), outs
+        got = np.concatenate([o for _, o in outs])
+        assert np.array_equal(got, allkeys)
+        sizes = [o.size for _, o in outs]
+        assert max(sizes) <= 1.15 * allkeys.size / len(shards) + 1
+
+
+@pytest.mark.parametrize("rounds", [1, 4])
+@pytest.mark.parametrize("kind", ["uniform", "28bit"])
+def test_two_ranks_hybrid_shape(kind, rounds):
+    """Every received sub-range is finished by the second MSD pass + local sort (no rank sorts from scratch)."""
+    shards = [keys_of(kind, 3000017, 1000), keys_of(kind, 2600001, 1001)]
+    res = run_ranks(shards, rounds)
+    check_sorted_ranges(shards, res)
+    for outs, (hybrid_rounds, fallback_rounds, byte_steps) in res:
+        assert byte_steps == 0 and fallback_rounds == 0 and hybrid_rounds == 2 * rounds
+
+
+@pytest.mark.parametrize("rounds", [1, 4])
+def test_two_ranks_one_empty_shard(rounds):
+    shards = [keys_of("uniform", 2500003, 7), np.zeros(0, np.uint32)]
+    res = run_ranks(shards, rounds, capacity=2000000 + 900000)
+    check_sorted_ranges(shards, res)
+    assert all(st[2] == 0 for _, st in res)  # still the hybrid shape: the empty shard has nothing to say about the key range
+
+
+def test_two_ranks_a_refused_round_is_sorted_from_scratch():
+    shards = [keys_of("hot_bucket", 3000000, 21), keys_of("uniform", 3000000, 22)]
+    res = run_ranks(shards, 2, capacity=5000000)
+    check_sorted_ranges(shards, res)
+    assert sum(st[1] for _, st in res) >= 2  # the round with the hot bucket, in both steps, on the rank that owns it
+
+
+@pytest.mark.parametrize("rounds", [1, 4])
+def test_two_ranks_byte_shape(rounds, monkeypatch):
+    monkeypatch.setenv("VRS_DIST_SHAPE", "byte")
+    shards = [keys_of("uniform", 1200007, 3), keys_of("uniform", 999999, 4)]
+    res = run_ranks(shards, rounds)
+    check_sorted_ranges(shards, res)
+    assert all(st[2] == 2 and st[0] == 0 for _, st in res)
+
+
+def test_two_ranks_small_shards_take_the_byte_shape_together():
+    shards = [keys_of("uniform", 40000, 5), keys_of("uniform", 3000000, 6)]  # rank 0 is below the partition's minimum
+    res = run_ranks(shards, 2, capacity=3200000)
+    check_sorted_ranges(shards, res)
+    assert all(st[2] == 2 for _, st in res)
+
+
+def test_three_ranks():
+    shards = [keys_of("uniform", 1500000 + 777 * r, 60 + r) for r in range(3)]
+    res = run_ranks(shards, 2)
+    check_sorted_ranges(shards, res)
+
+
+@pytest.mark.parametrize("kind", ["16bit", "clustered"])
+def test_two_ranks_unbalanced_key_ranges_leave_together(kind):
+    """Top bytes too concentrated for byte-aligned cuts: VRS_ERROR_UNBALANCED on BOTH ranks, nobody hangs."""
+    shards = [keys_of(kind, 2000000, 31), keys_of(kind, 2000000, 32)]
+    res = run_ranks(shards, 2)
+    for outs, _ in res:
+        assert all(rc == capi.VRS_ERROR_UNBALANCED for rc, _ in outs), outs
+
+
+def test_two_ranks_a_shard_above_its_capacity_fails_on_both():
+    """Rank 1's shard exceeds the capacity it was created with: it reports INVALID_ARGUMENT, rank 0 PEER -- after both took
+    part in the same collectives."""
+    shards = [keys_of("uniform", 1000000, 41), keys_of("uniform", 1500000, 42)]
+    res = run_ranks(shards, 1, capacity=1200000)
+    assert all(rc == capi.VRS_ERROR_PEER for rc, _ in res[0][0]), res[0][0]
+    assert all(rc == capi.VRS_ERROR_INVALID_ARGUMENT for rc, _ in res[1][0]), res[1][0]

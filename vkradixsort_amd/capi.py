@@ -19,6 +19,7 @@ VRS_ERROR_NO_DEVICE = 3
 VRS_ERROR_OUT_OF_MEMORY = 4
 VRS_ERROR_UNBALANCED = 5
 VRS_ERROR_TIMEOUT = 6
+VRS_ERROR_PEER = 7
 
 VRS_KERNEL_HISTOGRAM = 0
 VRS_KERNEL_PREFIX = 1
@@ -72,6 +73,15 @@ class VrsError(RuntimeError):
         self.message = message
 
 
+class DistTransport(ctypes.Structure):
+    """vrs_dist_transport: the wire of the multi-GPU step as a table of functions (include/vkradixsort_amd.h)."""
+    _fields_ = [("user", c_void_p), ("all_gather", c_void_p), ("all_reduce", c_void_p), ("group_start", c_void_p),
+                ("send", c_void_p), ("recv", c_void_p), ("group_end", c_void_p), ("error_string", c_void_p)]
+
+
+MSD_COUNT_WORDS = 16384 + 8 * 256 + 64
+MSD_SHIFT_WORD = 16384 + 8 * 256
+
 # every symbol include/vkradixsort_amd.h declares: (name, restype, argtypes)
 _SIGNATURES = [
     ("vrs_version", c_char_p, []),
@@ -116,7 +126,16 @@ _SIGNATURES = [
     ("vrs_profile_enable_mask", c_int, [c_void_p, c_uint32]),
     ("vrs_verify_keys_u32", c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
     ("vrs_dist_create", c_int, [c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, POINTER(c_void_p)]),
+    ("vrs_dist_create_with_transport", c_int, [c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, POINTER(c_void_p)]),
     ("vrs_dist_destroy", c_int, [c_void_p]),
+    ("vrs_dist_stats", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
+    ("vrs_dist_loopback_create", c_int, [c_int, POINTER(c_void_p)]),
+    ("vrs_dist_loopback_transport", c_int, [c_void_p, c_int, c_void_p]),
+    ("vrs_dist_loopback_destroy", c_int, [c_void_p]),
+    ("vrs_msd_partition_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
+    ("vrs_msd_finish_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
+    ("vrs_msd_finish_status", c_int, [c_void_p, POINTER(c_int)]),
+    ("vrs_context_device", c_int, [c_void_p]),
     ("vrs_dist_sort_keys_u32", c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_void_p), POINTER(c_uint32)]),
     ("vrs_dist_plan_splitters", c_int, [POINTER(c_uint64), c_int, POINTER(c_uint32)]),
     ("vrs_dist_last_error", c_char_p, [c_void_p]),

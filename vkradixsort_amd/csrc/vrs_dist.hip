@@ -136,7 +136,7 @@ struct vrs_dist_t {
     vrs_buffer grouped = nullptr, recv = nullptr, scratch = nullptr, hist = nullptr, row = nullptr, table = nullptr;
     vrs_buffer counts = nullptr, reduced = nullptr, round_counts = nullptr;
     std::vector<uint32_t> host_table;  // world x kRowWords
-    uint32_t host_row_tail[8] = {};
+    uint32_t host_row_tail[8] = {};  // host words on their way into device rows: [0..2] shard size, status, capacity; [3] range flag; [4] the agreed bucket shift
     std::string last_error;
     double max_imbalance = 1.15;
     uint64_t hybrid_rounds = 0, fallback_rounds = 0, byte_steps = 0;
@@ -601,12 +601,14 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
     // it says so through the shift it would have needed: ranks then disagree or the range check fails ... the flag word
     // itself decides on this rank only, so it is folded into the table by a second tiny all-gather when it is set anywhere.
     bool hybrid = try_hybrid;
-    const uint32_t shift = d->host_table[kRowShift];
+    uint32_t shift = 0xFFFFFFFFu;  // of the first non-empty shard; empty shards have nothing to say (and nothing to send)
     for (int q = 0; q < world && hybrid; ++q) {
         const uint32_t *r = &d->host_table[static_cast<size_t>(q) * kRowWords];
-        if (r[kRowN] != 0u && (r[kRowN] < (1u << 16) || r[kRowShift] != shift)) hybrid = false;
+        if (r[kRowN] == 0u) continue;
+        if (shift == 0xFFFFFFFFu) shift = r[kRowShift];
+        if (r[kRowN] < (1u << 16) || r[kRowShift] != shift) hybrid = false;  // a shard too small to have been partitioned, or another key range
     }
-    if (hybrid && (shift < 13u || shift > 18u)) hybrid = false;
+    if (hybrid && (shift < 13u || shift > 18u)) hybrid = false;  // (no keys at all: 0xFFFFFFFF)
     (void)partitioned;
     // the out-of-range flag is rank-local knowledge: make it common (one word per rank) before deciding
     if (try_hybrid) {
@@ -635,7 +637,6 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
             vrs_push_constants pc{n_eff, 24, vrs_workgroup_count(n_eff, 32), 32};
             int rc = vrs_multi_radixsort_histograms(ctx, keys, d->hist, &pc);
             if (rc == VRS_OK) rc = vrs_multi_radixsort(ctx, keys, d->grouped, d->hist, &pc);
-            vrs_buffer_t_view: ;
             if (rc == VRS_OK) {
                 vrs_buffer pv = nullptr;
                 rc = vrs_buffer_wrap(ctx, prefix, 256 * 4, &pv);
@@ -767,45 +768,55 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
     }
 
     // 4. round r's keys are finished while the later rounds are still on the wire; the sub-ranges are disjoint and ascending,
-    //    so their concatenation is the sorted range: nothing to merge.  Hybrid shape: the result of a round is built in the
-    //    scratch buffer (second MSD pass: receive buffer -> scratch; local sort in place there) and copied back.
+    //    so their concatenation is the sorted range: nothing to merge.  Hybrid shape: the result is built in the scratch
+    //    buffer (second MSD pass: receive buffer -> scratch; local sort in place there), at the round's own offset -- the
+    //    step's output then IS the scratch buffer.
     uint32_t *scratch = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->scratch));
     uint32_t *round_counts = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->round_counts));
+    d->host_row_tail[4] = shift;
     for (int r = 0; r < R; ++r) {
         const uint64_t cnt = round_off[static_cast<size_t>(r) + 1] - round_off[static_cast<size_t>(r)];
         VRS_DHIP(d, hipStreamWaitEvent(d->sort_stream, d->round_done[static_cast<size_t>(r)], 0));
         if (!cnt) continue;
         vrs_buffer view = nullptr, sview = nullptr;
         VRS_D(d, vrs_buffer_wrap(ctx, recv + round_off[static_cast<size_t>(r)], cnt * 4, &view));
+        rc = vrs_buffer_wrap(ctx, scratch + round_off[static_cast<size_t>(r)], cnt * 4, &sview);
+        if (rc != VRS_OK) {
+            (void)vrs_buffer_release(view);
+            return dfail_ctx(d, rc, "vrs_buffer_wrap");
+        }
         bool done = false;
         if (hybrid && cnt >= (1u << 16)) {
             // the bucket histogram of exactly this round's keys: the all-reduced one, masked to the round's top bytes
             const uint32_t lo = parts[static_cast<size_t>(me) * R + r], hi = parts[static_cast<size_t>(me) * R + r + 1];
             VRS_DHIP(d, hipMemsetAsync(round_counts, 0, static_cast<size_t>(VRS_MSD_COUNT_WORDS) * 4, d->sort_stream));
             VRS_DHIP(d, hipMemcpyAsync(round_counts + lo * 64u, reduced + lo * 64u, static_cast<size_t>(hi - lo) * 64 * 4, hipMemcpyDeviceToDevice, d->sort_stream));
-            VRS_DHIP(d, hipMemcpyAsync(round_counts + VRS_MSD_SHIFT_WORD, counts + VRS_MSD_SHIFT_WORD, 4, hipMemcpyDeviceToDevice, d->sort_stream));
-            rc = vrs_buffer_wrap(ctx, scratch + round_off[static_cast<size_t>(r)], cnt * 4, &sview);
-            if (rc == VRS_OK) rc = vrs_msd_finish_u32(ctx, view, sview, d->round_counts, static_cast<uint32_t>(cnt));
+            VRS_DHIP(d, hipMemcpyAsync(round_counts + VRS_MSD_SHIFT_WORD, &d->host_row_tail[4], 4, hipMemcpyHostToDevice, d->sort_stream));
+            rc = vrs_msd_finish_u32(ctx, view, sview, d->round_counts, static_cast<uint32_t>(cnt));
             int took = 0;
-            if (rc == VRS_OK) rc = vrs_msd_finish_status(ctx, &took);  // waits for the plan's head (the counts, not the sort)
+            if (rc == VRS_OK) rc = vrs_msd_finish_status(ctx, &took);  // waits for the plan's head (the round has landed by then; never for the sort)
             if (rc == VRS_OK && took) {
-                VRS_DHIP(d, hipMemcpyAsync(recv + round_off[static_cast<size_t>(r)], scratch + round_off[static_cast<size_t>(r)], cnt * 4, hipMemcpyDeviceToDevice, d->sort_stream));
                 d->hybrid_rounds++;
                 done = true;
             } else if (rc == VRS_OK) {
                 d->fallback_rounds++;  // the plan refused (a bucket beyond the local sort's capacity ...): the keys are still in the receive buffer
             }
-            if (sview) (void)vrs_buffer_release(sview);
             if (rc != VRS_OK) {
                 (void)vrs_buffer_release(view);
+                (void)vrs_buffer_release(sview);
                 return dfail_ctx(d, rc, "vrs_msd_finish_u32 (received sub-range)");
             }
         }
-        if (!done) rc = vrs_sort_keys_u32(ctx, view, d->scratch, static_cast<uint32_t>(cnt));
+        if (!done) {
+            rc = vrs_sort_keys_u32(ctx, view, sview, static_cast<uint32_t>(cnt));
+            // hybrid shape: the step's output is the scratch buffer
+            if (rc == VRS_OK && hybrid) rc = vrs_buffer_copy(ctx, sview, view, cnt * 4);
+        }
         (void)vrs_buffer_release(view);
+        (void)vrs_buffer_release(sview);
         if (rc) return dfail_ctx(d, rc, "vrs_sort_keys_u32 (received sub-range)");
     }
-    *out_keys = d->recv;
+    *out_keys = hybrid ? d->scratch : d->recv;
     *out_count = static_cast<uint32_t>(total);
     return VRS_OK;
 }
