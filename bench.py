@@ -340,7 +340,8 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
-def bench_multi(args):
+def bench_multi_python(args):
+    """N > 1 through the Python orchestration (vkradixsort_amd/distributed.py over torch.distributed): --dist-path python."""
     import torch
     import torch.distributed as dist
 
@@ -498,6 +499,228 @@ def bench_multi(args):
     return result
 
 
+def _rccl_communicator(torch, dist, rank, world, dev):
+    """A raw ncclComm_t of the RCCL copy PyTorch already loaded (vrs_dist_create binds that same copy at run time): rank 0
+    draws the unique id, torch.distributed carries it to the others."""
+    rccl_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    rccl = ctypes.CDLL(rccl_path if os.path.exists(rccl_path) else "librccl.so", mode=ctypes.RTLD_GLOBAL)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    if rank == 0 and rccl.ncclGetUniqueId(ctypes.byref(uid)) != 0:
+        raise RuntimeError("ncclGetUniqueId failed")
+    t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(dev)
+    dist.broadcast(t, 0)
+    ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    if rccl.ncclCommInitRank(ctypes.byref(comm), world, uid, rank) != 0:
+        raise RuntimeError("ncclCommInitRank failed")
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    return rccl, comm
+
+
+def bench_multi(args):
+    """N > 1 (or VRS_BENCH_FORCE_MULTI=1 at N = 1): the multi-GPU step behind the C ABI (vrs_dist_*, csrc/vrs_dist.hip) over a
+    raw RCCL communicator -- the single-GPU hybrid sort with the all-to-all between its two MSD passes."""
+    import torch
+    import torch.distributed as dist
+
+    import vkradixsort_amd as vrs
+    from vkradixsort_amd import capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    with _StdoutToStderr():
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        warm = torch.zeros(8, dtype=torch.int64, device=dev)
+        dist.all_reduce(warm)  # brings the communicator up (and its banner out) now
+        torch.cuda.synchronize()
+        rccl, comm = _rccl_communicator(torch, dist, rank, world, dev)
+    lib = capi.load_library()
+    n, K, W = args.n, args.steps, args.warmup
+    S = vrs.Buffer.BufferSettings
+    shard = mt19937_keys(1000 + rank, n)  # shard g uses seed 1000+g (SURVEY.md section 8d)
+    gpu = vrs.GPUContext(local)
+    gpu.init()
+    pristine = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), shard)
+    nbuf = max(K, W, 1)
+    batches = [vrs.Buffer(gpu, S(4 * n)) for _ in range(nbuf)]
+    cap = int(n * 1.25) + 4096
+
+    def make_dist(rounds):
+        d = ctypes.c_void_p()
+        rc = lib.vrs_dist_create(gpu.handle, comm, rank, world, cap, rounds, ctypes.byref(d))
+        if rc != 0:
+            raise RuntimeError(f"vrs_dist_create: {lib.vrs_dist_last_error(None).decode()}")
+        return d
+
+    def step(d, b):
+        out_buf, out_n = ctypes.c_void_p(), ctypes.c_uint32()
+        rc = lib.vrs_dist_sort_keys_u32(d, b.handle, n, ctypes.byref(out_buf), ctypes.byref(out_n))
+        if rc != 0:
+            raise RuntimeError(f"vrs_dist_sort_keys_u32 (rank {rank}): {lib.vrs_dist_last_error(d).decode()}")
+        return out_buf, out_n.value
+
+    def rearm():
+        for b in batches:
+            b.copyFrom(pristine)
+        gpu.waitIdle()
+
+    def barrier():
+        gpu.waitIdle()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    rearm()
+    # warm-up steps double as a measurement of the exchange pipelining depth: how many rounds pay off depends on the
+    # xGMI all-to-all rate relative to the local work, which only shows on the real node.  Every rank takes the same
+    # decision (MAX over ranks of each candidate's time).
+    max_rounds = max(1, 32 // min(world, 32))
+    want = min(args.rounds, max_rounds)
+    candidates = [want] if (world == 1 or args.rounds_forced) else list(dict.fromkeys(r for r in (want, 2, 1) if r <= max_rounds))
+    handles = {r: make_dist(r) for r in candidates}
+    tried = {}
+    for r, d in handles.items():  # set-up, not a step: first use allocates scratch and loads the code objects
+        step(d, batches[0])
+        gpu.waitIdle()
+        batches[0].copyFrom(pristine)
+    if len(candidates) > 1:
+        for r, d in handles.items():
+            barrier()
+            tw = time.perf_counter()
+            step(d, batches[0])
+            gpu.waitIdle()
+            tt = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tried[r] = float(tt.item())
+            batches[0].copyFrom(pristine)
+        rounds = min(tried, key=tried.get)
+    else:
+        rounds = candidates[0]
+    d = handles[rounds]
+    for i in range(W):
+        step(d, batches[i % nbuf])
+    gpu.waitIdle()
+    rearm()
+    st0 = [ctypes.c_uint64() for _ in range(3)]
+    lib.vrs_dist_stats(d, *[ctypes.byref(x) for x in st0])
+    gpu.profileReset()
+    gpu.profileEnableMask(1 << capi.VRS_KERNEL_LOOKBACK_SCATTER)  # events ride on the dominant kernel's own launches
+    barrier()
+    t0 = time.perf_counter()
+    out_buf, out_n = None, 0
+    for i in range(K):
+        out_buf, out_n = step(d, batches[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gpu.profileEnable(False)
+    lb_launches, lb_ms = gpu.profileQuery(capi.VRS_KERNEL_LOOKBACK_SCATTER)
+    st1 = [ctypes.c_uint64() for _ in range(3)]
+    lib.vrs_dist_stats(d, *[ctypes.byref(x) for x in st1])
+    hybrid_rounds, fallback_rounds, byte_steps = (b.value - a.value for a, b in zip(st0, st1))
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # verification outside the timed region: every range ascending (device check), ranges ordered across ranks, nothing lost
+    desc, ksum, kmix = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    gpu.check(lib.vrs_verify_keys_u32(gpu.handle, out_buf, out_n, ctypes.byref(desc), ctypes.byref(ksum), ctypes.byref(kmix)))
+    ends = np.zeros(2, np.uint32)
+    if out_n:
+        base_ptr = lib.vrs_buffer_device_ptr(out_buf)
+        for j, off in enumerate((0, out_n - 1)):
+            v = ctypes.c_void_p()
+            gpu.check(lib.vrs_buffer_wrap(gpu.handle, ctypes.c_void_p(base_ptr + 4 * off), 4, ctypes.byref(v)))
+            gpu.check(lib.vrs_buffer_download(gpu.handle, v, ends[j:].ctypes.data_as(ctypes.c_void_p), 4))
+            lib.vrs_buffer_release(v)
+    edges = torch.tensor([int(ends[0]), int(ends[1]), out_n, ksum.value & (2 ** 62 - 1), 1 if desc.value == 0 else 0], dtype=torch.int64, device=dev)
+    gathered = [torch.empty_like(edges) for _ in range(world)]
+    dist.all_gather(gathered, edges)
+    src_sum = torch.tensor([int(shard.astype(np.uint64).sum()) & (2 ** 62 - 1)], dtype=torch.int64, device=dev)
+    srcs = [torch.empty_like(src_sum) for _ in range(world)]
+    dist.all_gather(srcs, src_sum)
+    g = [x.cpu().tolist() for x in gathered]
+    nonempty = [x for x in g if x[2] > 0]
+    check = {"ranges_sorted": all(x[4] == 1 for x in g),
+             "ranges_ordered_across_ranks": all(nonempty[i][1] <= nonempty[i + 1][0] for i in range(len(nonempty) - 1)),
+             "count_ok": sum(x[2] for x in g) == n * world,
+             "checksum_ok": sum(x[3] for x in g) % 2 ** 62 == sum(int(x.item()) for x in srcs) % 2 ** 62}
+    result = None
+    if rank == 0:
+        if not all(check.values()):
+            raise SystemExit(f"VERIFICATION FAILED: {check}")
+        value = n * world * K / elapsed / 1e9
+        recv_keys = int(g[0][2])
+        hybrid = byte_steps == 0
+        # rank 0's look-back scatter launches of the timed region: hybrid shape = the first MSD pass over the shard + one second
+        # pass per received sub-range (each reads and writes its keys once); byte shape = the launches of the local sorts
+        lb_bytes = 8.0 * (n + recv_keys) * K if hybrid else 8.0 * (recv_keys / max(rounds, 1)) * lb_launches
+        lb_achieved = lb_bytes / (lb_ms * 1e-3) / 1e9 if lb_ms > 0 else None
+        sort_bpk = 28 if hybrid else 48
+        base = None
+        if not args.no_cpu_baseline:
+            from tests import _oracle
+            orc = _oracle.load()
+            sample = shard[:min(n, 2 * 10 ** 7)]
+            _, ms = orc.std_sort(sample)
+            cores, model = orc.cpu_info()
+            base = {"value": round(sample.size / (ms * 1e-3) / 1e9, 5), "unit": "Gkeys/s", "cores": 1, "kind": "port",
+                    "sample": f"std::sort of the first {sample.size} keys of rank 0's shard, 1 repetition, {ms:.0f} ms",
+                    "host": f"1 thread of {cores} hardware threads ({model})"}
+        result = {
+            "metric": "Gkeys/s sorting 10^8 uint32 at 1/2/4/8 MI355X; % of HBM roofline",
+            "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{world} x {n} uniform random uint32 keys (std::mt19937 seed 1000+rank), sharded by key range "
+                                   f"(BASELINE.json configs[4] at 8 GPUs), keys resident in HBM",
+                       "path": ("vrs_dist_sort_keys_u32, hybrid shape: counting read + first MSD pass of the shard, one all-gather + one "
+                                "all-reduce of counts, RCCL send/recv of one message per (sender, top byte) in "
+                                f"{rounds} round(s), second MSD pass + LDS-local sort per received sub-range") if hybrid else
+                               ("vrs_dist_sort_keys_u32, byte shape: contract partition pass by the top byte, RCCL send/recv per "
+                                f"(sender, round) in {rounds} round(s), vrs_sort_keys_u32 per received sub-range"),
+                       "num_elements_per_gpu": n, "parallelism": f"range-sharded x{world}", "exchange_rounds": rounds,
+                       "rounds_tried_in_warmup_ms": {str(k): round(v * 1e3, 3) for k, v in tried.items()},
+                       "received_sub_ranges": {"finished_in_hybrid_shape": int(hybrid_rounds), "sorted_from_scratch_after_a_refused_plan": int(fallback_rounds)},
+                       "hbm_bytes_per_key": sort_bpk + 8,
+                       "hbm_bytes_per_key_breakdown": ({"counting_read": 4, "first_msd_pass": 8, "exchange_read_and_landing_write": 8,
+                                                        "second_msd_pass": 8, "local_sort": 8} if hybrid else
+                                                       {"partition_pass": 12, "exchange_read_and_landing_write": 8,
+                                                        "local_sorts": "28-36 by sub-range size"})},
+            "roofline": {"bound": "hbm", "kernel": "lookback_scatter (rank 0's launches in the timed region: the first MSD pass over the "
+                                                   "shard and the second pass over every received sub-range)",
+                         "achieved": round(lb_achieved, 1) if lb_achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(lb_achieved / HBM_PEAK_GBS, 4) if lb_achieved else None,
+                         "launches": lb_launches, "avg_launch_us": round(lb_ms / lb_launches * 1e3, 2) if lb_launches else None,
+                         "algorithmic_bytes_per_launch": round(lb_bytes / lb_launches) if lb_launches else None,
+                         "traffic": None},
+            "step_roofline": {"bytes_per_key": sort_bpk + 8, "achieved_GBps_per_gpu": round((sort_bpk + 8) * n * K / elapsed / 1e9, 1),
+                              "frac_of_peak": round((sort_bpk + 8) * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+                              "note": "per GPU, whole step incl. the exchange's read of the sent keys and write of the received ones"},
+            "shard_sizes": [x[2] for x in g],
+            "verified": check,
+        }
+        if base:
+            result["cpu_baseline"] = base
+    for h in handles.values():
+        lib.vrs_dist_destroy(h)
+    for b in batches + [pristine]:
+        b.release()
+    gpu.shutdown()
+    rccl.ncclCommDestroy(comm)
+    dist.destroy_process_group()
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -510,6 +733,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=4, help="multi-GPU: sub-ranges per rank (exchange/sort pipelining)")
     ap.add_argument("--rounds-forced", action="store_true", help="use --rounds even at world size 1 (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-path", choices=["c", "python"], default="c",
+                    help="N > 1: the step behind the C ABI (vrs_dist_*, hybrid shape; default) or the Python orchestration "
+                         "(vkradixsort_amd/distributed.py over torch.distributed)")
     ap.add_argument("--path", choices=["one_call", "contract"], default="one_call",
                     help="N = 1: which path is timed as `value` (the other is reported beside it): the one-call sort "
                          "(one counting read + look-back scatters) or the reference's stage-by-stage contract path")
@@ -525,9 +751,16 @@ def main():
     capi.load_library()  # fails loudly if the HIP extension was not built; there is no fallback path
 
     if args.gpus > 1 or os.environ.get("VRS_BENCH_FORCE_MULTI") == "1":  # the latter: exchange path at world size 1
-        result = bench_multi(args)
-    else:
-        result = bench_single(args)
+        # RCCL prints its banner on the C stdout whenever a communicator first does something: fd 1 belongs to the ONE JSON
+        # line, everything else goes to fd 2 for the whole run
+        guard = _StdoutToStderr()
+        guard.__enter__()
+        result = bench_multi(args) if args.dist_path == "c" else bench_multi_python(args)
+        sys.stdout.flush()
+        if result is not None:
+            os.write(guard._saved, (json.dumps(result) + "\n").encode())
+        return
+    result = bench_single(args)
     if result is not None:
         print(json.dumps(result), flush=True)
 

@@ -115,7 +115,8 @@ constexpr int kRowSlices = 8 * 256;         // top-byte counts of the shard's ei
 constexpr int kRowN = kRowSlices;           // shard size
 constexpr int kRowStatus = kRowSlices + 1;  // 0, or the VRS_ERROR_* that keeps this rank from taking part
 constexpr int kRowCapacity = kRowSlices + 2;
-constexpr int kRowShift = kRowSlices + 3;   // hybrid shape: the probed bucket shift; 0xFFFFFFFF = a key above the probed range
+constexpr int kRowShift = kRowSlices + 3;   // hybrid shape: the probed bucket shift ...
+constexpr int kRowOver = kRowSlices + 4;    // ... and != 0: a key of the shard lies above the probed range
 constexpr int kRowWords = kRowSlices + 8;
 
 }  // namespace
@@ -136,7 +137,7 @@ struct vrs_dist_t {
     vrs_buffer grouped = nullptr, recv = nullptr, scratch = nullptr, hist = nullptr, row = nullptr, table = nullptr;
     vrs_buffer counts = nullptr, reduced = nullptr, round_counts = nullptr;
     std::vector<uint32_t> host_table;  // world x kRowWords
-    uint32_t host_row_tail[8] = {};  // host words on their way into device rows: [0..2] shard size, status, capacity; [3] range flag; [4] the agreed bucket shift
+    uint32_t host_row_tail[8] = {};  // host words on their way into device rows: [0..2] shard size, status, capacity; [4] the agreed bucket shift
     std::string last_error;
     double max_imbalance = 1.15;
     uint64_t hybrid_rounds = 0, fallback_rounds = 0, byte_steps = 0;
@@ -560,7 +561,7 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
             partitioned = true;
             // the row's slice counts = words [16384, 16384 + 2048) of the counts
             VRS_DHIP(d, hipMemcpyAsync(row, counts + 16384, kRowSlices * 4, hipMemcpyDeviceToDevice, d->sort_stream));
-            VRS_DHIP(d, hipMemcpyAsync(row + kRowShift, counts + VRS_MSD_SHIFT_WORD, 4, hipMemcpyDeviceToDevice, d->sort_stream));
+            VRS_DHIP(d, hipMemcpyAsync(row + kRowShift, counts + VRS_MSD_SHIFT_WORD, 2 * 4, hipMemcpyDeviceToDevice, d->sort_stream));  // shift word + range flag
         } else {
             my_status = rc;
             my_error = std::string("vrs_msd_partition_u32: ") + vrs_last_error(ctx);
@@ -570,7 +571,6 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
     d->host_row_tail[1] = static_cast<uint32_t>(my_status);
     d->host_row_tail[2] = d->capacity;
     VRS_DHIP(d, hipMemcpyAsync(row + kRowN, d->host_row_tail, 3 * 4, hipMemcpyHostToDevice, d->sort_stream));
-    uint32_t over_flag = 0;  // read back with the table below (my own flag word travels in the counts)
 
     // 2. the collectives: every rank learns every rank's row; the bucket histograms are summed
     if (d->has_transport) {
@@ -581,7 +581,6 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         if (try_hybrid) VRS_DHIP(d, hipMemcpyAsync(reduced, counts, 16384 * 4, hipMemcpyDeviceToDevice, d->sort_stream));
     }
     VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, d->host_table.size() * 4, hipMemcpyDeviceToHost, d->sort_stream));
-    VRS_DHIP(d, hipMemcpyAsync(&over_flag, counts + VRS_MSD_SHIFT_WORD + 1, 4, hipMemcpyDeviceToHost, d->sort_stream));
     VRS_DHIP(d, hipStreamSynchronize(d->sort_stream));
 
     // ---- from here on every rank holds the same table: every decision below is the same on all of them
@@ -596,35 +595,18 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         min_capacity = std::min(min_capacity, r[kRowCapacity]);
         grand_total += r[kRowN];
     }
-    // hybrid shape iff every rank partitioned its shard with the same bucket shift of a 27..32-bit key range.  A rank whose
-    // keys reach above its probed range cannot say so in its row (the flag is written by the same kernels as the row) --
-    // it says so through the shift it would have needed: ranks then disagree or the range check fails ... the flag word
-    // itself decides on this rank only, so it is folded into the table by a second tiny all-gather when it is set anywhere.
+    // hybrid shape iff every non-empty shard was partitioned with the same bucket shift of a 27..32-bit key range and no key
+    // of any shard lies above the range its rank probed
     bool hybrid = try_hybrid;
     uint32_t shift = 0xFFFFFFFFu;  // of the first non-empty shard; empty shards have nothing to say (and nothing to send)
     for (int q = 0; q < world && hybrid; ++q) {
         const uint32_t *r = &d->host_table[static_cast<size_t>(q) * kRowWords];
         if (r[kRowN] == 0u) continue;
         if (shift == 0xFFFFFFFFu) shift = r[kRowShift];
-        if (r[kRowN] < (1u << 16) || r[kRowShift] != shift) hybrid = false;  // a shard too small to have been partitioned, or another key range
+        if (r[kRowN] < (1u << 16) || r[kRowShift] != shift || r[kRowOver] != 0u) hybrid = false;  // too small to have been partitioned, another key range, a stray key
     }
     if (hybrid && (shift < 13u || shift > 18u)) hybrid = false;  // (no keys at all: 0xFFFFFFFF)
     (void)partitioned;
-    // the out-of-range flag is rank-local knowledge: make it common (one word per rank) before deciding
-    if (try_hybrid) {
-        d->host_row_tail[3] = over_flag;
-        VRS_DHIP(d, hipMemcpyAsync(row, &d->host_row_tail[3], 4, hipMemcpyHostToDevice, d->sort_stream));
-        std::vector<uint32_t> flags(static_cast<size_t>(world), 0);
-        if (d->has_transport) {
-            VRS_DTR(d, "all-gather of the range flags", d->tr.all_gather(d->tr.user, row, table, 1, d->sort_stream));
-            VRS_DHIP(d, hipMemcpyAsync(flags.data(), table, static_cast<size_t>(world) * 4, hipMemcpyDeviceToHost, d->sort_stream));
-            VRS_DHIP(d, hipStreamSynchronize(d->sort_stream));
-        } else {
-            flags[0] = over_flag;
-        }
-        for (uint32_t f : flags)
-            if (f) hybrid = false;
-    }
 
     // top-byte counts per rank (hybrid shape: sums over the eight slices; byte shape: filled in below) and their prefixes
     std::vector<std::vector<uint64_t>> base(static_cast<size_t>(world), std::vector<uint64_t>(257, 0));
@@ -730,11 +712,26 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         const uint32_t lo = parts[static_cast<size_t>(me) * R + r], hi = parts[static_cast<size_t>(me) * R + r + 1];
         uint64_t off = round_off[static_cast<size_t>(r)];
         hipError_t he = hipSuccess;
+        // my own slices are device copies; neighbouring ones are merged (a copy of a megabyte is launch-bound: at world size 1
+        // the 256 top bytes of the hybrid shape would be 256 copies of 5 us each instead of one of 0.15 ms)
+        uint64_t run_src = 0, run_dst = 0, run_len = 0;
+        const auto flush_own = [&] {
+            if (run_len && he == hipSuccess)
+                he = hipMemcpyAsync(recv + run_dst, grouped + run_src, run_len * 4, hipMemcpyDeviceToDevice, d->comm_stream);
+            run_len = 0;
+        };
         const auto land = [&](int s, uint32_t t0, uint32_t t1) {  // source s's keys with top bytes [t0, t1) land at `off`
             const uint64_t a = base[static_cast<size_t>(s)][t0], b = base[static_cast<size_t>(s)][t1];
             if (b > a) {
                 if (s == me) {
-                    if (he == hipSuccess) he = hipMemcpyAsync(recv + off, grouped + a, (b - a) * 4, hipMemcpyDeviceToDevice, d->comm_stream);
+                    if (run_len && run_src + run_len == a && run_dst + run_len == off) {
+                        run_len += b - a;
+                    } else {
+                        flush_own();
+                        run_src = a;
+                        run_dst = off;
+                        run_len = b - a;
+                    }
                 } else if (failed == 0) {
                     tr("recv", d->tr.recv(d->tr.user, recv + off, b - a, s, d->comm_stream));
                 }
@@ -747,6 +744,7 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         } else {
             for (int s = 0; s < world; ++s) land(s, lo, hi);
         }
+        flush_own();
         for (int dst = 0; dst < world && failed == 0; ++dst) {
             if (dst == me) continue;
             const uint32_t dlo = parts[static_cast<size_t>(dst) * R + r], dhi = parts[static_cast<size_t>(dst) * R + r + 1];
