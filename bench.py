@@ -4,13 +4,14 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-A step = one complete sort (four 8-bit passes) of one batch of synthetic keys that is already resident in HBM when
-the timed region starts.  N = 1 times the library's one-call sort (vrs_sort_keys_u32: one counting read + four
-look-back scatter passes, 36 B/key) and reports the reference's stage-by-stage contract path (4 x [histograms,
-prefix, scatter], 48 B/key) beside it; --path contract swaps the two.  N = 1 sorts BASELINE.json configs[2]: 10^8 uniform
-random uint32 (std::mt19937 raw outputs, seeds 1/2/3 cycled over the K pre-staged batches).  N > 1 sorts
-N x 10^8 keys sharded by key range (configs[4] at N = 8): top-byte partition pass, RCCL all-to-all, local sort.
-Rank 0 prints ONE JSON line.
+A step = one complete sort of one batch of synthetic keys that is already resident in HBM when the timed region starts.
+N = 1 times the library's one-call sort (vrs_sort_keys_u32; at 10^8 keys its hybrid form: one counting read, two MSD
+look-back scatter passes, the LDS-local bucket sort -- 28 B/key; below 4e7 keys the LSD form: one counting read + four
+look-back scatter passes, 36 B/key) and reports the reference's stage-by-stage contract path (4 x [histograms, prefix,
+scatter], 48 B/key) beside it; --path contract swaps the two.  N = 1 sorts BASELINE.json configs[2]: 10^8 uniform random
+uint32 (std::mt19937 raw outputs, seeds 1/2/3 cycled over the K pre-staged batches); --n 1e7 is configs[1], --pairs
+configs[3] (key + payload pairs).  N > 1 sorts N x 10^8 keys sharded by key range (configs[4] at N = 8) through
+vrs_dist_sort_keys_u32: the hybrid sort with the RCCL all-to-all between its two MSD passes.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -156,13 +157,16 @@ def bench_single(args):
                 t[name] = {"launches": cnt, "avg_us": round(ms / cnt * 1e3, 2)}
         return t
 
-    def run_steps(fn, count, mask):
-        """count steps of fn over the pre-staged batches; mask = kernels that carry events (0 = none)"""
+    def run_steps(fn, count, mask, every=1):
+        """count steps of fn over the pre-staged batches; mask = kernels whose launches carry events (0 = none) in every
+        `every`-th step (an event pair costs the launch it brackets a few microseconds: the timed region samples)"""
         gpu.profileReset()
         gpu.profileEnableMask(mask)
         gpu.waitIdle()
         t0 = time.perf_counter()
         for i in range(count):
+            if every > 1:
+                gpu.profileEnableMask(mask if i % every == 0 else 0)
             fn(batches[i])
         gpu.waitIdle()
         dt = time.perf_counter() - t0
@@ -173,10 +177,10 @@ def bench_single(args):
     run_steps(primary, W, 0)
     rearm()
 
-    # ---- timed region: exactly K steps, inputs resident.  The dominant kernel's launches carry HIP events on their
-    # own dispatch packets, on the stream they are launched on; nothing else is instrumented.
+    # ---- timed region: exactly K steps, inputs resident.  The dominant kernel's launches of every 4th step carry HIP events
+    # on their own dispatch packets, on the stream they are launched on; nothing else is instrumented.
     hybrid_before, recounts_before = hybrid_sorts(), hybrid_recounts()
-    elapsed, kernels = run_steps(primary, K, 1 << dominant_id)
+    elapsed, kernels = run_steps(primary, K, 1 << dominant_id, every=args.event_every)
     hybrid_steps = hybrid_sorts() - hybrid_before  # K if every timed one-call sort took the hybrid form, 0 if none did
     recount_steps = hybrid_recounts() - recounts_before
     # the timed region's own outputs, every one of them, before anything overwrites them (one device read each)
@@ -303,6 +307,7 @@ def bench_single(args):
                           "achieved_GBps": round(sort_bytes * K / elapsed / 1e9, 1),
                           "frac_of_peak": round(sort_bytes * K / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
         "kernels_timed_region": kernels,
+        "kernels_timed_region_note": f"HIP events on the dominant kernel's launches of every {args.event_every}th step of the timed region",
         "kernels_all_instrumented_rerun": breakdown,
         "ms_per_step_uninstrumented_rerun": round(unprofiled / K * 1e3, 4),
         f"{other_name}_path": {
@@ -321,6 +326,141 @@ def bench_single(args):
     for b in batches + pristine + [buf1, hist]:
         b.release()
     p.release()
+    gpu.shutdown()
+    return result
+
+
+def bench_pairs(args):
+    """--pairs: BASELINE.json configs[3] -- n uint32 keys, each with a uint32 payload (its input position), sorted by
+    vrs_sort_pairs_u32 (stable: == std::stable_sort by key; the reference has no key-value path, SURVEY.md section 8c).  Same
+    contract as the keys line: K pre-staged batches, the dominant kernel's launches carry HIP events in the timed region."""
+    import vkradixsort_amd as vrs
+    from vkradixsort_amd import capi
+
+    n, K, W = args.n, args.steps, args.warmup
+    S = vrs.Buffer.BufferSettings
+    seeds = [1, 2, 3]
+    host_keys = [mt19937_keys(s, n) for s in seeds[:max(1, min(3, K))]]
+    iota = np.arange(n, dtype=np.uint32)
+    gpu = vrs.GPUContext(int(os.environ.get("LOCAL_RANK", "0")))
+    gpu.init()
+    dev_name, cus, mem = gpu.deviceInfo()
+    nbuf = max(K, W, 1)
+    if (2 * nbuf + len(host_keys) + 3) * 4 * n > 0.8 * mem:
+        raise SystemExit("too many pre-staged batches for this device; lower --steps")
+    pristine = [vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), k) for k in host_keys]
+    pristine_vals = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), iota)
+    keys = [vrs.Buffer(gpu, S(4 * n)) for _ in range(nbuf)]
+    vals = [vrs.Buffer(gpu, S(4 * n)) for _ in range(nbuf)]
+    ktmp, vtmp = vrs.Buffer(gpu, S(4 * n)), vrs.Buffer(gpu, S(4 * n))
+
+    def rearm():
+        for i in range(nbuf):
+            keys[i].copyFrom(pristine[i % len(pristine)])
+            vals[i].copyFrom(pristine_vals)
+        gpu.waitIdle()
+
+    def sort(i):
+        gpu.check(gpu.lib.vrs_sort_pairs_u32(gpu.handle, keys[i].handle, ktmp.handle, vals[i].handle, vtmp.handle, n))
+
+    def hybrid_sorts():
+        h = ctypes.c_uint64()
+        gpu.check(gpu.lib.vrs_one_call_hybrid_sorts(gpu.handle, ctypes.byref(h)))
+        return h.value
+
+    def kernel_table():
+        t = {}
+        for kid, name in capi.KERNEL_NAMES.items():
+            cnt, ms = gpu.profileQuery(kid)
+            if cnt:
+                t[name] = {"launches": cnt, "avg_us": round(ms / cnt * 1e3, 2)}
+        return t
+
+    def run_steps(count, mask, every=1):
+        gpu.profileReset()
+        gpu.profileEnableMask(mask)
+        gpu.waitIdle()
+        t0 = time.perf_counter()
+        for i in range(count):
+            if every > 1:
+                gpu.profileEnableMask(mask if i % every == 0 else 0)
+            sort(i)
+        gpu.waitIdle()
+        dt = time.perf_counter() - t0
+        gpu.profileEnable(False)
+        return dt, kernel_table()
+
+    rearm()
+    run_steps(W, 0)
+    rearm()
+    h0 = hybrid_sorts()
+    elapsed, kernels = run_steps(K, 1 << capi.VRS_KERNEL_LOOKBACK_SCATTER, every=args.event_every)
+    hybrid_steps = hybrid_sorts() - h0
+    # every output of the timed region: keys ascending and a permutation of the input's, payloads a permutation of 0 .. n-1
+    key_prints = [p_.verifyKeys(n)[1:] for p_ in pristine]
+    val_print = pristine_vals.verifyKeys(n)[1:]
+    bad = [i for i in range(K) if (lambda r: r[0] != 0 or r[1:] != key_prints[i % len(pristine)])(keys[i].verifyKeys(n))
+           or vals[i].verifyKeys(n)[1:] != val_print]
+    if bad:
+        raise SystemExit(f"VERIFICATION FAILED: timed-region outputs of steps {bad}")
+    # bit for bit against std::stable_sort (keys AND payloads) for the first batch of every seed; its time is the CPU baseline
+    base = None
+    exact = None
+    if not args.no_cpu_baseline:
+        from tests import _oracle
+        orc = _oracle.load()
+        ok, ov = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        times, exact = [], True
+        for j in range(min(len(pristine), K)):
+            rk, rv, ms = orc.stable_sort_pairs(host_keys[j], iota)
+            times.append(ms)
+            keys[j].downloadWithStagingBuffer(ok)
+            vals[j].downloadWithStagingBuffer(ov)
+            exact = exact and bool(np.array_equal(rk, ok)) and bool(np.array_equal(rv, ov))
+        if not exact:
+            raise SystemExit("VERIFICATION FAILED: pairs differ from std::stable_sort")
+        cores, model = orc.cpu_info()
+        base = {"value": round(n / (min(times) * 1e-3) / 1e9, 5), "unit": "Gkeys/s", "cores": 1, "kind": "port",
+                "sample": f"std::stable_sort by key of the full {n}-pair batches of seeds 1..{len(times)} (key << 32 | payload), one "
+                          "repetition each: " + ", ".join(f"{t:.0f}" for t in times) + " ms (value = the fastest)",
+                "host": f"1 thread of {cores} hardware threads ({model})"}
+    rearm()
+    unprofiled, _ = run_steps(K, 0)
+    rearm()
+    _, breakdown = run_steps(K, (1 << capi.VRS_KERNEL_COUNT) - 1)
+    if hybrid_steps not in (0, K):
+        raise SystemExit(f"the timed steps mixed the two forms of the one-call sort ({hybrid_steps} of {K} hybrid)")
+    hybrid = hybrid_steps == K
+    bpp = 52 if hybrid else 68  # counting read 4 + (2 MSD passes + local sort | 4 LSD passes) x (read 8 + write 8)
+    dom_us = kernels.get("lookback_scatter", {}).get("avg_us")
+    achieved = 16 * n / (dom_us * 1e-6) / 1e9 if dom_us else None
+    result = {
+        "metric": "Gkeys/s sorting 10^8 uint32 at 1/2/4/8 MI355X; % of HBM roofline",
+        "value": round(n * K / elapsed / 1e9, 3), "unit": "Gkeys/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[3]: {n} uint32 key + uint32 payload pairs (keys: std::mt19937 seeds 1,2,3; payload = "
+                               "input position), 1xMI355X, resident in HBM; every key counts once (a pair per key)",
+                   "path": ("vrs_sort_pairs_u32, hybrid form: one counting read of the keys, two stable MSD scatter passes with decoupled "
+                            "look-back (keys + payloads), LDS-local bucket sort -- 52 B/pair") if hybrid else
+                           "vrs_sort_pairs_u32: one counting read + four stable look-back scatter passes -- 68 B/pair",
+                   "num_elements": n, "device": dev_name, "compute_units": cus},
+        "roofline": {"bound": "hbm", "kernel": "lookback_scatter with payloads (reads and writes every key and payload once per launch)",
+                     "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "algorithmic_bytes_per_launch": 16 * n,
+                     "avg_launch_us": dom_us, "traffic": load_traffic_profile("lookback_scatter_pairs") if n == 10 ** 8 else None,
+                     "traffic_source": "profiles/lookback_scatter_pairs_traffic.json (rocprofv3 --pmc passes of an earlier run of this command)"},
+        "sort_roofline": {"algorithmic_bytes": bpp * n, "bytes_per_key": bpp, "achieved_GBps": round(bpp * n * K / elapsed / 1e9, 1),
+                          "frac_of_peak": round(bpp * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
+        "kernels_timed_region": kernels, "kernels_all_instrumented_rerun": breakdown,
+        "ms_per_step_uninstrumented_rerun": round(unprofiled / K * 1e3, 4),
+        "verified": {"timed_region_every_batch_keys_ascending_and_permutations": True, "timed_region_batches_checked_on_device": K,
+                     "bit_exact_vs_std_stable_sort_seeds": exact},
+    }
+    if base:
+        result["cpu_baseline"] = base
+    for b in keys + vals + pristine + [pristine_vals, ktmp, vtmp]:
+        b.release()
     gpu.shutdown()
     return result
 
@@ -733,6 +873,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=4, help="multi-GPU: sub-ranges per rank (exchange/sort pipelining)")
     ap.add_argument("--rounds-forced", action="store_true", help="use --rounds even at world size 1 (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="N = 1: the dominant kernel's launches carry HIP events in every this-many-th step of the timed region")
+    ap.add_argument("--pairs", action="store_true", help="N = 1: BASELINE.json configs[3], key + payload pairs through vrs_sort_pairs_u32")
     ap.add_argument("--dist-path", choices=["c", "python"], default="c",
                     help="N > 1: the step behind the C ABI (vrs_dist_*, hybrid shape; default) or the Python orchestration "
                          "(vkradixsort_amd/distributed.py over torch.distributed)")
@@ -760,7 +903,7 @@ def main():
         if result is not None:
             os.write(guard._saved, (json.dumps(result) + "\n").encode())
         return
-    result = bench_single(args)
+    result = bench_pairs(args) if args.pairs else bench_single(args)
     if result is not None:
         print(json.dumps(result), flush=True)
 

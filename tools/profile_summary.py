@@ -62,8 +62,10 @@ json.dump(rows, open(f"{out}/{rnd}_hbm_traffic_per_launch.json", "w"), indent=1)
 src = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 10 --warmup 2 --no-cpu-baseline`"
 corr = "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE x1; both x1024 B"
 # bench.py reads <dominant kernel>_traffic.json: the contract path's scatter and the one-call path's look-back scatter
+pairs = "pairs" in rnd
 for fname, kname, pick in (("scatter_traffic.json", "scatter_kernel", lambda k: "scatter_kernel" in k and "onesweep" not in k),
-                           ("lookback_scatter_traffic.json", "onesweep_scatter_kernel", lambda k: "onesweep_scatter_kernel" in k)):
+                           ("lookback_scatter_pairs_traffic.json" if pairs else "lookback_scatter_traffic.json", "onesweep_scatter_kernel",
+                            lambda k: "onesweep_scatter_kernel" in k)):
     hit = [v for k, v in rows.items() if pick(k)]
     if hit:
         json.dump({"kernel": kname, "round": rnd, "source": src, "correction": corr, **hit[0]}, open(f"{out}/{fname}", "w"), indent=1)

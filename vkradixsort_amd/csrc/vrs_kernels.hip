@@ -50,6 +50,9 @@
 #ifndef VRS_LB_BATCH
 #define VRS_LB_BATCH 4
 #endif
+#ifndef VRS_LB_WAVES
+#define VRS_LB_WAVES 8  // waves of a look-back workgroup of the LSD passes (lab builds: 4 = 4096-key tiles of 256 threads)
+#endif
 
 namespace vrs {
 
@@ -2555,7 +2558,7 @@ hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks) 
     return hipGetLastError();
 }
 
-uint32_t onesweep_tile_keys(int key_bytes) { return key_bytes == 8 ? 4096u : VRS_LB_ITEMS * 512u; }
+uint32_t onesweep_tile_keys(int key_bytes) { return key_bytes == 8 ? 4096u * VRS_LB_WAVES / 8u : VRS_LB_ITEMS * 64u * VRS_LB_WAVES; }
 
 // largest power of two <= x (x >= 1)
 static uint32_t floor_pow2(uint32_t x) {
@@ -2714,10 +2717,10 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
                                    LaunchEvents ev, bool misplace) {
     const int mis = misplace ? 1 : 0, force = forced ? 1 : 0;
     if (grid_tiles == 0) return hipSuccess;
-    const dim3 grid(kStreams * grid_tiles), block(512);
+    const dim3 grid(kStreams * grid_tiles), block(64 * VRS_LB_WAVES);
     const bool pairs = values_in != nullptr;
 #define VRS_ONESWEEP(K, ITEMS, PAIRS, RANK)                                                                           \
-    VRS_LAUNCH((onesweep_scatter_kernel<K, ITEMS, 8, PAIRS, RANK, 4>), grid, block, stream, ev,                       \
+    VRS_LAUNCH((onesweep_scatter_kernel<K, ITEMS, VRS_LB_WAVES, PAIRS, RANK, 4>), grid, block, stream, ev,            \
                static_cast<const K *>(keys_in), static_cast<K *>(keys_out), values_in, values_out, plan, pass, force,  \
                shift, status, xcc_map, mis, spin_budget, hold_tile)
     if (key_bytes == 8) {
