@@ -1154,6 +1154,10 @@ __device__ __forceinline__ void plan_body(uint32_t *__restrict__ tables, Oneswee
             if (mode != kPassLookback) first = static_cast<uint32_t>(q);
         }
         s_head.first_abnormal = first;
+        s_head.msd_ok = 0;  // the hybrid form's fields: msd_plan_kernel fills them in when it runs
+        s_head.msd_tiles_b = 0;
+        s_head.msd_max_bucket = 0;
+        s_head.msd_shift_a = 0;
         s_head.lsd_missing = 0;
         s_head.ready = 0;
     }

@@ -1,4 +1,9 @@
-"""Key-range sharded sort across the GPUs of one node (BASELINE.json config 5).
+"""Key-range sharded sort across the GPUs of one node (BASELINE.json configs[4]) -- the Python
+orchestration.  The step ALSO exists behind the C ABI (csrc/vrs_dist.hip: vrs_dist_sort_keys_u32 over an RCCL communicator
+or any injected transport), and that one has the leaner shape -- the single-GPU hybrid sort with the exchange between its two
+MSD passes, 28 B/key per GPU; bench.py --gpus N times it by default (--dist-path python times this module).  What this
+module adds on top of the same C entry points: sampled splitters for keys that byte-aligned ranges cannot balance, and a
+gather path for totals too small to amortise an exchange.
 
 The reference is single-GPU; this is the build's multi-GPU path.  One process per GPU, torch.distributed
 (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests).  Per step:
@@ -16,8 +21,9 @@ The reference is single-GPU; this is the build's multi-GPU path.  One process pe
                   the sub-ranges are disjoint and ascending, so their concatenation is the sorted range -- no merge
 
 Rank g ends up holding range g in ascending order; the global result is the concatenation of ranks 0..W-1.
-HBM bytes per key: 12 (step 1) + 36 (step 4: the one-call sort, one counting read + four look-back scatters) = 48, plus one trip over xGMI for (world-1)/world of the keys; only the
-first round's transfer and the last round's sort are not overlapped.
+HBM bytes per key: 12 (step 1) + what vrs_sort_keys_u32 moves for a received sub-range in step 4 (28 in its hybrid form from
+4e7 keys on, 36 in its LSD form below) = 40 ... 48, plus one trip over xGMI for (world-1)/world of the keys; only the first
+round's transfer and the last round's sort are not overlapped.
 
 The device work is behind `LocalSortBackend`; the product backend drives the C ABI on torch's current stream.
 The CPU tests substitute a numpy backend to exercise steps 2-3 under gloo (the product never does).
