@@ -6,7 +6,7 @@
 
 A step = one complete sort of one batch of synthetic keys that is already resident in HBM when the timed region starts.
 N = 1 times the library's one-call sort (vrs_sort_keys_u32; at 10^8 keys its hybrid form: one counting read, two MSD
-look-back scatter passes, the LDS-local bucket sort -- 28 B/key; below 4e7 keys the LSD form: one counting read + four
+look-back scatter passes, the LDS-local bucket sort -- 28 B/key; below 1.3e7 keys the LSD form: one counting read + four
 look-back scatter passes, 36 B/key) and reports the reference's stage-by-stage contract path (4 x [histograms, prefix,
 scatter], 48 B/key) beside it; --path contract swaps the two.  N = 1 sorts BASELINE.json configs[2]: 10^8 uniform random
 uint32 (std::mt19937 raw outputs, seeds 1/2/3 cycled over the K pre-staged batches); --n 1e7 is configs[1], --pairs

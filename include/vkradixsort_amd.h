@@ -183,7 +183,7 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * host memory -- i.e. until the counting read has run; it never waits for the sort itself, which still completes
  * asynchronously on the context's stream.  Passes whose digit is the same for every key (small keys, constant bytes)
  * are the identity and are left out.  Same result, bit for bit.
- * uint32 keys from 4 * 10^7 keys on, uint32 key + payload pairs from 2.5 * 10^7 pairs on (VRS_TUNE_HYBRID,
+ * uint32 keys from 1.3 * 10^7 keys on, uint32 key + payload pairs from 2.5 * 10^7 pairs on (VRS_TUNE_HYBRID,
  * VRS_TUNE_HYBRID_MIN_KEYS):
  * the same counting read also histograms the top 14 bits of the key range, and when every such bucket fits one workgroup's
  * LDS (14333 keys or 6656 pairs; uniform keys: up to about 2.2 * 10^8 keys, 1.03 * 10^8 pairs) the four LSD passes are
@@ -398,7 +398,8 @@ typedef enum vrs_tuning_key {
                                      bucket) whenever every bucket fits a workgroup's LDS, else the four LSD passes (decided
                                      on the device from the same counting read); 0 = always the LSD passes */
     VRS_TUNE_HYBRID_MIN_KEYS = 12, /* the hybrid form is considered from this many keys on, from 5/8 as many pairs and from
-                                     half as many 64-bit keys (default 4 * 10^7; never below 2^22 elements) */
+                                     half as many 64-bit keys; 0 (default): the measured crossovers -- 1.3 * 10^7 keys, 2.5 * 10^7
+                                     pairs, 2 * 10^7 64-bit keys.  Never below 2^22 elements */
     VRS_TUNE_HYBRID_FAST_COUNT = 13, /* the counting read of a sort the hybrid form may take: 0 = always counts the LSD
                                      tables beside the bucket histogram (a refusal costs nothing extra); 2 = counts only
                                      the bucket histogram when the probed key range allows the hybrid form (1 LDS add per

@@ -30,6 +30,8 @@ with vrs.GPUContext(0) as gpu:
     tmp = vrs.Buffer(gpu, S(4 * n))
     if groups:
         gpu.setTuning(8, groups)
+    if os.environ.get("VRS_HYBRID_MIN"):
+        gpu.setTuning(12, int(float(os.environ["VRS_HYBRID_MIN"])))
     if os.environ.get("VRS_FUSED_PLAN"):
         gpu.setTuning(10, int(os.environ["VRS_FUSED_PLAN"]))
 

@@ -79,7 +79,10 @@ struct vrs_context_t {
     bool os_wide_refused = false;        // 64-bit keys: the last attempt at the hybrid form was refused
     uint32_t os_wide_skipped = 0;        //   ... sorts since (every 16th tries again)
     uint64_t os_hybrid_recounts = 0;     // sorts that started over as LSD sorts after a fast count and a refusal
-    uint32_t os_hybrid_min_keys = 40000000u;  // VRS_TUNE_HYBRID_MIN_KEYS (measured crossover with the fast count: 3.5-4e7 keys)
+    // VRS_TUNE_HYBRID_MIN_KEYS; 0 (default) = the measured crossovers per kind of sort: 1.3e7 bare uint32 keys (small buckets are
+    // sorted one wave per bucket: profiles/labs/r03_hybrid_by_size.txt), 2.5e7 pairs, 2e7 64-bit keys (profiles/labs/r02_*).  A set
+    // value v means v keys, 5/8 v pairs, v/2 64-bit keys.
+    uint32_t os_hybrid_min_keys = 0u;
     uint32_t *os_msd_counts = nullptr;   // [16384] top-14-bit histogram + [8][256] top-byte counts per pass-0 group, zero between sorts
     vrs::MsdPlan *os_msd_plan = nullptr;
     vrs::OnesweepPlan *os_plan_a = nullptr;  // seeds and streams of the first MSD pass
@@ -780,8 +783,11 @@ static OneReadGeometry one_read_geometry(vrs_context ctx, const vrs_context_t::O
     // the local sort's capacity per bucket; launched blind, the workgroup shape of bare uint32 keys is chosen from N alone
     // (uniform keys: buckets of N / 16384 +- a few per cent)
     g.local_cap = vrs::msd_local_capacity(pairs || wide);
-    if (st.blind_tail && !pairs && !wide && static_cast<uint64_t>(n) * 11u / 10u / vrs::kMsdBucketCount + 64u <= vrs::msd_local_capacity_small())
-        g.local_cap = vrs::msd_local_capacity_small();
+    if (st.blind_tail && !pairs && !wide) {
+        const uint64_t expect = static_cast<uint64_t>(n) * 11u / 10u / vrs::kMsdBucketCount + 64u;  // uniform keys: N / 16384 + a few per cent
+        if (expect <= vrs::msd_local_capacity_wave()) g.local_cap = vrs::msd_local_capacity_wave();
+        else if (expect <= vrs::msd_local_capacity_small()) g.local_cap = vrs::msd_local_capacity_small();
+    }
     g.rows = static_cast<size_t>(S) * std::max(g.tile_cap, st.msd_capable ? g.tiles_b_cap : 0u);  // status rows: one region for all passes (tagged words)
     return g;
 }
@@ -885,13 +891,16 @@ static int one_read_enqueue(vrs_context ctx) {
     const bool wide = key_bytes == 8, pairs = st.vptr[0] != nullptr;
     if (st.group == 0) {
         // Hybrid form (K5b): uint32 keys, with or without uint32 payloads, and bare 64-bit keys, from os_hybrid_min_keys on
-        // (default 4e7 keys, 2.5e7 pairs, 2e7 64-bit keys: below, the fixed cost per bucket workgroup outweighs the saved
-        // pass -- measured crossovers, profiles/labs/r02_fast_count.txt, r02_hybrid_pairs.txt, r02_hybrid_u64.txt); above
+        // (default 1.3e7 keys, 2.5e7 pairs, 2e7 64-bit keys: below, the fixed costs of the 16384-bin counting read and of a
+        // launch per bucket outweigh the saved pass -- measured crossovers, profiles/labs/r03_hybrid_by_size.txt,
+        // r02_hybrid_pairs.txt, r02_hybrid_u64.txt); above
         // about 2.3 * 10^8 uniform keys (1.03 * 10^8 pairs) the largest bucket no longer fits a workgroup's LDS and the plan
         // says no.  Its local sort ranks with returning LDS atomics, so the lane-order self-test must have passed.
         // 64-bit keys: the counting read never makes LSD tables (their LSD form counts twice anyway), so a refusal always
         // starts over; after one, only every 16th such sort of the context tries again.
-        const uint32_t hybrid_min = wide ? ctx->os_hybrid_min_keys / 2u : pairs ? ctx->os_hybrid_min_keys / 8u * 5u : ctx->os_hybrid_min_keys;
+        const uint32_t set = ctx->os_hybrid_min_keys;
+        const uint32_t hybrid_min = set == 0u ? (wide ? 20000000u : pairs ? 25000000u : 13000000u)
+                                              : (wide ? set / 2u : pairs ? set / 8u * 5u : set);
         bool wide_try = wide && !pairs;
         if (wide_try && !st.no_hybrid && ctx->os_wide_refused && (++ctx->os_wide_skipped % 16u) != 0u) wide_try = false;
         st.msd_capable = !st.no_hybrid && (key_bytes == 4 || wide_try) && ctx->os_hybrid && ctx->atomic_rank_verified &&

@@ -18,6 +18,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -1887,15 +1888,19 @@ __device__ __forceinline__ void local_sort_bucket(uint32_t *bucket, uint32_t *bu
 //    only a bucket in which some instruction has half its lanes on one counter runs the guarded form.
 constexpr int kLeanRow = 512 + 64;  // words per counter table: 512 digits + one dummy per lane for slots without a key
 constexpr int kLeanMaxVec = 7;      // 16-byte vectors per thread: capacity THREADS * 28 slots
+template <int THREADS, int VEC, bool GUARD>
+__device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
+                                               uint32_t *s_hist2, uint32_t *s_tmp, bool guard1, bool guard2);
+
 template <int THREADS, int VEC>
 __device__ __forceinline__ void lean_sort_bucket(uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *s_hist2,
                                                  uint32_t *s_tmp) {
-    constexpr int WAVES = THREADS / 64, ITEMS = 4 * VEC, PER = 512 / THREADS;
+    constexpr int WAVES = THREADS / 64, ITEMS = 4 * VEC;
     static_assert(THREADS == 256 || THREADS == 512, "the scans give every thread 2 or 1 bins");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t end = mis + n;  // slots [mis, end) hold keys
     const uint32_t nvec = (end + 3u) / 4u;
-    uint32_t k[ITEMS], rank[ITEMS];
+    uint32_t k[ITEMS];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         uint32_t v = j * THREADS + tid;
@@ -1926,7 +1931,21 @@ __device__ __forceinline__ void lean_sort_bucket(uint32_t *abase, uint32_t mis, 
     uint32_t guards = 0;
 #pragma unroll
     for (int v = 0; v < WAVES; ++v) guards |= s_tmp[16 + v];
-    const bool guard1 = (__builtin_amdgcn_readfirstlane(guards) & 1u) != 0u, guard2 = (__builtin_amdgcn_readfirstlane(guards) & 2u) != 0u;
+    guards = __builtin_amdgcn_readfirstlane(guards);
+    // two copies of the rest: the guarded one keeps the flags, the common one carries no trace of the guard (registers!)
+    if (guards == 0u) lean_sort_body<THREADS, VEC, false>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false);
+    else lean_sort_body<THREADS, VEC, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, (guards & 1u) != 0u, (guards & 2u) != 0u);
+}
+
+template <int THREADS, int VEC, bool GUARD>
+__device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
+                                               uint32_t *s_hist2, uint32_t *s_tmp, bool guard1, bool guard2) {
+    constexpr int WAVES = THREADS / 64, ITEMS = 4 * VEC, PER = 512 / THREADS;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t end = mis + n;
+    const uint32_t nvec = (end + 3u) / 4u;
+    uint32_t rank[ITEMS];
+    uint32_t *s_hist = s_hist2 + WAVES * kLeanRow;
     // ---- pass 1: low 9 bits, one table, ties in any order; byte address of counter d = 4 d
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
@@ -1938,7 +1957,7 @@ __device__ __forceinline__ void lean_sort_bucket(uint32_t *abase, uint32_t mis, 
                 a = (q - mis < n) ? a : 2048u + 4u * lane;
             }
             uint32_t *counter = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_hist) + a);
-            if (guard1) {  // workgroup-uniform
+            if (GUARD && guard1) {  // workgroup-uniform
                 const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
                 if (__ballot(a == a0) == ~0ull) {  // one counter for the whole instruction: lane 0 adds the 64 keys
                     uint32_t old = 0;
@@ -2021,7 +2040,7 @@ __device__ __forceinline__ void lean_sort_bucket(uint32_t *abase, uint32_t mis, 
         uint32_t a = (k[i] >> 7) & 0x7FCu;
         if (i >= kFirstMaybeEmpty) a = (seg + i * 64 + lane < n) ? a : 2048u + 4u * lane;
         uint32_t *counter = reinterpret_cast<uint32_t *>(my + a);
-        if (guard2) {
+        if (GUARD && guard2) {
             const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
             if (__ballot(a == a0) == ~0ull) {
                 uint32_t old = 0;
@@ -2133,6 +2152,199 @@ __global__ __launch_bounds__(THREADS, 4) void msd_local_sort_keys_kernel(uint32_
     }
 }
 constexpr uint32_t kLeanCap = 256u * 4u * kLeanMaxVec - 3u, kLeanBigCap = 512u * 4u * kLeanMaxVec - 3u;  // whatever the misalignment
+
+// ---- small buckets (up to 1789 keys: uniform keys below about 2.5e7): ONE WAVE per bucket, no workgroup barrier anywhere --
+// the LDS executes one wave's operations in order -- so a CU runs 16 independent buckets instead of 4 workgroups that each wait
+// on barriers with their lanes mostly empty.  The same two 9-bit passes and the same slot / dummy-counter scheme as
+// lean_sort_bucket, one 512-counter table reused by both passes (a single wave ranks in instruction, then lane order: stable).
+// What made 10^7 keys worth the hybrid form: 16384 buckets of 610 keys take 16 us here, 60 us with 256 threads per bucket.
+__device__ __forceinline__ void wave_phase() {  // orders this wave's LDS traffic for the compiler; the hardware keeps it in order anyway
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// exclusive prefix of the 512 byte-counters of a wave's table, 8 per lane, starting at `start`
+__device__ __forceinline__ void wave_scan512(uint32_t *tbl, uint32_t lane, uint32_t start) {
+    uint4 a = reinterpret_cast<uint4 *>(tbl)[2 * lane], b = reinterpret_cast<uint4 *>(tbl)[2 * lane + 1];
+    const uint32_t s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    uint32_t incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= static_cast<uint32_t>(o)) incl += t;
+    }
+    uint32_t acc = incl - s + start;
+    uint4 oa, ob;
+    oa.x = acc; acc += a.x; oa.y = acc; acc += a.y; oa.z = acc; acc += a.z; oa.w = acc; acc += a.w;
+    ob.x = acc; acc += b.x; ob.y = acc; acc += b.y; ob.z = acc; acc += b.z; ob.w = acc;
+    reinterpret_cast<uint4 *>(tbl)[2 * lane] = oa;
+    reinterpret_cast<uint4 *>(tbl)[2 * lane + 1] = ob;
+}
+template <int VEC, bool GUARD>
+__device__ __forceinline__ void wave_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
+                                               uint32_t *tbl, bool guard1, bool guard2);
+
+template <int VEC>
+__device__ __forceinline__ void wave_sort_bucket(uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *tbl) {
+    constexpr int ITEMS = 4 * VEC;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t end = mis + n, nvec = (end + 3u) / 4u;
+    uint32_t k[ITEMS];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        uint32_t v = j * 64 + lane;
+        if (j == VEC - 1) v = v < nvec ? v : nvec - 1u;
+        const uint4 t = reinterpret_cast<const uint4 *>(abase)[v];
+        k[4 * j] = t.x;
+        k[4 * j + 1] = t.y;
+        k[4 * j + 2] = t.z;
+        k[4 * j + 3] = t.w;
+    }
+    char *tb = reinterpret_cast<char *>(tbl);
+    const auto zero_table = [&] {  // 576 words: two 16-byte stores per lane + one more from the first 16 lanes
+        reinterpret_cast<uint4 *>(tbl)[2 * lane] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4 *>(tbl)[2 * lane + 1] = make_uint4(0, 0, 0, 0);
+        if (lane < 16u) reinterpret_cast<uint4 *>(tbl)[128 + lane] = make_uint4(0, 0, 0, 0);
+    };
+    zero_table();
+    uint32_t skew = 0;  // does an instruction of the first row put half its lanes on one counter?  bit 0: pass 1, bit 1: pass 2
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t a1 = k[c] & 511u, a2 = (k[c] >> 9) & 511u;
+        skew |= __popcll(__ballot(a1 == __builtin_amdgcn_readfirstlane(a1))) >= 32 ? 1u : 0u;
+        skew |= __popcll(__ballot(a2 == __builtin_amdgcn_readfirstlane(a2))) >= 32 ? 2u : 0u;
+    }
+    skew = __builtin_amdgcn_readfirstlane(skew);
+    wave_phase();
+    if (skew == 0u) wave_sort_body<VEC, false>(k, abase, mis, n, s_keys, tbl, false, false);
+    else wave_sort_body<VEC, true>(k, abase, mis, n, s_keys, tbl, (skew & 1u) != 0u, (skew & 2u) != 0u);
+}
+
+template <int VEC, bool GUARD>
+__device__ __forceinline__ void wave_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
+                                               uint32_t *tbl, bool guard1, bool guard2) {
+    constexpr int ITEMS = 4 * VEC;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t end = mis + n, nvec = (end + 3u) / 4u;
+    uint32_t rank[ITEMS];
+    char *tb = reinterpret_cast<char *>(tbl);
+    const auto zero_table = [&] {
+        reinterpret_cast<uint4 *>(tbl)[2 * lane] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4 *>(tbl)[2 * lane + 1] = make_uint4(0, 0, 0, 0);
+        if (lane < 16u) reinterpret_cast<uint4 *>(tbl)[128 + lane] = make_uint4(0, 0, 0, 0);
+    };
+    const auto ranked_add = [&](uint32_t a, bool guard) -> uint32_t {
+        uint32_t *counter = reinterpret_cast<uint32_t *>(tb + a);
+        if (GUARD && guard) {
+            const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
+            if (__ballot(a == a0) == ~0ull) {
+                uint32_t old = 0;
+                if (lane == 0u) old = __hip_atomic_fetch_add(counter, 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return __builtin_amdgcn_readfirstlane(old) + 4u * lane;
+            }
+        }
+        return __hip_atomic_fetch_add(counter, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // ---- pass 1: low 9 bits (any order of ties)
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        uint32_t a = (k[i] << 2) & 0x7FCu;
+        if (i < 4 || i >= ITEMS - 4) {
+            const uint32_t q = 4u * ((i >> 2) * 64 + lane) + (i & 3);
+            a = (q - mis < n) ? a : 2048u + 4u * lane;
+        }
+        rank[i] = ranked_add(a, guard1);
+    }
+    wave_phase();
+    wave_scan512(tbl, lane, 0u);
+    wave_phase();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        uint32_t a = (k[i] << 2) & 0x7FCu;
+        if (i < 4 || i >= ITEMS - 4) {
+            const uint32_t q = 4u * ((i >> 2) * 64 + lane) + (i & 3);
+            const bool valid = q - mis < n;
+            a = valid ? a : 2048u + 4u * lane;
+            const uint32_t r = rank[i] + *reinterpret_cast<const uint32_t *>(tb + a);
+            rank[i] = valid ? r : 4u * (q < mis ? n + q : q);
+            continue;
+        }
+        rank[i] += *reinterpret_cast<const uint32_t *>(tb + a);
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t Lb = rank[i];
+        const uint32_t ph = (Lb & ~1023u) | ((Lb & 252u) << 2) | ((Lb >> 6) & 12u);
+        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_keys) + ph) = k[i];
+    }
+    wave_phase();
+    zero_table();  // behind pass 1's base reads in the LDS queue
+#pragma unroll
+    for (int g = 0; g < VEC; ++g) {
+        const uint4 t = reinterpret_cast<const uint4 *>(s_keys + g * 256)[lane];
+        k[4 * g] = t.x;
+        k[4 * g + 1] = t.y;
+        k[4 * g + 2] = t.z;
+        k[4 * g + 3] = t.w;
+    }
+    wave_phase();
+    // ---- pass 2: high 9 bits, stable (instruction order, then lane order); any slot may be empty here: a bucket of a few rows
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        uint32_t a = (k[i] >> 7) & 0x7FCu;
+        a = (i * 64 + lane < n) ? a : 2048u + 4u * lane;
+        rank[i] = ranked_add(a, guard2);
+    }
+    wave_phase();
+    wave_scan512(tbl, lane, 4u * mis);
+    wave_phase();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t L = i * 64 + lane;
+        uint32_t a = (k[i] >> 7) & 0x7FCu;
+        a = L < n ? a : 2048u + 4u * lane;
+        const uint32_t r = rank[i] + *reinterpret_cast<const uint32_t *>(tb + a);
+        rank[i] = L < n ? r : 4u * (mis + L);
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_keys) + rank[i]) = k[i];
+    wave_phase();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const uint32_t v = j * 64 + lane;
+        if (v < nvec) {
+            const uint4 q4 = reinterpret_cast<const uint4 *>(s_keys)[v];
+            const uint32_t q = 4u * v;
+            if (q >= mis && q + 4u <= end) {
+                reinterpret_cast<uint4 *>(abase)[v] = q4;
+            } else {
+                if (q + 0u - mis < n) abase[q + 0u] = q4.x;
+                if (q + 1u - mis < n) abase[q + 1u] = q4.y;
+                if (q + 2u - mis < n) abase[q + 2u] = q4.z;
+                if (q + 3u - mis < n) abase[q + 3u] = q4.w;
+            }
+        }
+    }
+}
+constexpr uint32_t kWaveCap = 64u * 4u * kLeanMaxVec - 3u;  // 1789 keys
+__global__ __launch_bounds__(64, 4) void msd_local_sort_wave_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[64 * 4 * kLeanMaxVec + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tbl[kLeanRow];
+    if (msd->ok == 0u) return;
+    const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
+    const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
+    if (n == 0 || mis + n > 64u * 4u * kLeanMaxVec) return;
+    uint32_t *abase = keys + begin - mis;
+    switch ((mis + n + 255u) / 256u) {
+        case 1: wave_sort_bucket<1>(abase, mis, n, s_keys, s_tbl); break;
+        case 2: wave_sort_bucket<2>(abase, mis, n, s_keys, s_tbl); break;
+        case 3: wave_sort_bucket<3>(abase, mis, n, s_keys, s_tbl); break;
+        case 4: wave_sort_bucket<4>(abase, mis, n, s_keys, s_tbl); break;
+        case 5: wave_sort_bucket<5>(abase, mis, n, s_keys, s_tbl); break;
+        case 6: wave_sort_bucket<6>(abase, mis, n, s_keys, s_tbl); break;
+        default: wave_sort_bucket<7>(abase, mis, n, s_keys, s_tbl); break;
+    }
+}
 
 // Key + payload pairs: the payload doubles a bucket's LDS footprint (53 + 16 KB), so two workgroups of 512 threads x up
 // to 13 pairs share a CU.
@@ -2578,7 +2790,13 @@ static void launch_digit_tables_variant(hipStream_t stream, const void *keys, ui
                                         uint32_t *msd_counts = nullptr, uint32_t msd_only = 0) {
     // one workgroup per (pass-0 group, slice): a power-of-two number of slices that fills the chip once
     const uint32_t wgs = static_cast<uint32_t>(compute_units) * (OCC * 256 / THREADS);
-    const uint32_t slices = floor_pow2(wgs / GROUPS > 0 ? wgs / GROUPS : 1u);
+    uint32_t slices = floor_pow2(wgs / GROUPS > 0 ? wgs / GROUPS : 1u);
+    if (MSD) {
+        // every workgroup of the hybrid form's counting read zeroes and flushes 16384 counters whatever it counts: below about
+        // 3e7 keys fewer, longer-running workgroups are cheaper (10^7 keys: 64 workgroups, 1 M instead of 4 M counter flushes)
+        const uint32_t by_size = floor_pow2(std::max<uint32_t>(n / (GROUPS * 131072u), 1u));
+        slices = std::min(slices, by_size);
+    }
     const dim3 grid(GROUPS * slices), block(THREADS);
     const uint32_t vecs = static_cast<uint32_t>(status_words / 4);
     VRS_LAUNCH((digit_tables_kernel<K, GROUPS, THREADS, COPIES, UNROLL, OCC, MSD>), grid, block, stream, ev,
@@ -2645,6 +2863,8 @@ hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *v
     if (max_bucket > msd_local_capacity(values != nullptr)) return hipErrorInvalidValue;  // the plan would have refused
     if (values != nullptr)
         VRS_LAUNCH(msd_local_sort_pairs_kernel, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, keys, values, msd);
+    else if (max_bucket <= kWaveCap)
+        VRS_LAUNCH(msd_local_sort_wave_kernel, dim3(kMsdBuckets), dim3(64), stream, ev, keys, msd);
     else if (max_bucket > kLeanCap)
         VRS_LAUNCH(msd_local_sort_keys_kernel<512>, dim3(kMsdBuckets), dim3(512), stream, ev, keys, msd);
     else
@@ -2653,6 +2873,7 @@ hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *v
 }
 
 uint32_t msd_local_capacity_small() { return kLeanCap; }
+uint32_t msd_local_capacity_wave() { return kWaveCap; }
 uint32_t msd_local_capacity(bool pairs_or_wide) { return pairs_or_wide ? kLocalCap : kLeanBigCap; }
 
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,

@@ -22,7 +22,7 @@ The reference is single-GPU; this is the build's multi-GPU path.  One process pe
 
 Rank g ends up holding range g in ascending order; the global result is the concatenation of ranks 0..W-1.
 HBM bytes per key: 12 (step 1) + what vrs_sort_keys_u32 moves for a received sub-range in step 4 (28 in its hybrid form from
-4e7 keys on, 36 in its LSD form below) = 40 ... 48, plus one trip over xGMI for (world-1)/world of the keys; only the first
+1.3e7 keys on, 36 in its LSD form below) = 40 ... 48, plus one trip over xGMI for (world-1)/world of the keys; only the first
 round's transfer and the last round's sort are not overlapped.
 
 The device work is behind `LocalSortBackend`; the product backend drives the C ABI on torch's current stream.
