@@ -69,6 +69,8 @@ def main():
             one_call = rs.randint(0, 3) == 0 and not (bits64 and pairs)  # no one-call pairs entry point for 64-bit keys
             if one_call:
                 n = int(rs.choice([rs.randint(1, 20000), rs.randint(1, 3000000), rs.randint(1000000, 9000000), rs.randint(4200000, 12000000)]))
+                if not bits64 and not pairs and rs.randint(0, 12) == 0:
+                    n = int(rs.randint(30000000, 45000000))  # buckets beyond one wave: the 256-thread local sort
             keys, kind = make_keys(rs, n, bits64)
             vals = rs.randint(0, 2 ** 32, n, dtype=np.uint32) if pairs else None
             if one_call:
@@ -81,6 +83,8 @@ def main():
                 ctx.setTuning(capi.VRS_TUNE_HYBRID, int(rs.randint(0, 4) != 0))
                 ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, int(rs.choice([1 << 22, 1 << 22, capi.HYBRID_MIN_KEYS_DEFAULT])))
                 ctx.setTuning(capi.VRS_TUNE_HYBRID_FAST_COUNT, int(rs.randint(0, 3)))
+                # round 3: enqueue-only sorts (the download below settles them)
+                ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, int(rs.randint(0, 3) == 0))
                 hold = rs.randint(0, 8) == 0
                 ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, int(rs.randint(0, 6)) if hold else -1)
                 ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, int(rs.choice([0, 3, 40])) if hold else 4096)
@@ -113,6 +117,7 @@ def main():
                 for b in (k0, k1, big):
                     b.release()
                 ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, capi.ONE_CALL_MIN_KEYS_DEFAULT)
+                ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 0)
                 ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, -1)
                 ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 4096)
                 cases += 1
