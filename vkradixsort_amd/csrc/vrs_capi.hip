@@ -59,6 +59,7 @@ struct vrs_context_t {
     vrs::OnesweepPlan *os_plan = nullptr;
     uint32_t *os_status = nullptr;       // look-back status rows
     size_t os_status_rows = 0;
+    bool os_status_clean = false;        // every status word is zero: the last kernel on the stream that touched them was a local sort that cleared them
     vrs::OnesweepPlanHead *os_host_head = nullptr;      // pinned host copy of the plan's head (the plan kernel writes it)
     vrs::OnesweepPlanHead *os_host_head_dev = nullptr;  // the same memory as the device sees it
     uint32_t os_stamp = 0;               // stamp of the most recent plan (never 0)
@@ -845,6 +846,7 @@ static int one_read_scratch(vrs_context ctx, const vrs_context_t::OneRead &st, c
         }
         VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_status), g.rows * VRS_RADIX_SORT_BINS * sizeof(uint32_t)));
         ctx->os_status_rows = g.rows;
+        ctx->os_status_clean = false;
     }
     return VRS_OK;
 }
@@ -875,11 +877,17 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
                                         pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr, ctx->os_msd_plan, ctx->os_status,
                                         tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map, st.key_bytes, ctx->os_spin_budget, ev));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
+    // Launched with the plan known (it said yes), the local sort also clears the look-back status words -- it is LDS-bound and
+    // has HBM time to spare, the next sort's counting read does not.  Launched blind it may leave at once: nothing is promised.
+    uint32_t *clear = st.blind_tail ? nullptr : ctx->os_status;
+    const size_t clear_words = st.blind_tail ? 0 : ctx->os_status_rows * VRS_RADIX_SORT_BINS;
     if (wide)
-        VRS_HIP(ctx, vrs::launch_msd_local_sort_u64(ctx->stream, st.kptr[home], ctx->os_msd_plan, max_bucket, ev));
+        VRS_HIP(ctx, vrs::launch_msd_local_sort_u64(ctx->stream, st.kptr[home], ctx->os_msd_plan, max_bucket, ev, clear, clear_words));
     else
         VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(st.kptr[home]),
-                                                pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr, ctx->os_msd_plan, max_bucket, ev));
+                                                pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr, ctx->os_msd_plan, max_bucket, ev,
+                                                clear, clear_words));
+    if (clear) ctx->os_status_clean = true;
     (void)g;
     return VRS_OK;
 }
@@ -933,6 +941,9 @@ static int one_read_enqueue(vrs_context ctx) {
         }
     } guard{ctx};
     const uint32_t group = st.group;
+    // the previous hybrid sort's local sort left the status words cleared (see one_read_hybrid_tail): nothing to zero then
+    const size_t zero_words = ctx->os_status_clean ? 0 : g.rows * VRS_RADIX_SORT_BINS;
+    ctx->os_status_clean = false;  // this sort's passes write them
     if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
     if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
     st.stamp = ctx->os_stamp;
@@ -944,10 +955,10 @@ static int one_read_enqueue(vrs_context ctx) {
         // passes and stamps the head
         if (wide)
             VRS_HIP(ctx, vrs::launch_msd_count_u64(ctx->stream, st.kptr[st.cur], n, g.group_len, ctx->os_status,
-                                                   g.rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts, ev));
+                                                   zero_words, ctx->scatter.compute_units, ctx->os_msd_counts, ev));
         else
             VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, st.kptr[st.cur], n, g.group_len, ctx->os_tables, ctx->os_status,
-                                                      g.rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts,
+                                                      zero_words, ctx->scatter.compute_units, ctx->os_msd_counts,
                                                       st.fast_count, ev));
         VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
                                           ctx->os_host_head_dev, st.stamp, n, g.T, g.tiles_b_cap, g.local_cap, ctx->os_tables,
@@ -955,7 +966,7 @@ static int one_read_enqueue(vrs_context ctx) {
                                           wide ? 50u : 18u));
     } else {
         VRS_HIP(ctx, vrs::launch_digit_tables(ctx->stream, st.kptr[st.cur], n, key_bytes, 32u * group, g.group_len, g.G, ctx->os_tables,
-                                              ctx->os_status, g.rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ev,
+                                              ctx->os_status, zero_words, ctx->scatter.compute_units, ev,
                                               ctx->os_fused_plan ? &fused : nullptr));
         if (!ctx->os_fused_plan)
             VRS_HIP(ctx, vrs::launch_plan(ctx->stream, ctx->os_tables, ctx->os_plan, ctx->os_host_head_dev, st.stamp, n, g.group_len,
@@ -1200,6 +1211,7 @@ int vrs_msd_partition_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer out, vrs_
     OneReadGeometry g;
     if ((rc = msd_half_setup(ctx, n, &st, &g))) return rc;
     ctx->sub_cache.valid = false;
+    ctx->os_status_clean = false;  // the first MSD pass writes status words (the counting read below zeroes them first)
     vrs::LaunchEvents ev;
     if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
     if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
@@ -1235,6 +1247,7 @@ int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_
     ctx->sub_cache.valid = false;
     if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
     ctx->os_msd_half_stamp = ctx->os_stamp;
+    ctx->os_status_clean = false;
     // the look-back rows of the second pass must read "never written": the counting read of a whole sort clears them, here
     // nothing else does
     VRS_HIP(ctx, hipMemsetAsync(ctx->os_status, 0, g.rows * VRS_RADIX_SORT_BINS * sizeof(uint32_t), ctx->stream));

@@ -198,10 +198,12 @@ hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys
 // the status words) and the local sort of every bucket by its low msd->shift bits (ceil(shift / 9) LDS passes)
 hipError_t launch_msd_count_u64(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *status,
                                 size_t status_words, int compute_units, uint32_t *msd_counts, LaunchEvents ev = {});
-hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, const MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev = {});
+// clear_status / clear_words (a multiple of 4): look-back status words the kernel clears on the side (for the next sort), or nullptr
+hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, const MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev = {},
+                                     uint32_t *clear_status = nullptr, size_t clear_words = 0);
 // max_bucket: the plan's msd_max_bucket (picks the workgroup shape: 256 threads up to 7165 keys, else 512)
 hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *values, const MsdPlan *msd, uint32_t max_bucket,
-                                 LaunchEvents ev = {});
+                                 LaunchEvents ev = {}, uint32_t *clear_status = nullptr, size_t clear_words = 0);
 // keys the local sort of one bucket can hold (the plan refuses the hybrid form when a bucket has more)
 uint32_t msd_local_capacity_small();  // bare uint32 keys, 256-thread workgroup: 7165
 uint32_t msd_local_capacity_wave();   // bare uint32 keys, one wave per bucket: 1789

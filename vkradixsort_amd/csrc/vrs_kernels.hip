@@ -1725,6 +1725,20 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
         scatter_chunk<K, ITEMS, 8, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
 }
 
+// The local sort is the last kernel of a hybrid sort and LDS-bound: it has HBM time to spare, so it also clears the look-back
+// status words for the NEXT sort (the counting read, which is HBM-bound, then skips its 15.6 MB of zero stores): workgroup b
+// of `blocks` clears the b-th share of status[0, vecs).
+struct StatusClear {
+    uint4 *status;   // nullptr: nothing to clear
+    uint32_t vecs;
+};
+__device__ __forceinline__ void clear_status_share(const StatusClear &sc, uint32_t threads) {
+    if (sc.status == nullptr) return;
+    const uint32_t per = (sc.vecs + gridDim.x - 1u) / gridDim.x;
+    const uint32_t z0 = blockIdx.x * per, z1 = min(z0 + per, sc.vecs);
+    for (uint32_t c = z0 + threadIdx.x; c < z1; c += threads) sc.status[c] = make_uint4(0, 0, 0, 0);
+}
+
 // One LSD pass over the keys a workgroup holds in registers (wave-striped: wave v owns ITEMS * 64 consecutive positions,
 // item i of lane l is position v * ITEMS * 64 + i * 64 + l; positions >= n hold nothing and stay where they are), through
 // LDS: counters fed by returning LDS atomics, a scan over the bins, re-bucketing, striped read-back.
@@ -2132,11 +2146,12 @@ __device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
 // THREADS = 256: up to 7165 keys per bucket (uniform keys: N <= 1.05e8), 38 KB of LDS, four workgroups per CU;
 // THREADS = 512: up to 14333 keys (N <= 2.1e8), 78 KB, two per CU -- the same 16 waves
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void msd_local_sort_keys_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd) {
+__global__ __launch_bounds__(THREADS, 4) void msd_local_sort_keys_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd, StatusClear sc) {
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * kLeanMaxVec + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
     __shared__ uint32_t s_tmp[32];
     if (msd->ok == 0u) return;  // enqueued before the plan was known, and the plan refused the hybrid form
+    clear_status_share(sc, THREADS);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
     if (n == 0 || mis + n > THREADS * 4u * kLeanMaxVec) return;  // uniform; above the capacity cannot happen (the plan would have refused)
@@ -2327,10 +2342,11 @@ __device__ __forceinline__ void wave_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
     }
 }
 constexpr uint32_t kWaveCap = 64u * 4u * kLeanMaxVec - 3u;  // 1789 keys
-__global__ __launch_bounds__(64, 4) void msd_local_sort_wave_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd) {
+__global__ __launch_bounds__(64, 4) void msd_local_sort_wave_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd, StatusClear sc) {
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[64 * 4 * kLeanMaxVec + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_tbl[kLeanRow];
     if (msd->ok == 0u) return;
+    clear_status_share(sc, 64);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
     if (n == 0 || mis + n > 64u * 4u * kLeanMaxVec) return;
@@ -2351,13 +2367,14 @@ __global__ __launch_bounds__(64, 4) void msd_local_sort_wave_kernel(uint32_t *__
 constexpr int kLocalPairThreads = 512, kLocalPairItems = kLocalCap / kLocalPairThreads;  // 13
 __global__ __launch_bounds__(kLocalPairThreads, 4) void msd_local_sort_pairs_kernel(uint32_t *__restrict__ keys,
                                                                                    uint32_t *__restrict__ values,
-                                                                                   const MsdPlan *__restrict__ msd) {
+                                                                                   const MsdPlan *__restrict__ msd, StatusClear sc) {
     constexpr int WAVES = kLocalPairThreads / 64;
     __shared__ uint32_t s_keys[kLocalCap];
     __shared__ uint32_t s_vals[kLocalCap];
     __shared__ uint32_t s_hist[WAVES << 9];
     __shared__ uint32_t s_tmp[1 + WAVES];
     if (msd->ok == 0u) return;
+    clear_status_share(sc, kLocalPairThreads);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     if (n == 0 || n > kLocalCap) return;
     uint32_t *bucket = keys + begin, *bvals = values + begin;
@@ -2421,12 +2438,13 @@ __device__ __forceinline__ void local_sort_bucket_u64(uint64_t *bucket, uint32_t
 }
 
 __global__ __launch_bounds__(kLocalPairThreads, 4) void msd_local_sort_u64_kernel(uint64_t *__restrict__ keys,
-                                                                                 const MsdPlan *__restrict__ msd) {
+                                                                                 const MsdPlan *__restrict__ msd, StatusClear sc) {
     constexpr int WAVES = kLocalPairThreads / 64;
     __shared__ uint64_t s_keys[kLocalCap];
     __shared__ uint32_t s_hist[WAVES << 9];
     __shared__ uint32_t s_tmp[1 + WAVES];
     if (msd->ok == 0u) return;
+    clear_status_share(sc, kLocalPairThreads);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     if (n == 0 || n > kLocalCap) return;
     const uint32_t passes = (msd->shift + 8u) / 9u;
@@ -2852,23 +2870,26 @@ hipError_t launch_msd_count_u64(hipStream_t stream, const void *keys, uint32_t n
     return hipGetLastError();
 }
 
-hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, const MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev) {
+hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, const MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev,
+                                     uint32_t *clear_status, size_t clear_words) {
     if (max_bucket > kLocalCap) return hipErrorInvalidValue;  // the plan would have refused
-    VRS_LAUNCH(msd_local_sort_u64_kernel, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, static_cast<uint64_t *>(keys), msd);
+    const StatusClear sc{reinterpret_cast<uint4 *>(clear_status), static_cast<uint32_t>(clear_words / 4)};
+    VRS_LAUNCH(msd_local_sort_u64_kernel, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, static_cast<uint64_t *>(keys), msd, sc);
     return hipGetLastError();
 }
 
 hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *values, const MsdPlan *msd, uint32_t max_bucket,
-                                 LaunchEvents ev) {
+                                 LaunchEvents ev, uint32_t *clear_status, size_t clear_words) {
     if (max_bucket > msd_local_capacity(values != nullptr)) return hipErrorInvalidValue;  // the plan would have refused
+    const StatusClear sc{reinterpret_cast<uint4 *>(clear_status), static_cast<uint32_t>(clear_words / 4)};
     if (values != nullptr)
-        VRS_LAUNCH(msd_local_sort_pairs_kernel, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, keys, values, msd);
+        VRS_LAUNCH(msd_local_sort_pairs_kernel, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, keys, values, msd, sc);
     else if (max_bucket <= kWaveCap)
-        VRS_LAUNCH(msd_local_sort_wave_kernel, dim3(kMsdBuckets), dim3(64), stream, ev, keys, msd);
+        VRS_LAUNCH(msd_local_sort_wave_kernel, dim3(kMsdBuckets), dim3(64), stream, ev, keys, msd, sc);
     else if (max_bucket > kLeanCap)
-        VRS_LAUNCH(msd_local_sort_keys_kernel<512>, dim3(kMsdBuckets), dim3(512), stream, ev, keys, msd);
+        VRS_LAUNCH(msd_local_sort_keys_kernel<512>, dim3(kMsdBuckets), dim3(512), stream, ev, keys, msd, sc);
     else
-        VRS_LAUNCH(msd_local_sort_keys_kernel<256>, dim3(kMsdBuckets), dim3(256), stream, ev, keys, msd);
+        VRS_LAUNCH(msd_local_sort_keys_kernel<256>, dim3(kMsdBuckets), dim3(256), stream, ev, keys, msd, sc);
     return hipGetLastError();
 }
 
