@@ -205,6 +205,11 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * behind the sort that reads its result.  vrs_sort_pending tells whether a second half is outstanding (0 / 1).
  */
 int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements);
+/* The same sort for keys the caller knows to lie in [key_floor, 2^32) -- a sub-range of a larger sort (the received key range
+ * of a multi-GPU step): the hybrid form then takes its 16384 buckets from key - (key_floor rounded down to a multiple of 2^24),
+ * as it would for a full key range, instead of finding almost all of them empty and the rest too large.  A hint only: a key
+ * below the floor makes the plan refuse the hybrid form (the LSD passes run) -- the result is the same either way. */
+int vrs_sort_keys_u32_ranged(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements, uint32_t key_floor);
 int vrs_sort_settle(vrs_context ctx);
 int vrs_sort_pending(vrs_context ctx);
 int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
@@ -224,14 +229,16 @@ int vrs_sort_pairs_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vr
  *     histogram is empty and `out` is not a partition), [VRS_MSD_SHIFT_WORD + 1] != 0: a key above the probed range.
  *   vrs_msd_finish_u32: second MSD pass + local sort of n keys that ARE grouped by that top byte (`grouped`; clobbered as
  *     scratch), result in `out`.  counts: the same layout, [0, 16384) = the bucket histogram of exactly these n keys, the
- *     slice counts zero, the shift word set, the flag word zero.  The plan may refuse (a bucket beyond the local sort's
+ *     slice counts zero, the shift word set, the flag word zero.  bucket_hint: the largest bucket to expect (it picks the local
+ *     sort's workgroup shape before the plan is known; 0 = num_elements / 16384 + 10 %).  The plan may refuse (a bucket beyond the local sort's
  *     capacity, top-byte buckets too unequal for the grid): vrs_msd_finish_status waits for the plan's head and tells
  *     (*took == 0: `out` holds nothing useful, `grouped` still holds the keys -- sort them with vrs_sort_keys_u32).
  */
 #define VRS_MSD_COUNT_WORDS (16384u + 8u * 256u + 64u)
 #define VRS_MSD_SHIFT_WORD (16384u + 8u * 256u)
 int vrs_msd_partition_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer out, vrs_buffer counts_out, uint32_t num_elements);
-int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_buffer counts, uint32_t num_elements);
+int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_buffer counts, uint32_t num_elements,
+                       uint32_t bucket_hint);
 int vrs_msd_finish_status(vrs_context ctx, int *took);
 
 /*

@@ -171,3 +171,32 @@ def test_dist_plan_splitters_matches_the_python_orchestration():
                                              out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
             assert rc == 0
             assert np.array_equal(out.astype(np.int64), plan_splitters(counts.astype(np.int64), parts)), (counts[:8], parts)
+
+
+def test_round3_entry_points_reject_null_and_need_no_device(lib):
+    """The enqueue-only sorts' settle / pending calls, the context accessor and the in-process transport hub of the multi-GPU
+    step validate their arguments without touching a device (host-side objects only)."""
+    assert lib.vrs_sort_settle(None) == capi.VRS_ERROR_INVALID_ARGUMENT
+    assert lib.vrs_sort_pending(None) == 0
+    assert lib.vrs_context_device(None) == -1
+    took = ctypes.c_int(7)
+    assert lib.vrs_msd_finish_status(None, ctypes.byref(took)) == capi.VRS_ERROR_INVALID_ARGUMENT
+    hub = ctypes.c_void_p()
+    assert lib.vrs_dist_loopback_create(0, ctypes.byref(hub)) == capi.VRS_ERROR_INVALID_ARGUMENT
+    assert lib.vrs_dist_loopback_create(2, None) == capi.VRS_ERROR_INVALID_ARGUMENT
+    assert lib.vrs_dist_loopback_create(2, ctypes.byref(hub)) == capi.VRS_OK and hub.value
+    tr = capi.DistTransport()
+    assert lib.vrs_dist_loopback_transport(hub, 2, ctypes.byref(tr)) == capi.VRS_ERROR_INVALID_ARGUMENT  # rank out of range
+    assert lib.vrs_dist_loopback_destroy(hub) == capi.VRS_OK
+    assert lib.vrs_dist_loopback_destroy(None) == capi.VRS_OK
+    d = ctypes.c_void_p()
+    assert lib.vrs_dist_create_with_transport(None, None, 0, 1, 1000, 1, ctypes.byref(d)) == capi.VRS_ERROR_INVALID_ARGUMENT
+    assert b"context" in lib.vrs_dist_last_error(None)
+
+
+def test_dist_transport_table_layout():
+    # include/vkradixsort_amd.h: user + seven function pointers, in this order
+    assert ctypes.sizeof(capi.DistTransport) == 8 * ctypes.sizeof(ctypes.c_void_p)
+    assert [f[0] for f in capi.DistTransport._fields_] == ["user", "all_gather", "all_reduce", "group_start", "send", "recv",
+                                                           "group_end", "error_string"]
+    assert capi.MSD_COUNT_WORDS == 16384 + 2048 + 64 and capi.MSD_SHIFT_WORD == 16384 + 2048

@@ -828,3 +828,34 @@ def test_the_wait_for_the_plan_is_bounded():
         assert np.array_equal(kt.cpu().numpy().view(np.uint32), np.sort(keys))
         k0.release()
         k1.release()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("span_bits", [27, 29])
+def test_ranged_sort_buckets_a_sub_range_of_the_key_space(gpu_context, span_bits):
+    """vrs_sort_keys_u32_ranged: keys of a sub-range [floor, floor + 2^span) -- what a rank of the multi-GPU step receives --
+    are bucketed by key - floor, so the hybrid form sees the 16384 evenly filled buckets a full key range would give; a key
+    below the promised floor only costs the hybrid form (the plan refuses), never the result."""
+    ctx, lib = gpu_context, gpu_context.lib
+    n = (1 << 23) + 3
+    floor_key = 0xA3000000 if span_bits == 27 else 0x60000000
+    rs = np.random.RandomState(span_bits)
+    keys = (np.uint32(floor_key) + rs.randint(0, 1 << span_bits, size=n, dtype=np.uint32)).astype(np.uint32)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    try:
+        for stray in (False, True):
+            k = keys.copy()
+            if stray:
+                k[n // 3] = np.uint32(floor_key - 5)
+            k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), k)
+            k1 = vrs.Buffer(ctx, S(4 * n))
+            h0 = hybrid_sorts(ctx)
+            ctx.check(lib.vrs_sort_keys_u32_ranged(ctx.handle, k0.handle, k1.handle, n, floor_key + 12345))  # rounded down to 2^24
+            out = np.empty(n, np.uint32)
+            k0.downloadWithStagingBuffer(out)
+            assert np.array_equal(out, np.sort(k))
+            assert hybrid_sorts(ctx) - h0 == (0 if stray else 1)
+            k0.release()
+            k1.release()
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)

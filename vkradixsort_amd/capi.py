@@ -116,6 +116,7 @@ _SIGNATURES = [
     ("vrs_queue_wait_idle", c_int, [c_void_p]),
     ("vrs_single_radixsort", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_sort_keys_u32", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
+    ("vrs_sort_keys_u32_ranged", c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_uint32]),
     ("vrs_sort_settle", c_int, [c_void_p]),
     ("vrs_sort_pending", c_int, [c_void_p]),
     ("vrs_sort_pairs_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
@@ -133,7 +134,7 @@ _SIGNATURES = [
     ("vrs_dist_loopback_transport", c_int, [c_void_p, c_int, c_void_p]),
     ("vrs_dist_loopback_destroy", c_int, [c_void_p]),
     ("vrs_msd_partition_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
-    ("vrs_msd_finish_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
+    ("vrs_msd_finish_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_uint32]),
     ("vrs_msd_finish_status", c_int, [c_void_p, POINTER(c_int)]),
     ("vrs_context_device", c_int, [c_void_p]),
     ("vrs_dist_sort_keys_u32", c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_void_p), POINTER(c_uint32)]),

@@ -105,6 +105,8 @@ struct vrs_context_t {
         uint32_t blind_passes = 0;
         bool msd_capable = false, fast_count = false, blind_tail = false, no_hybrid = false;
         size_t ev_lb_before = 0, ev_ls_before = 0;
+        uint32_t key_base = 0;      // vrs_sort_keys_u32_ranged: every key is promised to be >= this (a multiple of 2^24)
+        uint32_t bucket_hint = 0;   // blind tail: expected largest bucket (0 = from n); picks the local sort's workgroup shape
     } one_read;
     bool one_read_settling = false;
     uint32_t os_msd_half_stamp = 0;      // stamp of the most recent vrs_msd_finish_u32's plan
@@ -785,7 +787,8 @@ static OneReadGeometry one_read_geometry(vrs_context ctx, const vrs_context_t::O
     // (uniform keys: buckets of N / 16384 +- a few per cent)
     g.local_cap = vrs::msd_local_capacity(pairs || wide);
     if (st.blind_tail && !pairs && !wide) {
-        const uint64_t expect = static_cast<uint64_t>(n) * 11u / 10u / vrs::kMsdBucketCount + 64u;  // uniform keys: N / 16384 + a few per cent
+        // uniform keys: N / 16384 + a few per cent -- unless the caller knows better (a sub-range of a larger sort: vrs_msd_finish_u32)
+        const uint64_t expect = st.bucket_hint ? st.bucket_hint : static_cast<uint64_t>(n) * 11u / 10u / vrs::kMsdBucketCount + 64u;
         if (expect <= vrs::msd_local_capacity_wave()) g.local_cap = vrs::msd_local_capacity_wave();
         else if (expect <= vrs::msd_local_capacity_small()) g.local_cap = vrs::msd_local_capacity_small();
     }
@@ -875,7 +878,8 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
     VRS_HIP(ctx, vrs::launch_msd_pass_b(ctx->stream, st.kptr[home ^ 1u], st.kptr[home],
                                         pairs ? static_cast<const uint32_t *>(st.vptr[home ^ 1u]) : nullptr,
                                         pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr, ctx->os_msd_plan, ctx->os_status,
-                                        tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map, st.key_bytes, ctx->os_spin_budget, ev));
+                                        tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map, st.key_bytes, ctx->os_spin_budget, ev,
+                                        st.key_base));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
     // Launched with the plan known (it said yes), the local sort also clears the look-back status words -- it is LDS-bound and
     // has HBM time to spare, the next sort's counting read does not.  Launched blind it may leave at once: nothing is promised.
@@ -959,7 +963,7 @@ static int one_read_enqueue(vrs_context ctx) {
         else
             VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, st.kptr[st.cur], n, g.group_len, ctx->os_tables, ctx->os_status,
                                                       zero_words, ctx->scatter.compute_units, ctx->os_msd_counts,
-                                                      st.fast_count, ev));
+                                                      st.fast_count, ev, st.key_base));
         VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
                                           ctx->os_host_head_dev, st.stamp, n, g.T, g.tiles_b_cap, g.local_cap, ctx->os_tables,
                                           g.group_len, g.tile_cap, g.blind_cap, g.cuts0, wide ? 2u : st.fast_count ? 1u : 0u,
@@ -988,7 +992,8 @@ static int one_read_enqueue(vrs_context ctx) {
                                                   pairs ? static_cast<const uint32_t *>(st.vptr[c]) : nullptr,
                                                   pairs ? static_cast<uint32_t *>(st.vptr[c ^ 1u]) : nullptr, ctx->os_plan_a, 0,
                                                   vrs::kShiftFromPlan, ctx->os_status, g.tiles0, false, ctx->scatter.atomic_rank,
-                                                  ctx->xcc_map, key_bytes, ctx->os_spin_budget, ctx->os_hold_tile, ev, ctx->os_misplace));
+                                                  ctx->xcc_map, key_bytes, ctx->os_spin_budget, ctx->os_hold_tile, ev, ctx->os_misplace,
+                                                  st.key_base));
     }
     for (uint32_t i = 0; i < st.blind_passes; ++i)
         if ((rc = one_read_lookback_pass(ctx, st, i, 32u * group + 8u * i, i == 0 ? g.tiles0 : g.blind_cap, false))) return rc;
@@ -1114,9 +1119,10 @@ int settle_pending(vrs_context ctx) { return ctx->one_read.active && !ctx->one_r
 extern "C" {
 
 static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values, vrs_buffer values_tmp,
-                         uint32_t n, int key_bytes) {
+                         uint32_t n, int key_bytes, uint32_t key_base) {
     vrs_context_t::OneRead &st = ctx->one_read;
     st = vrs_context_t::OneRead{};
+    st.key_base = key_bytes == 4 ? key_base & 0xFF000000u : 0u;
     st.kptr[0] = keys->ptr;
     st.kptr[1] = keys_tmp->ptr;
     st.vptr[0] = values ? values->ptr : nullptr;
@@ -1135,7 +1141,7 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
 // One-call form: the four passes of MultiRadixSort::execute's hot loop (MultiRadixSort.cpp:50-61) with the
 // library choosing NUM_BLOCKS_PER_WORKGROUP and owning the histogram table.
 static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
-                           vrs_buffer values_tmp, uint32_t n, int key_bytes = 4) {
+                           vrs_buffer values_tmp, uint32_t n, int key_bytes = 4, uint32_t key_base = 0) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     if (n == 0) return VRS_OK;
     const uint32_t B = launch_tile_blocks(key_bytes);
@@ -1168,7 +1174,7 @@ static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp
     // the look-back status words carry 28-bit stream counts; there is no one-call pairs entry point for 64-bit keys
     if (ctx->xcc_map_valid && ctx->one_call_min_keys != 0 && n >= ctx->one_call_min_keys && n < (1u << 30) &&
         (key_bytes == 4 || !values))
-        return sort_one_read(ctx, keys, keys_tmp, values, values_tmp, n, key_bytes);
+        return sort_one_read(ctx, keys, keys_tmp, values, values_tmp, n, key_bytes, key_base);
     if ((rc = ensure_sort_hist(ctx, pc.g_num_workgroups))) return rc;
     for (uint32_t i = 0; i < static_cast<uint32_t>(key_bytes); ++i) {  // one pass per key byte: 4 or 8 (even either way)
         const bool odd = (i & 1u) != 0;
@@ -1183,7 +1189,7 @@ static_assert(VRS_MSD_COUNT_WORDS == vrs::kMsdCountWords && VRS_MSD_SHIFT_WORD =
 
 // ---- the hybrid form in two halves, for callers that move the keys between its two MSD passes (vrs_dist_*: the exchange
 // between the GPUs sits there).  Both halves only enqueue.
-static int msd_half_setup(vrs_context ctx, uint32_t n, vrs_context_t::OneRead *st, OneReadGeometry *g) {
+static int msd_half_setup(vrs_context ctx, uint32_t n, vrs_context_t::OneRead *st, OneReadGeometry *g, uint32_t bucket_hint = 0) {
     if (!ctx->xcc_map_valid || !ctx->atomic_rank_verified || !ctx->scatter.atomic_rank)
         return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the hybrid form needs the look-back placement probe and the LDS-atomic ranking self-test to have passed on this device");
     if (n == 0 || n >= (1u << 30)) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the hybrid form takes 1 .. 2^30 - 1 keys");
@@ -1193,6 +1199,7 @@ static int msd_half_setup(vrs_context ctx, uint32_t n, vrs_context_t::OneRead *s
     st->msd_capable = true;
     st->blind_tail = true;
     st->fast_count = true;
+    st->bucket_hint = bucket_hint;
     *g = one_read_geometry(ctx, *st);
     return one_read_scratch(ctx, *st, *g);
 }
@@ -1231,7 +1238,7 @@ int vrs_msd_partition_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer out, vrs_
     return VRS_OK;
 }
 
-int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_buffer counts, uint32_t n) {
+int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_buffer counts, uint32_t n, uint32_t bucket_hint) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     int rc;
     const size_t bytes = static_cast<size_t>(n) * sizeof(uint32_t);
@@ -1243,7 +1250,7 @@ int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_
     if ((rc = settle_pending(ctx))) return rc;
     vrs_context_t::OneRead st;
     OneReadGeometry g;
-    if ((rc = msd_half_setup(ctx, n, &st, &g))) return rc;
+    if ((rc = msd_half_setup(ctx, n, &st, &g, bucket_hint))) return rc;
     ctx->sub_cache.valid = false;
     if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
     ctx->os_msd_half_stamp = ctx->os_stamp;
@@ -1289,6 +1296,10 @@ int vrs_sort_keys_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uin
 
 int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements) {
     return sort_all_passes(ctx, keys, keys_tmp, nullptr, nullptr, num_elements);
+}
+
+int vrs_sort_keys_u32_ranged(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements, uint32_t key_floor) {
+    return sort_all_passes(ctx, keys, keys_tmp, nullptr, nullptr, num_elements, 4, key_floor);
 }
 
 int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,

@@ -118,6 +118,7 @@ constexpr int kRowCapacity = kRowSlices + 2;
 constexpr int kRowShift = kRowSlices + 3;   // hybrid shape: the probed bucket shift ...
 constexpr int kRowOver = kRowSlices + 4;    // ... and != 0: a key of the shard lies above the probed range
 constexpr int kRowWords = kRowSlices + 8;
+constexpr uint64_t kHybridShapeMaxBucket = 14333;  // msd_local_capacity of bare uint32 keys (vrs_kernels.hip)
 
 }  // namespace
 
@@ -606,6 +607,11 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         if (r[kRowN] < (1u << 16) || r[kRowShift] != shift || r[kRowOver] != 0u) hybrid = false;  // too small to have been partitioned, another key range, a stray key
     }
     if (hybrid && (shift < 13u || shift > 18u)) hybrid = false;  // (no keys at all: 0xFFFFFFFF)
+    // the hybrid shape's buckets are the top 14 bits of the GLOBAL key range: N_total / 16384 keys each, whatever the number
+    // of ranks -- they must fit the local sort (14333 keys: about 2e8 keys in total).  Larger totals take the byte shape,
+    // whose per-range sorts bucket each received sub-range on its own (vrs_sort_keys_u32_ranged).
+    const uint64_t bucket_expect = grand_total / 16384u + grand_total / 16384u / 8u + 64u;
+    if (hybrid && bucket_expect > kHybridShapeMaxBucket) hybrid = false;
     (void)partitioned;
 
     // top-byte counts per rank (hybrid shape: sums over the eight slices; byte shape: filled in below) and their prefixes
@@ -790,7 +796,7 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
             VRS_DHIP(d, hipMemsetAsync(round_counts, 0, static_cast<size_t>(VRS_MSD_COUNT_WORDS) * 4, d->sort_stream));
             VRS_DHIP(d, hipMemcpyAsync(round_counts + lo * 64u, reduced + lo * 64u, static_cast<size_t>(hi - lo) * 64 * 4, hipMemcpyDeviceToDevice, d->sort_stream));
             VRS_DHIP(d, hipMemcpyAsync(round_counts + VRS_MSD_SHIFT_WORD, &d->host_row_tail[4], 4, hipMemcpyHostToDevice, d->sort_stream));
-            rc = vrs_msd_finish_u32(ctx, view, sview, d->round_counts, static_cast<uint32_t>(cnt));
+            rc = vrs_msd_finish_u32(ctx, view, sview, d->round_counts, static_cast<uint32_t>(cnt), static_cast<uint32_t>(bucket_expect));
             int took = 0;
             if (rc == VRS_OK) rc = vrs_msd_finish_status(ctx, &took);  // waits for the plan's head (the round has landed by then; never for the sort)
             if (rc == VRS_OK && took) {
@@ -806,7 +812,9 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
             }
         }
         if (!done) {
-            rc = vrs_sort_keys_u32(ctx, view, sview, static_cast<uint32_t>(cnt));
+            // every key of the round is >= its first top byte << 24: the sort buckets the sub-range as if it were a whole key range
+            const uint32_t floor_key = parts[static_cast<size_t>(me) * R + r] << 24;
+            rc = vrs_sort_keys_u32_ranged(ctx, view, sview, static_cast<uint32_t>(cnt), floor_key);
             // hybrid shape: the step's output is the scratch buffer
             if (rc == VRS_OK && hybrid) rc = vrs_buffer_copy(ctx, sview, view, cnt * 4);
         }

@@ -157,7 +157,7 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
                                    uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
                                    uint32_t *status, uint32_t grid_tiles, bool forced, bool atomic_rank,
                                    unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, int hold_tile,
-                                   LaunchEvents ev = {}, bool misplace = false);
+                                   LaunchEvents ev = {}, bool misplace = false, uint32_t key_base = 0);
 // ---- hybrid form of the one-call sort (K5b, uint32 keys): MSD partition by the top 14 bits in two look-back passes,
 // then one workgroup per bucket sorts the low 18 bits inside LDS.
 constexpr uint32_t kMsdBucketCount = 1u << 14;
@@ -177,7 +177,7 @@ constexpr uint32_t kShiftFromPlan = 0xFFFFFFFFu;  // launch_onesweep_scatter: ta
 // the hybrid form can take gets ONLY the bucket histogram -- launch_msd_plan must be told the same
 hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *tables,
                                    uint32_t *status, size_t status_words, int compute_units, uint32_t *msd_counts,
-                                   bool msd_only, LaunchEvents ev = {});
+                                   bool msd_only, LaunchEvents ev = {}, uint32_t key_base = 0);
 // ONE workgroup: the plan of the four LSD passes (what launch_plan does, 8 groups), then the hybrid form's: bucket
 // offsets, the first MSD pass's seeds (into plan_a->group_seed[0]) and streams, the second pass's tile tables; decides
 // msd_ok (key range 27-32 bits and fully probed, largest bucket <= the local sort's capacity, XCD tile counts <=
@@ -193,7 +193,10 @@ hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *ms
 // values_in / values_out: uint32 payloads that follow their keys (nullptr: keys only)
 hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                              uint32_t *values_out, const MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
-                             unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev = {});
+                             unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev = {}, uint32_t key_base = 0);
+// key_base (uint32 keys of the hybrid form only): the caller promises keys >= key_base (a multiple of 2^24); buckets and MSD
+// digits are taken from key - key_base, so a sub-range of the key space gets the same 16384 buckets a full range would;
+// a key below it makes the counting read flag the sort and the plan refuse the hybrid form
 // 64-bit keys: the counting read of the hybrid form (bucket histogram + top-byte counts of the 8 input slices only; zeroes
 // the status words) and the local sort of every bucket by its low msd->shift bits (ceil(shift / 9) LDS passes)
 hipError_t launch_msd_count_u64(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *status,

@@ -101,7 +101,11 @@ struct KeyVec<uint64_t> {
 template <typename K>
 struct RadixDigit {
     uint32_t shift;
-    __device__ __forceinline__ uint32_t operator()(K key) const { return digit_of(key, shift); }
+    K base = 0;  // the first MSD pass of a sort whose keys are known to start at `base` (vrs_sort_keys_u32_ranged): digit of key - base
+    __device__ __forceinline__ uint32_t operator()(K key) const { return digit_of(static_cast<K>(key - base), shift); }
+    // the key a ragged tile is padded with: it must carry the largest digit under every shift (it then ranks behind every real key)
+    template <typename KK>
+    __device__ __forceinline__ KK pad() const { return static_cast<KK>(base - static_cast<K>(1)); }
 };
 template <typename K>
 struct SplitDigit {
@@ -117,6 +121,8 @@ struct SplitDigit {
         }
         return pos;
     }
+    template <typename KK>
+    __device__ __forceinline__ KK pad() const { return static_cast<KK>(~static_cast<KK>(0)); }
 };
 // stage `count` splitters into LDS (all threads of the workgroup call this; ends with a barrier)
 template <typename K>
@@ -672,10 +678,10 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
         if constexpr (FULL) {
             key[i] = kin[idx];
         } else {
-            // unpredicated load from a clamped index, then select: the all-ones padding key has digit 255
-            // under every shift and the highest chunk indices, so it ranks behind every real key
+            // unpredicated load from a clamped index, then select: the padding key (all ones, seen from the digit's base) has
+            // the largest digit under every shift and the highest chunk indices, so it ranks behind every real key
             const K k = kin[idx < valid ? idx : valid - 1u];
-            key[i] = idx < valid ? k : static_cast<K>(~static_cast<K>(0));
+            key[i] = idx < valid ? k : dg.template pad<K>();
         }
     }
     uint32_t val[PAIRS ? ITEMS : 1];
@@ -996,7 +1002,7 @@ __device__ __forceinline__ uint32_t digit_word(uint64_t key, uint32_t base_shift
 // hm: the 16384-bin histogram of the key's top 14 bits (hybrid form, K5b), or nullptr; t0: nullptr = no LSD tables
 template <typename TI>
 __device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t *hm,
-                                                   uint32_t msd_shift, uint32_t &msd_over, uint32_t w) {
+                                                   uint32_t msd_shift, uint32_t msd_base, uint32_t &msd_over, uint32_t w) {
     if (t0) {  // workgroup-uniform: nullptr when only the bucket histogram is counted (hybrid form, fast count)
         atomicAdd(&t0[TI::t0(w, lane_id())], 1u);
         atomicAdd(&t1[TI::t1(w)], 1u);
@@ -1004,8 +1010,8 @@ __device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, u
         atomicAdd(&t3[TI::t3(w)], 1u);
     }
     if (hm) {
-        const uint32_t b = w >> msd_shift;
-        msd_over |= b >> kMsdBits;  // a key above the probed range: the plan will refuse the hybrid form
+        const uint32_t b = (w - msd_base) >> msd_shift;
+        msd_over |= (b >> kMsdBits) | (w < msd_base ? 1u : 0u);  // a key above the probed range (or below the promised floor): the plan will refuse the hybrid form
         atomicAdd(&hm[min(b, kMsdBuckets - 1u)], 1u);
     }
 }
@@ -1013,7 +1019,7 @@ __device__ __forceinline__ void digit_tables_count(uint32_t *t0, uint32_t *t1, u
 // one 16-byte vector of keys per lane: 4 uint32 or 2 uint64.  vote: bit t = table t takes the run-length form
 template <typename K, typename TI, bool VOTE, bool MSD>
 __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t1, uint32_t *t2, uint32_t *t3, uint32_t *hm,
-                                                       uint32_t msd_shift, uint32_t &msd_over,
+                                                       uint32_t msd_shift, uint32_t msd_base, uint32_t &msd_over,
                                                        const typename KeyVec<K>::type &q, uint32_t base_shift,
                                                        uint32_t lane, uint32_t &vote) {
     constexpr int V = KeyVec<K>::kKeys;
@@ -1022,8 +1028,9 @@ __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t
             uint32_t im[V];
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                const uint32_t b = digit_word(KeyVec<K>::get(q, j), base_shift) >> msd_shift;
-                msd_over |= b >> kMsdBits;
+                const uint32_t w = digit_word(KeyVec<K>::get(q, j), base_shift);
+                const uint32_t b = (w - msd_base) >> msd_shift;
+                msd_over |= (b >> kMsdBits) | (w < msd_base ? 1u : 0u);
                 im[j] = min(b, kMsdBuckets - 1u);
             }
             if constexpr (VOTE) vote = table_vote<V>(im) ? 16u : 0u;
@@ -1040,8 +1047,8 @@ __device__ __forceinline__ void digit_tables_count_vec(uint32_t *t0, uint32_t *t
         i2[j] = TI::t2(w);
         i3[j] = TI::t3(w);
         if constexpr (MSD) {
-            const uint32_t b = w >> msd_shift;
-            msd_over |= b >> kMsdBits;
+            const uint32_t b = (w - msd_base) >> msd_shift;
+            msd_over |= (b >> kMsdBits) | (w < msd_base ? 1u : 0u);
             im[j] = min(b, kMsdBuckets - 1u);
         }
     }
@@ -1205,7 +1212,8 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
                                                                     uint32_t slices, uint32_t *__restrict__ tables,
                                                                     uint4 *__restrict__ status, uint32_t status_vecs,
                                                                     FusedPlanArgs fp, uint32_t *__restrict__ msd_hist,
-                                                                    uint32_t *__restrict__ msd_slices, uint32_t msd_only) {
+                                                                    uint32_t *__restrict__ msd_slices, uint32_t msd_only,
+                                                                    uint32_t msd_base) {
     using Vec = typename KeyVec<K>::type;
     using TI = TableIndex<GROUPS, COPIES>;
     constexpr uint32_t V = KeyVec<K>::kKeys;
@@ -1229,7 +1237,7 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
         const uint32_t samples = min(n, 4096u);
         const uint64_t stride = n / samples;  // >= 1
         uint32_t acc = 0;
-        for (uint32_t i = tid; i < samples; i += THREADS) acc |= digit_word(keys[static_cast<uint64_t>(i) * stride], base_shift);
+        for (uint32_t i = tid; i < samples; i += THREADS) acc |= digit_word(keys[static_cast<uint64_t>(i) * stride], base_shift) - msd_base;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) acc |= __shfl_down(acc, o);
         if (lane == 0u && acc) atomicOr(&s_or, acc);
@@ -1265,7 +1273,7 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
         // allocation; every slice starts a multiple of V keys after it)
         const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) / sizeof(K)) % V);
         const uint32_t head = min((V - mis) % V, len);
-        if (tid < head) digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, msd_shift, msd_over, digit_word(keys[begin + tid], base_shift));
+        if (tid < head) digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, msd_shift, msd_base, msd_over, digit_word(keys[begin + tid], base_shift));
         const Vec *v = reinterpret_cast<const Vec *>(keys + begin + head);
         const uint32_t nvec = (len - head) / V;
         constexpr uint32_t kStep = THREADS * UNROLL;
@@ -1295,19 +1303,19 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
                 cur[r] = v[refill + r * THREADS + tid];
                 __builtin_amdgcn_sched_barrier(0);
                 if (r == 0)
-                    digit_tables_count_vec<K, TI, true, MSD>(t0, t[0], t[1], t[2], hm, msd_shift, msd_over, x, base_shift, lane, vote);
+                    digit_tables_count_vec<K, TI, true, MSD>(t0, t[0], t[1], t[2], hm, msd_shift, msd_base, msd_over, x, base_shift, lane, vote);
                 else
-                    digit_tables_count_vec<K, TI, false, MSD>(t0, t[0], t[1], t[2], hm, msd_shift, msd_over, x, base_shift, lane, vote);
+                    digit_tables_count_vec<K, TI, false, MSD>(t0, t[0], t[1], t[2], hm, msd_shift, msd_base, msd_over, x, base_shift, lane, vote);
             }
         }
         for (uint32_t i = i0 + tid; i < nvec; i += THREADS) {
             const Vec q = v[i];
 #pragma unroll
             for (int j = 0; j < static_cast<int>(V); ++j)
-                digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, msd_shift, msd_over, digit_word(KeyVec<K>::get(q, j), base_shift));
+                digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, msd_shift, msd_base, msd_over, digit_word(KeyVec<K>::get(q, j), base_shift));
         }
         const uint32_t tail = head + nvec * V + tid;  // at most V - 1 keys
-        if (tail < len) digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, msd_shift, msd_over, digit_word(keys[begin + tail], base_shift));
+        if (tail < len) digit_tables_count<TI>(t0, t[0], t[1], t[2], hm, msd_shift, msd_base, msd_over, digit_word(keys[begin + tail], base_shift));
     }
     __syncthreads();
     if (t0 != nullptr) {
@@ -1378,7 +1386,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
                                                                        uint32_t pass, int forced, uint32_t shift,
                                                                        uint32_t *__restrict__ status,
                                                                        unsigned long long xcc_map, int misplace,
-                                                                       uint32_t spin_budget, int hold_tile) {
+                                                                       uint32_t spin_budget, int hold_tile, uint32_t key_base) {
     constexpr uint32_t kTile = ITEMS * WAVES * 64;  // the tile the plan counted with (onesweep_tile_keys)
     __shared__ ChunkSmem<K, ITEMS, WAVES, PAIRS> sm;
     const uint32_t k = blockIdx.x >> 3, i = k / (kStreams / 8);
@@ -1395,6 +1403,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     const uint32_t valid = min(kTile, sd.len - done);
     RadixDigit<K> dg;
     dg.shift = shift == kShiftFromPlan ? plan->head.msd_shift_a : shift;  // first MSD pass of the hybrid form: set by msd_plan_kernel
+    dg.base = shift == kShiftFromPlan ? static_cast<K>(key_base) : static_cast<K>(0);
     StreamLookback lb;
     // byte x of xcc_map = XCC of the blocks with blockIdx % 8 == x (probed); my stream's tiles sit in blocks = s (mod 8)
     lb.foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * (s & 7u))) & 0xFFu);
@@ -1433,9 +1442,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
 
 // a digit of fewer than 8 bits: (key >> shift) & mask
 struct BitsDigit {
-    uint32_t shift, mask;
-    __device__ __forceinline__ uint32_t operator()(uint32_t key) const { return (key >> shift) & mask; }
+    uint32_t shift, mask, base;  // base: see RadixDigit (uint32 keys only)
+    __device__ __forceinline__ uint32_t operator()(uint32_t key) const { return ((key - base) >> shift) & mask; }
     __device__ __forceinline__ uint32_t operator()(uint64_t key) const { return static_cast<uint32_t>(key >> shift) & mask; }
+    template <typename KK>
+    __device__ __forceinline__ KK pad() const { return sizeof(KK) == 4 ? static_cast<KK>(base - 1u) : static_cast<KK>(~static_cast<KK>(0)); }
 };
 
 // Hybrid form for 64-bit keys: the counting read.  Same workgroup -> slice mapping as digit_tables_kernel with 8 groups; ONLY
@@ -1682,7 +1693,7 @@ template <typename K, int ITEMS, int RANK, bool PAIRS>
 __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                             const uint32_t *__restrict__ values_in, uint32_t *__restrict__ values_out,
                                                             const MsdPlan *__restrict__ msd, uint32_t *__restrict__ status,
-                                                            unsigned long long xcc_map, uint32_t spin_budget) {
+                                                            unsigned long long xcc_map, uint32_t spin_budget, uint32_t key_base) {
     constexpr uint32_t kTile = ITEMS * 8 * 64;  // the tile the plan counted with (onesweep_tile_keys)
     __shared__ ChunkSmem<K, ITEMS, 8, PAIRS> sm;
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
@@ -1697,7 +1708,7 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
     const uint32_t done = i * kTile;
     const uint32_t begin = first + done;
     const uint32_t valid = min(kTile, last - begin);
-    BitsDigit dg{msd->shift, kMsdSub - 1u};
+    BitsDigit dg{msd->shift, kMsdSub - 1u, key_base};
     StreamLookback lb;
     lb.foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * x)) & 0xFFu);
     lb.stream_keys = keys_in + first;
@@ -2805,7 +2816,7 @@ template <typename K, int GROUPS, int THREADS, int COPIES, int UNROLL, int OCC, 
 static void launch_digit_tables_variant(hipStream_t stream, const void *keys, uint32_t n, uint32_t base_shift,
                                         uint32_t group_len, uint32_t *tables, uint32_t *status, size_t status_words,
                                         int compute_units, LaunchEvents ev, const FusedPlanArgs &fp,
-                                        uint32_t *msd_counts = nullptr, uint32_t msd_only = 0) {
+                                        uint32_t *msd_counts = nullptr, uint32_t msd_only = 0, uint32_t msd_base = 0) {
     // one workgroup per (pass-0 group, slice): a power-of-two number of slices that fills the chip once
     const uint32_t wgs = static_cast<uint32_t>(compute_units) * (OCC * 256 / THREADS);
     uint32_t slices = floor_pow2(wgs / GROUPS > 0 ? wgs / GROUPS : 1u);
@@ -2819,15 +2830,15 @@ static void launch_digit_tables_variant(hipStream_t stream, const void *keys, ui
     const uint32_t vecs = static_cast<uint32_t>(status_words / 4);
     VRS_LAUNCH((digit_tables_kernel<K, GROUPS, THREADS, COPIES, UNROLL, OCC, MSD>), grid, block, stream, ev,
                static_cast<const K *>(keys), n, base_shift, group_len, slices, tables, reinterpret_cast<uint4 *>(status), vecs,
-               fp, msd_counts, msd_counts ? msd_counts + kMsdBuckets : nullptr, msd_only);
+               fp, msd_counts, msd_counts ? msd_counts + kMsdBuckets : nullptr, msd_only, msd_base);
 }
 
 hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *tables,
                                    uint32_t *status, size_t status_words, int compute_units, uint32_t *msd_counts,
-                                   bool msd_only, LaunchEvents ev) {
+                                   bool msd_only, LaunchEvents ev, uint32_t key_base) {
     launch_digit_tables_variant<uint32_t, 8, 1024, 32, VRS_DT_UNROLL, 4, true>(stream, keys, n, 0, group_len, tables, status,
                                                                                status_words, compute_units, ev,
-                                                                               FusedPlanArgs{}, msd_counts, msd_only ? 1u : 0u);
+                                                                               FusedPlanArgs{}, msd_counts, msd_only ? 1u : 0u, key_base);
     return hipGetLastError();
 }
 
@@ -2842,13 +2853,13 @@ hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *ms
 
 hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                              uint32_t *values_out, const MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
-                             unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev) {
+                             unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev, uint32_t key_base) {
     if (tiles_b == 0) return hipSuccess;
     if (key_bytes == 8 && values_in != nullptr) return hipErrorInvalidValue;
     const dim3 grid(8 * tiles_b), block(512);
 #define VRS_PASS_B(K, ITEMS, RANK, PAIRS)                                                                                  \
     VRS_LAUNCH((msd_pass_b_kernel<K, ITEMS, RANK, PAIRS>), grid, block, stream, ev, static_cast<const K *>(keys_in),         \
-               static_cast<K *>(keys_out), values_in, values_out, msd, status, xcc_map, spin_budget)
+               static_cast<K *>(keys_out), values_in, values_out, msd, status, xcc_map, spin_budget, key_base)
     if (key_bytes == 8) {
         if (atomic_rank) VRS_PASS_B(uint64_t, 8, RANK_ATOMIC, false); else VRS_PASS_B(uint64_t, 8, RANK_BALLOT, false);
     } else if (values_in != nullptr) {
@@ -2960,7 +2971,7 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
                                    uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
                                    uint32_t *status, uint32_t grid_tiles, bool forced, bool atomic_rank,
                                    unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, int hold_tile,
-                                   LaunchEvents ev, bool misplace) {
+                                   LaunchEvents ev, bool misplace, uint32_t key_base) {
     const int mis = misplace ? 1 : 0, force = forced ? 1 : 0;
     if (grid_tiles == 0) return hipSuccess;
     const dim3 grid(kStreams * grid_tiles), block(64 * VRS_LB_WAVES);
@@ -2968,7 +2979,7 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
 #define VRS_ONESWEEP(K, ITEMS, PAIRS, RANK)                                                                           \
     VRS_LAUNCH((onesweep_scatter_kernel<K, ITEMS, VRS_LB_WAVES, PAIRS, RANK, 4>), grid, block, stream, ev,            \
                static_cast<const K *>(keys_in), static_cast<K *>(keys_out), values_in, values_out, plan, pass, force,  \
-               shift, status, xcc_map, mis, spin_budget, hold_tile)
+               shift, status, xcc_map, mis, spin_budget, hold_tile, key_base)
     if (key_bytes == 8) {
         if (pairs) return hipErrorInvalidValue;  // no one-call pairs entry point for 64-bit keys
         if (atomic_rank) VRS_ONESWEEP(uint64_t, 8, false, RANK_ATOMIC); else VRS_ONESWEEP(uint64_t, 8, false, RANK_BALLOT);
