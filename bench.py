@@ -805,7 +805,9 @@ def bench_multi(args):
         # pass per received sub-range (each reads and writes its keys once); byte shape = the launches of the local sorts
         lb_bytes = 8.0 * (n + recv_keys) * K if hybrid else 8.0 * (recv_keys / max(rounds, 1)) * lb_launches
         lb_achieved = lb_bytes / (lb_ms * 1e-3) / 1e9 if lb_ms > 0 else None
-        sort_bpk = 28 if hybrid else 48
+        # byte shape: 12 (contract partition pass) + what vrs_sort_keys_u32_ranged moves per received sub-range: 28 in its hybrid
+        # form (from 1.3e7 keys on), 36 in its LSD form
+        sort_bpk = 28 if hybrid else (40 if recv_keys / max(rounds, 1) >= 1.3e7 else 48)
         base = None
         if not args.no_cpu_baseline:
             from tests import _oracle
@@ -826,8 +828,9 @@ def bench_multi(args):
                        "path": ("vrs_dist_sort_keys_u32, hybrid shape: counting read + first MSD pass of the shard, one all-gather + one "
                                 "all-reduce of counts, RCCL send/recv of one message per (sender, top byte) in "
                                 f"{rounds} round(s), second MSD pass + LDS-local sort per received sub-range") if hybrid else
-                               ("vrs_dist_sort_keys_u32, byte shape: contract partition pass by the top byte, RCCL send/recv per "
-                                f"(sender, round) in {rounds} round(s), vrs_sort_keys_u32 per received sub-range"),
+                               ("vrs_dist_sort_keys_u32, byte shape (the global top-14-bit buckets would not fit the local sort): contract "
+                                f"partition pass by the top byte, RCCL send/recv per (sender, round) in {rounds} round(s), "
+                                "vrs_sort_keys_u32_ranged per received sub-range (its own 16384 buckets)"),
                        "num_elements_per_gpu": n, "parallelism": f"range-sharded x{world}", "exchange_rounds": rounds,
                        "rounds_tried_in_warmup_ms": {str(k): round(v * 1e3, 3) for k, v in tried.items()},
                        "received_sub_ranges": {"finished_in_hybrid_shape": int(hybrid_rounds), "sorted_from_scratch_after_a_refused_plan": int(fallback_rounds)},
@@ -835,7 +838,7 @@ def bench_multi(args):
                        "hbm_bytes_per_key_breakdown": ({"counting_read": 4, "first_msd_pass": 8, "exchange_read_and_landing_write": 8,
                                                         "second_msd_pass": 8, "local_sort": 8} if hybrid else
                                                        {"partition_pass": 12, "exchange_read_and_landing_write": 8,
-                                                        "local_sorts": "28-36 by sub-range size"})},
+                                                        "local_sorts": sort_bpk - 12})},
             "roofline": {"bound": "hbm", "kernel": "lookback_scatter (rank 0's launches in the timed region: the first MSD pass over the "
                                                    "shard and the second pass over every received sub-range)",
                          "achieved": round(lb_achieved, 1) if lb_achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1911,11 +1911,21 @@ __device__ __forceinline__ void local_sort_bucket(uint32_t *bucket, uint32_t *bu
 //  * the same-counter guard of local_pass (a whole instruction on one counter: constant digits) costs 16 us at 10^8 uniform
 //    keys when compiled into every item, so it is switched per bucket and pass: every wave looks at its first vector row, and
 //    only a bucket in which some instruction has half its lanes on one counter runs the guarded form.
+// the value unchanged, but opaque to the optimiser: used to make it RECOMPUTE a counter address (two VALU instructions)
+// instead of keeping 28 of them alive from the returning adds to the base reads -- the registers that decide between 119 and
+// "128 + spills to scratch" (scratch traffic is HBM traffic: 230 MB per launch at 10^8 keys, profiles/labs/r03_local_sort_spills.txt)
+__device__ __forceinline__ uint32_t opaque(uint32_t x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 constexpr int kLeanRow = 512 + 64;  // words per counter table: 512 digits + one dummy per lane for slots without a key
 constexpr int kLeanMaxVec = 7;      // 16-byte vectors per thread: capacity THREADS * 28 slots
 template <int THREADS, int VEC, bool GUARD>
 __device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
                                                uint32_t *s_hist2, uint32_t *s_tmp, bool guard1, bool guard2);
+template <int THREADS, int VEC>
+__device__ __attribute__((noinline)) void lean_sort_guarded(uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *s_hist2,
+                                                           uint32_t *s_tmp, uint32_t guards);
 
 template <int THREADS, int VEC>
 __device__ __forceinline__ void lean_sort_bucket(uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *s_hist2,
@@ -1957,9 +1967,33 @@ __device__ __forceinline__ void lean_sort_bucket(uint32_t *abase, uint32_t mis, 
 #pragma unroll
     for (int v = 0; v < WAVES; ++v) guards |= s_tmp[16 + v];
     guards = __builtin_amdgcn_readfirstlane(guards);
-    // two copies of the rest: the guarded one keeps the flags, the common one carries no trace of the guard (registers!)
+#ifdef VRS_LAB_NO_LOCAL_GUARD  // lab builds: the guarded copy compiled away
+    guards = 0;
+#endif
+    // Two copies of the rest.  The common one is inlined and carries no trace of the guard; the guarded one is a CALL that loads
+    // the bucket again -- kept out of line so that its register demand cannot push the common path into scratch spills (spills
+    // are HBM traffic: with both inlined the kernel moved 1032 instead of 800 MB per launch at 10^8 keys).
     if (guards == 0u) lean_sort_body<THREADS, VEC, false>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false);
-    else lean_sort_body<THREADS, VEC, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, (guards & 1u) != 0u, (guards & 2u) != 0u);
+    else lean_sort_guarded<THREADS, VEC>(abase, mis, n, s_keys, s_hist2, s_tmp, guards);
+}
+
+template <int THREADS, int VEC>
+__device__ __attribute__((noinline)) void lean_sort_guarded(uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *s_hist2,
+                                                           uint32_t *s_tmp, uint32_t guards) {
+    constexpr int ITEMS = 4 * VEC;
+    const uint32_t nvec = (mis + n + 3u) / 4u;
+    uint32_t k[ITEMS];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        uint32_t v = j * THREADS + threadIdx.x;
+        if (j == VEC - 1) v = v < nvec ? v : nvec - 1u;
+        const uint4 t = reinterpret_cast<const uint4 *>(abase)[v];
+        k[4 * j] = t.x;
+        k[4 * j + 1] = t.y;
+        k[4 * j + 2] = t.z;
+        k[4 * j + 3] = t.w;
+    }
+    lean_sort_body<THREADS, VEC, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, (guards & 1u) != 0u, (guards & 2u) != 0u);
 }
 
 template <int THREADS, int VEC, bool GUARD>
@@ -2024,7 +2058,7 @@ __device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
     for (int j = 0; j < VEC; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            uint32_t a = (k[4 * j + c] << 2) & 0x7FCu;
+            uint32_t a = (opaque(k[4 * j + c]) << 2) & 0x7FCu;
             if (j == 0 || j == VEC - 1) {
                 // a slot behind the bucket keeps its place (position q: mis + n slots lie before the first of them, mis of those
                 // without a key), the ones before the bucket follow the keys (position n + q)
@@ -2119,7 +2153,7 @@ __device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        uint32_t a = (k[i] >> 7) & 0x7FCu;
+        uint32_t a = (opaque(k[i]) >> 7) & 0x7FCu;
         if (i >= kFirstMaybeEmpty) {  // a slot without a key stays where it is: slot mis + L
             const uint32_t L = seg + i * 64 + lane;
             a = L < n ? a : 2048u + 4u * lane;
@@ -2209,6 +2243,9 @@ __device__ __forceinline__ void wave_scan512(uint32_t *tbl, uint32_t lane, uint3
 template <int VEC, bool GUARD>
 __device__ __forceinline__ void wave_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
                                                uint32_t *tbl, bool guard1, bool guard2);
+template <int VEC>
+__device__ __attribute__((noinline)) void wave_sort_guarded(uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *tbl,
+                                                           uint32_t skew);
 
 template <int VEC>
 __device__ __forceinline__ void wave_sort_bucket(uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *tbl) {
@@ -2243,7 +2280,27 @@ __device__ __forceinline__ void wave_sort_bucket(uint32_t *abase, uint32_t mis, 
     skew = __builtin_amdgcn_readfirstlane(skew);
     wave_phase();
     if (skew == 0u) wave_sort_body<VEC, false>(k, abase, mis, n, s_keys, tbl, false, false);
-    else wave_sort_body<VEC, true>(k, abase, mis, n, s_keys, tbl, (skew & 1u) != 0u, (skew & 2u) != 0u);
+    else wave_sort_guarded<VEC>(abase, mis, n, s_keys, tbl, skew);  // out of line, loads the bucket again: see lean_sort_bucket
+}
+
+template <int VEC>
+__device__ __attribute__((noinline)) void wave_sort_guarded(uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *tbl,
+                                                           uint32_t skew) {
+    constexpr int ITEMS = 4 * VEC;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nvec = (mis + n + 3u) / 4u;
+    uint32_t k[ITEMS];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        uint32_t v = j * 64 + lane;
+        if (j == VEC - 1) v = v < nvec ? v : nvec - 1u;
+        const uint4 t = reinterpret_cast<const uint4 *>(abase)[v];
+        k[4 * j] = t.x;
+        k[4 * j + 1] = t.y;
+        k[4 * j + 2] = t.z;
+        k[4 * j + 3] = t.w;
+    }
+    wave_sort_body<VEC, true>(k, abase, mis, n, s_keys, tbl, (skew & 1u) != 0u, (skew & 2u) != 0u);
 }
 
 template <int VEC, bool GUARD>
@@ -2286,7 +2343,7 @@ __device__ __forceinline__ void wave_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
     wave_phase();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        uint32_t a = (k[i] << 2) & 0x7FCu;
+        uint32_t a = (opaque(k[i]) << 2) & 0x7FCu;
         if (i < 4 || i >= ITEMS - 4) {
             const uint32_t q = 4u * ((i >> 2) * 64 + lane) + (i & 3);
             const bool valid = q - mis < n;
@@ -2327,7 +2384,7 @@ __device__ __forceinline__ void wave_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t L = i * 64 + lane;
-        uint32_t a = (k[i] >> 7) & 0x7FCu;
+        uint32_t a = (opaque(k[i]) >> 7) & 0x7FCu;
         a = L < n ? a : 2048u + 4u * lane;
         const uint32_t r = rank[i] + *reinterpret_cast<const uint32_t *>(tb + a);
         rank[i] = L < n ? r : 4u * (mis + L);
