@@ -20,7 +20,7 @@ for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
         us = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
         # the one-call sort enqueues its candidate first passes before the plan is known; the one the plan disarms leaves
         # at once (all its workgroups read one word and exit): listed apart, it is not a pass over the keys
-        if "onesweep_scatter_kernel" in name and us < 20.0:
+        if "onesweep_scatter_kernel" in name and us < 10.0:
             name += " [speculative launch the plan disarmed: left at once]"
         dur[name].append(us)
 total = sum(sum(v) for v in dur.values())
