@@ -158,3 +158,15 @@ def test_two_ranks_a_shard_above_its_capacity_fails_on_both():
     res = run_ranks(shards, 1, capacity=1200000)
     assert all(rc == capi.VRS_ERROR_PEER for rc, _ in res[0][0]), res[0][0]
     assert all(rc == capi.VRS_ERROR_INVALID_ARGUMENT for rc, _ in res[1][0]), res[1][0]
+
+
+def test_cpp_host_drives_the_step_over_the_loopback_transport():
+    """distsortexample: the step from a C++ host through the C ABI alone -- one std::thread per rank, the in-process transport --
+    verified the reference's way (equal to std::sort of all keys, MultiRadixSort.cpp:141-161)."""
+    import subprocess
+    from vkradixsort_amd import build
+    exe = build.build_dist_example()
+    for args in (["2", "1500000", "2"], ["3", "700001", "1", "7"], ["2", "40000", "1"]):
+        p = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "[DistSort] Test passed." in p.stdout

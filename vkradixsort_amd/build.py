@@ -73,7 +73,20 @@ def build_host(force: bool = False):
         if force or _stale(exe, [src, out_lib] + hdrs):
             _run([cxx, *common, src, "-o", exe, f"-L{PKG_DIR}", "-lvkradixsort_host", *link])
         exes.append(exe)
+    build_dist_example(force)
     return out_lib, exes
+
+
+def build_dist_example(force: bool = False) -> Path:
+    """g++ -> distsortexample: the multi-GPU step from a C++ host, one thread per rank over the in-process transport (C ABI only)."""
+    build_library(force)
+    src = HOST / "bin" / "DistSortExample.cpp"
+    exe = PKG_DIR / "distsortexample"
+    if force or _stale(exe, [src, LIB_PATH, INCLUDE / "vkradixsort_amd.h"]):
+        cxx = shutil.which("g++") or "g++"
+        _run([cxx, "-O2", "-std=c++20", "-pthread", f"-I{INCLUDE}", src, "-o", exe, f"-L{PKG_DIR}", "-lvkradixsort_amd",
+              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
 
 
 def build_host_logic_test(force: bool = False) -> Path:
