@@ -215,7 +215,9 @@ int vrs_sort_pending(vrs_context ctx);
 int vrs_sort_pairs_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
                        vrs_buffer values_tmp, uint32_t num_elements);
 int vrs_sort_keys_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements); /* 8 LSD passes, or the hybrid form */
-/* uint64 keys with uint32 payloads: always the eight contract passes (no look-back form). */
+/* uint64 keys with uint32 payloads: two groups of [counting read + four look-back scatter passes] from
+ * VRS_TUNE_ONE_CALL_MIN_KEYS pairs on (2 x (8 + 4 x 24) = 208 instead of 8 x (8 + 24) = 256 bytes per pair), the eight contract passes
+ * below; stable either way.  No hybrid form. */
 int vrs_sort_pairs_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vrs_buffer values,
                        vrs_buffer values_tmp, uint32_t num_elements);
 

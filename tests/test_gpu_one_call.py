@@ -185,10 +185,14 @@ def test_one_read_pairs_are_stable(gpu_context, oracle, dist):
         b.release()
 
 
-def test_one_call_pairs_u64(gpu_context):
-    """uint64 keys + uint32 payloads in one call: the eight contract passes, stable."""
+@pytest.mark.parametrize("shift,min_keys", [(40, capi.ONE_CALL_MIN_KEYS_DEFAULT), (40, 0), (0, capi.ONE_CALL_MIN_KEYS_DEFAULT), (17, capi.ONE_CALL_MIN_KEYS_DEFAULT)])
+def test_one_call_pairs_u64(gpu_context, shift, min_keys):
+    """uint64 keys + uint32 payloads in one call, stable: two groups of [counting read + four look-back passes] (round 3), or the
+    eight contract passes below the one-call threshold (min_keys 0 = never the look-back form); 24-bit values (plenty of ties, six
+    identity passes), full 64-bit keys, 47-bit keys."""
     ctx, lib, n = gpu_context, gpu_context.lib, 1300001
-    keys = make_keys64(n, "uniform") >> np.uint64(40)  # 24-bit values: plenty of ties
+    ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, min_keys)
+    keys = make_keys64(n, "uniform") >> np.uint64(shift)
     vals = np.arange(n, dtype=np.uint32)
     k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(8 * n), keys)
     v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
@@ -197,6 +201,7 @@ def test_one_call_pairs_u64(gpu_context):
     ok, ov = np.empty(n, np.uint64), np.empty(n, np.uint32)
     k0.downloadWithStagingBuffer(ok)
     v0.downloadWithStagingBuffer(ov)
+    ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, capi.ONE_CALL_MIN_KEYS_DEFAULT)
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(ok, keys[order]) and np.array_equal(ov, vals[order])
     for b in (k0, k1, v0, v1):

@@ -34,7 +34,9 @@ def run(gpu, keys, vals, reps):
                 v0.copyFrom(vsrc)
             gpu.waitIdle()
             t0 = time.perf_counter()
-            if vals is not None:
+            if vals is not None and kb == 8:
+                gpu.check(lib.vrs_sort_pairs_u64(gpu.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+            elif vals is not None:
                 gpu.check(lib.vrs_sort_pairs_u32(gpu.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
             elif kb == 8:
                 gpu.check(lib.vrs_sort_keys_u64(gpu.handle, k0.handle, k1.handle, n))
@@ -72,6 +74,8 @@ def main():
         result["10^8 sorted uint32 keys"] = run(gpu, np.sort(k8), None, reps)
         k64 = (k8.astype(np.uint64) << np.uint64(32)) | k8[::-1].astype(np.uint64)
         result["10^8 uint64 keys (SORT_64_BIT)"] = run(gpu, k64, None, max(3, reps // 2))
+        n5 = 5 * 10 ** 7
+        result["5 x 10^7 uint64 key + uint32 payload pairs"] = run(gpu, k64[:n5].copy(), np.arange(n5, dtype=np.uint32), max(3, reps // 2))
     print(json.dumps(result, indent=1))
 
 

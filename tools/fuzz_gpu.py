@@ -66,7 +66,7 @@ def main():
             ctx.setTuning(capi.VRS_TUNE_RANK_MODE, mode)
             ctx.setTuning(capi.VRS_TUNE_FUSED_PREFIX, int(rs.randint(0, 2)))
             ctx.setTuning(capi.VRS_TUNE_XCD_REMAP, int(rs.randint(0, 2)))
-            one_call = rs.randint(0, 3) == 0 and not (bits64 and pairs)  # no one-call pairs entry point for 64-bit keys
+            one_call = rs.randint(0, 3) == 0
             if one_call:
                 n = int(rs.choice([rs.randint(1, 20000), rs.randint(1, 3000000), rs.randint(1000000, 9000000), rs.randint(4200000, 12000000)]))
                 if not bits64 and not pairs and rs.randint(0, 12) == 0:
@@ -99,7 +99,8 @@ def main():
                 if pairs:
                     v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
                     v1 = vrs.Buffer(ctx, S(4 * n))
-                    ctx.check(lib.vrs_sort_pairs_u32(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+                    sort_pairs = lib.vrs_sort_pairs_u64 if bits64 else lib.vrs_sort_pairs_u32
+                    ctx.check(sort_pairs(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
                 elif bits64:
                     ctx.check(lib.vrs_sort_keys_u64(ctx.handle, k0.handle, k1.handle, n))
                 else:

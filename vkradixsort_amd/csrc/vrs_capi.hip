@@ -1171,9 +1171,8 @@ static int sort_all_passes(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp
                                         n, ev));
         return VRS_OK;
     }
-    // the look-back status words carry 28-bit stream counts; there is no one-call pairs entry point for 64-bit keys
-    if (ctx->xcc_map_valid && ctx->one_call_min_keys != 0 && n >= ctx->one_call_min_keys && n < (1u << 30) &&
-        (key_bytes == 4 || !values))
+    // the look-back status words carry 28-bit stream counts
+    if (ctx->xcc_map_valid && ctx->one_call_min_keys != 0 && n >= ctx->one_call_min_keys && n < (1u << 30))
         return sort_one_read(ctx, keys, keys_tmp, values, values_tmp, n, key_bytes, key_base);
     if ((rc = ensure_sort_hist(ctx, pc.g_num_workgroups))) return rc;
     for (uint32_t i = 0; i < static_cast<uint32_t>(key_bytes); ++i) {  // one pass per key byte: 4 or 8 (even either way)

@@ -3037,8 +3037,9 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
     VRS_LAUNCH((onesweep_scatter_kernel<K, ITEMS, VRS_LB_WAVES, PAIRS, RANK, 4>), grid, block, stream, ev,            \
                static_cast<const K *>(keys_in), static_cast<K *>(keys_out), values_in, values_out, plan, pass, force,  \
                shift, status, xcc_map, mis, spin_budget, hold_tile, key_base)
-    if (key_bytes == 8) {
-        if (pairs) return hipErrorInvalidValue;  // no one-call pairs entry point for 64-bit keys
+    if (key_bytes == 8 && pairs) {  // uint64 keys + uint32 payloads: 4096-pair tiles (32 KB of keys + 16 KB of payloads in LDS)
+        if (atomic_rank) VRS_ONESWEEP(uint64_t, 8, true, RANK_ATOMIC); else VRS_ONESWEEP(uint64_t, 8, true, RANK_BALLOT);
+    } else if (key_bytes == 8) {
         if (atomic_rank) VRS_ONESWEEP(uint64_t, 8, false, RANK_ATOMIC); else VRS_ONESWEEP(uint64_t, 8, false, RANK_BALLOT);
     } else if (pairs) {
         if (atomic_rank) VRS_ONESWEEP(uint32_t, VRS_LB_ITEMS, true, RANK_ATOMIC); else VRS_ONESWEEP(uint32_t, VRS_LB_ITEMS, true, RANK_BALLOT);
