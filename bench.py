@@ -480,24 +480,28 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
-def bench_multi_python(args):
-    """N > 1 through the Python orchestration (vkradixsort_amd/distributed.py over torch.distributed): --dist-path python."""
+def bench_multi_python(args, fallback_reason=None):
+    """N > 1 through the Python orchestration (vkradixsort_amd/distributed.py over torch.distributed): --dist-path python, and the
+    fallback of the C path should its set-up fail on any rank (fallback_reason: the process group is up already)."""
     import torch
     import torch.distributed as dist
 
     from vkradixsort_amd.distributed import HipLocalSortBackend, RangeShardedSort
 
-    rank = int(os.environ["RANK"])
-    world = int(os.environ["WORLD_SIZE"])
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    with _StdoutToStderr():
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        warm = torch.zeros(8, dtype=torch.int64, device=dev)
-        dist.all_reduce(warm)  # brings the communicator up (and its banner out) now
-        torch.cuda.synchronize()
+    if fallback_reason is None:
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            warm = torch.zeros(8, dtype=torch.int64, device=dev)
+            dist.all_reduce(warm)  # brings the communicator up (and its banner out) now
+            torch.cuda.synchronize()
     # run the sort on a non-blocking stream of its own: work on the legacy null stream would implicitly serialise
     # with every blocking stream, and the exchange of round r+1 (RCCL's stream) is meant to overlap the sort of round r
     work_stream = torch.cuda.Stream(device=dev)
@@ -612,6 +616,7 @@ def bench_multi_python(args):
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{world} x {n} uniform random uint32 keys (std::mt19937 seed 1000+rank), sharded by key "
                                    f"range: top-byte partition pass, RCCL all-to-all over xGMI, local 4-pass multi_radixsort (one-call form)",
+                       "fallback_from_the_c_path_because": fallback_reason,
                        "num_elements_per_gpu": n, "num_blocks_per_workgroup": B, "parallelism": f"range-sharded x{world}",
                        "exchange_rounds": sorter.rounds, "rounds_tried_in_warmup_ms": {str(k): round(v * 1e3, 3) for k, v in tried.items()},
                        "hbm_bytes_per_key": 48,
@@ -727,12 +732,28 @@ def bench_multi(args):
     max_rounds = max(1, 32 // min(world, 32))
     want = min(args.rounds, max_rounds)
     candidates = [want] if (world == 1 or args.rounds_forced) else list(dict.fromkeys(r for r in (want, 2, 1) if r <= max_rounds))
-    handles = {r: make_dist(r) for r in candidates}
-    tried = {}
-    for r, d in handles.items():  # set-up, not a step: first use allocates scratch and loads the code objects
-        step(d, batches[0])
-        gpu.waitIdle()
-        batches[0].copyFrom(pristine)
+    # set-up, not a step: first use allocates scratch and loads the code objects.  Should it fail on ANY rank (no RCCL to bind, a
+    # transport error), every rank learns so and the run goes through the Python orchestration instead -- a number from the other
+    # path is worth more than none; config.path says which path ran.
+    handles, tried, failure = {}, {}, None
+    try:
+        handles = {r: make_dist(r) for r in candidates}
+        for r, d in handles.items():
+            step(d, batches[0])
+            gpu.waitIdle()
+            batches[0].copyFrom(pristine)
+    except Exception as e:  # noqa: BLE001 -- reported and agreed on below
+        failure = repr(e)
+    flag = torch.tensor([0 if failure else 1], dtype=torch.int64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        print(f"[bench] rank {rank}: the C path's set-up failed ({failure or 'on another rank'}); falling back to --dist-path python", file=sys.stderr)
+        for h in handles.values():
+            lib.vrs_dist_destroy(h)
+        for b in batches + [pristine]:
+            b.release()
+        gpu.shutdown()
+        return bench_multi_python(args, fallback_reason=failure or "another rank failed")
     if len(candidates) > 1:
         for r, d in handles.items():
             barrier()
