@@ -78,7 +78,8 @@ def _worker(rank, world, port, n_per_rank, mode, q, rounds=4):
                 base = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
                 return torch.from_numpy(k[order].view(np.int32).copy()), base
 
-            def sort(self, keys, n):
+            def sort(self, keys, n, key_floor=0):
+                assert n == 0 or int(keys[:n].numpy().view(np.uint32).min()) >= key_floor  # the hint must hold
                 k = np.sort(keys[:n].numpy().view(np.uint32))
                 keys[:n] = torch.from_numpy(k.view(np.int32))
                 return keys

@@ -78,8 +78,9 @@ class LocalSortBackend:
         int64[len(splitters) + 2] with the total appended)"""
         raise NotImplementedError
 
-    def sort(self, keys, n: int):
-        """-> sorted keys tensor (first n entries)"""
+    def sort(self, keys, n: int, key_floor: int = 0):
+        """-> sorted keys tensor (first n entries).  key_floor: every key is >= this (a hint the product backend hands to
+        vrs_sort_keys_u32_ranged: a received sub-range is bucketed from its own first key, not from 0)"""
         raise NotImplementedError
 
 
@@ -186,16 +187,17 @@ class HipLocalSortBackend(LocalSortBackend):
         spb.release()
         return self.grouped, np.concatenate([first[:sp.size + 1].astype(np.int64), [n]])
 
-    def sort(self, keys, n):
+    def sort(self, keys, n, key_floor=0):
         if n == 0:
             return keys
         if n > self.capacity or keys.numel() < n:
             raise ValueError("received more keys than the backend capacity")
-        # the library's own four-pass loop (one counting read + look-back scatters from 2^13 keys on); the result is
-        # back in `keys`, `scratch` is the ping-pong partner
+        # the library's own loop over the passes (one counting read + look-back scatters from 2^13 keys on, the hybrid form
+        # from 1.3e7 keys on -- bucketed from key_floor, so a sub-range of the key space fills its 16384 buckets evenly); the
+        # result is back in `keys`, `scratch` is the ping-pong partner
         ctx = self.ctx
         k, t = self._handles(keys, self.scratch)
-        ctx.check(ctx.lib.vrs_sort_keys_u32(ctx.handle, k, t, n))
+        ctx.check(ctx.lib.vrs_sort_keys_u32_ranged(ctx.handle, k, t, n, int(key_floor) & 0xFFFFFFFF))
         return keys
 
 
@@ -270,6 +272,7 @@ class RangeShardedSort:
         base = np.concatenate([[0], np.cumsum(all_counts[me])]).astype(np.int64)  # my own prefix, back from the table
         # world*R parts of (almost) equal size; part q*R + r = rank q, round r
         parts = plan_splitters(all_counts.sum(axis=0), world * R)
+        floors = np.minimum(parts[:-1].astype(np.int64), 255) << 24  # part p starts at top byte parts[p]
         bounds = parts[::R]
         per_rank = np.array([all_counts[:, bounds[q]:bounds[q + 1]].sum() for q in range(world)], dtype=np.int64)
         ideal = max(int(all_counts.sum()) / world, 1.0)
@@ -294,6 +297,7 @@ class RangeShardedSort:
             dist.all_gather_into_tensor(table2, mine2, group=self.group)
             all_counts = table2.cpu().numpy().reshape(world, P)
             parts = np.arange(P + 1, dtype=np.int64)
+            floors = np.concatenate([[0], splitters.astype(np.int64)])  # first key value of every range
             bounds = parts[::R]
         send_counts = (base[bounds[1:]] - base[bounds[:-1]]).astype(np.int64)
         # what I receive in round r from source s, and where it lands: rounds ascending, sources ascending
@@ -334,6 +338,6 @@ class RangeShardedSort:
             cnt = int(round_total[r])
             if cnt:
                 off = int(round_off[r])
-                self.backend.sort(self.recv[off:off + cnt], cnt)
+                self.backend.sort(self.recv[off:off + cnt], cnt, int(floors[me * R + r]))
             pending = nxt
         return StepResult(self.recv, total, bounds, send_counts, recv_rs.sum(axis=0))
