@@ -599,6 +599,10 @@ def bench_multi_python(args, fallback_reason=None):
         # times per sub-range, the hybrid form twice)
         lb_bytes = 8 * (recv_keys / max(sorter.rounds, 1)) * lb_launches
         lb_achieved = lb_bytes / (lb_ms * 1e-3) / 1e9 if lb_ms > 0 else None
+        # the form the per-range sorts took, read off the launch count: two look-back passes per range = hybrid (28 B/key)
+        passes_per_range = lb_launches / max(K * max(sorter.rounds, 1), 1)
+        sort_bpk = 28 if passes_per_range <= 2.5 else 36
+        step_bpk = 12 + sort_bpk
         base = None
         if not args.no_cpu_baseline:
             from tests import _oracle
@@ -615,25 +619,27 @@ def bench_multi_python(args, fallback_reason=None):
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{world} x {n} uniform random uint32 keys (std::mt19937 seed 1000+rank), sharded by key "
-                                   f"range: top-byte partition pass, RCCL all-to-all over xGMI, local 4-pass multi_radixsort (one-call form)",
+                                   f"range: top-byte partition pass, RCCL all-to-all over xGMI, one ranged one-call sort per received sub-range",
                        "fallback_from_the_c_path_because": fallback_reason,
                        "num_elements_per_gpu": n, "num_blocks_per_workgroup": B, "parallelism": f"range-sharded x{world}",
                        "exchange_rounds": sorter.rounds, "rounds_tried_in_warmup_ms": {str(k): round(v * 1e3, 3) for k, v in tried.items()},
-                       "hbm_bytes_per_key": 48,
+                       "hbm_bytes_per_key": step_bpk,
                        "hbm_bytes_per_key_breakdown": {"partition_pass_histogram_read": 4, "partition_pass_scatter": 8,
-                                                       "local_sorts_counting_read": 4, "local_sorts_four_lookback_scatters": 32,
-                                                       "note": "sub-ranges of 4e7 keys or more take the 28-byte hybrid form "
-                                                               "(two look-back scatters + the LDS-local bucket sort): 40 in total"}},
+                                                       "local_sorts": sort_bpk,
+                                                       "local_sort_form": ("hybrid: counting read 4 + two look-back scatters 16 + "
+                                                                           "LDS-local bucket sort 8" if sort_bpk == 28 else
+                                                                           "LSD: counting read 4 + four look-back scatters 32"),
+                                                       "lookback_passes_per_range_sort": round(passes_per_range, 2)}},
             "roofline": {"bound": "hbm", "kernel": "lookback_scatter of the local sorts (rank 0's launches in the timed region)",
                          "achieved": round(lb_achieved, 1) if lb_achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(lb_achieved / HBM_PEAK_GBS, 4) if lb_achieved else None,
                          "launches": lb_launches, "avg_launch_us": round(lb_ms / lb_launches * 1e3, 2) if lb_launches else None,
                          "algorithmic_bytes_per_launch": round(lb_bytes / lb_launches) if lb_launches else None,
                          "traffic": None},
-            "step_roofline": {"bytes_per_key": 48, "achieved_GBps_per_gpu": round(48 * n * K / elapsed / 1e9, 1),
-                              "frac_of_peak": round(48 * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4),
-                              "note": "per GPU, whole step incl. the xGMI exchange: 12 B/key partition pass + 36 B/key "
-                                      "local sorts (one counting read + four look-back scatter passes per received sub-range)"},
+            "step_roofline": {"bytes_per_key": step_bpk, "achieved_GBps_per_gpu": round(step_bpk * n * K / elapsed / 1e9, 1),
+                              "frac_of_peak": round(step_bpk * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+                              "note": f"per GPU, whole step incl. the xGMI exchange: 12 B/key partition pass + {sort_bpk} B/key "
+                                      "ranged sorts of the received sub-ranges"},
             "shard_sizes": [x[2] for x in g],
             "verified": check,
         }
