@@ -186,7 +186,7 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * uint32 keys from 1.3 * 10^7 keys on, uint32 key + payload pairs from 2.5 * 10^7 pairs on (VRS_TUNE_HYBRID,
  * VRS_TUNE_HYBRID_MIN_KEYS):
  * the same counting read also histograms the top 14 bits of the key range, and when every such bucket fits one workgroup's
- * LDS (14333 keys or 6656 pairs; uniform keys: up to about 2.2 * 10^8 keys, 1.03 * 10^8 pairs) the four LSD passes are
+ * LDS (14333 keys, 13312 pairs or 64-bit keys; uniform input: up to about 2.2 * 10^8 keys, 2.1 * 10^8 pairs) the four LSD passes are
  * replaced by an MSD partition in two look-back scatter passes (8 + 6 bits) plus one pass in which every bucket is sorted
  * inside LDS -- 28 bytes per key instead of 36, 52 per pair instead of 68 (DESIGN.md "K5b").  The choice is made on the
  * device from that one read; either form gives the same bits, payloads of equal keys in input order included.

@@ -629,20 +629,42 @@ def test_hybrid_form_pairs_are_stable(gpu_context, oracle, n, dist):
     assert took == (1 if fits else 0), (dist, shift)
 
 
-@pytest.mark.parametrize("mode", ["keys", "pairs"])
+@pytest.mark.parametrize("mode", ["keys", "pairs", "u64", "pairs_too_large"])
 def test_hybrid_form_with_buckets_beyond_the_small_local_sort(gpu_context, mode):
-    """Buckets of 7166-14333 keys take the 512-thread local sort (keys only; pairs of that size fall back to the LSD
-    passes).  Three of four top-14-bit buckets are empty here, so 3.6e7 keys fill the others with about 8800 each."""
-    ctx, n = gpu_context, 36000001
+    """Buckets of 7166-14333 keys take the 512-thread local sort, buckets of 6657-13312 pairs or 64-bit keys the 1024-thread
+    one (what uniform inputs of 10^8 to 2 * 10^8 elements have).  Three of four top-14-bit buckets are empty here, so 3.6e7
+    keys fill the others with about 8800 each; 5.6e7 pairs fill them with 13700: refused, the LSD passes run."""
+    ctx, lib = gpu_context, gpu_context.lib
+    n = 56000001 if mode == "pairs_too_large" else 36000001
     keys = make_keys(n, "uniform", seed=23) & np.uint32(0xFFF3FFFF)
-    assert capi.LOCAL_SORT_SMALL_KEYS < int(np.bincount(keys >> np.uint32(18), minlength=1 << 14).max()) <= capi.LOCAL_SORT_MAX_KEYS
+    largest = int(np.bincount(keys >> np.uint32(18), minlength=1 << 14).max())
+    if mode == "keys":
+        assert capi.LOCAL_SORT_SMALL_KEYS < largest <= capi.LOCAL_SORT_MAX_KEYS
+    elif mode == "pairs_too_large":
+        assert largest > capi.LOCAL_SORT_MAX_PAIRS
+    else:
+        assert capi.LOCAL_SORT_SMALL_PAIRS < largest <= capi.LOCAL_SORT_MAX_PAIRS
     ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID, 1)  # forgets an earlier refusal of a 64-bit sort
     h0 = hybrid_sorts(ctx)
     try:
         if mode == "keys":
             out, stats = sort_keys(ctx, keys)
             assert np.array_equal(out, np.sort(keys))
             assert stats["local_sort"] == 1 and stats["lookback_scatter"] == 2
+        elif mode == "u64":
+            low = make_keys(n, "uniform", seed=24).astype(np.uint64)
+            keys64 = (keys.astype(np.uint64) << np.uint64(32)) | low
+            k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(8 * n), keys64)
+            k1 = vrs.Buffer(ctx, S(8 * n))
+            try:
+                ctx.check(lib.vrs_sort_keys_u64(ctx.handle, k0.handle, k1.handle, n))
+                out = np.empty(n, np.uint64)
+                k0.downloadWithStagingBuffer(out)
+            finally:
+                k0.release()
+                k1.release()
+            assert np.array_equal(out, np.sort(keys64))
         else:
             vals = np.arange(n, dtype=np.uint32)
             ok, ov = sort_pairs_once(ctx, keys, vals)
@@ -650,7 +672,7 @@ def test_hybrid_form_with_buckets_beyond_the_small_local_sort(gpu_context, mode)
             assert np.array_equal(ok, keys[order]) and np.array_equal(ov, vals[order])
     finally:
         ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
-    assert hybrid_sorts(ctx) - h0 == (1 if mode == "keys" else 0)
+    assert hybrid_sorts(ctx) - h0 == (0 if mode == "pairs_too_large" else 1)
 
 
 def make_hybrid_keys64(n, dist, seed):

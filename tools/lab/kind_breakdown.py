@@ -26,6 +26,8 @@ kb = keys.itemsize
 with vrs.GPUContext(0) as gpu:
     S = vrs.Buffer.BufferSettings
     lib = gpu.lib
+    if os.environ.get("VRS_NO_HYBRID"):
+        gpu.setTuning(capi.VRS_TUNE_HYBRID, 0)
     src = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(kb * n), keys)
     k0, k1 = vrs.Buffer(gpu, S(kb * n)), vrs.Buffer(gpu, S(kb * n))
     if pairs:

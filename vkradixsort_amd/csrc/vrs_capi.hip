@@ -786,11 +786,16 @@ static OneReadGeometry one_read_geometry(vrs_context ctx, const vrs_context_t::O
     // the local sort's capacity per bucket; launched blind, the workgroup shape of bare uint32 keys is chosen from N alone
     // (uniform keys: buckets of N / 16384 +- a few per cent)
     g.local_cap = vrs::msd_local_capacity(pairs || wide);
-    if (st.blind_tail && !pairs && !wide) {
+    if (st.blind_tail) {
         // uniform keys: N / 16384 + a few per cent -- unless the caller knows better (a sub-range of a larger sort: vrs_msd_finish_u32)
         const uint64_t expect = st.bucket_hint ? st.bucket_hint : static_cast<uint64_t>(n) * 11u / 10u / vrs::kMsdBucketCount + 64u;
-        if (expect <= vrs::msd_local_capacity_wave()) g.local_cap = vrs::msd_local_capacity_wave();
-        else if (expect <= vrs::msd_local_capacity_small()) g.local_cap = vrs::msd_local_capacity_small();
+        if (pairs || wide) {
+            if (expect <= vrs::msd_local_capacity_pairs_small()) g.local_cap = vrs::msd_local_capacity_pairs_small();
+        } else if (expect <= vrs::msd_local_capacity_wave()) {
+            g.local_cap = vrs::msd_local_capacity_wave();
+        } else if (expect <= vrs::msd_local_capacity_small()) {
+            g.local_cap = vrs::msd_local_capacity_small();
+        }
     }
     g.rows = static_cast<size_t>(S) * std::max(g.tile_cap, st.msd_capable ? g.tiles_b_cap : 0u);  // status rows: one region for all passes (tagged words)
     return g;
@@ -906,7 +911,7 @@ static int one_read_enqueue(vrs_context ctx) {
         // (default 1.3e7 keys, 2.5e7 pairs, 2e7 64-bit keys: below, the fixed costs of the 16384-bin counting read and of a
         // launch per bucket outweigh the saved pass -- measured crossovers, profiles/labs/r03_hybrid_by_size.txt,
         // r02_hybrid_pairs.txt, r02_hybrid_u64.txt); above
-        // about 2.3 * 10^8 uniform keys (1.03 * 10^8 pairs) the largest bucket no longer fits a workgroup's LDS and the plan
+        // about 2.3 * 10^8 uniform keys (2.1 * 10^8 pairs or 64-bit keys) the largest bucket no longer fits a workgroup's LDS and the plan
         // says no.  Its local sort ranks with returning LDS atomics, so the lane-order self-test must have passed.
         // 64-bit keys: the counting read never makes LSD tables (their LSD form counts twice anyway), so a refusal always
         // starts over; after one, only every 16th such sort of the context tries again.

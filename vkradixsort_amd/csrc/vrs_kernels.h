@@ -210,7 +210,8 @@ hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *v
 // keys the local sort of one bucket can hold (the plan refuses the hybrid form when a bucket has more)
 uint32_t msd_local_capacity_small();  // bare uint32 keys, 256-thread workgroup: 7165
 uint32_t msd_local_capacity_wave();   // bare uint32 keys, one wave per bucket: 1789
-uint32_t msd_local_capacity(bool pairs_or_wide);  // pairs and 64-bit keys: 6656, uint32 keys: 14333
+uint32_t msd_local_capacity(bool pairs_or_wide);  // pairs and 64-bit keys: 13312, uint32 keys: 14333
+uint32_t msd_local_capacity_pairs_small();         // pairs and 64-bit keys, 512-thread workgroup (two per CU): 6656
 
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups
 hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks);

@@ -1760,9 +1760,12 @@ __device__ __forceinline__ void clear_status_share(const StatusClear &sc, uint32
 template <int THREADS, int ITEMS, int BITS, bool PAIRS, bool STABLE, typename K = uint32_t>
 __device__ __forceinline__ void local_pass(K (&key)[ITEMS], uint32_t (&val)[PAIRS ? ITEMS : 1], K *s_keys,
                                            uint32_t *s_vals, uint32_t *s_hist, uint32_t *s_tmp, uint32_t shift, uint32_t n) {
-    constexpr int WAVES = THREADS / 64, BINS = 1 << BITS, TABLES = STABLE ? WAVES : 1, PER = BINS / THREADS;
-    static_assert(PER >= 1 && PER * THREADS == BINS, "every thread scans PER whole bins");
+    // thread t scans bins [t * PER, (t + 1) * PER); a workgroup of more threads than bins (1024 threads, 512 bins: the large
+    // buckets of pairs and 64-bit keys) leaves its upper waves out of the scan
+    constexpr int WAVES = THREADS / 64, BINS = 1 << BITS, TABLES = STABLE ? WAVES : 1, PER = BINS >= THREADS ? BINS / THREADS : 1;
+    static_assert(PER * THREADS == BINS || (PER == 1 && THREADS % BINS == 0), "every scanning thread owns PER whole bins");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool scans = THREADS <= BINS || tid < static_cast<uint32_t>(BINS);  // wave-uniform
     for (uint32_t c = tid; c < TABLES * BINS; c += THREADS) s_hist[c] = 0;
     __syncthreads();
     uint32_t *my = s_hist + (STABLE ? wave * BINS : 0u);
@@ -1799,7 +1802,7 @@ __device__ __forceinline__ void local_pass(K (&key)[ITEMS], uint32_t (&val)[PAIR
             } else {
 #pragma unroll
                 for (int p_ = 0; p_ < PER; ++p_) {
-                    c[v][p_] = s_hist[v * BINS + tid * PER + p_];
+                    c[v][p_] = scans ? s_hist[v * BINS + tid * PER + p_] : 0u;
                     total += c[v][p_];
                 }
             }
@@ -1830,7 +1833,8 @@ __device__ __forceinline__ void local_pass(K (&key)[ITEMS], uint32_t (&val)[PAIR
                 reinterpret_cast<uint2 *>(s_hist + v * BINS)[tid] = make_uint2(out[v][0], out[v][1]);
             } else {
 #pragma unroll
-                for (int p_ = 0; p_ < PER; ++p_) s_hist[v * BINS + tid * PER + p_] = out[v][p_];
+                for (int p_ = 0; p_ < PER; ++p_)
+                    if (scans) s_hist[v * BINS + tid * PER + p_] = out[v][p_];
             }
         }
     }
@@ -2431,34 +2435,39 @@ __global__ __launch_bounds__(64, 4) void msd_local_sort_wave_kernel(uint32_t *__
 }
 
 // Key + payload pairs: the payload doubles a bucket's LDS footprint (53 + 16 KB), so two workgroups of 512 threads x up
-// to 13 pairs share a CU.
+// to 13 pairs share a CU.  Buckets of up to twice that (inputs of 10^8 to 2 * 10^8 pairs) get ONE workgroup of 1024 threads
+// per CU (106 + 32 KB).
 constexpr int kLocalPairThreads = 512, kLocalPairItems = kLocalCap / kLocalPairThreads;  // 13
-__global__ __launch_bounds__(kLocalPairThreads, 4) void msd_local_sort_pairs_kernel(uint32_t *__restrict__ keys,
-                                                                                   uint32_t *__restrict__ values,
-                                                                                   const MsdPlan *__restrict__ msd, StatusClear sc) {
-    constexpr int WAVES = kLocalPairThreads / 64;
-    __shared__ uint32_t s_keys[kLocalCap];
-    __shared__ uint32_t s_vals[kLocalCap];
+constexpr int kLocalPairThreadsBig = 1024;
+constexpr uint32_t kLocalCapBig = kLocalPairThreadsBig * kLocalPairItems;  // 13312
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void msd_local_sort_pairs_kernel(uint32_t *__restrict__ keys,
+                                                                                         uint32_t *__restrict__ values,
+                                                                                         const MsdPlan *__restrict__ msd, StatusClear sc) {
+    constexpr int WAVES = THREADS / 64;
+    constexpr uint32_t CAP = THREADS * kLocalPairItems;
+    __shared__ uint32_t s_keys[CAP];
+    __shared__ uint32_t s_vals[CAP];
     __shared__ uint32_t s_hist[WAVES << 9];
     __shared__ uint32_t s_tmp[1 + WAVES];
     if (msd->ok == 0u) return;
-    clear_status_share(sc, kLocalPairThreads);
+    clear_status_share(sc, THREADS);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
-    if (n == 0 || n > kLocalCap) return;
+    if (n == 0 || n > CAP) return;
     uint32_t *bucket = keys + begin, *bvals = values + begin;
-    const uint32_t used = (n + kLocalPairThreads - 1u) / kLocalPairThreads;
-    if (used <= 2) local_sort_bucket<kLocalPairThreads, 2, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-    else if (used <= 4) local_sort_bucket<kLocalPairThreads, 4, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-    else if (used <= 6) local_sort_bucket<kLocalPairThreads, 6, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-    else if (used <= 8) local_sort_bucket<kLocalPairThreads, 8, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-    else if (used <= 10) local_sort_bucket<kLocalPairThreads, 10, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-    else if (used <= 12) local_sort_bucket<kLocalPairThreads, 12, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-    else local_sort_bucket<kLocalPairThreads, kLocalPairItems, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    const uint32_t used = (n + THREADS - 1u) / THREADS;
+    if (used <= 2) local_sort_bucket<THREADS, 2, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 4) local_sort_bucket<THREADS, 4, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 6) local_sort_bucket<THREADS, 6, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 8) local_sort_bucket<THREADS, 8, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 10) local_sort_bucket<THREADS, 10, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 12) local_sort_bucket<THREADS, 12, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else local_sort_bucket<THREADS, kLocalPairItems, true>(bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
 }
 
 // 64-bit keys: the bucket's keys differ only in their low `shift` bits (up to 50): ceil(shift / 9) LDS passes, the first in any
 // order of ties, the others stable -- or, when that is more than four, the top four and a check (see below).  512 threads x up to 13 keys (8 bytes each: the footprint of the pairs kernel).
-template <int ITEMS>
+template <int THREADS, int ITEMS>
 __device__ __forceinline__ void local_sort_bucket_u64(uint64_t *bucket, uint32_t n, uint32_t passes, uint64_t *s_keys,
                                                       uint32_t *s_hist, uint32_t *s_tmp) {
     constexpr int BITS = 9;
@@ -2476,9 +2485,9 @@ __device__ __forceinline__ void local_sort_bucket_u64(uint64_t *bucket, uint32_t
         // 36 bits (three digits are not enough: 23 bits below the bucket's own, two ties per bucket of 6000 uniform keys) -- and
         // look whether that already is the order of the whole keys (neighbours compared in LDS).  Only a bucket with a pair
         // still out of order runs all the passes, from the bottom.
-        local_pass<kLocalPairThreads, ITEMS, BITS, false, false, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, BITS * (passes - 4u), n);
+        local_pass<THREADS, ITEMS, BITS, false, false, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, BITS * (passes - 4u), n);
         for (uint32_t p_ = passes - 3u; p_ < passes; ++p_)
-            local_pass<kLocalPairThreads, ITEMS, BITS, false, true, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, BITS * p_, n);
+            local_pass<THREADS, ITEMS, BITS, false, true, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, BITS * p_, n);
         int bad = 0;
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -2494,9 +2503,9 @@ __device__ __forceinline__ void local_sort_bucket_u64(uint64_t *bucket, uint32_t
             return;
         }
     }
-    if (passes > 0u) local_pass<kLocalPairThreads, ITEMS, BITS, false, false, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, 0, n);
+    if (passes > 0u) local_pass<THREADS, ITEMS, BITS, false, false, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, 0, n);
     for (uint32_t p_ = 1; p_ < passes; ++p_)
-        local_pass<kLocalPairThreads, ITEMS, BITS, false, true, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, BITS * p_, n);
+        local_pass<THREADS, ITEMS, BITS, false, true, uint64_t>(key, none, s_keys, nullptr, s_hist, s_tmp, BITS * p_, n);
     if (passes == 0u) return;  // one distinct key per bucket
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -2505,26 +2514,28 @@ __device__ __forceinline__ void local_sort_bucket_u64(uint64_t *bucket, uint32_t
     }
 }
 
-__global__ __launch_bounds__(kLocalPairThreads, 4) void msd_local_sort_u64_kernel(uint64_t *__restrict__ keys,
-                                                                                 const MsdPlan *__restrict__ msd, StatusClear sc) {
-    constexpr int WAVES = kLocalPairThreads / 64;
-    __shared__ uint64_t s_keys[kLocalCap];
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void msd_local_sort_u64_kernel(uint64_t *__restrict__ keys,
+                                                                        const MsdPlan *__restrict__ msd, StatusClear sc) {
+    constexpr int WAVES = THREADS / 64;
+    constexpr uint32_t CAP = THREADS * kLocalPairItems;
+    __shared__ uint64_t s_keys[CAP];
     __shared__ uint32_t s_hist[WAVES << 9];
     __shared__ uint32_t s_tmp[1 + WAVES];
     if (msd->ok == 0u) return;
-    clear_status_share(sc, kLocalPairThreads);
+    clear_status_share(sc, THREADS);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
-    if (n == 0 || n > kLocalCap) return;
+    if (n == 0 || n > CAP) return;
     const uint32_t passes = (msd->shift + 8u) / 9u;
     uint64_t *bucket = keys + begin;
-    const uint32_t used = (n + kLocalPairThreads - 1u) / kLocalPairThreads;
-    if (used <= 2) local_sort_bucket_u64<2>(bucket, n, passes, s_keys, s_hist, s_tmp);
-    else if (used <= 4) local_sort_bucket_u64<4>(bucket, n, passes, s_keys, s_hist, s_tmp);
-    else if (used <= 6) local_sort_bucket_u64<6>(bucket, n, passes, s_keys, s_hist, s_tmp);
-    else if (used <= 8) local_sort_bucket_u64<8>(bucket, n, passes, s_keys, s_hist, s_tmp);
-    else if (used <= 10) local_sort_bucket_u64<10>(bucket, n, passes, s_keys, s_hist, s_tmp);
-    else if (used <= 12) local_sort_bucket_u64<12>(bucket, n, passes, s_keys, s_hist, s_tmp);
-    else local_sort_bucket_u64<kLocalPairItems>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    const uint32_t used = (n + THREADS - 1u) / THREADS;
+    if (used <= 2) local_sort_bucket_u64<THREADS, 2>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    else if (used <= 4) local_sort_bucket_u64<THREADS, 4>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    else if (used <= 6) local_sort_bucket_u64<THREADS, 6>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    else if (used <= 8) local_sort_bucket_u64<THREADS, 8>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    else if (used <= 10) local_sort_bucket_u64<THREADS, 10>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    else if (used <= 12) local_sort_bucket_u64<THREADS, 12>(bucket, n, passes, s_keys, s_hist, s_tmp);
+    else local_sort_bucket_u64<THREADS, kLocalPairItems>(bucket, n, passes, s_keys, s_hist, s_tmp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2940,9 +2951,12 @@ hipError_t launch_msd_count_u64(hipStream_t stream, const void *keys, uint32_t n
 
 hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, const MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev,
                                      uint32_t *clear_status, size_t clear_words) {
-    if (max_bucket > kLocalCap) return hipErrorInvalidValue;  // the plan would have refused
+    if (max_bucket > kLocalCapBig) return hipErrorInvalidValue;  // the plan would have refused
     const StatusClear sc{reinterpret_cast<uint4 *>(clear_status), static_cast<uint32_t>(clear_words / 4)};
-    VRS_LAUNCH(msd_local_sort_u64_kernel, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, static_cast<uint64_t *>(keys), msd, sc);
+    if (max_bucket > kLocalCap)
+        VRS_LAUNCH(msd_local_sort_u64_kernel<kLocalPairThreadsBig>, dim3(kMsdBuckets), dim3(kLocalPairThreadsBig), stream, ev, static_cast<uint64_t *>(keys), msd, sc);
+    else
+        VRS_LAUNCH(msd_local_sort_u64_kernel<kLocalPairThreads>, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, static_cast<uint64_t *>(keys), msd, sc);
     return hipGetLastError();
 }
 
@@ -2950,8 +2964,10 @@ hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *v
                                  LaunchEvents ev, uint32_t *clear_status, size_t clear_words) {
     if (max_bucket > msd_local_capacity(values != nullptr)) return hipErrorInvalidValue;  // the plan would have refused
     const StatusClear sc{reinterpret_cast<uint4 *>(clear_status), static_cast<uint32_t>(clear_words / 4)};
-    if (values != nullptr)
-        VRS_LAUNCH(msd_local_sort_pairs_kernel, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, keys, values, msd, sc);
+    if (values != nullptr && max_bucket > kLocalCap)
+        VRS_LAUNCH(msd_local_sort_pairs_kernel<kLocalPairThreadsBig>, dim3(kMsdBuckets), dim3(kLocalPairThreadsBig), stream, ev, keys, values, msd, sc);
+    else if (values != nullptr)
+        VRS_LAUNCH(msd_local_sort_pairs_kernel<kLocalPairThreads>, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, keys, values, msd, sc);
     else if (max_bucket <= kWaveCap)
         VRS_LAUNCH(msd_local_sort_wave_kernel, dim3(kMsdBuckets), dim3(64), stream, ev, keys, msd, sc);
     else if (max_bucket > kLeanCap)
@@ -2963,7 +2979,8 @@ hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *v
 
 uint32_t msd_local_capacity_small() { return kLeanCap; }
 uint32_t msd_local_capacity_wave() { return kWaveCap; }
-uint32_t msd_local_capacity(bool pairs_or_wide) { return pairs_or_wide ? kLocalCap : kLeanBigCap; }
+uint32_t msd_local_capacity(bool pairs_or_wide) { return pairs_or_wide ? kLocalCapBig : kLeanBigCap; }
+uint32_t msd_local_capacity_pairs_small() { return kLocalCap; }
 
 hipError_t launch_digit_tables(hipStream_t stream, const void *keys, uint32_t n, int key_bytes, uint32_t base_shift,
                                uint32_t group_len, uint32_t groups, uint32_t *tables, uint32_t *status,
