@@ -71,7 +71,14 @@ def main():
                 n = int(rs.choice([rs.randint(1, 20000), rs.randint(1, 3000000), rs.randint(1000000, 9000000), rs.randint(4200000, 12000000)]))
                 if not bits64 and not pairs and rs.randint(0, 12) == 0:
                     n = int(rs.randint(30000000, 45000000))  # buckets beyond one wave: the 256-thread local sort
+            sparse = one_call and (bits64 or pairs) and rs.randint(0, 10) == 0
+            if sparse:
+                n = int(rs.randint(28000000, 52000000))
             keys, kind = make_keys(rs, n, bits64)
+            if sparse:
+                # three of four top-14-bit buckets empty: the others hold 6800 to 12700 elements -- the 1024-thread local sort of
+                # pairs and 64-bit keys (uniform keys only: other kinds have their own bucket shapes)
+                keys = keys & ~(keys.dtype.type(3) << keys.dtype.type(8 * keys.itemsize - 14))
             vals = rs.randint(0, 2 ** 32, n, dtype=np.uint32) if pairs else None
             if one_call:
                 ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, int(rs.choice([0, 1, n, max(1, n // 2), 1 << 20, capi.ONE_CALL_MIN_KEYS_DEFAULT])))
