@@ -742,18 +742,32 @@ def bench_multi(args):
     # transport error), every rank learns so and the run goes through the Python orchestration instead -- a number from the other
     # path is worth more than none; config.path says which path ran.
     handles, tried, failure = {}, {}, None
-    try:
+
+    def agreed(stage):
+        """True if `stage` went well on EVERY rank (a rank that failed skipped its collectives: the others must not enter the
+        next stage's and wait for it)."""
+        flag = torch.tensor([0 if failure else 1], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return True
+        print(f"[bench] rank {rank}: the C path's {stage} failed ({failure or 'on another rank'}); falling back to --dist-path python", file=sys.stderr)
+        return False
+
+    try:  # stage 1, no communication: the endpoints (binds RCCL, allocates the landing areas)
         handles = {r: make_dist(r) for r in candidates}
-        for r, d in handles.items():
-            step(d, batches[0])
-            gpu.waitIdle()
-            batches[0].copyFrom(pristine)
     except Exception as e:  # noqa: BLE001 -- reported and agreed on below
         failure = repr(e)
-    flag = torch.tensor([0 if failure else 1], dtype=torch.int64, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 0:
-        print(f"[bench] rank {rank}: the C path's set-up failed ({failure or 'on another rank'}); falling back to --dist-path python", file=sys.stderr)
+    ok = agreed("set-up")
+    if ok:
+        try:  # stage 2: a first step per candidate (every exit of a step is decided collectively inside the library)
+            for r, d in handles.items():
+                step(d, batches[0])
+                gpu.waitIdle()
+                batches[0].copyFrom(pristine)
+        except Exception as e:  # noqa: BLE001
+            failure = repr(e)
+        ok = agreed("first step")
+    if not ok:
         for h in handles.values():
             lib.vrs_dist_destroy(h)
         for b in batches + [pristine]:
