@@ -231,17 +231,27 @@ int vrs_sort_pairs_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vr
  *     histogram is empty and `out` is not a partition), [VRS_MSD_SHIFT_WORD + 1] != 0: a key above the probed range.
  *   vrs_msd_finish_u32: second MSD pass + local sort of n keys that ARE grouped by that top byte (`grouped`; clobbered as
  *     scratch), result in `out`.  counts: the same layout, [0, 16384) = the bucket histogram of exactly these n keys, the
- *     slice counts zero, the shift word set, the flag word zero.  bucket_hint: the largest bucket to expect (it picks the local
+ *     slice counts zero, the shift word set, the flag word zero; read in place by the plan kernel, which leaves the histogram zeroed.  bucket_hint: the largest bucket to expect (it picks the local
  *     sort's workgroup shape before the plan is known; 0 = num_elements / 16384 + 10 %).  The plan may refuse (a bucket beyond the local sort's
  *     capacity, top-byte buckets too unequal for the grid): vrs_msd_finish_status waits for the plan's head and tells
  *     (*took == 0: `out` holds nothing useful, `grouped` still holds the keys -- sort them with vrs_sort_keys_u32).
+ *   A caller that enqueues several finishes before it looks (the rounds of the multi-GPU step: a wait per round would leave the
+ *     GPU idle while the host enqueues the next) takes a ticket after each (vrs_msd_finish_ticket) and asks later:
+ *     vrs_msd_finish_status_at(ticket) waits until THAT finish's plan has run.  The context keeps the last 32 decisions.
  */
 #define VRS_MSD_COUNT_WORDS (16384u + 8u * 256u + 64u)
 #define VRS_MSD_SHIFT_WORD (16384u + 8u * 256u)
 int vrs_msd_partition_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer out, vrs_buffer counts_out, uint32_t num_elements);
+/* The same; counts_ready_event (a hipEvent_t of the caller's, or NULL) is recorded on the context's stream as soon as counts_out is
+ * complete -- before the first MSD pass -- so that work on ANOTHER stream that needs only the counts (the multi-GPU step's
+ * collectives) runs beside that pass. */
+int vrs_msd_partition_signal_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer out, vrs_buffer counts_out, uint32_t num_elements,
+                                 void *counts_ready_event);
 int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_buffer counts, uint32_t num_elements,
                        uint32_t bucket_hint);
 int vrs_msd_finish_status(vrs_context ctx, int *took);
+int vrs_msd_finish_ticket(vrs_context ctx, uint32_t *ticket);
+int vrs_msd_finish_status_at(vrs_context ctx, uint32_t ticket, int *took);
 
 /*
  * Key preprocessing the reference leaves to the integrator ("you have to preprocess negative numbers",

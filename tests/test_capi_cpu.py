@@ -181,6 +181,9 @@ def test_round3_entry_points_reject_null_and_need_no_device(lib):
     assert lib.vrs_context_device(None) == -1
     took = ctypes.c_int(7)
     assert lib.vrs_msd_finish_status(None, ctypes.byref(took)) == capi.VRS_ERROR_INVALID_ARGUMENT
+    ticket = ctypes.c_uint32(0)
+    assert lib.vrs_msd_finish_ticket(None, ctypes.byref(ticket)) == capi.VRS_ERROR_INVALID_ARGUMENT
+    assert lib.vrs_msd_finish_status_at(None, 1, ctypes.byref(took)) == capi.VRS_ERROR_INVALID_ARGUMENT
     hub = ctypes.c_void_p()
     assert lib.vrs_dist_loopback_create(0, ctypes.byref(hub)) == capi.VRS_ERROR_INVALID_ARGUMENT
     assert lib.vrs_dist_loopback_create(2, None) == capi.VRS_ERROR_INVALID_ARGUMENT

@@ -170,3 +170,74 @@ def test_cpp_host_drives_the_step_over_the_loopback_transport():
         p = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stdout + p.stderr
         assert "[DistSort] Test passed." in p.stdout
+
+
+def test_msd_halves_several_finishes_enqueued_before_any_is_asked_about():
+    """vrs_msd_partition_u32 + TWO vrs_msd_finish_u32 (the lower and the upper half of the top bytes, like two rounds of the
+    step), both enqueued before either plan is looked at: a ticket per finish, vrs_msd_finish_status_at answers for that
+    finish whatever ran since (asked in reverse order), the concatenation is std::sort of the input.  A third finish over a
+    sub-range with one bucket far beyond the local sort's capacity is refused -- its ticket says so -- while the tickets of
+    the other two still answer."""
+    lib = capi.load_library()
+    n = (1 << 23) + 12345
+    keys = keys_of("uniform", n, 77)
+    with vrs.GPUContext(0) as gpu:
+        kb = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), keys)
+        grouped, out = vrs.Buffer(gpu, S(4 * n)), vrs.Buffer(gpu, S(4 * n))
+        counts = vrs.Buffer(gpu, S(4 * capi.MSD_COUNT_WORDS))
+        gpu.check(lib.vrs_msd_partition_u32(gpu.handle, kb.handle, grouped.handle, counts.handle, n))
+        host_counts = np.empty(capi.MSD_COUNT_WORDS, np.uint32)
+        counts.downloadWithStagingBuffer(host_counts)
+        hist, shift = host_counts[:16384], int(host_counts[16384 + 8 * 256])
+        assert shift == 18 and int(hist.sum()) == n
+        cut = int(hist[: 128 * 64].sum())  # keys under top bytes 0..127
+        tickets, parts = [], [(0, cut, 0, 128), (cut, n - cut, 128, 256)]
+        round_counts = []
+        for off, cnt, lo, hi in parts:
+            c = np.zeros(capi.MSD_COUNT_WORDS, np.uint32)
+            c[lo * 64: hi * 64] = hist[lo * 64: hi * 64]
+            c[16384 + 8 * 256] = shift
+            cb = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * capi.MSD_COUNT_WORDS), c)
+            round_counts.append(cb)
+            gv = vrs.Buffer(gpu, S(4 * cnt), device_ptr=grouped.getDeviceAddress() + 4 * off)
+            ov = vrs.Buffer(gpu, S(4 * cnt), device_ptr=out.getDeviceAddress() + 4 * off)
+            gpu.check(lib.vrs_msd_finish_u32(gpu.handle, gv.handle, ov.handle, cb.handle, cnt, 0))
+            t = ctypes.c_uint32()
+            gpu.check(lib.vrs_msd_finish_ticket(gpu.handle, ctypes.byref(t)))
+            tickets.append(t.value)
+            gv.release()
+            ov.release()
+        assert tickets[1] == tickets[0] + 1
+        # a third finish the plan must refuse: the same lower half, but its histogram claims one bucket of 100 000 keys
+        c = np.zeros(capi.MSD_COUNT_WORDS, np.uint32)
+        c[: 128 * 64] = hist[: 128 * 64]
+        moved = min(100000, cut // 2)
+        c[5] += moved
+        big = int(np.argmax(c[6: 128 * 64])) + 6
+        take = moved
+        for b in range(6, 128 * 64):  # keep the total: take the keys from other buckets
+            d = min(int(c[b]), take)
+            c[b] -= d
+            take -= d
+            if take == 0:
+                break
+        assert int(c[: 128 * 64].sum()) == cut and big >= 6
+        c[16384 + 8 * 256] = shift
+        cb = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * capi.MSD_COUNT_WORDS), c)
+        scratch_in, scratch_out = vrs.Buffer(gpu, S(4 * cut)), vrs.Buffer(gpu, S(4 * cut))
+        gpu.check(lib.vrs_msd_finish_u32(gpu.handle, scratch_in.handle, scratch_out.handle, cb.handle, cut, 0))
+        t = ctypes.c_uint32()
+        gpu.check(lib.vrs_msd_finish_ticket(gpu.handle, ctypes.byref(t)))
+        took = ctypes.c_int(-1)
+        gpu.check(lib.vrs_msd_finish_status_at(gpu.handle, t.value, ctypes.byref(took)))
+        assert took.value == 0
+        for tk in reversed(tickets):
+            gpu.check(lib.vrs_msd_finish_status_at(gpu.handle, tk, ctypes.byref(took)))
+            assert took.value == 1
+        assert lib.vrs_msd_finish_status_at(gpu.handle, 0, ctypes.byref(took)) == capi.VRS_ERROR_INVALID_ARGUMENT
+        assert lib.vrs_msd_finish_status_at(gpu.handle, (t.value - 40) & 0xFFFFFFFF, ctypes.byref(took)) == capi.VRS_ERROR_INVALID_ARGUMENT
+        res = np.empty(n, np.uint32)
+        out.downloadWithStagingBuffer(res)
+        assert np.array_equal(res, np.sort(keys))
+        for b in [kb, grouped, out, counts, cb, scratch_in, scratch_out] + round_counts:
+            b.release()

@@ -136,7 +136,10 @@ _SIGNATURES = [
     ("vrs_dist_loopback_destroy", c_int, [c_void_p]),
     ("vrs_msd_partition_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
     ("vrs_msd_finish_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_uint32]),
+    ("vrs_msd_partition_signal_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     ("vrs_msd_finish_status", c_int, [c_void_p, POINTER(c_int)]),
+    ("vrs_msd_finish_ticket", c_int, [c_void_p, POINTER(c_uint32)]),
+    ("vrs_msd_finish_status_at", c_int, [c_void_p, c_uint32, POINTER(c_int)]),
     ("vrs_context_device", c_int, [c_void_p]),
     ("vrs_dist_sort_keys_u32", c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_void_p), POINTER(c_uint32)]),
     ("vrs_dist_plan_splitters", c_int, [POINTER(c_uint64), c_int, POINTER(c_uint32)]),

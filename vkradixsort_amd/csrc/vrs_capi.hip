@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -689,9 +690,7 @@ static int contract_pass(vrs_context ctx, vrs_buffer kin, vrs_buffer kout, vrs_b
 // there already, or microseconds away), then the thread yields between looks, sleeping a little longer each time, and asks
 // the stream now and then so that a faulted queue surfaces as an error instead of an endless wait.  Bounded in time
 // (VRS_TUNE_PLAN_WAIT_MS, default 60 s): a stream stuck behind work that never finishes returns VRS_ERROR_TIMEOUT.
-static int wait_for_plan(vrs_context ctx, uint32_t stamp) {
-    volatile uint32_t *ready = &ctx->os_host_head->ready;
-    const auto arrived = [&] { return __atomic_load_n(ready, __ATOMIC_ACQUIRE) == stamp; };
+static int wait_for_host_word(vrs_context ctx, const std::function<bool()> &arrived) {
     for (int spins = 0; spins < 20000; ++spins) {  // ~50-100 us
         if (arrived()) return VRS_OK;
 #if defined(__x86_64__) || defined(__i386__)
@@ -720,6 +719,11 @@ static int wait_for_plan(vrs_context ctx, uint32_t stamp) {
         if (nap_us <= 2) sched_yield(); else usleep(nap_us);
         if (nap_us < 200) nap_us *= 2;
     }
+}
+
+static int wait_for_plan(vrs_context ctx, uint32_t stamp) {
+    volatile uint32_t *ready = &ctx->os_host_head->ready;
+    return wait_for_host_word(ctx, [&] { return __atomic_load_n(ready, __ATOMIC_ACQUIRE) == stamp; });
 }
 
 // ---- the one-call sort for large N (K5 / K5b), in two halves around the plan's arrival on the host.
@@ -811,8 +815,8 @@ static int one_read_scratch(vrs_context ctx, const vrs_context_t::OneRead &st, c
         if (e == hipSuccess) e = hipMemsetAsync(tables, 0, (vrs::kDigitTableWords + 64) * sizeof(uint32_t), ctx->stream);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&plan), sizeof(vrs::OnesweepPlan));
         if (e == hipSuccess)
-            e = hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(vrs::OnesweepPlanHead),
-                              hipHostMallocMapped | hipHostMallocCoherent);
+            e = hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(vrs::OnesweepPlanHead) + vrs::kMsdLogWords * sizeof(uint32_t),
+                              hipHostMallocMapped | hipHostMallocCoherent);  // behind the head: the log of vrs_msd_finish_u32's decisions
         if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&host_dev), host, 0);
         if (e != hipSuccess) {  // all or nothing: a half-made set would be dereferenced by the next call
             if (host) (void)hipHostFree(host);
@@ -820,7 +824,7 @@ static int one_read_scratch(vrs_context ctx, const vrs_context_t::OneRead &st, c
             if (tables) (void)hipFree(tables);
             return fail_hip(ctx, "one-call sort scratch allocation", e);
         }
-        std::memset(host, 0, sizeof *host);
+        std::memset(host, 0, sizeof *host + vrs::kMsdLogWords * sizeof(uint32_t));
         ctx->os_tables = tables;
         ctx->os_ticket = tables + vrs::kDigitTableWords;
         ctx->os_plan = plan;
@@ -874,7 +878,8 @@ static int one_read_lookback_pass(vrs_context ctx, vrs_context_t::OneRead &st, u
 }
 
 // second MSD pass + local sort of the hybrid form: partner -> home, then the buckets in place
-static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, const OneReadGeometry &g, uint32_t tiles_b, uint32_t max_bucket) {
+static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, const OneReadGeometry &g, uint32_t tiles_b, uint32_t max_bucket,
+                                bool status_was_clean = false) {
     const bool pairs = st.vptr[0] != nullptr, wide = st.key_bytes == 8;
     const uint32_t home = st.cur_at_start;
     vrs::LaunchEvents ev;
@@ -888,8 +893,11 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
     // Launched with the plan known (it said yes), the local sort also clears the look-back status words -- it is LDS-bound and
     // has HBM time to spare, the next sort's counting read does not.  Launched blind it may leave at once: nothing is promised.
-    uint32_t *clear = st.blind_tail ? nullptr : ctx->os_status;
-    const size_t clear_words = st.blind_tail ? 0 : ctx->os_status_rows * VRS_RADIX_SORT_BINS;
+    // (Blind, but with every status word zero before the second pass -- vrs_msd_finish_u32 -- the promise holds again: either both
+    // kernels run, and the local sort clears what the pass wrote, or both leave at once.)
+    const bool clears = !st.blind_tail || status_was_clean;
+    uint32_t *clear = clears ? ctx->os_status : nullptr;
+    const size_t clear_words = clears ? ctx->os_status_rows * VRS_RADIX_SORT_BINS : 0;
     if (wide)
         VRS_HIP(ctx, vrs::launch_msd_local_sort_u64(ctx->stream, st.kptr[home], ctx->os_msd_plan, max_bucket, ev, clear, clear_words));
     else
@@ -1209,6 +1217,10 @@ static int msd_half_setup(vrs_context ctx, uint32_t n, vrs_context_t::OneRead *s
 }
 
 int vrs_msd_partition_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer out, vrs_buffer counts_out, uint32_t n) {
+    return vrs_msd_partition_signal_u32(ctx, keys, out, counts_out, n, nullptr);
+}
+
+int vrs_msd_partition_signal_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer out, vrs_buffer counts_out, uint32_t n, void *counts_ready_event) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     int rc;
     const size_t bytes = static_cast<size_t>(n) * sizeof(uint32_t);
@@ -1231,6 +1243,8 @@ int vrs_msd_partition_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer out, vrs_
     VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, keys->ptr, n, g.group_len, ctx->os_tables, ctx->os_status,
                                               g.rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts, true, ev));
     VRS_HIP(ctx, hipMemcpyAsync(counts_out->ptr, ctx->os_msd_counts, VRS_MSD_COUNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    // the counts are all a caller needs to start talking to its peers: the first pass below runs meanwhile
+    if (counts_ready_event) VRS_HIP(ctx, hipEventRecord(static_cast<hipEvent_t>(counts_ready_event), ctx->stream));
     VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
                                       ctx->os_host_head_dev, ctx->os_stamp, n, g.T, g.tiles_b_cap, g.local_cap, ctx->os_tables,
                                       g.group_len, g.tile_cap, g.blind_cap, g.cuts0, 1u, 18u));
@@ -1250,6 +1264,7 @@ int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_
     if ((rc = check_buffer(ctx, out, bytes, "out"))) return rc;
     if ((rc = check_buffer(ctx, counts, VRS_MSD_COUNT_WORDS * sizeof(uint32_t), "counts"))) return rc;
     if (grouped->ptr == out->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "grouped and out alias");
+    if (reinterpret_cast<uintptr_t>(counts->ptr) % 16u) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "counts must be 16-byte aligned");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = settle_pending(ctx))) return rc;
     vrs_context_t::OneRead st;
@@ -1258,18 +1273,20 @@ int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_
     ctx->sub_cache.valid = false;
     if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
     ctx->os_msd_half_stamp = ctx->os_stamp;
-    ctx->os_status_clean = false;
     // the look-back rows of the second pass must read "never written": the counting read of a whole sort clears them, here
-    // nothing else does
-    VRS_HIP(ctx, hipMemsetAsync(ctx->os_status, 0, g.rows * VRS_RADIX_SORT_BINS * sizeof(uint32_t), ctx->stream));
-    VRS_HIP(ctx, hipMemcpyAsync(ctx->os_msd_counts, counts->ptr, VRS_MSD_COUNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-    VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
+    // nothing else does -- unless the last kernel that touched them was a local sort that cleared them (the previous round's)
+    if (!ctx->os_status_clean)
+        VRS_HIP(ctx, hipMemsetAsync(ctx->os_status, 0, ctx->os_status_rows * VRS_RADIX_SORT_BINS * sizeof(uint32_t), ctx->stream));
+    ctx->os_status_clean = false;
+    // the plan reads the caller's table in place (and leaves its histogram zeroed, like the context's own)
+    VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, static_cast<uint32_t *>(counts->ptr), ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
                                       ctx->os_host_head_dev, ctx->os_stamp, n, g.T, g.tiles_b_cap, g.local_cap, ctx->os_tables,
-                                      g.group_len, g.tile_cap, g.blind_cap, g.cuts0, 1u, 18u));
+                                      g.group_len, g.tile_cap, g.blind_cap, g.cuts0, 1u, 18u,
+                                      reinterpret_cast<uint32_t *>(ctx->os_host_head_dev + 1)));
     st.kptr[0] = out->ptr;      // "home": the second pass writes here, the local sort works here
     st.kptr[1] = grouped->ptr;  // the partner holds the first pass's output
     st.cur_at_start = 0;
-    return one_read_hybrid_tail(ctx, st, g, g.tiles_b_cap, g.local_cap);
+    return one_read_hybrid_tail(ctx, st, g, g.tiles_b_cap, g.local_cap, true);
 }
 
 int vrs_msd_finish_status(vrs_context ctx, int *took) {
@@ -1280,6 +1297,29 @@ int vrs_msd_finish_status(vrs_context ctx, int *took) {
     const int rc = wait_for_plan(ctx, ctx->os_msd_half_stamp);
     if (rc) return rc;
     *took = ctx->os_host_head->msd_ok ? 1 : 0;
+    return VRS_OK;
+}
+
+int vrs_msd_finish_ticket(vrs_context ctx, uint32_t *ticket) {
+    if (!ctx || !ticket) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or ticket is NULL");
+    if (ctx->os_msd_half_stamp == 0) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "no vrs_msd_finish_u32 to ask about");
+    *ticket = ctx->os_msd_half_stamp;
+    return VRS_OK;
+}
+
+int vrs_msd_finish_status_at(vrs_context ctx, uint32_t ticket, int *took) {
+    if (!ctx || !took) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or took is NULL");
+    *took = 0;
+    if (ticket == 0 || !ctx->os_host_head) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "not a ticket of vrs_msd_finish_ticket");
+    // stamps count up by one per plan (0 skipped): the log keeps the last kMsdLogWords
+    if (ctx->os_stamp - ticket >= vrs::kMsdLogWords)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "ticket too old: the log keeps the decisions of the last 32 plans");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    volatile uint32_t *word = reinterpret_cast<volatile uint32_t *>(ctx->os_host_head + 1) + (ticket & (vrs::kMsdLogWords - 1u));
+    const uint32_t want = ticket << 1;
+    const int rc = wait_for_host_word(ctx, [&] { return (__atomic_load_n(word, __ATOMIC_ACQUIRE) & ~1u) == want; });
+    if (rc) return rc;
+    *took = static_cast<int>(*word & 1u);
     return VRS_OK;
 }
 

@@ -47,6 +47,24 @@
 
 namespace {
 
+// The bucket histograms of a step's rounds, one table per round in vrs_msd_finish_u32's layout, made in ONE launch before the
+// rounds start (five small fills and copies per round were 25 us of every round): round r's table = the all-reduced
+// histogram masked to the round's top bytes [lo, hi), slice counts and flag zero, the shift word set.
+struct RoundCuts {
+    uint32_t lo[32], hi[32];
+    uint32_t shift;
+};
+__global__ __launch_bounds__(1024) void round_tables_kernel(const uint32_t *__restrict__ reduced, uint32_t *__restrict__ tables, RoundCuts cuts) {
+    const uint32_t r = blockIdx.x;
+    uint32_t *t = tables + static_cast<size_t>(r) * VRS_MSD_COUNT_WORDS;
+    for (uint32_t c = threadIdx.x; c < VRS_MSD_COUNT_WORDS; c += 1024u) {
+        uint32_t v = 0;
+        if (c < 16384u && (c >> 6) >= cuts.lo[r] && (c >> 6) < cuts.hi[r]) v = reduced[c];
+        if (c == VRS_MSD_SHIFT_WORD) v = cuts.shift;
+        t[c] = v;
+    }
+}
+
 // ---- RCCL, bound at run time (rccl.h: ncclResult_t == int, ncclSuccess == 0, ncclUint32 == 3, ncclSum == 0)
 struct Rccl {
     void *handle = nullptr;
@@ -134,11 +152,11 @@ struct vrs_dist_t {
     hipStream_t sort_stream = nullptr;  // the context's stream
     hipStream_t comm_stream = nullptr;  // exchange rounds run here, beside the sorts
     std::vector<hipEvent_t> round_done;  // round r has landed in the receive buffer
-    hipEvent_t grouped_ready = nullptr, sorts_done = nullptr;
+    hipEvent_t grouped_ready = nullptr, sorts_done = nullptr, counts_ready = nullptr;
     vrs_buffer grouped = nullptr, recv = nullptr, scratch = nullptr, hist = nullptr, row = nullptr, table = nullptr;
     vrs_buffer counts = nullptr, reduced = nullptr, round_counts = nullptr;
     std::vector<uint32_t> host_table;  // world x kRowWords
-    uint32_t host_row_tail[8] = {};  // host words on their way into device rows: [0..2] shard size, status, capacity; [4] the agreed bucket shift
+    uint32_t host_row_tail[8] = {};  // host words on their way into device rows: [0..2] shard size, status, capacity
     std::string last_error;
     double max_imbalance = 1.15;
     uint64_t hybrid_rounds = 0, fallback_rounds = 0, byte_steps = 0;
@@ -458,7 +476,8 @@ int vrs_dist_create_with_transport(vrs_context ctx, const vrs_dist_transport *tr
     for (auto &e : d->round_done)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return cleanup(VRS_ERROR_HIP, "hipEventCreate failed");
     if (hipEventCreateWithFlags(&d->grouped_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&d->sorts_done, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&d->sorts_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d->counts_ready, hipEventDisableTiming) != hipSuccess)
         return cleanup(VRS_ERROR_HIP, "hipEventCreate failed");
     const size_t kb = static_cast<size_t>(capacity_keys) * sizeof(uint32_t);
     const uint32_t W = vrs_workgroup_count(capacity_keys, 32);
@@ -466,7 +485,7 @@ int vrs_dist_create_with_transport(vrs_context ctx, const vrs_dist_transport *tr
     if (vrs_buffer_create(ctx, kb, &d->grouped) || vrs_buffer_create(ctx, kb, &d->recv) || vrs_buffer_create(ctx, kb, &d->scratch) ||
         vrs_buffer_create(ctx, static_cast<size_t>(W) * 256 * 4, &d->hist) || vrs_buffer_create(ctx, kRowWords * 4, &d->row) ||
         vrs_buffer_create(ctx, static_cast<size_t>(world) * kRowWords * 4, &d->table) || vrs_buffer_create(ctx, cw, &d->counts) ||
-        vrs_buffer_create(ctx, cw, &d->reduced) || vrs_buffer_create(ctx, cw, &d->round_counts))
+        vrs_buffer_create(ctx, cw, &d->reduced) || vrs_buffer_create(ctx, cw * static_cast<size_t>(d->rounds), &d->round_counts))
         return cleanup(VRS_ERROR_OUT_OF_MEMORY, std::string("buffer allocation failed: ") + vrs_last_error(ctx));
     d->host_table.resize(static_cast<size_t>(world) * kRowWords);
     *out = d;
@@ -505,6 +524,7 @@ int vrs_dist_destroy(vrs_dist d) {
         if (e) (void)hipEventDestroy(e);
     if (d->grouped_ready) (void)hipEventDestroy(d->grouped_ready);
     if (d->sorts_done) (void)hipEventDestroy(d->sorts_done);
+    if (d->counts_ready) (void)hipEventDestroy(d->counts_ready);
     if (d->comm_stream) (void)hipStreamDestroy(d->comm_stream);
     delete d->rccl;  // the RCCL handle itself stays mapped: the process may hold communicators made by it
     delete d;
@@ -556,33 +576,39 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
     bool partitioned = false;
     VRS_DHIP(d, hipMemsetAsync(row, 0, kRowWords * 4, d->sort_stream));
     VRS_DHIP(d, hipMemsetAsync(counts, 0, static_cast<size_t>(VRS_MSD_COUNT_WORDS) * 4, d->sort_stream));
+    // The collectives need the counts, not the partitioned keys: they run on the exchange stream from the moment the counts
+    // are out (counts_ready), beside the first MSD pass, and the host waits for them only.
     if (try_hybrid && n_eff >= (1u << 16)) {
-        const int rc = vrs_msd_partition_u32(ctx, keys, d->grouped, d->counts, n_eff);
+        const int rc = vrs_msd_partition_signal_u32(ctx, keys, d->grouped, d->counts, n_eff, d->counts_ready);
         if (rc == VRS_OK) {
             partitioned = true;
-            // the row's slice counts = words [16384, 16384 + 2048) of the counts
-            VRS_DHIP(d, hipMemcpyAsync(row, counts + 16384, kRowSlices * 4, hipMemcpyDeviceToDevice, d->sort_stream));
-            VRS_DHIP(d, hipMemcpyAsync(row + kRowShift, counts + VRS_MSD_SHIFT_WORD, 2 * 4, hipMemcpyDeviceToDevice, d->sort_stream));  // shift word + range flag
         } else {
             my_status = rc;
             my_error = std::string("vrs_msd_partition_u32: ") + vrs_last_error(ctx);
         }
     }
+    if (!partitioned) VRS_DHIP(d, hipEventRecord(d->counts_ready, d->sort_stream));  // (the memsets above)
+    VRS_DHIP(d, hipStreamWaitEvent(d->comm_stream, d->counts_ready, 0));
+    if (partitioned) {
+        // the row's slice counts = words [16384, 16384 + 2048) of the counts
+        VRS_DHIP(d, hipMemcpyAsync(row, counts + 16384, kRowSlices * 4, hipMemcpyDeviceToDevice, d->comm_stream));
+        VRS_DHIP(d, hipMemcpyAsync(row + kRowShift, counts + VRS_MSD_SHIFT_WORD, 2 * 4, hipMemcpyDeviceToDevice, d->comm_stream));  // shift word + range flag
+    }
     d->host_row_tail[0] = my_status == VRS_OK ? n : 0u;
     d->host_row_tail[1] = static_cast<uint32_t>(my_status);
     d->host_row_tail[2] = d->capacity;
-    VRS_DHIP(d, hipMemcpyAsync(row + kRowN, d->host_row_tail, 3 * 4, hipMemcpyHostToDevice, d->sort_stream));
+    VRS_DHIP(d, hipMemcpyAsync(row + kRowN, d->host_row_tail, 3 * 4, hipMemcpyHostToDevice, d->comm_stream));
 
     // 2. the collectives: every rank learns every rank's row; the bucket histograms are summed
     if (d->has_transport) {
-        VRS_DTR(d, "all-gather of the shard rows", d->tr.all_gather(d->tr.user, row, table, kRowWords, d->sort_stream));
-        if (try_hybrid) VRS_DTR(d, "all-reduce of the bucket histograms", d->tr.all_reduce(d->tr.user, counts, reduced, 16384, d->sort_stream));
+        VRS_DTR(d, "all-gather of the shard rows", d->tr.all_gather(d->tr.user, row, table, kRowWords, d->comm_stream));
+        if (try_hybrid) VRS_DTR(d, "all-reduce of the bucket histograms", d->tr.all_reduce(d->tr.user, counts, reduced, 16384, d->comm_stream));
     } else {
-        VRS_DHIP(d, hipMemcpyAsync(table, row, kRowWords * 4, hipMemcpyDeviceToDevice, d->sort_stream));
-        if (try_hybrid) VRS_DHIP(d, hipMemcpyAsync(reduced, counts, 16384 * 4, hipMemcpyDeviceToDevice, d->sort_stream));
+        VRS_DHIP(d, hipMemcpyAsync(table, row, kRowWords * 4, hipMemcpyDeviceToDevice, d->comm_stream));
+        if (try_hybrid) VRS_DHIP(d, hipMemcpyAsync(reduced, counts, 16384 * 4, hipMemcpyDeviceToDevice, d->comm_stream));
     }
-    VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, d->host_table.size() * 4, hipMemcpyDeviceToHost, d->sort_stream));
-    VRS_DHIP(d, hipStreamSynchronize(d->sort_stream));
+    VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, d->host_table.size() * 4, hipMemcpyDeviceToHost, d->comm_stream));
+    VRS_DHIP(d, hipStreamSynchronize(d->comm_stream));  // the collectives; the first MSD pass may still be running
 
     // ---- from here on every rank holds the same table: every decision below is the same on all of them
     uint32_t min_capacity = 0xFFFFFFFFu;
@@ -777,50 +803,69 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
     //    step's output then IS the scratch buffer.
     uint32_t *scratch = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->scratch));
     uint32_t *round_counts = static_cast<uint32_t *>(vrs_buffer_device_ptr(d->round_counts));
-    d->host_row_tail[4] = shift;
+    if (hybrid) {
+        RoundCuts cuts{};
+        for (int r = 0; r < R; ++r) {
+            cuts.lo[r] = parts[static_cast<size_t>(me) * R + r];
+            cuts.hi[r] = parts[static_cast<size_t>(me) * R + r + 1];
+        }
+        cuts.shift = shift;
+        hipLaunchKernelGGL(round_tables_kernel, dim3(static_cast<uint32_t>(R)), dim3(1024), 0, d->sort_stream, reduced, round_counts, cuts);
+        VRS_DHIP(d, hipGetLastError());
+    }
+    // one round sorted with vrs_sort_keys_u32_ranged: every key of the round is >= its first top byte << 24, so the sort buckets the
+    // sub-range as if it were a whole key range (hybrid shape: the step's output is the scratch buffer)
+    const auto ranged_round = [&](int r, uint64_t cnt) -> int {
+        vrs_buffer view = nullptr, sview = nullptr;
+        int e = vrs_buffer_wrap(ctx, recv + round_off[static_cast<size_t>(r)], cnt * 4, &view);
+        if (e == VRS_OK) e = vrs_buffer_wrap(ctx, scratch + round_off[static_cast<size_t>(r)], cnt * 4, &sview);
+        if (e == VRS_OK) e = vrs_sort_keys_u32_ranged(ctx, view, sview, static_cast<uint32_t>(cnt), parts[static_cast<size_t>(me) * R + r] << 24);
+        if (e == VRS_OK && hybrid) e = vrs_buffer_copy(ctx, sview, view, cnt * 4);
+        if (view) (void)vrs_buffer_release(view);
+        if (sview) (void)vrs_buffer_release(sview);
+        return e;
+    };
+    // Hybrid shape: every round's second half is enqueued before any of their plans is looked at -- a host wait per round would
+    // leave the GPU idle while the next round is enqueued -- and a round its plan refused (its kernels left at once, the keys are
+    // still in the receive buffer) is sorted whole afterwards.
+    std::vector<uint32_t> ticket(static_cast<size_t>(R), 0u);
     for (int r = 0; r < R; ++r) {
         const uint64_t cnt = round_off[static_cast<size_t>(r) + 1] - round_off[static_cast<size_t>(r)];
         VRS_DHIP(d, hipStreamWaitEvent(d->sort_stream, d->round_done[static_cast<size_t>(r)], 0));
         if (!cnt) continue;
-        vrs_buffer view = nullptr, sview = nullptr;
-        VRS_D(d, vrs_buffer_wrap(ctx, recv + round_off[static_cast<size_t>(r)], cnt * 4, &view));
-        rc = vrs_buffer_wrap(ctx, scratch + round_off[static_cast<size_t>(r)], cnt * 4, &sview);
-        if (rc != VRS_OK) {
-            (void)vrs_buffer_release(view);
-            return dfail_ctx(d, rc, "vrs_buffer_wrap");
-        }
-        bool done = false;
         if (hybrid && cnt >= (1u << 16)) {
-            // the bucket histogram of exactly this round's keys: the all-reduced one, masked to the round's top bytes
-            const uint32_t lo = parts[static_cast<size_t>(me) * R + r], hi = parts[static_cast<size_t>(me) * R + r + 1];
-            VRS_DHIP(d, hipMemsetAsync(round_counts, 0, static_cast<size_t>(VRS_MSD_COUNT_WORDS) * 4, d->sort_stream));
-            VRS_DHIP(d, hipMemcpyAsync(round_counts + lo * 64u, reduced + lo * 64u, static_cast<size_t>(hi - lo) * 64 * 4, hipMemcpyDeviceToDevice, d->sort_stream));
-            VRS_DHIP(d, hipMemcpyAsync(round_counts + VRS_MSD_SHIFT_WORD, &d->host_row_tail[4], 4, hipMemcpyHostToDevice, d->sort_stream));
-            rc = vrs_msd_finish_u32(ctx, view, sview, d->round_counts, static_cast<uint32_t>(cnt), static_cast<uint32_t>(bucket_expect));
-            int took = 0;
-            if (rc == VRS_OK) rc = vrs_msd_finish_status(ctx, &took);  // waits for the plan's head (the round has landed by then; never for the sort)
-            if (rc == VRS_OK && took) {
-                d->hybrid_rounds++;
-                done = true;
-            } else if (rc == VRS_OK) {
-                d->fallback_rounds++;  // the plan refused (a bucket beyond the local sort's capacity ...): the keys are still in the receive buffer
-            }
+            vrs_buffer view = nullptr, sview = nullptr;
+            VRS_D(d, vrs_buffer_wrap(ctx, recv + round_off[static_cast<size_t>(r)], cnt * 4, &view));
+            rc = vrs_buffer_wrap(ctx, scratch + round_off[static_cast<size_t>(r)], cnt * 4, &sview);
             if (rc != VRS_OK) {
                 (void)vrs_buffer_release(view);
-                (void)vrs_buffer_release(sview);
-                return dfail_ctx(d, rc, "vrs_msd_finish_u32 (received sub-range)");
+                return dfail_ctx(d, rc, "vrs_buffer_wrap");
             }
+            // the bucket histogram of exactly this round's keys: table r (the plan kernel reads it in place)
+            vrs_buffer table = nullptr;
+            rc = vrs_buffer_wrap(ctx, round_counts + static_cast<size_t>(r) * VRS_MSD_COUNT_WORDS, static_cast<size_t>(VRS_MSD_COUNT_WORDS) * 4, &table);
+            if (rc == VRS_OK) rc = vrs_msd_finish_u32(ctx, view, sview, table, static_cast<uint32_t>(cnt), static_cast<uint32_t>(bucket_expect));
+            if (table) (void)vrs_buffer_release(table);
+            if (rc == VRS_OK) rc = vrs_msd_finish_ticket(ctx, &ticket[static_cast<size_t>(r)]);
+            (void)vrs_buffer_release(view);
+            (void)vrs_buffer_release(sview);
+            if (rc != VRS_OK) return dfail_ctx(d, rc, "vrs_msd_finish_u32 (received sub-range)");
+        } else {
+            if ((rc = ranged_round(r, cnt))) return dfail_ctx(d, rc, "vrs_sort_keys_u32_ranged (received sub-range)");
         }
-        if (!done) {
-            // every key of the round is >= its first top byte << 24: the sort buckets the sub-range as if it were a whole key range
-            const uint32_t floor_key = parts[static_cast<size_t>(me) * R + r] << 24;
-            rc = vrs_sort_keys_u32_ranged(ctx, view, sview, static_cast<uint32_t>(cnt), floor_key);
-            // hybrid shape: the step's output is the scratch buffer
-            if (rc == VRS_OK && hybrid) rc = vrs_buffer_copy(ctx, sview, view, cnt * 4);
+    }
+    for (int r = 0; r < R; ++r) {
+        if (!ticket[static_cast<size_t>(r)]) continue;
+        int took = 0;
+        // waits for that round's plan (the round has landed by then), never for its sort
+        if ((rc = vrs_msd_finish_status_at(ctx, ticket[static_cast<size_t>(r)], &took))) return dfail_ctx(d, rc, "vrs_msd_finish_status_at");
+        if (took) {
+            d->hybrid_rounds++;
+            continue;
         }
-        (void)vrs_buffer_release(view);
-        (void)vrs_buffer_release(sview);
-        if (rc) return dfail_ctx(d, rc, "vrs_sort_keys_u32 (received sub-range)");
+        d->fallback_rounds++;
+        const uint64_t cnt = round_off[static_cast<size_t>(r) + 1] - round_off[static_cast<size_t>(r)];
+        if ((rc = ranged_round(r, cnt))) return dfail_ctx(d, rc, "vrs_sort_keys_u32_ranged (a round the hybrid form refused)");
     }
     *out_keys = hybrid ? d->scratch : d->recv;
     *out_count = static_cast<uint32_t>(total);

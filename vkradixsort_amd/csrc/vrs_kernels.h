@@ -188,7 +188,11 @@ hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_
 hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                            uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
-                           uint32_t blind_cap, const StreamCuts &cuts0, uint32_t msd_only, uint32_t max_shift);
+                           uint32_t blind_cap, const StreamCuts &cuts0, uint32_t msd_only, uint32_t max_shift,
+                           uint32_t *host_log = nullptr);
+// host_log: kMsdLogWords words of pinned host memory (device view) or nullptr; word stamp % kMsdLogWords receives
+// (stamp << 1) | msd_ok before the head's stamp
+constexpr uint32_t kMsdLogWords = 32;
 // second MSD pass: bits [18, 24) inside every top-byte bucket; grid of 8 * tiles_b workgroups; status rows: 8 * tiles_b
 // values_in / values_out: uint32 payloads that follow their keys (nullptr: keys only)
 hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,

@@ -1540,7 +1540,8 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
                                                        OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                                                        uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *__restrict__ tables,
                                                        uint32_t group_len, uint32_t tile_cap, uint32_t blind_cap,
-                                                       StreamCuts cuts0, uint32_t msd_only, uint32_t max_shift) {
+                                                       StreamCuts cuts0, uint32_t msd_only, uint32_t max_shift,
+                                                       uint32_t *host_log) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_start[kBins + 1];  // where top byte a starts
     __shared__ uint32_t s_tiles[kBins];
@@ -1680,6 +1681,10 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
             __hip_atomic_store(&host_head->msd_ok, s_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_head->msd_tiles_b, s_tiles_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_head->msd_max_bucket, s_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // a caller that enqueues several plans before it looks (the rounds of the multi-GPU step) finds each decision in a
+            // log of the last 32, keyed by the stamp (pinned host memory): {stamp's low 31 bits, ok}
+            if (host_log)
+                __hip_atomic_store(&host_log[stamp & (kMsdLogWords - 1u)], (stamp << 1) | s_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __threadfence_system();
             __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -2913,9 +2918,9 @@ hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_
 hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                            uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
-                           uint32_t blind_cap, const StreamCuts &cuts0, uint32_t msd_only, uint32_t max_shift) {
+                           uint32_t blind_cap, const StreamCuts &cuts0, uint32_t msd_only, uint32_t max_shift, uint32_t *host_log) {
     hipLaunchKernelGGL(msd_plan_kernel, dim3(1), dim3(1024), 0, stream, msd_counts, msd, plan_a, plan_lsd, host_head, stamp, n,
-                       tile, tiles_b_cap, local_cap, tables, group_len, tile_cap, blind_cap, cuts0, msd_only, max_shift);
+                       tile, tiles_b_cap, local_cap, tables, group_len, tile_cap, blind_cap, cuts0, msd_only, max_shift, host_log);
     return hipGetLastError();
 }
 
