@@ -31,8 +31,8 @@ def keys_of(kind, n, seed):
     return k
 
 
-def run_ranks(shards, rounds, capacity=None, world=None, env_shape=None):
-    """One step with len(shards) ranks as threads; returns [(rc, sorted range or error text, stats)] per rank."""
+def run_ranks(shards, rounds, capacity=None, world=None, env_shape=None, steps=2):
+    """`steps` steps with len(shards) ranks as threads; returns [(rc, sorted range or error text, stats)] per rank."""
     world = world or len(shards)
     lib = capi.load_library()
     hub = ctypes.c_void_p()
@@ -53,7 +53,7 @@ def run_ranks(shards, rounds, capacity=None, world=None, env_shape=None):
                 kb = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * max(keys.size, 1)), keys) if keys.size else vrs.Buffer(gpu, S(16))
                 out_buf, out_n = ctypes.c_void_p(), ctypes.c_uint32()
                 outs = []
-                for _ in range(2):  # twice: every buffer and event of the step is reused
+                for _ in range(steps):  # more than once: every buffer and event of the step is reused
                     rc = lib.vrs_dist_sort_keys_u32(d, kb.handle, keys.size, ctypes.byref(out_buf), ctypes.byref(out_n))
                     if rc != 0:
                         outs.append((rc, lib.vrs_dist_last_error(d).decode()))
@@ -83,9 +83,9 @@ def run_ranks(shards, rounds, capacity=None, world=None, env_shape=None):
     return results
 
 
-def check_sorted_ranges(shards, results):
+def check_sorted_ranges(shards, results, steps=2):
     allkeys = np.sort(np.concatenate(shards))
-    for step in range(2):
+    for step in range(steps):
         outs = [results[r][0][step] for r in range(len(shards))]
         assert all(rc == 0 for rc, _ in outs), outs
         got = np.concatenate([o for _, o in outs])
@@ -127,6 +127,17 @@ def test_two_ranks_byte_shape(rounds, monkeypatch):
     res = run_ranks(shards, rounds)
     check_sorted_ranges(shards, res)
     assert all(st[2] == 2 and st[0] == 0 for _, st in res)
+
+
+def test_two_ranks_a_total_beyond_the_hybrid_shape_is_remembered(monkeypatch):
+    """N_total / 16384 beyond the local sort's capacity (8 x 1e8 keys in earnest; here the test knob lowers the limit): the first
+    step finds out from the gathered table and takes the byte shape, the following ones go straight to it -- no counting read
+    and first MSD pass for nothing, one all-gather -- and the 17th looks again.  Every step bit-exact, both ranks alike."""
+    monkeypatch.setenv("VRS_DIST_HYBRID_MAX_BUCKET", "100")
+    shards = [keys_of("uniform", 1100003, 13), keys_of("uniform", 1000001, 14)]
+    res = run_ranks(shards, 2, steps=18)
+    check_sorted_ranges(shards, res, steps=18)
+    assert all(st[2] == 18 and st[0] == 0 for _, st in res)
 
 
 def test_two_ranks_small_shards_take_the_byte_shape_together():

@@ -136,7 +136,7 @@ constexpr int kRowCapacity = kRowSlices + 2;
 constexpr int kRowShift = kRowSlices + 3;   // hybrid shape: the probed bucket shift ...
 constexpr int kRowOver = kRowSlices + 4;    // ... and != 0: a key of the shard lies above the probed range
 constexpr int kRowWords = kRowSlices + 8;
-constexpr uint64_t kHybridShapeMaxBucket = 14333;  // msd_local_capacity of bare uint32 keys (vrs_kernels.hip)
+constexpr uint64_t kHybridShapeMaxBucket = 14333;  // msd_local_capacity of bare uint32 keys (vrs_kernels.hip); VRS_DIST_HYBRID_MAX_BUCKET (tests) lowers it
 
 }  // namespace
 
@@ -149,6 +149,9 @@ struct vrs_dist_t {
     vrs_dist_transport tr{};
     RcclEndpoint *rccl = nullptr;  // owned; the transport's `user` when vrs_dist_create made it
     bool byte_shape_only = false;  // VRS_DIST_SHAPE=byte
+    uint64_t hybrid_max_bucket = kHybridShapeMaxBucket;
+    bool too_large_for_hybrid = false;  // the last step that tried found N_total / 16384 beyond the local sort: the same on every rank
+    uint64_t steps = 0;
     hipStream_t sort_stream = nullptr;  // the context's stream
     hipStream_t comm_stream = nullptr;  // exchange rounds run here, beside the sorts
     std::vector<hipEvent_t> round_done;  // round r has landed in the receive buffer
@@ -464,6 +467,10 @@ int vrs_dist_create_with_transport(vrs_context ctx, const vrs_dist_transport *tr
     }
     const char *shape = std::getenv("VRS_DIST_SHAPE");
     d->byte_shape_only = shape && std::strcmp(shape, "byte") == 0;
+    if (const char *mb = std::getenv("VRS_DIST_HYBRID_MAX_BUCKET")) {  // test knob: the "total too large for the hybrid shape" path at test sizes
+        const long v = std::atol(mb);
+        if (v > 0 && static_cast<uint64_t>(v) < kHybridShapeMaxBucket) d->hybrid_max_bucket = static_cast<uint64_t>(v);
+    }
     d->sort_stream = static_cast<hipStream_t>(vrs_context_stream(ctx));
     const auto cleanup = [&](int code, const std::string &msg) {
         vrs_dist_destroy(d);
@@ -572,81 +579,94 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
     // 1. local step.  Hybrid shape: counting read + first MSD pass (the shard grouped by the top byte of its key range).
     //    The byte shape's contract partition pass, if the ranks settle on it, runs after the all-gather (the keys are
     //    untouched until then).
-    const bool try_hybrid = !d->byte_shape_only;
+    // A total the hybrid shape cannot take (about 2e8 keys: every step of 8 x 1e8) is remembered: the next steps go straight to
+    // the byte shape -- no counting read and first MSD pass for nothing, ONE all-gather instead of two -- and every 16th looks
+    // again.  The memory is the same on every rank (it comes from the gathered table), so the ranks still issue the same
+    // collectives.
+    const bool byte_first = d->byte_shape_only || (d->too_large_for_hybrid && (d->steps % 16u) != 0u);
+    d->steps++;
+    const bool try_hybrid = !byte_first;
     bool partitioned = false;
-    VRS_DHIP(d, hipMemsetAsync(row, 0, kRowWords * 4, d->sort_stream));
-    VRS_DHIP(d, hipMemsetAsync(counts, 0, static_cast<size_t>(VRS_MSD_COUNT_WORDS) * 4, d->sort_stream));
-    // The collectives need the counts, not the partitioned keys: they run on the exchange stream from the moment the counts
-    // are out (counts_ready), beside the first MSD pass, and the host waits for them only.
-    if (try_hybrid && n_eff >= (1u << 16)) {
-        const int rc = vrs_msd_partition_signal_u32(ctx, keys, d->grouped, d->counts, n_eff, d->counts_ready);
-        if (rc == VRS_OK) {
-            partitioned = true;
-        } else {
-            my_status = rc;
-            my_error = std::string("vrs_msd_partition_u32: ") + vrs_last_error(ctx);
+    if (!byte_first) {
+        VRS_DHIP(d, hipMemsetAsync(row, 0, kRowWords * 4, d->sort_stream));
+        VRS_DHIP(d, hipMemsetAsync(counts, 0, static_cast<size_t>(VRS_MSD_COUNT_WORDS) * 4, d->sort_stream));
+        // The collectives need the counts, not the partitioned keys: they run on the exchange stream from the moment the counts
+        // are out (counts_ready), beside the first MSD pass, and the host waits for them only.
+        if (try_hybrid && n_eff >= (1u << 16)) {
+            const int rc = vrs_msd_partition_signal_u32(ctx, keys, d->grouped, d->counts, n_eff, d->counts_ready);
+            if (rc == VRS_OK) {
+                partitioned = true;
+            } else {
+                my_status = rc;
+                my_error = std::string("vrs_msd_partition_u32: ") + vrs_last_error(ctx);
+            }
         }
-    }
-    if (!partitioned) VRS_DHIP(d, hipEventRecord(d->counts_ready, d->sort_stream));  // (the memsets above)
-    VRS_DHIP(d, hipStreamWaitEvent(d->comm_stream, d->counts_ready, 0));
-    if (partitioned) {
-        // the row's slice counts = words [16384, 16384 + 2048) of the counts
-        VRS_DHIP(d, hipMemcpyAsync(row, counts + 16384, kRowSlices * 4, hipMemcpyDeviceToDevice, d->comm_stream));
-        VRS_DHIP(d, hipMemcpyAsync(row + kRowShift, counts + VRS_MSD_SHIFT_WORD, 2 * 4, hipMemcpyDeviceToDevice, d->comm_stream));  // shift word + range flag
-    }
-    d->host_row_tail[0] = my_status == VRS_OK ? n : 0u;
-    d->host_row_tail[1] = static_cast<uint32_t>(my_status);
-    d->host_row_tail[2] = d->capacity;
-    VRS_DHIP(d, hipMemcpyAsync(row + kRowN, d->host_row_tail, 3 * 4, hipMemcpyHostToDevice, d->comm_stream));
+        if (!partitioned) VRS_DHIP(d, hipEventRecord(d->counts_ready, d->sort_stream));  // (the memsets above)
+        VRS_DHIP(d, hipStreamWaitEvent(d->comm_stream, d->counts_ready, 0));
+        if (partitioned) {
+            // the row's slice counts = words [16384, 16384 + 2048) of the counts
+            VRS_DHIP(d, hipMemcpyAsync(row, counts + 16384, kRowSlices * 4, hipMemcpyDeviceToDevice, d->comm_stream));
+            VRS_DHIP(d, hipMemcpyAsync(row + kRowShift, counts + VRS_MSD_SHIFT_WORD, 2 * 4, hipMemcpyDeviceToDevice, d->comm_stream));  // shift word + range flag
+        }
+        d->host_row_tail[0] = my_status == VRS_OK ? n : 0u;
+        d->host_row_tail[1] = static_cast<uint32_t>(my_status);
+        d->host_row_tail[2] = d->capacity;
+        VRS_DHIP(d, hipMemcpyAsync(row + kRowN, d->host_row_tail, 3 * 4, hipMemcpyHostToDevice, d->comm_stream));
 
-    // 2. the collectives: every rank learns every rank's row; the bucket histograms are summed
-    if (d->has_transport) {
-        VRS_DTR(d, "all-gather of the shard rows", d->tr.all_gather(d->tr.user, row, table, kRowWords, d->comm_stream));
-        if (try_hybrid) VRS_DTR(d, "all-reduce of the bucket histograms", d->tr.all_reduce(d->tr.user, counts, reduced, 16384, d->comm_stream));
-    } else {
-        VRS_DHIP(d, hipMemcpyAsync(table, row, kRowWords * 4, hipMemcpyDeviceToDevice, d->comm_stream));
-        if (try_hybrid) VRS_DHIP(d, hipMemcpyAsync(reduced, counts, 16384 * 4, hipMemcpyDeviceToDevice, d->comm_stream));
+        // 2. the collectives: every rank learns every rank's row; the bucket histograms are summed
+        if (d->has_transport) {
+            VRS_DTR(d, "all-gather of the shard rows", d->tr.all_gather(d->tr.user, row, table, kRowWords, d->comm_stream));
+            if (try_hybrid) VRS_DTR(d, "all-reduce of the bucket histograms", d->tr.all_reduce(d->tr.user, counts, reduced, 16384, d->comm_stream));
+        } else {
+            VRS_DHIP(d, hipMemcpyAsync(table, row, kRowWords * 4, hipMemcpyDeviceToDevice, d->comm_stream));
+            if (try_hybrid) VRS_DHIP(d, hipMemcpyAsync(reduced, counts, 16384 * 4, hipMemcpyDeviceToDevice, d->comm_stream));
+        }
+        VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, d->host_table.size() * 4, hipMemcpyDeviceToHost, d->comm_stream));
+        VRS_DHIP(d, hipStreamSynchronize(d->comm_stream));  // the collectives; the first MSD pass may still be running
     }
-    VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, d->host_table.size() * 4, hipMemcpyDeviceToHost, d->comm_stream));
-    VRS_DHIP(d, hipStreamSynchronize(d->comm_stream));  // the collectives; the first MSD pass may still be running
 
     // ---- from here on every rank holds the same table: every decision below is the same on all of them
     uint32_t min_capacity = 0xFFFFFFFFu;
     uint64_t grand_total = 0;
-    for (int q = 0; q < world; ++q) {
-        const uint32_t *r = &d->host_table[static_cast<size_t>(q) * kRowWords];
-        if (r[kRowStatus] != 0u) {
-            if (q == me) return dfail(d, my_status, my_error);
-            return dfail(d, VRS_ERROR_PEER, "rank " + std::to_string(q) + " could not take part in the step (its status " + std::to_string(r[kRowStatus]) + ")");
-        }
-        min_capacity = std::min(min_capacity, r[kRowCapacity]);
-        grand_total += r[kRowN];
-    }
-    // hybrid shape iff every non-empty shard was partitioned with the same bucket shift of a 27..32-bit key range and no key
-    // of any shard lies above the range its rank probed
     bool hybrid = try_hybrid;
     uint32_t shift = 0xFFFFFFFFu;  // of the first non-empty shard; empty shards have nothing to say (and nothing to send)
-    for (int q = 0; q < world && hybrid; ++q) {
-        const uint32_t *r = &d->host_table[static_cast<size_t>(q) * kRowWords];
-        if (r[kRowN] == 0u) continue;
-        if (shift == 0xFFFFFFFFu) shift = r[kRowShift];
-        if (r[kRowN] < (1u << 16) || r[kRowShift] != shift || r[kRowOver] != 0u) hybrid = false;  // too small to have been partitioned, another key range, a stray key
+    uint64_t bucket_expect = 0;
+    if (!byte_first) {
+        for (int q = 0; q < world; ++q) {
+            const uint32_t *r = &d->host_table[static_cast<size_t>(q) * kRowWords];
+            if (r[kRowStatus] != 0u) {
+                if (q == me) return dfail(d, my_status, my_error);
+                return dfail(d, VRS_ERROR_PEER, "rank " + std::to_string(q) + " could not take part in the step (its status " + std::to_string(r[kRowStatus]) + ")");
+            }
+            min_capacity = std::min(min_capacity, r[kRowCapacity]);
+            grand_total += r[kRowN];
+        }
+        // hybrid shape iff every non-empty shard was partitioned with the same bucket shift of a 27..32-bit key range and no key
+        // of any shard lies above the range its rank probed
+        for (int q = 0; q < world && hybrid; ++q) {
+            const uint32_t *r = &d->host_table[static_cast<size_t>(q) * kRowWords];
+            if (r[kRowN] == 0u) continue;
+            if (shift == 0xFFFFFFFFu) shift = r[kRowShift];
+            if (r[kRowN] < (1u << 16) || r[kRowShift] != shift || r[kRowOver] != 0u) hybrid = false;  // too small to have been partitioned, another key range, a stray key
+        }
+        if (hybrid && (shift < 13u || shift > 18u)) hybrid = false;  // (no keys at all: 0xFFFFFFFF)
+        // the hybrid shape's buckets are the top 14 bits of the GLOBAL key range: N_total / 16384 keys each, whatever the number
+        // of ranks -- they must fit the local sort (14333 keys: about 2e8 keys in total).  Larger totals take the byte shape,
+        // whose per-range sorts bucket each received sub-range on its own (vrs_sort_keys_u32_ranged).
+        bucket_expect = grand_total / 16384u + grand_total / 16384u / 8u + 64u;
+        d->too_large_for_hybrid = bucket_expect > d->hybrid_max_bucket;
+        if (hybrid && d->too_large_for_hybrid) hybrid = false;
     }
-    if (hybrid && (shift < 13u || shift > 18u)) hybrid = false;  // (no keys at all: 0xFFFFFFFF)
-    // the hybrid shape's buckets are the top 14 bits of the GLOBAL key range: N_total / 16384 keys each, whatever the number
-    // of ranks -- they must fit the local sort (14333 keys: about 2e8 keys in total).  Larger totals take the byte shape,
-    // whose per-range sorts bucket each received sub-range on its own (vrs_sort_keys_u32_ranged).
-    const uint64_t bucket_expect = grand_total / 16384u + grand_total / 16384u / 8u + 64u;
-    if (hybrid && bucket_expect > kHybridShapeMaxBucket) hybrid = false;
     (void)partitioned;
 
     // top-byte counts per rank (hybrid shape: sums over the eight slices; byte shape: filled in below) and their prefixes
     std::vector<std::vector<uint64_t>> base(static_cast<size_t>(world), std::vector<uint64_t>(257, 0));
     uint64_t byte_counts[256] = {};
     if (!hybrid) {
-        // byte shape: contract partition pass by the top byte now (12 B/key), then a second all-gather of the real rows
+        // byte shape: contract partition pass by the top byte now (12 B/key), then an all-gather of the real rows (the only one
+        // of a step that went straight here)
         d->byte_steps++;
-        uint32_t *prefix = row;  // row words [0, 256): exclusive prefix of my top-byte counts; [256]: my shard size
+        uint32_t *prefix = row;  // row words [0, 256): exclusive prefix of my top-byte counts; [256]: my shard size, [257] status, [258] capacity
         if (n_eff) {
             vrs_push_constants pc{n_eff, 24, vrs_workgroup_count(n_eff, 32), 32};
             int rc = vrs_multi_radixsort_histograms(ctx, keys, d->hist, &pc);
@@ -664,22 +684,28 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         } else {
             VRS_DHIP(d, hipMemsetAsync(prefix, 0, 256 * 4, d->sort_stream));
         }
-        d->host_row_tail[0] = n_eff;
+        constexpr size_t kByteRow = 259;
+        d->host_row_tail[0] = my_status == VRS_OK ? n_eff : 0u;
         d->host_row_tail[1] = static_cast<uint32_t>(my_status);
-        VRS_DHIP(d, hipMemcpyAsync(row + 256, d->host_row_tail, 2 * 4, hipMemcpyHostToDevice, d->sort_stream));
+        d->host_row_tail[2] = d->capacity;
+        VRS_DHIP(d, hipMemcpyAsync(row + 256, d->host_row_tail, 3 * 4, hipMemcpyHostToDevice, d->sort_stream));
         if (d->has_transport) {
-            VRS_DTR(d, "all-gather of the top-byte prefixes", d->tr.all_gather(d->tr.user, row, table, 258, d->sort_stream));
+            VRS_DTR(d, "all-gather of the top-byte prefixes", d->tr.all_gather(d->tr.user, row, table, kByteRow, d->sort_stream));
         } else {
-            VRS_DHIP(d, hipMemcpyAsync(table, row, 258 * 4, hipMemcpyDeviceToDevice, d->sort_stream));
+            VRS_DHIP(d, hipMemcpyAsync(table, row, kByteRow * 4, hipMemcpyDeviceToDevice, d->sort_stream));
         }
-        VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, static_cast<size_t>(world) * 258 * 4, hipMemcpyDeviceToHost, d->sort_stream));
+        VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, static_cast<size_t>(world) * kByteRow * 4, hipMemcpyDeviceToHost, d->sort_stream));
         VRS_DHIP(d, hipStreamSynchronize(d->sort_stream));
+        min_capacity = 0xFFFFFFFFu;
+        grand_total = 0;
         for (int q = 0; q < world; ++q) {
-            const uint32_t *r = &d->host_table[static_cast<size_t>(q) * 258];
+            const uint32_t *r = &d->host_table[static_cast<size_t>(q) * kByteRow];
             if (r[257] != 0u) {
                 if (q == me) return dfail(d, my_status, my_error);
-                return dfail(d, VRS_ERROR_PEER, "rank " + std::to_string(q) + " failed in its partition pass (status " + std::to_string(r[257]) + ")");
+                return dfail(d, VRS_ERROR_PEER, "rank " + std::to_string(q) + " could not take part in the step or failed in its partition pass (status " + std::to_string(r[257]) + ")");
             }
+            min_capacity = std::min(min_capacity, r[258]);
+            grand_total += r[256];
             for (int t = 0; t < 256; ++t) base[static_cast<size_t>(q)][static_cast<size_t>(t)] = r[t];
             base[static_cast<size_t>(q)][256] = r[256];
             for (int t = 0; t < 256; ++t) byte_counts[t] += base[static_cast<size_t>(q)][static_cast<size_t>(t) + 1] - base[static_cast<size_t>(q)][static_cast<size_t>(t)];
