@@ -135,6 +135,11 @@ int vrs_multi_radixsort_digit_offsets(vrs_context ctx, void *host_u32x256);
 /* The same 256 words copied into a device buffer, asynchronously (no host round trip: the multi-GPU step feeds
  * them straight into its count all-gather). */
 int vrs_multi_radixsort_digit_offsets_device(vrs_context ctx, vrs_buffer out_u32x256);
+/* One-shot hook for the NEXT RADIX_SORT stage of the context: as soon as its offset table is complete -- before its scatter kernel --
+ * the stage copies the 256 digit offsets to out_u32x256 (may be NULL) and records `event` (a hipEvent_t of the caller's, may be NULL)
+ * on the context's stream.  Work on another stream that needs only the offsets (the multi-GPU step's all-gather) then runs beside
+ * the scatter.  (The reference has no counterpart: its prefix lives inside multi_radixsort.comp:63-87.) */
+int vrs_multi_radixsort_offsets_hook(vrs_context ctx, vrs_buffer out_u32x256, void *event);
 /*
  * 64-bit keys: the reference's SORT_64_BIT switch (MultiRadixSort.h:10-18; NUM_ITERATIONS = 8,
  * MultiRadixSort.cpp:51-55), which it leaves as a stub ("requires changes in the two shaders").  Same two

@@ -76,6 +76,12 @@ def main():
         result["10^8 uint64 keys (SORT_64_BIT)"] = run(gpu, k64, None, max(3, reps // 2))
         n5 = 5 * 10 ** 7
         result["5 x 10^7 uint64 key + uint32 payload pairs"] = run(gpu, k64[:n5].copy(), np.arange(n5, dtype=np.uint32), max(3, reps // 2))
+        # beyond 1.03e8 elements: buckets of 6657-13312 pairs / 64-bit keys (the 1024-thread local sort of the hybrid form)
+        k2 = np.concatenate([k8, rs.randint(0, 2 ** 32, size=10 ** 8, dtype=np.uint32)])
+        result["2 x 10^8 uint32 key + uint32 payload pairs"] = run(gpu, k2, np.arange(2 * 10 ** 8, dtype=np.uint32), 3)
+        k64b = (k2.astype(np.uint64) << np.uint64(32)) | k2[::-1].astype(np.uint64)
+        del k2
+        result["2 x 10^8 uint64 keys"] = run(gpu, k64b, None, 3)
     print(json.dumps(result, indent=1))
 
 

@@ -29,6 +29,8 @@ struct vrs_context_t {
     uint32_t scratch_workgroups = 0;  // capacity of scratch.offsets in workgroups
     uint32_t scratch_chunks = 0;      // capacity of scratch.chunk_sums in chunks
     uint32_t last_offsets_workgroups = 0;  // contract workgroups of the most recent RADIX_SORT stage
+    void *offsets_hook_out = nullptr;      // one-shot (vrs_multi_radixsort_offsets_hook): the next RADIX_SORT stage copies its digit
+    void *offsets_hook_event = nullptr;    //   offsets here and records this event BEFORE its scatter kernel
     uint32_t last_offsets_stride = 1;      // rows of scratch.offsets per contract workgroup (sub-tiled launches)
     // NUM_BLOCKS_PER_WORKGROUP > 32: the histogram stage also keeps the 8192-key sub-tile table it folded the
     // caller's table from; the sort stage uses it iff it is called for exactly the same (keys, N, shift, B)
@@ -369,6 +371,13 @@ int run_sort_stage(vrs_context ctx, vrs_buffer keys_in, vrs_buffer keys_out, vrs
     VRS_HIP(ctx, vrs::launch_prefix(ctx->stream, table, ctx->scratch, prefix_rows, ev));
     ctx->last_offsets_workgroups = W;
     ctx->last_offsets_stride = rows_per_contract_tile;
+    if (ctx->offsets_hook_out || ctx->offsets_hook_event) {
+        void *out = ctx->offsets_hook_out, *event = ctx->offsets_hook_event;
+        ctx->offsets_hook_out = ctx->offsets_hook_event = nullptr;
+        if (out)
+            VRS_HIP(ctx, hipMemcpyAsync(out, ctx->scratch.offsets, VRS_RADIX_SORT_BINS * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        if (event) VRS_HIP(ctx, hipEventRecord(static_cast<hipEvent_t>(event), ctx->stream));
+    }
 
     if (row_stride > 1) {
         launch_B = kLaunchTileBlocks;
@@ -1513,6 +1522,17 @@ int vrs_multi_radixsort_digit_offsets_device(vrs_context ctx, vrs_buffer out_u32
     VRS_HIP(ctx, hipSetDevice(ctx->device));
     VRS_HIP(ctx, hipMemcpyAsync(out_u32x256->ptr, ctx->scratch.offsets, VRS_RADIX_SORT_BINS * sizeof(uint32_t),
                                 hipMemcpyDeviceToDevice, ctx->stream));
+    return VRS_OK;
+}
+
+int vrs_multi_radixsort_offsets_hook(vrs_context ctx, vrs_buffer out_u32x256, void *event) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (out_u32x256) {
+        const int rc = check_buffer(ctx, out_u32x256, VRS_RADIX_SORT_BINS * sizeof(uint32_t), "digit offsets");
+        if (rc) return rc;
+    }
+    ctx->offsets_hook_out = out_u32x256 ? out_u32x256->ptr : nullptr;
+    ctx->offsets_hook_event = event;
     return VRS_OK;
 }
 

@@ -667,15 +667,22 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         // of a step that went straight here)
         d->byte_steps++;
         uint32_t *prefix = row;  // row words [0, 256): exclusive prefix of my top-byte counts; [256]: my shard size, [257] status, [258] capacity
+        // the all-gather needs the prefix of my top-byte counts, not the partitioned keys: the sort stage hands the prefix out (and
+        // signals counts_ready) before its scatter kernel, and the collective runs on the exchange stream beside that kernel
+        bool signalled = false;
         if (n_eff) {
             vrs_push_constants pc{n_eff, 24, vrs_workgroup_count(n_eff, 32), 32};
             int rc = vrs_multi_radixsort_histograms(ctx, keys, d->hist, &pc);
-            if (rc == VRS_OK) rc = vrs_multi_radixsort(ctx, keys, d->grouped, d->hist, &pc);
             if (rc == VRS_OK) {
                 vrs_buffer pv = nullptr;
                 rc = vrs_buffer_wrap(ctx, prefix, 256 * 4, &pv);
-                if (rc == VRS_OK) rc = vrs_multi_radixsort_digit_offsets_device(ctx, pv);
-                (void)vrs_buffer_release(pv);
+                if (rc == VRS_OK) rc = vrs_multi_radixsort_offsets_hook(ctx, pv, d->counts_ready);
+                if (rc == VRS_OK) {
+                    rc = vrs_multi_radixsort(ctx, keys, d->grouped, d->hist, &pc);
+                    signalled = rc == VRS_OK;
+                    if (!signalled) (void)vrs_multi_radixsort_offsets_hook(ctx, nullptr, nullptr);  // (a stage that failed before its prefix)
+                }
+                if (pv) (void)vrs_buffer_release(pv);
             }
             if (rc != VRS_OK) {
                 my_status = rc;
@@ -684,18 +691,20 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         } else {
             VRS_DHIP(d, hipMemsetAsync(prefix, 0, 256 * 4, d->sort_stream));
         }
+        if (!signalled) VRS_DHIP(d, hipEventRecord(d->counts_ready, d->sort_stream));
+        VRS_DHIP(d, hipStreamWaitEvent(d->comm_stream, d->counts_ready, 0));
         constexpr size_t kByteRow = 259;
         d->host_row_tail[0] = my_status == VRS_OK ? n_eff : 0u;
         d->host_row_tail[1] = static_cast<uint32_t>(my_status);
         d->host_row_tail[2] = d->capacity;
-        VRS_DHIP(d, hipMemcpyAsync(row + 256, d->host_row_tail, 3 * 4, hipMemcpyHostToDevice, d->sort_stream));
+        VRS_DHIP(d, hipMemcpyAsync(row + 256, d->host_row_tail, 3 * 4, hipMemcpyHostToDevice, d->comm_stream));
         if (d->has_transport) {
-            VRS_DTR(d, "all-gather of the top-byte prefixes", d->tr.all_gather(d->tr.user, row, table, kByteRow, d->sort_stream));
+            VRS_DTR(d, "all-gather of the top-byte prefixes", d->tr.all_gather(d->tr.user, row, table, kByteRow, d->comm_stream));
         } else {
-            VRS_DHIP(d, hipMemcpyAsync(table, row, kByteRow * 4, hipMemcpyDeviceToDevice, d->sort_stream));
+            VRS_DHIP(d, hipMemcpyAsync(table, row, kByteRow * 4, hipMemcpyDeviceToDevice, d->comm_stream));
         }
-        VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, static_cast<size_t>(world) * kByteRow * 4, hipMemcpyDeviceToHost, d->sort_stream));
-        VRS_DHIP(d, hipStreamSynchronize(d->sort_stream));
+        VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, static_cast<size_t>(world) * kByteRow * 4, hipMemcpyDeviceToHost, d->comm_stream));
+        VRS_DHIP(d, hipStreamSynchronize(d->comm_stream));  // the collective; the scatter may still be running
         min_capacity = 0xFFFFFFFFu;
         grand_total = 0;
         for (int q = 0; q < world; ++q) {
