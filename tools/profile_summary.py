@@ -26,7 +26,7 @@ for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
 total = sum(sum(v) for v in dur.values())
 lines = ["kernel,calls,total_us,avg_us,min_us,max_us,percent"]
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-    lines.append(f"{k},{len(v)},{sum(v):.1f},{sum(v)/len(v):.2f},{min(v):.2f},{max(v):.2f},{100*sum(v)/total:.2f}")
+    lines.append(f'"{k}",{len(v)},{sum(v):.1f},{sum(v)/len(v):.2f},{min(v):.2f},{max(v):.2f},{100*sum(v)/total:.2f}')  # names hold commas
 open(f"{out}/{rnd}_bench_kernel_stats.csv", "w").write("\n".join(lines) + "\n")
 
 # rocprofv3's own stats file, verbatim
