@@ -794,6 +794,8 @@ def bench_multi(args):
     rearm()
     st0 = [ctypes.c_uint64() for _ in range(3)]
     lib.vrs_dist_stats(d, *[ctypes.byref(x) for x in st0])
+    gr0 = ctypes.c_uint64()
+    lib.vrs_dist_grouped_rounds(d, ctypes.byref(gr0))
     gpu.profileReset()
     gpu.profileEnableMask(1 << capi.VRS_KERNEL_LOOKBACK_SCATTER)  # events ride on the dominant kernel's own launches
     barrier()
@@ -808,6 +810,9 @@ def bench_multi(args):
     st1 = [ctypes.c_uint64() for _ in range(3)]
     lib.vrs_dist_stats(d, *[ctypes.byref(x) for x in st1])
     hybrid_rounds, fallback_rounds, byte_steps = (b.value - a.value for a, b in zip(st0, st1))
+    gr1 = ctypes.c_uint64()
+    lib.vrs_dist_grouped_rounds(d, ctypes.byref(gr1))
+    grouped_rounds = gr1.value - gr0.value
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -844,11 +849,13 @@ def bench_multi(args):
         hybrid = byte_steps == 0
         # rank 0's look-back scatter launches of the timed region: hybrid shape = the first MSD pass over the shard + one second
         # pass per received sub-range (each reads and writes its keys once); byte shape = the launches of the local sorts
+        grouped = (not hybrid) and grouped_rounds > 0 and fallback_rounds == 0
         lb_bytes = 8.0 * (n + recv_keys) * K if hybrid else 8.0 * (recv_keys / max(rounds, 1)) * lb_launches
         lb_achieved = lb_bytes / (lb_ms * 1e-3) / 1e9 if lb_ms > 0 else None
         # byte shape: 12 (contract partition pass) + what vrs_sort_keys_u32_ranged moves per received sub-range: 28 in its hybrid
         # form (from 1.3e7 keys on), 36 in its LSD form
-        sort_bpk = 28 if hybrid else (40 if recv_keys / max(rounds, 1) >= 1.3e7 else 48)
+        # byte shape with the grouped finish: 12 + (counting read 4 + second MSD pass 8 + local sort 8)
+        sort_bpk = 28 if hybrid else 32 if grouped else (40 if recv_keys / max(rounds, 1) >= 1.3e7 else 48)
         base = None
         if not args.no_cpu_baseline:
             from tests import _oracle
@@ -870,11 +877,16 @@ def bench_multi(args):
                                 "all-reduce of counts, RCCL send/recv of one message per (sender, top byte) in "
                                 f"{rounds} round(s), second MSD pass + LDS-local sort per received sub-range") if hybrid else
                                ("vrs_dist_sort_keys_u32, byte shape (the global top-14-bit buckets would not fit the local sort): contract "
+                                f"partition pass by the top byte, RCCL send/recv of one message per (sender, top byte) in {rounds} round(s), "
+                                "per received sub-range one counting read + second MSD pass by the next 8 bits + LDS-local sort "
+                                "(vrs_msd_finish_grouped_u32)") if grouped else
+                               ("vrs_dist_sort_keys_u32, byte shape (the global top-14-bit buckets would not fit the local sort): contract "
                                 f"partition pass by the top byte, RCCL send/recv per (sender, round) in {rounds} round(s), "
                                 "vrs_sort_keys_u32_ranged per received sub-range (its own 16384 buckets)"),
                        "num_elements_per_gpu": n, "parallelism": f"range-sharded x{world}", "exchange_rounds": rounds,
                        "rounds_tried_in_warmup_ms": {str(k): round(v * 1e3, 3) for k, v in tried.items()},
-                       "received_sub_ranges": {"finished_in_hybrid_shape": int(hybrid_rounds), "sorted_from_scratch_after_a_refused_plan": int(fallback_rounds)},
+                       "received_sub_ranges": {"finished_in_hybrid_shape": int(hybrid_rounds), "finished_grouped_in_byte_shape": int(grouped_rounds),
+                                               "sorted_from_scratch_after_a_refused_plan": int(fallback_rounds)},
                        "hbm_bytes_per_key": sort_bpk + 8,
                        "hbm_bytes_per_key_breakdown": ({"counting_read": 4, "first_msd_pass": 8, "exchange_read_and_landing_write": 8,
                                                         "second_msd_pass": 8, "local_sort": 8} if hybrid else

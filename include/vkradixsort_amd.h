@@ -254,6 +254,13 @@ int vrs_msd_partition_signal_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer ou
                                  void *counts_ready_event);
 int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_buffer counts, uint32_t num_elements,
                        uint32_t bucket_hint);
+/* The same second half for keys that are grouped by their TOP BYTE and lie in top bytes [first_top_byte, first_top_byte + top_bytes)
+ * -- what a rank of a large multi-GPU sort holds after the exchange -- with no histogram from the caller: one counting read of the
+ * n keys (buckets = top byte and the next min(8, 14 - ceil(log2(top_bytes))) bits), then the second MSD pass by those bits and the
+ * local sort: 20 bytes per key instead of the 28 of a whole sort.  Refused (ticket / status as above; `grouped` untouched) when a
+ * bucket exceeds the local sort's capacity: about 3.6 * 10^6 keys per top byte. */
+int vrs_msd_finish_grouped_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, uint32_t num_elements, uint32_t first_top_byte,
+                               uint32_t top_bytes);
 int vrs_msd_finish_status(vrs_context ctx, int *took);
 int vrs_msd_finish_ticket(vrs_context ctx, uint32_t *ticket);
 int vrs_msd_finish_status_at(vrs_context ctx, uint32_t ticket, int *took);
@@ -342,6 +349,9 @@ const char *vrs_dist_last_error(vrs_dist dist);
 /* cumulative: received sub-ranges finished in the hybrid shape / sorted by vrs_sort_keys_u32 after a refused plan; steps
  * that took the byte shape.  Any pointer may be NULL. */
 int vrs_dist_stats(vrs_dist dist, uint64_t *hybrid_rounds, uint64_t *fallback_rounds, uint64_t *byte_shape_steps);
+/* rounds of byte-shape steps finished by vrs_msd_finish_grouped_u32 (one counting read + second MSD pass + local sort: 20 B/key)
+ * instead of a whole ranged sort (28) */
+int vrs_dist_grouped_rounds(vrs_dist dist, uint64_t *grouped_rounds);
 typedef struct vrs_dist_loopback_t *vrs_dist_loopback;
 int vrs_dist_loopback_create(int world, vrs_dist_loopback *out_hub);
 /* fills *out with rank `rank`'s end of the hub; call it on the thread that drives the rank, its device current */

@@ -252,3 +252,58 @@ def test_msd_halves_several_finishes_enqueued_before_any_is_asked_about():
         assert np.array_equal(res, np.sort(keys))
         for b in [kb, grouped, out, counts, cb, scratch_in, scratch_out] + round_counts:
             b.release()
+
+
+@pytest.mark.parametrize("first,top_bytes,n", [(0, 256, 6000001), (0x40, 64, 5000003), (0xA0, 32, 4000001), (0x10, 9, 3000007),
+                                                (0xFE, 2, 2500001), (0x7F, 1, 2000003), (0x03, 100, 7000001), (0xE0, 32, 70001)])
+def test_msd_finish_grouped_sorts_keys_that_arrive_grouped_by_top_byte(first, top_bytes, n):
+    """vrs_msd_finish_grouped_u32: keys of top bytes [first, first + count), grouped by top byte in any inner order (what a rank
+    holds after the exchange of a large multi-GPU sort) -> one counting read, the second MSD pass by the next 8 (or 14 -
+    ceil(log2(count))) bits, the local sort.  Bit-exact vs std::sort for group counts from 1 to 256 (no multiple of 8 among them:
+    some XCDs then walk one group more), and the ticket says the form was taken."""
+    lib = capi.load_library()
+    rs = np.random.RandomState(first * 1000 + top_bytes)
+    keys = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    keys = (keys & np.uint32(0x00FFFFFF)) | ((rs.randint(first, first + top_bytes, size=n).astype(np.uint32)) << np.uint32(24))
+    grouped_host = keys[np.argsort(keys >> np.uint32(24), kind="stable")]
+    with vrs.GPUContext(0) as gpu:
+        g = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), grouped_host)
+        out = vrs.Buffer(gpu, S(4 * n))
+        for _ in range(2):  # twice: the second call finds the status words already clear
+            gpu.check(lib.vrs_buffer_upload(gpu.handle, g.handle, grouped_host.ctypes.data_as(ctypes.c_void_p), grouped_host.nbytes))
+            gpu.check(lib.vrs_msd_finish_grouped_u32(gpu.handle, g.handle, out.handle, n, first, top_bytes))
+            t = ctypes.c_uint32()
+            gpu.check(lib.vrs_msd_finish_ticket(gpu.handle, ctypes.byref(t)))
+            took = ctypes.c_int(-1)
+            gpu.check(lib.vrs_msd_finish_status_at(gpu.handle, t.value, ctypes.byref(took)))
+            assert took.value == 1
+            res = np.empty(n, np.uint32)
+            out.downloadWithStagingBuffer(res)
+            assert np.array_equal(res, np.sort(keys))
+        g.release()
+        out.release()
+
+
+def test_msd_finish_grouped_refuses_a_bucket_no_workgroup_can_hold_and_rejects_bad_ranges():
+    lib = capi.load_library()
+    n, first, top_bytes = 3000001, 0x20, 16
+    rs = np.random.RandomState(5)
+    keys = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    keys = (keys & np.uint32(0x00FFFFFF)) | ((rs.randint(first, first + top_bytes, size=n).astype(np.uint32)) << np.uint32(24))
+    keys[: n // 8] = (keys[: n // 8] & np.uint32(0xFFFF)) | np.uint32(0x25AB0000)  # 375 000 keys in ONE (top byte, next 8 bits) bucket
+    grouped_host = keys[np.argsort(keys >> np.uint32(24), kind="stable")]
+    with vrs.GPUContext(0) as gpu:
+        g = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), grouped_host)
+        out = vrs.Buffer(gpu, S(4 * n))
+        gpu.check(lib.vrs_msd_finish_grouped_u32(gpu.handle, g.handle, out.handle, n, first, top_bytes))
+        took = ctypes.c_int(-1)
+        gpu.check(lib.vrs_msd_finish_status(gpu.handle, ctypes.byref(took)))
+        assert took.value == 0
+        back = np.empty(n, np.uint32)
+        g.downloadWithStagingBuffer(back)
+        assert np.array_equal(back, grouped_host)  # refused: nothing has moved
+        assert lib.vrs_msd_finish_grouped_u32(gpu.handle, g.handle, out.handle, n, 250, 10) == capi.VRS_ERROR_INVALID_ARGUMENT
+        assert lib.vrs_msd_finish_grouped_u32(gpu.handle, g.handle, out.handle, n, 0, 0) == capi.VRS_ERROR_INVALID_ARGUMENT
+        assert lib.vrs_msd_finish_grouped_u32(gpu.handle, g.handle, g.handle, n, 0, 16) == capi.VRS_ERROR_INVALID_ARGUMENT
+        g.release()
+        out.release()

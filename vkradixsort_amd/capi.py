@@ -131,6 +131,7 @@ _SIGNATURES = [
     ("vrs_dist_create_with_transport", c_int, [c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, POINTER(c_void_p)]),
     ("vrs_dist_destroy", c_int, [c_void_p]),
     ("vrs_dist_stats", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
+    ("vrs_dist_grouped_rounds", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_dist_loopback_create", c_int, [c_int, POINTER(c_void_p)]),
     ("vrs_dist_loopback_transport", c_int, [c_void_p, c_int, c_void_p]),
     ("vrs_dist_loopback_destroy", c_int, [c_void_p]),
@@ -138,6 +139,7 @@ _SIGNATURES = [
     ("vrs_msd_finish_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_uint32]),
     ("vrs_multi_radixsort_offsets_hook", c_int, [c_void_p, c_void_p, c_void_p]),
     ("vrs_msd_partition_signal_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
+    ("vrs_msd_finish_grouped_u32", c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_uint32, c_uint32]),
     ("vrs_msd_finish_status", c_int, [c_void_p, POINTER(c_int)]),
     ("vrs_msd_finish_ticket", c_int, [c_void_p, POINTER(c_uint32)]),
     ("vrs_msd_finish_status_at", c_int, [c_void_p, c_uint32, POINTER(c_int)]),

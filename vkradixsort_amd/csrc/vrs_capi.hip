@@ -110,6 +110,7 @@ struct vrs_context_t {
         size_t ev_lb_before = 0, ev_ls_before = 0;
         uint32_t key_base = 0;      // vrs_sort_keys_u32_ranged: every key is promised to be >= this (a multiple of 2^24)
         uint32_t bucket_hint = 0;   // blind tail: expected largest bucket (0 = from n); picks the local sort's workgroup shape
+        uint32_t pass_b_groups = 0; // second MSD pass over fewer than 256 groups (vrs_msd_finish_grouped_u32): XCD x walks groups x, x + 8, ...
     } one_read;
     bool one_read_settling = false;
     uint32_t os_msd_half_stamp = 0;      // stamp of the most recent vrs_msd_finish_u32's plan
@@ -796,6 +797,12 @@ static OneReadGeometry one_read_geometry(vrs_context ctx, const vrs_context_t::O
     // second MSD pass: every XCD walks 32 top-byte buckets, each rounded up to whole tiles.  Launched once the plan is known
     // it may be up to 25 % over the even share; launched blind (async mode) the grid IS the cap, so the slack is 6 %
     g.tiles_b_cap = st.blind_tail ? even + even / 16 + 40 : even + even / 4 + 40;
+    if (st.pass_b_groups) {
+        // a number of groups that is no multiple of 8 leaves some XCDs one group more than others: room for the fullest
+        const uint32_t per_xcd = (st.pass_b_groups + 7u) / 8u;
+        const uint32_t group_tiles_b = (g.tiles_total + st.pass_b_groups - 1) / st.pass_b_groups + 1;
+        g.tiles_b_cap = std::max(g.tiles_b_cap, per_xcd * (group_tiles_b + group_tiles_b / 16u) + 40u);
+    }
     // the local sort's capacity per bucket; launched blind, the workgroup shape of bare uint32 keys is chosen from N alone
     // (uniform keys: buckets of N / 16384 +- a few per cent)
     g.local_cap = vrs::msd_local_capacity(pairs || wide);
@@ -1210,7 +1217,8 @@ static_assert(VRS_MSD_COUNT_WORDS == vrs::kMsdCountWords && VRS_MSD_SHIFT_WORD =
 
 // ---- the hybrid form in two halves, for callers that move the keys between its two MSD passes (vrs_dist_*: the exchange
 // between the GPUs sits there).  Both halves only enqueue.
-static int msd_half_setup(vrs_context ctx, uint32_t n, vrs_context_t::OneRead *st, OneReadGeometry *g, uint32_t bucket_hint = 0) {
+static int msd_half_setup(vrs_context ctx, uint32_t n, vrs_context_t::OneRead *st, OneReadGeometry *g, uint32_t bucket_hint = 0,
+                          uint32_t pass_b_groups = 0) {
     if (!ctx->xcc_map_valid || !ctx->atomic_rank_verified || !ctx->scatter.atomic_rank)
         return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the hybrid form needs the look-back placement probe and the LDS-atomic ranking self-test to have passed on this device");
     if (n == 0 || n >= (1u << 30)) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the hybrid form takes 1 .. 2^30 - 1 keys");
@@ -1221,6 +1229,7 @@ static int msd_half_setup(vrs_context ctx, uint32_t n, vrs_context_t::OneRead *s
     st->blind_tail = true;
     st->fast_count = true;
     st->bucket_hint = bucket_hint;
+    st->pass_b_groups = pass_b_groups;
     *g = one_read_geometry(ctx, *st);
     return one_read_scratch(ctx, *st, *g);
 }
@@ -1294,6 +1303,49 @@ int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_
                                       reinterpret_cast<uint32_t *>(ctx->os_host_head_dev + 1)));
     st.kptr[0] = out->ptr;      // "home": the second pass writes here, the local sort works here
     st.kptr[1] = grouped->ptr;  // the partner holds the first pass's output
+    st.cur_at_start = 0;
+    return one_read_hybrid_tail(ctx, st, g, g.tiles_b_cap, g.local_cap, true);
+}
+
+int vrs_msd_finish_grouped_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, uint32_t n, uint32_t first_top_byte,
+                               uint32_t top_bytes) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    int rc;
+    const size_t bytes = static_cast<size_t>(n) * sizeof(uint32_t);
+    if ((rc = check_buffer(ctx, grouped, bytes, "grouped"))) return rc;
+    if ((rc = check_buffer(ctx, out, bytes, "out"))) return rc;
+    if (grouped->ptr == out->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "grouped and out alias");
+    if (top_bytes == 0 || first_top_byte > 255u || first_top_byte + top_bytes > 256u)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "top bytes [first, first + count) must lie in [0, 256)");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = settle_pending(ctx))) return rc;
+    // the 14-bit bucket index = (top byte - first) in its high bits, the next sub_bits of the key below: as many as the
+    // second pass can sort by (8) while all groups fit the 16384 buckets
+    uint32_t group_bits = 0;
+    while ((1u << group_bits) < top_bytes) ++group_bits;
+    const uint32_t sub_bits = std::min(8u, 14u - group_bits), shift = 24u - sub_bits;
+    const uint32_t key_base = first_top_byte << 24;
+    vrs_context_t::OneRead st;
+    OneReadGeometry g;
+    const uint32_t hint = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(n) * 9u / 8u) / (static_cast<uint64_t>(top_bytes) << sub_bits) + 64u, 0xFFFFFFFFu));
+    if ((rc = msd_half_setup(ctx, n, &st, &g, hint, top_bytes))) return rc;
+    st.key_base = key_base;
+    ctx->sub_cache.valid = false;
+    if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
+    ctx->os_msd_half_stamp = ctx->os_stamp;
+    // the counting read clears the look-back rows unless the last kernel that touched them left them clear
+    const size_t zero_words = ctx->os_status_clean ? 0 : ctx->os_status_rows * VRS_RADIX_SORT_BINS;
+    ctx->os_status_clean = false;
+    vrs::LaunchEvents ev;
+    if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, grouped->ptr, n, g.group_len, ctx->os_tables, ctx->os_status, zero_words,
+                                              ctx->scatter.compute_units, ctx->os_msd_counts, true, ev, key_base, shift));
+    VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
+                                      ctx->os_host_head_dev, ctx->os_stamp, n, g.T, g.tiles_b_cap, g.local_cap, ctx->os_tables,
+                                      g.group_len, g.tile_cap, g.blind_cap, g.cuts0, 1u, 18u,
+                                      reinterpret_cast<uint32_t *>(ctx->os_host_head_dev + 1), sub_bits));
+    st.kptr[0] = out->ptr;
+    st.kptr[1] = grouped->ptr;
     st.cur_at_start = 0;
     return one_read_hybrid_tail(ctx, st, g, g.tiles_b_cap, g.local_cap, true);
 }

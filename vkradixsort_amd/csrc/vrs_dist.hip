@@ -162,7 +162,8 @@ struct vrs_dist_t {
     uint32_t host_row_tail[8] = {};  // host words on their way into device rows: [0..2] shard size, status, capacity
     std::string last_error;
     double max_imbalance = 1.15;
-    uint64_t hybrid_rounds = 0, fallback_rounds = 0, byte_steps = 0;
+    uint64_t hybrid_rounds = 0, fallback_rounds = 0, byte_steps = 0, grouped_rounds = 0;
+    bool no_grouped_finish = false;  // VRS_DIST_GROUPED_FINISH=0: the byte shape with whole ranged sorts (tests, A/B)
 };
 
 namespace {
@@ -467,6 +468,7 @@ int vrs_dist_create_with_transport(vrs_context ctx, const vrs_dist_transport *tr
     }
     const char *shape = std::getenv("VRS_DIST_SHAPE");
     d->byte_shape_only = shape && std::strcmp(shape, "byte") == 0;
+    if (const char *gf = std::getenv("VRS_DIST_GROUPED_FINISH")) d->no_grouped_finish = std::strcmp(gf, "0") == 0;
     if (const char *mb = std::getenv("VRS_DIST_HYBRID_MAX_BUCKET")) {  // test knob: the "total too large for the hybrid shape" path at test sizes
         const long v = std::atol(mb);
         if (v > 0 && static_cast<uint64_t>(v) < kHybridShapeMaxBucket) d->hybrid_max_bucket = static_cast<uint64_t>(v);
@@ -543,6 +545,12 @@ int vrs_dist_stats(vrs_dist d, uint64_t *hybrid_rounds, uint64_t *fallback_round
     if (hybrid_rounds) *hybrid_rounds = d->hybrid_rounds;
     if (fallback_rounds) *fallback_rounds = d->fallback_rounds;
     if (byte_shape_steps) *byte_shape_steps = d->byte_steps;
+    return VRS_OK;
+}
+
+int vrs_dist_grouped_rounds(vrs_dist d, uint64_t *grouped_rounds) {
+    if (!d || !grouped_rounds) return dfail(d, VRS_ERROR_INVALID_ARGUMENT, "dist or grouped_rounds is NULL");
+    *grouped_rounds = d->grouped_rounds;
     return VRS_OK;
 }
 
@@ -752,8 +760,19 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
                      "top bytes too concentrated for byte-aligned key ranges (small or clustered keys): use the sampled-splitter "
                      "path of vkradixsort_amd.distributed.RangeShardedSort, or a larger capacity (the smallest capacity of all ranks counts)");
 
-    // what I receive in round r: hybrid shape one message per (top byte, source) in that order -- the round's keys land
-    // grouped by top byte; byte shape one message per source.  round_off: where round r starts in the receive buffer.
+    // Byte shape: if no top byte holds more keys than its 256 sub-buckets can take (the same verdict on every rank: the summed
+    // top-byte counts decide), the keys also land grouped by top byte and every round is finished by ONE counting read, the
+    // second MSD pass by the next 8 bits and the local sort (vrs_msd_finish_grouped_u32: 20 B/key instead of a whole ranged sort's 28).
+    bool grouped_finish = false;
+    if (!hybrid && !d->no_grouped_finish) {
+        uint64_t fullest = 0;
+        for (int t = 0; t < 256; ++t) fullest = std::max(fullest, byte_counts[t]);
+        grouped_finish = fullest <= 256u * 12500u && grand_total >= (1u << 16);
+    }
+    const bool by_top_byte = hybrid || grouped_finish;  // one message per (top byte, source), the result built in the scratch buffer
+
+    // what I receive in round r: one message per (top byte, source) in that order -- the round's keys land grouped by top byte --
+    // or (byte shape with whole ranged sorts) one message per source.  round_off: where round r starts in the receive buffer.
     std::vector<uint64_t> round_off(static_cast<size_t>(R) + 1, 0);
     for (int r = 0; r < R; ++r) {
         const uint32_t lo = parts[static_cast<size_t>(me) * R + r], hi = parts[static_cast<size_t>(me) * R + r + 1];
@@ -805,7 +824,7 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
             }
             off += b - a;
         };
-        if (hybrid) {
+        if (by_top_byte) {
             for (uint32_t t = lo; t < hi; ++t)
                 for (int s = 0; s < world; ++s) land(s, t, t + 1);
         } else {
@@ -815,7 +834,7 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         for (int dst = 0; dst < world && failed == 0; ++dst) {
             if (dst == me) continue;
             const uint32_t dlo = parts[static_cast<size_t>(dst) * R + r], dhi = parts[static_cast<size_t>(dst) * R + r + 1];
-            if (hybrid) {
+            if (by_top_byte) {
                 for (uint32_t t = dlo; t < dhi && failed == 0; ++t) {
                     const uint64_t a = base[static_cast<size_t>(me)][t], b = base[static_cast<size_t>(me)][t + 1];
                     if (b > a) tr("send", d->tr.send(d->tr.user, grouped + a, b - a, dst, d->comm_stream));
@@ -855,7 +874,7 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         int e = vrs_buffer_wrap(ctx, recv + round_off[static_cast<size_t>(r)], cnt * 4, &view);
         if (e == VRS_OK) e = vrs_buffer_wrap(ctx, scratch + round_off[static_cast<size_t>(r)], cnt * 4, &sview);
         if (e == VRS_OK) e = vrs_sort_keys_u32_ranged(ctx, view, sview, static_cast<uint32_t>(cnt), parts[static_cast<size_t>(me) * R + r] << 24);
-        if (e == VRS_OK && hybrid) e = vrs_buffer_copy(ctx, sview, view, cnt * 4);
+        if (e == VRS_OK && by_top_byte) e = vrs_buffer_copy(ctx, sview, view, cnt * 4);
         if (view) (void)vrs_buffer_release(view);
         if (sview) (void)vrs_buffer_release(sview);
         return e;
@@ -868,7 +887,7 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         const uint64_t cnt = round_off[static_cast<size_t>(r) + 1] - round_off[static_cast<size_t>(r)];
         VRS_DHIP(d, hipStreamWaitEvent(d->sort_stream, d->round_done[static_cast<size_t>(r)], 0));
         if (!cnt) continue;
-        if (hybrid && cnt >= (1u << 16)) {
+        if (by_top_byte && cnt >= (1u << 16)) {
             vrs_buffer view = nullptr, sview = nullptr;
             VRS_D(d, vrs_buffer_wrap(ctx, recv + round_off[static_cast<size_t>(r)], cnt * 4, &view));
             rc = vrs_buffer_wrap(ctx, scratch + round_off[static_cast<size_t>(r)], cnt * 4, &sview);
@@ -876,15 +895,20 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
                 (void)vrs_buffer_release(view);
                 return dfail_ctx(d, rc, "vrs_buffer_wrap");
             }
-            // the bucket histogram of exactly this round's keys: table r (the plan kernel reads it in place)
-            vrs_buffer table = nullptr;
-            rc = vrs_buffer_wrap(ctx, round_counts + static_cast<size_t>(r) * VRS_MSD_COUNT_WORDS, static_cast<size_t>(VRS_MSD_COUNT_WORDS) * 4, &table);
-            if (rc == VRS_OK) rc = vrs_msd_finish_u32(ctx, view, sview, table, static_cast<uint32_t>(cnt), static_cast<uint32_t>(bucket_expect));
-            if (table) (void)vrs_buffer_release(table);
+            if (hybrid) {
+                // the bucket histogram of exactly this round's keys: table r (the plan kernel reads it in place)
+                vrs_buffer table = nullptr;
+                rc = vrs_buffer_wrap(ctx, round_counts + static_cast<size_t>(r) * VRS_MSD_COUNT_WORDS, static_cast<size_t>(VRS_MSD_COUNT_WORDS) * 4, &table);
+                if (rc == VRS_OK) rc = vrs_msd_finish_u32(ctx, view, sview, table, static_cast<uint32_t>(cnt), static_cast<uint32_t>(bucket_expect));
+                if (table) (void)vrs_buffer_release(table);
+            } else {
+                const uint32_t lo = parts[static_cast<size_t>(me) * R + r], hi = parts[static_cast<size_t>(me) * R + r + 1];
+                rc = vrs_msd_finish_grouped_u32(ctx, view, sview, static_cast<uint32_t>(cnt), lo, hi - lo);
+            }
             if (rc == VRS_OK) rc = vrs_msd_finish_ticket(ctx, &ticket[static_cast<size_t>(r)]);
             (void)vrs_buffer_release(view);
             (void)vrs_buffer_release(sview);
-            if (rc != VRS_OK) return dfail_ctx(d, rc, "vrs_msd_finish_u32 (received sub-range)");
+            if (rc != VRS_OK) return dfail_ctx(d, rc, hybrid ? "vrs_msd_finish_u32 (received sub-range)" : "vrs_msd_finish_grouped_u32 (received sub-range)");
         } else {
             if ((rc = ranged_round(r, cnt))) return dfail_ctx(d, rc, "vrs_sort_keys_u32_ranged (received sub-range)");
         }
@@ -895,14 +919,15 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         // waits for that round's plan (the round has landed by then), never for its sort
         if ((rc = vrs_msd_finish_status_at(ctx, ticket[static_cast<size_t>(r)], &took))) return dfail_ctx(d, rc, "vrs_msd_finish_status_at");
         if (took) {
-            d->hybrid_rounds++;
+            if (hybrid) d->hybrid_rounds++;
+            else d->grouped_rounds++;
             continue;
         }
         d->fallback_rounds++;
         const uint64_t cnt = round_off[static_cast<size_t>(r) + 1] - round_off[static_cast<size_t>(r)];
         if ((rc = ranged_round(r, cnt))) return dfail_ctx(d, rc, "vrs_sort_keys_u32_ranged (a round the hybrid form refused)");
     }
-    *out_keys = hybrid ? d->scratch : d->recv;
+    *out_keys = by_top_byte ? d->scratch : d->recv;
     *out_count = static_cast<uint32_t>(total);
     return VRS_OK;
 }

@@ -164,7 +164,8 @@ constexpr uint32_t kMsdBucketCount = 1u << 14;
 struct MsdPlan {
     uint32_t shift;                       // bucket = key >> shift (the top 14 bits of the key range)
     uint32_t ok;                          // 1 = the plan took the hybrid form; 0 = a second MSD pass / local sort enqueued before the plan was known leaves at once
-    uint32_t pad[2];
+    uint32_t sub_bits;                    // bucket bits the second MSD pass sorts by (6: a whole sort; up to 8: vrs_msd_finish_grouped_u32)
+    uint32_t pad;
     uint32_t xcd_tiles[8][33];            // XCD x walks top-byte buckets x, x+8, ...: exclusive prefix of their tile counts
     uint32_t base[kMsdBucketCount + 1];   // exclusive prefix of the bucket sizes = where bucket b starts when sorted
 };
@@ -177,7 +178,9 @@ constexpr uint32_t kShiftFromPlan = 0xFFFFFFFFu;  // launch_onesweep_scatter: ta
 // the hybrid form can take gets ONLY the bucket histogram -- launch_msd_plan must be told the same
 hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *tables,
                                    uint32_t *status, size_t status_words, int compute_units, uint32_t *msd_counts,
-                                   bool msd_only, LaunchEvents ev = {}, uint32_t key_base = 0);
+                                   bool msd_only, LaunchEvents ev = {}, uint32_t key_base = 0, uint32_t force_shift = 0);
+// force_shift != 0: no range probe, bucket = (key - key_base) >> force_shift (a caller that knows the range: keys grouped by
+// top byte, vrs_msd_finish_grouped_u32)
 // ONE workgroup: the plan of the four LSD passes (what launch_plan does, 8 groups), then the hybrid form's: bucket
 // offsets, the first MSD pass's seeds (into plan_a->group_seed[0]) and streams, the second pass's tile tables; decides
 // msd_ok (key range 27-32 bits and fully probed, largest bucket <= the local sort's capacity, XCD tile counts <=
@@ -189,7 +192,9 @@ hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *ms
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                            uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
                            uint32_t blind_cap, const StreamCuts &cuts0, uint32_t msd_only, uint32_t max_shift,
-                           uint32_t *host_log = nullptr);
+                           uint32_t *host_log = nullptr, uint32_t sub_bits = 6);
+// sub_bits: the low bits of the 14-bit bucket index the second MSD pass sorts by; the input of that pass is grouped by the
+// remaining 14 - sub_bits high bits (a whole sort: 8 + 6, pass A's digit + pass B's)
 // host_log: kMsdLogWords words of pinned host memory (device view) or nullptr; word stamp % kMsdLogWords receives
 // (stamp << 1) | msd_ok before the head's stamp
 constexpr uint32_t kMsdLogWords = 32;

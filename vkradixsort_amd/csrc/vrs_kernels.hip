@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
                                                                     uint4 *__restrict__ status, uint32_t status_vecs,
                                                                     FusedPlanArgs fp, uint32_t *__restrict__ msd_hist,
                                                                     uint32_t *__restrict__ msd_slices, uint32_t msd_only,
-                                                                    uint32_t msd_base) {
+                                                                    uint32_t msd_base, uint32_t msd_force_shift) {
     using Vec = typename KeyVec<K>::type;
     using TI = TableIndex<GROUPS, COPIES>;
     constexpr uint32_t V = KeyVec<K>::kKeys;
@@ -1232,10 +1232,10 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
         // after the first few) and derives the same bucket shift; every key above the sampled range is flagged below, so
         // a wrong guess costs the hybrid form, never the result.
         __shared__ uint32_t s_or;
-        if (tid == 0) s_or = 0;
+        if (tid == 0) s_or = msd_force_shift ? 0xFFFFFFFFu >> (18u - min(msd_force_shift, 18u)) : 0u;  // forced: as if keys < 2^(shift + 14) had been seen
         __syncthreads();
-        const uint32_t samples = min(n, 4096u);
-        const uint64_t stride = n / samples;  // >= 1
+        const uint32_t samples = msd_force_shift ? 0u : min(n, 4096u);
+        const uint64_t stride = n / max(samples, 1u);  // >= 1
         uint32_t acc = 0;
         for (uint32_t i = tid; i < samples; i += THREADS) acc |= digit_word(keys[static_cast<uint64_t>(i) * stride], base_shift) - msd_base;
 #pragma unroll
@@ -1541,7 +1541,7 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
                                                        uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *__restrict__ tables,
                                                        uint32_t group_len, uint32_t tile_cap, uint32_t blind_cap,
                                                        StreamCuts cuts0, uint32_t msd_only, uint32_t max_shift,
-                                                       uint32_t *host_log) {
+                                                       uint32_t *host_log, uint32_t sub_bits) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_start[kBins + 1];  // where top byte a starts
     __shared__ uint32_t s_tiles[kBins];
@@ -1619,13 +1619,16 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
     for (uint32_t j = 0; j < kPer; ++j) {
         const uint32_t b = tid * kPer + j;
         msd->base[b] = run;
-        if ((b & (kMsdSub - 1u)) == 0u) s_start[b >> kMsdSubBits] = run;
+        if ((b & ((1u << sub_bits) - 1u)) == 0u) s_start[b >> sub_bits] = run;
         run += c[j];
     }
     if (tid == 1023u) {
         msd->base[kMsdBuckets] = run;  // == n
         s_start[kBins] = run;
     }
+    __syncthreads();
+    // with more than 6 bits for the second pass there are fewer than 256 groups for it to walk: the others are empty
+    if (tid < kBins && tid >= (kMsdBuckets >> sub_bits)) s_start[tid] = s_start[kBins];
     __syncthreads();
     // (2) seeds of the first MSD pass: where top byte a of pass-0 group g goes = start of a + its keys in earlier groups
     if (tid < kBins) {
@@ -1670,8 +1673,9 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
         counts[kMsdOverWord] = 0;  // re-armed for the next sort (the shift word is rewritten by every counting read)
         msd->shift = shift;
         msd->ok = s_ok;
+        msd->sub_bits = sub_bits;
         plan_a->head.first_abnormal = 4;
-        plan_a->head.msd_shift_a = shift + kMsdSubBits;  // the first MSD pass's digit: the top 8 bits of the range
+        plan_a->head.msd_shift_a = shift + sub_bits;  // the first MSD pass's digit: the top 8 bits of the range
         plan_lsd->head.msd_ok = s_ok;
         plan_lsd->head.msd_tiles_b = s_tiles_b;
         plan_lsd->head.msd_max_bucket = s_max;
@@ -1709,11 +1713,13 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
     for (uint32_t step = 16; step >= 1; step >>= 1)
         if (pt[k + step] <= j) k += step;
     const uint32_t a = x + 8u * k, i = j - pt[k];
-    const uint32_t first = msd->base[a << kMsdSubBits], last = msd->base[(a + 1u) << kMsdSubBits];
+    const uint32_t sub_bits = msd->sub_bits;  // 6 in a whole sort; up to 8 when the caller grouped the keys by fewer bits
+    if (((a + 1u) << sub_bits) > kMsdBuckets) return;  // (no such group: the plan gave it no tiles)
+    const uint32_t first = msd->base[a << sub_bits], last = msd->base[(a + 1u) << sub_bits];
     const uint32_t done = i * kTile;
     const uint32_t begin = first + done;
     const uint32_t valid = min(kTile, last - begin);
-    BitsDigit dg{msd->shift, kMsdSub - 1u, key_base};
+    BitsDigit dg{msd->shift, (1u << sub_bits) - 1u, key_base};
     StreamLookback lb;
     lb.foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * x)) & 0xFFu);
     lb.stream_keys = keys_in + first;
@@ -1732,7 +1738,7 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
     lb.index = static_cast<int>(i);
     lb.tag = 6u << kLbTagShift;
     lb.budget = spin_budget;
-    lb.seed = threadIdx.x < kMsdSub ? msd->base[(a << kMsdSubBits) + threadIdx.x] : 0u;
+    lb.seed = threadIdx.x < (1u << sub_bits) ? msd->base[(a << sub_bits) + threadIdx.x] : 0u;
     uint32_t unused = 0;
     const uint32_t *vin = PAIRS ? values_in + begin : nullptr;
     if (valid == kTile)
@@ -2889,7 +2895,8 @@ template <typename K, int GROUPS, int THREADS, int COPIES, int UNROLL, int OCC, 
 static void launch_digit_tables_variant(hipStream_t stream, const void *keys, uint32_t n, uint32_t base_shift,
                                         uint32_t group_len, uint32_t *tables, uint32_t *status, size_t status_words,
                                         int compute_units, LaunchEvents ev, const FusedPlanArgs &fp,
-                                        uint32_t *msd_counts = nullptr, uint32_t msd_only = 0, uint32_t msd_base = 0) {
+                                        uint32_t *msd_counts = nullptr, uint32_t msd_only = 0, uint32_t msd_base = 0,
+                                        uint32_t msd_force_shift = 0) {
     // one workgroup per (pass-0 group, slice): a power-of-two number of slices that fills the chip once
     const uint32_t wgs = static_cast<uint32_t>(compute_units) * (OCC * 256 / THREADS);
     uint32_t slices = floor_pow2(wgs / GROUPS > 0 ? wgs / GROUPS : 1u);
@@ -2903,24 +2910,25 @@ static void launch_digit_tables_variant(hipStream_t stream, const void *keys, ui
     const uint32_t vecs = static_cast<uint32_t>(status_words / 4);
     VRS_LAUNCH((digit_tables_kernel<K, GROUPS, THREADS, COPIES, UNROLL, OCC, MSD>), grid, block, stream, ev,
                static_cast<const K *>(keys), n, base_shift, group_len, slices, tables, reinterpret_cast<uint4 *>(status), vecs,
-               fp, msd_counts, msd_counts ? msd_counts + kMsdBuckets : nullptr, msd_only, msd_base);
+               fp, msd_counts, msd_counts ? msd_counts + kMsdBuckets : nullptr, msd_only, msd_base, msd_force_shift);
 }
 
 hipError_t launch_digit_tables_msd(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *tables,
                                    uint32_t *status, size_t status_words, int compute_units, uint32_t *msd_counts,
-                                   bool msd_only, LaunchEvents ev, uint32_t key_base) {
+                                   bool msd_only, LaunchEvents ev, uint32_t key_base, uint32_t force_shift) {
     launch_digit_tables_variant<uint32_t, 8, 1024, 32, VRS_DT_UNROLL, 4, true>(stream, keys, n, 0, group_len, tables, status,
                                                                                status_words, compute_units, ev,
-                                                                               FusedPlanArgs{}, msd_counts, msd_only ? 1u : 0u, key_base);
+                                                                               FusedPlanArgs{}, msd_counts, msd_only ? 1u : 0u, key_base, force_shift);
     return hipGetLastError();
 }
 
 hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                            uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
-                           uint32_t blind_cap, const StreamCuts &cuts0, uint32_t msd_only, uint32_t max_shift, uint32_t *host_log) {
+                           uint32_t blind_cap, const StreamCuts &cuts0, uint32_t msd_only, uint32_t max_shift, uint32_t *host_log,
+                           uint32_t sub_bits) {
     hipLaunchKernelGGL(msd_plan_kernel, dim3(1), dim3(1024), 0, stream, msd_counts, msd, plan_a, plan_lsd, host_head, stamp, n,
-                       tile, tiles_b_cap, local_cap, tables, group_len, tile_cap, blind_cap, cuts0, msd_only, max_shift, host_log);
+                       tile, tiles_b_cap, local_cap, tables, group_len, tile_cap, blind_cap, cuts0, msd_only, max_shift, host_log, sub_bits);
     return hipGetLastError();
 }
 
