@@ -63,9 +63,10 @@ def run_ranks(shards, rounds, capacity=None, world=None, env_shape=None, steps=2
                     if out.size:
                         gpu.check(lib.vrs_buffer_download(gpu.handle, out_buf, out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
                     outs.append((0, out))
-                st = [ctypes.c_uint64() for _ in range(3)]
-                lib.vrs_dist_stats(d, *[ctypes.byref(x) for x in st])
-                results[r] = (outs, tuple(x.value for x in st))
+                st = [ctypes.c_uint64() for _ in range(4)]
+                lib.vrs_dist_stats(d, *[ctypes.byref(x) for x in st[:3]])
+                lib.vrs_dist_grouped_rounds(d, ctypes.byref(st[3]))
+                results[r] = (outs, tuple(x.value for x in st))  # (hybrid rounds, refused rounds, byte-shape steps, grouped rounds)
                 kb.release()
                 lib.vrs_dist_destroy(d)
         except Exception as e:  # noqa: BLE001 -- reported by the main thread
@@ -101,7 +102,7 @@ def test_two_ranks_hybrid_shape(kind, rounds):
     shards = [keys_of(kind, 3000017, 1000), keys_of(kind, 2600001, 1001)]
     res = run_ranks(shards, rounds)
     check_sorted_ranges(shards, res)
-    for outs, (hybrid_rounds, fallback_rounds, byte_steps) in res:
+    for outs, (hybrid_rounds, fallback_rounds, byte_steps, _grouped) in res:
         assert byte_steps == 0 and fallback_rounds == 0 and hybrid_rounds == 2 * rounds
 
 
@@ -120,13 +121,31 @@ def test_two_ranks_a_refused_round_is_sorted_from_scratch():
     assert sum(st[1] for _, st in res) >= 2  # the round with the hot bucket, in both steps, on the rank that owns it
 
 
+@pytest.mark.parametrize("grouped_finish", [True, False])
 @pytest.mark.parametrize("rounds", [1, 4])
-def test_two_ranks_byte_shape(rounds, monkeypatch):
+def test_two_ranks_byte_shape(rounds, grouped_finish, monkeypatch):
+    """Byte shape: top-byte partition pass, the keys landing grouped by top byte and every round finished by ONE counting read +
+    the second MSD pass + the local sort (vrs_msd_finish_grouped_u32) -- or, switched off, one message per (sender, round) and a
+    whole ranged sort per round."""
     monkeypatch.setenv("VRS_DIST_SHAPE", "byte")
+    if not grouped_finish:
+        monkeypatch.setenv("VRS_DIST_GROUPED_FINISH", "0")
     shards = [keys_of("uniform", 1200007, 3), keys_of("uniform", 999999, 4)]
     res = run_ranks(shards, rounds)
     check_sorted_ranges(shards, res)
     assert all(st[2] == 2 and st[0] == 0 for _, st in res)
+    assert all((st[3] == 2 * rounds) == grouped_finish and (st[3] > 0) == grouped_finish for _, st in res), [st for _, st in res]
+
+
+def test_two_ranks_byte_shape_a_round_the_grouped_finish_refuses_is_sorted_whole(monkeypatch):
+    """One (top byte, next 8 bits) bucket of 300 000 keys: that round's plan refuses, its keys have not moved, and the rank
+    sorts the sub-range whole; the other rounds take the grouped finish."""
+    monkeypatch.setenv("VRS_DIST_SHAPE", "byte")
+    shards = [keys_of("uniform", 2000003, 21), keys_of("uniform", 2100001, 22)]
+    shards[0][:300000] = (shards[0][:300000] & np.uint32(0xFFFF)) | np.uint32(0x9ABC0000)
+    res = run_ranks(shards, 2, capacity=3200000)
+    check_sorted_ranges(shards, res)
+    assert sum(st[1] for _, st in res) == 2 and sum(st[3] for _, st in res) == 6  # 2 steps x (4 rounds: 1 refused, 3 grouped)
 
 
 def test_two_ranks_a_total_beyond_the_hybrid_shape_is_remembered(monkeypatch):

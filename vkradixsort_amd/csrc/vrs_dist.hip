@@ -17,9 +17,16 @@
 //     4. per round, while the later rounds are on the wire: vrs_msd_finish_u32 (second MSD pass + LDS-local sort) with the
 //        all-reduced histogram masked to the round's buckets.  A round whose plan refuses (a bucket beyond the local
 //        sort's capacity) is sorted by vrs_sort_keys_u32 instead -- a rank-local matter.
-//   byte shape (fallback, chosen by ALL ranks together from the gathered rows: a key range below 27 bits, ranks that
-//     probed different ranges, or VRS_DIST_SHAPE=byte): contract partition pass by the top byte (12 B/key), the same
-//     exchange with one message per (sender, round), vrs_sort_keys_u32 per received sub-range.
+//   byte shape (chosen by ALL ranks together from the gathered rows: a total whose global top-14-bit buckets would not fit
+//     the local sort -- about 2e8 keys, so every step of 8 x 1e8 --, a key range below 27 bits, ranks that probed different
+//     ranges, or VRS_DIST_SHAPE=byte; 32 B/key per GPU): contract partition pass by the top byte (12 B/key), the same
+//     exchange, and per received sub-range vrs_msd_finish_grouped_u32: ONE counting read, the second MSD pass by the next 8
+//     bits, the local sort (20 B/key).  A sub-range it cannot take (a top byte with more keys than its 256 sub-buckets
+//     hold: then one message per (sender, round), decided by all ranks from the summed top-byte counts; or a refused plan)
+//     is sorted whole by vrs_sort_keys_u32_ranged (28 B/key).  A total too large for the hybrid shape is remembered: the
+//     following steps start here (no counting read + first pass for nothing, one all-gather), every 16th looks again.
+//   In both shapes the collectives run on the exchange stream beside the local step's last kernel, and every round's second
+//   half is enqueued before any of their plans is looked at: the host waits once per step, for the collectives.
 //
 // Every decision to leave the step is made by all ranks from the same gathered data (a rank that cannot take part says so
 // in its row and still joins the collectives), so no rank is left waiting inside a collective.
