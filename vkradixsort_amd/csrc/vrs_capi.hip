@@ -110,6 +110,7 @@ struct vrs_context_t {
         size_t ev_lb_before = 0, ev_ls_before = 0;
         uint32_t key_base = 0;      // vrs_sort_keys_u32_ranged: every key is promised to be >= this (a multiple of 2^24)
         uint32_t bucket_hint = 0;   // blind tail: expected largest bucket (0 = from n); picks the local sort's workgroup shape
+        uint32_t sub_bits = 6;      // bucket bits the second MSD pass sorts by (what its plan is made with)
         uint32_t pass_b_groups = 0; // second MSD pass over fewer than 256 groups (vrs_msd_finish_grouped_u32): XCD x walks groups x, x + 8, ...
     } one_read;
     bool one_read_settling = false;
@@ -905,7 +906,7 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
                                         pairs ? static_cast<const uint32_t *>(st.vptr[home ^ 1u]) : nullptr,
                                         pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr, ctx->os_msd_plan, ctx->os_status,
                                         tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map, st.key_bytes, ctx->os_spin_budget, ev,
-                                        st.key_base));
+                                        st.key_base, st.sub_bits));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
     // Launched with the plan known (it said yes), the local sort also clears the look-back status words -- it is LDS-bound and
     // has HBM time to spare, the next sort's counting read does not.  Launched blind it may leave at once: nothing is promised.
@@ -1330,6 +1331,7 @@ int vrs_msd_finish_grouped_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer o
     const uint32_t hint = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(n) * 9u / 8u) / (static_cast<uint64_t>(top_bytes) << sub_bits) + 64u, 0xFFFFFFFFu));
     if ((rc = msd_half_setup(ctx, n, &st, &g, hint, top_bytes))) return rc;
     st.key_base = key_base;
+    st.sub_bits = sub_bits;
     ctx->sub_cache.valid = false;
     if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
     ctx->os_msd_half_stamp = ctx->os_stamp;

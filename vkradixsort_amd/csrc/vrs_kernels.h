@@ -202,7 +202,7 @@ constexpr uint32_t kMsdLogWords = 32;
 // values_in / values_out: uint32 payloads that follow their keys (nullptr: keys only)
 hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                              uint32_t *values_out, const MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
-                             unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev = {}, uint32_t key_base = 0);
+                             unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev = {}, uint32_t key_base = 0, uint32_t sub_bits = 6);
 // key_base (uint32 keys of the hybrid form only): the caller promises keys >= key_base (a multiple of 2^24); buckets and MSD
 // digits are taken from key - key_base, so a sub-range of the key space gets the same 16384 buckets a full range would;
 // a key below it makes the counting read flag the sort and the plan refuse the hybrid form

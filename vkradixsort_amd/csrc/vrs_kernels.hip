@@ -1702,7 +1702,8 @@ template <typename K, int ITEMS, int RANK, bool PAIRS>
 __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                             const uint32_t *__restrict__ values_in, uint32_t *__restrict__ values_out,
                                                             const MsdPlan *__restrict__ msd, uint32_t *__restrict__ status,
-                                                            unsigned long long xcc_map, uint32_t spin_budget, uint32_t key_base) {
+                                                            unsigned long long xcc_map, uint32_t spin_budget, uint32_t key_base,
+                                                            uint32_t sub_bits) {
     constexpr uint32_t kTile = ITEMS * 8 * 64;  // the tile the plan counted with (onesweep_tile_keys)
     __shared__ ChunkSmem<K, ITEMS, 8, PAIRS> sm;
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
@@ -1713,7 +1714,8 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
     for (uint32_t step = 16; step >= 1; step >>= 1)
         if (pt[k + step] <= j) k += step;
     const uint32_t a = x + 8u * k, i = j - pt[k];
-    const uint32_t sub_bits = msd->sub_bits;  // 6 in a whole sort; up to 8 when the caller grouped the keys by fewer bits
+    // sub_bits: 6 in a whole sort; up to 8 when the caller grouped the keys by fewer bits (a kernel argument, what the plan was
+    // made with: a word of the plan would be one more dependent load in front of the bucket's bounds)
     if (((a + 1u) << sub_bits) > kMsdBuckets) return;  // (no such group: the plan gave it no tiles)
     const uint32_t first = msd->base[a << sub_bits], last = msd->base[(a + 1u) << sub_bits];
     const uint32_t done = i * kTile;
@@ -2934,13 +2936,15 @@ hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *ms
 
 hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                              uint32_t *values_out, const MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
-                             unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev, uint32_t key_base) {
+                             unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev, uint32_t key_base,
+                             uint32_t sub_bits) {
     if (tiles_b == 0) return hipSuccess;
+    if (sub_bits < 6u || sub_bits > 8u) return hipErrorInvalidValue;
     if (key_bytes == 8 && values_in != nullptr) return hipErrorInvalidValue;
     const dim3 grid(8 * tiles_b), block(512);
 #define VRS_PASS_B(K, ITEMS, RANK, PAIRS)                                                                                  \
     VRS_LAUNCH((msd_pass_b_kernel<K, ITEMS, RANK, PAIRS>), grid, block, stream, ev, static_cast<const K *>(keys_in),         \
-               static_cast<K *>(keys_out), values_in, values_out, msd, status, xcc_map, spin_budget, key_base)
+               static_cast<K *>(keys_out), values_in, values_out, msd, status, xcc_map, spin_budget, key_base, sub_bits)
     if (key_bytes == 8) {
         if (atomic_rank) VRS_PASS_B(uint64_t, 8, RANK_ATOMIC, false); else VRS_PASS_B(uint64_t, 8, RANK_BALLOT, false);
     } else if (values_in != nullptr) {
