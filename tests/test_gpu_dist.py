@@ -166,10 +166,17 @@ def test_two_ranks_small_shards_take_the_byte_shape_together():
     assert all(st[2] == 2 for _, st in res)
 
 
-def test_three_ranks():
+@pytest.mark.parametrize("shape", ["hybrid", "byte"])
+def test_three_ranks(shape, monkeypatch):
+    """Three ranks: 85 / 86 top bytes each, rounds of 42-43 (no multiple of 8: some XCDs of the second MSD pass walk one group
+    more); the byte shape's rounds go through the grouped finish with 7 sub-bucket bits."""
+    if shape == "byte":
+        monkeypatch.setenv("VRS_DIST_SHAPE", "byte")
     shards = [keys_of("uniform", 1500000 + 777 * r, 60 + r) for r in range(3)]
     res = run_ranks(shards, 2)
     check_sorted_ranges(shards, res)
+    if shape == "byte":
+        assert all(st[3] == 4 and st[1] == 0 for _, st in res), [st for _, st in res]
 
 
 @pytest.mark.parametrize("kind", ["16bit", "clustered"])
