@@ -1535,13 +1535,14 @@ __global__ __launch_bounds__(1024) void msd_count_u64_kernel(const uint64_t *__r
 
 // One 1024-thread workgroup, after plan_kernel.  counts = [16384] top-14-bit histogram, then [8][256] top-byte counts per
 // pass-0 group (both left zeroed for the next sort).
+template <uint32_t sub_bits>  // the low bits of the bucket index the second MSD pass sorts by: 6 (a whole sort), 7 or 8
 __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ counts, MsdPlan *__restrict__ msd,
                                                        OnesweepPlan *__restrict__ plan_a, OnesweepPlan *__restrict__ plan_lsd,
                                                        OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                                                        uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *__restrict__ tables,
                                                        uint32_t group_len, uint32_t tile_cap, uint32_t blind_cap,
                                                        StreamCuts cuts0, uint32_t msd_only, uint32_t max_shift,
-                                                       uint32_t *host_log, uint32_t sub_bits) {
+                                                       uint32_t *host_log) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_start[kBins + 1];  // where top byte a starts
     __shared__ uint32_t s_tiles[kBins];
@@ -2929,8 +2930,14 @@ hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *ms
                            uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
                            uint32_t blind_cap, const StreamCuts &cuts0, uint32_t msd_only, uint32_t max_shift, uint32_t *host_log,
                            uint32_t sub_bits) {
-    hipLaunchKernelGGL(msd_plan_kernel, dim3(1), dim3(1024), 0, stream, msd_counts, msd, plan_a, plan_lsd, host_head, stamp, n,
-                       tile, tiles_b_cap, local_cap, tables, group_len, tile_cap, blind_cap, cuts0, msd_only, max_shift, host_log, sub_bits);
+#define VRS_MSD_PLAN(SUB)                                                                                                     \
+    hipLaunchKernelGGL(msd_plan_kernel<SUB>, dim3(1), dim3(1024), 0, stream, msd_counts, msd, plan_a, plan_lsd, host_head, stamp, \
+                       n, tile, tiles_b_cap, local_cap, tables, group_len, tile_cap, blind_cap, cuts0, msd_only, max_shift, host_log)
+    if (sub_bits == 6u) VRS_MSD_PLAN(6u);
+    else if (sub_bits == 7u) VRS_MSD_PLAN(7u);
+    else if (sub_bits == 8u) VRS_MSD_PLAN(8u);
+    else return hipErrorInvalidValue;
+#undef VRS_MSD_PLAN
     return hipGetLastError();
 }
 
