@@ -56,6 +56,36 @@ def main():
     with vrs.GPUContext(0) as ctx:
         lib = ctx.lib
         while time.time() < t_end:
+            if rs.randint(0, 12) == 0:
+                # round 3: the second half of the hybrid form for keys that arrive grouped by top byte (what a rank of a large
+                # multi-GPU sort receives): random run of top bytes, some of them empty or heavy, any inner order
+                first = int(rs.randint(0, 256))
+                T = int(rs.randint(1, 257 - first))
+                n = int(rs.choice([rs.randint(1, 5000), rs.randint(1, 300000), rs.randint(70000, 6000000)]))
+                low, kind = make_keys(rs, n, False)
+                tops = rs.randint(first, first + T, n)
+                if rs.randint(0, 3) == 0 and T > 2:  # a few top bytes only
+                    tops = rs.choice(rs.randint(first, first + T, max(1, T // 5)), n)
+                if rs.randint(0, 4) == 0:  # one heavy top byte
+                    tops = np.where(rs.randint(0, 100, n) < 60, first + T - 1, tops)
+                keys = (low & np.uint32(0x00FFFFFF)) | (tops.astype(np.uint32) << np.uint32(24))
+                grouped = keys[np.argsort(keys >> np.uint32(24), kind="stable")]
+                gb = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), grouped)
+                ob = vrs.Buffer(ctx, S(4 * n))
+                ctx.setTuning(capi.VRS_TUNE_RANK_MODE, 0)  # the form's local sort needs the LDS-atomic ranking (an earlier case may have switched it off)
+                ctx.check(lib.vrs_msd_finish_grouped_u32(ctx.handle, gb.handle, ob.handle, n, first, T))
+                took = ctypes.c_int(-1)
+                ctx.check(lib.vrs_msd_finish_status(ctx.handle, ctypes.byref(took)))
+                res = np.empty(n, np.uint32)
+                (ob if took.value else gb).downloadWithStagingBuffer(res)
+                ok = np.array_equal(res, np.sort(keys)) if took.value else np.array_equal(res, grouped)
+                gb.release()
+                ob.release()
+                cases += 1
+                if not ok:
+                    print(f"MISMATCH grouped finish n={n} first={first} T={T} kind={kind} took={took.value} seed={seed} case={cases}")
+                    sys.exit(1)
+                continue
             bits64 = bool(rs.randint(0, 3) == 0)
             pairs = bool(rs.randint(0, 3) == 0)
             n = int(rs.choice([rs.randint(1, 300), rs.randint(1, 20000), rs.randint(1, 3000000)]))
