@@ -24,7 +24,7 @@
 //     bits, the local sort (20 B/key).  A sub-range it cannot take (a top byte with more keys than its 256 sub-buckets
 //     hold: then one message per (sender, round), decided by all ranks from the summed top-byte counts; or a refused plan)
 //     is sorted whole by vrs_sort_keys_u32_ranged (28 B/key).  A total too large for the hybrid shape is remembered: the
-//     following steps start here (no counting read + first pass for nothing, one all-gather), every 16th looks again.
+//     following steps start here (no counting read + first pass for nothing, one all-gather), every 64th looks again.
 //   In both shapes the collectives run on the exchange stream beside the local step's last kernel, and every round's second
 //   half is enqueued before any of their plans is looked at: the host waits once per step, for the collectives.
 //
@@ -595,10 +595,10 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
     //    The byte shape's contract partition pass, if the ranks settle on it, runs after the all-gather (the keys are
     //    untouched until then).
     // A total the hybrid shape cannot take (about 2e8 keys: every step of 8 x 1e8) is remembered: the next steps go straight to
-    // the byte shape -- no counting read and first MSD pass for nothing, ONE all-gather instead of two -- and every 16th looks
+    // the byte shape -- no counting read and first MSD pass for nothing, ONE all-gather instead of two -- and every 64th looks
     // again.  The memory is the same on every rank (it comes from the gathered table), so the ranks still issue the same
     // collectives.
-    const bool byte_first = d->byte_shape_only || (d->too_large_for_hybrid && (d->steps % 16u) != 0u);
+    const bool byte_first = d->byte_shape_only || (d->too_large_for_hybrid && (d->steps % 64u) != 0u);
     d->steps++;
     const bool try_hybrid = !byte_first;
     bool partitioned = false;
