@@ -181,17 +181,24 @@ def test_three_ranks(shape, monkeypatch):
 
 
 @pytest.mark.parametrize("kind", ["16bit", "clustered"])
-def test_two_ranks_unbalanced_key_ranges_leave_together(kind):
-    """Top bytes too concentrated for byte-aligned cuts: VRS_ERROR_UNBALANCED on BOTH ranks, nobody hangs."""
+@pytest.mark.parametrize("shape", ["hybrid_first", "byte_first"])
+def test_two_ranks_unbalanced_key_ranges_leave_together(kind, shape, monkeypatch):
+    """Top bytes too concentrated for byte-aligned cuts: VRS_ERROR_UNBALANCED on BOTH ranks, nobody hangs -- whether the step
+    tried the hybrid shape first (two all-gathers) or went straight to the byte shape (one)."""
+    if shape == "byte_first":
+        monkeypatch.setenv("VRS_DIST_SHAPE", "byte")
     shards = [keys_of(kind, 2000000, 31), keys_of(kind, 2000000, 32)]
     res = run_ranks(shards, 2)
     for outs, _ in res:
         assert all(rc == capi.VRS_ERROR_UNBALANCED for rc, _ in outs), outs
 
 
-def test_two_ranks_a_shard_above_its_capacity_fails_on_both():
+@pytest.mark.parametrize("shape", ["hybrid_first", "byte_first"])
+def test_two_ranks_a_shard_above_its_capacity_fails_on_both(shape, monkeypatch):
     """Rank 1's shard exceeds the capacity it was created with: it reports INVALID_ARGUMENT, rank 0 PEER -- after both took
-    part in the same collectives."""
+    part in the same collectives (byte shape first: the status rides in the one all-gather of the top-byte prefixes)."""
+    if shape == "byte_first":
+        monkeypatch.setenv("VRS_DIST_SHAPE", "byte")
     shards = [keys_of("uniform", 1000000, 41), keys_of("uniform", 1500000, 42)]
     res = run_ranks(shards, 1, capacity=1200000)
     assert all(rc == capi.VRS_ERROR_PEER for rc, _ in res[0][0]), res[0][0]
