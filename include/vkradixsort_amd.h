@@ -450,7 +450,11 @@ typedef enum vrs_tuning_key {
     VRS_TUNE_ASYNC_SORT = 14,      /* 1: vrs_sort_keys_u32 / _pairs_u32 / _keys_u64 only enqueue and return at once;
                                      vrs_sort_settle (or any entry point that settles) finishes what the plan asks for.
                                      0 (default): they return once the plan's head has reached the host */
-    VRS_TUNE_PLAN_WAIT_MS = 15     /* longest wait for a plan's head in milliseconds (default 60000; 0 = no limit) */
+    VRS_TUNE_PLAN_WAIT_MS = 15,    /* longest wait for a plan's head in milliseconds (default 60000; 0 = no limit) */
+    VRS_TUNE_MSD_RESERVE = 16      /* the two MSD passes of the hybrid form over BARE keys reserve their output ranges with one L2-local atomic
+                                      add per tile and digit instead of a decoupled look-back (the order inside a bucket is free there;
+                                      payloads always take the stable look-back).  1 (default): from 3 * 10^7 keys on (below, a pass is bound
+                                      by its latency and gains nothing); 2: always; 0: look-back everywhere */
 } vrs_tuning_key;
 int vrs_set_tuning(vrs_context ctx, int key, int value);
 

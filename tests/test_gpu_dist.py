@@ -31,7 +31,7 @@ def keys_of(kind, n, seed):
     return k
 
 
-def run_ranks(shards, rounds, capacity=None, world=None, env_shape=None, steps=2):
+def run_ranks(shards, rounds, capacity=None, world=None, env_shape=None, steps=2, reserve=None):
     """`steps` steps with len(shards) ranks as threads; returns [(rc, sorted range or error text, stats)] per rank."""
     world = world or len(shards)
     lib = capi.load_library()
@@ -44,6 +44,8 @@ def run_ranks(shards, rounds, capacity=None, world=None, env_shape=None, steps=2
     def rank_main(r):
         try:
             with vrs.GPUContext(0) as gpu:
+                if reserve is not None:
+                    gpu.setTuning(capi.VRS_TUNE_MSD_RESERVE, reserve)
                 tr = capi.DistTransport()
                 assert lib.vrs_dist_loopback_transport(hub, r, ctypes.byref(tr)) == 0
                 d = ctypes.c_void_p()
@@ -104,6 +106,21 @@ def test_two_ranks_hybrid_shape(kind, rounds):
     check_sorted_ranges(shards, res)
     for outs, (hybrid_rounds, fallback_rounds, byte_steps, _grouped) in res:
         assert byte_steps == 0 and fallback_rounds == 0 and hybrid_rounds == 2 * rounds
+
+
+@pytest.mark.parametrize("shape", ["hybrid", "byte"])
+def test_two_ranks_with_the_msd_passes_reserving(shape, monkeypatch):
+    """What shards of 10^8 keys do by default, forced at test sizes: the partition's first MSD pass and every round's second pass
+    take their places by reservation (VRS_TUNE_MSD_RESERVE = 2); `grouped` is then grouped by top byte in no particular inner
+    order, which is all the exchange needs."""
+    if shape == "byte":
+        monkeypatch.setenv("VRS_DIST_SHAPE", "byte")
+    shards = [keys_of("uniform", 3000017, 1000), keys_of("28bit" if shape == "hybrid" else "uniform", 2600001, 1001)]
+    if shape == "hybrid":
+        shards[0] = keys_of("28bit", 3000017, 1000)
+    res = run_ranks(shards, 2, reserve=2)
+    check_sorted_ranges(shards, res)
+    assert all(st[1] == 0 for _, st in res)
 
 
 @pytest.mark.parametrize("rounds", [1, 4])

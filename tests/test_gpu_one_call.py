@@ -585,6 +585,79 @@ def test_hybrid_form_under_the_look_back_hooks(gpu_context, hook):
     assert hybrid_sorts(ctx) - h0 == (0 if hook == "ballot" else 1)
 
 
+@pytest.mark.parametrize("hook", ["none", "misplace", "hold"])
+@pytest.mark.parametrize("dist", ["uniform", "sorted", "low18_const", "28bit", "ties", "one_hot_bucket", "ragged_streams"])
+def test_hybrid_form_msd_passes_by_reservation(gpu_context, dist, hook):
+    """VRS_TUNE_MSD_RESERVE = 2: both MSD passes over bare keys take their places with one L2-local atomic add per tile and
+    digit instead of the look-back (default from 3e7 keys on; forced here at test sizes).  Any order inside a bucket is fine --
+    the result is std::sort either way -- for every bucket shape; with every other tile run OFF its stream's XCD (misplace) those
+    tiles take their room from the end of the range with device-wide atomics; a withheld tile has nobody waiting for it.  A
+    look-back sort (pairs) and a reserving one alternate on the same context: the status words and the counters stay consistent."""
+    ctx = gpu_context
+    n = 7000003 if dist != "ragged_streams" else (1 << 22) + 8 * 8192 * 3 + 1234
+    if dist == "28bit":
+        keys = make_keys(n, "uniform", seed=5) >> np.uint32(4)
+    elif dist == "ties":
+        keys = (make_keys(n, "uniform", seed=6) & np.uint32(0xFFFF)) * np.uint32(65537)
+    elif dist == "ragged_streams":
+        keys = make_keys(n, "uniform", seed=7)
+    else:
+        keys = make_hybrid_keys(n, dist, seed=n % 311)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 2)
+    if hook == "misplace":
+        ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 1)
+    elif hook == "hold":
+        ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, 2)
+        ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 8)
+    h0 = hybrid_sorts(ctx)
+    try:
+        out, _ = sort_keys(ctx, keys)
+        assert np.array_equal(out, np.sort(keys))
+        m = 1 << 22
+        pk, pv = make_keys(m, "uniform", seed=9), np.arange(m, dtype=np.uint32)
+        ok, ov = sort_pairs_once(ctx, pk, pv)  # look-back passes (payloads): they write the status words
+        order = np.argsort(pk, kind="stable")
+        assert np.array_equal(ok, pk[order]) and np.array_equal(ov, pv[order])
+        out, _ = sort_keys(ctx, keys[::-1].copy())
+        assert np.array_equal(out, np.sort(keys))
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
+        ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 1)
+        ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 0)
+        ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, -1)
+        ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 4096)
+    shift = int(keys.max()).bit_length() - 14
+    fits = 13 <= shift <= 18 and int(np.bincount(keys >> np.uint32(shift), minlength=1 << 14).max()) <= capi.LOCAL_SORT_MAX_KEYS
+    assert hybrid_sorts(ctx) - h0 == (2 if fits else 0) + 1, (dist, shift, hybrid_sorts(ctx) - h0)  # + the pairs sort
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_hybrid_form_u64_with_and_without_reservation(gpu_context, mode):
+    ctx, lib = gpu_context, gpu_context.lib
+    n = 6000001
+    keys = make_keys64(n, "uniform", 77)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID, 1)
+    ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, mode)
+    h0 = hybrid_sorts(ctx)
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(8 * n), keys)
+    k1 = vrs.Buffer(ctx, S(8 * n))
+    try:
+        for _ in range(2):
+            ctx.check(lib.vrs_buffer_upload(ctx.handle, k0.handle, keys.ctypes.data_as(ctypes.c_void_p), keys.nbytes))
+            ctx.check(lib.vrs_sort_keys_u64(ctx.handle, k0.handle, k1.handle, n))
+            out = np.empty(n, np.uint64)
+            k0.downloadWithStagingBuffer(out)
+            assert np.array_equal(out, np.sort(keys))
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
+        ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 1)
+        k0.release()
+        k1.release()
+    assert hybrid_sorts(ctx) - h0 == 2
+
+
 def sort_pairs_once(ctx, keys, vals):
     lib, n = ctx.lib, keys.size
     k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)

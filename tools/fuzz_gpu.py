@@ -72,6 +72,7 @@ def main():
                 grouped = keys[np.argsort(keys >> np.uint32(24), kind="stable")]
                 gb = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), grouped)
                 ob = vrs.Buffer(ctx, S(4 * n))
+                ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, int(rs.choice([0, 2])))
                 ctx.setTuning(capi.VRS_TUNE_RANK_MODE, 0)  # the form's local sort needs the LDS-atomic ranking (an earlier case may have switched it off)
                 ctx.check(lib.vrs_msd_finish_grouped_u32(ctx.handle, gb.handle, ob.handle, n, first, T))
                 took = ctypes.c_int(-1)
@@ -120,6 +121,7 @@ def main():
                 ctx.setTuning(capi.VRS_TUNE_HYBRID, int(rs.randint(0, 4) != 0))
                 ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, int(rs.choice([1 << 22, 1 << 22, capi.HYBRID_MIN_KEYS_DEFAULT])))
                 ctx.setTuning(capi.VRS_TUNE_HYBRID_FAST_COUNT, int(rs.randint(0, 3)))
+                ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, int(rs.choice([0, 1, 2, 2])))  # MSD passes by reservation at any size
                 # round 3: enqueue-only sorts (the download below settles them)
                 ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, int(rs.randint(0, 3) == 0))
                 hold = rs.randint(0, 8) == 0
@@ -155,6 +157,7 @@ def main():
                 for b in (k0, k1, big):
                     b.release()
                 ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, capi.ONE_CALL_MIN_KEYS_DEFAULT)
+                ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 1)
                 ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 0)
                 ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, -1)
                 ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 4096)

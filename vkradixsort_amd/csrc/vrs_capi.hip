@@ -95,6 +95,10 @@ struct vrs_context_t {
     uint64_t os_skipped_passes = 0;      // identity passes (one digit value holds every key) the one-call sort left out     // passes the one-call sort ran through the contract path (unbalanced streams)
     bool os_async = false;               // VRS_TUNE_ASYNC_SORT: the one-call sorts return without waiting for the plan; vrs_sort_settle finishes them
     uint32_t os_plan_wait_ms = 60000;    // VRS_TUNE_PLAN_WAIT_MS: longest wait for a plan's head (0 = no limit)
+    int os_reserve = 1;                  // VRS_TUNE_MSD_RESERVE: the MSD passes over bare keys reserve their output instead of looking back
+                                         // (1: from 3e7 keys on -- below, a pass is latency-bound and gains nothing; 2: always; 0: never)
+    bool os_cursors_open = false;        // a reserving pass may have run without the local sort that re-arms its counters behind it
+                                         // (a refused plan, a partition with no finish, an error in between): cleared before the next use
     // a one-call sort between its two halves (see one_read_enqueue / one_read_complete)
     struct OneRead {
         bool active = false;    // enqueued, its plan not yet looked at
@@ -855,6 +859,7 @@ static int one_read_scratch(vrs_context ctx, const vrs_context_t::OneRead &st, c
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&counts), vrs::kMsdCountWords * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemsetAsync(counts, 0, vrs::kMsdCountWords * sizeof(uint32_t), ctx->stream);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&mp), sizeof(vrs::MsdPlan));
+        if (e == hipSuccess) e = hipMemsetAsync(mp, 0, sizeof(vrs::MsdPlan), ctx->stream);  // the reservation counters start at zero
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pa), sizeof(vrs::OnesweepPlan));
         if (e != hipSuccess) {
             if (pa) (void)hipFree(pa);
@@ -894,6 +899,19 @@ static int one_read_lookback_pass(vrs_context ctx, vrs_context_t::OneRead &st, u
     return VRS_OK;
 }
 
+// Reservation counters (MsdPlan::cursor_* / back_*): zero when a reserving pass starts; the local sort leaves them so.  Every
+// entry point that is about to enqueue a reserving pass calls this first.
+static bool reserves(vrs_context ctx, uint32_t n, bool pairs) {
+    return !pairs && (ctx->os_reserve == 2 || (ctx->os_reserve == 1 && n >= 30000000u));
+}
+static int reservation_begin(vrs_context ctx) {
+    if (!ctx->os_reserve || !ctx->os_msd_plan) return VRS_OK;
+    if (ctx->os_cursors_open)
+        VRS_HIP(ctx, hipMemsetAsync(reinterpret_cast<char *>(ctx->os_msd_plan) + offsetof(vrs::MsdPlan, cursor_a), 0, vrs::kMsdCursorBytes, ctx->stream));
+    ctx->os_cursors_open = true;
+    return VRS_OK;
+}
+
 // second MSD pass + local sort of the hybrid form: partner -> home, then the buckets in place
 static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, const OneReadGeometry &g, uint32_t tiles_b, uint32_t max_bucket,
                                 bool status_was_clean = false) {
@@ -906,13 +924,16 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
                                         pairs ? static_cast<const uint32_t *>(st.vptr[home ^ 1u]) : nullptr,
                                         pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr, ctx->os_msd_plan, ctx->os_status,
                                         tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map, st.key_bytes, ctx->os_spin_budget, ev,
-                                        st.key_base, st.sub_bits));
+                                        st.key_base, st.sub_bits, reserves(ctx, st.n, pairs)));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
     // Launched with the plan known (it said yes), the local sort also clears the look-back status words -- it is LDS-bound and
     // has HBM time to spare, the next sort's counting read does not.  Launched blind it may leave at once: nothing is promised.
     // (Blind, but with every status word zero before the second pass -- vrs_msd_finish_u32 -- the promise holds again: either both
     // kernels run, and the local sort clears what the pass wrote, or both leave at once.)
-    const bool clears = !st.blind_tail || status_was_clean;
+    // Bare keys with reservation: neither MSD pass has touched the status words -- they are as clear as the counting read (or the
+    // caller's memset) left them, and the local sort has nothing to do about them.
+    const bool untouched = reserves(ctx, st.n, pairs);
+    const bool clears = !untouched && (!st.blind_tail || status_was_clean);
     uint32_t *clear = clears ? ctx->os_status : nullptr;
     const size_t clear_words = clears ? ctx->os_status_rows * VRS_RADIX_SORT_BINS : 0;
     if (wide)
@@ -921,7 +942,8 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
         VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(st.kptr[home]),
                                                 pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr, ctx->os_msd_plan, max_bucket, ev,
                                                 clear, clear_words));
-    if (clear) ctx->os_status_clean = true;
+    if (clear || untouched) ctx->os_status_clean = true;
+    ctx->os_cursors_open = false;  // the local sort is on the stream: it re-arms the reservation counters (or, the plan refusing, nothing touched them)
     (void)g;
     return VRS_OK;
 }
@@ -976,7 +998,9 @@ static int one_read_enqueue(vrs_context ctx) {
     } guard{ctx};
     const uint32_t group = st.group;
     // the previous hybrid sort's local sort left the status words cleared (see one_read_hybrid_tail): nothing to zero then
-    const size_t zero_words = ctx->os_status_clean ? 0 : g.rows * VRS_RADIX_SORT_BINS;
+    // ("clean" speaks for the whole allocation -- a sort whose MSD passes reserve leaves the words alone and hands the claim on --
+    // so a counting read that has to clear them clears all of them, not just the rows of this sort)
+    const size_t zero_words = ctx->os_status_clean ? 0 : ctx->os_status_rows * VRS_RADIX_SORT_BINS;
     ctx->os_status_clean = false;  // this sort's passes write them
     if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
     if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
@@ -1016,6 +1040,7 @@ static int one_read_enqueue(vrs_context ctx) {
     st.ev_ls_before = ctx->events_used[VRS_KERNEL_LOCAL_SORT];
     st.blind_passes = msd ? (st.fast_count ? 0u : 1u) : 4u;
     if (msd) {  // the first MSD pass goes first: it is the one that usually runs, the other then leaves behind it
+        if (!pairs && (rc = reservation_begin(ctx))) return rc;
         if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
         const uint32_t c = st.cur_at_start;
         VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, st.kptr[c], st.kptr[c ^ 1u],
@@ -1023,7 +1048,7 @@ static int one_read_enqueue(vrs_context ctx) {
                                                   pairs ? static_cast<uint32_t *>(st.vptr[c ^ 1u]) : nullptr, ctx->os_plan_a, 0,
                                                   vrs::kShiftFromPlan, ctx->os_status, g.tiles0, false, ctx->scatter.atomic_rank,
                                                   ctx->xcc_map, key_bytes, ctx->os_spin_budget, ctx->os_hold_tile, ev, ctx->os_misplace,
-                                                  st.key_base));
+                                                  st.key_base, reserves(ctx, n, pairs) ? ctx->os_msd_plan : nullptr));
     }
     for (uint32_t i = 0; i < st.blind_passes; ++i)
         if ((rc = one_read_lookback_pass(ctx, st, i, 32u * group + 8u * i, i == 0 ? g.tiles0 : g.blind_cap, false))) return rc;
@@ -1252,15 +1277,19 @@ int vrs_msd_partition_signal_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer ou
     vrs_context_t::OneRead st;
     OneReadGeometry g;
     if ((rc = msd_half_setup(ctx, n, &st, &g))) return rc;
+    if ((rc = reservation_begin(ctx))) return rc;
     ctx->sub_cache.valid = false;
-    ctx->os_status_clean = false;  // the first MSD pass writes status words (the counting read below zeroes them first)
+    // the counting read below clears the status words if anything has written them since they were last clear; the first MSD
+    // pass then leaves them alone when it reserves, and writes them when it looks back
+    const size_t partition_zero_words = ctx->os_status_clean ? 0 : ctx->os_status_rows * VRS_RADIX_SORT_BINS;
+    ctx->os_status_clean = reserves(ctx, n, false);
     vrs::LaunchEvents ev;
     if ((rc = profile_events(ctx, VRS_KERNEL_DIGIT_TABLES, &ev))) return rc;
     if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
     // counting read: only the bucket histogram and the slices' top-byte counts (a key range below 27 bits gets the LSD
     // tables instead -- the plan kernel clears them again -- and leaves the histogram empty: the caller sees the shift)
     VRS_HIP(ctx, vrs::launch_digit_tables_msd(ctx->stream, keys->ptr, n, g.group_len, ctx->os_tables, ctx->os_status,
-                                              g.rows * VRS_RADIX_SORT_BINS, ctx->scatter.compute_units, ctx->os_msd_counts, true, ev));
+                                              partition_zero_words, ctx->scatter.compute_units, ctx->os_msd_counts, true, ev));
     VRS_HIP(ctx, hipMemcpyAsync(counts_out->ptr, ctx->os_msd_counts, VRS_MSD_COUNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     // the counts are all a caller needs to start talking to its peers: the first pass below runs meanwhile
     if (counts_ready_event) VRS_HIP(ctx, hipEventRecord(static_cast<hipEvent_t>(counts_ready_event), ctx->stream));
@@ -1271,7 +1300,7 @@ int vrs_msd_partition_signal_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer ou
     if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, keys->ptr, out->ptr, nullptr, nullptr, ctx->os_plan_a, 0, vrs::kShiftFromPlan,
                                               ctx->os_status, g.tiles0, true, ctx->scatter.atomic_rank, ctx->xcc_map, 4,
-                                              ctx->os_spin_budget, -1, ev, false));
+                                              ctx->os_spin_budget, -1, ev, false, 0u, reserves(ctx, n, false) ? ctx->os_msd_plan : nullptr));
     return VRS_OK;
 }
 
@@ -1289,6 +1318,7 @@ int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_
     vrs_context_t::OneRead st;
     OneReadGeometry g;
     if ((rc = msd_half_setup(ctx, n, &st, &g, bucket_hint))) return rc;
+    if ((rc = reservation_begin(ctx))) return rc;
     ctx->sub_cache.valid = false;
     if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
     ctx->os_msd_half_stamp = ctx->os_stamp;
@@ -1330,6 +1360,7 @@ int vrs_msd_finish_grouped_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer o
     OneReadGeometry g;
     const uint32_t hint = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(n) * 9u / 8u) / (static_cast<uint64_t>(top_bytes) << sub_bits) + 64u, 0xFFFFFFFFu));
     if ((rc = msd_half_setup(ctx, n, &st, &g, hint, top_bytes))) return rc;
+    if ((rc = reservation_begin(ctx))) return rc;
     st.key_base = key_base;
     st.sub_bits = sub_bits;
     ctx->sub_cache.valid = false;
@@ -1707,6 +1738,10 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
         case VRS_TUNE_PLAN_WAIT_MS:
             if (value < 0) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the plan wait limit must be >= 0 ms");
             ctx->os_plan_wait_ms = static_cast<uint32_t>(value);
+            return VRS_OK;
+        case VRS_TUNE_MSD_RESERVE:
+            if (value < 0 || value > 2) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "MSD reservation must be 0 (never), 1 (from 3e7 keys on) or 2 (always)");
+            ctx->os_reserve = value;
             return VRS_OK;
         case VRS_TUNE_DIGIT_TABLE_GROUPS:
             if (value != 0 && value != 8 && value != 16 && value != 32)

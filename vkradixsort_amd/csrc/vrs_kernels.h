@@ -2,6 +2,7 @@
 // include/vkradixsort_amd.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <cstdint>
 
 namespace vrs {
@@ -157,7 +158,7 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
                                    uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
                                    uint32_t *status, uint32_t grid_tiles, bool forced, bool atomic_rank,
                                    unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, int hold_tile,
-                                   LaunchEvents ev = {}, bool misplace = false, uint32_t key_base = 0);
+                                   LaunchEvents ev = {}, bool misplace = false, uint32_t key_base = 0, struct MsdPlan *reserve = nullptr);
 // ---- hybrid form of the one-call sort (K5b, uint32 keys): MSD partition by the top 14 bits in two look-back passes,
 // then one workgroup per bucket sorts the low 18 bits inside LDS.
 constexpr uint32_t kMsdBucketCount = 1u << 14;
@@ -167,8 +168,19 @@ struct MsdPlan {
     uint32_t sub_bits;                    // bucket bits the second MSD pass sorts by (6: a whole sort; up to 8: vrs_msd_finish_grouped_u32)
     uint32_t pad;
     uint32_t xcd_tiles[8][33];            // XCD x walks top-byte buckets x, x+8, ...: exclusive prefix of their tile counts
+    // Reservation (MSD passes over BARE keys, where the order inside a digit's range is free): a tile takes its place in the range
+    // of (stream or bucket group, digit) with ONE atomic add on that range's counter -- in the L2 of the XCD all tiles of the
+    // stream run on -- instead of looking back over its predecessors.  A tile that finds itself on another XCD takes its keys' room from
+    // the END of the range with a device-wide atomic on a second counter: the two never meet, the range has room for exactly all.
+    // The counters count keys from zero; the local sort -- the last kernel of the form -- leaves them zero for the next sort.
+    uint32_t cursor_a[kStreams][256];     // first MSD pass: keys of (stream, top byte) placed so far
+    uint32_t back_a[kStreams][256];       //   keys taken from the range's end (zero unless a tile ran off its stream's XCD)
+    uint32_t cursor_b[kMsdBucketCount];   // second MSD pass: keys of bucket b placed so far
+    uint32_t back_b[kMsdBucketCount];
     uint32_t base[kMsdBucketCount + 1];   // exclusive prefix of the bucket sizes = where bucket b starts when sorted
 };
+static_assert(offsetof(MsdPlan, base) % 16 == 0, "the plan kernel stores the bucket starts as 16-byte vectors");
+constexpr size_t kMsdCursorBytes = offsetof(MsdPlan, base) - offsetof(MsdPlan, cursor_a);  // the four counter arrays, contiguous
 // words the hybrid's counting needs beside the digit tables: the 16384-bin histogram + 8 x 256 top-byte counts per
 // pass-0 group, zero between sorts
 constexpr size_t kMsdCountWords = kMsdBucketCount + 8u * 256u + 64u;  // + the probed shift and the out-of-range flag
@@ -201,8 +213,9 @@ constexpr uint32_t kMsdLogWords = 32;
 // second MSD pass: bits [18, 24) inside every top-byte bucket; grid of 8 * tiles_b workgroups; status rows: 8 * tiles_b
 // values_in / values_out: uint32 payloads that follow their keys (nullptr: keys only)
 hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
-                             uint32_t *values_out, const MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
-                             unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev = {}, uint32_t key_base = 0, uint32_t sub_bits = 6);
+                             uint32_t *values_out, MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
+                             unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev = {}, uint32_t key_base = 0, uint32_t sub_bits = 6,
+                             bool reserve = false);
 // key_base (uint32 keys of the hybrid form only): the caller promises keys >= key_base (a multiple of 2^24); buckets and MSD
 // digits are taken from key - key_base, so a sub-range of the key space gets the same 16384 buckets a full range would;
 // a key below it makes the counting read flag the sort and the plan refuse the hybrid form
@@ -211,10 +224,10 @@ hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys
 hipError_t launch_msd_count_u64(hipStream_t stream, const void *keys, uint32_t n, uint32_t group_len, uint32_t *status,
                                 size_t status_words, int compute_units, uint32_t *msd_counts, LaunchEvents ev = {});
 // clear_status / clear_words (a multiple of 4): look-back status words the kernel clears on the side (for the next sort), or nullptr
-hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, const MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev = {},
+hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev = {},
                                      uint32_t *clear_status = nullptr, size_t clear_words = 0);
 // max_bucket: the plan's msd_max_bucket (picks the workgroup shape: 256 threads up to 7165 keys, else 512)
-hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *values, const MsdPlan *msd, uint32_t max_bucket,
+hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *values, MsdPlan *msd, uint32_t max_bucket,
                                  LaunchEvents ev = {}, uint32_t *clear_status = nullptr, size_t clear_words = 0);
 // keys the local sort of one bucket can hold (the plan refuses the hybrid form when a bucket has more)
 uint32_t msd_local_capacity_small();  // bare uint32 keys, 256-thread workgroup: 7165

@@ -592,14 +592,37 @@ struct StreamLookback {
     uint32_t budget = 0;      // polls of an unpublished row before giving up
     const void *stream_keys = nullptr;  // first key of the stream in the pass's input
     uint32_t done = 0;        // keys of the stream before this tile
+    // Reservation instead of look-back (MsdPlan::cursor_a / cursor_b; cursor != nullptr): my digit's range hands out absolute
+    // positions.  157 -> 143 us per pass at 10^8 keys (profiles/labs/r03_reservation.txt): no status rows to publish, poll and clear.
+    uint32_t *cursor = nullptr;      // keys of my digit's range placed so far; L2-local: every tile of the stream runs behind the same L2
+    uint32_t *back = nullptr;        // a foreign tile's counter (device scope): keys taken from the range's end
+    uint32_t region_len = 0;         // foreign only: keys the range holds
+    uint32_t pad_keys = 0;           // padding keys of a ragged tile counted under my digit: they take no room
+    mutable uint32_t reserved = 0;
+    mutable bool reserved_yet = false;
 
+    __device__ __forceinline__ bool reserving() const { return cursor != nullptr; }
     __device__ __forceinline__ void publish(uint32_t v) const {
+        if (cursor) {  // the first call carries my digit's count; the second (the inclusive prefix) has nobody to tell
+            if (!reserved_yet) {
+                reserved_yet = true;
+                const uint32_t cnt = v - pad_keys;
+                if (cnt) {
+                    if (foreign)
+                        reserved = region_len - cnt - __hip_atomic_fetch_add(back, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        reserved = __hip_atomic_fetch_add(cursor, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            return;
+        }
         if (hold) return;
         uint32_t *p = col + static_cast<size_t>(index) * stride;
         if (foreign) lb_store_through(p, tag | v); else lb_store_l2(p, tag | v);
     }
     // rows first, first-1, ...: the row before the stream's first tile reads as "inclusive, 0"
     __device__ __forceinline__ void fetch(int first, uint32_t (&v)[kLbBatch]) const {
+        if (cursor) return;
 #pragma unroll
         for (int r = 0; r < kLbBatch; ++r)
             v[r] = first - r >= 0 ? lb_load(col + static_cast<size_t>(first - r) * stride) : (tag | kLbInclusive);
@@ -609,6 +632,7 @@ struct StreamLookback {
     // fetched again in one go (re-polling row by row would serialise one round trip per row).  gave_up: the budget
     // ran out on an unpublished row (the caller then counts the stream's earlier keys itself).
     __device__ __forceinline__ uint32_t resolve(uint32_t (&v)[kLbBatch], bool &gave_up) const {
+        if (cursor) return reserved;  // keys of my digit's range in front of this tile's, like the look-back's answer
         uint32_t acc = 0, polls = 0;
         [[maybe_unused]] uint32_t trips = 1;
         int first = index - 1;
@@ -796,7 +820,7 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     if constexpr (LB::kEnabled) {
         if (tid < kBins) {
             bool gave_up = false;
-            const uint32_t before = lb.foreign ? lb.recounted : lb.resolve(lb_rows, gave_up);
+            const uint32_t before = (lb.foreign && !lb.reserving()) ? lb.recounted : lb.resolve(lb_rows, gave_up);
             if (gave_up) sm.lb_gave_up = 1;
             lb_inclusive = kLbInclusive | (before + lb_total);  // published below, after the LDS reads of the write-out
             sm.gbase[tid] = lb.seed + before - lb_excl;
@@ -1386,7 +1410,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
                                                                        uint32_t pass, int forced, uint32_t shift,
                                                                        uint32_t *__restrict__ status,
                                                                        unsigned long long xcc_map, int misplace,
-                                                                       uint32_t spin_budget, int hold_tile, uint32_t key_base) {
+                                                                       uint32_t spin_budget, int hold_tile, uint32_t key_base,
+                                                                       MsdPlan *__restrict__ reserve) {
     constexpr uint32_t kTile = ITEMS * WAVES * 64;  // the tile the plan counted with (onesweep_tile_keys)
     __shared__ ChunkSmem<K, ITEMS, WAVES, PAIRS> sm;
     const uint32_t k = blockIdx.x >> 3, i = k / (kStreams / 8);
@@ -1410,7 +1435,19 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     lb.hold = hold_tile >= 0 && i == static_cast<uint32_t>(hold_tile);
     lb.stream_keys = keys_in + sd.start;
     lb.done = done;
-    if (lb.foreign) {
+    // first MSD pass over bare keys: the tile reserves its place in (stream, top byte)'s range instead of looking back
+    const bool reserving = !PAIRS && reserve != nullptr && shift == kShiftFromPlan;  // uniform
+    if (reserving) {
+        const uint32_t d = threadIdx.x & 255u;
+        lb.cursor = &reserve->cursor_a[s][d];
+        lb.back = &reserve->back_a[s][d];
+        lb.pad_keys = d == dg(dg.template pad<K>()) ? kTile - valid : 0u;
+        if (lb.foreign) {  // the range of (stream, digit) ends where the next stream's begins
+            const uint32_t next_group = s + 1u < static_cast<uint32_t>(kStreams) ? plan->head.stream[pass][s + 1u].first_group : 8u;
+            lb.region_len = plan->group_seed[pass][next_group][d] - plan->group_seed[pass][sd.first_group][d];
+        }
+    }
+    if (lb.foreign && !reserving) {
         // the earlier tiles of the stream are all full: count their digits from the keys themselves
         uint32_t *cnt = sm.whist[0];
         if (threadIdx.x < kBins) cnt[threadIdx.x] = 0;
@@ -1616,12 +1653,18 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
     atomicMax(&s_max, mx);
     uint32_t run = incl - sum;
     for (uint32_t j = 0; j < wave; ++j) run += s_wave[j];
+    {
+        uint32_t start[kPer];
 #pragma unroll
-    for (uint32_t j = 0; j < kPer; ++j) {
-        const uint32_t b = tid * kPer + j;
-        msd->base[b] = run;
-        if ((b & ((1u << sub_bits) - 1u)) == 0u) s_start[b >> sub_bits] = run;
-        run += c[j];
+        for (uint32_t j = 0; j < kPer; ++j) {
+            const uint32_t b = tid * kPer + j;
+            start[j] = run;
+            if ((b & ((1u << sub_bits) - 1u)) == 0u) s_start[b >> sub_bits] = run;
+            run += c[j];
+        }
+        uint4 *vb = reinterpret_cast<uint4 *>(msd->base + tid * kPer);
+#pragma unroll
+        for (uint32_t j = 0; j < kPer / 4u; ++j) vb[j] = make_uint4(start[4 * j], start[4 * j + 1], start[4 * j + 2], start[4 * j + 3]);
     }
     if (tid == 1023u) {
         msd->base[kMsdBuckets] = run;  // == n
@@ -1702,9 +1745,9 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
 template <typename K, int ITEMS, int RANK, bool PAIRS>
 __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                             const uint32_t *__restrict__ values_in, uint32_t *__restrict__ values_out,
-                                                            const MsdPlan *__restrict__ msd, uint32_t *__restrict__ status,
+                                                            MsdPlan *__restrict__ msd, uint32_t *__restrict__ status,
                                                             unsigned long long xcc_map, uint32_t spin_budget, uint32_t key_base,
-                                                            uint32_t sub_bits) {
+                                                            uint32_t sub_bits, uint32_t reserve) {
     constexpr uint32_t kTile = ITEMS * 8 * 64;  // the tile the plan counted with (onesweep_tile_keys)
     __shared__ ChunkSmem<K, ITEMS, 8, PAIRS> sm;
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
@@ -1727,7 +1770,15 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
     lb.foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * x)) & 0xFFu);
     lb.stream_keys = keys_in + first;
     lb.done = done;
-    if (lb.foreign) {
+    const bool reserving = !PAIRS && reserve != 0u;  // uniform: bare keys take their place in the bucket's range by reservation
+    if (reserving) {
+        const uint32_t b = (a << sub_bits) + min(threadIdx.x & 255u, (1u << sub_bits) - 1u);
+        lb.cursor = &msd->cursor_b[b];
+        lb.back = &msd->back_b[b];
+        lb.pad_keys = (threadIdx.x & 255u) == dg(dg.template pad<K>()) ? kTile - valid : 0u;
+        if (lb.foreign) lb.region_len = msd->base[b + 1u] - msd->base[b];
+    }
+    if (lb.foreign && !reserving) {
         uint32_t *cnt = sm.whist[0];
         if (threadIdx.x < kBins) cnt[threadIdx.x] = 0;
         __syncthreads();
@@ -1757,6 +1808,19 @@ struct StatusClear {
     uint4 *status;   // nullptr: nothing to clear
     uint32_t vecs;
 };
+// ... and it re-arms the reservation counters of the MSD passes (MsdPlan::cursor_* / back_*): workgroup b = bucket b clears the
+// second pass's counters of its bucket, the first 2 * kStreams workgroups one row each of the first pass's.
+__device__ __forceinline__ void rearm_reservation(MsdPlan *msd, uint32_t threads) {
+    const uint32_t b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        msd->cursor_b[b] = 0;
+        msd->back_b[b] = 0;
+    }
+    if (b < 2u * kStreams) {
+        uint32_t *row = b < static_cast<uint32_t>(kStreams) ? msd->cursor_a[b] : msd->back_a[b - kStreams];
+        for (uint32_t c = threadIdx.x; c < 256u; c += threads) row[c] = 0;
+    }
+}
 __device__ __forceinline__ void clear_status_share(const StatusClear &sc, uint32_t threads) {
     if (sc.status == nullptr) return;
     const uint32_t per = (sc.vecs + gridDim.x - 1u) / gridDim.x;
@@ -2209,11 +2273,12 @@ __device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
 // THREADS = 256: up to 7165 keys per bucket (uniform keys: N <= 1.05e8), 38 KB of LDS, four workgroups per CU;
 // THREADS = 512: up to 14333 keys (N <= 2.1e8), 78 KB, two per CU -- the same 16 waves
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void msd_local_sort_keys_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd, StatusClear sc) {
+__global__ __launch_bounds__(THREADS, 4) void msd_local_sort_keys_kernel(uint32_t *__restrict__ keys, MsdPlan *__restrict__ msd, StatusClear sc) {
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * kLeanMaxVec + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
     __shared__ uint32_t s_tmp[32];
     if (msd->ok == 0u) return;  // enqueued before the plan was known, and the plan refused the hybrid form
+    rearm_reservation(msd, THREADS);
     clear_status_share(sc, THREADS);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
@@ -2428,10 +2493,11 @@ __device__ __forceinline__ void wave_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
     }
 }
 constexpr uint32_t kWaveCap = 64u * 4u * kLeanMaxVec - 3u;  // 1789 keys
-__global__ __launch_bounds__(64, 4) void msd_local_sort_wave_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd, StatusClear sc) {
+__global__ __launch_bounds__(64, 4) void msd_local_sort_wave_kernel(uint32_t *__restrict__ keys, MsdPlan *__restrict__ msd, StatusClear sc) {
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[64 * 4 * kLeanMaxVec + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_tbl[kLeanRow];
     if (msd->ok == 0u) return;
+    rearm_reservation(msd, 64);
     clear_status_share(sc, 64);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
@@ -2457,7 +2523,7 @@ constexpr uint32_t kLocalCapBig = kLocalPairThreadsBig * kLocalPairItems;  // 13
 template <int THREADS>
 __global__ __launch_bounds__(THREADS, 4) void msd_local_sort_pairs_kernel(uint32_t *__restrict__ keys,
                                                                                          uint32_t *__restrict__ values,
-                                                                                         const MsdPlan *__restrict__ msd, StatusClear sc) {
+                                                                                         MsdPlan *__restrict__ msd, StatusClear sc) {
     constexpr int WAVES = THREADS / 64;
     constexpr uint32_t CAP = THREADS * kLocalPairItems;
     __shared__ uint32_t s_keys[CAP];
@@ -2465,6 +2531,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_local_sort_pairs_kernel(uint32
     __shared__ uint32_t s_hist[WAVES << 9];
     __shared__ uint32_t s_tmp[1 + WAVES];
     if (msd->ok == 0u) return;
+    rearm_reservation(msd, THREADS);
     clear_status_share(sc, THREADS);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     if (n == 0 || n > CAP) return;
@@ -2530,13 +2597,14 @@ __device__ __forceinline__ void local_sort_bucket_u64(uint64_t *bucket, uint32_t
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS, 4) void msd_local_sort_u64_kernel(uint64_t *__restrict__ keys,
-                                                                        const MsdPlan *__restrict__ msd, StatusClear sc) {
+                                                                        MsdPlan *__restrict__ msd, StatusClear sc) {
     constexpr int WAVES = THREADS / 64;
     constexpr uint32_t CAP = THREADS * kLocalPairItems;
     __shared__ uint64_t s_keys[CAP];
     __shared__ uint32_t s_hist[WAVES << 9];
     __shared__ uint32_t s_tmp[1 + WAVES];
     if (msd->ok == 0u) return;
+    rearm_reservation(msd, THREADS);
     clear_status_share(sc, THREADS);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     if (n == 0 || n > CAP) return;
@@ -2942,16 +3010,17 @@ hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *ms
 }
 
 hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
-                             uint32_t *values_out, const MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
+                             uint32_t *values_out, MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
                              unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev, uint32_t key_base,
-                             uint32_t sub_bits) {
+                             uint32_t sub_bits, bool reserve) {
     if (tiles_b == 0) return hipSuccess;
     if (sub_bits < 6u || sub_bits > 8u) return hipErrorInvalidValue;
     if (key_bytes == 8 && values_in != nullptr) return hipErrorInvalidValue;
     const dim3 grid(8 * tiles_b), block(512);
 #define VRS_PASS_B(K, ITEMS, RANK, PAIRS)                                                                                  \
     VRS_LAUNCH((msd_pass_b_kernel<K, ITEMS, RANK, PAIRS>), grid, block, stream, ev, static_cast<const K *>(keys_in),         \
-               static_cast<K *>(keys_out), values_in, values_out, msd, status, xcc_map, spin_budget, key_base, sub_bits)
+               static_cast<K *>(keys_out), values_in, values_out, msd, status, xcc_map, spin_budget, key_base, sub_bits,      \
+               reserve ? 1u : 0u)
     if (key_bytes == 8) {
         if (atomic_rank) VRS_PASS_B(uint64_t, 8, RANK_ATOMIC, false); else VRS_PASS_B(uint64_t, 8, RANK_BALLOT, false);
     } else if (values_in != nullptr) {
@@ -2973,7 +3042,7 @@ hipError_t launch_msd_count_u64(hipStream_t stream, const void *keys, uint32_t n
     return hipGetLastError();
 }
 
-hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, const MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev,
+hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev,
                                      uint32_t *clear_status, size_t clear_words) {
     if (max_bucket > kLocalCapBig) return hipErrorInvalidValue;  // the plan would have refused
     const StatusClear sc{reinterpret_cast<uint4 *>(clear_status), static_cast<uint32_t>(clear_words / 4)};
@@ -2984,7 +3053,7 @@ hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, const MsdPl
     return hipGetLastError();
 }
 
-hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *values, const MsdPlan *msd, uint32_t max_bucket,
+hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *values, MsdPlan *msd, uint32_t max_bucket,
                                  LaunchEvents ev, uint32_t *clear_status, size_t clear_words) {
     if (max_bucket > msd_local_capacity(values != nullptr)) return hipErrorInvalidValue;  // the plan would have refused
     const StatusClear sc{reinterpret_cast<uint4 *>(clear_status), static_cast<uint32_t>(clear_words / 4)};
@@ -3069,7 +3138,7 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
                                    uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
                                    uint32_t *status, uint32_t grid_tiles, bool forced, bool atomic_rank,
                                    unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, int hold_tile,
-                                   LaunchEvents ev, bool misplace, uint32_t key_base) {
+                                   LaunchEvents ev, bool misplace, uint32_t key_base, MsdPlan *reserve) {
     const int mis = misplace ? 1 : 0, force = forced ? 1 : 0;
     if (grid_tiles == 0) return hipSuccess;
     const dim3 grid(kStreams * grid_tiles), block(64 * VRS_LB_WAVES);
@@ -3077,7 +3146,7 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
 #define VRS_ONESWEEP(K, ITEMS, PAIRS, RANK)                                                                           \
     VRS_LAUNCH((onesweep_scatter_kernel<K, ITEMS, VRS_LB_WAVES, PAIRS, RANK, 4>), grid, block, stream, ev,            \
                static_cast<const K *>(keys_in), static_cast<K *>(keys_out), values_in, values_out, plan, pass, force,  \
-               shift, status, xcc_map, mis, spin_budget, hold_tile, key_base)
+               shift, status, xcc_map, mis, spin_budget, hold_tile, key_base, reserve)
     if (key_bytes == 8 && pairs) {  // uint64 keys + uint32 payloads: 4096-pair tiles (32 KB of keys + 16 KB of payloads in LDS)
         if (atomic_rank) VRS_ONESWEEP(uint64_t, 8, true, RANK_ATOMIC); else VRS_ONESWEEP(uint64_t, 8, true, RANK_BALLOT);
     } else if (key_bytes == 8) {
