@@ -632,6 +632,35 @@ def test_hybrid_form_msd_passes_by_reservation(gpu_context, dist, hook):
     assert hybrid_sorts(ctx) - h0 == (2 if fits else 0) + 1, (dist, shift, hybrid_sorts(ctx) - h0)  # + the pairs sort
 
 
+def test_a_refused_reserving_sort_enqueued_blind_makes_no_claim_about_the_status_words(gpu_context):
+    """Found by the fuzz (seed 7171): an enqueue-only sort of 24-bit keys with reserving MSD passes is refused by its plan (range
+    too narrow) and runs its four LSD look-back passes from one_read_complete -- they write the status words, so the context
+    must not go on believing them clear: the look-back sort that follows (pairs) has to clear them first."""
+    ctx = gpu_context
+    n = 5000003
+    keys = make_keys(n, "uniform", seed=3) & np.uint32(0xFF00FF)
+    m = 3000001
+    pk, pv = make_keys(m, "uniform", seed=4), np.arange(m, dtype=np.uint32)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 2)
+    try:
+        for _ in range(2):
+            ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)
+            out, _ = sort_keys(ctx, keys)
+            ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 0)
+            assert np.array_equal(out, np.sort(keys))
+            ctx.setTuning(capi.VRS_TUNE_RANK_MODE, 1)  # ballot ranking: no hybrid form, four look-back passes with payloads
+            ok, ov = sort_pairs_once(ctx, pk, pv)
+            ctx.setTuning(capi.VRS_TUNE_RANK_MODE, 0)
+            order = np.argsort(pk, kind="stable")
+            assert np.array_equal(ok, pk[order]) and np.array_equal(ov, pv[order])
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 0)
+        ctx.setTuning(capi.VRS_TUNE_RANK_MODE, 0)
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
+        ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 1)
+
+
 @pytest.mark.parametrize("mode", [0, 2])
 def test_hybrid_form_u64_with_and_without_reservation(gpu_context, mode):
     ctx, lib = gpu_context, gpu_context.lib

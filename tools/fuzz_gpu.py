@@ -53,8 +53,16 @@ def main():
     rs = np.random.RandomState(seed)
     t_end = time.time() + budget
     cases = 0
+    recent = []  # the last few cases, printed with a mismatch: what ran before matters (status words, counters, adaptive counts)
     with vrs.GPUContext(0) as ctx:
         lib = ctx.lib
+        knobs = {}
+        set_tuning = ctx.setTuning
+
+        def recording_set_tuning(key, value):
+            knobs[key] = value
+            set_tuning(key, value)
+        ctx.setTuning = recording_set_tuning
         while time.time() < t_end:
             if rs.randint(0, 12) == 0:
                 # round 3: the second half of the hybrid form for keys that arrive grouped by top byte (what a rank of a large
@@ -125,6 +133,9 @@ def main():
                 # round 3: enqueue-only sorts (the download below settles them)
                 ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, int(rs.randint(0, 3) == 0))
                 hold = rs.randint(0, 8) == 0
+                recent.append(("one-call", n, "u64" if bits64 else "u32", "pairs" if pairs else "keys", kind,
+                               dict(knobs)))
+                recent[:] = recent[-4:]
                 ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, int(rs.randint(0, 6)) if hold else -1)
                 ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, int(rs.choice([0, 3, 40])) if hold else 4096)
                 kb = keys.itemsize
@@ -163,7 +174,9 @@ def main():
                 ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 4096)
                 cases += 1
                 if not ok:
-                    print(f"MISMATCH one-call n={n} bits64={bits64} pairs={pairs} kind={kind} mode={mode} off={off} seed={seed} case={cases}")
+                    print(f"MISMATCH one-call n={n} bits64={bits64} pairs={pairs} kind={kind} mode={mode} off={off} seed={seed} case={cases} hold={hold}")
+                    for r in recent:
+                        print("   recent:", r)
                     sys.exit(1)
                 continue
             kb = 8 if bits64 else 4

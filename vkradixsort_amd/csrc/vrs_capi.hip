@@ -942,7 +942,9 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
         VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(st.kptr[home]),
                                                 pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr, ctx->os_msd_plan, max_bucket, ev,
                                                 clear, clear_words));
-    if (clear || untouched) ctx->os_status_clean = true;
+    // (a whole sort enqueued blind may still be refused and run its LSD passes, which write the words, from one_read_complete:
+    // it makes no claim)
+    if (clear || (untouched && (!st.blind_tail || status_was_clean))) ctx->os_status_clean = true;
     ctx->os_cursors_open = false;  // the local sort is on the stream: it re-arms the reservation counters (or, the plan refusing, nothing touched them)
     (void)g;
     return VRS_OK;
@@ -1102,6 +1104,8 @@ static int one_read_complete(vrs_context ctx, bool *done) {
             ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = st.ev_lb_before + (st.blind_tail ? 2 : 1);
         }
         if (!st.blind_tail && (rc = one_read_hybrid_tail(ctx, st, g, head.msd_tiles_b, head.msd_max_bucket))) return rc;
+        // enqueued blind and taken: reserving passes have left the status words as the counting read cleared them
+        if (st.blind_tail && reserves(ctx, n, pairs)) ctx->os_status_clean = true;
         st.cur = st.cur_at_start;
         ctx->os_hybrid_sorts++;
         return finish();  // the whole key is sorted (64-bit keys: no second group of passes)
