@@ -592,37 +592,15 @@ struct StreamLookback {
     uint32_t budget = 0;      // polls of an unpublished row before giving up
     const void *stream_keys = nullptr;  // first key of the stream in the pass's input
     uint32_t done = 0;        // keys of the stream before this tile
-    // Reservation instead of look-back (MsdPlan::cursor_a / cursor_b; cursor != nullptr): my digit's range hands out absolute
-    // positions.  157 -> 143 us per pass at 10^8 keys (profiles/labs/r03_reservation.txt): no status rows to publish, poll and clear.
-    uint32_t *cursor = nullptr;      // keys of my digit's range placed so far; L2-local: every tile of the stream runs behind the same L2
-    uint32_t *back = nullptr;        // a foreign tile's counter (device scope): keys taken from the range's end
-    uint32_t region_len = 0;         // foreign only: keys the range holds
-    uint32_t pad_keys = 0;           // padding keys of a ragged tile counted under my digit: they take no room
-    mutable uint32_t reserved = 0;
-    mutable bool reserved_yet = false;
 
-    __device__ __forceinline__ bool reserving() const { return cursor != nullptr; }
+    static constexpr bool kReserves = false;
     __device__ __forceinline__ void publish(uint32_t v) const {
-        if (cursor) {  // the first call carries my digit's count; the second (the inclusive prefix) has nobody to tell
-            if (!reserved_yet) {
-                reserved_yet = true;
-                const uint32_t cnt = v - pad_keys;
-                if (cnt) {
-                    if (foreign)
-                        reserved = region_len - cnt - __hip_atomic_fetch_add(back, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else
-                        reserved = __hip_atomic_fetch_add(cursor, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-            return;
-        }
         if (hold) return;
         uint32_t *p = col + static_cast<size_t>(index) * stride;
         if (foreign) lb_store_through(p, tag | v); else lb_store_l2(p, tag | v);
     }
     // rows first, first-1, ...: the row before the stream's first tile reads as "inclusive, 0"
     __device__ __forceinline__ void fetch(int first, uint32_t (&v)[kLbBatch]) const {
-        if (cursor) return;
 #pragma unroll
         for (int r = 0; r < kLbBatch; ++r)
             v[r] = first - r >= 0 ? lb_load(col + static_cast<size_t>(first - r) * stride) : (tag | kLbInclusive);
@@ -632,7 +610,6 @@ struct StreamLookback {
     // fetched again in one go (re-polling row by row would serialise one round trip per row).  gave_up: the budget
     // ran out on an unpublished row (the caller then counts the stream's earlier keys itself).
     __device__ __forceinline__ uint32_t resolve(uint32_t (&v)[kLbBatch], bool &gave_up) const {
-        if (cursor) return reserved;  // keys of my digit's range in front of this tile's, like the look-back's answer
         uint32_t acc = 0, polls = 0;
         [[maybe_unused]] uint32_t trips = 1;
         int first = index - 1;
@@ -668,6 +645,43 @@ struct StreamLookback {
             fetch(first, v);
         }
     }
+};
+
+// Reservation instead of look-back (MSD passes over BARE keys; MsdPlan::cursor_a / cursor_b): my digit's range hands out places
+// in the order tiles ask.  ONE atomic add per tile and digit in the L2 all tiles of the stream run behind -- no status rows to
+// publish, poll and clear: 160 -> 143 us for the first MSD pass of 10^8 keys (profiles/labs/r03_reservation.txt).  The same
+// interface as StreamLookback, so that scatter_chunk does not care; a type of its own, so that the look-back passes (LSD sorts,
+// payloads), which are bound by their latency at small sizes, carry none of it.
+struct StreamReserve {
+    static constexpr bool kEnabled = true;
+    static constexpr bool kReserves = true;
+    bool foreign = false;            // this workgroup is not behind its stream's L2: it takes room from the range's END (device scope)
+    uint32_t recounted = 0;          // (unused: interface of StreamLookback)
+    int index = 0;
+    const void *stream_keys = nullptr;
+    uint32_t done = 0;
+    uint32_t seed = 0;               // where my digit's range starts
+    uint32_t *cursor = nullptr;      // keys of the range placed so far (L2-local atomics)
+    uint32_t *back = nullptr;        // keys taken from its end by foreign tiles (device-scope atomics)
+    uint32_t region_len = 0;         // foreign only: keys the range holds
+    uint32_t pad_keys = 0;           // padding keys of a ragged tile counted under my digit: they take no room
+    mutable uint32_t reserved = 0;
+    mutable bool reserved_yet = false;
+
+    __device__ __forceinline__ void publish(uint32_t v) const {
+        if (reserved_yet) return;  // the second call (the inclusive prefix) has nobody to tell
+        reserved_yet = true;
+        const uint32_t cnt = v - pad_keys;
+        if (cnt) {
+            if (foreign)
+                reserved = region_len - cnt - __hip_atomic_fetch_add(back, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                reserved = __hip_atomic_fetch_add(cursor, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __device__ __forceinline__ void fetch(int, uint32_t (&)[kLbBatch]) const {}
+    // keys of my digit's range in front of this tile's: what the look-back would have answered for a stable pass
+    __device__ __forceinline__ uint32_t resolve(uint32_t (&)[kLbBatch], bool &) const { return reserved; }
 };
 
 // cnt[0..256) += digit counts of keys[0, count) (all threads of the workgroup; barriers are the caller's)
@@ -820,7 +834,7 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     if constexpr (LB::kEnabled) {
         if (tid < kBins) {
             bool gave_up = false;
-            const uint32_t before = (lb.foreign && !lb.reserving()) ? lb.recounted : lb.resolve(lb_rows, gave_up);
+            const uint32_t before = (lb.foreign && !LB::kReserves) ? lb.recounted : lb.resolve(lb_rows, gave_up);
             if (gave_up) sm.lb_gave_up = 1;
             lb_inclusive = kLbInclusive | (before + lb_total);  // published below, after the LDS reads of the write-out
             sm.gbase[tid] = lb.seed + before - lb_excl;
@@ -1401,7 +1415,7 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
 // tile (b/8) / (kStreams/8): every tile's predecessors in its stream sit in lower-numbered blocks of the same XCD.
 // The stream's range comes from the plan in device memory (three scalar loads): the host launches the pass before it
 // has seen the plan, with room for the longest stream the plan may accept (tile_cap tiles); surplus workgroups leave.
-template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, int OCC>
+template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, int OCC, bool RESERVE = false>
 __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const K *__restrict__ keys_in,
                                                                        K *__restrict__ keys_out,
                                                                        const uint32_t *__restrict__ values_in,
@@ -1429,47 +1443,54 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     RadixDigit<K> dg;
     dg.shift = shift == kShiftFromPlan ? plan->head.msd_shift_a : shift;  // first MSD pass of the hybrid form: set by msd_plan_kernel
     dg.base = shift == kShiftFromPlan ? static_cast<K>(key_base) : static_cast<K>(0);
-    StreamLookback lb;
     // byte x of xcc_map = XCC of the blocks with blockIdx % 8 == x (probed); my stream's tiles sit in blocks = s (mod 8)
-    lb.foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * (s & 7u))) & 0xFFu);
-    lb.hold = hold_tile >= 0 && i == static_cast<uint32_t>(hold_tile);
-    lb.stream_keys = keys_in + sd.start;
-    lb.done = done;
-    // first MSD pass over bare keys: the tile reserves its place in (stream, top byte)'s range instead of looking back
-    const bool reserving = !PAIRS && reserve != nullptr && shift == kShiftFromPlan;  // uniform
-    if (reserving) {
+    const bool foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * (s & 7u))) & 0xFFu);
+    uint32_t unused = 0;
+    const uint32_t *vin = PAIRS ? values_in + begin : nullptr;
+    if constexpr (RESERVE) {
+        // first MSD pass over bare keys: the tile reserves its place in (stream, top byte)'s range instead of looking back
+        StreamReserve lb;
         const uint32_t d = threadIdx.x & 255u;
+        lb.foreign = foreign;
         lb.cursor = &reserve->cursor_a[s][d];
         lb.back = &reserve->back_a[s][d];
         lb.pad_keys = d == dg(dg.template pad<K>()) ? kTile - valid : 0u;
-        if (lb.foreign) {  // the range of (stream, digit) ends where the next stream's begins
+        lb.seed = plan->group_seed[pass][sd.first_group][d];
+        if (foreign) {  // the range of (stream, digit) ends where the next stream's begins
             const uint32_t next_group = s + 1u < static_cast<uint32_t>(kStreams) ? plan->head.stream[pass][s + 1u].first_group : 8u;
-            lb.region_len = plan->group_seed[pass][next_group][d] - plan->group_seed[pass][sd.first_group][d];
+            lb.region_len = plan->group_seed[pass][next_group][d] - lb.seed;
         }
+        if (valid == kTile)
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
+        else
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
+    } else {
+        StreamLookback lb;
+        lb.foreign = foreign;
+        lb.hold = hold_tile >= 0 && i == static_cast<uint32_t>(hold_tile);
+        lb.stream_keys = keys_in + sd.start;
+        lb.done = done;
+        if (lb.foreign) {
+            // the earlier tiles of the stream are all full: count their digits from the keys themselves
+            uint32_t *cnt = sm.whist[0];
+            if (threadIdx.x < kBins) cnt[threadIdx.x] = 0;
+            __syncthreads();
+            recount_keys(cnt, keys_in + sd.start, done, dg);
+            __syncthreads();
+            if (threadIdx.x < kBins) lb.recounted = cnt[threadIdx.x];
+            __syncthreads();
+        }
+        lb.col = status + static_cast<size_t>(s) * kBins + (threadIdx.x & 255u);
+        lb.stride = static_cast<size_t>(kStreams) * kBins;
+        lb.index = static_cast<int>(i);
+        lb.tag = (pass + 1u) << kLbTagShift;
+        lb.budget = spin_budget;
+        lb.seed = threadIdx.x < kBins ? plan->group_seed[pass][sd.first_group][threadIdx.x] : 0u;
+        if (valid == kTile)
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
+        else
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     }
-    if (lb.foreign && !reserving) {
-        // the earlier tiles of the stream are all full: count their digits from the keys themselves
-        uint32_t *cnt = sm.whist[0];
-        if (threadIdx.x < kBins) cnt[threadIdx.x] = 0;
-        __syncthreads();
-        recount_keys(cnt, keys_in + sd.start, done, dg);
-        __syncthreads();
-        if (threadIdx.x < kBins) lb.recounted = cnt[threadIdx.x];
-        __syncthreads();
-    }
-    lb.col = status + static_cast<size_t>(s) * kBins + (threadIdx.x & 255u);
-    lb.stride = static_cast<size_t>(kStreams) * kBins;
-    lb.index = static_cast<int>(i);
-    lb.tag = (pass + 1u) << kLbTagShift;
-    lb.budget = spin_budget;
-    lb.seed = threadIdx.x < kBins ? plan->group_seed[pass][sd.first_group][threadIdx.x] : 0u;
-    uint32_t unused = 0;
-    const uint32_t *vin = PAIRS ? values_in + begin : nullptr;
-    if (valid == kTile)
-        scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
-    else
-        scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused,
-                                                          lb);
     VRS_MARK_FLUSH();
 }
 
@@ -1742,12 +1763,12 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
 // Second MSD pass: inside every top-byte bucket (a contiguous range of the first pass's output) a stable scatter by bits
 // 18-23 -- the look-back machinery with one chain per bucket.  Block b -> XCD b % 8, which walks its 32 buckets in order;
 // status row of (XCD x, its j-th tile) = j * 8 + x, so a bucket's tiles are 8 rows apart like a stream's.
-template <typename K, int ITEMS, int RANK, bool PAIRS>
+template <typename K, int ITEMS, int RANK, bool PAIRS, bool RESERVE = false>
 __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                             const uint32_t *__restrict__ values_in, uint32_t *__restrict__ values_out,
                                                             MsdPlan *__restrict__ msd, uint32_t *__restrict__ status,
                                                             unsigned long long xcc_map, uint32_t spin_budget, uint32_t key_base,
-                                                            uint32_t sub_bits, uint32_t reserve) {
+                                                            uint32_t sub_bits) {
     constexpr uint32_t kTile = ITEMS * 8 * 64;  // the tile the plan counted with (onesweep_tile_keys)
     __shared__ ChunkSmem<K, ITEMS, 8, PAIRS> sm;
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
@@ -1766,39 +1787,48 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
     const uint32_t begin = first + done;
     const uint32_t valid = min(kTile, last - begin);
     BitsDigit dg{msd->shift, (1u << sub_bits) - 1u, key_base};
-    StreamLookback lb;
-    lb.foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * x)) & 0xFFu);
-    lb.stream_keys = keys_in + first;
-    lb.done = done;
-    const bool reserving = !PAIRS && reserve != 0u;  // uniform: bare keys take their place in the bucket's range by reservation
-    if (reserving) {
+    const bool foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * x)) & 0xFFu);
+    uint32_t unused = 0;
+    const uint32_t *vin = PAIRS ? values_in + begin : nullptr;
+    if constexpr (RESERVE) {
+        // bare keys take their place in the bucket's range by reservation (StreamReserve)
+        StreamReserve lb;
         const uint32_t b = (a << sub_bits) + min(threadIdx.x & 255u, (1u << sub_bits) - 1u);
+        lb.foreign = foreign;
         lb.cursor = &msd->cursor_b[b];
         lb.back = &msd->back_b[b];
         lb.pad_keys = (threadIdx.x & 255u) == dg(dg.template pad<K>()) ? kTile - valid : 0u;
-        if (lb.foreign) lb.region_len = msd->base[b + 1u] - msd->base[b];
+        lb.seed = msd->base[b];
+        if (foreign) lb.region_len = msd->base[b + 1u] - lb.seed;
+        if (valid == kTile)
+            scatter_chunk<K, ITEMS, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
+        else
+            scatter_chunk<K, ITEMS, 8, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
+    } else {
+        StreamLookback lb;
+        lb.foreign = foreign;
+        lb.stream_keys = keys_in + first;
+        lb.done = done;
+        if (lb.foreign) {
+            uint32_t *cnt = sm.whist[0];
+            if (threadIdx.x < kBins) cnt[threadIdx.x] = 0;
+            __syncthreads();
+            recount_keys(cnt, keys_in + first, done, dg);
+            __syncthreads();
+            if (threadIdx.x < kBins) lb.recounted = cnt[threadIdx.x];
+            __syncthreads();
+        }
+        lb.col = status + (static_cast<size_t>(pt[k]) * 8u + x) * kBins + (threadIdx.x & 255u);
+        lb.stride = static_cast<size_t>(8) * kBins;
+        lb.index = static_cast<int>(i);
+        lb.tag = 6u << kLbTagShift;
+        lb.budget = spin_budget;
+        lb.seed = threadIdx.x < (1u << sub_bits) ? msd->base[(a << sub_bits) + threadIdx.x] : 0u;
+        if (valid == kTile)
+            scatter_chunk<K, ITEMS, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
+        else
+            scatter_chunk<K, ITEMS, 8, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     }
-    if (lb.foreign && !reserving) {
-        uint32_t *cnt = sm.whist[0];
-        if (threadIdx.x < kBins) cnt[threadIdx.x] = 0;
-        __syncthreads();
-        recount_keys(cnt, keys_in + first, done, dg);
-        __syncthreads();
-        if (threadIdx.x < kBins) lb.recounted = cnt[threadIdx.x];
-        __syncthreads();
-    }
-    lb.col = status + (static_cast<size_t>(pt[k]) * 8u + x) * kBins + (threadIdx.x & 255u);
-    lb.stride = static_cast<size_t>(8) * kBins;
-    lb.index = static_cast<int>(i);
-    lb.tag = 6u << kLbTagShift;
-    lb.budget = spin_budget;
-    lb.seed = threadIdx.x < (1u << sub_bits) ? msd->base[(a << sub_bits) + threadIdx.x] : 0u;
-    uint32_t unused = 0;
-    const uint32_t *vin = PAIRS ? values_in + begin : nullptr;
-    if (valid == kTile)
-        scatter_chunk<K, ITEMS, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
-    else
-        scatter_chunk<K, ITEMS, 8, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
 }
 
 // The local sort is the last kernel of a hybrid sort and LDS-bound: it has HBM time to spare, so it also clears the look-back
@@ -3017,16 +3047,20 @@ hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys
     if (sub_bits < 6u || sub_bits > 8u) return hipErrorInvalidValue;
     if (key_bytes == 8 && values_in != nullptr) return hipErrorInvalidValue;
     const dim3 grid(8 * tiles_b), block(512);
-#define VRS_PASS_B(K, ITEMS, RANK, PAIRS)                                                                                  \
-    VRS_LAUNCH((msd_pass_b_kernel<K, ITEMS, RANK, PAIRS>), grid, block, stream, ev, static_cast<const K *>(keys_in),         \
-               static_cast<K *>(keys_out), values_in, values_out, msd, status, xcc_map, spin_budget, key_base, sub_bits,      \
-               reserve ? 1u : 0u)
+#define VRS_PASS_B(K, ITEMS, RANK, PAIRS, RESERVE)                                                                         \
+    VRS_LAUNCH((msd_pass_b_kernel<K, ITEMS, RANK, PAIRS, RESERVE>), grid, block, stream, ev, static_cast<const K *>(keys_in), \
+               static_cast<K *>(keys_out), values_in, values_out, msd, status, xcc_map, spin_budget, key_base, sub_bits)
+    // (the hybrid form runs only with the LDS-atomic ranking; bare keys may take their places by reservation)
     if (key_bytes == 8) {
-        if (atomic_rank) VRS_PASS_B(uint64_t, 8, RANK_ATOMIC, false); else VRS_PASS_B(uint64_t, 8, RANK_BALLOT, false);
+        if (!atomic_rank) VRS_PASS_B(uint64_t, 8, RANK_BALLOT, false, false);
+        else if (reserve) VRS_PASS_B(uint64_t, 8, RANK_ATOMIC, false, true);
+        else VRS_PASS_B(uint64_t, 8, RANK_ATOMIC, false, false);
     } else if (values_in != nullptr) {
-        if (atomic_rank) VRS_PASS_B(uint32_t, 16, RANK_ATOMIC, true); else VRS_PASS_B(uint32_t, 16, RANK_BALLOT, true);
+        if (atomic_rank) VRS_PASS_B(uint32_t, 16, RANK_ATOMIC, true, false); else VRS_PASS_B(uint32_t, 16, RANK_BALLOT, true, false);
     } else {
-        if (atomic_rank) VRS_PASS_B(uint32_t, 16, RANK_ATOMIC, false); else VRS_PASS_B(uint32_t, 16, RANK_BALLOT, false);
+        if (!atomic_rank) VRS_PASS_B(uint32_t, 16, RANK_BALLOT, false, false);
+        else if (reserve) VRS_PASS_B(uint32_t, 16, RANK_ATOMIC, false, true);
+        else VRS_PASS_B(uint32_t, 16, RANK_ATOMIC, false, false);
     }
 #undef VRS_PASS_B
     return hipGetLastError();
@@ -3143,11 +3177,16 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
     if (grid_tiles == 0) return hipSuccess;
     const dim3 grid(kStreams * grid_tiles), block(64 * VRS_LB_WAVES);
     const bool pairs = values_in != nullptr;
-#define VRS_ONESWEEP(K, ITEMS, PAIRS, RANK)                                                                           \
-    VRS_LAUNCH((onesweep_scatter_kernel<K, ITEMS, VRS_LB_WAVES, PAIRS, RANK, 4>), grid, block, stream, ev,            \
+#define VRS_ONESWEEP_R(K, ITEMS, PAIRS, RANK, RESERVE)                                                                \
+    VRS_LAUNCH((onesweep_scatter_kernel<K, ITEMS, VRS_LB_WAVES, PAIRS, RANK, 4, RESERVE>), grid, block, stream, ev,   \
                static_cast<const K *>(keys_in), static_cast<K *>(keys_out), values_in, values_out, plan, pass, force,  \
                shift, status, xcc_map, mis, spin_budget, hold_tile, key_base, reserve)
-    if (key_bytes == 8 && pairs) {  // uint64 keys + uint32 payloads: 4096-pair tiles (32 KB of keys + 16 KB of payloads in LDS)
+#define VRS_ONESWEEP(K, ITEMS, PAIRS, RANK) VRS_ONESWEEP_R(K, ITEMS, PAIRS, RANK, false)
+    // the first MSD pass of the hybrid form over bare keys (LDS-atomic ranking) may take its places by reservation
+    if (reserve != nullptr && !pairs && atomic_rank && shift == kShiftFromPlan) {
+        if (key_bytes == 8) VRS_ONESWEEP_R(uint64_t, 8, false, RANK_ATOMIC, true);
+        else VRS_ONESWEEP_R(uint32_t, VRS_LB_ITEMS, false, RANK_ATOMIC, true);
+    } else if (key_bytes == 8 && pairs) {  // uint64 keys + uint32 payloads: 4096-pair tiles (32 KB of keys + 16 KB of payloads in LDS)
         if (atomic_rank) VRS_ONESWEEP(uint64_t, 8, true, RANK_ATOMIC); else VRS_ONESWEEP(uint64_t, 8, true, RANK_BALLOT);
     } else if (key_bytes == 8) {
         if (atomic_rank) VRS_ONESWEEP(uint64_t, 8, false, RANK_ATOMIC); else VRS_ONESWEEP(uint64_t, 8, false, RANK_BALLOT);
@@ -3157,6 +3196,7 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
         if (atomic_rank) VRS_ONESWEEP(uint32_t, VRS_LB_ITEMS, false, RANK_ATOMIC); else VRS_ONESWEEP(uint32_t, VRS_LB_ITEMS, false, RANK_BALLOT);
     }
 #undef VRS_ONESWEEP
+#undef VRS_ONESWEEP_R
     return hipGetLastError();
 }
 
