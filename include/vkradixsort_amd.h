@@ -230,7 +230,8 @@ int vrs_sort_pairs_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vr
  * The hybrid form of vrs_sort_keys_u32 in two halves, for callers that move the keys between its two MSD passes -- the
  * multi-GPU step (vrs_dist_*) puts the exchange between the GPUs there.  Both only enqueue.
  *   vrs_msd_partition_u32: counting read (histogram of the top 14 bits of the probed key range + top-byte counts) and the first
- *     MSD pass: `out` = the keys grouped by the top 8 bits of the range, stable.  counts_out (VRS_MSD_COUNT_WORDS uint32):
+ *     MSD pass: `out` = the keys grouped by the top 8 bits of the range (in no particular order inside a group when the pass takes
+ *     its places by reservation, VRS_TUNE_MSD_RESERVE: from 3 * 10^7 keys on).  counts_out (VRS_MSD_COUNT_WORDS uint32):
  *     [0, 16384) the bucket histogram, [16384, 16384 + 8 * 256) the top-byte counts of the eight input slices,
  *     [VRS_MSD_SHIFT_WORD] the bucket shift (bucket = key >> shift; below 13 the key range is too narrow for the form: the
  *     histogram is empty and `out` is not a partition), [VRS_MSD_SHIFT_WORD + 1] != 0: a key above the probed range.
@@ -366,7 +367,8 @@ typedef enum vrs_kernel_id {
     VRS_KERNEL_SCATTER = 2,   /* stable scatter (the dominant kernel) */
     VRS_KERNEL_SINGLE = 3,    /* single_radixsort */
     VRS_KERNEL_DIGIT_TABLES = 4,     /* one-call sort, large N: the single counting read of all four digits */
-    VRS_KERNEL_LOOKBACK_SCATTER = 5, /* one-call sort, large N: stable scatter with decoupled look-back */
+    VRS_KERNEL_LOOKBACK_SCATTER = 5, /* one-call sort, large N: scatter pass with decoupled look-back (stable), or -- MSD passes over bare keys --
+                                        with reserved places */
     VRS_KERNEL_LOCAL_SORT = 6,       /* one-call sort, hybrid form: every top-14-bit bucket sorted inside LDS */
     VRS_KERNEL_COUNT = 7
 } vrs_kernel_id;
