@@ -960,8 +960,9 @@ def test_the_wait_for_the_plan_is_bounded():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("reserve", [1, 2])
 @pytest.mark.parametrize("span_bits", [27, 29])
-def test_ranged_sort_buckets_a_sub_range_of_the_key_space(gpu_context, span_bits):
+def test_ranged_sort_buckets_a_sub_range_of_the_key_space(gpu_context, span_bits, reserve):
     """vrs_sort_keys_u32_ranged: keys of a sub-range [floor, floor + 2^span) -- what a rank of the multi-GPU step receives --
     are bucketed by key - floor, so the hybrid form sees the 16384 evenly filled buckets a full key range would give; a key
     below the promised floor only costs the hybrid form (the plan refuses), never the result."""
@@ -971,6 +972,7 @@ def test_ranged_sort_buckets_a_sub_range_of_the_key_space(gpu_context, span_bits
     rs = np.random.RandomState(span_bits)
     keys = (np.uint32(floor_key) + rs.randint(0, 1 << span_bits, size=n, dtype=np.uint32)).astype(np.uint32)
     ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+    ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, reserve)  # 2: the MSD passes reserve at this size too (ragged tiles pad with floor - 1)
     try:
         for stray in (False, True):
             k = keys.copy()
@@ -988,3 +990,4 @@ def test_ranged_sort_buckets_a_sub_range_of_the_key_space(gpu_context, span_bits
             k1.release()
     finally:
         ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
+        ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 1)
