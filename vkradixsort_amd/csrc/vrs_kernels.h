@@ -181,6 +181,10 @@ struct MsdPlan {
 };
 static_assert(offsetof(MsdPlan, base) % 16 == 0, "the plan kernel stores the bucket starts as 16-byte vectors");
 constexpr size_t kMsdCursorBytes = offsetof(MsdPlan, base) - offsetof(MsdPlan, cursor_a);  // the four counter arrays, contiguous
+static_assert(offsetof(MsdPlan, back_a) == offsetof(MsdPlan, cursor_a) + sizeof(uint32_t) * kStreams * 256 &&
+                  offsetof(MsdPlan, cursor_b) == offsetof(MsdPlan, back_a) + sizeof(uint32_t) * kStreams * 256 &&
+                  offsetof(MsdPlan, back_b) == offsetof(MsdPlan, cursor_b) + sizeof(uint32_t) * kMsdBucketCount,
+              "rearm_reservation walks cursor_a, back_a, cursor_b, back_b as one block");
 // words the hybrid's counting needs beside the digit tables: the 16384-bin histogram + 8 x 256 top-byte counts per
 // pass-0 group, zero between sorts
 constexpr size_t kMsdCountWords = kMsdBucketCount + 8u * 256u + 64u;  // + the probed shift and the out-of-range flag

@@ -1840,16 +1840,18 @@ struct StatusClear {
 };
 // ... and it re-arms the reservation counters of the MSD passes (MsdPlan::cursor_* / back_*): workgroup b = bucket b clears the
 // second pass's counters of its bucket, the first 2 * kStreams workgroups one row each of the first pass's.
-__device__ __forceinline__ void rearm_reservation(MsdPlan *msd, uint32_t threads) {
+// (`cursors` = &MsdPlan::cursor_a of the same plan the kernel reads through a const pointer: a pointer of its own, so that the
+// plan's fields stay scalar loads)
+__device__ __forceinline__ void rearm_reservation(uint32_t *__restrict__ cursors, uint32_t threads) {
+    constexpr uint32_t kRowsA = 2u * kStreams;                   // cursor_a rows, then back_a rows
+    uint32_t *cursor_b = cursors + kRowsA * 256u, *back_b = cursor_b + kMsdBuckets;
     const uint32_t b = blockIdx.x;
     if (threadIdx.x == 0) {
-        msd->cursor_b[b] = 0;
-        msd->back_b[b] = 0;
+        cursor_b[b] = 0;
+        back_b[b] = 0;
     }
-    if (b < 2u * kStreams) {
-        uint32_t *row = b < static_cast<uint32_t>(kStreams) ? msd->cursor_a[b] : msd->back_a[b - kStreams];
-        for (uint32_t c = threadIdx.x; c < 256u; c += threads) row[c] = 0;
-    }
+    if (b < kRowsA)
+        for (uint32_t c = threadIdx.x; c < 256u; c += threads) cursors[b * 256u + c] = 0;
 }
 __device__ __forceinline__ void clear_status_share(const StatusClear &sc, uint32_t threads) {
     if (sc.status == nullptr) return;
@@ -2303,12 +2305,13 @@ __device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
 // THREADS = 256: up to 7165 keys per bucket (uniform keys: N <= 1.05e8), 38 KB of LDS, four workgroups per CU;
 // THREADS = 512: up to 14333 keys (N <= 2.1e8), 78 KB, two per CU -- the same 16 waves
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void msd_local_sort_keys_kernel(uint32_t *__restrict__ keys, MsdPlan *__restrict__ msd, StatusClear sc) {
+__global__ __launch_bounds__(THREADS, 4) void msd_local_sort_keys_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd, StatusClear sc,
+                                                                         uint32_t *__restrict__ cursors) {
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * kLeanMaxVec + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
     __shared__ uint32_t s_tmp[32];
     if (msd->ok == 0u) return;  // enqueued before the plan was known, and the plan refused the hybrid form
-    rearm_reservation(msd, THREADS);
+    rearm_reservation(cursors, THREADS);
     clear_status_share(sc, THREADS);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
@@ -2523,11 +2526,12 @@ __device__ __forceinline__ void wave_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
     }
 }
 constexpr uint32_t kWaveCap = 64u * 4u * kLeanMaxVec - 3u;  // 1789 keys
-__global__ __launch_bounds__(64, 4) void msd_local_sort_wave_kernel(uint32_t *__restrict__ keys, MsdPlan *__restrict__ msd, StatusClear sc) {
+__global__ __launch_bounds__(64, 4) void msd_local_sort_wave_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd, StatusClear sc,
+                                                                  uint32_t *__restrict__ cursors) {
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[64 * 4 * kLeanMaxVec + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_tbl[kLeanRow];
     if (msd->ok == 0u) return;
-    rearm_reservation(msd, 64);
+    rearm_reservation(cursors, 64);
     clear_status_share(sc, 64);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
@@ -2553,7 +2557,8 @@ constexpr uint32_t kLocalCapBig = kLocalPairThreadsBig * kLocalPairItems;  // 13
 template <int THREADS>
 __global__ __launch_bounds__(THREADS, 4) void msd_local_sort_pairs_kernel(uint32_t *__restrict__ keys,
                                                                                          uint32_t *__restrict__ values,
-                                                                                         MsdPlan *__restrict__ msd, StatusClear sc) {
+                                                                                         const MsdPlan *__restrict__ msd, StatusClear sc,
+                                                                                         uint32_t *__restrict__ cursors) {
     constexpr int WAVES = THREADS / 64;
     constexpr uint32_t CAP = THREADS * kLocalPairItems;
     __shared__ uint32_t s_keys[CAP];
@@ -2561,7 +2566,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_local_sort_pairs_kernel(uint32
     __shared__ uint32_t s_hist[WAVES << 9];
     __shared__ uint32_t s_tmp[1 + WAVES];
     if (msd->ok == 0u) return;
-    rearm_reservation(msd, THREADS);
+    rearm_reservation(cursors, THREADS);
     clear_status_share(sc, THREADS);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     if (n == 0 || n > CAP) return;
@@ -2627,14 +2632,15 @@ __device__ __forceinline__ void local_sort_bucket_u64(uint64_t *bucket, uint32_t
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS, 4) void msd_local_sort_u64_kernel(uint64_t *__restrict__ keys,
-                                                                        MsdPlan *__restrict__ msd, StatusClear sc) {
+                                                                        const MsdPlan *__restrict__ msd, StatusClear sc,
+                                                                        uint32_t *__restrict__ cursors) {
     constexpr int WAVES = THREADS / 64;
     constexpr uint32_t CAP = THREADS * kLocalPairItems;
     __shared__ uint64_t s_keys[CAP];
     __shared__ uint32_t s_hist[WAVES << 9];
     __shared__ uint32_t s_tmp[1 + WAVES];
     if (msd->ok == 0u) return;
-    rearm_reservation(msd, THREADS);
+    rearm_reservation(cursors, THREADS);
     clear_status_share(sc, THREADS);
     const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
     if (n == 0 || n > CAP) return;
@@ -3081,9 +3087,9 @@ hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, MsdPlan *ms
     if (max_bucket > kLocalCapBig) return hipErrorInvalidValue;  // the plan would have refused
     const StatusClear sc{reinterpret_cast<uint4 *>(clear_status), static_cast<uint32_t>(clear_words / 4)};
     if (max_bucket > kLocalCap)
-        VRS_LAUNCH(msd_local_sort_u64_kernel<kLocalPairThreadsBig>, dim3(kMsdBuckets), dim3(kLocalPairThreadsBig), stream, ev, static_cast<uint64_t *>(keys), msd, sc);
+        VRS_LAUNCH(msd_local_sort_u64_kernel<kLocalPairThreadsBig>, dim3(kMsdBuckets), dim3(kLocalPairThreadsBig), stream, ev, static_cast<uint64_t *>(keys), msd, sc, &msd->cursor_a[0][0]);
     else
-        VRS_LAUNCH(msd_local_sort_u64_kernel<kLocalPairThreads>, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, static_cast<uint64_t *>(keys), msd, sc);
+        VRS_LAUNCH(msd_local_sort_u64_kernel<kLocalPairThreads>, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, static_cast<uint64_t *>(keys), msd, sc, &msd->cursor_a[0][0]);
     return hipGetLastError();
 }
 
@@ -3092,15 +3098,15 @@ hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *v
     if (max_bucket > msd_local_capacity(values != nullptr)) return hipErrorInvalidValue;  // the plan would have refused
     const StatusClear sc{reinterpret_cast<uint4 *>(clear_status), static_cast<uint32_t>(clear_words / 4)};
     if (values != nullptr && max_bucket > kLocalCap)
-        VRS_LAUNCH(msd_local_sort_pairs_kernel<kLocalPairThreadsBig>, dim3(kMsdBuckets), dim3(kLocalPairThreadsBig), stream, ev, keys, values, msd, sc);
+        VRS_LAUNCH(msd_local_sort_pairs_kernel<kLocalPairThreadsBig>, dim3(kMsdBuckets), dim3(kLocalPairThreadsBig), stream, ev, keys, values, msd, sc, &msd->cursor_a[0][0]);
     else if (values != nullptr)
-        VRS_LAUNCH(msd_local_sort_pairs_kernel<kLocalPairThreads>, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, keys, values, msd, sc);
+        VRS_LAUNCH(msd_local_sort_pairs_kernel<kLocalPairThreads>, dim3(kMsdBuckets), dim3(kLocalPairThreads), stream, ev, keys, values, msd, sc, &msd->cursor_a[0][0]);
     else if (max_bucket <= kWaveCap)
-        VRS_LAUNCH(msd_local_sort_wave_kernel, dim3(kMsdBuckets), dim3(64), stream, ev, keys, msd, sc);
+        VRS_LAUNCH(msd_local_sort_wave_kernel, dim3(kMsdBuckets), dim3(64), stream, ev, keys, msd, sc, &msd->cursor_a[0][0]);
     else if (max_bucket > kLeanCap)
-        VRS_LAUNCH(msd_local_sort_keys_kernel<512>, dim3(kMsdBuckets), dim3(512), stream, ev, keys, msd, sc);
+        VRS_LAUNCH(msd_local_sort_keys_kernel<512>, dim3(kMsdBuckets), dim3(512), stream, ev, keys, msd, sc, &msd->cursor_a[0][0]);
     else
-        VRS_LAUNCH(msd_local_sort_keys_kernel<256>, dim3(kMsdBuckets), dim3(256), stream, ev, keys, msd, sc);
+        VRS_LAUNCH(msd_local_sort_keys_kernel<256>, dim3(kMsdBuckets), dim3(256), stream, ev, keys, msd, sc, &msd->cursor_a[0][0]);
     return hipGetLastError();
 }
 
