@@ -294,7 +294,7 @@ def bench_single(args):
                    "compute_units": cus},
         "roofline": {"bound": "hbm", "kernel": f"{dominant_name} (one launch per scatter pass: reads and writes every key once"
                                                + ("; two launches per sort in the hybrid form -- onesweep_scatter_kernel and msd_pass_b_kernel, whose tiles take their "
-                                                  "places by reservation from 3e7 bare keys on, by decoupled look-back otherwise -- 47 % of the step" if hybrid else "") + ")",
+                                                  "places by reservation (bare keys; payloads: decoupled look-back) -- 47 % of the step" if hybrid else "") + ")",
                      "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                      "algorithmic_bytes_per_launch": BYTES_PER_KEY_SCATTER * n, "avg_launch_us": dom_us,

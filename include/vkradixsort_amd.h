@@ -231,7 +231,7 @@ int vrs_sort_pairs_u64(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, vr
  * multi-GPU step (vrs_dist_*) puts the exchange between the GPUs there.  Both only enqueue.
  *   vrs_msd_partition_u32: counting read (histogram of the top 14 bits of the probed key range + top-byte counts) and the first
  *     MSD pass: `out` = the keys grouped by the top 8 bits of the range (in no particular order inside a group when the pass takes
- *     its places by reservation, VRS_TUNE_MSD_RESERVE: from 3 * 10^7 keys on).  counts_out (VRS_MSD_COUNT_WORDS uint32):
+ *     its places by reservation, VRS_TUNE_MSD_RESERVE: the default).  counts_out (VRS_MSD_COUNT_WORDS uint32):
  *     [0, 16384) the bucket histogram, [16384, 16384 + 8 * 256) the top-byte counts of the eight input slices,
  *     [VRS_MSD_SHIFT_WORD] the bucket shift (bucket = key >> shift; below 13 the key range is too narrow for the form: the
  *     histogram is empty and `out` is not a partition), [VRS_MSD_SHIFT_WORD + 1] != 0: a key above the probed range.
@@ -455,8 +455,8 @@ typedef enum vrs_tuning_key {
     VRS_TUNE_PLAN_WAIT_MS = 15,    /* longest wait for a plan's head in milliseconds (default 60000; 0 = no limit) */
     VRS_TUNE_MSD_RESERVE = 16      /* the two MSD passes of the hybrid form over BARE keys reserve their output ranges with one L2-local atomic
                                       add per tile and digit instead of a decoupled look-back (the order inside a bucket is free there;
-                                      payloads always take the stable look-back).  1 (default): from 3 * 10^7 keys on (below, a pass is bound
-                                      by its latency and gains nothing); 2: always; 0: look-back everywhere */
+                                      payloads always take the stable look-back).  1 (default; 2 means the same): on; 0: look-back
+                                      everywhere */
 } vrs_tuning_key;
 int vrs_set_tuning(vrs_context ctx, int key, int value);
 

@@ -512,12 +512,15 @@ def test_hybrid_form_equals_std_sort(gpu_context, oracle, n, dist, fast_count):
     keys = make_hybrid_keys(n, dist, seed=n % 313)
     ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
     ctx.setTuning(capi.VRS_TUNE_HYBRID_FAST_COUNT, fast_count)
+    # the two MSD passes: with decoupled look-back (beside the full count) or by reservation, the default (beside the fast count)
+    ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 0 if fast_count == 0 else 1)
     h0, r0 = hybrid_sorts(ctx), hybrid_recounts(ctx)
     try:
         out, stats = sort_keys(ctx, keys)
     finally:
         ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
         ctx.setTuning(capi.VRS_TUNE_HYBRID_FAST_COUNT, 1)
+        ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 1)
     took, recounts = hybrid_sorts(ctx) - h0, hybrid_recounts(ctx) - r0
     assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
     # the buckets are the top 14 bits of the key RANGE (32-bit keys: bits 18-31, the reference's 28-bit keys: bits 14-27);
@@ -557,11 +560,14 @@ def test_fast_count_is_armed_by_a_hybrid_sort_and_disarmed_by_a_refusal(gpu_cont
     assert seen == [(1, 0, 1), (1, 0, 1), (0, 1, 2), (0, 0, 1), (1, 0, 1), (1, 0, 1)]
 
 
+@pytest.mark.parametrize("reserve", [0, 1])
 @pytest.mark.parametrize("hook", ["misplace", "hold", "ballot"])
-def test_hybrid_form_under_the_look_back_hooks(gpu_context, hook):
-    """The first MSD pass is the ordinary look-back kernel: XCD misplacement and a withheld tile must be survived there;
-    with ballot ranking forced the hybrid form is off (its local sort ranks with returning LDS atomics)."""
+def test_hybrid_form_under_the_look_back_hooks(gpu_context, hook, reserve):
+    """The MSD passes with decoupled look-back (VRS_TUNE_MSD_RESERVE = 0; payloads always) or by reservation (the default for
+    bare keys): XCD misplacement and a withheld tile must be survived either way; with ballot ranking forced the hybrid form
+    is off (its local sort ranks with returning LDS atomics)."""
     ctx = gpu_context
+    ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, reserve)
     n = (1 << 23) + 4321
     keys = make_keys(n, "uniform", seed=91)
     ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
@@ -581,6 +587,7 @@ def test_hybrid_form_under_the_look_back_hooks(gpu_context, hook):
         ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, -1)
         ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 4096)
         ctx.setTuning(capi.VRS_TUNE_RANK_MODE, 0)
+        ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 1)
     assert np.array_equal(out, np.sort(keys))
     assert hybrid_sorts(ctx) - h0 == (0 if hook == "ballot" else 1)
 

@@ -32,6 +32,8 @@ with vrs.GPUContext(0) as gpu:
         gpu.setTuning(8, groups)
     if os.environ.get("VRS_HYBRID_MIN"):
         gpu.setTuning(12, int(float(os.environ["VRS_HYBRID_MIN"])))
+    if os.environ.get("VRS_RESERVE"):
+        gpu.setTuning(16, int(os.environ["VRS_RESERVE"]))
     if os.environ.get("VRS_FUSED_PLAN"):
         gpu.setTuning(10, int(os.environ["VRS_FUSED_PLAN"]))
 

@@ -96,7 +96,7 @@ struct vrs_context_t {
     bool os_async = false;               // VRS_TUNE_ASYNC_SORT: the one-call sorts return without waiting for the plan; vrs_sort_settle finishes them
     uint32_t os_plan_wait_ms = 60000;    // VRS_TUNE_PLAN_WAIT_MS: longest wait for a plan's head (0 = no limit)
     int os_reserve = 1;                  // VRS_TUNE_MSD_RESERVE: the MSD passes over bare keys reserve their output instead of looking back
-                                         // (1: from 3e7 keys on -- below, a pass is latency-bound and gains nothing; 2: always; 0: never)
+                                         // (1 or 2: whenever the hybrid form runs on bare keys; 0: never)
     bool os_cursors_open = false;        // a reserving pass may have run without the local sort that re-arms its counters behind it
                                          // (a refused plan, a partition with no finish, an error in between): cleared before the next use
     // a one-call sort between its two halves (see one_read_enqueue / one_read_complete)
@@ -902,7 +902,8 @@ static int one_read_lookback_pass(vrs_context ctx, vrs_context_t::OneRead &st, u
 // Reservation counters (MsdPlan::cursor_* / back_*): zero when a reserving pass starts; the local sort leaves them so.  Every
 // entry point that is about to enqueue a reserving pass calls this first.
 static bool reserves(vrs_context ctx, uint32_t n, bool pairs) {
-    return !pairs && (ctx->os_reserve == 2 || (ctx->os_reserve == 1 && n >= 30000000u));
+    (void)n;  // (measured from 1.5e7 to 1e8 keys: 2 to 5 % of the sort at every size the hybrid form takes)
+    return !pairs && ctx->os_reserve != 0;
 }
 static int reservation_begin(vrs_context ctx) {
     if (!ctx->os_reserve || !ctx->os_msd_plan) return VRS_OK;
@@ -1744,7 +1745,7 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             ctx->os_plan_wait_ms = static_cast<uint32_t>(value);
             return VRS_OK;
         case VRS_TUNE_MSD_RESERVE:
-            if (value < 0 || value > 2) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "MSD reservation must be 0 (never), 1 (from 3e7 keys on) or 2 (always)");
+            if (value < 0 || value > 2) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "MSD reservation must be 0 (never) or 1 / 2 (bare keys of the hybrid form)");
             ctx->os_reserve = value;
             return VRS_OK;
         case VRS_TUNE_DIGIT_TABLE_GROUPS:
