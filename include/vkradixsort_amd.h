@@ -370,7 +370,8 @@ typedef enum vrs_kernel_id {
     VRS_KERNEL_LOOKBACK_SCATTER = 5, /* one-call sort, large N: scatter pass with decoupled look-back (stable), or -- MSD passes over bare keys --
                                         with reserved places */
     VRS_KERNEL_LOCAL_SORT = 6,       /* one-call sort, hybrid form: every top-14-bit bucket sorted inside LDS */
-    VRS_KERNEL_COUNT = 7
+    VRS_KERNEL_POOL_SAMPLE = 7,      /* one-call sort, pool form: the sample (1/32 of the keys) that sizes the first MSD pass's regions */
+    VRS_KERNEL_COUNT = 8
 } vrs_kernel_id;
 
 /* When enabled, every kernel launch carries a (start, stop) hipEvent pair on its own dispatch packet
@@ -406,6 +407,10 @@ int vrs_one_call_hybrid_sorts(vrs_context ctx, uint64_t *hybrid_sorts);
 /* One-call sorts that, after a fast count (VRS_TUNE_HYBRID_FAST_COUNT) and a plan that refused the hybrid form, started over
  * as LSD sorts with a second counting read.  Cumulative; diagnostics only. */
 int vrs_one_call_hybrid_recounts(vrs_context ctx, uint64_t *recounts);
+
+/* One-call sorts of bare uint32 keys that took the pool form (the hybrid form without a counting read, VRS_TUNE_MSD_POOL), and
+ * sorts whose pool form the plan refused (they ran in the counted form afterwards).  Cumulative; diagnostics only. */
+int vrs_one_call_pool_sorts(vrs_context ctx, uint64_t *pool_sorts, uint64_t *pool_refusals);
 
 /* Ranking method in effect: 1 = __ballot match-any, 2 = returning LDS atomics. */
 int vrs_rank_mode(vrs_context ctx);
@@ -453,10 +458,17 @@ typedef enum vrs_tuning_key {
                                      vrs_sort_settle (or any entry point that settles) finishes what the plan asks for.
                                      0 (default): they return once the plan's head has reached the host */
     VRS_TUNE_PLAN_WAIT_MS = 15,    /* longest wait for a plan's head in milliseconds (default 60000; 0 = no limit) */
-    VRS_TUNE_MSD_RESERVE = 16      /* the two MSD passes of the hybrid form over BARE keys reserve their output ranges with one L2-local atomic
+    VRS_TUNE_MSD_RESERVE = 16,     /* the two MSD passes of the hybrid form over BARE keys reserve their output ranges with one L2-local atomic
                                       add per tile and digit instead of a decoupled look-back (the order inside a bucket is free there;
                                       payloads always take the stable look-back).  1 (default; 2 means the same): on; 0: look-back
                                       everywhere */
+    VRS_TUNE_MSD_POOL = 17         /* the hybrid form of BARE uint32 keys without its counting read (24 instead of 28 bytes per key): a sample of
+                                      1/32 of the keys sizes a region of the partner buffer per (input slice, top byte), the first MSD
+                                      pass reserves its output there and counts the 16384 buckets on the way, the second pass reads the
+                                      regions.  A sort the plan refuses (a region the sample misjudged, a bucket too large) starts over in
+                                      the counted form with its input untouched.  1 (default) = adaptive: after a refusal the next 15
+                                      such sorts of the context take the counted form; 2 = always tried; 0 = never.  Needs
+                                      VRS_TUNE_MSD_RESERVE != 0. */
 } vrs_tuning_key;
 int vrs_set_tuning(vrs_context ctx, int key, int value);
 

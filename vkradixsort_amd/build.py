@@ -17,8 +17,8 @@ HOST = PKG_DIR / "host"
 INCLUDE = REPO_ROOT / "include"
 LIB_PATH = PKG_DIR / "libvkradixsort_amd.so"
 
-HIP_SOURCES = [CSRC / "vrs_kernels.hip", CSRC / "vrs_capi.hip", CSRC / "vrs_dist.hip"]
-HIP_HEADERS = [CSRC / "vrs_kernels.h", INCLUDE / "vkradixsort_amd.h"]
+HIP_SOURCES = [CSRC / "vrs_kernels.hip", CSRC / "vrs_msd_pool.hip", CSRC / "vrs_capi.hip", CSRC / "vrs_dist.hip"]
+HIP_HEADERS = [CSRC / "vrs_kernels.h", CSRC / "vrs_device.hpp", INCLUDE / "vkradixsort_amd.h"]
 ARCH = "gfx950"
 
 
@@ -43,10 +43,18 @@ def _run(cmd, cwd=None) -> None:
 
 
 def build_library(force: bool = False) -> Path:
-    """hipcc --offload-arch=gfx950 -> vkradixsort_amd/libvkradixsort_amd.so (kernels + C ABI)."""
-    if force or _stale(LIB_PATH, HIP_SOURCES + HIP_HEADERS):
-        _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-              f"-I{INCLUDE}", f"-I{CSRC}", *HIP_SOURCES, "-ldl", "-o", LIB_PATH])
+    """hipcc --offload-arch=gfx950 -> vkradixsort_amd/libvkradixsort_amd.so (kernels + C ABI): one object per source
+    (compiled side by side, only the stale ones), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = PKG_DIR / "_build"
+    obj_dir.mkdir(exist_ok=True)
+    objs = [obj_dir / (src.stem + ".o") for src in HIP_SOURCES]
+    stale = [(src, obj) for src, obj in zip(HIP_SOURCES, objs) if force or _stale(obj, [src] + HIP_HEADERS)]
+    with ThreadPoolExecutor(max_workers=max(len(stale), 1)) as pool:
+        list(pool.map(lambda so: _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c",
+                                       f"-I{INCLUDE}", f"-I{CSRC}", so[0], "-o", so[1]]), stale))
+    if stale or force or _stale(LIB_PATH, objs):
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-fPIC", "-shared", *objs, "-ldl", "-o", LIB_PATH])
     return LIB_PATH
 
 

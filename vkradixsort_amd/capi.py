@@ -28,9 +28,10 @@ VRS_KERNEL_SINGLE = 3
 VRS_KERNEL_DIGIT_TABLES = 4
 VRS_KERNEL_LOOKBACK_SCATTER = 5
 VRS_KERNEL_LOCAL_SORT = 6
-VRS_KERNEL_COUNT = 7
+VRS_KERNEL_POOL_SAMPLE = 7
+VRS_KERNEL_COUNT = 8
 KERNEL_NAMES = {0: "histogram", 1: "prefix", 2: "scatter", 3: "single", 4: "digit_tables", 5: "lookback_scatter",
-                6: "local_sort"}
+                6: "local_sort", 7: "pool_sample"}
 
 VRS_KEYS_INT32 = 0
 VRS_KEYS_FLOAT32_TO_SORTABLE = 1
@@ -54,6 +55,7 @@ VRS_TUNE_HYBRID_FAST_COUNT = 13
 VRS_TUNE_ASYNC_SORT = 14
 VRS_TUNE_PLAN_WAIT_MS = 15
 VRS_TUNE_MSD_RESERVE = 16
+VRS_TUNE_MSD_POOL = 17
 # keys the local sort of one top-14-bit bucket can hold (msd_local_capacity): uint32 keys with the 256- / 512-thread workgroup, pairs and 64-bit keys
 LOCAL_SORT_SMALL_KEYS, LOCAL_SORT_MAX_KEYS = 7165, 14333
 LOCAL_SORT_SMALL_PAIRS, LOCAL_SORT_MAX_PAIRS = 6656, 13312  # pairs and 64-bit keys: 512 / 1024-thread workgroups
@@ -155,6 +157,7 @@ _SIGNATURES = [
     ("vrs_one_call_relaunched_passes", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_one_call_hybrid_sorts", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_one_call_hybrid_recounts", c_int, [c_void_p, POINTER(c_uint64)]),
+    ("vrs_one_call_pool_sorts", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     ("vrs_debug_download_offsets", c_int, [c_void_p, c_void_p, c_size_t]),
     ("vrs_debug_atomic_rank_selftest", c_int, [c_void_p, c_uint32, c_uint32, POINTER(c_uint64)]),
     ("vrs_rank_mode", c_int, [c_void_p]),

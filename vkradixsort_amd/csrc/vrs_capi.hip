@@ -97,6 +97,13 @@ struct vrs_context_t {
     uint32_t os_plan_wait_ms = 60000;    // VRS_TUNE_PLAN_WAIT_MS: longest wait for a plan's head (0 = no limit)
     int os_reserve = 1;                  // VRS_TUNE_MSD_RESERVE: the MSD passes over bare keys reserve their output instead of looking back
                                          // (1 or 2: whenever the hybrid form runs on bare keys; 0: never)
+    // pool form (vrs_msd_pool.hip): the hybrid form of bare uint32 keys without the counting read
+    int os_pool = 1;                     // VRS_TUNE_MSD_POOL: 0 never, 1 (default) adaptive -- after a refusal the next 15 such sorts take the counted form --, 2 always tried
+    uint32_t os_pool_skip = 0;           // adaptive: hybrid-capable sorts of bare keys left before the pool form is tried again
+    vrs::PoolPlan *os_pool_plan = nullptr;
+    uint32_t *os_pool_overflow = nullptr;  // overflow regions of the first pass
+    uint32_t os_pool_overflow_cap = 0;     //   keys they hold
+    uint64_t os_pool_sorts = 0, os_pool_refusals = 0;
     bool os_cursors_open = false;        // a reserving pass may have run without the local sort that re-arms its counters behind it
                                          // (a refused plan, a partition with no finish, an error in between): cleared before the next use
     // a one-call sort between its two halves (see one_read_enqueue / one_read_complete)
@@ -111,6 +118,7 @@ struct vrs_context_t {
         uint32_t cur = 0, cur_at_start = 0;  // which of the two buffers holds the data (now / when the group started)
         uint32_t blind_passes = 0;
         bool msd_capable = false, fast_count = false, blind_tail = false, no_hybrid = false;
+        bool pool = false, no_pool = false;  // the pool form is on the stream / was refused for this sort
         size_t ev_lb_before = 0, ev_ls_before = 0;
         uint32_t key_base = 0;      // vrs_sort_keys_u32_ranged: every key is promised to be >= this (a multiple of 2^24)
         uint32_t bucket_hint = 0;   // blind tail: expected largest bucket (0 = from n); picks the local sort's workgroup shape
@@ -442,6 +450,8 @@ int vrs_context_destroy(vrs_context ctx) {
     if (ctx->os_plan) (void)hipFree(ctx->os_plan);
     if (ctx->os_status) (void)hipFree(ctx->os_status);
     if (ctx->os_host_head) (void)hipHostFree(ctx->os_host_head);
+    if (ctx->os_pool_plan) (void)hipFree(ctx->os_pool_plan);
+    if (ctx->os_pool_overflow) (void)hipFree(ctx->os_pool_overflow);
     if (ctx->os_msd_counts) (void)hipFree(ctx->os_msd_counts);
     if (ctx->os_msd_plan) (void)hipFree(ctx->os_msd_plan);
     if (ctx->os_plan_a) (void)hipFree(ctx->os_plan_a);
@@ -951,6 +961,26 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
     return VRS_OK;
 }
 
+// ---- pool form (vrs_msd_pool.hip): the hybrid form of bare uint32 keys without the counting read -- sample, first pass into
+// sampled regions (counting the buckets on the way), plan, second pass out of the regions, local sort: 24 bytes per key.
+// second pass + local sort: partner regions -> home, then the buckets in place
+static int one_read_pool_tail(vrs_context ctx, vrs_context_t::OneRead &st, uint32_t tiles_b, uint32_t max_bucket) {
+    const uint32_t home = st.cur_at_start;
+    vrs::LaunchEvents ev;
+    int rc;
+    if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, static_cast<const uint32_t *>(st.kptr[home ^ 1u]), ctx->os_pool_overflow,
+                                         static_cast<uint32_t *>(st.kptr[home]), ctx->os_msd_plan, ctx->os_pool_plan, tiles_b,
+                                         ctx->xcc_map, st.key_base, ev));
+    if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(st.kptr[home]), nullptr, ctx->os_msd_plan, max_bucket, ev,
+                                            nullptr, 0));
+    ctx->os_cursors_open = false;  // the local sort re-arms the reservation counters (a refusal is handled by one_read_complete)
+    return VRS_OK;
+}
+
+static int one_read_enqueue_pool(vrs_context ctx, const struct OneReadGeometry &g);
+
 static int one_read_enqueue(vrs_context ctx) {
     vrs_context_t::OneRead &st = ctx->one_read;
     const uint32_t n = st.n;
@@ -984,9 +1014,18 @@ static int one_read_enqueue(vrs_context ctx) {
                                            (ctx->os_fast_count == 1 && ctx->os_fast_count_armed[pairs ? 1 : 0]));
     }
     const bool msd = st.msd_capable && st.group == 0;
+    if (st.group == 0) {
+        // Pool form: bare uint32 keys the hybrid form may take skip the counting read altogether.  A refusal (a sample that
+        // misjudged a region, a key range the probe missed, a bucket above the local sort's capacity) costs the first pass, so
+        // the default is adaptive: after one, the next 15 such sorts of the context take the counted form.
+        const bool candidate = st.msd_capable && !pairs && !wide && !st.no_pool && ctx->os_pool != 0 && reserves(ctx, n, false);
+        st.pool = candidate && (ctx->os_pool == 2 || ctx->os_pool_skip == 0);
+        if (candidate && !st.pool) --ctx->os_pool_skip;
+    }
     const OneReadGeometry g = one_read_geometry(ctx, st);
     int rc = one_read_scratch(ctx, st, g);
     if (rc) return rc;
+    if (msd && st.pool) return one_read_enqueue_pool(ctx, g);
     vrs::LaunchEvents ev;
     // the digit tables must be all zero when a counting read starts; plan_kernel leaves them so.  Should anything fail
     // between the two launches, re-arm them for the next sort.
@@ -1060,6 +1099,67 @@ static int one_read_enqueue(vrs_context ctx) {
     return VRS_OK;
 }
 
+static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
+    vrs_context_t::OneRead &st = ctx->one_read;
+    const uint32_t n = st.n;
+    int rc;
+    const uint32_t room = vrs::pool_overflow_capacity(n);
+    if (!ctx->os_pool_plan) {
+        vrs::PoolPlan *pp = nullptr;
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&pp), sizeof(vrs::PoolPlan)));
+        const hipError_t e = hipMemsetAsync(pp, 0, sizeof(vrs::PoolPlan), ctx->stream);  // sample counts, ticket, fail: zero between sorts
+        if (e != hipSuccess) {
+            (void)hipFree(pp);
+            return fail_hip(ctx, "pool plan allocation", e);
+        }
+        ctx->os_pool_plan = pp;
+    }
+    if (room > ctx->os_pool_overflow_cap) {
+        if (ctx->os_pool_overflow) {
+            VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            VRS_HIP(ctx, hipFree(ctx->os_pool_overflow));
+            ctx->os_pool_overflow = nullptr;
+            ctx->os_pool_overflow_cap = 0;
+        }
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_overflow), static_cast<size_t>(room) * sizeof(uint32_t)));
+        ctx->os_pool_overflow_cap = room;
+    }
+    if ((rc = reservation_begin(ctx))) return rc;
+    const vrs::PoolStreams ps = vrs::pool_streams(n);
+    const uint32_t c = st.cur;
+    vrs::LaunchEvents ev;
+    st.cur_at_start = c;
+    st.blind_passes = 0;
+    if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
+    st.stamp = ctx->os_stamp;
+    if ((rc = profile_events(ctx, VRS_KERNEL_POOL_SAMPLE, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_pool_sample(ctx->stream, static_cast<const uint32_t *>(st.kptr[c]), n, st.key_base, ps, ctx->os_pool_plan, room, ev));
+    st.ev_lb_before = ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER];
+    st.ev_ls_before = ctx->events_used[VRS_KERNEL_LOCAL_SORT];
+    // the bucket histogram (zero between sorts) is filled by the first pass; should anything fail before the plan kernel that
+    // zeroes it again is on the stream, re-arm it for the next sort
+    struct HistGuard {
+        vrs_context ctx;
+        bool armed = true;
+        ~HistGuard() {
+            if (armed) (void)hipMemsetAsync(ctx->os_msd_counts, 0, vrs::kMsdCountWords * sizeof(uint32_t), ctx->stream);
+        }
+    } guard{ctx};
+    if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_pool_pass_a(ctx->stream, static_cast<const uint32_t *>(st.kptr[c]), static_cast<uint32_t *>(st.kptr[c ^ 1u]),
+                                         ctx->os_pool_overflow, n, st.key_base, ps, ctx->os_pool_plan, ctx->os_msd_plan, ctx->os_msd_counts,
+                                         ctx->xcc_map, ctx->scatter.compute_units, ctx->os_misplace, room, ev));
+    const uint32_t tiles_b_cap = vrs::pool_tiles_b_cap(n, st.blind_tail);
+    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_pool_plan, &ctx->os_plan->head,
+                                       ctx->os_host_head_dev, st.stamp, n, tiles_b_cap, g.local_cap, nullptr));
+    guard.armed = false;
+    // async mode: the rest of the form as well, with grids sized for the worst plan the form accepts (MsdPlan::ok == 0 makes
+    // their workgroups leave at once)
+    if (st.blind_tail && (rc = one_read_pool_tail(ctx, st, tiles_b_cap, g.local_cap))) return rc;
+    st.active = true;
+    return VRS_OK;
+}
+
 // the plan's head has arrived: finish the group; *done = the whole sort is on the stream
 static int one_read_complete(vrs_context ctx, bool *done) {
     vrs_context_t::OneRead &st = ctx->one_read;
@@ -1083,6 +1183,28 @@ static int one_read_complete(vrs_context ctx, bool *done) {
         *done = true;
         return VRS_OK;
     };
+    if (msd && st.pool) {
+        if (head.msd_ok) {  // the first pass is running (keys -> the partner's regions); second pass back, then the buckets in place
+            if (!st.blind_tail && (rc = one_read_pool_tail(ctx, st, head.msd_tiles_b, head.msd_max_bucket))) return rc;
+            st.cur = st.cur_at_start;
+            ctx->os_hybrid_sorts++;
+            ctx->os_pool_sorts++;
+            return finish();
+        }
+        // Refused: no key of the caller's buffer has moved (the first pass wrote the partner and the overflow scratch only).
+        // A blind tail left at once: hand its events back (the first pass did run: its time stays on the books).  The
+        // reservation counters hold what the first pass reserved and no local sort re-armed them.
+        if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = st.ev_lb_before + 1;
+        if (timed_ls) ctx->events_used[VRS_KERNEL_LOCAL_SORT] = st.ev_ls_before;
+        ctx->os_cursors_open = true;
+        ctx->os_pool_refusals++;
+        if (ctx->os_pool == 1) ctx->os_pool_skip = 15;
+        st.no_pool = true;
+        st.pool = false;
+        st.group = 0;
+        st.cur = st.cur_at_start;
+        return one_read_enqueue(ctx);
+    }
     if (msd && !head.msd_ok && head.lsd_missing) {
         // fast count, and the plan refused the hybrid form: every speculative launch left at once, no key has moved.
         // Start over as an LSD sort (its own counting read).
@@ -1672,6 +1794,13 @@ int vrs_one_call_hybrid_recounts(vrs_context ctx, uint64_t *recounts) {
     return VRS_OK;
 }
 
+int vrs_one_call_pool_sorts(vrs_context ctx, uint64_t *pool_sorts, uint64_t *pool_refusals) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (pool_sorts) *pool_sorts = ctx->os_pool_sorts;
+    if (pool_refusals) *pool_refusals = ctx->os_pool_refusals;
+    return VRS_OK;
+}
+
 int vrs_rank_mode(vrs_context ctx) { return ctx && ctx->scatter.atomic_rank ? 2 : 1; }
 
 int vrs_set_tuning(vrs_context ctx, int key, int value) {
@@ -1747,6 +1876,11 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
         case VRS_TUNE_MSD_RESERVE:
             if (value < 0 || value > 2) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "MSD reservation must be 0 (never) or 1 / 2 (bare keys of the hybrid form)");
             ctx->os_reserve = value;
+            return VRS_OK;
+        case VRS_TUNE_MSD_POOL:
+            if (value < 0 || value > 2) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form must be 0 (never), 1 (adaptive) or 2 (always tried)");
+            ctx->os_pool = value;
+            ctx->os_pool_skip = 0;
             return VRS_OK;
         case VRS_TUNE_DIGIT_TABLE_GROUPS:
             if (value != 0 && value != 8 && value != 16 && value != 32)

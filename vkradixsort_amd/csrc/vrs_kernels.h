@@ -239,6 +239,56 @@ uint32_t msd_local_capacity_wave();   // bare uint32 keys, one wave per bucket: 
 uint32_t msd_local_capacity(bool pairs_or_wide);  // pairs and 64-bit keys: 13312, uint32 keys: 14333
 uint32_t msd_local_capacity_pairs_small();         // pairs and 64-bit keys, 512-thread workgroup (two per CU): 6656
 
+// ---- hybrid form WITHOUT a counting read ("pool" form, vrs_msd_pool.hip; bare uint32 keys): 24 instead of 28 bytes per key.
+// The counting read exists to tell the first MSD pass where every top byte's keys go.  Here a SAMPLE of the input (the first
+// 256 keys of every 8192-key tile, 1/32 of it) sizes a region of the partner buffer for every (input slice, top byte) plus a
+// few standard deviations of overflow room in context scratch; the first pass reserves its output in those regions (one
+// L2-local atomic per tile and top byte) and counts the 16384 buckets on the way (packed 16-bit LDS counters, flushed once per
+// workgroup); a plan kernel then knows every bucket's exact size, the second pass gathers its input from the regions and
+// writes every bucket to its final place, the local sort is the counted form's.  A region that overflows its room, a key
+// outside the sampled range or a bucket above the local sort's capacity make the plan refuse (MsdPlan::ok == 0): no key of
+// the caller's buffer has moved by then, and the sort starts over in the counted form.
+constexpr uint32_t kPoolTile = 8192;           // keys per tile of both passes
+constexpr uint32_t kPoolSampleKeys = 256;      // leading keys of every tile the sample kernel counts
+constexpr uint32_t kPoolSampleTiles = 32;      // tiles per workgroup of the sample kernel
+struct PoolStreams {                           // the eight slices of the input the first pass walks (whole tiles), by value
+    uint32_t start[8], len[8], sampled[8];     // first key, keys, keys the sample kernel counts
+    uint32_t tiles_per_stream, tiles_total;
+};
+struct PoolPlan {
+    uint32_t shift;             // bucket = (key - key_base) >> shift: the top 14 bits of the probed key range
+    uint32_t armed;             // 1 = the sample kernel laid the regions out: the first pass runs
+    uint32_t fail;              // first pass: a region overflowed / a key outside the probed range / a CU behind no known L2 (zero between sorts)
+    uint32_t ticket;            // sample kernel: workgroups done (zero between launches)
+    uint32_t sample[8][256];    // sampled keys of (slice, top byte), zero between sorts
+    uint32_t base[8][256];      // primary region of (slice, top byte): first slot in the partner buffer
+    uint32_t cap[8][256];       //   its slots
+    uint32_t obase[8][256];     // overflow region: first slot in the overflow scratch
+    uint32_t ocap[8][256];
+    uint32_t tiles_b[8][260];   // second pass: XCD x walks entries e = 8 k + s (top byte x + 8 k, slice s): exclusive prefix of their tile counts, [256] = all
+};
+PoolStreams pool_streams(uint32_t n);
+uint32_t pool_overflow_capacity(uint32_t n);   // keys of overflow scratch a sort of n keys may use
+hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
+                              PoolPlan *pool, uint32_t overflow_capacity, LaunchEvents ev = {});
+// keys_out: the partner buffer (n slots); overflow: pool_overflow_capacity(n) slots; hist: the 16384-bin bucket histogram (zero
+// when the pass starts); cursors: MsdPlan::cursor_a (zero when the pass starts); misplace: test hook, odd rows of workgroups walk the neighbouring slice
+hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, uint32_t *overflow, uint32_t n,
+                              uint32_t key_base, const PoolStreams &ps, PoolPlan *pool, MsdPlan *msd, uint32_t *hist,
+                              unsigned long long xcc_map, int compute_units, bool misplace, uint32_t overflow_capacity,
+                              LaunchEvents ev = {});
+// ONE workgroup, after the first pass: bucket offsets, the second pass's tile tables, the verdict (MsdPlan::ok), the host head
+// (msd_ok, msd_tiles_b, msd_max_bucket, lsd_missing = 1) stamped last; leaves hist zeroed and PoolPlan::fail re-armed
+hipError_t launch_pool_plan(hipStream_t stream, uint32_t *hist, MsdPlan *msd, PoolPlan *pool, OnesweepPlanHead *dev_head,
+                            OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tiles_b_cap, uint32_t local_cap,
+                            uint32_t *host_log);
+// second pass: grid of 8 * tiles_b workgroups (tiles_b >= the plan's msd_tiles_b); regions -> keys_out, every bucket in place
+hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *keys_out,
+                              MsdPlan *msd, const PoolPlan *pool, uint32_t tiles_b, unsigned long long xcc_map, uint32_t key_base,
+                              LaunchEvents ev = {});
+// rows of workgroups the second pass may need for n keys: every (top byte, slice) share ends in a partial tile
+uint32_t pool_tiles_b_cap(uint32_t n, bool blind);
+
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups
 hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks);
 
