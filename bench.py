@@ -41,15 +41,29 @@ def mt19937_keys(seed: int, n: int) -> np.ndarray:
     return np.random.RandomState(seed).randint(0, 2 ** 32, size=n, dtype=np.uint32)
 
 
-def load_traffic_profile(kernel: str = "scatter"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), if present."""
+def load_traffic_profile(kernel: str = "scatter", algorithmic_bytes: float = 0.0):
+    """HBM bytes per launch of the dominant kernel(s) from the committed rocprofv3 --pmc passes (profiles/), if present:
+    (bytes per launch of the first dominant kernel or None, detail).  A figure below half the algorithmic bytes cannot be a
+    pass over the keys (round 3 committed the 15 KiB of a launch that left at once): refused, with a note."""
     p = ROOT / "profiles" / f"{kernel}_traffic.json"
     if not p.exists():
-        return None
+        return None, {"note": f"profiles/{kernel}_traffic.json is absent"}
     try:
-        return json.loads(p.read_text()).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+        rec = json.loads(p.read_text())
+    except Exception as e:  # noqa: BLE001
+        return None, {"note": f"profiles/{kernel}_traffic.json is unreadable: {e}"}
+    passes = rec.get("passes") or [rec]
+    detail = {"round": rec.get("round"), "passes": []}
+    for q in passes:
+        b = q.get("hbm_bytes_per_launch")
+        ratio = (b / algorithmic_bytes) if (b and algorithmic_bytes) else None
+        detail["passes"].append({"kernel": q.get("instantiation", q.get("kernel")), "hbm_bytes_per_launch": b, "dispatches": q.get("dispatches"),
+                                 "ratio_to_algorithmic": round(ratio, 3) if ratio else None})
+    first = detail["passes"][0]["hbm_bytes_per_launch"] if detail["passes"] else None
+    if algorithmic_bytes and any((q["hbm_bytes_per_launch"] or 0) < 0.5 * algorithmic_bytes for q in detail["passes"]):
+        detail["note"] = "refused: a committed figure is below half the algorithmic bytes per launch -- not a pass over the keys"
+        return None, detail
+    return first, detail
 
 
 def cpu_baseline(host_keys):
@@ -266,6 +280,7 @@ def bench_single(args):
     bytes_per_key_sort = {"one_call": BYTES_PER_KEY_SORT_HYBRID if (hybrid or other_hybrid) else BYTES_PER_KEY_SORT_ONE_READ,
                           "contract": BYTES_PER_KEY_SORT}
     dom_us = kernels.get(dominant_name, {}).get("avg_us")
+    traffic, traffic_detail = load_traffic_profile(dominant_name, BYTES_PER_KEY_SCATTER * n) if n == 10 ** 8 else (None, {"note": "committed for N = 10^8 only"})
     achieved = (BYTES_PER_KEY_SCATTER * n / (dom_us * 1e-6) / 1e9) if dom_us else None
     value = n * K / elapsed / 1e9
     sort_bytes = bytes_per_key_sort[args.path] * n
@@ -298,7 +313,7 @@ def bench_single(args):
                      "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                      "algorithmic_bytes_per_launch": BYTES_PER_KEY_SCATTER * n, "avg_launch_us": dom_us,
-                     "traffic": load_traffic_profile(dominant_name) if n == 10 ** 8 else None,
+                     "traffic": traffic, "traffic_detail": traffic_detail,
                      "traffic_source": f"profiles/{dominant_name}_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                        "this command at N = 10^8 in an earlier run (counters cannot be read from inside this run)",
                      "measured_d2d_copy_GBps": round(copy_gbps, 1),
@@ -449,7 +464,7 @@ def bench_pairs(args):
         "roofline": {"bound": "hbm", "kernel": "lookback_scatter with payloads (reads and writes every key and payload once per launch)",
                      "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "algorithmic_bytes_per_launch": 16 * n,
-                     "avg_launch_us": dom_us, "traffic": load_traffic_profile("lookback_scatter_pairs") if n == 10 ** 8 else None,
+                     "avg_launch_us": dom_us, "traffic": load_traffic_profile("lookback_scatter_pairs", 16.0 * n)[0] if n == 10 ** 8 else None,
                      "traffic_source": "profiles/lookback_scatter_pairs_traffic.json (rocprofv3 --pmc passes of an earlier run of this command)"},
         "sort_roofline": {"algorithmic_bytes": bpp * n, "bytes_per_key": bpp, "achieved_GBps": round(bpp * n * K / elapsed / 1e9, 1),
                           "frac_of_peak": round(bpp * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4)},

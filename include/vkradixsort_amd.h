@@ -462,13 +462,14 @@ typedef enum vrs_tuning_key {
                                       add per tile and digit instead of a decoupled look-back (the order inside a bucket is free there;
                                       payloads always take the stable look-back).  1 (default; 2 means the same): on; 0: look-back
                                       everywhere */
-    VRS_TUNE_MSD_POOL = 17         /* the hybrid form of BARE uint32 keys without its counting read (24 instead of 28 bytes per key): a sample of
+    VRS_TUNE_MSD_POOL = 17,        /* the hybrid form of BARE uint32 keys without its counting read (24 instead of 28 bytes per key): a sample of
                                       1/32 of the keys sizes a region of the partner buffer per (input slice, top byte), the first MSD
-                                      pass reserves its output there and counts the 16384 buckets on the way, the second pass reads the
-                                      regions.  A sort the plan refuses (a region the sample misjudged, a bucket too large) starts over in
-                                      the counted form with its input untouched.  1 (default) = adaptive: after a refusal the next 15
+                                      pass reserves its output there, the second pass groups every tile by the next 6 bits in place, the
+                                      local sort gathers every bucket's runs.  A sort a verdict refuses (a region the sample misjudged, a
+                                      bucket too large) starts over in the counted form with its input untouched.  1 (default) = adaptive: after a refusal the next 15
                                       such sorts of the context take the counted form; 2 = always tried; 0 = never.  Needs
                                       VRS_TUNE_MSD_RESERVE != 0. */
+    VRS_TUNE_MSD_POOL_MIN_KEYS = 18 /* the pool form is considered from this many keys on (default 3.2 * 10^7; never below 2^22) */
 } vrs_tuning_key;
 int vrs_set_tuning(vrs_context ctx, int key, int value);
 

@@ -1,0 +1,63 @@
+"""CPU tests of the measurement tooling: tools/profile_summary.py picks the instantiation that actually passed over the keys
+(round 3 committed the 15 KiB of a speculative launch the plan disarmed), bench.py refuses a figure that cannot be a pass."""
+import importlib.util
+import json
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _write_pmc(root, sub, counter, rows):
+    d = root / sub / "x"
+    d.mkdir(parents=True)
+    lines = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+    for disp, kernel, value in rows:
+        lines.append(f'{disp},"{kernel}",{counter},{value}')
+    (d / "p_counter_collection.csv").write_text("\n".join(lines) + "\n")
+
+
+def test_profile_summary_picks_the_instantiation_that_moved_the_bytes(tmp_path):
+    ps = _load(ROOT / "tools" / "profile_summary.py", "profile_summary")
+    armed = "void vrs::onesweep_scatter_kernel<unsigned int, 16, 8, false, 1, 4, true>(unsigned int const*, unsigned int*)"
+    disarmed = "void vrs::onesweep_scatter_kernel<unsigned int, 16, 8, false, 1, 4, false>(unsigned int const*, unsigned int*)"
+    pass_b = "void vrs::msd_pass_b_kernel<unsigned int, 16, 1, false, true>(unsigned int const*)"
+    pool_a = "vrs::(anonymous namespace)::pool_pass_a_kernel(unsigned int const*, unsigned int*)"
+    # FETCH_SIZE in KiB units, reported at half the bytes (x2 correction); ten armed launches of 400 MB, one disarmed of 15 KiB
+    fetch = [(i, armed, 195312.5) for i in range(10)] + [(100, disarmed, 7.5)] + [(200 + i, pass_b, 195312.5) for i in range(10)]
+    write = [(i, armed, 390625.0) for i in range(10)] + [(100, disarmed, 0.0)] + [(200 + i, pass_b, 390625.0) for i in range(10)]
+    _write_pmc(tmp_path, "pmc_fetch", "FETCH_SIZE", fetch)
+    _write_pmc(tmp_path, "pmc_write", "WRITE_SIZE", write)
+    rows = ps.traffic_rows(ps.counter_per_dispatch("pmc_fetch", "FETCH_SIZE", root=tmp_path),
+                           ps.counter_per_dispatch("pmc_write", "WRITE_SIZE", root=tmp_path))
+    files = ps.dominant_records(rows)
+    rec = files["lookback_scatter_traffic.json"]
+    assert rec["instantiation"].endswith("4, true>") and rec["dispatches"] == 10
+    assert abs(rec["hbm_bytes_per_launch"] - 8.0e8) < 1e3
+    assert [q["instantiation"].split("<")[0].split("::")[-1] for q in rec["passes"]] == ["onesweep_scatter_kernel", "msd_pass_b_kernel"]
+    # kernels in an unnamed namespace keep their names
+    assert ps.short(pool_a) == "vrs::pool_pass_a_kernel"
+
+
+def test_bench_refuses_a_traffic_figure_that_is_no_pass_over_the_keys(tmp_path, monkeypatch):
+    bench = _load(ROOT / "bench.py", "bench_under_test")
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    (prof / "lookback_scatter_traffic.json").write_text(json.dumps({"kernel": "onesweep_scatter_kernel", "hbm_bytes_per_launch": 30720.0}))
+    value, detail = bench.load_traffic_profile("lookback_scatter", 8.0e8)
+    assert value is None and "refused" in detail["note"]
+    (prof / "lookback_scatter_traffic.json").write_text(json.dumps({
+        "kernel": "x", "hbm_bytes_per_launch": 8.19e8, "instantiation": "a",
+        "passes": [{"instantiation": "a", "hbm_bytes_per_launch": 8.19e8, "dispatches": 10},
+                   {"instantiation": "b", "hbm_bytes_per_launch": 8.06e8, "dispatches": 10}]}))
+    value, detail = bench.load_traffic_profile("lookback_scatter", 8.0e8)
+    assert value == 8.19e8 and [q["ratio_to_algorithmic"] for q in detail["passes"]] == [1.024, 1.008]
+    value, detail = bench.load_traffic_profile("absent_kernel", 8.0e8)
+    assert value is None and "absent" in detail["note"]

@@ -28,29 +28,40 @@ __global__ void xcc_probe(uint32_t *out) {
     if (threadIdx.x == 0) out[blockIdx.x] = vrs::xcc_id();
 }
 
+__global__ void check_sorted(const uint32_t *k, uint32_t n, unsigned long long *out) {
+    unsigned long long bad = 0, sum = 0;
+    for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        if (i + 1 < n && k[i] > k[i + 1]) ++bad;
+        sum += k[i];
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], sum);
+}
+
 int main(int argc, char **argv) {
     const uint32_t n = argc > 1 ? static_cast<uint32_t>(atof(argv[1])) : 100000000u;
     const int reps = argc > 2 ? atoi(argv[2]) : 6;
     hipStream_t st;
     CK(hipStreamCreate(&st));
-    uint32_t *keys[4], *partner, *home, *ovf, *hist, *xo;
+    uint32_t *keys[4], *partner, *ovf, *rows, *xo;
     vrs::PoolPlan *pool;
+    vrs::PoolRun *runs;
     vrs::MsdPlan *msd;
     vrs::OnesweepPlanHead *head;
+    unsigned long long *chk;
     const uint32_t room = vrs::pool_overflow_capacity(n);
     for (auto &k : keys) CK(hipMalloc(&k, 4ull * n));
     CK(hipMalloc(&partner, 4ull * n));
-    CK(hipMalloc(&home, 4ull * n));
     CK(hipMalloc(&ovf, 4ull * room));
-    CK(hipMalloc(&hist, 4ull * vrs::kMsdCountWords));
+    CK(hipMalloc(&rows, vrs::pool_rows_bytes(n)));
+    CK(hipMalloc(&runs, vrs::kPoolRunBytes));
     CK(hipMalloc(&pool, sizeof(vrs::PoolPlan)));
     CK(hipMalloc(&msd, sizeof(vrs::MsdPlan)));
     CK(hipMalloc(&head, sizeof(vrs::OnesweepPlanHead)));
     CK(hipMalloc(&xo, 4 * 64));
-    CK(hipMemset(hist, 0, 4ull * vrs::kMsdCountWords));
+    CK(hipMalloc(&chk, 32));
     CK(hipMemset(pool, 0, sizeof(vrs::PoolPlan)));
     CK(hipMemset(msd, 0, sizeof(vrs::MsdPlan)));
-    for (int b = 0; b < 4; ++b) hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, st, keys[b], n, 12345u + b);
     hipLaunchKernelGGL(xcc_probe, dim3(64), dim3(512), 0, st, xo);
     uint32_t hx[64];
     CK(hipMemcpyAsync(hx, xo, sizeof hx, hipMemcpyDeviceToHost, st));
@@ -58,60 +69,50 @@ int main(int argc, char **argv) {
     unsigned long long xcc_map = 0;
     for (int b = 0; b < 8; ++b) xcc_map |= static_cast<unsigned long long>(hx[b] & 0xFF) << (8 * b);
     const vrs::PoolStreams ps = vrs::pool_streams(n);
-#ifdef VRS_POOL_LAB_MARKS
-    {
-        unsigned long long *dm;
-        CK(hipMalloc(&dm, 8ull * 12 * 8 * 64));
-        CK(hipMemset(dm, 0, 8ull * 12 * 8 * 64));
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(vrs::g_pool_marks), &dm, sizeof dm));
-    }
-#endif
-    hipEvent_t ev[6];
+    hipEvent_t ev[8];
     for (auto &e : ev) CK(hipEventCreate(&e));
-    const uint32_t tiles_b_cap = vrs::pool_tiles_b_cap(n, false);
-    double sum[5] = {0, 0, 0, 0, 0};
+    const uint32_t tiles_b = vrs::pool_tiles_b_cap(n);
+    const bool big = static_cast<uint64_t>(n) * 11u / 10u / vrs::kMsdBucketCount + 64u > vrs::pool_local_capacity(false);
+    double sum[7] = {0, 0, 0, 0, 0, 0, 0};
     int counted = 0;
     for (int r = 0; r < reps + 2; ++r) {
-        const uint32_t *in = keys[r % 4];
+        uint32_t *in = keys[r % 4];
+        hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, st, in, n, 12345u + r);
+        CK(hipMemsetAsync(chk, 0, 32, st));
+        hipLaunchKernelGGL(check_sorted, dim3(2048), dim3(256), 0, st, in, n, chk + 2);  // chk[3] = key sum of the input
         CK(hipMemsetAsync(reinterpret_cast<char *>(msd) + offsetof(vrs::MsdPlan, cursor_a), 0, vrs::kMsdCursorBytes, st));
         CK(hipEventRecord(ev[0], st));
         CK(vrs::launch_pool_sample(st, in, n, 0, ps, pool, room));
         CK(hipEventRecord(ev[1], st));
-        CK(vrs::launch_pool_pass_a(st, in, partner, ovf, n, 0, ps, pool, msd, hist, xcc_map, 256, false, room));
+        CK(vrs::launch_pool_pass_a(st, in, partner, ovf, n, 0, ps, pool, msd, xcc_map, false, room));
         CK(hipEventRecord(ev[2], st));
-        CK(vrs::launch_pool_plan(st, hist, msd, pool, head, nullptr, 1, n, tiles_b_cap, 14333, nullptr));
+        CK(vrs::launch_pool_plan(st, msd, pool, n, tiles_b));
         CK(hipEventRecord(ev[3], st));
-        CK(vrs::launch_pool_pass_b(st, partner, ovf, home, msd, pool, tiles_b_cap, xcc_map, 0));
+        CK(vrs::launch_pool_pass_b(st, partner, ovf, n, msd, pool, rows, tiles_b, 0));
         CK(hipEventRecord(ev[4], st));
+        CK(vrs::launch_pool_runs(st, msd, pool, rows, runs, n));
+        CK(hipEventRecord(ev[5], st));
+        CK(vrs::launch_pool_local_sort(st, partner, ovf, in, n, msd, pool, runs, big, head, nullptr, 1));
+        CK(hipEventRecord(ev[6], st));
+        hipLaunchKernelGGL(check_sorted, dim3(2048), dim3(256), 0, st, in, n, chk);
         CK(hipStreamSynchronize(st));
         vrs::MsdPlan hm;
+        vrs::PoolPlan hp;
+        unsigned long long hc[4];
         CK(hipMemcpy(&hm, msd, 16, hipMemcpyDeviceToHost));
-        float t[4];
-        for (int i = 0; i < 4; ++i) CK(hipEventElapsedTime(&t[i], ev[i], ev[i + 1]));
-        std::printf("rep %d: sample %.1f  passA %.1f  plan %.1f  passB %.1f us   ok=%u shift=%u\n", r, t[0] * 1e3, t[1] * 1e3, t[2] * 1e3, t[3] * 1e3, hm.ok, hm.shift);
+        CK(hipMemcpy(&hp, pool, 32, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hc, chk, 32, hipMemcpyDeviceToHost));
+        float t[6];
+        for (int i = 0; i < 6; ++i) CK(hipEventElapsedTime(&t[i], ev[i], ev[i + 1]));
+        std::printf("rep %d: sample %.1f  passA %.1f  plan %.1f  passB %.1f  runs %.1f  local %.1f us   ok_a=%u ok=%u shift=%u  descents=%llu sum %s\n", r, t[0] * 1e3,
+                    t[1] * 1e3, t[2] * 1e3, t[3] * 1e3, t[4] * 1e3, t[5] * 1e3, hp.ok_a, hm.ok, hm.shift, hc[0], hc[1] == hc[3] ? "same" : "DIFFERENT");
         if (r >= 2) {
-            for (int i = 0; i < 4; ++i) sum[i] += t[i] * 1e3;
+            for (int i = 0; i < 6; ++i) sum[i] += t[i] * 1e3;
             ++counted;
         }
     }
-#ifdef VRS_POOL_LAB_MARKS
-    {
-        const uint32_t wgs = 8u * std::min<uint32_t>(64u, ps.tiles_per_stream);
-        std::vector<unsigned long long> m(static_cast<size_t>(wgs) * 12);
-        unsigned long long *dm;
-        CK(hipMemcpyFromSymbol(&dm, HIP_SYMBOL(vrs::g_pool_marks), sizeof dm));
-        CK(hipMemcpy(m.data(), dm, m.size() * 8, hipMemcpyDeviceToHost));
-        double s[12] = {};
-        for (uint32_t w = 0; w < wgs; ++w)
-            for (int k = 0; k < 12; ++k) s[k] += static_cast<double>(m[static_cast<size_t>(w) * 12 + k]);
-        const char *nm[12] = {"prev-end->start", "zero+B1", "rank issue", "B2 wait", "scan+atomic+prefetch", "B4 wait", "rebucket+gbase", "B5 wait", "writeout issue", "loop end->flush", "flush", "-"};
-        double tot = 0;
-        for (int k = 0; k < 11; ++k) tot += s[k];
-        for (int k = 0; k < 11; ++k) std::printf("   mark %2d %-22s %10.0f ticks per workgroup  %5.1f %%\n", k, nm[k], s[k] / wgs, 100.0 * s[k] / tot);
-        std::printf("   total %.0f ticks per workgroup\n", tot / wgs);
-    }
-#endif
-    std::printf("AVG n=%u: sample %.1f  passA %.1f  plan %.1f  passB %.1f us (events bracket each launch: +~2 us each)\n", n, sum[0] / counted, sum[1] / counted,
-                sum[2] / counted, sum[3] / counted);
+    std::printf("AVG n=%u: sample %.1f  passA %.1f  plan %.1f  passB %.1f  runs %.1f  local %.1f us (events bracket each launch: +~2 us each); total %.1f\n", n,
+                sum[0] / counted, sum[1] / counted, sum[2] / counted, sum[3] / counted, sum[4] / counted, sum[5] / counted,
+                (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5]) / counted);
     return 0;
 }

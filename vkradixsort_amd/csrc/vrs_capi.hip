@@ -103,7 +103,11 @@ struct vrs_context_t {
     vrs::PoolPlan *os_pool_plan = nullptr;
     uint32_t *os_pool_overflow = nullptr;  // overflow regions of the first pass
     uint32_t os_pool_overflow_cap = 0;     //   keys they hold
+    uint32_t *os_pool_rows = nullptr;      // the second pass's (offset, count) rows
+    size_t os_pool_rows_bytes = 0;
+    vrs::PoolRun *os_pool_runs = nullptr;  // run descriptors [top byte][run slot][bucket of the top byte]
     uint64_t os_pool_sorts = 0, os_pool_refusals = 0;
+    uint32_t os_pool_min_keys = 32000000u;  // VRS_TUNE_MSD_POOL_MIN_KEYS
     bool os_cursors_open = false;        // a reserving pass may have run without the local sort that re-arms its counters behind it
                                          // (a refused plan, a partition with no finish, an error in between): cleared before the next use
     // a one-call sort between its two halves (see one_read_enqueue / one_read_complete)
@@ -452,6 +456,8 @@ int vrs_context_destroy(vrs_context ctx) {
     if (ctx->os_host_head) (void)hipHostFree(ctx->os_host_head);
     if (ctx->os_pool_plan) (void)hipFree(ctx->os_pool_plan);
     if (ctx->os_pool_overflow) (void)hipFree(ctx->os_pool_overflow);
+    if (ctx->os_pool_rows) (void)hipFree(ctx->os_pool_rows);
+    if (ctx->os_pool_runs) (void)hipFree(ctx->os_pool_runs);
     if (ctx->os_msd_counts) (void)hipFree(ctx->os_msd_counts);
     if (ctx->os_msd_plan) (void)hipFree(ctx->os_msd_plan);
     if (ctx->os_plan_a) (void)hipFree(ctx->os_plan_a);
@@ -961,24 +967,7 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
     return VRS_OK;
 }
 
-// ---- pool form (vrs_msd_pool.hip): the hybrid form of bare uint32 keys without the counting read -- sample, first pass into
-// sampled regions (counting the buckets on the way), plan, second pass out of the regions, local sort: 24 bytes per key.
-// second pass + local sort: partner regions -> home, then the buckets in place
-static int one_read_pool_tail(vrs_context ctx, vrs_context_t::OneRead &st, uint32_t tiles_b, uint32_t max_bucket) {
-    const uint32_t home = st.cur_at_start;
-    vrs::LaunchEvents ev;
-    int rc;
-    if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
-    VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, static_cast<const uint32_t *>(st.kptr[home ^ 1u]), ctx->os_pool_overflow,
-                                         static_cast<uint32_t *>(st.kptr[home]), ctx->os_msd_plan, ctx->os_pool_plan, tiles_b,
-                                         ctx->xcc_map, st.key_base, ev));
-    if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
-    VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(st.kptr[home]), nullptr, ctx->os_msd_plan, max_bucket, ev,
-                                            nullptr, 0));
-    ctx->os_cursors_open = false;  // the local sort re-arms the reservation counters (a refusal is handled by one_read_complete)
-    return VRS_OK;
-}
-
+// ---- pool form (vrs_msd_pool.hip): the hybrid form of bare uint32 keys without the counting read: 24 bytes per key.
 static int one_read_enqueue_pool(vrs_context ctx, const struct OneReadGeometry &g);
 
 static int one_read_enqueue(vrs_context ctx) {
@@ -1018,7 +1007,10 @@ static int one_read_enqueue(vrs_context ctx) {
         // Pool form: bare uint32 keys the hybrid form may take skip the counting read altogether.  A refusal (a sample that
         // misjudged a region, a key range the probe missed, a bucket above the local sort's capacity) costs the first pass, so
         // the default is adaptive: after one, the next 15 such sorts of the context take the counted form.
-        const bool candidate = st.msd_capable && !pairs && !wide && !st.no_pool && ctx->os_pool != 0 && reserves(ctx, n, false);
+        // (sizes: the local sort gathers a bucket from at most 56 runs -- one per second-pass tile of its top byte, about
+        // n / 256 / 8192 + 8 -- and below 3.2e7 keys the counted form's one-wave-per-bucket local sort is the faster one)
+        const bool candidate = st.msd_capable && !pairs && !wide && !st.no_pool && ctx->os_pool != 0 && reserves(ctx, n, false) &&
+                               n >= ctx->os_pool_min_keys && (ctx->os_pool == 2 || n <= 115000000u);
         st.pool = candidate && (ctx->os_pool == 2 || ctx->os_pool_skip == 0);
         if (candidate && !st.pool) --ctx->os_pool_skip;
     }
@@ -1100,62 +1092,72 @@ static int one_read_enqueue(vrs_context ctx) {
 }
 
 static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
+    (void)g;
     vrs_context_t::OneRead &st = ctx->one_read;
     const uint32_t n = st.n;
     int rc;
     const uint32_t room = vrs::pool_overflow_capacity(n);
+    const size_t rows_bytes = vrs::pool_rows_bytes(n);
     if (!ctx->os_pool_plan) {
         vrs::PoolPlan *pp = nullptr;
-        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&pp), sizeof(vrs::PoolPlan)));
-        const hipError_t e = hipMemsetAsync(pp, 0, sizeof(vrs::PoolPlan), ctx->stream);  // sample counts, ticket, fail: zero between sorts
+        vrs::PoolRun *runs = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&pp), sizeof(vrs::PoolPlan));
+        if (e == hipSuccess) e = hipMemsetAsync(pp, 0, sizeof(vrs::PoolPlan), ctx->stream);  // sample counts, tickets, flags: zero between sorts
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&runs), vrs::kPoolRunBytes);
         if (e != hipSuccess) {
-            (void)hipFree(pp);
-            return fail_hip(ctx, "pool plan allocation", e);
+            if (runs) (void)hipFree(runs);
+            if (pp) (void)hipFree(pp);
+            return fail_hip(ctx, "pool form scratch allocation", e);
         }
         ctx->os_pool_plan = pp;
+        ctx->os_pool_runs = runs;
     }
-    if (room > ctx->os_pool_overflow_cap) {
-        if (ctx->os_pool_overflow) {
+    if (room > ctx->os_pool_overflow_cap || rows_bytes > ctx->os_pool_rows_bytes) {
+        if (ctx->os_pool_overflow || ctx->os_pool_rows) {
             VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            VRS_HIP(ctx, hipFree(ctx->os_pool_overflow));
+            if (ctx->os_pool_overflow) VRS_HIP(ctx, hipFree(ctx->os_pool_overflow));
+            if (ctx->os_pool_rows) VRS_HIP(ctx, hipFree(ctx->os_pool_rows));
             ctx->os_pool_overflow = nullptr;
+            ctx->os_pool_rows = nullptr;
             ctx->os_pool_overflow_cap = 0;
+            ctx->os_pool_rows_bytes = 0;
         }
         VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_overflow), static_cast<size_t>(room) * sizeof(uint32_t)));
         ctx->os_pool_overflow_cap = room;
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_rows), rows_bytes));
+        ctx->os_pool_rows_bytes = rows_bytes;
     }
-    if ((rc = reservation_begin(ctx))) return rc;
+    if ((rc = reservation_begin(ctx))) return rc;  // the first pass's cursors: zero
     const vrs::PoolStreams ps = vrs::pool_streams(n);
     const uint32_t c = st.cur;
+    uint32_t *home = static_cast<uint32_t *>(st.kptr[c]), *partner = static_cast<uint32_t *>(st.kptr[c ^ 1u]);
     vrs::LaunchEvents ev;
     st.cur_at_start = c;
     st.blind_passes = 0;
     if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
     st.stamp = ctx->os_stamp;
+    // Everything is enqueued here, before any verdict is known (the workgroups of what a verdict refuses leave at once): the
+    // second verdict falls only when the second pass has run, and a host that enqueued the local sort after it would leave the
+    // GPU idle for a round trip.  The local sort's shape is chosen from n alone (uniform keys: buckets of n / 16384 + a few per
+    // cent); a bucket above its capacity makes the second verdict refuse.
+    const bool big = static_cast<uint64_t>(n) * 11u / 10u / vrs::kMsdBucketCount + 64u > vrs::pool_local_capacity(false);
+    const uint32_t tiles_b = vrs::pool_tiles_b_cap(n);
     if ((rc = profile_events(ctx, VRS_KERNEL_POOL_SAMPLE, &ev))) return rc;
-    VRS_HIP(ctx, vrs::launch_pool_sample(ctx->stream, static_cast<const uint32_t *>(st.kptr[c]), n, st.key_base, ps, ctx->os_pool_plan, room, ev));
+    VRS_HIP(ctx, vrs::launch_pool_sample(ctx->stream, home, n, st.key_base, ps, ctx->os_pool_plan, room, ev));
     st.ev_lb_before = ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER];
     st.ev_ls_before = ctx->events_used[VRS_KERNEL_LOCAL_SORT];
-    // the bucket histogram (zero between sorts) is filled by the first pass; should anything fail before the plan kernel that
-    // zeroes it again is on the stream, re-arm it for the next sort
-    struct HistGuard {
-        vrs_context ctx;
-        bool armed = true;
-        ~HistGuard() {
-            if (armed) (void)hipMemsetAsync(ctx->os_msd_counts, 0, vrs::kMsdCountWords * sizeof(uint32_t), ctx->stream);
-        }
-    } guard{ctx};
     if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
-    VRS_HIP(ctx, vrs::launch_pool_pass_a(ctx->stream, static_cast<const uint32_t *>(st.kptr[c]), static_cast<uint32_t *>(st.kptr[c ^ 1u]),
-                                         ctx->os_pool_overflow, n, st.key_base, ps, ctx->os_pool_plan, ctx->os_msd_plan, ctx->os_msd_counts,
-                                         ctx->xcc_map, ctx->scatter.compute_units, ctx->os_misplace, room, ev));
-    const uint32_t tiles_b_cap = vrs::pool_tiles_b_cap(n, st.blind_tail);
-    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_pool_plan, &ctx->os_plan->head,
-                                       ctx->os_host_head_dev, st.stamp, n, tiles_b_cap, g.local_cap, nullptr));
-    guard.armed = false;
-    // async mode: the rest of the form as well, with grids sized for the worst plan the form accepts (MsdPlan::ok == 0 makes
-    // their workgroups leave at once)
-    if (st.blind_tail && (rc = one_read_pool_tail(ctx, st, tiles_b_cap, g.local_cap))) return rc;
+    VRS_HIP(ctx, vrs::launch_pool_pass_a(ctx->stream, home, partner, ctx->os_pool_overflow, n, st.key_base, ps, ctx->os_pool_plan, ctx->os_msd_plan,
+                                         ctx->xcc_map, ctx->os_misplace, room, ev));
+    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b));
+    if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, partner, ctx->os_pool_overflow, n, ctx->os_msd_plan, ctx->os_pool_plan, ctx->os_pool_rows, tiles_b,
+                                         st.key_base, ev));
+    VRS_HIP(ctx, vrs::launch_pool_runs(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, ctx->os_pool_rows, ctx->os_pool_runs, n));
+    if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, partner, ctx->os_pool_overflow, home, n, ctx->os_msd_plan, ctx->os_pool_plan, ctx->os_pool_runs,
+                                             big, &ctx->os_plan->head, ctx->os_host_head_dev, st.stamp, ev));
+    ctx->os_cursors_open = false;  // the local sort re-arms the reservation counters (a refusal is handled by one_read_complete)
     st.active = true;
     return VRS_OK;
 }
@@ -1184,17 +1186,15 @@ static int one_read_complete(vrs_context ctx, bool *done) {
         return VRS_OK;
     };
     if (msd && st.pool) {
-        if (head.msd_ok) {  // the first pass is running (keys -> the partner's regions); second pass back, then the buckets in place
-            if (!st.blind_tail && (rc = one_read_pool_tail(ctx, st, head.msd_tiles_b, head.msd_max_bucket))) return rc;
+        if (head.msd_ok) {  // both verdicts said yes: the whole form is on the stream, the result lands in the caller's buffer
             st.cur = st.cur_at_start;
             ctx->os_hybrid_sorts++;
             ctx->os_pool_sorts++;
             return finish();
         }
-        // Refused: no key of the caller's buffer has moved (the first pass wrote the partner and the overflow scratch only).
-        // A blind tail left at once: hand its events back (the first pass did run: its time stays on the books).  The
-        // reservation counters hold what the first pass reserved and no local sort re-armed them.
-        if (timed) ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER] = st.ev_lb_before + 1;
+        // Refused: no key of the caller's buffer has moved (the passes wrote the partner and the context's scratch only; the
+        // local sort left at once).  Hand the events of what left at once back (what ran stays on the books: the two
+        // passes).  The reservation counters hold what the first pass reserved and no local sort re-armed them.
         if (timed_ls) ctx->events_used[VRS_KERNEL_LOCAL_SORT] = st.ev_ls_before;
         ctx->os_cursors_open = true;
         ctx->os_pool_refusals++;
@@ -1284,7 +1284,14 @@ static int one_read_settle(vrs_context ctx) {
     } settling(ctx);
     while (ctx->one_read.active) {
         int rc = wait_for_plan(ctx, ctx->one_read.stamp);
-        if (rc) return rc;  // still pending: a later settle may succeed (VRS_ERROR_TIMEOUT)
+        if (rc == VRS_ERROR_TIMEOUT) return rc;  // still pending: a later settle may succeed
+        if (rc) {  // the plan never arrived / the stream faulted: nothing to resume, and the next sort must not find this one "pending"
+            ctx->one_read.active = false;
+            if (ctx->os_tables) (void)hipMemsetAsync(ctx->os_tables, 0, (vrs::kDigitTableWords + 64) * sizeof(uint32_t), ctx->stream);
+            if (ctx->os_msd_counts) (void)hipMemsetAsync(ctx->os_msd_counts, 0, vrs::kMsdCountWords * sizeof(uint32_t), ctx->stream);
+            ctx->os_cursors_open = true;
+            return rc;
+        }
         bool done = false;
         if ((rc = one_read_complete(ctx, &done))) {
             ctx->one_read.active = false;  // the sort failed half-way: nothing to resume
@@ -1423,10 +1430,12 @@ int vrs_msd_partition_signal_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer ou
     VRS_HIP(ctx, vrs::launch_msd_plan(ctx->stream, ctx->os_msd_counts, ctx->os_msd_plan, ctx->os_plan_a, ctx->os_plan,
                                       ctx->os_host_head_dev, ctx->os_stamp, n, g.T, g.tiles_b_cap, g.local_cap, ctx->os_tables,
                                       g.group_len, g.tile_cap, g.blind_cap, g.cuts0, 1u, 18u));
-    // the first MSD pass, whatever the plan thinks of this shard's buckets (forced: the streams, not their armed copies)
+    // the first MSD pass, whatever the plan thinks of this shard's buckets (forced: the streams, not their armed copies) -- but not
+    // without counts (2: a key range below 27 bits, or a key outside the probed range: the workgroups leave at once, `out` is not
+    // written, and the caller, who sees the shift and the flag in counts_out, takes another shape)
     if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, keys->ptr, out->ptr, nullptr, nullptr, ctx->os_plan_a, 0, vrs::kShiftFromPlan,
-                                              ctx->os_status, g.tiles0, true, ctx->scatter.atomic_rank, ctx->xcc_map, 4,
+                                              ctx->os_status, g.tiles0, 2, ctx->scatter.atomic_rank, ctx->xcc_map, 4,
                                               ctx->os_spin_budget, -1, ev, false, 0u, reserves(ctx, n, false) ? ctx->os_msd_plan : nullptr));
     return VRS_OK;
 }
@@ -1532,14 +1541,22 @@ int vrs_msd_finish_status_at(vrs_context ctx, uint32_t ticket, int *took) {
     if (!ctx || !took) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or took is NULL");
     *took = 0;
     if (ticket == 0 || !ctx->os_host_head) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "not a ticket of vrs_msd_finish_ticket");
-    // stamps count up by one per plan (0 skipped): the log keeps the last kMsdLogWords
-    if (ctx->os_stamp - ticket >= vrs::kMsdLogWords)
-        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "ticket too old: the log keeps the decisions of the last 32 plans");
+    // The log word of a ticket is (stamp % 32): only plans of vrs_msd_finish_* write the log, so the word keeps this ticket's
+    // decision until ANOTHER finish plan whose stamp is congruent to it is made -- however many plans of other kinds (partitions,
+    // ranged sorts, recounts) come in between.  The word itself says whose decision it holds.
     VRS_HIP(ctx, hipSetDevice(ctx->device));
     volatile uint32_t *word = reinterpret_cast<volatile uint32_t *>(ctx->os_host_head + 1) + (ticket & (vrs::kMsdLogWords - 1u));
     const uint32_t want = ticket << 1;
-    const int rc = wait_for_host_word(ctx, [&] { return (__atomic_load_n(word, __ATOMIC_ACQUIRE) & ~1u) == want; });
+    bool overwritten = false;
+    const int rc = wait_for_host_word(ctx, [&] {
+        const uint32_t w = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+        if ((w & ~1u) == want) return true;
+        // a later plan's decision in this word (stamps count up; a word that is zero or older has not been written yet)
+        overwritten = w != 0u && static_cast<int32_t>((w >> 1) - (ticket & 0x7FFFFFFFu)) > 0;
+        return overwritten;
+    });
     if (rc) return rc;
+    if (overwritten) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "ticket too old: a later vrs_msd_finish plan has taken its place in the log");
     *took = static_cast<int>(*word & 1u);
     return VRS_OK;
 }
@@ -1621,12 +1638,14 @@ int vrs_verify_keys_u32(vrs_context ctx, vrs_buffer keys, uint32_t num_elements,
 
 int vrs_profile_enable(vrs_context ctx, int enabled) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (const int settled = settle_pending(ctx)) return settled;  // a pending sort's second half counts its events under the mask its first half saw
     ctx->profile_mask = enabled ? (1u << VRS_KERNEL_COUNT) - 1u : 0u;
     return VRS_OK;
 }
 
 int vrs_profile_enable_mask(vrs_context ctx, uint32_t kernel_mask) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (const int settled = settle_pending(ctx)) return settled;
     ctx->profile_mask = kernel_mask & ((1u << VRS_KERNEL_COUNT) - 1u);
     return VRS_OK;
 }
@@ -1634,6 +1653,7 @@ int vrs_profile_enable_mask(vrs_context ctx, uint32_t kernel_mask) {
 int vrs_profile_reset(vrs_context ctx) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int settled = settle_pending(ctx)) return settled;  // (its second half rewinds event slots it remembered)
     VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (auto &u : ctx->events_used) u = 0;
     return VRS_OK;
@@ -1644,6 +1664,7 @@ int vrs_profile_query(vrs_context ctx, int kernel_id, uint64_t *launches, double
     if (kernel_id < 0 || kernel_id >= VRS_KERNEL_COUNT)
         return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "kernel_id out of range");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int settled = settle_pending(ctx)) return settled;
     VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double sum = 0.0;
     const size_t used = ctx->events_used[kernel_id];
@@ -1661,8 +1682,9 @@ int vrs_profile_query_launch(vrs_context ctx, int kernel_id, uint64_t index, dou
     if (!ctx || !ms) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or ms is NULL");
     if (kernel_id < 0 || kernel_id >= VRS_KERNEL_COUNT)
         return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "kernel_id out of range");
-    if (index >= ctx->events_used[kernel_id]) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "no such instrumented launch");
     VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int settled = settle_pending(ctx)) return settled;
+    if (index >= ctx->events_used[kernel_id]) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "no such instrumented launch");
     VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     float t = 0.f;
     VRS_HIP(ctx, hipEventElapsedTime(&t, ctx->events[kernel_id][index].start, ctx->events[kernel_id][index].stop));
@@ -1881,6 +1903,10 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             if (value < 0 || value > 2) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form must be 0 (never), 1 (adaptive) or 2 (always tried)");
             ctx->os_pool = value;
             ctx->os_pool_skip = 0;
+            return VRS_OK;
+        case VRS_TUNE_MSD_POOL_MIN_KEYS:
+            if (value < (1 << 22)) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form takes 2^22 keys or more");
+            ctx->os_pool_min_keys = static_cast<uint32_t>(value);
             return VRS_OK;
         case VRS_TUNE_DIGIT_TABLE_GROUPS:
             if (value != 0 && value != 8 && value != 16 && value != 32)

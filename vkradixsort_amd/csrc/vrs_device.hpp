@@ -252,6 +252,7 @@ __device__ __forceinline__ void lb_store_l2(uint32_t *p, uint32_t v) {
 
 struct NoLookback {
     static constexpr bool kEnabled = false;
+    static constexpr bool kPool = false;
 };
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3u << 11) | 20u); }  // HW_REG_XCC_ID[3:0]
 
@@ -270,6 +271,7 @@ struct StreamLookback {
     uint32_t done = 0;        // keys of the stream before this tile
 
     static constexpr bool kReserves = false;
+    static constexpr bool kPool = false;
     __device__ __forceinline__ void publish(uint32_t v) const {
         if (hold) return;
         uint32_t *p = col + static_cast<size_t>(index) * stride;
@@ -331,6 +333,7 @@ struct StreamLookback {
 struct StreamReserve {
     static constexpr bool kEnabled = true;
     static constexpr bool kReserves = true;
+    static constexpr bool kPool = false;
     bool foreign = false;            // this workgroup is not behind its stream's L2: it takes room from the range's END (device scope)
     uint32_t recounted = 0;          // (unused: interface of StreamLookback)
     int index = 0;
@@ -349,9 +352,11 @@ struct StreamReserve {
         reserved_yet = true;
         const uint32_t cnt = v - pad_keys;
         if (cnt) {
-            if (foreign)
-                reserved = region_len - cnt - __hip_atomic_fetch_add(back, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else
+            if (foreign) {
+                // (the range holds exactly all its keys; should a plan ever say otherwise, stay inside it rather than wrap around)
+                const uint32_t taken = cnt + __hip_atomic_fetch_add(back, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                reserved = region_len >= taken ? region_len - taken : 0u;
+            } else
                 reserved = __hip_atomic_fetch_add(cursor, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
@@ -520,7 +525,8 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
             const uint32_t before = (lb.foreign && !LB::kReserves) ? lb.recounted : lb.resolve(lb_rows, gave_up);
             if (gave_up) sm.lb_gave_up = 1;
             lb_inclusive = kLbInclusive | (before + lb_total);  // published below, after the LDS reads of the write-out
-            sm.gbase[tid] = lb.seed + before - lb_excl;
+            if constexpr (LB::kPool) lb.place(sm.gbase, tid, before, lb_excl);  // (the pool form's regions: vrs_msd_pool.hip)
+            else sm.gbase[tid] = lb.seed + before - lb_excl;
         }
     }
     __syncthreads();
@@ -555,9 +561,15 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
         // wait would hold the whole write-out back until the store is acknowledged.
         if (tid < kBins) lb.publish(lb_inclusive);
     }
+    if constexpr (LB::kPool) {
+        // the pool form's first pass: a slot is a VIRTUAL one (partner buffer, then overflow scratch), and the one run of a region
+        // that crosses the end of its primary part continues elsewhere
+        lb.template store<K, ITEMS, THREADS, FULL>(sm.gbase, key, dst, kout, valid, dg);
+    } else {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        if (FULL || i * THREADS + tid < valid) kout[dst[i]] = key[i];
+        for (int i = 0; i < ITEMS; ++i) {
+            if (FULL || i * THREADS + tid < valid) kout[dst[i]] = key[i];
+        }
     }
     VRS_MARK(5);
 

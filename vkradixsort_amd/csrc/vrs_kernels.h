@@ -100,6 +100,7 @@ struct OnesweepPlanHead {
     uint32_t msd_max_bucket;    // keys in the largest top-14-bit bucket
     uint32_t msd_shift_a;       // the first MSD pass's digit shift (top 8 bits of the key range)
     uint32_t lsd_missing;       // 1 = the counting read counted only the bucket histogram (fast count): no LSD plan exists
+    uint32_t msd_counted;       // (the first MSD pass's plan) 1 = the bucket histogram holds every key: the probed range was 27-32 bits wide and no key lay outside it
     uint32_t ready;             // host copy only: the sort's stamp, written after everything else
 };
 struct OnesweepPlan {
@@ -150,13 +151,13 @@ hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan,
                        uint32_t blind_cap, const StreamCuts &cuts0);
 // pass = 0..3 inside the group of four the plan was made for, shift = the pass's absolute bit position; the streams
 // come from plan->head (device memory).  grid_tiles: rows of workgroups to launch (>= the pass's max_tiles, which the
-// host may not know yet: tile_cap).  forced: run even if the plan marks an earlier pass abnormal (the host's second
-// enqueue).  status: kStreams * grid_tiles rows of 256 tagged words.  spin_budget: polls of an unpublished row before
+// host may not know yet: tile_cap).  forced: 1 = run even if the plan marks an earlier pass abnormal (the host's second
+// enqueue); 2 = the same, unless the plan's counts are void (OnesweepPlanHead::msd_counted == 0: the workgroups leave at once).  status: kStreams * grid_tiles rows of 256 tagged words.  spin_budget: polls of an unpublished row before
 // a tile stops waiting and counts its stream's earlier keys itself; hold_tile >= 0: test hook, that tile of every
 // stream never publishes.
 hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                                    uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
-                                   uint32_t *status, uint32_t grid_tiles, bool forced, bool atomic_rank,
+                                   uint32_t *status, uint32_t grid_tiles, int forced, bool atomic_rank,
                                    unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, int hold_tile,
                                    LaunchEvents ev = {}, bool misplace = false, uint32_t key_base = 0, struct MsdPlan *reserve = nullptr);
 // ---- hybrid form of the one-call sort (K5b, uint32 keys): MSD partition by the top 14 bits in two look-back passes,
@@ -240,54 +241,76 @@ uint32_t msd_local_capacity(bool pairs_or_wide);  // pairs and 64-bit keys: 1331
 uint32_t msd_local_capacity_pairs_small();         // pairs and 64-bit keys, 512-thread workgroup (two per CU): 6656
 
 // ---- hybrid form WITHOUT a counting read ("pool" form, vrs_msd_pool.hip; bare uint32 keys): 24 instead of 28 bytes per key.
-// The counting read exists to tell the first MSD pass where every top byte's keys go.  Here a SAMPLE of the input (the first
-// 256 keys of every 8192-key tile, 1/32 of it) sizes a region of the partner buffer for every (input slice, top byte) plus a
-// few standard deviations of overflow room in context scratch; the first pass reserves its output in those regions (one
-// L2-local atomic per tile and top byte) and counts the 16384 buckets on the way (packed 16-bit LDS counters, flushed once per
-// workgroup); a plan kernel then knows every bucket's exact size, the second pass gathers its input from the regions and
-// writes every bucket to its final place, the local sort is the counted form's.  A region that overflows its room, a key
-// outside the sampled range or a bucket above the local sort's capacity make the plan refuse (MsdPlan::ok == 0): no key of
-// the caller's buffer has moved by then, and the sort starts over in the counted form.
+// The counting read exists to tell the MSD passes where every bucket's keys go.  Here nothing is counted ahead:
+//   sample      1/32 of the input (the first 256 keys of every 8192-key tile) sizes, for every (input slice, top byte), a region
+//               of the partner buffer plus a few standard deviations of overflow room in context scratch;
+//   first pass  every tile reserves its output in those regions (one L2-local atomic per tile and top byte);
+//   plan        one workgroup: exact top-byte totals from the first pass's cursors, the second pass's tile tables, verdict 1;
+//   second pass every tile of a (top byte, slice) share groups its OWN 8192 keys by the next 6 bits IN PLACE (coalesced 16-byte
+//               stores, no global atomic) and leaves a row of 64 (offset, count) pairs;
+//   runs        one workgroup per top byte: the rows -> per-bucket run descriptors, exact bucket starts, verdict 2 (every
+//               bucket fits the local sort) -- the caller's buffer is still untouched at this point;
+//   local sort  one workgroup per bucket gathers the bucket's runs (about 48 of about 128 keys), sorts them inside LDS
+//               (lean_sort_body, vrs_local_sort.hpp) and writes the bucket to its final place in the caller's buffer.
+// A region that overflows its room, a key outside the sampled range, a top byte with more tiles than a bucket may have runs or a
+// bucket above the local sort's capacity make a verdict say no (MsdPlan::ok == 0): the sort starts over in the counted form.
 constexpr uint32_t kPoolTile = 8192;           // keys per tile of both passes
 constexpr uint32_t kPoolSampleKeys = 256;      // leading keys of every tile the sample kernel counts
 constexpr uint32_t kPoolSampleTiles = 32;      // tiles per workgroup of the sample kernel
+constexpr uint32_t kPoolMaxTiles = 56;         // second-pass tiles a top byte may have (its buckets' runs: 56 + 8 split pieces = one wave's scan)
+constexpr uint32_t kPoolRunSlots = kPoolMaxTiles + 8;
 struct PoolStreams {                           // the eight slices of the input the first pass walks (whole tiles), by value
     uint32_t start[8], len[8], sampled[8];     // first key, keys, keys the sample kernel counts
     uint32_t tiles_per_stream, tiles_total;
+};
+struct PoolRun {            // one run of a bucket: `len` keys from virtual slot `slot` on (slots < n: partner buffer, else overflow scratch)
+    uint32_t slot, len;
 };
 struct PoolPlan {
     uint32_t shift;             // bucket = (key - key_base) >> shift: the top 14 bits of the probed key range
     uint32_t armed;             // 1 = the sample kernel laid the regions out: the first pass runs
     uint32_t fail;              // first pass: a region overflowed / a key outside the probed range / a CU behind no known L2 (zero between sorts)
     uint32_t ticket;            // sample kernel: workgroups done (zero between launches)
+    uint32_t ok_a;              // verdict 1 (plan kernel): the second pass runs
+    uint32_t runs_ticket;       // runs kernel: workgroups done (zero between launches)
+    uint32_t max_bucket;        // runs kernel: keys in the largest bucket (zero between sorts)
+    uint32_t pad;
     uint32_t sample[8][256];    // sampled keys of (slice, top byte), zero between sorts
     uint32_t base[8][256];      // primary region of (slice, top byte): first slot in the partner buffer
     uint32_t cap[8][256];       //   its slots
     uint32_t obase[8][256];     // overflow region: first slot in the overflow scratch
     uint32_t ocap[8][256];
+    uint32_t top_base[260];     // where top byte a starts in the sorted order (exact), [256] = n
+    uint32_t top_tiles[256];    // second-pass tiles of top byte a
     uint32_t tiles_b[8][260];   // second pass: XCD x walks entries e = 8 k + s (top byte x + 8 k, slice s): exclusive prefix of their tile counts, [256] = all
 };
 PoolStreams pool_streams(uint32_t n);
 uint32_t pool_overflow_capacity(uint32_t n);   // keys of overflow scratch a sort of n keys may use
+uint32_t pool_tiles_b_cap(uint32_t n);         // rows of workgroups of the second pass (its grid is sized before the plan is known)
+size_t pool_rows_bytes(uint32_t n);            // the second pass's (offset, count) rows: 8 * pool_tiles_b_cap(n) rows of 64 words
+constexpr size_t kPoolRunBytes = sizeof(PoolRun) * 256u * 64u * kPoolRunSlots;  // run descriptors [bucket][run slot]
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
                               PoolPlan *pool, uint32_t overflow_capacity, LaunchEvents ev = {});
-// keys_out: the partner buffer (n slots); overflow: pool_overflow_capacity(n) slots; hist: the 16384-bin bucket histogram (zero
-// when the pass starts); cursors: MsdPlan::cursor_a (zero when the pass starts); misplace: test hook, odd rows of workgroups walk the neighbouring slice
+// keys_out: the partner buffer (n slots); overflow: pool_overflow_capacity(n) slots; cursors: MsdPlan::cursor_a (zero when the pass
+// starts); misplace: test hook, odd rows of workgroups walk the neighbouring slice
 hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, uint32_t *overflow, uint32_t n,
-                              uint32_t key_base, const PoolStreams &ps, PoolPlan *pool, MsdPlan *msd, uint32_t *hist,
-                              unsigned long long xcc_map, int compute_units, bool misplace, uint32_t overflow_capacity,
-                              LaunchEvents ev = {});
-// ONE workgroup, after the first pass: bucket offsets, the second pass's tile tables, the verdict (MsdPlan::ok), the host head
-// (msd_ok, msd_tiles_b, msd_max_bucket, lsd_missing = 1) stamped last; leaves hist zeroed and PoolPlan::fail re-armed
-hipError_t launch_pool_plan(hipStream_t stream, uint32_t *hist, MsdPlan *msd, PoolPlan *pool, OnesweepPlanHead *dev_head,
-                            OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tiles_b_cap, uint32_t local_cap,
-                            uint32_t *host_log);
-// second pass: grid of 8 * tiles_b workgroups (tiles_b >= the plan's msd_tiles_b); regions -> keys_out, every bucket in place
-hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *keys_out,
-                              MsdPlan *msd, const PoolPlan *pool, uint32_t tiles_b, unsigned long long xcc_map, uint32_t key_base,
-                              LaunchEvents ev = {});
-// rows of workgroups the second pass may need for n keys: every (top byte, slice) share ends in a partial tile
-uint32_t pool_tiles_b_cap(uint32_t n, bool blind);
+                              uint32_t key_base, const PoolStreams &ps, PoolPlan *pool, MsdPlan *msd, unsigned long long xcc_map,
+                              bool misplace, uint32_t overflow_capacity, LaunchEvents ev = {});
+// ONE workgroup, after the first pass: verdict 1, top-byte starts, tile tables; re-arms PoolPlan::fail / max_bucket
+hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap);
+// second pass, in place in the regions: grid of 8 * tiles_b workgroups (tiles_b = pool_tiles_b_cap(n))
+hipError_t launch_pool_pass_b(hipStream_t stream, uint32_t *regions, uint32_t *overflow, uint32_t n, MsdPlan *msd, PoolPlan *pool,
+                              uint32_t *rows, uint32_t tiles_b, uint32_t key_base, LaunchEvents ev = {});
+// 256 workgroups: run descriptors, MsdPlan::base, the largest bucket
+hipError_t launch_pool_runs(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, const uint32_t *rows, PoolRun *runs, uint32_t n);
+// gathers every bucket from its runs, sorts it, writes it to keys_out[MsdPlan::base[b] ...); big: the 512-thread shape (buckets
+// up to 14333 keys) instead of the 256-thread one (7165).  Gives verdict 2 (verdict 1, no flag from the passes, the largest bucket
+// fits the shape) = MsdPlan::ok and the host head (msd_ok, msd_max_bucket, lsd_missing = 1, stamped last); re-arms the reservation
+// counters like the counted local sort
+hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *keys_out, uint32_t n,
+                                  MsdPlan *msd, const PoolPlan *pool, const PoolRun *runs, bool big, OnesweepPlanHead *dev_head,
+                                  OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev = {});
+uint32_t pool_local_capacity(bool big);
 
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups
 hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks);

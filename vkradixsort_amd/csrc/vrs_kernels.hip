@@ -15,6 +15,7 @@
 //                         LDS re-bucketing, then digit-contiguous global stores.  Stable.
 //   K4 single_kernel      the single_radixsort path: four passes inside one workgroup.
 #include "vrs_device.hpp"
+#include "vrs_local_sort.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -882,6 +883,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     // (the plan keeps a second copy of the streams in which such a pass has no tiles: ONE scalar load decides)
     const StreamDesc sd = forced ? plan->head.stream[pass][s] : plan->head.blind[pass][s];
     if (i >= sd.tiles) return;  // uniform per workgroup
+    // forced == 2 (vrs_msd_partition_*: the first MSD pass whatever the plan thinks of THIS shard's buckets): still not without
+    // counts -- a key range below 27 bits or a key outside the probed range left the bucket histogram empty or wrong, every seed
+    // would be void and a reservation could run out of its range
+    if (forced == 2 && plan->head.msd_counted == 0u) return;
     const uint32_t done = i * kTile;
     const uint32_t begin = sd.start + done;
     const uint32_t valid = min(kTile, sd.len - done);
@@ -1177,6 +1182,7 @@ __global__ __launch_bounds__(1024) void msd_plan_kernel(uint32_t *__restrict__ c
         msd->sub_bits = sub_bits;
         plan_a->head.first_abnormal = 4;
         plan_a->head.msd_shift_a = shift + sub_bits;  // the first MSD pass's digit: the top 8 bits of the range
+        plan_a->head.msd_counted = (over == 0u && shift >= kMsdMinShift && shift <= max_shift) ? 1u : 0u;  // the bucket histogram holds every key
         plan_lsd->head.msd_ok = s_ok;
         plan_lsd->head.msd_tiles_b = s_tiles_b;
         plan_lsd->head.msd_max_bucket = s_max;
@@ -1465,11 +1471,7 @@ __device__ __forceinline__ void local_sort_bucket(uint32_t *bucket, uint32_t *bu
 // instead of keeping 28 of them alive from the returning adds to the base reads -- the registers that decide between 119 and
 // "128 + spills to scratch" (scratch traffic is HBM traffic: 230 MB per launch at 10^8 keys, profiles/labs/r03_local_sort_spills.txt)
 // (opaque(): vrs_device.hpp)
-constexpr int kLeanRow = 512 + 64;  // words per counter table: 512 digits + one dummy per lane for slots without a key
-constexpr int kLeanMaxVec = 7;      // 16-byte vectors per thread: capacity THREADS * 28 slots
-template <int THREADS, int VEC, bool GUARD>
-__device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
-                                               uint32_t *s_hist2, uint32_t *s_tmp, bool guard1, bool guard2);
+// (kLeanRow, kLeanMaxVec, lean_sort_body: vrs_local_sort.hpp)
 template <int THREADS, int VEC>
 __device__ __attribute__((noinline)) void lean_sort_guarded(uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *s_hist2,
                                                            uint32_t *s_tmp, uint32_t guards);
@@ -1541,198 +1543,6 @@ __device__ __attribute__((noinline)) void lean_sort_guarded(uint32_t *abase, uin
         k[4 * j + 3] = t.w;
     }
     lean_sort_body<THREADS, VEC, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, (guards & 1u) != 0u, (guards & 2u) != 0u);
-}
-
-template <int THREADS, int VEC, bool GUARD>
-__device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
-                                               uint32_t *s_hist2, uint32_t *s_tmp, bool guard1, bool guard2) {
-    constexpr int WAVES = THREADS / 64, ITEMS = 4 * VEC, PER = 512 / THREADS;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t end = mis + n;
-    const uint32_t nvec = (end + 3u) / 4u;
-    uint32_t rank[ITEMS];
-    uint32_t *s_hist = s_hist2 + WAVES * kLeanRow;
-    // ---- pass 1: low 9 bits, one table, ties in any order; byte address of counter d = 4 d
-#pragma unroll
-    for (int j = 0; j < VEC; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            uint32_t a = (k[4 * j + c] << 2) & 0x7FCu;
-            if (j == 0 || j == VEC - 1) {
-                const uint32_t q = 4u * (j * THREADS + tid) + c;
-                a = (q - mis < n) ? a : 2048u + 4u * lane;
-            }
-            uint32_t *counter = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_hist) + a);
-            if (GUARD && guard1) {  // workgroup-uniform
-                const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
-                if (__ballot(a == a0) == ~0ull) {  // one counter for the whole instruction: lane 0 adds the 64 keys
-                    uint32_t old = 0;
-                    if (lane == 0u) old = __hip_atomic_fetch_add(counter, 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    rank[4 * j + c] = __builtin_amdgcn_readfirstlane(old) + 4u * lane;
-                    continue;
-                }
-            }
-            rank[4 * j + c] = __hip_atomic_fetch_add(counter, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    __syncthreads();
-    {   // exclusive prefix over the 512 bins
-        uint32_t c[PER], total = 0;
-        if constexpr (PER == 2) {
-            const uint2 q = reinterpret_cast<const uint2 *>(s_hist)[tid];
-            c[0] = q.x;
-            c[1] = q.y;
-            total = q.x + q.y;
-        } else {
-            c[0] = s_hist[tid];
-            total = c[0];
-        }
-        uint32_t incl = total;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
-            if (lane >= static_cast<uint32_t>(o)) incl += t;
-        }
-        if (lane == 63u) s_tmp[wave] = incl;
-        __syncthreads();
-        uint32_t acc = incl - total;
-#pragma unroll
-        for (int v = 0; v < WAVES; ++v) acc += (static_cast<uint32_t>(v) < wave) ? s_tmp[v] : 0u;
-        if constexpr (PER == 2) reinterpret_cast<uint2 *>(s_hist)[tid] = make_uint2(acc, acc + c[0]);
-        else s_hist[tid] = acc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < VEC; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            uint32_t a = (opaque(k[4 * j + c]) << 2) & 0x7FCu;
-            if (j == 0 || j == VEC - 1) {
-                // a slot behind the bucket keeps its place (position q: mis + n slots lie before the first of them, mis of those
-                // without a key), the ones before the bucket follow the keys (position n + q)
-                const uint32_t q = 4u * (j * THREADS + tid) + c;
-                const bool valid = q - mis < n;
-                a = valid ? a : 2048u + 4u * lane;
-                const uint32_t r = rank[4 * j + c] + *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_hist) + a);
-                rank[4 * j + c] = valid ? r : 4u * (q < mis ? n + q : q);
-                continue;
-            }
-            rank[4 * j + c] += *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_hist) + a);
-        }
-    // byte offset Lb = 4 L of position L goes to byte (Lb & ~1023) | ((Lb & 252) << 2) | ((Lb >> 6) & 12)
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t Lb = rank[i];
-        const uint32_t ph = (Lb & ~1023u) | ((Lb & 252u) << 2) | ((Lb >> 6) & 12u);
-        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_keys) + ph) = k[i];
-    }
-    __syncthreads();
-    // ---- pass 2: high 9 bits, one table per wave, stable
-    const uint32_t seg = wave * (ITEMS * 64);
-#pragma unroll
-    for (int g = 0; g < VEC; ++g) {
-        const uint4 t = reinterpret_cast<const uint4 *>(s_keys + seg + g * 256)[lane];
-        k[4 * g] = t.x;
-        k[4 * g + 1] = t.y;
-        k[4 * g + 2] = t.z;
-        k[4 * g + 3] = t.w;
-    }
-    char *my = reinterpret_cast<char *>(s_hist2 + wave * kLeanRow);
-    // fewer than a row (4 THREADS slots) + 3 slots hold no key, all at the end of the position space: with 256 threads and five
-    // rows or more that is the last 17 items of the last wave, otherwise it may be any item of any wave
-    constexpr int kEmptyItems = (4 * THREADS + 3 + 63) / 64;
-    constexpr int kFirstMaybeEmpty = ITEMS >= kEmptyItems ? ITEMS - kEmptyItems : 0;
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        uint32_t a = (k[i] >> 7) & 0x7FCu;
-        if (i >= kFirstMaybeEmpty) a = (seg + i * 64 + lane < n) ? a : 2048u + 4u * lane;
-        uint32_t *counter = reinterpret_cast<uint32_t *>(my + a);
-        if (GUARD && guard2) {
-            const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
-            if (__ballot(a == a0) == ~0ull) {
-                uint32_t old = 0;
-                if (lane == 0u) old = __hip_atomic_fetch_add(counter, 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                rank[i] = __builtin_amdgcn_readfirstlane(old) + 4u * lane;
-                continue;
-            }
-        }
-        rank[i] = __hip_atomic_fetch_add(counter, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __syncthreads();
-    {   // exclusive prefix over (bin, wave); starts at the bucket's misalignment: pass 2 writes slot = mis + position
-        uint32_t c[WAVES][PER], total = 0;
-#pragma unroll
-        for (int v = 0; v < WAVES; ++v) {
-            if constexpr (PER == 2) {
-                const uint2 q = reinterpret_cast<const uint2 *>(s_hist2 + v * kLeanRow)[tid];
-                c[v][0] = q.x;
-                c[v][1] = q.y;
-                total += q.x + q.y;
-            } else {
-                c[v][0] = s_hist2[v * kLeanRow + tid];
-                total += c[v][0];
-            }
-        }
-        uint32_t incl = total;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
-            if (lane >= static_cast<uint32_t>(o)) incl += t;
-        }
-        if (lane == 63u) s_tmp[wave] = incl;
-        __syncthreads();
-        uint32_t acc = incl - total + 4u * mis;
-#pragma unroll
-        for (int v = 0; v < WAVES; ++v) acc += (static_cast<uint32_t>(v) < wave) ? s_tmp[v] : 0u;
-        uint32_t out[WAVES][PER];
-#pragma unroll
-        for (int p_ = 0; p_ < PER; ++p_)
-#pragma unroll
-            for (int v = 0; v < WAVES; ++v) {
-                out[v][p_] = acc;
-                acc += c[v][p_];
-            }
-#pragma unroll
-        for (int v = 0; v < WAVES; ++v) {
-            if constexpr (PER == 2) reinterpret_cast<uint2 *>(s_hist2 + v * kLeanRow)[tid] = make_uint2(out[v][0], out[v][1]);
-            else s_hist2[v * kLeanRow + tid] = out[v][0];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        uint32_t a = (opaque(k[i]) >> 7) & 0x7FCu;
-        if (i >= kFirstMaybeEmpty) {  // a slot without a key stays where it is: slot mis + L
-            const uint32_t L = seg + i * 64 + lane;
-            a = L < n ? a : 2048u + 4u * lane;
-            const uint32_t r = rank[i] + *reinterpret_cast<const uint32_t *>(my + a);
-            rank[i] = L < n ? r : 4u * (mis + L);
-            continue;
-        }
-        rank[i] += *reinterpret_cast<const uint32_t *>(my + a);
-    }
-    // (every wave read its pass-2 keys out of s_keys before its atomics, and two barriers lie behind those: s_keys is free)
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_keys) + rank[i]) = k[i];
-    __syncthreads();
-    // ---- store: slot q = 4 v + c holds sorted position q - mis
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        const uint32_t v = j * THREADS + tid;
-        if (j > 0 && j < VEC - 1) {
-            reinterpret_cast<uint4 *>(abase)[v] = reinterpret_cast<const uint4 *>(s_keys)[v];
-        } else if (v < nvec) {
-            const uint4 q4 = reinterpret_cast<const uint4 *>(s_keys)[v];
-            const uint32_t q = 4u * v;
-            if (q >= mis && q + 4u <= end) {
-                reinterpret_cast<uint4 *>(abase)[v] = q4;
-            } else {  // the two ends of the bucket: the neighbours' keys in the same 16 bytes are not ours to write
-                if (q + 0u - mis < n) abase[q + 0u] = q4.x;
-                if (q + 1u - mis < n) abase[q + 1u] = q4.y;
-                if (q + 2u - mis < n) abase[q + 2u] = q4.z;
-                if (q + 3u - mis < n) abase[q + 3u] = q4.w;
-            }
-        }
-    }
 }
 
 // THREADS = 256: up to 7165 keys per bucket (uniform keys: N <= 1.05e8), 38 KB of LDS, four workgroups per CU;
@@ -2609,10 +2419,10 @@ hipError_t launch_plan(hipStream_t stream, uint32_t *tables, OnesweepPlan *plan,
 
 hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                                    uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
-                                   uint32_t *status, uint32_t grid_tiles, bool forced, bool atomic_rank,
+                                   uint32_t *status, uint32_t grid_tiles, int forced, bool atomic_rank,
                                    unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, int hold_tile,
                                    LaunchEvents ev, bool misplace, uint32_t key_base, MsdPlan *reserve) {
-    const int mis = misplace ? 1 : 0, force = forced ? 1 : 0;
+    const int mis = misplace ? 1 : 0, force = forced;
     if (grid_tiles == 0) return hipSuccess;
     const dim3 grid(kStreams * grid_tiles), block(64 * VRS_LB_WAVES);
     const bool pairs = values_in != nullptr;

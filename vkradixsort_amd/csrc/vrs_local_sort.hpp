@@ -1,0 +1,206 @@
+// vrs_local_sort.hpp -- the LDS-local sort of one bucket of bare uint32 keys by its low 18 bits (two 9-bit passes), shared by
+// the counted hybrid form (vrs_kernels.hip: the bucket lies contiguous in the buffer and is sorted in place) and the pool form
+// (vrs_msd_pool.hip: the bucket is gathered from runs and written to its final place).  See vrs_kernels.hip, "the local sort of
+// bare uint32 keys", for how the body is laid out for the LDS pipe.
+#pragma once
+#include "vrs_device.hpp"
+
+namespace vrs {
+
+constexpr int kLeanRow = 512 + 64;  // words per counter table: 512 digits + one dummy per lane for slots without a key
+constexpr int kLeanMaxVec = 7;      // 16-byte vectors per thread: capacity THREADS * 28 slots
+// k[4 j + c] = slot q = 4 (j THREADS + tid) + c of the bucket seen from its first 16-byte boundary `abase`; slots [mis, mis + n)
+// hold keys (mis < 4).  Sorts them and stores the sorted bucket to abase[mis .. mis + n) (16-byte vector stores inside).
+template <int THREADS, int VEC, bool GUARD>
+__device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
+                                               uint32_t *s_hist2, uint32_t *s_tmp, bool guard1, bool guard2) {
+    constexpr int WAVES = THREADS / 64, ITEMS = 4 * VEC, PER = 512 / THREADS;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t end = mis + n;
+    const uint32_t nvec = (end + 3u) / 4u;
+    uint32_t rank[ITEMS];
+    uint32_t *s_hist = s_hist2 + WAVES * kLeanRow;
+    // ---- pass 1: low 9 bits, one table, ties in any order; byte address of counter d = 4 d
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t a = (k[4 * j + c] << 2) & 0x7FCu;
+            if (j == 0 || j == VEC - 1) {
+                const uint32_t q = 4u * (j * THREADS + tid) + c;
+                a = (q - mis < n) ? a : 2048u + 4u * lane;
+            }
+            uint32_t *counter = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_hist) + a);
+            if (GUARD && guard1) {  // workgroup-uniform
+                const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
+                if (__ballot(a == a0) == ~0ull) {  // one counter for the whole instruction: lane 0 adds the 64 keys
+                    uint32_t old = 0;
+                    if (lane == 0u) old = __hip_atomic_fetch_add(counter, 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    rank[4 * j + c] = __builtin_amdgcn_readfirstlane(old) + 4u * lane;
+                    continue;
+                }
+            }
+            rank[4 * j + c] = __hip_atomic_fetch_add(counter, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    __syncthreads();
+    {   // exclusive prefix over the 512 bins
+        uint32_t c[PER], total = 0;
+        if constexpr (PER == 2) {
+            const uint2 q = reinterpret_cast<const uint2 *>(s_hist)[tid];
+            c[0] = q.x;
+            c[1] = q.y;
+            total = q.x + q.y;
+        } else {
+            c[0] = s_hist[tid];
+            total = c[0];
+        }
+        uint32_t incl = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= static_cast<uint32_t>(o)) incl += t;
+        }
+        if (lane == 63u) s_tmp[wave] = incl;
+        __syncthreads();
+        uint32_t acc = incl - total;
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) acc += (static_cast<uint32_t>(v) < wave) ? s_tmp[v] : 0u;
+        if constexpr (PER == 2) reinterpret_cast<uint2 *>(s_hist)[tid] = make_uint2(acc, acc + c[0]);
+        else s_hist[tid] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t a = (opaque(k[4 * j + c]) << 2) & 0x7FCu;
+            if (j == 0 || j == VEC - 1) {
+                // a slot behind the bucket keeps its place (position q: mis + n slots lie before the first of them, mis of those
+                // without a key), the ones before the bucket follow the keys (position n + q)
+                const uint32_t q = 4u * (j * THREADS + tid) + c;
+                const bool valid = q - mis < n;
+                a = valid ? a : 2048u + 4u * lane;
+                const uint32_t r = rank[4 * j + c] + *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_hist) + a);
+                rank[4 * j + c] = valid ? r : 4u * (q < mis ? n + q : q);
+                continue;
+            }
+            rank[4 * j + c] += *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_hist) + a);
+        }
+    // byte offset Lb = 4 L of position L goes to byte (Lb & ~1023) | ((Lb & 252) << 2) | ((Lb >> 6) & 12)
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t Lb = rank[i];
+        const uint32_t ph = (Lb & ~1023u) | ((Lb & 252u) << 2) | ((Lb >> 6) & 12u);
+        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_keys) + ph) = k[i];
+    }
+    __syncthreads();
+    // ---- pass 2: high 9 bits, one table per wave, stable
+    const uint32_t seg = wave * (ITEMS * 64);
+#pragma unroll
+    for (int g = 0; g < VEC; ++g) {
+        const uint4 t = reinterpret_cast<const uint4 *>(s_keys + seg + g * 256)[lane];
+        k[4 * g] = t.x;
+        k[4 * g + 1] = t.y;
+        k[4 * g + 2] = t.z;
+        k[4 * g + 3] = t.w;
+    }
+    char *my = reinterpret_cast<char *>(s_hist2 + wave * kLeanRow);
+    // fewer than a row (4 THREADS slots) + 3 slots hold no key, all at the end of the position space: with 256 threads and five
+    // rows or more that is the last 17 items of the last wave, otherwise it may be any item of any wave
+    constexpr int kEmptyItems = (4 * THREADS + 3 + 63) / 64;
+    constexpr int kFirstMaybeEmpty = ITEMS >= kEmptyItems ? ITEMS - kEmptyItems : 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        uint32_t a = (k[i] >> 7) & 0x7FCu;
+        if (i >= kFirstMaybeEmpty) a = (seg + i * 64 + lane < n) ? a : 2048u + 4u * lane;
+        uint32_t *counter = reinterpret_cast<uint32_t *>(my + a);
+        if (GUARD && guard2) {
+            const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
+            if (__ballot(a == a0) == ~0ull) {
+                uint32_t old = 0;
+                if (lane == 0u) old = __hip_atomic_fetch_add(counter, 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rank[i] = __builtin_amdgcn_readfirstlane(old) + 4u * lane;
+                continue;
+            }
+        }
+        rank[i] = __hip_atomic_fetch_add(counter, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    {   // exclusive prefix over (bin, wave); starts at the bucket's misalignment: pass 2 writes slot = mis + position
+        uint32_t c[WAVES][PER], total = 0;
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) {
+            if constexpr (PER == 2) {
+                const uint2 q = reinterpret_cast<const uint2 *>(s_hist2 + v * kLeanRow)[tid];
+                c[v][0] = q.x;
+                c[v][1] = q.y;
+                total += q.x + q.y;
+            } else {
+                c[v][0] = s_hist2[v * kLeanRow + tid];
+                total += c[v][0];
+            }
+        }
+        uint32_t incl = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= static_cast<uint32_t>(o)) incl += t;
+        }
+        if (lane == 63u) s_tmp[wave] = incl;
+        __syncthreads();
+        uint32_t acc = incl - total + 4u * mis;
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) acc += (static_cast<uint32_t>(v) < wave) ? s_tmp[v] : 0u;
+        uint32_t out[WAVES][PER];
+#pragma unroll
+        for (int p_ = 0; p_ < PER; ++p_)
+#pragma unroll
+            for (int v = 0; v < WAVES; ++v) {
+                out[v][p_] = acc;
+                acc += c[v][p_];
+            }
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) {
+            if constexpr (PER == 2) reinterpret_cast<uint2 *>(s_hist2 + v * kLeanRow)[tid] = make_uint2(out[v][0], out[v][1]);
+            else s_hist2[v * kLeanRow + tid] = out[v][0];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        uint32_t a = (opaque(k[i]) >> 7) & 0x7FCu;
+        if (i >= kFirstMaybeEmpty) {  // a slot without a key stays where it is: slot mis + L
+            const uint32_t L = seg + i * 64 + lane;
+            a = L < n ? a : 2048u + 4u * lane;
+            const uint32_t r = rank[i] + *reinterpret_cast<const uint32_t *>(my + a);
+            rank[i] = L < n ? r : 4u * (mis + L);
+            continue;
+        }
+        rank[i] += *reinterpret_cast<const uint32_t *>(my + a);
+    }
+    // (every wave read its pass-2 keys out of s_keys before its atomics, and two barriers lie behind those: s_keys is free)
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_keys) + rank[i]) = k[i];
+    __syncthreads();
+    // ---- store: slot q = 4 v + c holds sorted position q - mis
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const uint32_t v = j * THREADS + tid;
+        if (j > 0 && j < VEC - 1) {
+            reinterpret_cast<uint4 *>(abase)[v] = reinterpret_cast<const uint4 *>(s_keys)[v];
+        } else if (v < nvec) {
+            const uint4 q4 = reinterpret_cast<const uint4 *>(s_keys)[v];
+            const uint32_t q = 4u * v;
+            if (q >= mis && q + 4u <= end) {
+                reinterpret_cast<uint4 *>(abase)[v] = q4;
+            } else {  // the two ends of the bucket: the neighbours' keys in the same 16 bytes are not ours to write
+                if (q + 0u - mis < n) abase[q + 0u] = q4.x;
+                if (q + 1u - mis < n) abase[q + 1u] = q4.y;
+                if (q + 2u - mis < n) abase[q + 2u] = q4.z;
+                if (q + 3u - mis < n) abase[q + 3u] = q4.w;
+            }
+        }
+    }
+}
+
+}  // namespace vrs

@@ -1,31 +1,33 @@
 // vrs_msd_pool.hip -- the hybrid form of the one-call sort WITHOUT a counting read (bare uint32 keys): 24 bytes per key.
 //
 // The reference reads the keys once per pass just to count them (multi_radixsort_histograms.comp:42-50); the counted hybrid
-// form (vrs_kernels.hip, K5b) still reads them once for that.  Here they are not read for counting at all:
+// form (vrs_kernels.hip, K5b) still reads them once for that.  Here they are not read for counting at all, and no pass waits
+// for a histogram either:
 //
-//   pool_sample_kernel   1/32 of the input (the first 256 keys of every 8192-key tile): probes the key range (bucket shift)
-//                        and counts the top byte per input slice; its last workgroup lays out, for every (slice, top byte),
-//                        a PRIMARY region of the partner buffer sized by the estimate (the estimates of a slice sum to its
-//                        length, so the regions tile the n-key buffer exactly) and an OVERFLOW region in context scratch of six
-//                        standard deviations of that estimate;
-//   pool_pass_a_kernel   first MSD pass (top 8 bits of the key range).  Persistent workgroups, 64 per slice: a tile reserves
-//                        its place in (slice, top byte)'s region with ONE atomic add on the region's cursor, in the L2 of the
-//                        XCD that runs the slice (StreamReserve's idea, vrs_device.hpp) -- positions below the region's
-//                        capacity are primary slots, the rest overflow slots.  On the way every key is counted in a 16384-bin
-//                        histogram of the top 14 bits: packed 16-bit LDS counters that live as long as the workgroup and are
-//                        flushed to memory once (64-bit atomics on counter pairs), so the flush costs 0.04 atomics per key;
-//   pool_plan_kernel     ONE workgroup: exact bucket offsets from the histogram, the second pass's tile tables from the cursors,
-//                        the verdict -- no region overflowed, no key outside the sampled range, every bucket fits the local
-//                        sort -- and the host head;
-//   pool_pass_b_kernel   second MSD pass (the next 6 bits): walks every (top byte, slice) share -- primary part, then overflow
-//                        part -- in tiles and writes every bucket to its FINAL range by reservation, exactly like the counted
-//                        form's second pass (scatter_chunk with two sources);
-//   the local sort       msd_local_sort_*_kernel of the counted form, unchanged.
+//   pool_sample_kernel      1/32 of the input (the first 256 keys of every 8192-key tile): probes the key range (bucket shift)
+//                           and counts the top byte per input slice; its last workgroup lays out, for every (slice, top byte), a
+//                           PRIMARY region of the partner buffer sized by the estimate (the estimates of a slice sum to its
+//                           length, so the regions tile the n-key buffer) and an OVERFLOW region in context scratch of six
+//                           standard deviations of that estimate;
+//   pool_pass_a_kernel      first MSD pass (top 8 bits of the key range): a tile reserves its place in (slice, top byte)'s region
+//                           with ONE atomic add on the region's cursor, in the L2 of the XCD that runs the slice (StreamReserve's
+//                           idea, vrs_device.hpp) -- positions below the region's capacity are primary slots, the rest overflow;
+//   pool_plan_kernel        ONE workgroup: top-byte totals are the cursors' sums, exact -- where every top byte starts in the
+//                           sorted order, the second pass's tile tables, verdict 1;
+//   pool_pass_b_kernel      second MSD pass (the next 6 bits) WITHOUT any global offset: a tile groups its own 8192 keys by the 6
+//                           bits in LDS and writes them back to the slots it read them from, 16 bytes per lane, and leaves a
+//                           row of 64 (offset, count) pairs.  A bucket is then a set of RUNS, one per tile of its top byte;
+//   pool_runs_kernel        one workgroup per top byte: rows -> run descriptors per bucket, exact bucket starts (MsdPlan::base),
+//                           the largest bucket; the last one to finish gives verdict 2 and stamps the host head.  Up to here
+//                           the caller's buffer has not been written;
+//   pool_local_sort_kernel  one workgroup per bucket: gathers the bucket's runs (about 48 of about 128 keys), sorts the keys by
+//                           their low 18 bits inside LDS (lean_sort_body, vrs_local_sort.hpp) and stores the bucket at its final
+//                           place in the caller's buffer.
 //
 // Nothing here is assumed about the data: a sample that misjudges a region (keys whose distribution changes inside a tile
-// with the tile's period, say) makes the first pass flag the sort, the plan refuse, and the caller run the counted form on the
-// untouched input.  The first pass is not stable (arrival order inside a region); bare keys do not care.
-#include "vrs_device.hpp"
+// with the tile's period, say) makes the first pass flag the sort, a verdict refuse, and the caller run the counted form on the
+// untouched input.  Neither MSD pass is stable (arrival order inside a region, any order inside a run); bare keys do not care.
+#include "vrs_local_sort.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -73,8 +75,10 @@ __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__rest
     // The buckets are the top 14 bits of the key RANGE: every workgroup ORs the same strided 4096 keys (as the counted form's
     // counting read does) and derives the same shift; a key outside that range is flagged by the first pass.
     {
-        const uint32_t samples = min(n, 4096u);
-        const uint64_t stride = n / samples;
+        // (512 keys, not the counting read's 4096: hundreds of workgroups asking the L2s for the same lines at the same time
+        // is what this costs -- 4096 lines took 11 of the kernel's 30 us)
+        const uint32_t samples = min(n, 512u);
+        const uint64_t stride = n / max(samples, 1u);
         uint32_t acc = 0;
         for (uint32_t i = tid; i < samples; i += 256u) acc |= keys[static_cast<uint64_t>(i) * stride] - key_base;
 #pragma unroll
@@ -124,11 +128,12 @@ __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__rest
         const uint32_t m = __hip_atomic_load(&pool->sample[s][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&pool->sample[s][tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next sort
         const uint32_t len = ps.len[s], sampled = ps.sampled[s];
-        // estimate: the slice's keys in proportion to the sample's; the estimates of a slice sum to at most its length
-        const uint32_t est = sampled ? static_cast<uint32_t>(static_cast<uint64_t>(m) * len / sampled) : 0u;
-        cap[s] = est & ~31u;
-        // the estimate scales m sampled keys up by r = len / sampled: its standard deviation is sqrt(r * est)
+        // estimate: the slice's keys in proportion to the sample's, r = len / sampled for one sampled key (float arithmetic,
+        // rounded DOWN by a hair: the estimates of a slice must sum to at most its length -- the primary regions tile the buffer)
         const float r = sampled ? static_cast<float>(len) / static_cast<float>(sampled) : 1.0f;
+        const uint32_t est = min(static_cast<uint32_t>(static_cast<float>(m) * r * 0.999999f), len);
+        cap[s] = est & ~31u;
+        // the estimate scales m sampled keys up by r: its standard deviation is sqrt(r * est)
         const uint32_t dev = static_cast<uint32_t>(kPoolSigmas * sqrtf(r * static_cast<float>(est)));
         room[s] = len ? (dev + (est - cap[s]) + kPoolRoomFloor + 31u) & ~31u : 0u;
         caps += cap[s];
@@ -167,6 +172,7 @@ __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__rest
         br += room[s];
     }
     if (tid == 0) {
+        pool->fail = 0;  // re-armed here: the passes of THIS sort set it, its local sort reads it
         pool->shift = shift;
         // a key range below 27 bits is left to the LSD passes, like the counted form does (vrs_kernels.hip, msd_plan_kernel)
         pool->armed = (shift >= kPoolMinShift && shift <= kPoolMaxShift && total_room <= overflow_capacity) ? 1u : 0u;
@@ -174,215 +180,49 @@ __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// First pass.
-#ifdef VRS_POOL_LAB_MARKS  // lab (tools/lab/pool_lab.hip): thread 0 of every workgroup sums the cycles between phase marks
-__device__ unsigned long long *g_pool_marks;
-#define POOL_MARK(k)                                            \
-    do {                                                        \
-        if (threadIdx.x == 0) {                                 \
-            const unsigned long long t_ = __builtin_readcyclecounter(); \
-            sm.marks[k] += t_ - sm.mark_last;                   \
-            sm.mark_last = t_;                                  \
-        }                                                       \
-    } while (0)
-#else
-#define POOL_MARK(k)
-#endif
-struct alignas(16) PoolSmem {
-#ifdef VRS_POOL_LAB_MARKS
-    unsigned long long marks[12], mark_last;
-#endif
-    uint32_t keys[kPoolTile];      // re-bucketed keys, tile order by top byte
-    alignas(16) uint32_t whist[8][kBins];  // per-wave digit counters -> per-wave digit starts
-    alignas(16) uint32_t dstart[kBins];    // where digit d's run starts inside the tile
-    uint32_t gbase[kBins];         // virtual slot of the digit's first key minus its start inside the tile (slots >= n: overflow scratch)
-    uint32_t gbase2[kBins];        //   ... of the part of the run behind `split` (a run that crosses its primary region's end)
-    uint32_t split[kBins];         // tile position from which gbase2 applies (0xFFFFFFFF: nowhere)
-    uint32_t scan_tmp[8];
-    uint32_t acc[kBins];           // keys of top byte d counted into the packed counters since their last flush
-    uint32_t flags[2];             // by tile parity.  1: some run crosses its primary region's end; 4: flush the bucket counters behind this tile
-#ifdef VRS_POOL_LAB_SMALL_HIST  // lab: what would three workgroups per CU buy (wrong counts: the plan refuses)
-    uint32_t hist[64];
-#else
-    uint32_t hist[kPoolBuckets / 2];  // packed 16-bit counters of the 16384 buckets, as long as the workgroup lives
-#endif
-};
+// First pass: scatter_chunk (vrs_device.hpp) with the regions as its offset source.
+// (The digit is the counted form's: RadixDigit on the top 8 bits of the key range.  A key OUTSIDE the probed range lands in
+// some region here; the second pass, which looks at every key anyway, flags it.)
+// Reservation in sampled regions: StreamReserve's one atomic add per tile and digit (in the L2 every workgroup that adds to this
+// row of cursors sits behind), then positions below the region's capacity are primary slots, the rest overflow slots.
+static_assert(offsetof(PoolPlan, cap) == offsetof(PoolPlan, base) + 8 * 256 * 4 && offsetof(PoolPlan, obase) == offsetof(PoolPlan, base) + 16 * 256 * 4 &&
+                  offsetof(PoolPlan, ocap) == offsetof(PoolPlan, base) + 24 * 256 * 4,
+              "PoolReserve reads a region's four words 2048 words apart");
+struct PoolReserve {
+    static constexpr bool kEnabled = true;
+    static constexpr bool kReserves = true;
+    static constexpr bool kPool = true;
+    bool foreign = false;            // (interface of StreamLookback: unused -- the row is chosen by the XCC the workgroup runs on)
+    uint32_t recounted = 0;
+    int index = 0;
+    const void *stream_keys = nullptr;
+    uint32_t done = 0;
+    uint32_t seed = 0;
+    uint32_t *cursor = nullptr;      // this thread's digit's cursor
+    const uint32_t *region = nullptr;  // &PoolPlan::base[row][digit]: base, cap, obase, ocap are 8 * 256 words apart
+    uint32_t pad_keys = 0;
+    uint32_t n_virt = 0;             // virtual slots >= n_virt are overflow slots
+    uint32_t *overflow = nullptr;
+    uint32_t overflow_last = 0;
+    uint32_t *gbase2 = nullptr, *split = nullptr, *flags = nullptr;  // LDS: see place()
+    uint32_t *fail_word = nullptr;
+    mutable uint32_t reserved = 0, cnt = 0, rb = 0, rc = 0, ob = 0, oc = 0;
+    mutable bool reserved_yet = false;
 
-__device__ __forceinline__ void pool_flush_hist(uint32_t *s_hist, uint32_t *__restrict__ hist) {
-#ifdef VRS_POOL_LAB_SMALL_HIST
-    for (uint32_t w = threadIdx.x; w < 64u; w += 512u) {
-#else
-    for (uint32_t w = threadIdx.x; w < kPoolBuckets / 2u; w += 512u) {
-#endif
-        const uint32_t x = s_hist[w];
-        if (x) {
-            s_hist[w] = 0;
-            // buckets 2 w and 2 w + 1 in one 64-bit add (neither count reaches 2^32: no carry between them)
-            const unsigned long long v = (static_cast<unsigned long long>(x >> 16) << 32) | (x & 0xFFFFu);
-            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(hist) + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    __device__ __forceinline__ void publish(uint32_t v) const {
+        if (reserved_yet) return;  // the second call (the inclusive prefix) has nobody to tell
+        reserved_yet = true;
+        cnt = v - pad_keys;
+        if (cnt) reserved = __hip_atomic_fetch_add(cursor, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        rb = region[0];  // four L2-resident words, in flight beside the atomic while the keys are re-bucketed
+        rc = region[8 * 256];
+        ob = region[16 * 256];
+        oc = region[24 * 256];
     }
-}
-
-// One tile of 8192 keys by a workgroup of 512 threads x 16 keys: rank inside the wave with returning LDS atomics (RANK_ATOMIC:
-// the library runs the hybrid forms only after the lane-order self-test passed), count the buckets, reserve, re-bucket through
-// LDS, write every top byte's run to the slots it reserved -- scatter_chunk's job (vrs_device.hpp), laid out for a PERSISTENT
-// workgroup of which a CU holds only two (the bucket counters take 32 KB of LDS each), so that every barrier and every exposed
-// latency counts:
-//  * key[]: the tile's keys already in registers, in ANY assignment to threads (the pass is not stable); next[] / next_kin: the
-//    keys of the workgroup's NEXT tile are asked for in the middle of this one -- behind the reservation atomic, in front of
-//    the write-out's stores (loads and stores retire on one in-order counter: a load issued behind the stores would wait for
-//    all of them) -- as four 16-byte loads per thread;
-//  * three barriers instead of scatter_chunk's five: EVERY wave reads all eight per-wave count rows (lane l: digits 4l..4l+3,
-//    one ds_read_b128 per row) and computes the digit prefix and its own starts redundantly, so no thread hands a scan
-//    result to another; a wave's row is zeroed again by the wave itself at the end of the tile, off the critical path;
-//  * the reservation atomic of digit 4l + w is issued by lane l of wave w < 4 as soon as the digit's total is known, before
-//    the prefix is scanned.
-// parity: tiles alternate between two flag words (a slow wave may still read the previous tile's).
-template <bool FULL, bool PREFETCH>
-__device__ __forceinline__ uint32_t pool_tile_a(PoolSmem &sm, uint32_t (&key)[16], uint32_t (&next)[16], const uint32_t *__restrict__ next_kin,
-                                            uint32_t *__restrict__ kout,
-                                            uint32_t *__restrict__ overflow, uint32_t overflow_last, uint32_t n_virt, uint32_t valid, uint32_t shift,
-                                            uint32_t key_base, uint32_t *__restrict__ cursor_row, const PoolPlan *__restrict__ pool,
-                                            uint32_t s_out, uint32_t parity, uint32_t &over, uint32_t *fail_word) {
-    constexpr int ITEMS = 16, WAVES = 8;
-    constexpr uint32_t THREADS = WAVES * 64;
-    // (the thread index opaque to the optimiser: everything derived from it -- sixteen tile positions, LDS addresses, the
-    // digit this lane owns -- is then recomputed per tile, a few VALU instructions, instead of being kept alive across the
-    // persistent loop in registers the tile needs: the compiler spills such invariants, and a reload is a VMEM operation
-    // that waits behind every load and store in flight)
-    const uint32_t tid = opaque(threadIdx.x), lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t dshift = kMsdBits - 8u;  // bucket -> top byte
-    POOL_MARK(0);
-    if (tid == 0) sm.flags[parity] = 0;  // (read behind this tile's last barrier; the other word may still be read by a slow wave)
-
-    // ---- rank inside the wave (this wave's own row of counters, zero since the wave's previous tile); count the bucket
-    uint32_t rank2[ITEMS / 2];  // two tile positions (< 8192) per register: the registers decide between 128 and spills
-    uint32_t *my_hist = sm.whist[wave];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        uint32_t rank_i;
-        const uint32_t raw = (key[i] - key_base) >> shift;
-        // ragged tile (wave-striped 4-byte loads, pool_ragged_tile_a): positions >= valid hold the padding key
-        const bool real = FULL || wave * (ITEMS * 64) + i * 64 + lane < valid;
-        if (real) over |= raw >> kMsdBits;
-        const uint32_t b = min(raw, kPoolBuckets - 1u);
-        const uint32_t d = b >> dshift;
-#ifdef VRS_POOL_LAB_SMALL_HIST
-        const uint32_t hw = (b >> 1) & 63u, hv = 1u << ((b & 1u) << 4);
-#else
-        const uint32_t hw = b >> 1, hv = 1u << ((b & 1u) << 4);
-#endif
-        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-        if (__ballot(d == d0) == ~0ull) {  // wave-uniform: one add by lane 0 instead of 64 on one counter (scatter_chunk's skew guard)
-            uint32_t old = 0;
-            if (lane == 0u) old = __hip_atomic_fetch_add(&my_hist[d0], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            rank_i = __builtin_amdgcn_readfirstlane(old) + lane;
-            const uint32_t b0 = __builtin_amdgcn_readfirstlane(b);
-            if (__ballot(real && b == b0) == ~0ull) {  // ... and one bucket: sorted or constant keys
-                if (lane == 0u) __hip_atomic_fetch_add(&sm.hist[__builtin_amdgcn_readfirstlane(hw)], 64u << ((b0 & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else if (real) {
-                __hip_atomic_fetch_add(&sm.hist[hw], hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        } else {
-            rank_i = __hip_atomic_fetch_add(&my_hist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (real) __hip_atomic_fetch_add(&sm.hist[hw], hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (i & 1) rank2[i >> 1] |= rank_i << 16; else rank2[i >> 1] = rank_i;
-    }
-    POOL_MARK(2);
-    __syncthreads();
-    POOL_MARK(3);
-
-    // ---- waves 0-3: lane l of wave w owns digit D = 64 w + l (consecutive lanes, consecutive cursors: one wave's atomic touches
-    // two cache lines of the row -- with the digits dealt four to a lane it touched eight, every line took four times the
-    // atomics, and the pass 60 % longer).  Its total and its reservation first: the scan below hides part of the round trip.
-    const uint32_t D = tid & 255u;
-    uint32_t cnt = 0, reserved = 0, rb = 0, rc = 0, ob = 0, oc = 0;
-    if (wave < 4u) {  // wave-uniform
-        uint32_t dtot = 0;
-#pragma unroll
-        for (int v = 0; v < WAVES; ++v) dtot += sm.whist[v][D];
-        cnt = dtot - ((!FULL && D == 255u) ? kPoolTile - valid : 0u);  // padding keys take no room
-        // ONE atomic add in the L2 this workgroup's CU sits behind: every workgroup that adds to this row sits behind the same
-        if (cnt) reserved = __hip_atomic_fetch_add(cursor_row + D, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // this digit's region: four L2-resident words, in flight beside the atomic
-        rb = pool->base[s_out][D];
-        rc = pool->cap[s_out][D];
-        ob = pool->obase[s_out][D];
-        oc = pool->ocap[s_out][D];
-        // keys counted into the 16-bit bucket counters of this top byte since the last flush: none may pass 65535
-        const uint32_t acc = sm.acc[D] + dtot;
-        sm.acc[D] = acc;
-        if (acc > kPoolFlushAt) atomicOr(&sm.flags[parity], 4u);
-    }
-    // ---- every wave: lane l takes digits 4l .. 4l + 3 -- their totals, their starts inside the tile, this wave's own starts
-    uint32_t tot[4] = {0, 0, 0, 0}, mine[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int v = 0; v < WAVES; ++v) {
-        const uint4 c = reinterpret_cast<const uint4 *>(sm.whist[v])[lane];
-        const uint32_t m = static_cast<uint32_t>(v) < wave ? ~0u : 0u;  // wave-uniform
-        mine[0] += c.x & m;
-        mine[1] += c.y & m;
-        mine[2] += c.z & m;
-        mine[3] += c.w & m;
-        tot[0] += c.x;
-        tot[1] += c.y;
-        tot[2] += c.z;
-        tot[3] += c.w;
-        if (v == 3) __builtin_amdgcn_sched_barrier(0);  // two batches of four reads: eight at once cost 32 registers beside keys and ranks
-    }
-    __builtin_amdgcn_sched_barrier(0);  // (the prefetch's 16 registers only once the count rows' are free)
-    if constexpr (PREFETCH) {
-        const uint4 *nv = reinterpret_cast<const uint4 *>(next_kin);
-#pragma unroll
-        for (int i = 0; i < ITEMS / 4; ++i) {
-            const uint4 q = nv[i * THREADS + tid];
-            next[4 * i] = q.x;
-            next[4 * i + 1] = q.y;
-            next[4 * i + 2] = q.z;
-            next[4 * i + 3] = q.w;
-        }
-    }
-    // exclusive prefix of the digit totals over the lanes (every wave computes the same)
-    const uint32_t four = tot[0] + tot[1] + tot[2] + tot[3];
-    uint32_t incl = four;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o);
-        if (lane >= static_cast<uint32_t>(o)) incl += t;
-    }
-    uint32_t start[4];
-    start[0] = incl - four;
-    start[1] = start[0] + tot[0];
-    start[2] = start[1] + tot[1];
-    start[3] = start[2] + tot[2];
-    if (wave == 0u) reinterpret_cast<uint4 *>(sm.dstart)[lane] = make_uint4(start[0], start[1], start[2], start[3]);
-    POOL_MARK(4);
-    __syncthreads();  // every wave has read every row's counts
-    POOL_MARK(5);
-
-    // ---- this wave's starts into its own row, then (same wave: the LDS keeps its operations in order) the re-bucketing
-    reinterpret_cast<uint4 *>(my_hist)[lane] = make_uint4(start[0] + mine[0], start[1] + mine[1], start[2] + mine[2], start[3] + mine[3]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // (the keys opaque to the optimiser from here on: it would otherwise keep the sixteen digits of the ranking phase alive across
-    // the scan -- registers the scan's count rows and the prefetch need -- instead of recomputing them, two VALU instructions each)
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) key[i] = opaque(key[i]);
-#pragma unroll
-    for (int j = 0; j < ITEMS / 2; ++j) {
-        const uint32_t s0 = my_hist[min((key[2 * j] - key_base) >> shift, kPoolBuckets - 1u) >> dshift];
-        const uint32_t s1 = my_hist[min((key[2 * j + 1] - key_base) >> shift, kPoolBuckets - 1u) >> dshift];
-        rank2[j] += s0 | (s1 << 16);  // (no carry: every position is below 8192)
-    }
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) sm.keys[(i & 1) ? rank2[i >> 1] >> 16 : rank2[i >> 1] & 0xFFFFu] = key[i];
-    if (wave < 4u) {
-        const uint32_t excl = sm.dstart[D];
-        // run [reserved, reserved + cnt) of the region's position space: positions below rc are primary slots rb + position,
-        // the others overflow slots (virtual n_virt + ob + position - rc)
+    __device__ __forceinline__ void fetch(int, uint32_t (&)[kLbBatch]) const {}
+    __device__ __forceinline__ uint32_t resolve(uint32_t (&)[kLbBatch], bool &) const { return reserved; }
+    // run [reserved, reserved + cnt) of the region's position space; excl: where the digit's run starts inside the tile
+    __device__ __forceinline__ void place(uint32_t *gbase, uint32_t tid, uint32_t, uint32_t excl) const {
         const uint32_t end = reserved + cnt;
         uint32_t g, g2 = 0, sp = 0xFFFFFFFFu;
         bool bad = false;
@@ -396,88 +236,49 @@ __device__ __forceinline__ uint32_t pool_tile_a(PoolSmem &sm, uint32_t (&key)[16
             sp = excl + (rc - reserved);
             g = rb + reserved - excl;
             g2 = n_virt + ob - sp;
-            atomicOr(&sm.flags[parity], 1u);
+            atomicOr(flags, 1u);
         }
-        // a region out of room: the sort is refused (the keys of this run still go somewhere inside the scratch, see below)
+        // a region out of room: the sort is refused (the keys of this run still go somewhere inside the scratch: store())
         if (cnt && bad) __hip_atomic_fetch_or(fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sm.gbase[D] = g;
-        sm.gbase2[D] = g2;
-        sm.split[D] = sp;
+        gbase[tid] = g;
+        gbase2[tid] = g2;
+        split[tid] = sp;
     }
-    POOL_MARK(6);
-    __syncthreads();
-    POOL_MARK(7);
-    const uint32_t flags = sm.flags[parity];  // workgroup-uniform
-
-    // ---- write out: tile position q goes to slot gbase[digit] + q; reads batched before stores.  EVERY path through here issues
-    // the same 16 stores (a run beyond its region's room -- the sort is refused then -- is clamped into the scratch instead of
-    // skipped): the compiler's wait for the prefetched keys of the next tile is "all but the 16 youngest operations" only if
-    // no path has fewer.
+    template <typename K, int ITEMS, uint32_t THREADS, bool FULL, typename DG>
+    __device__ __forceinline__ void store(const uint32_t *, const K (&key)[ITEMS], uint32_t (&dst)[ITEMS], K *kout, uint32_t valid, const DG &dg) const {
+        const uint32_t tid = threadIdx.x;
+        if (*flags & 1u) {  // workgroup-uniform
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) key[i] = sm.keys[i * THREADS + tid];
-    uint32_t dst[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) dst[i] = sm.gbase[min((key[i] - key_base) >> shift, kPoolBuckets - 1u) >> dshift] + (i * THREADS + tid);
-    if (flags & 1u) {
+            for (int i = 0; i < ITEMS; ++i) {
+                const uint32_t d = dg(key[i]);
+                if (i * THREADS + tid >= split[d]) dst[i] = gbase2[d] + (i * THREADS + tid);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            const uint32_t d = min((key[i] - key_base) >> shift, kPoolBuckets - 1u) >> dshift;
-            if (i * THREADS + tid >= sm.split[d]) dst[i] = sm.gbase2[d] + (i * THREADS + tid);
+            K *p = dst[i] < n_virt ? kout + dst[i] : overflow + min(dst[i] - n_virt, overflow_last);
+            if (FULL || i * THREADS + tid < valid) *p = key[i];
         }
     }
-    // this wave's row of counters, zero for the wave's next tile (nobody else reads it before that tile's first barrier)
-    {
-        const uint32_t z = tid >> 10;  // zero, made here (a constant zero vector would be one more invariant held across the loop -- and spilled)
-        reinterpret_cast<uint4 *>(my_hist)[lane] = make_uint4(z, z, z, z);
-    }
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        // (a ragged tile's padding keys rank last: their slots are the first ones behind the last key's, or clamped -- harmless,
-        // nobody reads them)
-        const bool primary = dst[i] < n_virt;
-        uint32_t *p = primary ? kout + dst[i] : overflow + min(dst[i] - n_virt, overflow_last);
-        if (FULL || i * THREADS + tid < valid) *p = key[i];
-    }
-    POOL_MARK(8);
-    return flags;
-}
+};
 
-// out of line: at most eight tiles of a sort are ragged, and their index arithmetic must not sit in the registers of the loop.
-// Returns "a key lies outside the probed range".
-__device__ __attribute__((noinline)) uint32_t pool_ragged_tile_a(PoolSmem &sm, const uint32_t *__restrict__ kin, uint32_t *__restrict__ kout,
-                                                                 uint32_t *__restrict__ overflow, uint32_t overflow_last, uint32_t n_virt,
-                                                                 uint32_t valid, uint32_t shift, uint32_t key_base,
-                                                                 uint32_t *__restrict__ cursor_row, const PoolPlan *__restrict__ pool,
-                                                                 uint32_t s_out, uint32_t parity, uint32_t *fail_word) {
-    const uint32_t seg = (threadIdx.x >> 6) * 1024u + (threadIdx.x & 63u);
-    uint32_t key[16], none[16], over = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t idx = seg + i * 64;
-        const uint32_t k = kin[idx < valid ? idx : valid - 1u];
-        key[i] = idx < valid ? k : key_base - 1u;  // the padding key: top byte 255 of the range, the highest tile positions
-    }
-    // (a flush this tile asks for is the kernel's final one)
-    (void)pool_tile_a<false, false>(sm, key, none, nullptr, kout, overflow, overflow_last, n_virt, valid, shift, key_base, cursor_row, pool, s_out,
-                                    parity, over, fail_word);
-    return over;
-}
-
-// grid = 8 * wgs_per_stream workgroups; workgroup b walks tiles (b >> 3), (b >> 3) + wgs_per_stream, ... of slice b & 7 -- the
-// slice whose keys the sample counted for the regions of row b & 7, and (observed placement: block b on XCD b % 8) the row
-// whose cursors live in this CU's L2.  Neither is assumed: the row a workgroup ADDS TO is chosen by the XCC it finds itself
-// on, so that a row's L2-local atomics always meet in one L2, whichever slice the workgroup reads.
+// grid = 8 * tiles_per_stream workgroups; workgroup b takes tile b >> 3 of slice b & 7 -- the slice whose keys the sample counted
+// for the regions of row b & 7, and (observed placement: block b on XCD b % 8) the row whose cursors live in this CU's L2.
+// Neither is assumed: the row a workgroup ADDS TO is chosen by the XCC it finds itself on, so that a row's L2-local atomics
+// always meet in one L2, whichever slice the workgroup reads.
 __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out,
                                                              uint32_t *__restrict__ overflow, uint32_t n, uint32_t key_base,
                                                              PoolStreams ps, PoolPlan *__restrict__ pool, MsdPlan *__restrict__ msd,
-                                                             uint32_t *__restrict__ hist, unsigned long long xcc_map,
-                                                             uint32_t wgs_per_stream, int misplace, uint32_t overflow_capacity) {
-    __shared__ PoolSmem sm;
+                                                             unsigned long long xcc_map, int misplace, uint32_t overflow_capacity) {
+    __shared__ ChunkSmem<uint32_t, 16, 8, false> sm;
+    __shared__ uint32_t s_gbase2[kBins], s_split[kBins], s_flags;
     if (pool->armed == 0u) return;  // uniform: the sample kernel did not lay regions out (key range below 27 bits)
-    const uint32_t tid = threadIdx.x;
-    const uint32_t r = blockIdx.x >> 3;
-    // misplace (test hook): odd rows of workgroups read the neighbouring slice
-    const uint32_t s_in = (blockIdx.x + (misplace ? (r & 1u) : 0u)) & 7u;
+    const uint32_t i = blockIdx.x >> 3;
+    // misplace (test hook): odd tiles are read from the neighbouring slice
+    const uint32_t s_in = (blockIdx.x + (misplace ? (i & 1u) : 0u)) & 7u;
+    const uint32_t len = ps.len[s_in];
+    const uint32_t done = i * kPoolTile;
+    if (done >= len) return;
     const uint32_t my_xcc = xcc_id();
     uint32_t s_out = blockIdx.x & 7u;
     if (xcc_of(xcc_map, s_out) != my_xcc) {  // not where block b % 8 was observed to run: the row of the L2 this CU does sit behind
@@ -486,127 +287,59 @@ __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__r
             if (s_out == 8u && xcc_of(xcc_map, x) == my_xcc) s_out = x;
     }
     if (s_out == 8u) {  // behind an L2 the probe never saw: no row is safe to add to -- the sort is refused
-        if (tid == 0) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    for (uint32_t w = tid; w < sizeof(sm.hist) / 4u; w += 512u) sm.hist[w] = 0;  // (the first tile's first barrier orders this)
-#ifdef VRS_POOL_LAB_MARKS
-    if (tid == 0) {
-        for (int k = 0; k < 12; ++k) sm.marks[k] = 0;
-        sm.mark_last = __builtin_readcyclecounter();
-    }
-#endif
-    if (tid < kBins) sm.acc[tid] = 0;
-    for (uint32_t w = tid; w < 8u * kBins; w += 512u) (&sm.whist[0][0])[w] = 0;  // (afterwards every wave re-zeroes its own row, tile by tile)
-    const uint32_t shift = pool->shift;
-    const uint32_t len = ps.len[s_in];
-    const uint32_t tiles = (len + kPoolTile - 1u) / kPoolTile;
-    const uint32_t *kin = keys_in + ps.start[s_in];
-    uint32_t *cursor_row = &msd->cursor_a[s_out][0];
-    uint32_t over = 0, parity = 0;
-    // Full tiles in a software pipeline: the keys of the workgroup's next tile are in flight while this one is written out.
-    // Two copies of the tile body, ka -> kb and kb -> ka, so that no register is copied at the seam (a copy would wait for
-    // the loads AND, with them, for every store issued since).  The last tile prefetches the slice's last full tile again (one
-    // tile for all 64 workgroups of the slice: served by L2) -- a path with fewer loads would weaken every wait behind it.
-    const uint32_t full = len / kPoolTile;
-    const uint32_t overflow_last = overflow_capacity - 1u;
-    uint32_t ka[16], kb[16];
-    if (r < full) {
-        const uint4 *v = reinterpret_cast<const uint4 *>(kin + r * kPoolTile);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4 q = v[i * 512 + tid];
-            ka[4 * i] = q.x;
-            ka[4 * i + 1] = q.y;
-            ka[4 * i + 2] = q.z;
-            ka[4 * i + 3] = q.w;
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered with nothing in flight, like its back edge minus the stores
-    }
-    __syncthreads();  // the counters are zero
-    const auto flush_if = [&](uint32_t flags) {
-        if (flags & 4u) {  // a 16-bit bucket counter could overflow in the next tile (thousands of keys per tile in one bucket)
-            __syncthreads();
-            pool_flush_hist(sm.hist, hist);
-            if (tid < kBins) sm.acc[tid] = 0;
-            __syncthreads();  // the next tile counts at once
-        }
-    };
-    for (uint32_t i = r; i < full;) {
-        uint32_t nxt = min(i + wgs_per_stream, full - 1u);
-        flush_if(pool_tile_a<true, true>(sm, ka, kb, kin + nxt * kPoolTile, keys_out, overflow, overflow_last, n, kPoolTile, shift, key_base, cursor_row,
-                                         pool, s_out, parity, over, &pool->fail));
-        i += wgs_per_stream;
-        parity ^= 1u;
-        if (i >= full) break;
-        nxt = min(i + wgs_per_stream, full - 1u);
-        flush_if(pool_tile_a<true, true>(sm, kb, ka, kin + nxt * kPoolTile, keys_out, overflow, overflow_last, n, kPoolTile, shift, key_base, cursor_row,
-                                         pool, s_out, parity, over, &pool->fail));
-        i += wgs_per_stream;
-        parity ^= 1u;
-    }
-    // the slice's ragged last tile, by the workgroup whose turn it is
-    if (full < tiles && full % wgs_per_stream == r)
-        over |= pool_ragged_tile_a(sm, kin + full * kPoolTile, keys_out, overflow, overflow_last, n, len - full * kPoolTile, shift, key_base, cursor_row,
-                                   pool, s_out, parity, &pool->fail);
-    __syncthreads();
-    POOL_MARK(9);
-    pool_flush_hist(sm.hist, hist);
-#ifdef VRS_POOL_LAB_MARKS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    POOL_MARK(10);
-    if (tid == 0)
-        for (int k = 0; k < 12; ++k) g_pool_marks[static_cast<size_t>(blockIdx.x) * 12 + k] = sm.marks[k];
-#endif
-    if (__syncthreads_or(static_cast<int>(over)) && tid == 0)  // a key above the probed range (or below the promised floor)
-        __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) s_flags = 0;  // (set behind the chunk's barriers, read behind its last one)
+    const uint32_t valid = min(kPoolTile, len - done);
+    const uint32_t *kin = keys_in + ps.start[s_in] + done;
+    const uint32_t d = threadIdx.x & 255u;
+    RadixDigit<uint32_t> dg;
+    dg.shift = pool->shift + (kMsdBits - 8u);
+    dg.base = key_base;
+    PoolReserve lb;
+    lb.cursor = &msd->cursor_a[s_out][d];
+    lb.region = &pool->base[s_out][d];
+    lb.pad_keys = d == 255u ? kPoolTile - valid : 0u;
+    lb.n_virt = n;
+    lb.overflow = overflow;
+    lb.overflow_last = overflow_capacity - 1u;
+    lb.gbase2 = s_gbase2;
+    lb.split = s_split;
+    lb.flags = &s_flags;
+    lb.fail_word = &pool->fail;
+    uint32_t unused = 0;
+    if (valid == kPoolTile)
+        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true>(sm, kin, nullptr, keys_out, nullptr, valid, dg, unused, lb);
+    else
+        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, false>(sm, kin, nullptr, keys_out, nullptr, valid, dg, unused, lb);
 }
 
 // ---------------------------------------------------------------------------------------------
-// The plan, once the first pass has run: ONE workgroup of 1024 threads (msd_plan_kernel's job in the counted form).
-__global__ __launch_bounds__(1024) void pool_plan_kernel(uint32_t *__restrict__ counts, MsdPlan *__restrict__ msd,
-                                                        PoolPlan *__restrict__ pool, OnesweepPlanHead *__restrict__ dev_head,
-                                                        OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n,
-                                                        uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *host_log) {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_start[kBins + 1];      // where top byte a starts in the sorted order
+// The plan, once the first pass has run: ONE workgroup of 256 threads, thread a = top byte a.
+__global__ __launch_bounds__(256) void pool_plan_kernel(MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool, uint32_t n, uint32_t tiles_b_cap) {
+    __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_tiles[8][kBins];       // [XCD x][entry e = 8 k + s]: tiles of slice s's share of top byte x + 8 k
-    __shared__ uint32_t s_max, s_tiles_b, s_bad, s_ok;
+    __shared__ uint32_t s_tiles_b, s_bad;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    constexpr uint32_t kPer = kPoolBuckets / 1024u;  // 16 buckets per thread
     const uint32_t shift = pool->shift, armed = pool->armed, failed = pool->fail;
-    uint32_t c[kPer], cur[8];
-    {
-        const uint4 *cv = reinterpret_cast<const uint4 *>(counts + tid * kPer);
-#pragma unroll
-        for (uint32_t j = 0; j < kPer / 4u; ++j) {
-            const uint4 q = cv[j];
-            c[4 * j] = q.x;
-            c[4 * j + 1] = q.y;
-            c[4 * j + 2] = q.z;
-            c[4 * j + 3] = q.w;
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) cur[s] = tid < kBins ? msd->cursor_a[s][tid] : 0u;
     if (tid == 0) {
-        s_max = 0;
         s_tiles_b = 0;
         s_bad = 0;
     }
-    // (1) exclusive prefix over the 16384 buckets; the histogram is left zeroed for the next sort
-    uint32_t sum = 0, mx = 0;
-    {
-        uint4 *cv = reinterpret_cast<uint4 *>(counts + tid * kPer);
+    __syncthreads();
+    uint32_t keys_a = 0, tiles_a = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < kPer / 4u; ++j) cv[j] = make_uint4(0, 0, 0, 0);
+    for (int s = 0; s < 8; ++s) {
+        const uint32_t c = msd->cursor_a[s][tid];
+        const uint32_t t = (c + kPoolTile - 1u) / kPoolTile;
+        keys_a += c;
+        tiles_a += t;
+        s_tiles[tid & 7u][(tid >> 3) * 8u + s] = t;
     }
-#pragma unroll
-    for (uint32_t j = 0; j < kPer; ++j) {
-        sum += c[j];
-        mx = max(mx, c[j]);
-    }
-    uint32_t incl = sum;
+    if (tiles_a > kPoolMaxTiles) s_bad = 1;  // a bucket of this top byte would have more runs than the local sort gathers
+    pool->top_tiles[tid] = tiles_a;
+    uint32_t incl = keys_a;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t t = __shfl_up(incl, o);
@@ -614,44 +347,19 @@ __global__ __launch_bounds__(1024) void pool_plan_kernel(uint32_t *__restrict__ 
     }
     if (lane == 63u) s_wave[wave] = incl;
     __syncthreads();
-    atomicMax(&s_max, mx);
-    uint32_t run = incl - sum;
-    for (uint32_t j = 0; j < wave; ++j) run += s_wave[j];
-    {
-        uint32_t start[kPer];
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; ++j) {
-            const uint32_t b = tid * kPer + j;
-            start[j] = run;
-            if ((b & (kMsdSub - 1u)) == 0u) s_start[b >> kMsdSubBits] = run;
-            run += c[j];
-        }
-        uint4 *vb = reinterpret_cast<uint4 *>(msd->base + tid * kPer);
-#pragma unroll
-        for (uint32_t j = 0; j < kPer / 4u; ++j) vb[j] = make_uint4(start[4 * j], start[4 * j + 1], start[4 * j + 2], start[4 * j + 3]);
+    uint32_t before = incl - keys_a;
+    for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+    pool->top_base[tid] = before;
+    if (tid == 255u) {
+        pool->top_base[256] = before + keys_a;
+        if (before + keys_a != n) s_bad = 1;  // keys the first pass did not place: it did not run, or a workgroup left early
     }
-    if (tid == 1023u) {
-        msd->base[kPoolBuckets] = run;
-        s_start[kBins] = run;
-        if (run != n) s_bad = 1;  // keys the first pass did not count: it dropped a tile (a region overflowed) or did not run
-    }
-    __syncthreads();
-    // (2) the second pass's tiles: top byte a = tid, its eight shares; what the cursors say must be what the histogram says
-    if (tid < kBins) {
-        uint32_t keys_a = 0;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            keys_a += cur[s];
-            s_tiles[tid & 7u][(tid >> 3) * 8u + s] = (cur[s] + kPoolTile - 1u) / kPoolTile;
-        }
-        if (keys_a != s_start[tid + 1] - s_start[tid]) s_bad = 1;
-    }
-    __syncthreads();
-    if (wave < 8u) {  // wave x: the exclusive prefix of XCD x's 256 entries, four per lane
+    // the exclusive prefix of every XCD's 256 entries: wave w takes XCDs w and w + 4, four entries per lane
+    for (uint32_t x = wave; x < 8u; x += 4u) {
         uint32_t t[4], tot = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            t[j] = s_tiles[wave][4 * lane + j];
+            t[j] = s_tiles[x][4 * lane + j];
             tot += t[j];
         }
         uint32_t inc = tot;
@@ -663,53 +371,138 @@ __global__ __launch_bounds__(1024) void pool_plan_kernel(uint32_t *__restrict__ 
         uint32_t a = inc - tot;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            pool->tiles_b[wave][4 * lane + j] = a;
+            pool->tiles_b[x][4 * lane + j] = a;
             a += t[j];
         }
         if (lane == 63u) {
-            pool->tiles_b[wave][kBins] = a;
+            pool->tiles_b[x][kBins] = a;
             atomicMax(&s_tiles_b, a);
         }
     }
     __syncthreads();
     if (tid == 0) {
-        s_ok = (armed != 0u && failed == 0u && s_bad == 0u && shift >= kPoolMinShift && shift <= kPoolMaxShift && s_max <= local_cap &&
-                s_tiles_b <= tiles_b_cap)
-                   ? 1u
-                   : 0u;
-        pool->fail = 0;  // re-armed for the next sort
+        pool->ok_a = (armed != 0u && failed == 0u && s_bad == 0u && shift >= kPoolMinShift && shift <= kPoolMaxShift && s_tiles_b <= tiles_b_cap) ? 1u : 0u;
+        pool->max_bucket = 0;  // (PoolPlan::fail stays: the second pass may still set it; the next sort's sample kernel re-arms it)
         msd->shift = shift;
-        msd->ok = s_ok;
         msd->sub_bits = kMsdSubBits;
-        dev_head->msd_ok = s_ok;
-        dev_head->msd_tiles_b = s_tiles_b;
-        dev_head->msd_max_bucket = s_max;
-        dev_head->lsd_missing = 1u;
-        if (host_head) {
-            __hip_atomic_store(&host_head->lsd_missing, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&host_head->msd_ok, s_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&host_head->msd_tiles_b, s_tiles_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&host_head->msd_max_bucket, s_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (host_log)
-                __hip_atomic_store(&host_log[stamp & (kMsdLogWords - 1u)], (stamp << 1) | s_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __threadfence_system();
-            __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        msd->ok = 0;           // the runs kernel decides
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Second pass: block b -> XCD b % 8, which walks the shares (top byte x + 8 k, slice s) in entry order e = 8 k + s; every
-// bucket's keys go to its final range by reservation on the bucket's cursor (MsdPlan::cursor_b, in this XCD's L2; a tile off
-// its XCD takes room from the range's END with a device-scope atomic: StreamReserve, vrs_device.hpp).
-__global__ __launch_bounds__(512, 4) void pool_pass_b_kernel(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
-                                                             uint32_t *__restrict__ keys_out, MsdPlan *__restrict__ msd,
-                                                             const PoolPlan *__restrict__ pool, unsigned long long xcc_map,
-                                                             uint32_t key_base) {
-    __shared__ ChunkSmem<uint32_t, 16, 8, false> sm;
+// Second pass: block b -> XCD b % 8 (no correctness in that), which walks the shares (top byte x + 8 k, slice s) in entry order
+// e = 8 k + s.  A tile reads 8192 slots of its share -- the share's positions run through its primary region, then its overflow
+// region -- groups the keys by the 6 bits below the top byte in LDS and writes them back to the SAME slots.  No offset from
+// anywhere: the tile's row says where each of its 64 runs starts and how long it is.
+struct alignas(16) PoolSmemB {
+    uint32_t keys[kPoolTile];
+    alignas(16) uint32_t whist[8][kMsdSub];  // per-wave counters of the 64 digits -> per-wave starts
+};
+
+template <bool VECTOR>  // VECTOR: a full tile inside the primary region (16-byte aligned): 16-byte loads and stores
+__device__ __forceinline__ uint32_t pool_tile_b(PoolSmemB &sm, uint32_t *__restrict__ t0, uint32_t *__restrict__ t1, uint32_t split, uint32_t valid,
+                                                uint32_t shift, uint32_t key_base, uint32_t *__restrict__ row) {
+    constexpr int ITEMS = 16, WAVES = 8;
+    constexpr uint32_t THREADS = WAVES * 64;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t key[ITEMS];
+    if constexpr (VECTOR) {
+        const uint4 *v = reinterpret_cast<const uint4 *>(t0);
+#pragma unroll
+        for (int i = 0; i < ITEMS / 4; ++i) {
+            const uint4 q = v[i * THREADS + tid];
+            key[4 * i] = q.x;
+            key[4 * i + 1] = q.y;
+            key[4 * i + 2] = q.z;
+            key[4 * i + 3] = q.w;
+        }
+    } else {  // tile positions below `split` at t0, the others at t1; positions >= valid hold the padding key (digit 63, ranks last)
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t idx = wave * (ITEMS * 64) + i * 64 + lane;
+            const uint32_t j = idx < valid ? idx : valid - 1u;
+            const uint32_t k = *(j < split ? t0 + j : t1 + j);
+            key[i] = idx < valid ? k : key_base - 1u;
+        }
+    }
+    uint32_t *my_hist = sm.whist[wave];
+    my_hist[lane] = 0;  // this wave's own row (64 counters): its LDS operations stay in order
+    // a key outside the probed range has bits above the range's 14 + shift (a range of 32 bits has no such key)
+    const uint32_t above = shift + kMsdBits < 32u ? ~0u << (shift + kMsdBits) : 0u;
+    uint32_t rank[ITEMS], over = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (VECTOR || wave * (ITEMS * 64) + i * 64 + lane < valid) over |= (key[i] - key_base) & above;  // (the padding key is no key)
+    // (key_base is a multiple of 2^24 and the 6 bits end at or below bit 24: the digit needs no subtraction)
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t d = (key[i] >> shift) & (kMsdSub - 1u);
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__ballot(d == d0) == ~0ull) {
+            uint32_t old = 0;
+            if (lane == 0u) old = __hip_atomic_fetch_add(&my_hist[d0], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            rank[i] = __builtin_amdgcn_readfirstlane(old) + lane;
+        } else {
+            rank[i] = __hip_atomic_fetch_add(&my_hist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    // every wave: lane l = digit l -- its total, its start inside the tile, this wave's own start
+    uint32_t tot = 0, mine = 0;
+#pragma unroll
+    for (int v = 0; v < WAVES; ++v) {
+        const uint32_t c = sm.whist[v][lane];
+        mine += static_cast<uint32_t>(v) < wave ? c : 0u;
+        tot += c;
+    }
+    uint32_t incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= static_cast<uint32_t>(o)) incl += t;
+    }
+    const uint32_t start = incl - tot;
+    if (wave == 0u) {  // the tile's row: where run l starts inside the tile, and its keys (the padding of a ragged tile is not a key)
+        const uint32_t real = tot - (lane == kMsdSub - 1u ? kPoolTile - valid : 0u);
+        row[lane] = start | (real << 16);
+    }
+    __syncthreads();  // every wave has read every row's counts
+    my_hist[lane] = start + mine;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) rank[i] += my_hist[(key[i] >> shift) & (kMsdSub - 1u)];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) sm.keys[rank[i]] = key[i];
+    __syncthreads();
+    // back to the slots the tile was read from, in tile order
+    if constexpr (VECTOR) {
+        uint4 *v = reinterpret_cast<uint4 *>(t0);
+#pragma unroll
+        for (int i = 0; i < ITEMS / 4; ++i) v[i * THREADS + tid] = reinterpret_cast<const uint4 *>(sm.keys)[i * THREADS + tid];
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t q = i * THREADS + tid;
+            if (q < valid) *(q < split ? t0 + q : t1 + q) = sm.keys[q];
+        }
+    }
+    return over;
+}
+
+// the general form out of line: its index arithmetic must not cost the common (vector) form its third workgroup per CU
+__device__ __attribute__((noinline)) uint32_t pool_tile_b_general(PoolSmemB &sm, uint32_t *__restrict__ t0, uint32_t *__restrict__ t1, uint32_t split,
+                                                                  uint32_t valid, uint32_t shift, uint32_t key_base, uint32_t *__restrict__ row) {
+    return pool_tile_b<false>(sm, t0, t1, split, valid, shift, key_base, row);
+}
+
+__global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(uint32_t *__restrict__ regions, uint32_t *__restrict__ overflow, const MsdPlan *__restrict__ msd,
+                                                             PoolPlan *__restrict__ pool, uint32_t *__restrict__ rows, uint32_t key_base) {
+    __shared__ PoolSmemB sm;
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
     const uint32_t *pt = pool->tiles_b[x];
-    if (msd->ok == 0u || j >= pt[kBins]) return;  // uniform (enqueued before the plan was known: it may have said no)
+    if (pool->ok_a == 0u || j >= pt[kBins]) return;  // uniform (enqueued before the plan was known: it may have said no)
     uint32_t e = 0;  // the entry whose tiles contain j: largest e with pt[e] <= j
 #pragma unroll
     for (uint32_t step = 128; step >= 1; step >>= 1)
@@ -720,22 +513,298 @@ __global__ __launch_bounds__(512, 4) void pool_pass_b_kernel(const uint32_t *__r
     const uint32_t done = i * kPoolTile;
     const uint32_t valid = min(kPoolTile, keys_sa - done);
     const uint32_t split = prim > done ? prim - done : 0u;      // leading tile positions that lie in the primary region
-    const uint32_t *kin0 = regions + pool->base[s][a] + done;
-    const uint32_t *kin1 = overflow + pool->obase[s][a] + (static_cast<int64_t>(done) - static_cast<int64_t>(prim));
-    BitsDigit dg{msd->shift, kMsdSub - 1u, key_base};
-    StreamReserve lb;
-    const uint32_t b = (a << kMsdSubBits) + min(threadIdx.x & 255u, kMsdSub - 1u);
-    lb.foreign = xcc_id() != xcc_of(xcc_map, x);
-    lb.cursor = &msd->cursor_b[b];
-    lb.back = &msd->back_b[b];
-    lb.pad_keys = (threadIdx.x & 255u) == dg(dg.template pad<uint32_t>()) ? kPoolTile - valid : 0u;
-    lb.seed = msd->base[b];
-    if (lb.foreign) lb.region_len = msd->base[b + 1u] - lb.seed;
-    uint32_t unused = 0;
-    if (valid == kPoolTile)
-        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, StreamReserve, true>(sm, kin0, nullptr, keys_out, nullptr, valid, dg, unused, lb, kin1, split);
+    uint32_t *t0 = regions + pool->base[s][a] + done;
+    uint32_t *t1 = overflow + pool->obase[s][a] + (static_cast<int64_t>(done) - static_cast<int64_t>(prim));
+    uint32_t *row = rows + static_cast<size_t>(blockIdx.x) * kMsdSub;
+    uint32_t over;
+    if (valid == kPoolTile && split >= kPoolTile && (reinterpret_cast<uintptr_t>(t0) & 15u) == 0u)  // workgroup-uniform
+        over = pool_tile_b<true>(sm, t0, t1, split, valid, msd->shift, key_base, row);
     else
-        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, false, BitsDigit, StreamReserve, true>(sm, kin0, nullptr, keys_out, nullptr, valid, dg, unused, lb, kin1, split);
+        over = pool_tile_b_general(sm, t0, t1, split, valid, msd->shift, key_base, row);
+    // a key above the probed range (or below the promised floor): the runs kernel, which gives the last verdict, sees this
+    if (__ballot(over != 0u) != 0ull && (threadIdx.x & 63u) == 0u) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Runs: workgroup a = top byte a (256 threads).  The rows of its tiles -> for every bucket (a, c) its 64 run descriptors
+// (slot r = the run of the top byte's r-th tile; slots R .. R + 7 = the overflow piece of a run whose tile crosses its share's
+// primary region's end, one per slice, usually empty; the rest empty), its start in the sorted order, its size.
+__global__ __launch_bounds__(256) void pool_runs_kernel(MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool, const uint32_t *__restrict__ rows,
+                                                        PoolRun *__restrict__ runs, uint32_t n) {
+    __shared__ uint32_t s_rows[kPoolMaxTiles][kMsdSub];
+    __shared__ uint2 s_desc[kMsdSub][kPoolRunSlots + 1];  // [bucket][run slot] (+1: the buckets' rows on different banks)
+    __shared__ uint32_t s_pos[kPoolMaxTiles], s_prim[kPoolMaxTiles], s_base[kPoolMaxTiles], s_obase[kPoolMaxTiles], s_share[kPoolMaxTiles],
+        s_rowidx[kPoolMaxTiles];
+    __shared__ uint32_t s_part[4][kMsdSub], s_tot[kMsdSub];
+    const uint32_t tid = threadIdx.x, a = blockIdx.x, x = a & 7u, e0 = (a >> 3) * 8u;
+    const uint32_t ok_a = pool->ok_a;
+    uint32_t biggest = 0;
+    if (ok_a) {
+        const uint32_t *pt = pool->tiles_b[x];
+        const uint32_t R = pool->top_tiles[a];  // <= kPoolMaxTiles (verdict 1)
+        if (tid < R) {  // run r = tid: which share, which tile of it
+            const uint32_t j = pt[e0] + tid;
+            uint32_t s = 0;
+#pragma unroll
+            for (uint32_t q = 1; q < 8u; ++q) s += pt[e0 + q] <= j ? 1u : 0u;  // entries are non-decreasing: the share whose tiles contain j
+            const uint32_t i = j - pt[e0 + s];
+            const uint32_t keys_sa = msd->cursor_a[s][a];
+            s_share[tid] = s;
+            s_pos[tid] = i * kPoolTile;                               // the tile's first position inside its share
+            s_prim[tid] = min(keys_sa, pool->cap[s][a]);              // positions below this lie in the primary region
+            s_base[tid] = pool->base[s][a];
+            s_obase[tid] = pool->obase[s][a];
+            s_rowidx[tid] = j * 8u + x;                               // the tile's row: the second pass's block index
+        }
+        for (uint32_t w = tid; w < kMsdSub * (kPoolRunSlots + 1u); w += 256u) (&s_desc[0][0])[w] = make_uint2(0, 0);
+        __syncthreads();
+        for (uint32_t w = tid; w < R * kMsdSub; w += 256u)  // the rows, coalesced (14 KB per workgroup)
+            s_rows[w >> kMsdSubBits][w & (kMsdSub - 1u)] = rows[static_cast<size_t>(s_rowidx[w >> kMsdSubBits]) * kMsdSub + (w & (kMsdSub - 1u))];
+        __syncthreads();
+        const uint32_t c = tid & (kMsdSub - 1u), q = tid >> kMsdSubBits;
+        {   // thread (q, c): the runs r in [16 q, 16 q + 16) of bucket (a, c)
+            uint32_t total = 0;
+            for (uint32_t r = 16u * q; r < min(16u * q + 16u, R); ++r) {
+                const uint32_t w = s_rows[r][c];
+                const uint32_t off = w & 0xFFFFu, len = w >> 16;
+                const uint32_t pos = s_pos[r] + off, prim = s_prim[r];
+                uint2 d;
+                if (pos + len <= prim) {
+                    d = make_uint2(s_base[r] + pos, len);
+                } else if (pos >= prim) {
+                    d = make_uint2(n + s_obase[r] + (pos - prim), len);
+                } else {  // the run crosses from the primary region into the overflow region: two pieces (one such tile per share at most)
+                    d = make_uint2(s_base[r] + pos, prim - pos);
+                    s_desc[c][R + s_share[r]] = make_uint2(n + s_obase[r], pos + len - prim);
+                }
+                s_desc[c][r] = d;
+                total += d.y;  // (a crossing run's second piece is counted with the pieces below)
+            }
+            s_part[q][c] = total;
+        }
+        __syncthreads();
+        {   // every run's place inside the bucket: (keys before the run) | (the run's keys) << 16; the pieces behind the runs, the
+            // unused slots behind those (empty, at the bucket's end: the local sort reads the bucket's size off the last slot)
+            uint32_t off = 0;
+            for (uint32_t qq = 0; qq < q; ++qq) off += s_part[qq][c];
+            for (uint32_t r = 16u * q; r < min(16u * q + 16u, R); ++r) {
+                const uint32_t len = s_desc[c][r].y;
+                s_desc[c][r].y = min(off, 0xFFFFu) | (len << 16);  // (a bucket beyond 65535 keys is refused anyway)
+                off += len;
+            }
+            if (q == 3u) {
+                for (uint32_t r = R; r < kPoolRunSlots; ++r) {
+                    const uint32_t len = s_desc[c][r].y;  // (zero but for a crossing run's second piece)
+                    s_desc[c][r].y = min(off, 0xFFFFu) | (len << 16);
+                    off += len;
+                }
+                s_tot[c] = off;  // the bucket's keys
+            }
+        }
+        __syncthreads();
+        if (tid < kMsdSub) {  // where the bucket starts: the top byte's start + the buckets before it
+            const uint32_t total = s_tot[tid];
+            uint32_t incl = total;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o);
+                if (tid >= static_cast<uint32_t>(o)) incl += t;
+            }
+            msd->base[a * kMsdSub + tid] = pool->top_base[a] + incl - total;
+            biggest = total;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) biggest = max(biggest, __shfl_down(biggest, o));
+        }
+        // the descriptors, bucket by bucket: what one local-sort workgroup reads is 512 contiguous bytes
+        uint2 *out = reinterpret_cast<uint2 *>(runs) + static_cast<size_t>(a) * kMsdSub * kPoolRunSlots;
+        for (uint32_t w = tid; w < kMsdSub * kPoolRunSlots; w += 256u) out[w] = s_desc[w / kPoolRunSlots][w % kPoolRunSlots];
+        if (a == 255u && tid == 0) msd->base[kPoolBuckets] = n;
+    }
+    // (verdict 2 is the local sort's: every one of its workgroups reads ok_a, fail and max_bucket -- all final when it starts)
+    if (tid == 0 && biggest) __hip_atomic_fetch_max(&pool->max_bucket, biggest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Local sort: workgroup b = bucket b.  The bucket's keys lie in up to 64 runs.  They are first copied, run by run, into the
+// sort's LDS buffer -- wave w takes runs w, w + WAVES, ...; consecutive lanes read consecutive keys of a run: coalesced, no search
+// -- at word mis + (key's index in the bucket), mis = the misalignment of the bucket's FINAL place: from there every thread reads
+// its 16-byte vectors exactly as lean_sort_bucket (vrs_kernels.hip) reads them from the bucket in global memory.
+struct PoolGather {
+    const uint32_t *regions, *overflow;
+    uint32_t n_virt;
+    // (the pointers cross a function boundary: say that they are GLOBAL ones, or the loads become flat loads)
+    using gptr = const uint32_t __attribute__((address_space(1))) *;
+    __device__ __forceinline__ gptr at(uint32_t v) const { return v < n_virt ? (gptr)regions + v : (gptr)overflow + (v - n_virt); }
+};
+
+// s_keys[mis + g] = key g of the bucket; all threads of the workgroup, ends with a barrier.  dx, dy: lane l holds run l's
+// descriptor (virtual slot of its first key; keys of the bucket before it | its keys << 16) -- every wave has loaded all 64, so a
+// run's descriptor is two v_readlane away and its address a scalar: no LDS, no barrier, no search in front of the loads.
+// (inline: a call would save and restore the callee's registers through scratch, 300 bytes per thread of a kernel with 4 M threads)
+template <int THREADS>
+__device__ __forceinline__ void pool_stage(const PoolGather &gt, uint32_t dx, uint32_t dy, uint32_t *s_keys, uint32_t mis) {
+    constexpr uint32_t WAVES = THREADS / 64, PER = 64 / WAVES;  // runs per wave
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // ALL of the wave's runs at once, three 64-key chunks of each (a run is about 128 keys): every load of the wave is in flight
+    // before the first is written to LDS -- a workgroup lives for one memory latency here, and four would be four.  The loads
+    // are unconditional, from a clamped index (an empty chunk reads its run's last key again: one more hit on a line that is
+    // being read anyway) -- a predicated load is a branch, and a branch costs the loads behind it their overlap.
+    uint32_t x[PER][3];
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t r = wave + u * WAVES;
+        const uint32_t slot = __builtin_amdgcn_readlane(dx, r), len = __builtin_amdgcn_readlane(dy, r) >> 16;
+        const PoolGather::gptr src = gt.at(slot);  // (an empty run's slot is 0: a valid address)
+        const uint32_t last = len ? len - 1u : 0u;
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; ++c) x[u][c] = src[min(c * 64u + lane, last)];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t pk = __builtin_amdgcn_readlane(dy, wave + u * WAVES);
+        const uint32_t len = pk >> 16, dst = mis + (pk & 0xFFFFu);
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; ++c) {
+            const uint32_t idx = c * 64u + lane;
+            if (idx < len) s_keys[dst + idx] = x[u][c];
+        }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t r = wave + u * WAVES;
+        const uint32_t pk = __builtin_amdgcn_readlane(dy, r);
+        if ((pk >> 16) > 192u) {  // a long run (skewed keys; wave-uniform): the rest of it, 64 keys at a time
+            const PoolGather::gptr src = gt.at(__builtin_amdgcn_readlane(dx, r));
+            const uint32_t dst = mis + (pk & 0xFFFFu);
+            for (uint32_t idx = 192u + lane; idx < (pk >> 16); idx += 64u) s_keys[dst + idx] = src[idx];
+        }
+    }
+    __syncthreads();
+}
+
+template <int THREADS, int VEC>
+__device__ __forceinline__ void pool_read_staged(uint32_t (&k)[4 * VEC], const uint32_t *s_keys, uint32_t nvec) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        uint32_t v = j * THREADS + threadIdx.x;
+        if (j == VEC - 1) v = v < nvec ? v : nvec - 1u;  // only the last row can reach behind the bucket
+        const uint4 t = reinterpret_cast<const uint4 *>(s_keys)[v];
+        k[4 * j] = t.x;
+        k[4 * j + 1] = t.y;
+        k[4 * j + 2] = t.z;
+        k[4 * j + 3] = t.w;
+    }
+}
+
+template <int THREADS, int VEC>
+__device__ __attribute__((noinline)) void pool_sort_guarded(const PoolGather gt, uint32_t dx, uint32_t dy, uint32_t *abase, uint32_t mis, uint32_t n,
+                                                           uint32_t *s_keys, uint32_t *s_hist2, uint32_t *s_tmp, uint32_t guards) {
+    // (the common path has consumed the staged keys' registers: stage again -- run by run, in a loop: this function's registers
+    // are the KERNEL's registers, whichever path a bucket takes, and the form of pool_stage with every load in flight at once
+    // would cost every workgroup its occupancy)
+    __syncthreads();
+    {
+        constexpr uint32_t WAVES = THREADS / 64;
+        const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll 1
+        for (uint32_t r = wave; r < kPoolRunSlots; r += WAVES) {
+            const uint32_t pk = __builtin_amdgcn_readlane(dy, r);
+            const PoolGather::gptr src = gt.at(__builtin_amdgcn_readlane(dx, r));
+            const uint32_t dst = mis + (pk & 0xFFFFu);
+#pragma unroll 1
+            for (uint32_t idx = lane; idx < (pk >> 16); idx += 64u) s_keys[dst + idx] = src[idx];
+        }
+        __syncthreads();
+    }
+    uint32_t k[4 * VEC];
+    pool_read_staged<THREADS, VEC>(k, s_keys, (mis + n + 3u) / 4u);
+    __syncthreads();  // every vector is in registers before pass 1 writes the buffer
+    lean_sort_body<THREADS, VEC, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, (guards & 1u) != 0u, (guards & 2u) != 0u);
+}
+
+template <int THREADS, int VEC>
+__device__ __forceinline__ void pool_sort_bucket(const PoolGather &gt, uint32_t dx, uint32_t dy, uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
+                                                 uint32_t *s_hist2, uint32_t *s_tmp) {
+    constexpr int WAVES = THREADS / 64;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t k[4 * VEC];
+    pool_read_staged<THREADS, VEC>(k, s_keys, (mis + n + 3u) / 4u);
+    {   // every counter table zeroed here (lean_sort_bucket does the same): WAVES tables of pass 2, then pass 1's
+        constexpr uint32_t kVecs = (WAVES + 1) * kLeanRow / 4;
+        for (uint32_t c = tid; c < kVecs; c += THREADS) reinterpret_cast<uint4 *>(s_hist2)[c] = make_uint4(0, 0, 0, 0);
+    }
+    {   // does some instruction of this wave's first row put half its lanes on one counter?  bit 0: pass 1, bit 1: pass 2
+        uint32_t skew = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t a1 = k[c] & 511u, a2 = (k[c] >> 9) & 511u;
+            skew |= __popcll(__ballot(a1 == __builtin_amdgcn_readfirstlane(a1))) >= 32 ? 1u : 0u;
+            skew |= __popcll(__ballot(a2 == __builtin_amdgcn_readfirstlane(a2))) >= 32 ? 2u : 0u;
+        }
+        if (lane == 0u) s_tmp[16 + wave] = skew;
+    }
+    __syncthreads();  // (also: every vector is in registers before pass 1 writes the buffer)
+    uint32_t guards = 0;
+#pragma unroll
+    for (int v = 0; v < WAVES; ++v) guards |= s_tmp[16 + v];
+    guards = __builtin_amdgcn_readfirstlane(guards);
+    // (two copies of the rest, the guarded one out of line and staging again: see lean_sort_bucket, vrs_kernels.hip)
+    if (guards == 0u) lean_sort_body<THREADS, VEC, false>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false);
+    else pool_sort_guarded<THREADS, VEC>(gt, dx, dy, abase, mis, n, s_keys, s_hist2, s_tmp, guards);
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void pool_local_sort_kernel(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
+                                                                     uint32_t *__restrict__ keys_out, uint32_t n_virt, MsdPlan *__restrict__ msd,
+                                                                     const PoolPlan *__restrict__ pool, const PoolRun *__restrict__ runs,
+                                                                     uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
+                                                                     OnesweepPlanHead *host_head, uint32_t stamp) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * kLeanMaxVec + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
+    __shared__ uint32_t s_tmp[32];
+    // Verdict 2, by every workgroup from the same three words (all final when this kernel starts): verdict 1 said yes, no pass
+    // flagged the sort, and the largest bucket fits this kernel's shape.  Workgroup 0 tells the host.
+    const uint32_t mx = pool->max_bucket;
+    const uint32_t ok = (pool->ok_a != 0u && pool->fail == 0u && mx <= THREADS * 4u * kLeanMaxVec - 3u) ? 1u : 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        msd->ok = ok;
+        dev_head->msd_ok = ok;
+        dev_head->msd_max_bucket = mx;
+        dev_head->lsd_missing = 1u;
+        if (host_head) {
+            __hip_atomic_store(&host_head->lsd_missing, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_head->msd_ok, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_head->msd_max_bucket, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (ok == 0u) return;  // (enqueued before the verdicts were known, and one said no)
+    {   // the first pass's cursors, zero for the next sort (the counted form's local sort does the same: rearm_reservation)
+        const uint32_t b = blockIdx.x;
+        if (b < 2u * kStreams)
+            for (uint32_t c = threadIdx.x; c < 256u; c += THREADS) cursors[b * 256u + c] = 0;
+    }
+    const uint32_t b = blockIdx.x;
+    const uint32_t begin = msd->base[b];
+    // every wave: lane l = run l's descriptor (512 contiguous bytes of the table)
+    const uint2 d = reinterpret_cast<const uint2 *>(runs)[static_cast<size_t>(b) * kPoolRunSlots + (threadIdx.x & 63u)];
+    const uint32_t pk63 = __builtin_amdgcn_readlane(d.y, 63);
+    const uint32_t n = (pk63 & 0xFFFFu) + (pk63 >> 16);
+    const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys_out + begin) >> 2) & 3u);
+    if (n == 0 || mis + n > THREADS * 4u * kLeanMaxVec) return;  // uniform; above the capacity cannot happen (verdict 2 would have said no)
+    uint32_t *abase = keys_out + begin - mis;
+    const PoolGather gt{regions, overflow, n_virt};
+    pool_stage<THREADS>(gt, d.x, d.y, s_keys, mis);
+    switch ((mis + n + 4u * THREADS - 1u) / (4u * THREADS)) {  // rows of THREADS vectors the bucket touches
+        case 1: pool_sort_bucket<THREADS, 1>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 2: pool_sort_bucket<THREADS, 2>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 3: pool_sort_bucket<THREADS, 3>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 4: pool_sort_bucket<THREADS, 4>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 5: pool_sort_bucket<THREADS, 5>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 6: pool_sort_bucket<THREADS, 6>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        default: pool_sort_bucket<THREADS, 7>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
+    }
 }
 
 }  // namespace
@@ -764,46 +833,59 @@ uint32_t pool_overflow_capacity(uint32_t n) {
     return static_cast<uint32_t>(std::min<double>(room, 1u << 28)) & ~31u;
 }
 
-uint32_t pool_tiles_b_cap(uint32_t n, bool blind) {
+uint32_t pool_tiles_b_cap(uint32_t n) {
     const uint32_t tiles = (n + kPoolTile - 1u) / kPoolTile, even = (tiles + 7u) / 8u;
-    // an XCD walks 32 top bytes x 8 shares, each rounded up to whole tiles; blind, the grid IS the cap: little slack
-    return (blind ? even + even / 16u : even + even / 4u) + 256u + 40u;
+    // an XCD walks 32 top bytes x 8 shares, each rounded up to whole tiles; the grid is sized before the plan is known
+    return even + even / 8u + 256u + 40u;
 }
+
+size_t pool_rows_bytes(uint32_t n) { return static_cast<size_t>(8u) * pool_tiles_b_cap(n) * kMsdSub * sizeof(uint32_t); }
+
+uint32_t pool_local_capacity(bool big) { return (big ? 512u : 256u) * 4u * kLeanMaxVec - 3u; }
 
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
                               PoolPlan *pool, uint32_t overflow_capacity, LaunchEvents ev) {
-    if (n == 0) return hipErrorInvalidValue;
+    if (n == 0 || ps.tiles_per_stream < kPoolSampleTiles) return hipErrorInvalidValue;  // (a sample workgroup's tiles span at most two slices)
     const uint32_t grid = (ps.tiles_total + kPoolSampleTiles - 1u) / kPoolSampleTiles;
     VRS_LAUNCH(pool_sample_kernel, dim3(grid), dim3(256), stream, ev, keys, n, key_base, ps, pool, overflow_capacity);
     return hipGetLastError();
 }
 
 hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, uint32_t *overflow, uint32_t n,
-                              uint32_t key_base, const PoolStreams &ps, PoolPlan *pool, MsdPlan *msd, uint32_t *hist,
-                              unsigned long long xcc_map, int compute_units, bool misplace, uint32_t overflow_capacity, LaunchEvents ev) {
-    // two 512-thread workgroups per CU, an eighth of them per slice -- no more than the slice has tiles
-#ifndef VRS_POOL_LAB_WGS_PER_CU
-#define VRS_POOL_LAB_WGS_PER_CU 2
-#endif
-    const uint32_t resident = std::max<uint32_t>(static_cast<uint32_t>(compute_units) * VRS_POOL_LAB_WGS_PER_CU / 8u, 1u);
-    const uint32_t wgs = std::min(resident, ps.tiles_per_stream);
-    VRS_LAUNCH(pool_pass_a_kernel, dim3(8u * wgs), dim3(512), stream, ev, keys_in, keys_out, overflow, n, key_base, ps, pool, msd, hist,
-               xcc_map, wgs, misplace ? 1 : 0, overflow_capacity);
+                              uint32_t key_base, const PoolStreams &ps, PoolPlan *pool, MsdPlan *msd, unsigned long long xcc_map,
+                              bool misplace, uint32_t overflow_capacity, LaunchEvents ev) {
+    VRS_LAUNCH(pool_pass_a_kernel, dim3(8u * ps.tiles_per_stream), dim3(512), stream, ev, keys_in, keys_out, overflow, n, key_base, ps, pool, msd,
+               xcc_map, misplace ? 1 : 0, overflow_capacity);
     return hipGetLastError();
 }
 
-hipError_t launch_pool_plan(hipStream_t stream, uint32_t *hist, MsdPlan *msd, PoolPlan *pool, OnesweepPlanHead *dev_head,
-                            OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tiles_b_cap, uint32_t local_cap,
-                            uint32_t *host_log) {
-    hipLaunchKernelGGL(pool_plan_kernel, dim3(1), dim3(1024), 0, stream, hist, msd, pool, dev_head, host_head, stamp, n, tiles_b_cap,
-                       local_cap, host_log);
+hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap) {
+    hipLaunchKernelGGL(pool_plan_kernel, dim3(1), dim3(256), 0, stream, msd, pool, n, tiles_b_cap);
     return hipGetLastError();
 }
 
-hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *keys_out, MsdPlan *msd,
-                              const PoolPlan *pool, uint32_t tiles_b, unsigned long long xcc_map, uint32_t key_base, LaunchEvents ev) {
+hipError_t launch_pool_pass_b(hipStream_t stream, uint32_t *regions, uint32_t *overflow, uint32_t n, MsdPlan *msd, PoolPlan *pool,
+                              uint32_t *rows, uint32_t tiles_b, uint32_t key_base, LaunchEvents ev) {
+    (void)n;
     if (tiles_b == 0) return hipSuccess;
-    VRS_LAUNCH(pool_pass_b_kernel, dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, keys_out, msd, pool, xcc_map, key_base);
+    VRS_LAUNCH(pool_pass_b_kernel, dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, msd, pool, rows, key_base);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_runs(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, const uint32_t *rows, PoolRun *runs, uint32_t n) {
+    hipLaunchKernelGGL(pool_runs_kernel, dim3(256), dim3(256), 0, stream, msd, pool, rows, runs, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *keys_out, uint32_t n,
+                                  MsdPlan *msd, const PoolPlan *pool, const PoolRun *runs, bool big, OnesweepPlanHead *dev_head,
+                                  OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev) {
+    if (big)
+        VRS_LAUNCH(pool_local_sort_kernel<512>, dim3(kMsdBucketCount), dim3(512), stream, ev, regions, overflow, keys_out, n, msd, pool, runs,
+                   &msd->cursor_a[0][0], dev_head, host_head, stamp);
+    else
+        VRS_LAUNCH(pool_local_sort_kernel<256>, dim3(kMsdBucketCount), dim3(256), stream, ev, regions, overflow, keys_out, n, msd, pool, runs,
+                   &msd->cursor_a[0][0], dev_head, host_head, stamp);
     return hipGetLastError();
 }
 
