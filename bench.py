@@ -33,6 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s
 BYTES_PER_KEY_SORT = 48  # 4 passes x (histogram read 4 + scatter read 4 + scatter write 4)   SURVEY.md section 8d
 BYTES_PER_KEY_SORT_ONE_READ = 36  # one counting read 4 + 4 passes x (scatter read 4 + scatter write 4): SURVEY.md section 8d's rule
 BYTES_PER_KEY_SORT_HYBRID = 28  # one counting read 4 + 2 MSD scatter passes x 8 + the LDS-local bucket sort (read 4 + write 4)
+BYTES_PER_KEY_SORT_POOL = 24  # the hybrid form without the counting read (vrs_msd_pool.hip): 2 MSD passes x 8 + the gathering local sort 8
+#                               (+ 0.125: the sample reads 1/32 of the keys -- not counted, like the table traffic of the other forms)
 BYTES_PER_KEY_SCATTER = 8  # the dominant kernel of either path, per launch: read 4 + write 4
 
 
@@ -153,6 +155,11 @@ def bench_single(args):
         gpu.check(gpu.lib.vrs_one_call_hybrid_sorts(gpu.handle, ctypes.byref(h)))
         return h.value
 
+    def pool_sorts():  # (sorts that took the pool form, sorts whose pool form a verdict refused)
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        gpu.check(gpu.lib.vrs_one_call_pool_sorts(gpu.handle, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def hybrid_recounts():  # sorts that needed a second counting read (fast count, then a refused hybrid form)
         h = ctypes.c_uint64()
         gpu.check(gpu.lib.vrs_one_call_hybrid_recounts(gpu.handle, ctypes.byref(h)))
@@ -193,10 +200,12 @@ def bench_single(args):
 
     # ---- timed region: exactly K steps, inputs resident.  The dominant kernel's launches of every 4th step carry HIP events
     # on their own dispatch packets, on the stream they are launched on; nothing else is instrumented.
-    hybrid_before, recounts_before = hybrid_sorts(), hybrid_recounts()
+    hybrid_before, recounts_before, pool_before = hybrid_sorts(), hybrid_recounts(), pool_sorts()
     elapsed, kernels = run_steps(primary, K, 1 << dominant_id, every=args.event_every)
-    hybrid_steps = hybrid_sorts() - hybrid_before  # K if every timed one-call sort took the hybrid form, 0 if none did
+    hybrid_steps = hybrid_sorts() - hybrid_before  # K if every timed one-call sort took a hybrid form (pool or counted), 0 if none did
     recount_steps = hybrid_recounts() - recounts_before
+    pool_after = pool_sorts()
+    pool_steps, pool_refused = pool_after[0] - pool_before[0], pool_after[1] - pool_before[1]
     # the timed region's own outputs, every one of them, before anything overwrites them (one device read each)
     fingerprints = [p_.verifyKeys(n)[1:] for p_ in pristine]
     timed_bad = [i for i in range(K)
@@ -274,10 +283,13 @@ def bench_single(args):
         copy_times.append(time.perf_counter() - t0)
     copy_gbps = 2 * 4 * n / min(copy_times[1:]) / 1e9
 
-    if one_call and hybrid_steps not in (0, K):
-        raise SystemExit(f"the timed steps mixed the two forms of the one-call sort ({hybrid_steps} of {K} hybrid)")
+    if one_call and (hybrid_steps not in (0, K) or pool_steps not in (0, K) or pool_refused):
+        raise SystemExit(f"the timed steps mixed the forms of the one-call sort ({hybrid_steps} of {K} hybrid, {pool_steps} pool, {pool_refused} refused)")
     hybrid = one_call and hybrid_steps == K
-    bytes_per_key_sort = {"one_call": BYTES_PER_KEY_SORT_HYBRID if (hybrid or other_hybrid) else BYTES_PER_KEY_SORT_ONE_READ,
+    pool = hybrid and pool_steps == K
+    other_pool = (not one_call) and other_hybrid and pool_sorts()[0] - pool_after[0] >= K
+    bytes_per_key_sort = {"one_call": BYTES_PER_KEY_SORT_POOL if (pool or other_pool) else BYTES_PER_KEY_SORT_HYBRID if (hybrid or other_hybrid)
+                          else BYTES_PER_KEY_SORT_ONE_READ,
                           "contract": BYTES_PER_KEY_SORT}
     dom_us = kernels.get(dominant_name, {}).get("avg_us")
     traffic, traffic_detail = load_traffic_profile(dominant_name, BYTES_PER_KEY_SCATTER * n) if n == 10 ** 8 else (None, {"note": "committed for N = 10^8 only"})
@@ -295,7 +307,11 @@ def bench_single(args):
                                            "note": "K further steps, each bracketed by a queue-idle wait (outside the timed region)"},
         "config": {"workload": f"BASELINE.json configs[{ {10 ** 7: 1, 10 ** 8: 2}.get(n, 2) }]: {n} uniform random uint32 keys (std::mt19937 seeds 1,2,3), "
                                f"multi_radixsort, 1xMI355X, keys resident in HBM",
-                   "path": (("vrs_sort_keys_u32, hybrid form: one counting read of the keys, an MSD partition by the top 14 bits in "
+                   "path": ("vrs_sort_keys_u32, pool form -- the hybrid form without a counting read: a sample of 1/32 of the keys sizes a region "
+                            "per (input slice, top byte); the first MSD pass (8 bits) reserves its output there, the second (6 bits) groups every "
+                            "tile in place, the local sort gathers every bucket's runs, sorts them by their low 18 bits inside LDS and writes them to "
+                            "their final place (24 B/key)") if pool else
+                           (("vrs_sort_keys_u32, hybrid form: one counting read of the keys, an MSD partition by the top 14 bits in "
                              "two stable scatter passes with decoupled look-back (8 + 6 bits), then every bucket sorted by its "
                              "low 18 bits inside one workgroup's LDS (28 B/key); " + str(recount_steps) + " of the timed sorts "
                              "needed a second counting read") if hybrid else
@@ -308,7 +324,9 @@ def bench_single(args):
                    "rank_mode": {1: "ballot", 2: "lds_atomic"}[gpu.lib.vrs_rank_mode(gpu.handle)], "device": dev_name,
                    "compute_units": cus},
         "roofline": {"bound": "hbm", "kernel": f"{dominant_name} (one launch per scatter pass: reads and writes every key once"
-                                               + ("; two launches per sort in the hybrid form -- onesweep_scatter_kernel and msd_pass_b_kernel, whose tiles take their "
+                                               + ("; two launches per sort in the pool form -- pool_pass_a_kernel (reserves in sampled regions) and "
+                                                  "pool_pass_b_kernel (groups every tile in place) -- about half of the step" if pool else
+                                                  "; two launches per sort in the hybrid form -- onesweep_scatter_kernel and msd_pass_b_kernel, whose tiles take their "
                                                   "places by reservation (bare keys; payloads: decoupled look-back) -- 47 % of the step" if hybrid else "") + ")",
                      "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,

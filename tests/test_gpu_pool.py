@@ -1,0 +1,202 @@
+"""GPU parity tests of the pool form of vrs_sort_keys_u32 (vrs_msd_pool.hip): the hybrid form WITHOUT a counting read --
+a sample sizes a region per (input slice, top byte), the first MSD pass reserves its output there, the second groups every tile
+in place, the local sort gathers every bucket's runs (24 instead of 28 bytes per key).  The reference counts the keys once
+per pass (multi_radixsort_histograms.comp:42-50); here they are not counted at all, and the acceptance criterion stays the
+reference's own: the output equals std::sort, bit for bit (MultiRadixSort.cpp:141-161).  Whatever the sample misjudges -- a
+region, the key range, a bucket's size -- must end in a refusal and a counted sort of the untouched input, never in a wrong
+result."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import vkradixsort_amd as vrs
+from vkradixsort_amd import capi
+
+from .test_gpu_one_call import launches, make_keys
+
+pytestmark = pytest.mark.gpu
+S = vrs.Buffer.BufferSettings
+POOL_MIN = 1 << 22  # the form's own floor (the default threshold is 3.2e7 keys: below it the counted form is the faster one)
+
+
+def pool_counts(ctx):
+    a, b = ctypes.c_uint64(), ctypes.c_uint64()
+    ctx.check(ctx.lib.vrs_one_call_pool_sorts(ctx.handle, ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
+
+
+def pool_keys(n, dist, seed):
+    rs = np.random.RandomState(seed)
+    if dist == "gauss":  # top bytes far from uniform, but the same everywhere in the input: the sample sizes every region right
+        return np.clip(rs.normal(2.0 ** 31, 2.0 ** 28, size=n), 0, 2.0 ** 32 - 1).astype(np.uint32)
+    if dist == "halves":  # the input's first half holds small keys, the second large ones: the slices' regions differ
+        k = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+        k[: n // 2] >>= np.uint32(1)
+        k[n // 2:] |= np.uint32(0x80000000)
+        return k
+    if dist == "tile_period":  # the sampled head of every 8192-key tile is unlike the rest of it: every region is misjudged
+        k = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+        t = np.arange(n) % 8192
+        return np.where(t < 256, k >> np.uint32(1), k | np.uint32(0x80000000)).astype(np.uint32)
+    if dist == "dups":  # 256 distinct low parts per bucket: many ties inside every bucket
+        k = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+        return (k & np.uint32(0xFFFC0000)) | (k & np.uint32(0xFF))
+    if dist == "hot_bucket":  # one bucket with 0.33 % of the keys: above the local sort's capacity, verdict 2 must say no
+        k = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+        k[: n // 300] = (k[: n // 300] & np.uint32(0x3FFFF)) | np.uint32(0x12340000)
+        return k
+    if dist == "rare_high_bit":  # 28-bit keys except three that use bit 31: the probe misses them, the second pass must not
+        k = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32) >> np.uint32(4)
+        k[[5, n // 2 + 1, n - 2]] |= np.uint32(0x80000000)
+        return k
+    if dist == "24bit":
+        return rs.randint(0, 2 ** 32, size=n, dtype=np.uint32) >> np.uint32(8)
+    return make_keys(n, dist, seed)
+
+
+@pytest.fixture
+def pool_ctx(gpu_context):
+    """the shared context with the pool form forced at test sizes; everything restored afterwards"""
+    ctx = gpu_context
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, POOL_MIN)
+    ctx.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, POOL_MIN)
+    ctx.setTuning(capi.VRS_TUNE_MSD_POOL, 2)
+    yield ctx
+    ctx.setTuning(capi.VRS_TUNE_MSD_POOL, 1)
+    ctx.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 32000000)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 0)
+    ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 0)
+    ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 0)
+
+
+def sort_and_stats(ctx, keys, key_floor=None):
+    n = keys.size
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)
+    k1 = vrs.Buffer(ctx, S(4 * n))
+    ctx.profileReset()
+    ctx.profileEnable(True)
+    before = pool_counts(ctx)
+    try:
+        if key_floor is None:
+            ctx.check(ctx.lib.vrs_sort_keys_u32(ctx.handle, k0.handle, k1.handle, n))
+        else:
+            ctx.check(ctx.lib.vrs_sort_keys_u32_ranged(ctx.handle, k0.handle, k1.handle, n, key_floor))
+        out = np.empty(n, np.uint32)
+        k0.downloadWithStagingBuffer(out)
+        stats = {name: launches(ctx, kid) for kid, name in capi.KERNEL_NAMES.items()}
+    finally:
+        ctx.profileEnable(False)
+        k0.release()
+        k1.release()
+    after = pool_counts(ctx)
+    return out, stats, (after[0] - before[0], after[1] - before[1])
+
+
+TAKEN = ["uniform", "28bit", "gauss", "halves", "dups"]
+REFUSED = ["24bit", "const", "tile_period", "hot_bucket", "rare_high_bit", "two_values", "max_keys"]
+
+
+@pytest.mark.parametrize("dist", TAKEN)
+@pytest.mark.parametrize("n", [POOL_MIN + 5, 9000001, 30000001])
+def test_pool_form_equals_std_sort(pool_ctx, oracle, n, dist):
+    keys = pool_keys(n, dist, seed=n % 997)
+    out, stats, (took, refused) = sort_and_stats(pool_ctx, keys)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    # the form really ran, and nothing was counted ahead: a sample, two passes, the gathering local sort
+    assert (took, refused) == (1, 0)
+    assert stats["pool_sample"] == 1 and stats["digit_tables"] == 0 and stats["lookback_scatter"] == 2 and stats["local_sort"] == 1
+
+
+@pytest.mark.parametrize("dist", REFUSED)
+def test_pool_form_refuses_and_the_counted_form_sorts_the_untouched_input(pool_ctx, oracle, dist):
+    n = 12000003
+    keys = pool_keys(n, dist, seed=11)
+    out, stats, (took, refused) = sort_and_stats(pool_ctx, keys)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    assert (took, refused) == (0, 1)
+    assert stats["digit_tables"] >= 1  # the counted form (hybrid or LSD) ran after the refusal
+
+
+@pytest.mark.parametrize("dist", ["sorted", "reverse", "clustered"])
+def test_pool_form_on_ordered_input_is_exact_whatever_the_verdict(pool_ctx, oracle, dist):
+    """sorted input: every slice holds 32 of the 256 top bytes -- the regions follow (the sample sees every tile); whether a
+    verdict refuses is the form's business, the result is not"""
+    n = 16000001
+    keys = pool_keys(n, dist, seed=5)
+    out, _, (took, refused) = sort_and_stats(pool_ctx, keys)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    assert took + refused == 1
+
+
+def test_pool_form_with_workgroups_off_their_slices(pool_ctx, oracle):
+    """test hook: odd tiles of the first pass are read from the neighbouring slice (the row of cursors a workgroup adds to
+    follows the XCC it runs on, not the slice it reads)"""
+    n = 20000003
+    keys = pool_keys(n, "uniform", seed=3)
+    pool_ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 1)
+    out, _, (took, refused) = sort_and_stats(pool_ctx, keys)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    assert took + refused == 1
+    # slices with different key ranges: the neighbour's keys do not fit the regions the sample sized -- refused, still exact
+    keys = pool_keys(n, "halves", seed=4)
+    out, _, (took, refused) = sort_and_stats(pool_ctx, keys)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    assert took + refused == 1
+
+
+def test_pool_form_enqueue_only(pool_ctx, oracle):
+    """VRS_TUNE_ASYNC_SORT: the call returns with the whole form enqueued; a refusal is handled by the settle"""
+    pool_ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)
+    for dist in ("uniform", "tile_period"):
+        keys = pool_keys(10000019, dist, seed=8)
+        out, _, (took, refused) = sort_and_stats(pool_ctx, keys)
+        assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+        assert (took, refused) == ((1, 0) if dist == "uniform" else (0, 1))
+
+
+def test_pool_form_of_a_ranged_sort(pool_ctx, oracle):
+    """vrs_sort_keys_u32_ranged: buckets and digits are taken from key - floor; a key below the promised floor refuses"""
+    n = 10000007
+    rs = np.random.RandomState(21)
+    keys = (np.uint32(0x30000000) + rs.randint(0, 1 << 28, size=n, dtype=np.uint32)).astype(np.uint32)
+    out, stats, (took, refused) = sort_and_stats(pool_ctx, keys, key_floor=0x30000000)
+    assert np.array_equal(out, np.sort(keys)) and (took, refused) == (1, 0) and stats["digit_tables"] == 0
+    keys[12345] = 0x2FFFFFFF  # below the floor
+    out, _, (took, refused) = sort_and_stats(pool_ctx, keys, key_floor=0x30000000)
+    assert np.array_equal(out, np.sort(keys)) and (took, refused) == (0, 1)
+
+
+def test_pool_and_counted_forms_alternate_on_one_context(pool_ctx, oracle):
+    """the forms share the reservation counters, the bucket histogram's memory and the plan: whatever order they run in"""
+    ctx = pool_ctx
+    for i, (mode, dist) in enumerate([(2, "uniform"), (0, "uniform"), (2, "tile_period"), (2, "gauss"), (0, "28bit"), (2, "28bit"), (2, "hot_bucket"),
+                                      (2, "uniform")]):
+        ctx.setTuning(capi.VRS_TUNE_MSD_POOL, mode)
+        keys = pool_keys(6000011 + 4099 * i, dist, seed=30 + i)
+        out, _, _ = sort_and_stats(ctx, keys)
+        assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1, (i, mode, dist)
+
+
+def test_pool_form_adaptive_mode_backs_off_after_a_refusal(pool_ctx, oracle):
+    """VRS_TUNE_MSD_POOL = 1 (the default): after a refusal the next 15 hybrid-capable sorts of bare keys take the counted form"""
+    ctx = pool_ctx
+    ctx.setTuning(capi.VRS_TUNE_MSD_POOL, 1)
+    bad, good = pool_keys(POOL_MIN + 77, "tile_period", seed=2), pool_keys(POOL_MIN + 77, "uniform", seed=2)
+    _, _, first = sort_and_stats(ctx, bad)
+    assert first == (0, 1)
+    for _ in range(15):
+        out, _, c = sort_and_stats(ctx, good)
+        assert c == (0, 0) and np.array_equal(out, np.sort(good))
+    out, _, c = sort_and_stats(ctx, good)
+    assert c == (1, 0) and np.array_equal(out, np.sort(good))
+
+
+def test_pool_form_default_at_1e8_keys(gpu_context, oracle):
+    """BASELINE.json configs[2] with the library's defaults: the pool form, 24 B/key"""
+    n = 10 ** 8
+    keys = np.random.RandomState(2).randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    gpu_context.setTuning(capi.VRS_TUNE_MSD_POOL, 1)
+    out, stats, (took, refused) = sort_and_stats(gpu_context, keys)
+    assert (took, refused) == (1, 0) and stats["digit_tables"] == 0 and stats["pool_sample"] == 1
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1

@@ -61,6 +61,7 @@ def run_cases():
     with vrs.GPUContext(0) as gpu:
         lib = gpu.lib
         gpu.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 1 << 22)
         for n, dist in cases:
             keys = make(n, dist, rs)
             ref = np.sort(keys)

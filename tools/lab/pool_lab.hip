@@ -82,7 +82,7 @@ int main(int argc, char **argv) {
         hipLaunchKernelGGL(check_sorted, dim3(2048), dim3(256), 0, st, in, n, chk + 2);  // chk[3] = key sum of the input
         CK(hipMemsetAsync(reinterpret_cast<char *>(msd) + offsetof(vrs::MsdPlan, cursor_a), 0, vrs::kMsdCursorBytes, st));
         CK(hipEventRecord(ev[0], st));
-        CK(vrs::launch_pool_sample(st, in, n, 0, ps, pool, room));
+        CK(vrs::launch_pool_sample(st, in, n, 0, ps, pool, room));  // (sample + layout kernels)
         CK(hipEventRecord(ev[1], st));
         CK(vrs::launch_pool_pass_a(st, in, partner, ovf, n, 0, ps, pool, msd, xcc_map, false, room));
         CK(hipEventRecord(ev[2], st));

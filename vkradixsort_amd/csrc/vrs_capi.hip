@@ -721,7 +721,7 @@ static int contract_pass(vrs_context ctx, vrs_buffer kin, vrs_buffer kout, vrs_b
 // there already, or microseconds away), then the thread yields between looks, sleeping a little longer each time, and asks
 // the stream now and then so that a faulted queue surfaces as an error instead of an endless wait.  Bounded in time
 // (VRS_TUNE_PLAN_WAIT_MS, default 60 s): a stream stuck behind work that never finishes returns VRS_ERROR_TIMEOUT.
-static int wait_for_host_word(vrs_context ctx, const std::function<bool()> &arrived) {
+static int wait_for_host_word(vrs_context ctx, const std::function<bool()> &arrived, bool *never = nullptr) {
     for (int spins = 0; spins < 20000; ++spins) {  // ~50-100 us
         if (arrived()) return VRS_OK;
 #if defined(__x86_64__) || defined(__i386__)
@@ -738,6 +738,7 @@ static int wait_for_host_word(vrs_context ctx, const std::function<bool()> &arri
             const hipError_t q = hipStreamQuery(ctx->stream);
             if (q == hipSuccess) {  // everything enqueued has run: the stamp must be there
                 if (arrived()) return VRS_OK;
+                if (never) *never = true;
                 return fail(ctx, VRS_ERROR_HIP, "the one-call sort's plan never arrived on the host");
             }
             if (q != hipErrorNotReady) return fail_hip(ctx, "hipStreamQuery (waiting for the sort plan)", q);
@@ -1541,20 +1542,24 @@ int vrs_msd_finish_status_at(vrs_context ctx, uint32_t ticket, int *took) {
     if (!ctx || !took) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "context or took is NULL");
     *took = 0;
     if (ticket == 0 || !ctx->os_host_head) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "not a ticket of vrs_msd_finish_ticket");
+    // stamps count up: a ticket ahead of the last finish this context enqueued was never handed out (nothing would ever write its word)
+    if (ctx->os_msd_half_stamp == 0 || static_cast<int32_t>(ticket - ctx->os_msd_half_stamp) > 0)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "not a ticket of vrs_msd_finish_ticket");
     // The log word of a ticket is (stamp % 32): only plans of vrs_msd_finish_* write the log, so the word keeps this ticket's
     // decision until ANOTHER finish plan whose stamp is congruent to it is made -- however many plans of other kinds (partitions,
     // ranged sorts, recounts) come in between.  The word itself says whose decision it holds.
     VRS_HIP(ctx, hipSetDevice(ctx->device));
     volatile uint32_t *word = reinterpret_cast<volatile uint32_t *>(ctx->os_host_head + 1) + (ticket & (vrs::kMsdLogWords - 1u));
     const uint32_t want = ticket << 1;
-    bool overwritten = false;
+    bool overwritten = false, never = false;
     const int rc = wait_for_host_word(ctx, [&] {
         const uint32_t w = __atomic_load_n(word, __ATOMIC_ACQUIRE);
         if ((w & ~1u) == want) return true;
         // a later plan's decision in this word (stamps count up; a word that is zero or older has not been written yet)
         overwritten = w != 0u && static_cast<int32_t>((w >> 1) - (ticket & 0x7FFFFFFFu)) > 0;
         return overwritten;
-    });
+    }, &never);
+    if (never) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "not a ticket of vrs_msd_finish_ticket, or one too old: the stream is idle and the log does not hold its decision");
     if (rc) return rc;
     if (overwritten) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "ticket too old: a later vrs_msd_finish plan has taken its place in the log");
     *took = static_cast<int>(*word & 1u);

@@ -49,12 +49,11 @@ __device__ __forceinline__ uint32_t xcc_of(unsigned long long xcc_map, uint32_t 
 // ---------------------------------------------------------------------------------------------
 // The sample.  Workgroup g takes tiles [32 g, 32 g + 32) of the input; wave w of it the tiles 32 g + w + 4 j.
 __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t key_base,
-                                                          PoolStreams ps, PoolPlan *__restrict__ pool, uint32_t overflow_capacity) {
+                                                          PoolStreams ps, PoolPlan *__restrict__ pool) {
     constexpr int kPerWave = kPoolSampleTiles / 4;        // tiles per wave
     constexpr int kLoads = kPoolSampleKeys / 64;          // 4-byte loads per lane and tile
     __shared__ uint32_t s_hist[2][256];
-    __shared__ uint32_t s_or, s_last;
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_or;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     s_hist[0][tid] = 0;
     s_hist[1][tid] = 0;
@@ -109,24 +108,21 @@ __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__rest
         const uint32_t v = s_hist[h][tid];
         if (v) __hip_atomic_fetch_add(&pool->sample[s0 + h][tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // The workgroup that finishes LAST lays the regions out.  Everything handed over is an agent-scope atomic on both sides
-    // (the counts above, the ticket, the loads below), performed where every XCD sees it: no fence is needed, only that
-    // this workgroup's adds have been performed before its ticket is drawn (vmcnt(0) in every wave, then the barrier).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t ticket = __hip_atomic_fetch_add(&pool->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == gridDim.x - 1u ? 1u : 0u;
-        if (s_last) __hip_atomic_store(&pool->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
+    if (blockIdx.x == 0 && tid == 0) pool->shift = shift;  // (every workgroup derived the same)
+}
+
+// The regions, from the sample: ONE workgroup of 256 threads, thread d = top byte d of all eight slices.  (A kernel of its own:
+// as the sample kernel's last workgroup -- a ticket, which needs every workgroup's adds acknowledged first -- it took 13 us.)
+__global__ __launch_bounds__(256) void pool_layout_kernel(PoolStreams ps, PoolPlan *__restrict__ pool, uint32_t overflow_capacity) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t shift = pool->shift;
     // thread d: top byte d of all eight slices.  Regions are laid out top byte by top byte, slice by slice.
     uint32_t cap[8], room[8], caps = 0, rooms = 0;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const uint32_t m = __hip_atomic_load(&pool->sample[s][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&pool->sample[s][tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next sort
+        const uint32_t m = pool->sample[s][tid];
+        pool->sample[s][tid] = 0;  // zero for the next sort
         const uint32_t len = ps.len[s], sampled = ps.sampled[s];
         // estimate: the slice's keys in proportion to the sample's, r = len / sampled for one sampled key (float arithmetic,
         // rounded DOWN by a hair: the estimates of a slice must sum to at most its length -- the primary regions tile the buffer)
@@ -173,7 +169,6 @@ __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__rest
     }
     if (tid == 0) {
         pool->fail = 0;  // re-armed here: the passes of THIS sort set it, its local sort reads it
-        pool->shift = shift;
         // a key range below 27 bits is left to the LSD passes, like the counted form does (vrs_kernels.hip, msd_plan_kernel)
         pool->armed = (shift >= kPoolMinShift && shift <= kPoolMaxShift && total_room <= overflow_capacity) ? 1u : 0u;
     }
@@ -593,11 +588,18 @@ __global__ __launch_bounds__(256) void pool_runs_kernel(MsdPlan *__restrict__ ms
                 off += len;
             }
             if (q == 3u) {
-                for (uint32_t r = R; r < kPoolRunSlots; ++r) {
-                    const uint32_t len = s_desc[c][r].y;  // (zero but for a crossing run's second piece)
-                    s_desc[c][r].y = min(off, 0xFFFFu) | (len << 16);
-                    off += len;
+                // the second pieces of crossing runs (at most one per slice, usually none) move up behind the runs: the local sort
+                // stops at the last slot that holds keys
+                uint32_t w = R;
+                for (uint32_t r = R; r < R + 8u; ++r) {
+                    const uint2 d = s_desc[c][r];
+                    s_desc[c][r] = make_uint2(0, 0);
+                    if (d.y) {
+                        s_desc[c][w++] = make_uint2(d.x, min(off, 0xFFFFu) | (d.y << 16));
+                        off += d.y;
+                    }
                 }
+                for (uint32_t r = w; r < kPoolRunSlots; ++r) s_desc[c][r].y = min(off, 0xFFFFu);  // empty, at the bucket's end (slot 63 says its size)
                 s_tot[c] = off;  // the bucket's keys
             }
         }
@@ -646,37 +648,40 @@ __device__ __forceinline__ void pool_stage(const PoolGather &gt, uint32_t dx, ui
     constexpr uint32_t WAVES = THREADS / 64, PER = 64 / WAVES;  // runs per wave
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // ALL of the wave's runs at once, three 64-key chunks of each (a run is about 128 keys): every load of the wave is in flight
-    // before the first is written to LDS -- a workgroup lives for one memory latency here, and four would be four.  The loads
-    // are unconditional, from a clamped index (an empty chunk reads its run's last key again: one more hit on a line that is
-    // being read anyway) -- a predicated load is a branch, and a branch costs the loads behind it their overlap.
+    // before the first is written to LDS -- a workgroup lives for one memory latency here, and four would be four.  The loads of
+    // the first two chunks are unconditional, from a clamped index (a predicated load is a branch per lane); the third chunk and
+    // everything behind the last slot that holds keys are skipped wave by wave (scalar branches).
+    const uint32_t used = 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(__ballot((dy >> 16) != 0u) | 1ull)));  // slots [0, used) may hold keys
     uint32_t x[PER][3];
+    uint32_t slot[PER], pk[PER];  // (wave-uniform: scalar registers)
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t r = wave + u * WAVES;
-        const uint32_t slot = __builtin_amdgcn_readlane(dx, r), len = __builtin_amdgcn_readlane(dy, r) >> 16;
-        const PoolGather::gptr src = gt.at(slot);  // (an empty run's slot is 0: a valid address)
-        const uint32_t last = len ? len - 1u : 0u;
-#pragma unroll
-        for (uint32_t c = 0; c < 3u; ++c) x[u][c] = src[min(c * 64u + lane, last)];
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) {
-        const uint32_t pk = __builtin_amdgcn_readlane(dy, wave + u * WAVES);
-        const uint32_t len = pk >> 16, dst = mis + (pk & 0xFFFFu);
-#pragma unroll
-        for (uint32_t c = 0; c < 3u; ++c) {
-            const uint32_t idx = c * 64u + lane;
-            if (idx < len) s_keys[dst + idx] = x[u][c];
+        slot[u] = __builtin_amdgcn_readlane(dx, r);
+        pk[u] = __builtin_amdgcn_readlane(dy, r);
+        x[u][0] = x[u][1] = x[u][2] = 0;
+        if (r < used) {
+            const uint32_t len = pk[u] >> 16;
+            const PoolGather::gptr src = gt.at(slot[u]);  // (an empty run's slot is 0: a valid address)
+            const uint32_t last = len ? len - 1u : 0u;
+            x[u][0] = src[min(lane, last)];
+            x[u][1] = src[min(64u + lane, last)];
+            if (len > 128u) x[u][2] = src[min(128u + lane, last)];
         }
     }
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
-        const uint32_t r = wave + u * WAVES;
-        const uint32_t pk = __builtin_amdgcn_readlane(dy, r);
-        if ((pk >> 16) > 192u) {  // a long run (skewed keys; wave-uniform): the rest of it, 64 keys at a time
-            const PoolGather::gptr src = gt.at(__builtin_amdgcn_readlane(dx, r));
-            const uint32_t dst = mis + (pk & 0xFFFFu);
-            for (uint32_t idx = 192u + lane; idx < (pk >> 16); idx += 64u) s_keys[dst + idx] = src[idx];
+        const uint32_t len = pk[u] >> 16, dst = mis + (pk[u] & 0xFFFFu);
+        if (wave + u * WAVES < used) {
+#pragma unroll
+            for (uint32_t c = 0; c < 3u; ++c) {
+                const uint32_t idx = c * 64u + lane;
+                if (idx < len) s_keys[dst + idx] = x[u][c];
+            }
+            if (len > 192u) {  // a long run (skewed keys): the rest of it, 64 keys at a time
+                const PoolGather::gptr src = gt.at(slot[u]);
+                for (uint32_t idx = 192u + lane; idx < len; idx += 64u) s_keys[dst + idx] = src[idx];
+            }
         }
     }
     __syncthreads();
@@ -780,11 +785,11 @@ __global__ __launch_bounds__(THREADS, 4) void pool_local_sort_kernel(const uint3
         }
     }
     if (ok == 0u) return;  // (enqueued before the verdicts were known, and one said no)
-    {   // the first pass's cursors, zero for the next sort (the counted form's local sort does the same: rearm_reservation)
-        const uint32_t b = blockIdx.x;
-        if (b < 2u * kStreams)
-            for (uint32_t c = threadIdx.x; c < 256u; c += THREADS) cursors[b * 256u + c] = 0;
-    }
+    // the first pass's cursors, zero for the next sort (the counted form's local sort does the same: rearm_reservation)
+    if (blockIdx.x < 2u * kStreams)
+        for (uint32_t c = threadIdx.x; c < 256u; c += THREADS) cursors[blockIdx.x * 256u + c] = 0;
+    // (bucket = block index: neighbouring buckets run on different XCDs and fetch the cache lines they share twice -- 22 % more
+    // bytes than the keys -- but with XCD-contiguous ranges of buckets, xcd_contiguous_tile, the gather measured 178 instead of 160 us)
     const uint32_t b = blockIdx.x;
     const uint32_t begin = msd->base[b];
     // every wave: lane l = run l's descriptor (512 contiguous bytes of the table)
@@ -847,7 +852,8 @@ hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t
                               PoolPlan *pool, uint32_t overflow_capacity, LaunchEvents ev) {
     if (n == 0 || ps.tiles_per_stream < kPoolSampleTiles) return hipErrorInvalidValue;  // (a sample workgroup's tiles span at most two slices)
     const uint32_t grid = (ps.tiles_total + kPoolSampleTiles - 1u) / kPoolSampleTiles;
-    VRS_LAUNCH(pool_sample_kernel, dim3(grid), dim3(256), stream, ev, keys, n, key_base, ps, pool, overflow_capacity);
+    VRS_LAUNCH(pool_sample_kernel, dim3(grid), dim3(256), stream, ev, keys, n, key_base, ps, pool);
+    hipLaunchKernelGGL(pool_layout_kernel, dim3(1), dim3(256), 0, stream, ps, pool, overflow_capacity);
     return hipGetLastError();
 }
 
