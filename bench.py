@@ -374,7 +374,7 @@ def bench_pairs(args):
     n, K, W = args.n, args.steps, args.warmup
     S = vrs.Buffer.BufferSettings
     seeds = [1, 2, 3]
-    host_keys = [mt19937_keys(s, n) for s in seeds[:max(1, min(3, K))]]
+    host_keys = [mt19937_keys(s, n) for s in seeds[:max(1, min(3, K, getattr(args, "exact_seeds", 3)))]]
     iota = np.arange(n, dtype=np.uint32)
     gpu = vrs.GPUContext(int(os.environ.get("LOCAL_RANK", "0")))
     gpu.init()
@@ -597,9 +597,7 @@ def bench_multi_python(args, fallback_reason=None):
     elapsed = time.perf_counter() - t0
     backend.ctx.profileEnable(False)
     lb_launches, lb_ms = backend.ctx.profileQuery(capi.VRS_KERNEL_LOOKBACK_SCATTER)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = fabric.reduce(elapsed, "max")
 
     # verification outside the timed region: every range ascending, ranges ordered across ranks, nothing lost
     out = res.keys[:res.count]
@@ -707,29 +705,155 @@ def _rccl_communicator(torch, dist, rank, world, dev):
     return rccl, comm
 
 
-def bench_multi(args):
-    """N > 1 (or VRS_BENCH_FORCE_MULTI=1 at N = 1): the multi-GPU step behind the C ABI (vrs_dist_*, csrc/vrs_dist.hip) over a
-    raw RCCL communicator -- the single-GPU hybrid sort with the all-to-all between its two MSD passes."""
-    import torch
-    import torch.distributed as dist
+class _RcclFabric:
+    """What bench_multi needs of the ranks' fabric, over torch.distributed + a raw RCCL communicator (one process per GPU, the way
+    the driver launches the bench)."""
+    transport = "RCCL (send/recv over xGMI; one process per GPU)"
+    wire = "RCCL"
 
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", self.rank))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device("cuda", self.local)
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            warm = torch.zeros(8, dtype=torch.int64, device=self.dev)
+            dist.all_reduce(warm)  # brings the communicator up (and its banner out) now
+            torch.cuda.synchronize()
+            self.rccl, self.comm = _rccl_communicator(torch, dist, self.rank, self.world, self.dev)
+        self.devices = self.world
+        self.can_fall_back = True
+
+    def create(self, lib, gpu, cap, rounds, out):
+        return lib.vrs_dist_create(gpu.handle, self.comm, self.rank, self.world, cap, rounds, ctypes.byref(out))
+
+    def barrier(self):
+        self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce(self, value, op):
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def all_gather(self, ints):
+        t = self.torch.tensor(list(ints), dtype=self.torch.int64, device=self.dev)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [x.cpu().tolist() for x in out]
+
+    def close(self):
+        self.rccl.ncclCommDestroy(self.comm)
+        self.dist.destroy_process_group()
+
+
+class _LoopbackHub:
+    """--loopback-ranks W: the ranks are THREADS of this process, the wire the library's in-process transport
+    (vrs_dist_loopback_*: device copies ordered by events).  With one GPU all ranks share it -- no scaling number, but every rank-to-rank
+    code path of the step and of this bench runs; with W GPUs in one process this is a multi-GPU sort without RCCL."""
+
+    def __init__(self, lib, world, devices):
+        import threading
+        self.lib, self.world, self.devices = lib, world, devices
+        self.handle = ctypes.c_void_p()
+        if lib.vrs_dist_loopback_create(world, ctypes.byref(self.handle)) != 0:
+            raise RuntimeError("vrs_dist_loopback_create failed")
+        self.rendezvous = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def destroy(self):
+        self.lib.vrs_dist_loopback_destroy(self.handle)
+
+
+class _LoopbackFabric:
+    can_fall_back = False
+    wire = "loopback"
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank, self.world = hub, rank, hub.world
+        self.local = rank % hub.devices
+        self.devices = hub.devices
+        self.transport = (f"loopback: {hub.world} ranks as host threads of one process on {hub.devices} device(s), device-to-device "
+                          "copies ordered by events (no RCCL, no xGMI: not a scaling number)")
+        self._wire = None
+
+    def create(self, lib, gpu, cap, rounds, out):
+        from vkradixsort_amd import capi
+        if self._wire is None:
+            self._wire = capi.DistTransport()
+            if lib.vrs_dist_loopback_transport(self.hub.handle, self.rank, ctypes.byref(self._wire)) != 0:
+                return 1
+        return lib.vrs_dist_create_with_transport(gpu.handle, ctypes.byref(self._wire), self.rank, self.world, cap, rounds, ctypes.byref(out))
+
+    def barrier(self):
+        self.hub.rendezvous.wait()
+
+    def _exchange(self, value):
+        self.hub.slots[self.rank] = value
+        self.hub.rendezvous.wait()
+        got = list(self.hub.slots)
+        self.hub.rendezvous.wait()  # nobody overwrites its slot before everybody has read
+        return got
+
+    def reduce(self, value, op):
+        got = self._exchange(float(value))
+        return max(got) if op == "max" else min(got)
+
+    def all_gather(self, ints):
+        return [list(x) for x in self._exchange(list(ints))]
+
+    def close(self):
+        pass
+
+
+def bench_multi_loopback(args):
+    """bench.py --loopback-ranks W [--n ...]: bench_multi's step, verification and JSON assembly with W ranks as threads."""
+    import threading
+
+    from vkradixsort_amd import capi
+    lib = capi.load_library()
+    cnt = ctypes.c_int()
+    if lib.vrs_device_count(ctypes.byref(cnt)) != 0 or cnt.value == 0:
+        raise SystemExit("no device")
+    world = args.loopback_ranks
+    hub = _LoopbackHub(lib, world, min(cnt.value, world))
+    results, errors = [None] * world, []
+
+    def run(r):
+        try:
+            results[r] = bench_multi(args, _LoopbackFabric(hub, r))
+        except BaseException as e:  # noqa: BLE001 -- the other ranks must not wait for this one
+            errors.append((r, repr(e)))
+            hub.rendezvous.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    hub.destroy()
+    if errors:
+        raise SystemExit(f"loopback ranks failed: {errors}")
+    return results[0]
+
+
+def bench_multi(args, fabric=None):
+    """N > 1 (or VRS_BENCH_FORCE_MULTI=1 at N = 1): the multi-GPU step behind the C ABI (vrs_dist_*, csrc/vrs_dist.hip) over a
+    raw RCCL communicator -- the single-GPU hybrid sort with the all-to-all between its two MSD passes.  (fabric: the loopback
+    flavour of --loopback-ranks; default RCCL.)"""
     import vkradixsort_amd as vrs
     from vkradixsort_amd import capi
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", rank))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29512")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    with _StdoutToStderr():
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        warm = torch.zeros(8, dtype=torch.int64, device=dev)
-        dist.all_reduce(warm)  # brings the communicator up (and its banner out) now
-        torch.cuda.synchronize()
-        rccl, comm = _rccl_communicator(torch, dist, rank, world, dev)
+    fabric = fabric or _RcclFabric()
+    rank, world, local = fabric.rank, fabric.world, fabric.local
     lib = capi.load_library()
     n, K, W = args.n, args.steps, args.warmup
     S = vrs.Buffer.BufferSettings
@@ -743,7 +867,7 @@ def bench_multi(args):
 
     def make_dist(rounds):
         d = ctypes.c_void_p()
-        rc = lib.vrs_dist_create(gpu.handle, comm, rank, world, cap, rounds, ctypes.byref(d))
+        rc = fabric.create(lib, gpu, cap, rounds, d)
         if rc != 0:
             raise RuntimeError(f"vrs_dist_create: {lib.vrs_dist_last_error(None).decode()}")
         return d
@@ -762,8 +886,7 @@ def bench_multi(args):
 
     def barrier():
         gpu.waitIdle()
-        dist.barrier()
-        torch.cuda.synchronize()
+        fabric.barrier()
 
     rearm()
     # warm-up steps double as a measurement of the exchange pipelining depth: how many rounds pay off depends on the
@@ -780,11 +903,10 @@ def bench_multi(args):
     def agreed(stage):
         """True if `stage` went well on EVERY rank (a rank that failed skipped its collectives: the others must not enter the
         next stage's and wait for it)."""
-        flag = torch.tensor([0 if failure else 1], dtype=torch.int64, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
+        if int(fabric.reduce(0 if failure else 1, "min")) == 1:
             return True
-        print(f"[bench] rank {rank}: the C path's {stage} failed ({failure or 'on another rank'}); falling back to --dist-path python", file=sys.stderr)
+        print(f"[bench] rank {rank}: the C path's {stage} failed ({failure or 'on another rank'})" +
+              ("; falling back to --dist-path python" if fabric.can_fall_back else ""), file=sys.stderr)
         return False
 
     try:  # stage 1, no communication: the endpoints (binds RCCL, allocates the landing areas)
@@ -807,6 +929,8 @@ def bench_multi(args):
         for b in batches + [pristine]:
             b.release()
         gpu.shutdown()
+        if not fabric.can_fall_back:
+            raise RuntimeError(f"rank {rank}: {failure or 'another rank failed'}")
         return bench_multi_python(args, fallback_reason=failure or "another rank failed")
     if len(candidates) > 1:
         for r, d in handles.items():
@@ -814,9 +938,7 @@ def bench_multi(args):
             tw = time.perf_counter()
             step(d, batches[0])
             gpu.waitIdle()
-            tt = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tried[r] = float(tt.item())
+            tried[r] = fabric.reduce(time.perf_counter() - tw, "max")
             batches[0].copyFrom(pristine)
         rounds = min(tried, key=tried.get)
     else:
@@ -847,9 +969,7 @@ def bench_multi(args):
     gr1 = ctypes.c_uint64()
     lib.vrs_dist_grouped_rounds(d, ctypes.byref(gr1))
     grouped_rounds = gr1.value - gr0.value
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = fabric.reduce(elapsed, "max")
 
     # verification outside the timed region: every range ascending (device check), ranges ordered across ranks, nothing lost
     desc, ksum, kmix = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
@@ -862,18 +982,13 @@ def bench_multi(args):
             gpu.check(lib.vrs_buffer_wrap(gpu.handle, ctypes.c_void_p(base_ptr + 4 * off), 4, ctypes.byref(v)))
             gpu.check(lib.vrs_buffer_download(gpu.handle, v, ends[j:].ctypes.data_as(ctypes.c_void_p), 4))
             lib.vrs_buffer_release(v)
-    edges = torch.tensor([int(ends[0]), int(ends[1]), out_n, ksum.value & (2 ** 62 - 1), 1 if desc.value == 0 else 0], dtype=torch.int64, device=dev)
-    gathered = [torch.empty_like(edges) for _ in range(world)]
-    dist.all_gather(gathered, edges)
-    src_sum = torch.tensor([int(shard.astype(np.uint64).sum()) & (2 ** 62 - 1)], dtype=torch.int64, device=dev)
-    srcs = [torch.empty_like(src_sum) for _ in range(world)]
-    dist.all_gather(srcs, src_sum)
-    g = [x.cpu().tolist() for x in gathered]
+    g = fabric.all_gather([int(ends[0]), int(ends[1]), out_n, ksum.value & (2 ** 62 - 1), 1 if desc.value == 0 else 0,
+                           int(shard.astype(np.uint64).sum()) & (2 ** 62 - 1)])
     nonempty = [x for x in g if x[2] > 0]
     check = {"ranges_sorted": all(x[4] == 1 for x in g),
              "ranges_ordered_across_ranks": all(nonempty[i][1] <= nonempty[i + 1][0] for i in range(len(nonempty) - 1)),
              "count_ok": sum(x[2] for x in g) == n * world,
-             "checksum_ok": sum(x[3] for x in g) % 2 ** 62 == sum(int(x.item()) for x in srcs) % 2 ** 62}
+             "checksum_ok": sum(x[3] for x in g) % 2 ** 62 == sum(x[5] for x in g) % 2 ** 62}
     result = None
     if rank == 0:
         if not all(check.values()):
@@ -908,16 +1023,17 @@ def bench_multi(args):
             "config": {"workload": f"{world} x {n} uniform random uint32 keys (std::mt19937 seed 1000+rank), sharded by key range "
                                    f"(BASELINE.json configs[4] at 8 GPUs), keys resident in HBM",
                        "path": ("vrs_dist_sort_keys_u32, hybrid shape: counting read + first MSD pass of the shard, one all-gather + one "
-                                "all-reduce of counts, RCCL send/recv of one message per (sender, top byte) in "
+                                f"all-reduce of counts, {fabric.wire} send/recv of one message per (sender, top byte) in "
                                 f"{rounds} round(s), second MSD pass + LDS-local sort per received sub-range") if hybrid else
                                ("vrs_dist_sort_keys_u32, byte shape (the global top-14-bit buckets would not fit the local sort): contract "
-                                f"partition pass by the top byte, RCCL send/recv of one message per (sender, top byte) in {rounds} round(s), "
+                                f"partition pass by the top byte, {fabric.wire} send/recv of one message per (sender, top byte) in {rounds} round(s), "
                                 "per received sub-range one counting read + second MSD pass by the next 8 bits + LDS-local sort "
                                 "(vrs_msd_finish_grouped_u32)") if grouped else
                                ("vrs_dist_sort_keys_u32, byte shape (the global top-14-bit buckets would not fit the local sort): contract "
-                                f"partition pass by the top byte, RCCL send/recv per (sender, round) in {rounds} round(s), "
+                                f"partition pass by the top byte, {fabric.wire} send/recv per (sender, round) in {rounds} round(s), "
                                 "vrs_sort_keys_u32_ranged per received sub-range (its own 16384 buckets)"),
-                       "num_elements_per_gpu": n, "parallelism": f"range-sharded x{world}", "exchange_rounds": rounds,
+                       "num_elements_per_gpu": n, "parallelism": f"range-sharded x{world}", "transport": fabric.transport,
+                       "devices": fabric.devices, "exchange_rounds": rounds,
                        "rounds_tried_in_warmup_ms": {str(k): round(v * 1e3, 3) for k, v in tried.items()},
                        "received_sub_ranges": {"finished_in_hybrid_shape": int(hybrid_rounds), "finished_grouped_in_byte_shape": int(grouped_rounds),
                                                "sorted_from_scratch_after_a_refused_plan": int(fallback_rounds)},
@@ -946,9 +1062,36 @@ def bench_multi(args):
     for b in batches + [pristine]:
         b.release()
     gpu.shutdown()
-    rccl.ncclCommDestroy(comm)
-    dist.destroy_process_group()
+    fabric.close()
     return result
+
+
+def other_configs(args):
+    """The default line's `configs` block: BASELINE.json configs[1] (10^7 keys) and configs[3] (10^8 key + payload pairs) run the
+    same way as the headline -- pre-staged batches, back-to-back steps, every output verified on the device, the first batch of every
+    seed bit for bit against std::sort / std::stable_sort -- in short form (their full lines: --n 1e7 / --pairs)."""
+    import copy
+    out = {}
+    a1 = copy.copy(args)
+    a1.n, a1.pairs = 10 ** 7, False
+    r = bench_single(a1)
+    out["configs[1]"] = {"workload": r["config"]["workload"], "path": r["config"]["path"].split(":")[0].split(" --")[0], "value": r["value"],
+                         "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                         "ms_per_step_individually_timed": r["ms_per_step_individually_timed"],
+                         "sort_roofline": r["sort_roofline"], "contract_path_ms_per_step": r.get("contract_path", {}).get("ms_per_step"),
+                         "bit_exact_vs_std_sort": r["verified"].get("one_call_bit_exact_vs_std_sort_seeds"),
+                         "every_timed_output_verified_on_device": r["verified"].get("timed_region_every_batch_ascending_and_permutation_of_its_input"),
+                         "cpu_baseline": r.get("cpu_baseline", {}).get("value")}
+    a3 = copy.copy(args)
+    a3.n, a3.pairs, a3.steps, a3.exact_seeds = 10 ** 8, True, min(args.steps, 10), 1  # (one seed: its std::stable_sort takes 9 s)
+    r = bench_pairs(a3)
+    out["configs[3]"] = {"workload": r["config"]["workload"], "path": r["config"]["path"].split(":")[0], "value": r["value"], "unit": r["unit"],
+                         "ms_per_step": r["ms_per_step"], "steps": r["steps"], "sort_roofline": r["sort_roofline"],
+                         "roofline_frac_dominant_kernel": r["roofline"]["frac"],
+                         "bit_exact_vs_std_stable_sort": r["verified"].get("bit_exact_vs_std_stable_sort_seeds"),
+                         "every_timed_output_verified_on_device": r["verified"].get("timed_region_every_batch_keys_ascending_and_permutations"),
+                         "cpu_baseline": r.get("cpu_baseline", {}).get("value")}
+    return out
 
 
 def main():
@@ -963,6 +1106,10 @@ def main():
     ap.add_argument("--rounds", type=int, default=4, help="multi-GPU: sub-ranges per rank (exchange/sort pipelining)")
     ap.add_argument("--rounds-forced", action="store_true", help="use --rounds even at world size 1 (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1, default workload: leave out the `configs` block (10^7 keys, 10^8 pairs)")
+    ap.add_argument("--loopback-ranks", type=int, default=0,
+                    help="the multi-GPU step with this many ranks as THREADS of one process over the library's in-process transport "
+                         "(one GPU: all ranks share it -- exercises every rank-to-rank path, measures no scaling)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="N = 1: the dominant kernel's launches carry HIP events in every this-many-th step of the timed region")
     ap.add_argument("--pairs", action="store_true", help="N = 1: BASELINE.json configs[3], key + payload pairs through vrs_sort_pairs_u32")
@@ -983,6 +1130,11 @@ def main():
     from vkradixsort_amd import capi
     capi.load_library()  # fails loudly if the HIP extension was not built; there is no fallback path
 
+    if args.loopback_ranks > 0:
+        result = bench_multi_loopback(args)
+        if result is not None:
+            print(json.dumps(result), flush=True)
+        return
     if args.gpus > 1 or os.environ.get("VRS_BENCH_FORCE_MULTI") == "1":  # the latter: exchange path at world size 1
         # RCCL prints its banner on the C stdout whenever a communicator first does something: fd 1 belongs to the ONE JSON
         # line, everything else goes to fd 2 for the whole run
@@ -994,6 +1146,8 @@ def main():
             os.write(guard._saved, (json.dumps(result) + "\n").encode())
         return
     result = bench_pairs(args) if args.pairs else bench_single(args)
+    if result is not None and not args.pairs and args.n == 10 ** 8 and args.path == "one_call" and not args.no_configs:
+        result["configs"] = other_configs(args)
     if result is not None:
         print(json.dumps(result), flush=True)
 

@@ -33,7 +33,7 @@ typedef enum vrs_status {
     VRS_ERROR_HIP = 2,          /* a HIP runtime call failed; see vrs_last_error */
     VRS_ERROR_NO_DEVICE = 3,    /* no gfx950-capable device / bad ordinal */
     VRS_ERROR_OUT_OF_MEMORY = 4,
-    VRS_ERROR_UNBALANCED = 5,   /* vrs_dist_sort_keys_u32: key ranges cut at top-byte boundaries cannot be balanced */
+    VRS_ERROR_UNBALANCED = 5,   /* vrs_dist_sort_keys_u32: too many equal keys -- no cut between key values balances the ranks */
     VRS_ERROR_PEER = 7,         /* vrs_dist_sort_keys_u32: another rank could not take part; every rank left the step together */
     VRS_ERROR_TIMEOUT = 6       /* a one-call sort's plan did not reach the host within VRS_TUNE_PLAN_WAIT_MS (the stream is held
                                    up by earlier work); the sort is still queued, vrs_sort_settle may be called again */
@@ -306,11 +306,19 @@ int vrs_verify_keys_u32(vrs_context ctx, vrs_buffer keys, uint32_t num_elements,
  * sub-range; also forced by the environment variable VRS_DIST_SHAPE=byte, which must then be set on every rank).
  * Every decision to leave a step is taken by all ranks from the same gathered rows: a rank that cannot take part (shard
  * above its capacity, a failed local stage) says so in its row, still joins the collectives, and all ranks return together
- * (that rank its own error, the others VRS_ERROR_PEER).  Keys whose top bytes are too concentrated for byte-aligned ranges
- * (more than 15 % over the even share, or more than the SMALLEST capacity of all ranks) return VRS_ERROR_UNBALANCED on
- * every rank; the Python orchestration (vkradixsort_amd/distributed.py) adds sampled splitters and a gather path for small
- * totals on top of the same entry points.  Blocking for the count exchange and, per round, for the round's plan; the
- * exchange and the sorts complete on the context's stream.
+ * (that rank its own error, the others VRS_ERROR_PEER).  A rank whose step fails LOCALLY outside those stages (a HIP or
+ * transport call) returns at once without the collectives it has not reached: over RCCL the caller aborts the
+ * communicator, as after any failed rank; the loopback transport marks its hub broken whenever one of ITS calls fails
+ * (HIP, mismatch or misuse), so the peers leave their next rendezvous with an error instead of waiting.
+ * Keys whose top bytes are too concentrated for byte-aligned ranges (more than 15 % over the even share, or more than the
+ * SMALLEST capacity of all ranks: small keys, clustered keys) are cut at SAMPLED key values instead: every rank adds 2048
+ * keys of its shard to a pool (a second all-gather), the world * rounds - 1 cut keys are the pool's weighted quantiles,
+ * the shard is grouped by range (vrs_range_partition, 12 B/key) and a third all-gather hands out the range prefixes; one
+ * message per (sender, round), vrs_sort_keys_u32_ranged per received sub-range.  Only keys with massive ties -- one key
+ * VALUE holding more than a rank's share -- still return VRS_ERROR_UNBALANCED (on every rank); so does every
+ * concentrated input under VRS_DIST_SAMPLED_SPLITTERS=0 (tests).  The Python orchestration
+ * (vkradixsort_amd/distributed.py) adds a gather path for small totals on top of the same entry points.  Blocking for
+ * the count exchange and, per round, for the round's plan; the exchange and the sorts complete on the context's stream.
  *
  * The wire is a table of functions.  vrs_dist_create binds RCCL at run time (dlopen): `nccl_comm` is an ncclComm_t of the
  * RCCL copy already in the process; NULL at world size 1 (every transfer is then a device copy).
@@ -353,6 +361,8 @@ int vrs_dist_stats(vrs_dist dist, uint64_t *hybrid_rounds, uint64_t *fallback_ro
 /* rounds of byte-shape steps finished by vrs_msd_finish_grouped_u32 (one counting read + second MSD pass + local sort: 20 B/key)
  * instead of a whole ranged sort (28) */
 int vrs_dist_grouped_rounds(vrs_dist dist, uint64_t *grouped_rounds);
+/* steps that cut the key ranges at sampled key values (top bytes too concentrated for byte-aligned ranges) */
+int vrs_dist_splitter_steps(vrs_dist dist, uint64_t *splitter_steps);
 typedef struct vrs_dist_loopback_t *vrs_dist_loopback;
 int vrs_dist_loopback_create(int world, vrs_dist_loopback *out_hub);
 /* fills *out with rank `rank`'s end of the hub; call it on the thread that drives the rank, its device current */

@@ -23,6 +23,10 @@ def keys_of(kind, n, seed):
         k >>= np.uint32(4)  # the reference's own test keys (MultiRadixSort.cpp:121-133)
     if kind == "16bit":
         k >>= np.uint32(16)  # everything under top byte 0: no byte-aligned cut can balance two ranks
+    if kind == "24bit":
+        k >>= np.uint32(8)
+    if kind == "three_values":  # massive ties: no cut between key values balances anything
+        k = (k % np.uint32(3)) * np.uint32(0x10000001)
     if kind == "clustered":  # three quarters of the keys under ONE top byte
         m = rs.rand(n) < 0.75
         k[m] = (k[m] & np.uint32(0x00FFFFFF)) | np.uint32(0x40000000)
@@ -65,10 +69,11 @@ def run_ranks(shards, rounds, capacity=None, world=None, env_shape=None, steps=2
                     if out.size:
                         gpu.check(lib.vrs_buffer_download(gpu.handle, out_buf, out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
                     outs.append((0, out))
-                st = [ctypes.c_uint64() for _ in range(4)]
+                st = [ctypes.c_uint64() for _ in range(5)]
                 lib.vrs_dist_stats(d, *[ctypes.byref(x) for x in st[:3]])
                 lib.vrs_dist_grouped_rounds(d, ctypes.byref(st[3]))
-                results[r] = (outs, tuple(x.value for x in st))  # (hybrid rounds, refused rounds, byte-shape steps, grouped rounds)
+                lib.vrs_dist_splitter_steps(d, ctypes.byref(st[4]))
+                results[r] = (outs, tuple(x.value for x in st))  # (hybrid rounds, refused rounds, byte-shape steps, grouped rounds, splitter steps)
                 kb.release()
                 lib.vrs_dist_destroy(d)
         except Exception as e:  # noqa: BLE001 -- reported by the main thread
@@ -104,7 +109,7 @@ def test_two_ranks_hybrid_shape(kind, rounds):
     shards = [keys_of(kind, 3000017, 1000), keys_of(kind, 2600001, 1001)]
     res = run_ranks(shards, rounds)
     check_sorted_ranges(shards, res)
-    for outs, (hybrid_rounds, fallback_rounds, byte_steps, _grouped) in res:
+    for outs, (hybrid_rounds, fallback_rounds, byte_steps, _grouped, _splitters) in res:
         assert byte_steps == 0 and fallback_rounds == 0 and hybrid_rounds == 2 * rounds
 
 
@@ -197,17 +202,63 @@ def test_three_ranks(shape, monkeypatch):
         assert all(st[3] == 4 and st[1] == 0 for _, st in res), [st for _, st in res]
 
 
-@pytest.mark.parametrize("kind", ["16bit", "clustered"])
+@pytest.mark.parametrize("kind", ["16bit", "clustered", "24bit"])
 @pytest.mark.parametrize("shape", ["hybrid_first", "byte_first"])
-def test_two_ranks_unbalanced_key_ranges_leave_together(kind, shape, monkeypatch):
-    """Top bytes too concentrated for byte-aligned cuts: VRS_ERROR_UNBALANCED on BOTH ranks, nobody hangs -- whether the step
-    tried the hybrid shape first (two all-gathers) or went straight to the byte shape (one)."""
+def test_two_ranks_concentrated_top_bytes_are_cut_at_sampled_keys(kind, shape, monkeypatch):
+    """Top bytes too concentrated for byte-aligned cuts (small keys, clustered keys): the step pools 2048 sampled keys per rank,
+    cuts at their quantiles and groups the shard by range -- bit-exact, every rank within 15 % of the even share -- whether the
+    step tried the hybrid shape first (two all-gathers before the sample) or went straight to the byte shape (one)."""
     if shape == "byte_first":
         monkeypatch.setenv("VRS_DIST_SHAPE", "byte")
     shards = [keys_of(kind, 2000000, 31), keys_of(kind, 2000000, 32)]
     res = run_ranks(shards, 2)
+    check_sorted_ranges(shards, res)
+    assert all(st[4] == 2 for _, st in res), [st for _, st in res]
+
+
+def test_three_ranks_uneven_shards_cut_at_sampled_keys():
+    """Shards of very different sizes (one empty): every sample weighs its shard's size / 2048 keys, an empty shard adds nothing."""
+    shards = [keys_of("16bit", 3000000, 33), keys_of("16bit", 400000, 34), np.empty(0, np.uint32)]
+    res = run_ranks(shards, 2)
+    check_sorted_ranges(shards, res)
+    assert all(st[4] == 2 for _, st in res), [st for _, st in res]
+
+
+@pytest.mark.parametrize("kind", ["three_values", "16bit_sampling_off"])
+def test_two_ranks_unbalanced_key_ranges_leave_together(kind, monkeypatch):
+    """Massive ties (three key values for two ranks x two rounds: one value holds more than a rank's share), or concentrated top
+    bytes with the sampled splitters switched off: VRS_ERROR_UNBALANCED on BOTH ranks, nobody hangs."""
+    if kind == "16bit_sampling_off":
+        monkeypatch.setenv("VRS_DIST_SAMPLED_SPLITTERS", "0")
+        kind = "16bit"
+    shards = [keys_of(kind, 2000000, 31), keys_of(kind, 2000000, 32)]
+    res = run_ranks(shards, 2)
     for outs, _ in res:
         assert all(rc == capi.VRS_ERROR_UNBALANCED for rc, _ in outs), outs
+
+
+@pytest.mark.parametrize("rounds", [1, 4])
+@pytest.mark.parametrize("shape", ["hybrid", "byte"])
+def test_eight_ranks_loopback(shape, rounds, monkeypatch):
+    """World size 8 (BASELINE.json configs[4]'s node) on the one GPU of the box: eight contexts, 8 x 2e6 keys, uniform and the
+    reference's 28-bit test keys, one shard empty; 32 top bytes per rank, rounds of 8.  The concatenation of the eight outputs
+    must be std::sort of all keys, every rank within 15 % of the even share."""
+    if shape == "byte":
+        monkeypatch.setenv("VRS_DIST_SHAPE", "byte")
+    for kind, empty in (("uniform", None), ("28bit", None), ("uniform", 5)):
+        shards = [keys_of(kind, 2000000 + 1001 * r, 80 + r) if r != empty else np.empty(0, np.uint32) for r in range(8)]
+        res = run_ranks(shards, rounds, capacity=2800000, steps=1)
+        check_sorted_ranges(shards, res, steps=1)
+        if shape == "hybrid":
+            assert all(st[0] == rounds and st[1] == 0 for _, st in res), [st for _, st in res]
+
+
+def test_eight_ranks_small_keys_cut_at_sampled_keys():
+    """World size 8, 24-bit keys: 32 parts cut at the quantiles of 16384 pooled samples."""
+    shards = [keys_of("24bit", 1000000 + 77 * r, 90 + r) for r in range(8)]
+    res = run_ranks(shards, 4, steps=1)
+    check_sorted_ranges(shards, res, steps=1)
+    assert all(st[4] == 1 for _, st in res), [st for _, st in res]
 
 
 @pytest.mark.parametrize("shape", ["hybrid_first", "byte_first"])
@@ -222,13 +273,35 @@ def test_two_ranks_a_shard_above_its_capacity_fails_on_both(shape, monkeypatch):
     assert all(rc == capi.VRS_ERROR_INVALID_ARGUMENT for rc, _ in res[1][0]), res[1][0]
 
 
+def test_bench_multi_path_at_world_eight_over_the_loopback_transport():
+    """bench.py's multi-GPU path (step, cross-rank verification, JSON assembly) with eight ranks as threads on the one GPU:
+    what the driver runs on an 8-GPU node, minus RCCL -- n_gpus = 8, the byte breakdown, cpu_baseline, all checks true."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--loopback-ranks", "8", "--n", "2e6", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 3 and line["unit"] == "Gkeys/s" and line["value"] > 0
+    assert all(line["verified"].values()), line["verified"]
+    assert sum(line["shard_sizes"]) == 8 * 2000000 and max(line["shard_sizes"]) <= 1.15 * 2000000
+    assert sum(line["config"]["hbm_bytes_per_key_breakdown"].values()) == line["config"]["hbm_bytes_per_key"]
+    assert line["config"]["transport"].startswith("loopback") and line["cpu_baseline"]["kind"] == "port"
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["launches"] > 0
+
+
 def test_cpp_host_drives_the_step_over_the_loopback_transport():
     """distsortexample: the step from a C++ host through the C ABI alone -- one std::thread per rank, the in-process transport --
     verified the reference's way (equal to std::sort of all keys, MultiRadixSort.cpp:141-161)."""
     import subprocess
     from vkradixsort_amd import build
     exe = build.build_dist_example()
-    for args in (["2", "1500000", "2"], ["3", "700001", "1", "7"], ["2", "40000", "1"]):
+    for args in (["2", "1500000", "2"], ["3", "700001", "1", "7"], ["2", "40000", "1"], ["4", "600000", "2", "9", "20"]):
         p = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stdout + p.stderr
         assert "[DistSort] Test passed." in p.stdout

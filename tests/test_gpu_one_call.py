@@ -761,6 +761,7 @@ def test_hybrid_form_with_buckets_beyond_the_small_local_sort(gpu_context, mode)
         assert capi.LOCAL_SORT_SMALL_PAIRS < largest <= capi.LOCAL_SORT_MAX_PAIRS
     ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
     ctx.setTuning(capi.VRS_TUNE_HYBRID, 1)  # forgets an earlier refusal of a 64-bit sort
+    ctx.setTuning(capi.VRS_TUNE_MSD_POOL, 0)  # the COUNTED form is the subject (the pool form picks its local sort from n alone: it would refuse these buckets)
     h0 = hybrid_sorts(ctx)
     try:
         if mode == "keys":
@@ -787,6 +788,7 @@ def test_hybrid_form_with_buckets_beyond_the_small_local_sort(gpu_context, mode)
             assert np.array_equal(ok, keys[order]) and np.array_equal(ov, vals[order])
     finally:
         ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
+        ctx.setTuning(capi.VRS_TUNE_MSD_POOL, 1)
     assert hybrid_sorts(ctx) - h0 == (0 if mode == "pairs_too_large" else 1)
 
 

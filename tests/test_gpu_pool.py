@@ -103,6 +103,10 @@ def test_pool_form_equals_std_sort(pool_ctx, oracle, n, dist):
     keys = pool_keys(n, dist, seed=n % 997)
     out, stats, (took, refused) = sort_and_stats(pool_ctx, keys)
     assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    if dist == "gauss" and n > 20000000:
+        # the fullest top byte holds 2.5 % of the keys: 92 tiles of the second pass, more runs than a bucket's gather takes (56)
+        assert (took, refused) == (0, 1)
+        return
     # the form really ran, and nothing was counted ahead: a sample, two passes, the gathering local sort
     assert (took, refused) == (1, 0)
     assert stats["pool_sample"] == 1 and stats["digit_tables"] == 0 and stats["lookback_scatter"] == 2 and stats["local_sort"] == 1

@@ -136,6 +136,7 @@ _SIGNATURES = [
     ("vrs_dist_destroy", c_int, [c_void_p]),
     ("vrs_dist_stats", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
     ("vrs_dist_grouped_rounds", c_int, [c_void_p, POINTER(c_uint64)]),
+    ("vrs_dist_splitter_steps", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_dist_loopback_create", c_int, [c_int, POINTER(c_void_p)]),
     ("vrs_dist_loopback_transport", c_int, [c_void_p, c_int, c_void_p]),
     ("vrs_dist_loopback_destroy", c_int, [c_void_p]),

@@ -72,6 +72,12 @@ __global__ __launch_bounds__(1024) void round_tables_kernel(const uint32_t *__re
     }
 }
 
+// Sampled-splitter steps: `count` keys of the shard at evenly spaced positions (an empty shard adds zeros nobody weighs).
+__global__ __launch_bounds__(256) void sample_shard_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ out, uint32_t count) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < count) out[i] = n ? keys[static_cast<uint64_t>(i) * (n - 1u) / (count - 1u)] : 0u;
+}
+
 // ---- RCCL, bound at run time (rccl.h: ncclResult_t == int, ncclSuccess == 0, ncclUint32 == 3, ncclSum == 0)
 struct Rccl {
     void *handle = nullptr;
@@ -143,6 +149,7 @@ constexpr int kRowCapacity = kRowSlices + 2;
 constexpr int kRowShift = kRowSlices + 3;   // hybrid shape: the probed bucket shift ...
 constexpr int kRowOver = kRowSlices + 4;    // ... and != 0: a key of the shard lies above the probed range
 constexpr int kRowWords = kRowSlices + 8;
+constexpr uint32_t kSamplesPerRank = 2048;  // sampled-splitter steps: what every rank adds to the pool (<= kRowSlices: the pool travels in the row / table buffers)
 constexpr uint64_t kHybridShapeMaxBucket = 14333;  // msd_local_capacity of bare uint32 keys (vrs_kernels.hip); VRS_DIST_HYBRID_MAX_BUCKET (tests) lowers it
 
 }  // namespace
@@ -171,6 +178,10 @@ struct vrs_dist_t {
     double max_imbalance = 1.15;
     uint64_t hybrid_rounds = 0, fallback_rounds = 0, byte_steps = 0, grouped_rounds = 0;
     bool no_grouped_finish = false;  // VRS_DIST_GROUPED_FINISH=0: the byte shape with whole ranged sorts (tests, A/B)
+    vrs_buffer splitters = nullptr;  // sampled-splitter steps: the P - 1 cut keys on the device
+    uint32_t host_splitters[256] = {};
+    uint64_t splitter_steps = 0;
+    bool no_sampled_splitters = false;  // VRS_DIST_SAMPLED_SPLITTERS=0: concentrated top bytes return VRS_ERROR_UNBALANCED (tests)
 };
 
 namespace {
@@ -310,7 +321,7 @@ int loop_all_gather(void *u, const void *s, void *r, size_t words, void *st) { r
 int loop_all_reduce(void *u, const void *s, void *r, size_t words, void *st) { return loop_gather_like(u, s, r, words, st, true); }
 int loop_group_start(void *u) {
     auto *e = static_cast<LoopEndpoint *>(u);
-    if (e->grouping) return kLoopErrUsage;
+    if (e->grouping) return loop_break(e->hub, kLoopErrUsage);  // (a usage error of one rank: its peers leave their collectives too)
     e->grouping = true;
     e->sends.clear();
     e->recvs.clear();
@@ -319,14 +330,14 @@ int loop_group_start(void *u) {
 }
 int loop_send(void *u, const void *b, size_t words, int peer, void *st) {
     auto *e = static_cast<LoopEndpoint *>(u);
-    if (!e->grouping || peer < 0 || peer >= e->hub->world || peer == e->rank) return kLoopErrUsage;
+    if (!e->grouping || peer < 0 || peer >= e->hub->world || peer == e->rank) return loop_break(e->hub, kLoopErrUsage);
     e->sends.push_back(LoopOp{b, nullptr, words, peer});
     e->group_stream = static_cast<hipStream_t>(st);
     return 0;
 }
 int loop_recv(void *u, void *b, size_t words, int peer, void *st) {
     auto *e = static_cast<LoopEndpoint *>(u);
-    if (!e->grouping || peer < 0 || peer >= e->hub->world || peer == e->rank) return kLoopErrUsage;
+    if (!e->grouping || peer < 0 || peer >= e->hub->world || peer == e->rank) return loop_break(e->hub, kLoopErrUsage);
     e->recvs.push_back(LoopOp{nullptr, b, words, peer});
     e->group_stream = static_cast<hipStream_t>(st);
     return 0;
@@ -335,7 +346,7 @@ int loop_recv(void *u, void *b, size_t words, int peer, void *st) {
 int loop_group_end(void *u) {
     auto *e = static_cast<LoopEndpoint *>(u);
     vrs_dist_loopback_t *h = e->hub;
-    if (!e->grouping) return kLoopErrUsage;
+    if (!e->grouping) return loop_break(h, kLoopErrUsage);
     e->grouping = false;
     hipStream_t st = e->group_stream;  // nullptr: this rank has nothing to move in this group (it still takes part)
     h->sends[e->rank] = e->sends;
@@ -476,6 +487,7 @@ int vrs_dist_create_with_transport(vrs_context ctx, const vrs_dist_transport *tr
     const char *shape = std::getenv("VRS_DIST_SHAPE");
     d->byte_shape_only = shape && std::strcmp(shape, "byte") == 0;
     if (const char *gf = std::getenv("VRS_DIST_GROUPED_FINISH")) d->no_grouped_finish = std::strcmp(gf, "0") == 0;
+    if (const char *ss = std::getenv("VRS_DIST_SAMPLED_SPLITTERS")) d->no_sampled_splitters = std::strcmp(ss, "0") == 0;
     if (const char *mb = std::getenv("VRS_DIST_HYBRID_MAX_BUCKET")) {  // test knob: the "total too large for the hybrid shape" path at test sizes
         const long v = std::atol(mb);
         if (v > 0 && static_cast<uint64_t>(v) < kHybridShapeMaxBucket) d->hybrid_max_bucket = static_cast<uint64_t>(v);
@@ -501,7 +513,8 @@ int vrs_dist_create_with_transport(vrs_context ctx, const vrs_dist_transport *tr
     if (vrs_buffer_create(ctx, kb, &d->grouped) || vrs_buffer_create(ctx, kb, &d->recv) || vrs_buffer_create(ctx, kb, &d->scratch) ||
         vrs_buffer_create(ctx, static_cast<size_t>(W) * 256 * 4, &d->hist) || vrs_buffer_create(ctx, kRowWords * 4, &d->row) ||
         vrs_buffer_create(ctx, static_cast<size_t>(world) * kRowWords * 4, &d->table) || vrs_buffer_create(ctx, cw, &d->counts) ||
-        vrs_buffer_create(ctx, cw, &d->reduced) || vrs_buffer_create(ctx, cw * static_cast<size_t>(d->rounds), &d->round_counts))
+        vrs_buffer_create(ctx, cw, &d->reduced) || vrs_buffer_create(ctx, cw * static_cast<size_t>(d->rounds), &d->round_counts) ||
+        vrs_buffer_create(ctx, 256 * 4, &d->splitters))
         return cleanup(VRS_ERROR_OUT_OF_MEMORY, std::string("buffer allocation failed: ") + vrs_last_error(ctx));
     d->host_table.resize(static_cast<size_t>(world) * kRowWords);
     *out = d;
@@ -534,7 +547,7 @@ int vrs_dist_destroy(vrs_dist d) {
     if (!d) return VRS_OK;
     (void)hipSetDevice(d->device);
     if (d->comm_stream) (void)hipStreamSynchronize(d->comm_stream);
-    for (vrs_buffer b : {d->grouped, d->recv, d->scratch, d->hist, d->row, d->table, d->counts, d->reduced, d->round_counts})
+    for (vrs_buffer b : {d->grouped, d->recv, d->scratch, d->hist, d->row, d->table, d->counts, d->reduced, d->round_counts, d->splitters})
         if (b) (void)vrs_buffer_release(b);
     for (auto e : d->round_done)
         if (e) (void)hipEventDestroy(e);
@@ -552,6 +565,12 @@ int vrs_dist_stats(vrs_dist d, uint64_t *hybrid_rounds, uint64_t *fallback_round
     if (hybrid_rounds) *hybrid_rounds = d->hybrid_rounds;
     if (fallback_rounds) *fallback_rounds = d->fallback_rounds;
     if (byte_shape_steps) *byte_shape_steps = d->byte_steps;
+    return VRS_OK;
+}
+
+int vrs_dist_splitter_steps(vrs_dist d, uint64_t *splitter_steps) {
+    if (!d || !splitter_steps) return dfail(d, VRS_ERROR_INVALID_ARGUMENT, "dist or splitter_steps is NULL");
+    *splitter_steps = d->splitter_steps;
     return VRS_OK;
 }
 
@@ -762,16 +781,116 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         worst = std::max(worst, s);
     }
     const double ideal = std::max(static_cast<double>(grand_total) / world, 1.0);
-    if (static_cast<double>(worst) > d->max_imbalance * ideal || worst > min_capacity)
-        return dfail(d, VRS_ERROR_UNBALANCED,
-                     "top bytes too concentrated for byte-aligned key ranges (small or clustered keys): use the sampled-splitter "
-                     "path of vkradixsort_amd.distributed.RangeShardedSort, or a larger capacity (the smallest capacity of all ranks counts)");
+    // first key value of every part: what its ranged sort may assume of its keys (byte-aligned parts: the first top byte)
+    std::vector<uint32_t> floors(static_cast<size_t>(P));
+    for (int p = 0; p < P; ++p) floors[static_cast<size_t>(p)] = std::min<uint32_t>(parts[static_cast<size_t>(p)], 255u) << 24;
+    bool by_splitters = false;
+    if (static_cast<double>(worst) > d->max_imbalance * ideal || worst > min_capacity) {
+        if (d->no_sampled_splitters)
+            return dfail(d, VRS_ERROR_UNBALANCED, "top bytes too concentrated for byte-aligned key ranges (small or clustered keys) and VRS_DIST_SAMPLED_SPLITTERS=0");
+        // Sampled splitters (the same decision on every rank: it depends on the gathered table only).  Every rank adds 2048 keys
+        // of its shard, taken at evenly spaced positions, to a pool (one all-gather of 8 KiB rows); the P - 1 cut keys are the
+        // pool's quantiles, every sample weighing (its shard's size / 2048) keys; the shard -- the caller's buffer is still
+        // untouched -- is grouped again, by range this time (vrs_range_partition: range = number of cut keys <= key, one stable
+        // 12 B/key pass), and a third all-gather hands out the range prefixes.  Every part is then one message per source and
+        // one ranged sort.  Only keys with massive ties (one value holding more than a rank's share) still cannot be balanced.
+        by_splitters = true;
+        hybrid = false;
+        d->splitter_steps++;
+        std::vector<uint64_t> shard(static_cast<size_t>(world));
+        for (int q = 0; q < world; ++q) shard[static_cast<size_t>(q)] = base[static_cast<size_t>(q)][256];
+        const uint32_t S = kSamplesPerRank;
+        hipLaunchKernelGGL(sample_shard_kernel, dim3(S / 256u), dim3(256), 0, d->sort_stream, static_cast<const uint32_t *>(n_eff ? vrs_buffer_device_ptr(keys) : nullptr), n_eff, row, S);
+        VRS_DHIP(d, hipGetLastError());
+        VRS_DHIP(d, hipEventRecord(d->counts_ready, d->sort_stream));
+        VRS_DHIP(d, hipStreamWaitEvent(d->comm_stream, d->counts_ready, 0));
+        if (d->has_transport) {
+            VRS_DTR(d, "all-gather of the key samples", d->tr.all_gather(d->tr.user, row, table, S, d->comm_stream));
+        } else {
+            VRS_DHIP(d, hipMemcpyAsync(table, row, S * 4, hipMemcpyDeviceToDevice, d->comm_stream));
+        }
+        VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, static_cast<size_t>(world) * S * 4, hipMemcpyDeviceToHost, d->comm_stream));
+        VRS_DHIP(d, hipStreamSynchronize(d->comm_stream));
+        std::vector<std::pair<uint32_t, double>> pool;  // (key, keys it stands for)
+        pool.reserve(static_cast<size_t>(world) * S);
+        for (int q = 0; q < world; ++q) {
+            if (!shard[static_cast<size_t>(q)]) continue;
+            const double w = static_cast<double>(shard[static_cast<size_t>(q)]) / S;
+            for (uint32_t i = 0; i < S; ++i) pool.emplace_back(d->host_table[static_cast<size_t>(q) * S + i], w);
+        }
+        std::sort(pool.begin(), pool.end(), [](const std::pair<uint32_t, double> &a, const std::pair<uint32_t, double> &b) { return a.first < b.first; });
+        {
+            double cum = 0;
+            size_t i = 0;
+            for (int p = 1; p < P; ++p) {  // cut key p: the first sample at which p / P of the weight has gone by
+                const double target = static_cast<double>(grand_total) * p / P;
+                while (i < pool.size() && cum + pool[i].second < target) cum += pool[i++].second;
+                d->host_splitters[p - 1] = i < pool.size() ? pool[i].first : 0xFFFFFFFFu;
+            }
+        }
+        if (P > 1) VRS_DHIP(d, hipMemcpyAsync(vrs_buffer_device_ptr(d->splitters), d->host_splitters, static_cast<size_t>(P - 1) * 4, hipMemcpyHostToDevice, d->sort_stream));
+        uint32_t *prefix = row;  // as in the byte shape: [0, 256) exclusive prefix of my range counts, [256] shard size, [257] status, [258] capacity
+        if (n_eff) {
+            rc = vrs_range_partition(ctx, keys, d->grouped, d->splitters, static_cast<uint32_t>(P - 1), n_eff);
+            if (rc == VRS_OK) {
+                vrs_buffer pv = nullptr;
+                rc = vrs_buffer_wrap(ctx, prefix, 256 * 4, &pv);
+                if (rc == VRS_OK) rc = vrs_multi_radixsort_digit_offsets_device(ctx, pv);
+                if (pv) (void)vrs_buffer_release(pv);
+            }
+            if (rc != VRS_OK) {
+                my_status = rc;
+                my_error = std::string("range partition pass: ") + vrs_last_error(ctx);
+            }
+        } else {
+            VRS_DHIP(d, hipMemsetAsync(prefix, 0, 256 * 4, d->sort_stream));
+        }
+        VRS_DHIP(d, hipEventRecord(d->counts_ready, d->sort_stream));
+        VRS_DHIP(d, hipStreamWaitEvent(d->comm_stream, d->counts_ready, 0));
+        constexpr size_t kByteRow = 259;
+        d->host_row_tail[0] = my_status == VRS_OK ? n_eff : 0u;
+        d->host_row_tail[1] = static_cast<uint32_t>(my_status);
+        d->host_row_tail[2] = d->capacity;
+        VRS_DHIP(d, hipMemcpyAsync(row + 256, d->host_row_tail, 3 * 4, hipMemcpyHostToDevice, d->comm_stream));
+        if (d->has_transport) {
+            VRS_DTR(d, "all-gather of the range prefixes", d->tr.all_gather(d->tr.user, row, table, kByteRow, d->comm_stream));
+        } else {
+            VRS_DHIP(d, hipMemcpyAsync(table, row, kByteRow * 4, hipMemcpyDeviceToDevice, d->comm_stream));
+        }
+        VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, static_cast<size_t>(world) * kByteRow * 4, hipMemcpyDeviceToHost, d->comm_stream));
+        VRS_DHIP(d, hipStreamSynchronize(d->comm_stream));
+        std::vector<uint64_t> part_counts(static_cast<size_t>(P), 0);
+        for (int q = 0; q < world; ++q) {
+            const uint32_t *r = &d->host_table[static_cast<size_t>(q) * kByteRow];
+            if (r[257] != 0u) {
+                if (q == me) return dfail(d, my_status, my_error);
+                return dfail(d, VRS_ERROR_PEER, "rank " + std::to_string(q) + " failed in its range partition pass (status " + std::to_string(r[257]) + ")");
+            }
+            // the prefix of ranges [0, P): entry P (no such range: every later entry of the 256 holds the shard size) closes it
+            std::vector<uint64_t> &bq = base[static_cast<size_t>(q)];
+            for (int t = 0; t < P; ++t) bq[static_cast<size_t>(t)] = r[t];
+            bq[static_cast<size_t>(P)] = r[256];
+            for (int t = 0; t < P; ++t) part_counts[static_cast<size_t>(t)] += bq[static_cast<size_t>(t) + 1] - bq[static_cast<size_t>(t)];
+        }
+        for (int p = 0; p <= P; ++p) parts[static_cast<size_t>(p)] = static_cast<uint32_t>(p);  // part p IS range p
+        for (int p = 0; p < P; ++p) floors[static_cast<size_t>(p)] = p ? d->host_splitters[p - 1] : 0u;
+        worst = 0;
+        for (int q = 0; q < world; ++q) {
+            uint64_t s = 0;
+            for (int t = q * R; t < (q + 1) * R; ++t) s += part_counts[static_cast<size_t>(t)];
+            worst = std::max(worst, s);
+        }
+        if (static_cast<double>(worst) > d->max_imbalance * ideal || worst > min_capacity)
+            return dfail(d, VRS_ERROR_UNBALANCED,
+                         "too many equal keys: no cut between key VALUES gives every rank at most 15 % over the even share (and no more than "
+                         "the smallest capacity of all ranks)");
+    }
 
     // Byte shape: if no top byte holds more keys than its 256 sub-buckets can take (the same verdict on every rank: the summed
     // top-byte counts decide), the keys also land grouped by top byte and every round is finished by ONE counting read, the
     // second MSD pass by the next 8 bits and the local sort (vrs_msd_finish_grouped_u32: 20 B/key instead of a whole ranged sort's 28).
     bool grouped_finish = false;
-    if (!hybrid && !d->no_grouped_finish) {
+    if (!hybrid && !by_splitters && !d->no_grouped_finish) {
         uint64_t fullest = 0;
         for (int t = 0; t < 256; ++t) fullest = std::max(fullest, byte_counts[t]);
         grouped_finish = fullest <= 256u * 12500u && grand_total >= (1u << 16);
@@ -880,7 +999,7 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         vrs_buffer view = nullptr, sview = nullptr;
         int e = vrs_buffer_wrap(ctx, recv + round_off[static_cast<size_t>(r)], cnt * 4, &view);
         if (e == VRS_OK) e = vrs_buffer_wrap(ctx, scratch + round_off[static_cast<size_t>(r)], cnt * 4, &sview);
-        if (e == VRS_OK) e = vrs_sort_keys_u32_ranged(ctx, view, sview, static_cast<uint32_t>(cnt), parts[static_cast<size_t>(me) * R + r] << 24);
+        if (e == VRS_OK) e = vrs_sort_keys_u32_ranged(ctx, view, sview, static_cast<uint32_t>(cnt), floors[static_cast<size_t>(me) * R + r]);
         if (e == VRS_OK && by_top_byte) e = vrs_buffer_copy(ctx, sview, view, cnt * 4);
         if (view) (void)vrs_buffer_release(view);
         if (sview) (void)vrs_buffer_release(sview);

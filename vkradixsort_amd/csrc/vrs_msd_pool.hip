@@ -40,7 +40,7 @@ constexpr uint32_t kPoolBuckets = kMsdBucketCount;        // 16384
 constexpr uint32_t kPoolMinShift = 13, kPoolMaxShift = 18;  // a 27 ... 32-bit key range (the counted form's rule)
 constexpr uint32_t kPoolFlushAt = 65535u - kPoolTile;     // a 16-bit counter may take one more tile below this
 constexpr float kPoolSigmas = 6.0f;                       // overflow room, in standard deviations of the region's estimate
-constexpr uint32_t kPoolRoomFloor = 160;
+constexpr uint32_t kPoolRoomFloor = 320;
 
 __device__ __forceinline__ uint32_t xcc_of(unsigned long long xcc_map, uint32_t x) {
     return static_cast<uint32_t>((xcc_map >> (8u * x)) & 0xFFu);
@@ -129,8 +129,10 @@ __global__ __launch_bounds__(256) void pool_layout_kernel(PoolStreams ps, PoolPl
         const float r = sampled ? static_cast<float>(len) / static_cast<float>(sampled) : 1.0f;
         const uint32_t est = min(static_cast<uint32_t>(static_cast<float>(m) * r * 0.999999f), len);
         cap[s] = est & ~31u;
-        // the estimate scales m sampled keys up by r: its standard deviation is sqrt(r * est)
-        const uint32_t dev = static_cast<uint32_t>(kPoolSigmas * sqrtf(r * static_cast<float>(est)));
+        // the estimate scales m sampled keys up by r: its standard deviation is sqrt(r * est) -- of the TRUE expectation, which a
+        // small m underrates (m = 0 is what a region of 5 r keys shows once in 150 sorts): one more sampled key under the root,
+        // and a floor of 10 r keys
+        const uint32_t dev = static_cast<uint32_t>(kPoolSigmas * sqrtf(r * (static_cast<float>(est) + r)));
         room[s] = len ? (dev + (est - cap[s]) + kPoolRoomFloor + 31u) & ~31u : 0u;
         caps += cap[s];
         rooms += room[s];
@@ -834,7 +836,7 @@ PoolStreams pool_streams(uint32_t n) {
 uint32_t pool_overflow_capacity(uint32_t n) {
     // sum over the 2048 regions of [six deviations of an estimate scaled up 32-fold + rounding + floor], bounded by
     // Cauchy-Schwarz: sum sqrt(r e_i) <= sqrt(2048 r n); r is 32 but for the slices' ragged last tiles
-    const double room = 6.0 * std::sqrt(2048.0 * 33.0 * static_cast<double>(n)) + 2048.0 * (kPoolRoomFloor + 64.0);
+    const double room = 6.0 * std::sqrt(2048.0 * 33.0 * (static_cast<double>(n) + 2048.0 * 33.0)) + 2048.0 * (kPoolRoomFloor + 64.0);
     return static_cast<uint32_t>(std::min<double>(room, 1u << 28)) & ~31u;
 }
 

@@ -1,4 +1,5 @@
-// distsortexample [ranks] [keys per rank] [rounds] [seed]
+// distsortexample [ranks] [keys per rank] [rounds] [seed] [key bits]
+// (key bits < 32: keys >> (32 - bits) -- small keys, whose top bytes no byte-aligned cut can balance: the step cuts at sampled keys)
 // The multi-GPU step (vrs_dist_sort_keys_u32, BASELINE.json configs[4]) driven from a C++ host: one std::thread per rank, every
 // rank its own context on device (rank % device count), the wire the library's in-process transport (vrs_dist_loopback_*) --
 // device-to-device copies ordered by events.  With one GPU all ranks share it (how the rank-to-rank bookkeeping is tested here);
@@ -28,6 +29,7 @@ int main(int argc, char **argv) {
     const uint32_t n = argc > 2 ? static_cast<uint32_t>(std::strtod(argv[2], nullptr)) : 2000000u;
     const int rounds = argc > 3 ? std::atoi(argv[3]) : 2;
     const uint32_t seed = argc > 4 ? static_cast<uint32_t>(std::atoi(argv[4])) : 1000u;
+    const int key_bits = argc > 5 ? std::min(32, std::max(1, std::atoi(argv[5]))) : 32;
     try {
         int devices = 0;
         if (vrs_device_count(&devices) != VRS_OK || devices == 0) throw std::runtime_error(std::string("no device: ") + vrs_last_error(nullptr));
@@ -38,7 +40,7 @@ int main(int argc, char **argv) {
         for (int r = 0; r < world; ++r) {  // shard g uses seed + g
             std::mt19937 gen(seed + static_cast<uint32_t>(r));
             shards[static_cast<size_t>(r)].resize(n);
-            for (auto &k : shards[static_cast<size_t>(r)]) k = gen();
+            for (auto &k : shards[static_cast<size_t>(r)]) k = static_cast<uint32_t>(gen()) >> (32 - key_bits);
         }
         vrs_dist_loopback hub = nullptr;
         if (vrs_dist_loopback_create(world, &hub) != VRS_OK) throw std::runtime_error(vrs_dist_last_error(nullptr));
