@@ -273,6 +273,18 @@ def bench_single(args):
         primary(batches[i])
         gpu.waitIdle()
         singles.append((time.perf_counter() - t0) * 1e3)
+    # ---- the blocking form of the calls (VRS_TUNE_ASYNC_SORT = 0: every call waits for its plan's head), same batches back to back
+    blocking = None
+    if one_call:
+        rearm()
+        gpu.setTuning(capi.VRS_TUNE_ASYNC_SORT, 0)
+        gpu.waitIdle()
+        t0 = time.perf_counter()
+        for i in range(K):
+            primary(batches[i])
+        gpu.waitIdle()
+        blocking = (time.perf_counter() - t0) / K * 1e3
+        gpu.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)
     # ---- what a plain device-to-device copy of one batch achieves here (read + write bytes), beside the 8 TB/s figure
     copy_times = []
     for i in range(6):
@@ -305,6 +317,10 @@ def bench_single(args):
         "ms_per_step_individually_timed": {"min": round(min(singles), 4), "median": round(float(np.median(singles)), 4),
                                            "max": round(max(singles), 4),
                                            "note": "K further steps, each bracketed by a queue-idle wait (outside the timed region)"},
+        "calls": {"timed_region": "enqueue-only (the default on a context with its own stream: vrs_sort_keys_u32 returns at once, the next call "
+                                  "or vrs_queue_wait_idle settles what the plan still asks for)" if one_call else "stage calls (asynchronous)",
+                  "blocking_form_ms_per_step": round(blocking, 4) if blocking else None,
+                  "blocking_form_note": "VRS_TUNE_ASYNC_SORT = 0: every call waits for its plan's head; same batches back to back, outside the timed region"},
         "config": {"workload": f"BASELINE.json configs[{ {10 ** 7: 1, 10 ** 8: 2}.get(n, 2) }]: {n} uniform random uint32 keys (std::mt19937 seeds 1,2,3), "
                                f"multi_radixsort, 1xMI355X, keys resident in HBM",
                    "path": ("vrs_sort_keys_u32, pool form -- the hybrid form without a counting read: a sample of 1/32 of the keys sizes a region "

@@ -198,16 +198,21 @@ int vrs_single_radixsort(vrs_context ctx, vrs_buffer buffer0, vrs_buffer buffer1
  * vrs_sort_keys_u64 takes the same form from 2 * 10^7 keys on (56 instead of 144 bytes per key; the local sort then needs
  * ceil(low bits / 9) LDS passes, up to six); its counting read never makes LSD tables, so a refused sort starts over.
  *
- * Blocking behaviour.  By default these calls return once the plan's head has reached the host (they spin briefly, then yield;
- * never longer than VRS_TUNE_PLAN_WAIT_MS -> VRS_ERROR_TIMEOUT): on a stream that still has earlier work queued that means
- * waiting for that work.  With VRS_TUNE_ASYNC_SORT = 1 they only ENQUEUE -- like the reference's ComputePass::execute
- * (ComputePass.h:31-56), whose only blocking call is the queue-idle wait -- and return at once: a sort the hybrid form may take
- * is put on the stream completely (second MSD pass and local sort with grids sized for the worst plan the form accepts), the
- * LSD form as four speculative look-back passes.  What the plan may still ask for (a refused hybrid form: the LSD sort; a
- * pass with unbalanced or wide streams; the copy home after an odd number of passes) is enqueued by vrs_sort_settle, which
- * waits for the plan; vrs_queue_wait_idle, the blocking buffer transfers, vrs_verify_keys_u32, every stage / sort entry point
- * and vrs_context_destroy settle a pending sort first.  Until then the buffers must stay alive and nothing else may be queued
- * behind the sort that reads its result.  vrs_sort_pending tells whether a second half is outstanding (0 / 1).
+ * Blocking behaviour.  On a context with its OWN stream (vrs_context_create) these calls only ENQUEUE and return at once -- like
+ * the reference's ComputePass::execute (ComputePass.h:31-56), whose only blocking call is the queue-idle wait
+ * (MultiRadixSort.cpp:62): a sort the hybrid form is expected to take (the context's previous one of its kind did) is put on the
+ * stream completely (second MSD pass and local sort with grids sized for the worst plan the form accepts; the pool form with
+ * all six kernels), the LSD form as four speculative look-back passes.  What the plan may still ask for (a refused hybrid
+ * form: the LSD sort; a pass with unbalanced or wide streams; the copy home after an odd number of passes) is enqueued by
+ * vrs_sort_settle, which waits for the plan's head -- never for the sort; vrs_queue_wait_idle, the blocking buffer transfers,
+ * vrs_verify_keys_u32, every stage / sort entry point and vrs_context_destroy settle a pending sort first.  Until then the
+ * buffers must stay alive, and a caller who queues work of his own behind the sort (vrs_context_stream) calls vrs_sort_settle
+ * before he does.  vrs_sort_pending tells whether a second half is outstanding (0 / 1).
+ * On a BORROWED stream (vrs_context_create_on_stream) the caller waits with calls of his own (hipStreamSynchronize,
+ * torch.cuda.synchronize), so the default there is the blocking form: the call returns once the plan's head has reached the
+ * host and everything the plan asks for is on the stream (it spins briefly, then yields; never longer than
+ * VRS_TUNE_PLAN_WAIT_MS -> VRS_ERROR_TIMEOUT) -- on a stream that still has earlier work queued that means waiting for that
+ * work.  VRS_TUNE_ASYNC_SORT selects either form on either kind of context.
  */
 int vrs_sort_keys_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, uint32_t num_elements);
 /* The same sort for keys the caller knows to lie in [key_floor, 2^32) -- a sub-range of a larger sort (the received key range
@@ -464,9 +469,10 @@ typedef enum vrs_tuning_key {
     VRS_TUNE_SINGLE_MAX_KEYS = 9,  /* vrs_sort_keys_u32 runs up to this many keys as ONE single_radixsort launch (one
                                      workgroup, four passes) instead of twelve launch-bound multi-block launches;
                                      0 = never.  Default 4096 (measured crossover, profiles/r02_small_n_crossover.csv) */
-    VRS_TUNE_ASYNC_SORT = 14,      /* 1: vrs_sort_keys_u32 / _pairs_u32 / _keys_u64 only enqueue and return at once;
-                                     vrs_sort_settle (or any entry point that settles) finishes what the plan asks for.
-                                     0 (default): they return once the plan's head has reached the host */
+    VRS_TUNE_ASYNC_SORT = 14,      /* 1 (default on a context with its own stream): vrs_sort_keys_u32 / _pairs_u32 / _keys_u64 only
+                                     enqueue and return at once; vrs_sort_settle (or any entry point that settles) finishes what the
+                                     plan asks for.  0 (default on a borrowed stream): they return once the plan's head has reached
+                                     the host and the whole sort is on the stream */
     VRS_TUNE_PLAN_WAIT_MS = 15,    /* longest wait for a plan's head in milliseconds (default 60000; 0 = no limit) */
     VRS_TUNE_MSD_RESERVE = 16,     /* the two MSD passes of the hybrid form over BARE keys reserve their output ranges with one L2-local atomic
                                       add per tile and digit instead of a decoupled look-back (the order inside a bucket is free there;

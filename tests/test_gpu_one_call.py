@@ -1,4 +1,4 @@
-"""GPU parity tests of the one-call sort's large-N form (K5 in vrs_kernels.hip): ONE counting read of the keys
+"""GPU parity tests of the one-call sort's large-N form (K5 in vrs_one_call.hip): ONE counting read of the keys
 (digit_tables_kernel), then four scatter passes that find their offsets by decoupled look-back along 8 streams (one per XCD).
 The reference has no such entry point (its loop is MultiRadixSort.cpp:50-61); the acceptance criterion is the
 reference's own: the output must equal std::sort (MultiRadixSort.cpp:141-161), bit for bit, and pairs must

@@ -5,7 +5,7 @@
 #include <cstdlib>
 #include <random>
 #include <vector>
-#include "vrs_kernels.hip"
+#include "../../tools/lab/vrs_all_kernels.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 int main() {

@@ -32,7 +32,7 @@ __shared__ unsigned long long s_marks[8];
             g_marks[(size_t)blockIdx.x * 8 + 7] =                                                                \
                 ((unsigned long long)(polls) << 40) | ((unsigned long long)(rows) << 20) | (unsigned long long)(trips); \
     } while (0)
-#include "vrs_kernels.hip"
+#include "../../tools/lab/vrs_all_kernels.hip"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 

@@ -7,7 +7,7 @@
 #include <cstdlib>
 #include <random>
 #include <vector>
-#include "vrs_kernels.hip"
+#include "../../tools/lab/vrs_all_kernels.hip"
 
 namespace vrs {
 // ---------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ __shared__ unsigned long long s_marks[8];  // stamped in LDS, flushed once at th
             for (int i_ = 0; i_ < 7; ++i_) g_marks[(size_t)blockIdx.x * 8 + i_] = s_marks[i_]; \
         }                                                                                    \
     } while (0)
-#include "vrs_kernels.hip"
+#include "../../tools/lab/vrs_all_kernels.hip"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 

@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "vrs_kernels.hip"
+#include "../../tools/lab/vrs_all_kernels.hip"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 int main() {
     const uint32_t W = 12208;

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -55,7 +56,7 @@ struct vrs_context_t {
     };
     std::vector<EventPair> events[VRS_KERNEL_COUNT];
     size_t events_used[VRS_KERNEL_COUNT] = {};
-    // one-call sort for large N (K5 in vrs_kernels.hip)
+    // one-call sort for large N (K5 in vrs_one_call.hip)
     uint32_t one_call_min_keys = 1u << 13;  // measured: the one-read form wins from the single-launch threshold on (profiles/r02_one_call_crossover.csv)
     uint32_t single_max_keys = 4096;     // one-call uint32 key sorts up to this size run as ONE single_radixsort launch
     uint32_t *os_tables = nullptr;       // [4][kStreams][256] digit tables, zero between sorts
@@ -93,7 +94,7 @@ struct vrs_context_t {
     uint64_t os_hybrid_sorts = 0;        // one-call sorts that took the hybrid form
     uint64_t os_fallback_passes = 0;
     uint64_t os_skipped_passes = 0;      // identity passes (one digit value holds every key) the one-call sort left out     // passes the one-call sort ran through the contract path (unbalanced streams)
-    bool os_async = false;               // VRS_TUNE_ASYNC_SORT: the one-call sorts return without waiting for the plan; vrs_sort_settle finishes them
+    bool os_async = true;                // VRS_TUNE_ASYNC_SORT (default 1): the one-call sorts return without waiting for the plan; vrs_sort_settle finishes them
     uint32_t os_plan_wait_ms = 60000;    // VRS_TUNE_PLAN_WAIT_MS: longest wait for a plan's head (0 = no limit)
     int os_reserve = 1;                  // VRS_TUNE_MSD_RESERVE: the MSD passes over bare keys reserve their output instead of looking back
                                          // (1 or 2: whenever the hybrid form runs on bare keys; 0: never)
@@ -249,7 +250,7 @@ int check_buffer(vrs_context ctx, vrs_buffer b, size_t need, const char *name) {
     return VRS_OK;
 }
 
-// Runs the lane-order self-test the RANK_ATOMIC scatter variants depend on (see vrs_kernels.hip).
+// Runs the lane-order self-test the RANK_ATOMIC scatter variants depend on (see vrs_contract.hip).
 int atomic_rank_selftest(vrs_context ctx, uint32_t rounds, uint32_t seed, uint64_t *mismatches) {
     unsigned long long *d = nullptr;
     VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), sizeof(unsigned long long)));
@@ -313,6 +314,9 @@ int create_context(int device_ordinal, hipStream_t borrowed, bool borrow, vrs_co
     if (borrow) {
         ctx->stream = borrowed;
         ctx->owns_stream = false;
+        // whoever lends a stream waits on it with calls of his own (hipStreamSynchronize, torch.cuda.synchronize): what a sort puts
+        // on such a stream must be the whole sort when the call returns -- the blocking form is the default there
+        ctx->os_async = false;
     } else {
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
@@ -830,7 +834,10 @@ static OneReadGeometry one_read_geometry(vrs_context ctx, const vrs_context_t::O
     g.local_cap = vrs::msd_local_capacity(pairs || wide);
     if (st.blind_tail) {
         // uniform keys: N / 16384 + a few per cent -- unless the caller knows better (a sub-range of a larger sort: vrs_msd_finish_u32)
-        const uint64_t expect = st.bucket_hint ? st.bucket_hint : static_cast<uint64_t>(n) * 11u / 10u / vrs::kMsdBucketCount + 64u;
+        // (the fullest of 16384 buckets of uniform keys lies 4-4.5 deviations above the mean; one that does not fit after all is a
+        // refusal, not an error)
+        const double mean = static_cast<double>(n) / vrs::kMsdBucketCount;
+        const uint64_t expect = st.bucket_hint ? st.bucket_hint : static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u;
         if (pairs || wide) {
             if (expect <= vrs::msd_local_capacity_pairs_small()) g.local_cap = vrs::msd_local_capacity_pairs_small();
         } else if (expect <= vrs::msd_local_capacity_wave()) {
@@ -994,7 +1001,11 @@ static int one_read_enqueue(vrs_context ctx) {
                          ctx->scatter.atomic_rank && n >= hybrid_min && n >= (1u << 22) &&
                          static_cast<uint64_t>(n) <= 2ull * vrs::kMsdBucketCount * vrs::msd_local_capacity(pairs || wide) &&
                          (ctx->os_groups == 0 || ctx->os_groups == 8);
-        st.blind_tail = st.msd_capable && st.deferred;
+        // enqueued completely (enqueue-only calls): like the fast count it implies, only while the context's last hybrid-capable
+        // sort of this kind took the form (or always: VRS_TUNE_HYBRID_FAST_COUNT = 2) -- a refusal of a blind tail costs a second
+        // counting read, and data that was refused once is usually refused again
+        st.blind_tail = st.msd_capable && st.deferred &&
+                        (wide || ctx->os_fast_count == 2 || (ctx->os_fast_count == 1 && ctx->os_fast_count_armed[pairs ? 1 : 0]));
         // Fast count: the counting read of a hybrid-capable sort fills only the bucket histogram (1 LDS add per key instead
         // of 5).  If the plan then refuses the hybrid form, nothing has been moved and the sort starts over as an LSD sort
         // -- a second counting read.  Adaptive (default): fast only while the context's last hybrid-capable sort took the

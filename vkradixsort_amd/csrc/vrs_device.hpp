@@ -1,6 +1,6 @@
 // vrs_device.hpp -- device-side building blocks shared by the kernel families of libvkradixsort_amd (gfx950, wave64):
 // lane / digit helpers, the block scans, the stable scatter of one chunk through LDS (scatter_chunk) with its offset
-// sources (contract offsets, decoupled look-back, reservation).  Included by vrs_kernels.hip (contract stages K1-K4, the
+// sources (contract offsets, decoupled look-back, reservation).  Included by vrs_contract.hip (contract stages K1-K4), vrs_one_call.hip / vrs_msd_hybrid.hip (the
 // one-call sort K5 and its hybrid form K5b) and vrs_msd_pool.hip (the hybrid form without a counting read).
 #pragma once
 #include "vrs_kernels.h"
@@ -8,10 +8,6 @@
 #include <hip/hip_ext.h>
 
 #include <type_traits>
-
-#ifndef VRS_DT_UNROLL
-#define VRS_DT_UNROLL 8  // 16-byte loads in flight per lane in the counting read
-#endif
 
 // Launch with optional timing events bound to the dispatch packet itself (hipExtLaunchKernel): unlike
 // hipEventRecord brackets this adds no barrier packets between dependent kernels.
@@ -28,20 +24,13 @@
 #define VRS_MARK(i)
 #define VRS_MARK_FLUSH()
 #endif
-#ifndef VRS_LB_STAT
-#define VRS_LB_STAT(polls, rows, trips)
-#endif
-#ifndef VRS_LB_ITEMS
-#define VRS_LB_ITEMS 16  // keys per thread of a look-back tile of uint32 keys: 8192-key tiles (labs: 12 / 20 / 24 measure the same or worse)
-#endif
-#ifndef VRS_LB_BATCH
-#define VRS_LB_BATCH 4
-#endif
-#ifndef VRS_LB_WAVES
-#define VRS_LB_WAVES 8  // waves of a look-back workgroup of the LSD passes (lab builds: 4 = 4096-key tiles of 256 threads)
-#endif
-
 namespace vrs {
+
+// tile shapes of the one-call sort (measured choices: profiles/labs; lab builds that varied them are history)
+constexpr int kDtUnroll = 8;  // 16-byte loads in flight per lane in the counting read
+constexpr int kLbItems = 16;  // keys per thread of a look-back tile of uint32 keys: 8192-key tiles (12 / 20 / 24 measured the same or worse)
+constexpr int kLbBatch = 4;
+constexpr int kLbWaves = 8;   // waves of a look-back workgroup of the LSD passes
 
 constexpr int kBins = 256;     // RADIX_SORT_BINS
 constexpr int kThreads = 256;  // 4 wave64 per workgroup
@@ -238,7 +227,6 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_w(uint32_t v, uint32_t 
 // Progress never depends on another workgroup either: a tile polls an unpublished row at most `budget` times, then
 // stops waiting and counts the digits of its stream's earlier keys itself (same result; the guide's "bound every spin").
 constexpr uint32_t kLbInclusive = 1u << 28, kLbValue = (1u << 28) - 1u, kLbTagShift = 29;
-constexpr int kLbBatch = VRS_LB_BATCH;  // status rows fetched per round trip (2-4 measure the same, 8 and 16 slower)
 
 __device__ __forceinline__ uint32_t lb_load(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load sc1: L1 bypassed, L2 served
@@ -308,7 +296,6 @@ struct StreamLookback {
                 }
             }
             if (done_) {
-                VRS_LB_STAT(polls, static_cast<uint32_t>(index - first + consumed - 1), trips);
                 return acc;
             }
             first -= consumed;
@@ -436,7 +423,6 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const uint32_t d = dg(key[i]);
-#ifndef VRS_NO_UNIFORM_GUARD
             // Skew guard: 64 lanes on ONE counter are served one after the other (28 instead of 9 cycles per wave
             // instruction) -- input whose 64 consecutive keys share the digit (sorted keys under an MSD digit, constant
             // bytes) would crawl.  A wave-uniform digit needs no atomic per lane: lane 0 adds 64, rank = old + lane.
@@ -447,7 +433,6 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
                     old = __hip_atomic_fetch_add(&my_hist[d0], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 rank[i] = __builtin_amdgcn_readfirstlane(old) + lane;
             } else
-#endif
                 rank[i] = __hip_atomic_fetch_add(&my_hist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     } else {
@@ -584,7 +569,7 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     // the next chunk's first barrier (after it zeroes the counters) separates these LDS reads from its writes
 }
 
-// the hybrid forms (K5b in vrs_kernels.hip, vrs_msd_pool.hip): an MSD partition by the top kMsdBits bits of the key range
+// the hybrid forms (K5b in vrs_msd_hybrid.hip, vrs_msd_pool.hip): an MSD partition by the top kMsdBits bits of the key range
 constexpr uint32_t kMsdBits = 14, kMsdBuckets = 1u << kMsdBits;
 constexpr uint32_t kMsdMinShift = 13, kMsdMaxShift = 18;  // bucket shift of a 27 ... 32-bit key range
 // words behind the counts ([16384] histogram + [8][256] slice counts): the probed bucket shift and the "a key lies above

@@ -150,7 +150,7 @@ constexpr int kRowShift = kRowSlices + 3;   // hybrid shape: the probed bucket s
 constexpr int kRowOver = kRowSlices + 4;    // ... and != 0: a key of the shard lies above the probed range
 constexpr int kRowWords = kRowSlices + 8;
 constexpr uint32_t kSamplesPerRank = 2048;  // sampled-splitter steps: what every rank adds to the pool (<= kRowSlices: the pool travels in the row / table buffers)
-constexpr uint64_t kHybridShapeMaxBucket = 14333;  // msd_local_capacity of bare uint32 keys (vrs_kernels.hip); VRS_DIST_HYBRID_MAX_BUCKET (tests) lowers it
+constexpr uint64_t kHybridShapeMaxBucket = 14333;  // msd_local_capacity of bare uint32 keys (vrs_msd_hybrid.hip); VRS_DIST_HYBRID_MAX_BUCKET (tests) lowers it
 
 }  // namespace
 
@@ -606,7 +606,9 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
     }
     const uint32_t n_eff = my_status == VRS_OK ? n : 0u;
 
-    // the receive buffer may still be read by the sorts of the previous step's last round (they ran on the sort stream)
+    // the receive buffer may still be read by the sorts of the previous step's last round (they ran on the sort stream; one of
+    // them may still owe its second half: enqueue-only sorts)
+    VRS_D(d, vrs_sort_settle(ctx));
     VRS_DHIP(d, hipEventRecord(d->sorts_done, d->sort_stream));
     VRS_DHIP(d, hipStreamWaitEvent(d->comm_stream, d->sorts_done, 0));
 

@@ -7,6 +7,13 @@
 
 namespace vrs {
 
+// largest power of two <= x (x >= 1)
+inline uint32_t floor_pow2(uint32_t x) {
+    uint32_t p = 1;
+    while (p * 2u <= x) p *= 2u;
+    return p;
+}
+
 // Scratch owned by the context: offsets[W*256] and chunk_sums[G*256].
 struct PrefixScratch {
     uint32_t *offsets = nullptr;
@@ -70,11 +77,8 @@ hipError_t launch_verify_keys(hipStream_t stream, const uint32_t *keys, uint32_t
 // (fewer streams = fewer open write fronts per pass: 2048 instead of 8192, which is what the next pass's write drain
 // pays for).  groups is 8, 16 or 32 (a tuning choice: more groups = streams that follow skewed data better, fewer =
 // a cheaper counting read).
-#ifndef VRS_STREAMS
-#define VRS_STREAMS 8
-#endif
 constexpr int kMaxGroups = 32;
-constexpr int kStreams = VRS_STREAMS;    // a multiple of 8 that divides the group count: stream s runs on XCD s % 8
+constexpr int kStreams = 8;             // a multiple of 8 that divides the group count: stream s runs on XCD s % 8
 // one stream of one pass: a contiguous range of the pass's input
 struct StreamDesc {
     uint32_t start;        // first key of the stream in the pass's input

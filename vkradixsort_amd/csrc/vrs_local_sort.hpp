@@ -1,6 +1,6 @@
 // vrs_local_sort.hpp -- the LDS-local sort of one bucket of bare uint32 keys by its low 18 bits (two 9-bit passes), shared by
-// the counted hybrid form (vrs_kernels.hip: the bucket lies contiguous in the buffer and is sorted in place) and the pool form
-// (vrs_msd_pool.hip: the bucket is gathered from runs and written to its final place).  See vrs_kernels.hip, "the local sort of
+// the counted hybrid form (vrs_msd_hybrid.hip: the bucket lies contiguous in the buffer and is sorted in place) and the pool form
+// (vrs_msd_pool.hip: the bucket is gathered from runs and written to its final place).  See vrs_msd_hybrid.hip, "the local sort of
 // bare uint32 keys", for how the body is laid out for the LDS pipe.
 #pragma once
 #include "vrs_device.hpp"

@@ -1,7 +1,7 @@
 // vrs_msd_pool.hip -- the hybrid form of the one-call sort WITHOUT a counting read (bare uint32 keys): 24 bytes per key.
 //
 // The reference reads the keys once per pass just to count them (multi_radixsort_histograms.comp:42-50); the counted hybrid
-// form (vrs_kernels.hip, K5b) still reads them once for that.  Here they are not read for counting at all, and no pass waits
+// form (vrs_msd_hybrid.hip, K5b) still reads them once for that.  Here they are not read for counting at all, and no pass waits
 // for a histogram either:
 //
 //   pool_sample_kernel      1/32 of the input (the first 256 keys of every 8192-key tile): probes the key range (bucket shift)
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void pool_layout_kernel(PoolStreams ps, PoolPl
     }
     if (tid == 0) {
         pool->fail = 0;  // re-armed here: the passes of THIS sort set it, its local sort reads it
-        // a key range below 27 bits is left to the LSD passes, like the counted form does (vrs_kernels.hip, msd_plan_kernel)
+        // a key range below 27 bits is left to the LSD passes, like the counted form does (vrs_msd_hybrid.hip, msd_plan_kernel)
         pool->armed = (shift >= kPoolMinShift && shift <= kPoolMaxShift && total_room <= overflow_capacity) ? 1u : 0u;
     }
 }
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void pool_runs_kernel(MsdPlan *__restrict__ ms
 // Local sort: workgroup b = bucket b.  The bucket's keys lie in up to 64 runs.  They are first copied, run by run, into the
 // sort's LDS buffer -- wave w takes runs w, w + WAVES, ...; consecutive lanes read consecutive keys of a run: coalesced, no search
 // -- at word mis + (key's index in the bucket), mis = the misalignment of the bucket's FINAL place: from there every thread reads
-// its 16-byte vectors exactly as lean_sort_bucket (vrs_kernels.hip) reads them from the bucket in global memory.
+// its 16-byte vectors exactly as lean_sort_bucket (vrs_msd_hybrid.hip) reads them from the bucket in global memory.
 struct PoolGather {
     const uint32_t *regions, *overflow;
     uint32_t n_virt;
@@ -755,7 +755,7 @@ __device__ __forceinline__ void pool_sort_bucket(const PoolGather &gt, uint32_t 
 #pragma unroll
     for (int v = 0; v < WAVES; ++v) guards |= s_tmp[16 + v];
     guards = __builtin_amdgcn_readfirstlane(guards);
-    // (two copies of the rest, the guarded one out of line and staging again: see lean_sort_bucket, vrs_kernels.hip)
+    // (two copies of the rest, the guarded one out of line and staging again: see lean_sort_bucket, vrs_msd_hybrid.hip)
     if (guards == 0u) lean_sort_body<THREADS, VEC, false>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false);
     else pool_sort_guarded<THREADS, VEC>(gt, dx, dy, abase, mis, n, s_keys, s_hist2, s_tmp, guards);
 }
@@ -769,6 +769,14 @@ __global__ __launch_bounds__(THREADS, 4) void pool_local_sort_kernel(const uint3
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * kLeanMaxVec + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
     __shared__ uint32_t s_tmp[32];
+    // (bucket = block index: neighbouring buckets run on different XCDs and fetch the cache lines they share twice -- 22 % more
+    // bytes than the keys -- but with XCD-contiguous ranges of buckets, xcd_contiguous_tile, the gather measured 178 instead of 160 us)
+    const uint32_t b = blockIdx.x;
+    // The bucket's start and its run descriptors are asked for BEFORE the verdict is looked at (both tables exist whatever it
+    // says): a workgroup lives for a few memory latencies, and the verdict's words would be one more in front of these.
+    // every wave: lane l = run l's descriptor (512 contiguous bytes of the table)
+    const uint32_t begin = msd->base[b];
+    const uint2 d = reinterpret_cast<const uint2 *>(runs)[static_cast<size_t>(b) * kPoolRunSlots + (threadIdx.x & 63u)];
     // Verdict 2, by every workgroup from the same three words (all final when this kernel starts): verdict 1 said yes, no pass
     // flagged the sort, and the largest bucket fits this kernel's shape.  Workgroup 0 tells the host.
     const uint32_t mx = pool->max_bucket;
@@ -790,12 +798,6 @@ __global__ __launch_bounds__(THREADS, 4) void pool_local_sort_kernel(const uint3
     // the first pass's cursors, zero for the next sort (the counted form's local sort does the same: rearm_reservation)
     if (blockIdx.x < 2u * kStreams)
         for (uint32_t c = threadIdx.x; c < 256u; c += THREADS) cursors[blockIdx.x * 256u + c] = 0;
-    // (bucket = block index: neighbouring buckets run on different XCDs and fetch the cache lines they share twice -- 22 % more
-    // bytes than the keys -- but with XCD-contiguous ranges of buckets, xcd_contiguous_tile, the gather measured 178 instead of 160 us)
-    const uint32_t b = blockIdx.x;
-    const uint32_t begin = msd->base[b];
-    // every wave: lane l = run l's descriptor (512 contiguous bytes of the table)
-    const uint2 d = reinterpret_cast<const uint2 *>(runs)[static_cast<size_t>(b) * kPoolRunSlots + (threadIdx.x & 63u)];
     const uint32_t pk63 = __builtin_amdgcn_readlane(d.y, 63);
     const uint32_t n = (pk63 & 0xFFFFu) + (pk63 >> 16);
     const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys_out + begin) >> 2) & 3u);
