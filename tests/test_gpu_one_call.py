@@ -252,6 +252,43 @@ def test_look_back_does_not_depend_on_xcd_placement(gpu_context):
     assert np.array_equal(out, np.sort(keys))
 
 
+@pytest.mark.parametrize("stray", [9, 4095])
+def test_a_placement_that_holds_for_most_blocks_only_switches_the_l2_local_forms_off(stray):
+    """The look-back streams, the reservation cursors and the pool form's regions share L2-resident words between the workgroups of
+    one XCD: they rest on "block b runs on XCC f(b % 8)", which the context probes at creation (and every workgroup re-checks).  If the
+    probe finds the rule broken for even ONE block (test hook: block `stray` pretended elsewhere) none of those forms may run: the
+    sorts take the contract stages -- agent-scope data only -- whatever the size, and the hybrid form's halves refuse to start."""
+    with vrs.GPUContext(0) as gpu:
+        lib = gpu.lib
+        gpu.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 1 << 22)
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL, 2)
+        gpu.setTuning(capi.VRS_TUNE_DEBUG_XCC_STRAY_BLOCK, stray)
+        for n in (3000001, (1 << 23) + 5):
+            keys = make_keys(n, "uniform", seed=n % 89)
+            out, stats = sort_keys(gpu, keys)
+            assert np.array_equal(out, np.sort(keys))
+            assert stats["digit_tables"] == 0 and stats["lookback_scatter"] == 0 and stats["local_sort"] == 0 and stats["pool_sample"] == 0
+            assert stats["histogram"] == 4 and stats["scatter"] == 4
+        n = (1 << 22) + 1
+        keys = make_keys(n, "uniform", seed=3)
+        vals = np.arange(n, dtype=np.uint32)
+        ok, ov = sort_pairs_once(gpu, keys, vals)
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(ok, keys[order]) and np.array_equal(ov, vals[order])
+        kb = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), keys)
+        grouped, counts = vrs.Buffer(gpu, S(4 * n)), vrs.Buffer(gpu, S(4 * capi.MSD_COUNT_WORDS))
+        assert lib.vrs_msd_partition_u32(gpu.handle, kb.handle, grouped.handle, counts.handle, n) == capi.VRS_ERROR_INVALID_ARGUMENT
+        # probed again without the pretence: everything is back
+        gpu.setTuning(capi.VRS_TUNE_DEBUG_XCC_STRAY_BLOCK, -1)
+        gpu.check(lib.vrs_msd_partition_u32(gpu.handle, kb.handle, grouped.handle, counts.handle, n))
+        keys = make_keys((1 << 23) + 5, "uniform", seed=8)
+        out, stats = sort_keys(gpu, keys)
+        assert np.array_equal(out, np.sort(keys)) and stats["pool_sample"] == 1 and stats["histogram"] == 0
+        for b in (kb, grouped, counts):
+            b.release()
+
+
 @pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 1000, 4095, 4096, 4097, 5000, 10000, 70000])
 def test_small_n_goes_to_the_single_workgroup_kernel(gpu_context, oracle, n):
     """f1 of SURVEY section 8: vrs_sort_keys_u32 runs small inputs as ONE single_radixsort launch (the reference's

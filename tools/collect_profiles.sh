@@ -10,7 +10,7 @@ shift || true
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/profiles_$ROUND
 rm -rf $OUT; mkdir -p $OUT
-CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
+CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-configs $*"
 # 1. per-kernel time: kernel trace + stats of the bench command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 # 2. HBM traffic: separate --pmc passes (TCC: FETCH_SIZE costs 3 slots, WRITE_SIZE 2 -- not both in one pass)

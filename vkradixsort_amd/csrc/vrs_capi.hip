@@ -268,7 +268,7 @@ int atomic_rank_selftest(vrs_context ctx, uint32_t rounds, uint32_t seed, uint64
 // Where do the blocks of a big grid run?  The look-back streams of the one-call sort are laid out for "block b runs
 // on XCC b % 8" (any fixed function of b % 8 will do, a single XCC included).  That placement is observed, not
 // promised, so it is probed here; the kernels re-check it per workgroup and stay correct without it.
-int probe_xcc_map(vrs_context ctx) {
+int probe_xcc_map(vrs_context ctx, int stray_block = -1) {
     constexpr uint32_t kBlocks = 4096;
     uint32_t *d = nullptr;
     VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), kBlocks * sizeof(uint32_t)));
@@ -278,6 +278,9 @@ int probe_xcc_map(vrs_context ctx) {
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail_hip(ctx, "XCC placement probe", e);
+    // test hook (VRS_TUNE_DEBUG_XCC_STRAY_BLOCK): pretend ONE block of the probe ran elsewhere -- a placement that holds for most
+    // blocks only must switch every form that leans on it off, like one that holds for none
+    if (stray_block >= 0 && static_cast<uint32_t>(stray_block) < kBlocks) h[static_cast<size_t>(stray_block)] ^= 1u;
     unsigned long long map = 0;
     bool valid = true;
     for (uint32_t b = 0; b < kBlocks && valid; ++b) {
@@ -1920,6 +1923,8 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             ctx->os_pool = value;
             ctx->os_pool_skip = 0;
             return VRS_OK;
+        case VRS_TUNE_DEBUG_XCC_STRAY_BLOCK:
+            return probe_xcc_map(ctx, value);  // (a negative value probes again as at creation)
         case VRS_TUNE_MSD_POOL_MIN_KEYS:
             if (value < (1 << 22)) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form takes 2^22 keys or more");
             ctx->os_pool_min_keys = static_cast<uint32_t>(value);

@@ -396,14 +396,17 @@ struct alignas(16) PoolSmemB {
     alignas(16) uint32_t whist[8][kMsdSub];  // per-wave counters of the 64 digits -> per-wave starts
 };
 
-template <bool VECTOR>  // VECTOR: a full tile inside the primary region (16-byte aligned): 16-byte loads and stores
-__device__ __forceinline__ uint32_t pool_tile_b(PoolSmemB &sm, uint32_t *__restrict__ t0, uint32_t *__restrict__ t1, uint32_t split, uint32_t valid,
-                                                uint32_t shift, uint32_t key_base, uint32_t *__restrict__ row) {
+// vector: a full tile inside the primary region (16-byte aligned): 16-byte loads and stores.  The general form (a share's ragged
+// last tile, a tile that runs on into the overflow region: one tile in seven) goes through LDS with ROLLED loops on both sides --
+// its index arithmetic unrolled would cost the common form its third workgroup per CU, and out of line (a call) it cost 80 bytes
+// of scratch per lane saved and restored through HBM: 164 MB per sort, a fifth of this pass's traffic (profiles/r04: 968 -> 8xx MB).
+__device__ __forceinline__ uint32_t pool_tile_b(PoolSmemB &sm, bool vector, uint32_t *__restrict__ t0, uint32_t *__restrict__ t1, uint32_t split,
+                                                uint32_t valid, uint32_t shift, uint32_t key_base, uint32_t *__restrict__ row) {
     constexpr int ITEMS = 16, WAVES = 8;
     constexpr uint32_t THREADS = WAVES * 64;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t key[ITEMS];
-    if constexpr (VECTOR) {
+    if (vector) {  // (workgroup-uniform)
         const uint4 *v = reinterpret_cast<const uint4 *>(t0);
 #pragma unroll
         for (int i = 0; i < ITEMS / 4; ++i) {
@@ -414,34 +417,42 @@ __device__ __forceinline__ uint32_t pool_tile_b(PoolSmemB &sm, uint32_t *__restr
             key[4 * i + 3] = q.w;
         }
     } else {  // tile positions below `split` at t0, the others at t1; positions >= valid hold the padding key (digit 63, ranks last)
+#pragma unroll 1
+        for (uint32_t q = tid; q < kPoolTile; q += THREADS) sm.keys[q] = q < valid ? *(q < split ? t0 + q : t1 + q) : key_base - 1u;
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const uint32_t idx = wave * (ITEMS * 64) + i * 64 + lane;
-            const uint32_t j = idx < valid ? idx : valid - 1u;
-            const uint32_t k = *(j < split ? t0 + j : t1 + j);
-            key[i] = idx < valid ? k : key_base - 1u;
-        }
+        for (int i = 0; i < ITEMS; ++i) key[i] = sm.keys[wave * (ITEMS * 64) + i * 64 + lane];
+        // (the keys are written back to sm.keys two barriers further on)
     }
     uint32_t *my_hist = sm.whist[wave];
     my_hist[lane] = 0;  // this wave's own row (64 counters): its LDS operations stay in order
     // a key outside the probed range has bits above the range's 14 + shift (a range of 32 bits has no such key)
     const uint32_t above = shift + kMsdBits < 32u ? ~0u << (shift + kMsdBits) : 0u;
-    uint32_t rank[ITEMS], over = 0;
+    uint32_t rank2[ITEMS / 2], over = 0;  // two 13-bit ranks per register: 8 registers fewer, and the kernel fits a fourth workgroup per CU
+    if (vector) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i)
-        if (VECTOR || wave * (ITEMS * 64) + i * 64 + lane < valid) over |= (key[i] - key_base) & above;  // (the padding key is no key)
+        for (int i = 0; i < ITEMS; ++i) over |= (key[i] - key_base) & above;
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if (wave * (ITEMS * 64) + i * 64 + lane < valid) over |= (key[i] - key_base) & above;  // (the padding key is no key)
+    }
     // (key_base is a multiple of 2^24 and the 6 bits end at or below bit 24: the digit needs no subtraction)
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t d = (key[i] >> shift) & (kMsdSub - 1u);
         const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        uint32_t r;
         if (__ballot(d == d0) == ~0ull) {
             uint32_t old = 0;
             if (lane == 0u) old = __hip_atomic_fetch_add(&my_hist[d0], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            rank[i] = __builtin_amdgcn_readfirstlane(old) + lane;
+            r = __builtin_amdgcn_readfirstlane(old) + lane;
         } else {
-            rank[i] = __hip_atomic_fetch_add(&my_hist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            r = __hip_atomic_fetch_add(&my_hist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        if (i & 1) rank2[i / 2] |= r << 16;
+        else rank2[i / 2] = r;
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     // every wave: lane l = digit l -- its total, its start inside the tile, this wave's own start
@@ -469,32 +480,24 @@ __device__ __forceinline__ uint32_t pool_tile_b(PoolSmemB &sm, uint32_t *__restr
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) rank[i] += my_hist[(key[i] >> shift) & (kMsdSub - 1u)];
+    for (int i = 0; i < ITEMS; ++i)  // (ranks stay below 8192: no carry; opaque: the digits are computed again, not kept in 16 registers across the barriers)
+        rank2[i / 2] += my_hist[(opaque(key[i]) >> shift) & (kMsdSub - 1u)] << (16 * (i & 1));
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) sm.keys[rank[i]] = key[i];
+    for (int i = 0; i < ITEMS; ++i) sm.keys[(rank2[i / 2] >> (16 * (i & 1))) & 0xFFFFu] = key[i];
     __syncthreads();
     // back to the slots the tile was read from, in tile order
-    if constexpr (VECTOR) {
+    if (vector) {
         uint4 *v = reinterpret_cast<uint4 *>(t0);
 #pragma unroll
         for (int i = 0; i < ITEMS / 4; ++i) v[i * THREADS + tid] = reinterpret_cast<const uint4 *>(sm.keys)[i * THREADS + tid];
     } else {
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const uint32_t q = i * THREADS + tid;
-            if (q < valid) *(q < split ? t0 + q : t1 + q) = sm.keys[q];
-        }
+#pragma unroll 1
+        for (uint32_t q = tid; q < valid; q += THREADS) *(q < split ? t0 + q : t1 + q) = sm.keys[q];
     }
     return over;
 }
 
-// the general form out of line: its index arithmetic must not cost the common (vector) form its third workgroup per CU
-__device__ __attribute__((noinline)) uint32_t pool_tile_b_general(PoolSmemB &sm, uint32_t *__restrict__ t0, uint32_t *__restrict__ t1, uint32_t split,
-                                                                  uint32_t valid, uint32_t shift, uint32_t key_base, uint32_t *__restrict__ row) {
-    return pool_tile_b<false>(sm, t0, t1, split, valid, shift, key_base, row);
-}
-
-__global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(uint32_t *__restrict__ regions, uint32_t *__restrict__ overflow, const MsdPlan *__restrict__ msd,
+__global__ __launch_bounds__(512, 8) void pool_pass_b_kernel(uint32_t *__restrict__ regions, uint32_t *__restrict__ overflow, const MsdPlan *__restrict__ msd,
                                                              PoolPlan *__restrict__ pool, uint32_t *__restrict__ rows, uint32_t key_base) {
     __shared__ PoolSmemB sm;
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
@@ -513,11 +516,8 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(uint32_t *__restric
     uint32_t *t0 = regions + pool->base[s][a] + done;
     uint32_t *t1 = overflow + pool->obase[s][a] + (static_cast<int64_t>(done) - static_cast<int64_t>(prim));
     uint32_t *row = rows + static_cast<size_t>(blockIdx.x) * kMsdSub;
-    uint32_t over;
-    if (valid == kPoolTile && split >= kPoolTile && (reinterpret_cast<uintptr_t>(t0) & 15u) == 0u)  // workgroup-uniform
-        over = pool_tile_b<true>(sm, t0, t1, split, valid, msd->shift, key_base, row);
-    else
-        over = pool_tile_b_general(sm, t0, t1, split, valid, msd->shift, key_base, row);
+    const bool vector = valid == kPoolTile && split >= kPoolTile && (reinterpret_cast<uintptr_t>(t0) & 15u) == 0u;  // workgroup-uniform
+    const uint32_t over = pool_tile_b(sm, vector, t0, t1, split, valid, msd->shift, key_base, row);
     // a key above the probed range (or below the promised floor): the runs kernel, which gives the last verdict, sees this
     if (__ballot(over != 0u) != 0ull && (threadIdx.x & 63u) == 0u) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -771,6 +771,7 @@ __global__ __launch_bounds__(THREADS, 4) void pool_local_sort_kernel(const uint3
     __shared__ uint32_t s_tmp[32];
     // (bucket = block index: neighbouring buckets run on different XCDs and fetch the cache lines they share twice -- 22 % more
     // bytes than the keys -- but with XCD-contiguous ranges of buckets, xcd_contiguous_tile, the gather measured 178 instead of 160 us)
+    // (groups of 2 .. 16 neighbouring buckets per XCD, so that the lines neighbours share are fetched once: no difference, 218 us)
     const uint32_t b = blockIdx.x;
     // The bucket's start and its run descriptors are asked for BEFORE the verdict is looked at (both tables exist whatever it
     // says): a workgroup lives for a few memory latencies, and the verdict's words would be one more in front of these.
