@@ -359,6 +359,12 @@ def bench_single(args):
         "kernels_timed_region": kernels,
         "kernels_timed_region_note": f"HIP events on the dominant kernel's launches of every {args.event_every}th step of the timed region",
         "kernels_all_instrumented_rerun": breakdown,
+        "roofline_by_kernel": {name: {"algorithmic_bytes_per_launch": bpk * n, "avg_launch_us": breakdown[name]["avg_us"],
+                                      "frac": round(bpk * n / (breakdown[name]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                               for name, bpk in (("histogram", 4), ("scatter", 8), ("digit_tables", 4), ("lookback_scatter", 8), ("local_sort", 8))
+                               if name in breakdown and breakdown[name]["avg_us"]},
+        "roofline_by_kernel_note": "every byte-moving kernel of the timed path, from the all-kernels-instrumented rerun (launches carry events: "
+                                   "a few per cent slower than in the timed region); local_sort is LDS-bound, the others HBM-bound",
         "ms_per_step_uninstrumented_rerun": round(unprofiled / K * 1e3, 4),
         f"{other_name}_path": {
             "value": round(n * K / other_elapsed / 1e9, 3), "unit": "Gkeys/s", "ms_per_step": round(other_elapsed / K * 1e3, 4),
