@@ -273,10 +273,11 @@ def test_config2_1e8_keys_roofline_size(gpu_context, oracle):
 
 
 @pytest.mark.parametrize("one_call", [False, True], ids=["stages", "one_call"])
-def test_config3_1e8_pairs(gpu_context, one_call):
+def test_config3_1e8_pairs(gpu_context, oracle, one_call):
     # BASELINE.json configs[3]: 10^8 key+payload pairs; payload[i] = i; verified by properties:
     # keys sorted, keys[payload] reproduces the output keys (payload is a permutation that follows its key),
-    # and equal keys keep increasing payloads (stability).  Both ways to run the four passes.
+    # and equal keys keep increasing payloads (stability) -- which together ARE std::stable_sort's result; the one-call
+    # way is also compared with the oracle's std::stable_sort bit for bit, keys and payloads.  Both ways to run the passes.
     n = 10 ** 8
     keys = rand_keys(n, 2)
     vals = np.arange(n, dtype=np.uint32)
@@ -297,6 +298,9 @@ def test_config3_1e8_pairs(gpu_context, one_call):
     seen = np.zeros(n, np.bool_)
     seen[ov] = True
     assert seen.all()
+    if one_call:
+        rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
+        assert np.array_equal(rk, ok) and np.array_equal(rv, ov)
 
 
 @pytest.mark.parametrize("mode", [1, 2], ids=["ballot", "atomic"])
