@@ -276,7 +276,7 @@ struct PoolPlan {
     uint32_t fail;              // first pass: a region overflowed / a key outside the probed range / a CU behind no known L2 (zero between sorts)
     uint32_t ticket;            // sample kernel: workgroups done (zero between launches)
     uint32_t ok_a;              // verdict 1 (plan kernel): the second pass runs
-    uint32_t runs_ticket;       // runs kernel: workgroups done (zero between launches)
+    uint32_t runs_ticket;       // (unused)
     uint32_t max_bucket;        // runs kernel: keys in the largest bucket (zero between sorts)
     uint32_t pad;
     uint32_t sample[8][256];    // sampled keys of (slice, top byte), zero between sorts

@@ -5,8 +5,8 @@
 // for a histogram either:
 //
 //   pool_sample_kernel      1/32 of the input (the first 256 keys of every 8192-key tile): probes the key range (bucket shift)
-//                           and counts the top byte per input slice; its last workgroup lays out, for every (slice, top byte), a
-//                           PRIMARY region of the partner buffer sized by the estimate (the estimates of a slice sum to its
+//                           and counts the top byte per input slice; pool_layout_kernel (one workgroup behind it) lays out, for every
+//                           (slice, top byte), a PRIMARY region of the partner buffer sized by the estimate (the estimates of a slice sum to its
 //                           length, so the regions tile the n-key buffer) and an OVERFLOW region in context scratch of six
 //                           standard deviations of that estimate;
 //   pool_pass_a_kernel      first MSD pass (top 8 bits of the key range): a tile reserves its place in (slice, top byte)'s region
@@ -18,9 +18,9 @@
 //                           bits in LDS and writes them back to the slots it read them from, 16 bytes per lane, and leaves a
 //                           row of 64 (offset, count) pairs.  A bucket is then a set of RUNS, one per tile of its top byte;
 //   pool_runs_kernel        one workgroup per top byte: rows -> run descriptors per bucket, exact bucket starts (MsdPlan::base),
-//                           the largest bucket; the last one to finish gives verdict 2 and stamps the host head.  Up to here
-//                           the caller's buffer has not been written;
-//   pool_local_sort_kernel  one workgroup per bucket: gathers the bucket's runs (about 48 of about 128 keys), sorts the keys by
+//                           the largest bucket.  Up to here the caller's buffer has not been written;
+//   pool_local_sort_kernel  one workgroup per bucket -- every one derives verdict 2 from the same three words, workgroup 0 tells
+//                           the host: gathers the bucket's runs (about 48 of about 128 keys), sorts the keys by
 //                           their low 18 bits inside LDS (lean_sort_body, vrs_local_sort.hpp) and stores the bucket at its final
 //                           place in the caller's buffer.
 //
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void pool_plan_kernel(MsdPlan *__restrict__ ms
         pool->max_bucket = 0;  // (PoolPlan::fail stays: the second pass may still set it; the next sort's sample kernel re-arms it)
         msd->shift = shift;
         msd->sub_bits = kMsdSubBits;
-        msd->ok = 0;           // the runs kernel decides
+        msd->ok = 0;           // the local sort decides
     }
 }
 
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(512, 8) void pool_pass_b_kernel(uint32_t *__restric
     uint32_t *row = rows + static_cast<size_t>(blockIdx.x) * kMsdSub;
     const bool vector = valid == kPoolTile && split >= kPoolTile && (reinterpret_cast<uintptr_t>(t0) & 15u) == 0u;  // workgroup-uniform
     const uint32_t over = pool_tile_b(sm, vector, t0, t1, split, valid, msd->shift, key_base, row);
-    // a key above the probed range (or below the promised floor): the runs kernel, which gives the last verdict, sees this
+    // a key above the probed range (or below the promised floor): the local sort, which gives the last verdict, sees this
     if (__ballot(over != 0u) != 0ull && (threadIdx.x & 63u) == 0u) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
