@@ -1,6 +1,6 @@
 #!/bin/bash
-# The bench lines committed under profiles/ (unprofiled, as printed), all on ONE box:  gpurun -- 'tools/collect_bench_lines.sh r03'
-TAG=${1:-r03}
+# The bench lines committed under profiles/ (unprofiled, as printed), all on ONE box:  gpurun -- 'tools/collect_bench_lines.sh r04'
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/lines_$TAG
 rm -rf $OUT; mkdir -p $OUT
 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
@@ -10,6 +10,7 @@ for R in 1 4; do
   VRS_BENCH_FORCE_MULTI=1 python bench.py --rounds $R --rounds-forced --steps 10 --warmup 2 > $OUT/${TAG}_bench_multi_world1_R$R.json 2> $OUT/multi_R$R.err
   VRS_DIST_SHAPE=byte VRS_BENCH_FORCE_MULTI=1 python bench.py --rounds $R --rounds-forced --steps 10 --warmup 2 > $OUT/${TAG}_bench_multi_world1_byte_shape_R$R.json 2> $OUT/multi_byte_R$R.err
 done
+python bench.py --loopback-ranks 8 --n 2e6 --steps 5 > $OUT/${TAG}_bench_multi_loopback_world8.json 2> $OUT/loop8.err
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("$OUT/*.json")):
