@@ -34,6 +34,8 @@ with vrs.GPUContext(0) as gpu:
         gpu.setTuning(12, int(float(os.environ["VRS_HYBRID_MIN"])))
     if os.environ.get("VRS_RESERVE"):
         gpu.setTuning(16, int(os.environ["VRS_RESERVE"]))
+    if os.environ.get("VRS_POOL"):
+        gpu.setTuning(17, int(os.environ["VRS_POOL"]))
     if os.environ.get("VRS_FUSED_PLAN"):
         gpu.setTuning(10, int(os.environ["VRS_FUSED_PLAN"]))
 

@@ -352,6 +352,14 @@ struct StatusClear {
 };
 // ... and it re-arms the reservation counters of the MSD passes (MsdPlan::cursor_* / back_*): workgroup b = bucket b clears the
 // second pass's counters of its bucket, the first 2 * kStreams workgroups one row each of the first pass's.
+// Workgroup -> bucket of the local sorts: the LAST bucket first.  The second MSD pass writes the buckets in ascending order, so the
+// highest ones are what the memory-side cache (256 MB) still holds when the local sort starts; read in ascending order they would be
+// evicted by the time their turn comes (10^8 keys: the pool form's sort 214 -> 207 us, the counted form's 164 -> 160 and the counting read
+// behind it 138 -> 131; below 3e7 keys everything fits the cache either way; labs/r04_pool_form.txt).
+__device__ __forceinline__ uint32_t local_sort_bucket_of_block() {
+    return gridDim.x - 1u - blockIdx.x;
+}
+
 // (`cursors` = &MsdPlan::cursor_a of the same plan the kernel reads through a const pointer: a pointer of its own, so that the
 // plan's fields stay scalar loads)
 __device__ __forceinline__ void rearm_reservation(uint32_t *__restrict__ cursors, uint32_t threads) {
@@ -623,7 +631,8 @@ __global__ __launch_bounds__(THREADS, 4) void msd_local_sort_keys_kernel(uint32_
     if (msd->ok == 0u) return;  // enqueued before the plan was known, and the plan refused the hybrid form
     rearm_reservation(cursors, THREADS);
     clear_status_share(sc, THREADS);
-    const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
+    const uint32_t bkt = local_sort_bucket_of_block();
+    const uint32_t begin = msd->base[bkt], n = msd->base[bkt + 1] - begin;
     const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
     if (n == 0 || mis + n > THREADS * 4u * kLeanMaxVec) return;  // uniform; above the capacity cannot happen (the plan would have refused)
     uint32_t *abase = keys + begin - mis;
@@ -843,7 +852,8 @@ __global__ __launch_bounds__(64, 4) void msd_local_sort_wave_kernel(uint32_t *__
     if (msd->ok == 0u) return;
     rearm_reservation(cursors, 64);
     clear_status_share(sc, 64);
-    const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
+    const uint32_t bkt = local_sort_bucket_of_block();
+    const uint32_t begin = msd->base[bkt], n = msd->base[bkt + 1] - begin;
     const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys + begin) >> 2) & 3u);
     if (n == 0 || mis + n > 64u * 4u * kLeanMaxVec) return;
     uint32_t *abase = keys + begin - mis;
@@ -878,7 +888,8 @@ __global__ __launch_bounds__(THREADS, 4) void msd_local_sort_pairs_kernel(uint32
     if (msd->ok == 0u) return;
     rearm_reservation(cursors, THREADS);
     clear_status_share(sc, THREADS);
-    const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
+    const uint32_t bkt = local_sort_bucket_of_block();
+    const uint32_t begin = msd->base[bkt], n = msd->base[bkt + 1] - begin;
     if (n == 0 || n > CAP) return;
     uint32_t *bucket = keys + begin, *bvals = values + begin;
     const uint32_t used = (n + THREADS - 1u) / THREADS;
@@ -952,7 +963,8 @@ __global__ __launch_bounds__(THREADS, 4) void msd_local_sort_u64_kernel(uint64_t
     if (msd->ok == 0u) return;
     rearm_reservation(cursors, THREADS);
     clear_status_share(sc, THREADS);
-    const uint32_t begin = msd->base[blockIdx.x], n = msd->base[blockIdx.x + 1] - begin;
+    const uint32_t bkt = local_sort_bucket_of_block();
+    const uint32_t begin = msd->base[bkt], n = msd->base[bkt + 1] - begin;
     if (n == 0 || n > CAP) return;
     const uint32_t passes = (msd->shift + 8u) / 9u;
     uint64_t *bucket = keys + begin;
