@@ -34,6 +34,8 @@ with vrs.GPUContext(0) as gpu:
         gpu.setTuning(12, int(float(os.environ["VRS_HYBRID_MIN"])))
     if os.environ.get("VRS_RESERVE"):
         gpu.setTuning(16, int(os.environ["VRS_RESERVE"]))
+    if os.environ.get("VRS_ONE_CALL_MIN"):  # 0: vrs_sort_keys_u32 runs the contract stages (4 x [histogram, prefix, scatter])
+        gpu.setTuning(4, int(float(os.environ["VRS_ONE_CALL_MIN"])))
     if os.environ.get("VRS_POOL"):
         gpu.setTuning(17, int(os.environ["VRS_POOL"]))
     if os.environ.get("VRS_FUSED_PLAN"):
