@@ -373,12 +373,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
     uint32_t run_off =
         threadIdx.x < kBins ? offsets[static_cast<size_t>(w) * offset_row_stride * kBins + threadIdx.x] : 0u;
     constexpr uint32_t kChunk = ITEMS * WAVES * 64;
+    const bool stream_in = static_cast<size_t>(n) * sizeof(K) >= kStreamInBytes;
     for (uint32_t c0 = 0; c0 < tile_len; c0 += kChunk) {
         const uint32_t valid = min(kChunk, tile_len - c0);
         const K *kin = keys_in + tile_begin + c0;
         const uint32_t *vin = PAIRS ? values_in + tile_begin + c0 : nullptr;
         if (valid == kChunk)  // workgroup-uniform
-            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, kin, vin, keys_out, values_out, valid, dg, run_off);
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, kin, vin, keys_out, values_out, valid, dg, run_off, NoLookback{}, nullptr, 0u, stream_in);
         else
             scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, kin, vin, keys_out, values_out, valid, dg, run_off);
     }

@@ -26,6 +26,9 @@
 #endif
 namespace vrs {
 
+// a pass whose input is at least this large reads it with nontemporal loads (scatter_chunk, stream_in): half the memory-side cache
+constexpr size_t kStreamInBytes = size_t(128) << 20;
+
 // tile shapes of the one-call sort (measured choices: profiles/labs; lab builds that varied them are history)
 constexpr int kDtUnroll = 8;  // 16-byte loads in flight per lane in the counting read
 constexpr int kLbItems = 16;  // keys per thread of a look-back tile of uint32 keys: 8192-key tiles (12 / 20 / 24 measured the same or worse)
@@ -372,7 +375,7 @@ template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, bool FULL, typ
 __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> &sm, const K *kin,
                                               const uint32_t *vin, K *kout, uint32_t *vout,
                                               uint32_t valid, const DG &dg, uint32_t &run_off, const LB lb = {},
-                                              const K *kin1 = nullptr, uint32_t split = 0) {
+                                              const K *kin1 = nullptr, uint32_t split = 0, bool stream_in = false) {
     constexpr uint32_t THREADS = WAVES * 64;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -380,29 +383,42 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
 
     VRS_MARK(0);
     K key[ITEMS];
-    const uint32_t seg = wave * (ITEMS * 64) + lane;
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t idx = seg + i * 64;
-        if constexpr (SPLIT_SRC) {
-            const uint32_t j = FULL ? idx : (idx < valid ? idx : valid - 1u);
-            const K k = *(j < split ? kin + j : kin1 + j);
-            key[i] = (FULL || idx < valid) ? k : dg.template pad<K>();
-        } else if constexpr (FULL) {
-            key[i] = kin[idx];
-        } else {
-            // unpredicated load from a clamped index, then select: the padding key (all ones, seen from the digit's base) has
-            // the largest digit under every shift and the highest chunk indices, so it ranks behind every real key
-            const K k = kin[idx < valid ? idx : valid - 1u];
-            key[i] = idx < valid ? k : dg.template pad<K>();
-        }
-    }
     uint32_t val[PAIRS ? ITEMS : 1];
-    if constexpr (PAIRS) {
+    const uint32_t seg = wave * (ITEMS * 64) + lane;
+    // stream_in (workgroup-uniform): the pass's input is larger than the caches and nobody reads it again -- nontemporal loads, which
+    // leave the memory-side cache to what the pass WRITES (the next kernel reads that): 10^8 keys, contract scatter 138 -> 128 us, the
+    // MSD passes 146 -> 140, the pool form's first pass 154 -> 143; below about 3e7 keys everything fits the caches and it costs a
+    // little instead (10^7 keys: 0.108 -> 0.111 ms), so the callers switch it by size
+    if (FULL && !SPLIT_SRC && (LB::kPool || stream_in)) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) key[i] = __builtin_nontemporal_load(kin + seg + i * 64);
+        if constexpr (PAIRS) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) val[i] = __builtin_nontemporal_load(vin + seg + i * 64);
+        }
+    } else {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const uint32_t idx = seg + i * 64;
-            val[i] = vin[FULL ? idx : (idx < valid ? idx : valid - 1u)];
+            if constexpr (SPLIT_SRC) {
+                const uint32_t j = FULL ? idx : (idx < valid ? idx : valid - 1u);
+                const K k = *(j < split ? kin + j : kin1 + j);
+                key[i] = (FULL || idx < valid) ? k : dg.template pad<K>();
+            } else if constexpr (FULL) {
+                key[i] = kin[idx];
+            } else {
+                // unpredicated load from a clamped index, then select: the padding key (all ones, seen from the digit's base) has
+                // the largest digit under every shift and the highest chunk indices, so it ranks behind every real key
+                const K k = kin[idx < valid ? idx : valid - 1u];
+                key[i] = idx < valid ? k : dg.template pad<K>();
+            }
+        }
+        if constexpr (PAIRS) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const uint32_t idx = seg + i * 64;
+                val[i] = vin[FULL ? idx : (idx < valid ? idx : valid - 1u)];
+            }
         }
     }
     {

@@ -11,7 +11,22 @@ constexpr int kLeanRow = 512 + 64;  // words per counter table: 512 digits + one
 constexpr int kLeanMaxVec = 7;      // 16-byte vectors per thread: capacity THREADS * 28 slots
 // k[4 j + c] = slot q = 4 (j THREADS + tid) + c of the bucket seen from its first 16-byte boundary `abase`; slots [mis, mis + n)
 // hold keys (mis < 4).  Sorts them and stores the sorted bucket to abase[mis .. mis + n) (16-byte vector stores inside).
-template <int THREADS, int VEC, bool GUARD>
+// the sorted bucket's 16-byte stores.  STREAM: the bucket goes to a buffer nobody reads again soon (the pool form writes the caller's
+// buffer, its input came from elsewhere) -- a nontemporal store, which does not take room in the memory-side cache away from the
+// second pass's output the other buckets are still to read (pool form, 10^8 keys: 0.546 -> 0.529 ms).  Not for the in-place sorts of
+// the counted form: their lines are in the caches already.
+template <bool STREAM>
+__device__ __forceinline__ void store_sorted(uint4 *p, const uint4 &q) {
+    if constexpr (STREAM) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = {q.x, q.y, q.z, q.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+    } else {
+        *p = q;
+    }
+}
+
+template <int THREADS, int VEC, bool GUARD, bool STREAM = false>
 __device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
                                                uint32_t *s_hist2, uint32_t *s_tmp, bool guard1, bool guard2) {
     constexpr int WAVES = THREADS / 64, ITEMS = 4 * VEC, PER = 512 / THREADS;
@@ -187,12 +202,12 @@ __device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
     for (int j = 0; j < VEC; ++j) {
         const uint32_t v = j * THREADS + tid;
         if (j > 0 && j < VEC - 1) {
-            reinterpret_cast<uint4 *>(abase)[v] = reinterpret_cast<const uint4 *>(s_keys)[v];
+            store_sorted<STREAM>(reinterpret_cast<uint4 *>(abase) + v, reinterpret_cast<const uint4 *>(s_keys)[v]);
         } else if (v < nvec) {
             const uint4 q4 = reinterpret_cast<const uint4 *>(s_keys)[v];
             const uint32_t q = 4u * v;
             if (q >= mis && q + 4u <= end) {
-                reinterpret_cast<uint4 *>(abase)[v] = q4;
+                store_sorted<STREAM>(reinterpret_cast<uint4 *>(abase) + v, q4);
             } else {  // the two ends of the bucket: the neighbours' keys in the same 16 bytes are not ours to write
                 if (q + 0u - mis < n) abase[q + 0u] = q4.x;
                 if (q + 1u - mis < n) abase[q + 1u] = q4.y;

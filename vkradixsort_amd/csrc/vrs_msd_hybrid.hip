@@ -298,6 +298,7 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
     const uint32_t done = i * kTile;
     const uint32_t begin = first + done;
     const uint32_t valid = min(kTile, last - begin);
+    const bool stream_in = static_cast<size_t>(msd->base[kMsdBuckets]) * sizeof(K) >= kStreamInBytes;  // (all keys of the sort: the pass's input)
     BitsDigit dg{msd->shift, (1u << sub_bits) - 1u, key_base};
     const bool foreign = xcc_id() != static_cast<uint32_t>((xcc_map >> (8u * x)) & 0xFFu);
     uint32_t unused = 0;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
         lb.seed = msd->base[b];
         if (foreign) lb.region_len = msd->base[b + 1u] - lb.seed;
         if (valid == kTile)
-            scatter_chunk<K, ITEMS, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
+            scatter_chunk<K, ITEMS, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb, nullptr, 0u, stream_in);
         else
             scatter_chunk<K, ITEMS, 8, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     } else {
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
         lb.budget = spin_budget;
         lb.seed = threadIdx.x < (1u << sub_bits) ? msd->base[(a << sub_bits) + threadIdx.x] : 0u;
         if (valid == kTile)
-            scatter_chunk<K, ITEMS, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
+            scatter_chunk<K, ITEMS, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb, nullptr, 0u, stream_in);
         else
             scatter_chunk<K, ITEMS, 8, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     }

@@ -391,6 +391,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     if (forced == 2 && plan->head.msd_counted == 0u) return;
     const uint32_t done = i * kTile;
     const uint32_t begin = sd.start + done;
+    const bool stream_in = static_cast<size_t>(sd.len) * sizeof(K) * kStreams >= kStreamInBytes;  // (streams are about equal: the pass's input)
     const uint32_t valid = min(kTile, sd.len - done);
     RadixDigit<K> dg;
     dg.shift = shift == kShiftFromPlan ? plan->head.msd_shift_a : shift;  // first MSD pass of the hybrid form: set by msd_plan_kernel
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
             lb.region_len = plan->group_seed[pass][next_group][d] - lb.seed;
         }
         if (valid == kTile)
-            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb, nullptr, 0u, stream_in);
         else
             scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     } else {
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
         lb.budget = spin_budget;
         lb.seed = threadIdx.x < kBins ? plan->group_seed[pass][sd.first_group][threadIdx.x] : 0u;
         if (valid == kTile)
-            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb, nullptr, 0u, stream_in);
         else
             scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     }
