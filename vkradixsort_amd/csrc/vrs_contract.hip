@@ -105,10 +105,16 @@ __global__ __launch_bounds__(kThreads) void histogram_kernel(const K *__restrict
         const uint32_t nvec = (len - head) / V;
         constexpr uint32_t kStep = kThreads * UNROLL;  // vectors per fully unrolled step
         uint32_t i0 = 0;
+        const bool stream_in = static_cast<size_t>(n) * sizeof(K) >= kStreamInBytes;  // (below, everything fits the caches: plain loads)
         for (; i0 + kStep <= nvec; i0 += kStep) {  // every lane of every wave holds valid vectors
             Vec q[UNROLL];
+            if (stream_in) {
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) q[u] = v[i0 + u * kThreads + tid];
+                for (int u = 0; u < UNROLL; ++u) q[u] = load_stream16(v + i0 + u * kThreads + tid);
+            } else {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) q[u] = v[i0 + u * kThreads + tid];
+            }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) histogram_count_vec<K>(s_hist, q[u], dg);
         }

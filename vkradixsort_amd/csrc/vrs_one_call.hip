@@ -271,29 +271,38 @@ __global__ __launch_bounds__(THREADS, OCC) void digit_tables_kernel(const K *__r
         // vector) instead of one "all but one" at the top of the step.  It measures the same (the kernel runs at the
         // HBM rate of its 400 MB read plus the write-back of the previous kernel's dirty lines),
         // but the loads are what the comment above says they are.
-        if (kStep <= nvec) {
+        // (nontemporal loads when the keys exceed the caches: the counting read then runs at the rate it has with nothing before it --
+        // 98 instead of 133 us at 10^8 keys -- because it no longer has to push the previous kernel's dirty lines out in front of
+        // itself; what it saves the next kernel pays in part: 0.603 -> 0.587 ms per sort.  Below about 3e7 keys plain loads are faster.)
+        const auto main_loop = [&](auto nt) {
+            constexpr bool NT = decltype(nt)::value;
+            const auto load = [&](uint32_t at) { return NT ? load_stream16(v + at) : v[at]; };
+            if (kStep <= nvec) {
 #pragma unroll
-            for (int r = 0; r < UNROLL; ++r) {
-                cur[r] = v[r * THREADS + tid];
-                __builtin_amdgcn_sched_barrier(0);
+                for (int r = 0; r < UNROLL; ++r) {
+                    cur[r] = load(r * THREADS + tid);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-        }
-        for (; i0 + kStep <= nvec; i0 += kStep) {
-            // the refill is unconditional (the last step re-reads its own vectors, which nobody consumes): a
-            // conditional load would force the waits to cover the path on which it was not issued
-            const uint32_t refill = i0 + 2u * kStep <= nvec ? i0 + kStep : i0;  // workgroup-uniform
-            uint32_t vote = 0;
+            for (; i0 + kStep <= nvec; i0 += kStep) {
+                // the refill is unconditional (the last step re-reads its own vectors, which nobody consumes): a
+                // conditional load would force the waits to cover the path on which it was not issued
+                const uint32_t refill = i0 + 2u * kStep <= nvec ? i0 + kStep : i0;  // workgroup-uniform
+                uint32_t vote = 0;
 #pragma unroll
-            for (int r = 0; r < UNROLL; ++r) {
-                const Vec x = cur[r];
-                cur[r] = v[refill + r * THREADS + tid];
-                __builtin_amdgcn_sched_barrier(0);
-                if (r == 0)
-                    digit_tables_count_vec<K, TI, true, MSD>(t0, t[0], t[1], t[2], hm, msd_shift, msd_base, msd_over, x, base_shift, lane, vote);
-                else
-                    digit_tables_count_vec<K, TI, false, MSD>(t0, t[0], t[1], t[2], hm, msd_shift, msd_base, msd_over, x, base_shift, lane, vote);
+                for (int r = 0; r < UNROLL; ++r) {
+                    const Vec x = cur[r];
+                    cur[r] = load(refill + r * THREADS + tid);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r == 0)
+                        digit_tables_count_vec<K, TI, true, MSD>(t0, t[0], t[1], t[2], hm, msd_shift, msd_base, msd_over, x, base_shift, lane, vote);
+                    else
+                        digit_tables_count_vec<K, TI, false, MSD>(t0, t[0], t[1], t[2], hm, msd_shift, msd_base, msd_over, x, base_shift, lane, vote);
+                }
             }
-        }
+        };
+        if (static_cast<size_t>(n) * sizeof(K) >= kStreamInBytes) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
         for (uint32_t i = i0 + tid; i < nvec; i += THREADS) {
             const Vec q = v[i];
 #pragma unroll
