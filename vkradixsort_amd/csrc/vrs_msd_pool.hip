@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__rest
 #pragma unroll
         for (int c = 0; c < kLoads; ++c) {
             const uint64_t idx = begin + c * 64u + lane;
-            k[j][c] = keys[idx < n ? idx : n - 1u];
+            k[j][c] = __builtin_nontemporal_load(keys + (idx < n ? idx : n - 1u));  // (read again by the first pass: nothing to keep)
         }
     }
     // The buckets are the top 14 bits of the key RANGE: every workgroup ORs the same strided 4096 keys (as the counted form's
