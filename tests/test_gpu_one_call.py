@@ -705,7 +705,7 @@ def test_a_refused_reserving_sort_enqueued_blind_makes_no_claim_about_the_status
             order = np.argsort(pk, kind="stable")
             assert np.array_equal(ok, pk[order]) and np.array_equal(ov, pv[order])
     finally:
-        ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 0)
+        ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)  # (the default of a context with its own stream)
         ctx.setTuning(capi.VRS_TUNE_RANK_MODE, 0)
         ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
         ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 1)
@@ -799,6 +799,7 @@ def test_hybrid_form_with_buckets_beyond_the_small_local_sort(gpu_context, mode)
     ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
     ctx.setTuning(capi.VRS_TUNE_HYBRID, 1)  # forgets an earlier refusal of a 64-bit sort
     ctx.setTuning(capi.VRS_TUNE_MSD_POOL, 0)  # the COUNTED form is the subject (the pool form picks its local sort from n alone: it would refuse these buckets)
+    ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 0)  # ... in its blocking form, where the PLAN picks the local sort's shape (enqueued blind, N alone does)
     h0 = hybrid_sorts(ctx)
     try:
         if mode == "keys":
@@ -826,6 +827,7 @@ def test_hybrid_form_with_buckets_beyond_the_small_local_sort(gpu_context, mode)
     finally:
         ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
         ctx.setTuning(capi.VRS_TUNE_MSD_POOL, 1)
+        ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)
     assert hybrid_sorts(ctx) - h0 == (0 if mode == "pairs_too_large" else 1)
 
 

@@ -67,7 +67,7 @@ def pool_ctx(gpu_context):
     ctx.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 36000000)
     ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 0)
     ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 0)
-    ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 0)
+    ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)  # (the default of a context with its own stream)
 
 
 def sort_and_stats(ctx, keys, key_floor=None):

@@ -177,7 +177,7 @@ def main():
                 ctx.setTuning(capi.VRS_TUNE_MSD_POOL, 1)
                 ctx.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 36000000)
                 ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 0)
-                ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 0)
+                ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)
                 ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, -1)
                 ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 4096)
                 cases += 1

@@ -69,10 +69,11 @@ __global__ __launch_bounds__(1024) void msd_count_u64_kernel(const uint64_t *__r
         const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(keys + begin + head);
         const uint32_t nvec = (len - head) / 2u;
         uint32_t i0 = 0;
+        const bool stream_in = static_cast<size_t>(n) * sizeof(uint64_t) >= kStreamInBytes;  // (a read-only pass over keys beyond the caches: vrs_device.hpp)
         for (; i0 + THREADS * UNROLL <= nvec; i0 += THREADS * UNROLL) {
             ulonglong2 q[UNROLL];
 #pragma unroll
-            for (uint32_t r = 0; r < UNROLL; ++r) q[r] = v[i0 + r * THREADS + tid];
+            for (uint32_t r = 0; r < UNROLL; ++r) q[r] = stream_in ? load_stream16(v + i0 + r * THREADS + tid) : v[i0 + r * THREADS + tid];
 #pragma unroll
             for (uint32_t r = 0; r < UNROLL; ++r) {
                 count(q[r].x);
