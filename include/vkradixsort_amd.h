@@ -485,7 +485,7 @@ typedef enum vrs_tuning_key {
                                       bucket too large) starts over in the counted form with its input untouched.  1 (default) = adaptive: after a refusal the next 15
                                       such sorts of the context take the counted form; 2 = always tried; 0 = never.  Needs
                                       VRS_TUNE_MSD_RESERVE != 0. */
-    VRS_TUNE_MSD_POOL_MIN_KEYS = 18, /* the pool form is considered from this many keys on (default 3.6 * 10^7: the measured crossover with the counted form; never below 2^22) */
+    VRS_TUNE_MSD_POOL_MIN_KEYS = 18, /* the pool form is considered from this many keys on (default 3.2 * 10^7: the measured crossover with the counted form; never below 2^22) */
     VRS_TUNE_DEBUG_XCC_STRAY_BLOCK = 19 /* test hook: run the placement probe again and pretend block `value` (0 .. 4095) of it ran on
                                        another XCC: block b -> XCC (b % 8) then holds for most blocks only, and every form that leans on
                                        it (the one-call sorts' look-back streams, reservation, the hybrid and pool forms, vrs_msd_*) is

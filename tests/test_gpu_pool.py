@@ -17,7 +17,7 @@ from .test_gpu_one_call import launches, make_keys
 
 pytestmark = pytest.mark.gpu
 S = vrs.Buffer.BufferSettings
-POOL_MIN = 1 << 22  # the form's own floor (the default threshold is 3.6e7 keys: below it the counted form is the faster one)
+POOL_MIN = 1 << 22  # the form's own floor (the default threshold is 3.2e7 keys: below it the counted form is the faster one)
 
 
 def pool_counts(ctx):
@@ -64,7 +64,7 @@ def pool_ctx(gpu_context):
     ctx.setTuning(capi.VRS_TUNE_MSD_POOL, 2)
     yield ctx
     ctx.setTuning(capi.VRS_TUNE_MSD_POOL, 1)
-    ctx.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 36000000)
+    ctx.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 32000000)
     ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 0)
     ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 0)
     ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)  # (the default of a context with its own stream)

@@ -133,7 +133,7 @@ def main():
                 # round 4: the pool form (no counting read) at any size the hybrid form may take, off, adaptive or always; odd tiles of its
                 # first pass off their slices now and then
                 ctx.setTuning(capi.VRS_TUNE_MSD_POOL, int(rs.choice([0, 1, 2, 2])))
-                ctx.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, int(rs.choice([1 << 22, 1 << 22, 36000000])))
+                ctx.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, int(rs.choice([1 << 22, 1 << 22, 32000000])))
                 ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, int(rs.randint(0, 6) == 0))
                 # round 3: enqueue-only sorts (the download below settles them)
                 ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, int(rs.randint(0, 3) == 0))
@@ -175,7 +175,7 @@ def main():
                 ctx.setTuning(capi.VRS_TUNE_ONE_CALL_MIN_KEYS, capi.ONE_CALL_MIN_KEYS_DEFAULT)
                 ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 1)
                 ctx.setTuning(capi.VRS_TUNE_MSD_POOL, 1)
-                ctx.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 36000000)
+                ctx.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 32000000)
                 ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 0)
                 ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)
                 ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, -1)

@@ -108,7 +108,7 @@ struct vrs_context_t {
     size_t os_pool_rows_bytes = 0;
     vrs::PoolRun *os_pool_runs = nullptr;  // run descriptors [top byte][run slot][bucket of the top byte]
     uint64_t os_pool_sorts = 0, os_pool_refusals = 0;
-    uint32_t os_pool_min_keys = 36000000u;  // VRS_TUNE_MSD_POOL_MIN_KEYS
+    uint32_t os_pool_min_keys = 32000000u;  // VRS_TUNE_MSD_POOL_MIN_KEYS
     bool os_cursors_open = false;        // a reserving pass may have run without the local sort that re-arms its counters behind it
                                          // (a refused plan, a partition with no finish, an error in between): cleared before the next use
     // a one-call sort between its two halves (see one_read_enqueue / one_read_complete)
@@ -1023,7 +1023,7 @@ static int one_read_enqueue(vrs_context ctx) {
         // misjudged a region, a key range the probe missed, a bucket above the local sort's capacity) costs the first pass, so
         // the default is adaptive: after one, the next 15 such sorts of the context take the counted form.
         // (sizes: the local sort gathers a bucket from at most 56 runs -- one per second-pass tile of its top byte, about
-        // n / 256 / 8192 + 8 -- and below 3.6e7 keys the counted form's one-wave-per-bucket local sort is the faster one)
+        // n / 256 / 8192 + 8 -- and below 3.2e7 keys the counted form's one-wave-per-bucket local sort is the faster one)
         const bool candidate = st.msd_capable && !pairs && !wide && !st.no_pool && ctx->os_pool != 0 && reserves(ctx, n, false) &&
                                n >= ctx->os_pool_min_keys && (ctx->os_pool == 2 || n <= 115000000u);
         st.pool = candidate && (ctx->os_pool == 2 || ctx->os_pool_skip == 0);
