@@ -359,6 +359,11 @@ int vrs_dist_sort_keys_u32(vrs_dist dist, vrs_buffer keys, uint32_t num_elements
                            uint32_t *out_count);
 /* bounds[0] = 0 <= ... <= bounds[parts] = 256: part q owns top bytes [bounds[q], bounds[q+1]); host only */
 int vrs_dist_plan_splitters(const uint64_t *counts256, int parts, uint32_t *bounds);
+/* The cut keys of a sampled-splitter step (host only): samples[q * per_rank + i] = the i-th of per_rank keys taken at evenly spaced
+ * positions of rank q's shard; a sample of rank q stands for shard_sizes[q] / per_rank keys.  splitters[p - 1], 1 <= p < parts, = the
+ * first sample in key order at which p / parts of all keys have gone by (ascending; range r = number of splitters <= key). */
+int vrs_dist_plan_sampled_splitters(const uint32_t *samples, const uint64_t *shard_sizes, int world, uint32_t per_rank, int parts,
+                                    uint32_t *splitters);
 const char *vrs_dist_last_error(vrs_dist dist);
 /* cumulative: received sub-ranges finished in the hybrid shape / sorted by vrs_sort_keys_u32 after a refused plan; steps
  * that took the byte shape.  Any pointer may be NULL. */

@@ -173,6 +173,67 @@ def test_dist_plan_splitters_matches_the_python_orchestration():
             assert np.array_equal(out.astype(np.int64), plan_splitters(counts.astype(np.int64), parts)), (counts[:8], parts)
 
 
+def test_dist_sampled_splitters_cut_at_weighted_quantiles():
+    """vrs_dist_plan_sampled_splitters (host only): what the multi-GPU step cuts at when top bytes are too concentrated for
+    byte-aligned ranges -- the weighted quantiles of the pooled samples.  Simulated end to end on the CPU: shards of very different
+    sizes (one empty) with small / clustered keys, 2048 evenly spaced samples per rank, then every part must hold its share of ALL keys
+    within a few per cent; massive ties give equal cut keys (the caller then finds the parts unbalanced)."""
+    import ctypes
+
+    import numpy as np
+
+    from vkradixsort_amd import capi
+    lib = capi.load_library()
+    S = 2048
+    rs = np.random.RandomState(4)
+
+    def shards_of(kind, sizes):
+        out = []
+        for i, m in enumerate(sizes):
+            k = rs.randint(0, 2 ** 32, size=m, dtype=np.uint32)
+            if kind == "16bit":
+                k >>= np.uint32(16)
+            elif kind == "clustered":
+                c = rs.rand(m) < 0.75
+                k[c] = (k[c] & np.uint32(0x00FFFFFF)) | np.uint32(0x40000000)
+            elif kind == "per_rank_ranges":  # every rank holds another part of the key space: the weights matter
+                k = (k >> np.uint32(4)) + np.uint32(i << 28)
+            out.append(k)
+        return out
+
+    def cut(shards, parts):
+        world = len(shards)
+        samples = np.zeros(world * S, np.uint32)
+        for q, k in enumerate(shards):
+            if k.size:
+                samples[q * S:(q + 1) * S] = k[(np.arange(S, dtype=np.uint64) * np.uint64(k.size - 1) // np.uint64(S - 1)).astype(np.int64)]
+        sizes = np.array([k.size for k in shards], np.uint64)
+        sp = np.zeros(max(parts - 1, 1), np.uint32)
+        rc = lib.vrs_dist_plan_sampled_splitters(samples.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                                 sizes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), world, S, parts,
+                                                 sp.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+        assert rc == 0
+        return sp[:parts - 1]
+
+    for kind, sizes, parts in [("16bit", [300000, 300000], 4), ("clustered", [400000, 50000, 0], 6), ("per_rank_ranges", [600000, 60000, 200000, 0], 8),
+                               ("uniform", [100000] * 8, 32)]:
+        shards = shards_of(kind, sizes)
+        sp = cut(shards, parts)
+        assert np.all(sp[1:] >= sp[:-1])
+        allk = np.concatenate(shards)
+        part_of = np.searchsorted(sp, allk, side="right")  # range = number of cut keys <= key
+        counts = np.bincount(part_of, minlength=parts)
+        ideal = allk.size / parts
+        assert counts.max() <= 1.12 * ideal and counts.min() >= 0.88 * ideal, (kind, counts.tolist())
+    # massive ties: three key values for four parts -- some cut keys coincide, some part is empty: the step reports UNBALANCED
+    ties = [(rs.randint(0, 3, 200000).astype(np.uint32) * np.uint32(0x10000001)) for _ in range(2)]
+    sp = cut(ties, 4)
+    counts = np.bincount(np.searchsorted(sp, np.concatenate(ties), side="right"), minlength=4)
+    assert counts.max() > 1.15 * (400000 / 4)
+    # bad arguments
+    assert lib.vrs_dist_plan_sampled_splitters(None, None, 2, S, 4, None) == capi.VRS_ERROR_INVALID_ARGUMENT
+
+
 def test_round3_entry_points_reject_null_and_need_no_device(lib):
     """The enqueue-only sorts' settle / pending calls, the context accessor and the in-process transport hub of the multi-GPU
     step validate their arguments without touching a device (host-side objects only)."""

@@ -136,6 +136,7 @@ _SIGNATURES = [
     ("vrs_dist_create_with_transport", c_int, [c_void_p, c_void_p, c_int, c_int, c_uint32, c_int, POINTER(c_void_p)]),
     ("vrs_dist_destroy", c_int, [c_void_p]),
     ("vrs_dist_stats", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
+    ("vrs_dist_plan_sampled_splitters", c_int, [POINTER(c_uint32), POINTER(c_uint64), c_int, c_uint32, c_int, POINTER(c_uint32)]),
     ("vrs_dist_grouped_rounds", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_dist_splitter_steps", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_dist_loopback_create", c_int, [c_int, POINTER(c_void_p)]),

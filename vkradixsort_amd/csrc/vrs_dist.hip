@@ -460,6 +460,34 @@ int vrs_dist_plan_splitters(const uint64_t *counts256, int parts, uint32_t *boun
     return VRS_OK;
 }
 
+// The cut keys of a sampled-splitter step: `samples` holds per_rank keys of every rank's shard (rank-major), taken at evenly spaced
+// positions; a sample of rank q stands for shard_sizes[q] / per_rank keys (an empty shard's samples count for nothing).  Cut key p
+// (1 <= p < parts) is the first sample, in key order, at which p / parts of all keys have gone by; range r = number of cut keys <= key.
+// Host only, deterministic, the same on every rank.
+int vrs_dist_plan_sampled_splitters(const uint32_t *samples, const uint64_t *shard_sizes, int world, uint32_t per_rank, int parts,
+                                    uint32_t *splitters) {
+    if (!samples || !shard_sizes || !splitters || world < 1 || per_rank == 0 || parts < 1)
+        return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "samples, shard sizes, splitters, world, per_rank or parts invalid");
+    std::vector<std::pair<uint32_t, double>> pool;  // (key, keys it stands for)
+    pool.reserve(static_cast<size_t>(world) * per_rank);
+    uint64_t total = 0;
+    for (int q = 0; q < world; ++q) {
+        total += shard_sizes[q];
+        if (!shard_sizes[q]) continue;
+        const double w = static_cast<double>(shard_sizes[q]) / per_rank;
+        for (uint32_t i = 0; i < per_rank; ++i) pool.emplace_back(samples[static_cast<size_t>(q) * per_rank + i], w);
+    }
+    std::sort(pool.begin(), pool.end(), [](const std::pair<uint32_t, double> &a, const std::pair<uint32_t, double> &b) { return a.first < b.first; });
+    double cum = 0;
+    size_t i = 0;
+    for (int p = 1; p < parts; ++p) {
+        const double target = static_cast<double>(total) * p / parts;
+        while (i < pool.size() && cum + pool[i].second < target) cum += pool[i++].second;
+        splitters[p - 1] = i < pool.size() ? pool[i].first : 0xFFFFFFFFu;
+    }
+    return VRS_OK;
+}
+
 const char *vrs_dist_last_error(vrs_dist d) { return d ? d->last_error.c_str() : g_dist_error.c_str(); }
 
 int vrs_dist_create_with_transport(vrs_context ctx, const vrs_dist_transport *transport, int rank, int world,
@@ -813,23 +841,7 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         }
         VRS_DHIP(d, hipMemcpyAsync(d->host_table.data(), table, static_cast<size_t>(world) * S * 4, hipMemcpyDeviceToHost, d->comm_stream));
         VRS_DHIP(d, hipStreamSynchronize(d->comm_stream));
-        std::vector<std::pair<uint32_t, double>> pool;  // (key, keys it stands for)
-        pool.reserve(static_cast<size_t>(world) * S);
-        for (int q = 0; q < world; ++q) {
-            if (!shard[static_cast<size_t>(q)]) continue;
-            const double w = static_cast<double>(shard[static_cast<size_t>(q)]) / S;
-            for (uint32_t i = 0; i < S; ++i) pool.emplace_back(d->host_table[static_cast<size_t>(q) * S + i], w);
-        }
-        std::sort(pool.begin(), pool.end(), [](const std::pair<uint32_t, double> &a, const std::pair<uint32_t, double> &b) { return a.first < b.first; });
-        {
-            double cum = 0;
-            size_t i = 0;
-            for (int p = 1; p < P; ++p) {  // cut key p: the first sample at which p / P of the weight has gone by
-                const double target = static_cast<double>(grand_total) * p / P;
-                while (i < pool.size() && cum + pool[i].second < target) cum += pool[i++].second;
-                d->host_splitters[p - 1] = i < pool.size() ? pool[i].first : 0xFFFFFFFFu;
-            }
-        }
+        if ((rc = vrs_dist_plan_sampled_splitters(d->host_table.data(), shard.data(), world, S, P, d->host_splitters))) return rc;
         if (P > 1) VRS_DHIP(d, hipMemcpyAsync(vrs_buffer_device_ptr(d->splitters), d->host_splitters, static_cast<size_t>(P - 1) * 4, hipMemcpyHostToDevice, d->sort_stream));
         uint32_t *prefix = row;  // as in the byte shape: [0, 256) exclusive prefix of my range counts, [256] shard size, [257] status, [258] capacity
         if (n_eff) {
