@@ -273,6 +273,25 @@ def test_config2_1e8_keys_roofline_size(gpu_context, oracle):
 
 
 @pytest.mark.parametrize("one_call", [False, True], ids=["stages", "one_call"])
+@pytest.mark.parametrize("n", [(1 << 25) - 1, 1 << 25, (1 << 25) + 8193])
+def test_inputs_around_the_streaming_threshold(gpu_context, oracle, n, one_call):
+    """Inputs of 128 MB and more are read with nontemporal loads (histogram stage, counting read, scatter passes; the pool form, which
+    also streams its sorted output, starts at 3.2e7 keys): 2^25 uint32 keys are exactly 128 MB -- one key less, that many, a ragged
+    tile more, through the stages and through the one-call sort, bit for bit against std::sort."""
+    keys = rand_keys(n, n % 1000)
+    m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=32, keys=keys, quiet=True)
+    m.m_oneCallSort = one_call
+    m.setup(gpu_context)
+    m.enqueueSort()
+    gpu_context.waitIdle()
+    out = m.download()
+    m.releaseBuffers()
+    m.m_pass.release()
+    ref, _ = oracle.std_sort(keys)
+    assert oracle.test_sort(ref, out) == -1
+
+
+@pytest.mark.parametrize("one_call", [False, True], ids=["stages", "one_call"])
 def test_config3_1e8_pairs(gpu_context, oracle, one_call):
     # BASELINE.json configs[3]: 10^8 key+payload pairs; payload[i] = i; verified by properties:
     # keys sorted, keys[payload] reproduces the output keys (payload is a permutation that follows its key),
