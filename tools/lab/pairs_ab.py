@@ -21,3 +21,9 @@ with vrs.GPUContext(0) as gpu:
         gpu.waitIdle(); dt=(time.perf_counter()-t0)/K
         if rep: best=min(best,dt)
     print(f"{tag:10s} pairs n={n}: {best*1e3:.4f} ms/sort", flush=True)
+    if os.environ.get("VRS_CHECK"):
+        ok=np.empty(n,dtype=np.uint32); ov=np.empty(n,dtype=np.uint32)
+        kb[0].downloadWithStagingBuffer(ok); vb[0].downloadWithStagingBuffer(ov)
+        good = bool((np.diff(ok.astype(np.int64))>=0).all()) and bool((keys[ov]==ok).all())
+        eq = ok[1:]==ok[:-1]; good = good and bool((ov[1:][eq] > ov[:-1][eq]).all())
+        print(f"{tag:10s} check: {'ok' if good else 'BAD'}", flush=True)
