@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <random>
 #include <vector>
 
 #define CK(x)                                                                          \
@@ -41,11 +42,17 @@ __global__ void check_sorted(const uint32_t *k, uint32_t n, unsigned long long *
 int main(int argc, char **argv) {
     const uint32_t n = argc > 1 ? static_cast<uint32_t>(atof(argv[1])) : 100000000u;
     const int reps = argc > 2 ? atoi(argv[2]) : 6;
+    const int mt_seed = argc > 3 ? atoi(argv[3]) : -1;  // >= 0: keys = std::mt19937(seed) outputs (what numpy's RandomState(seed).randint(0, 2**32) draws)
+    std::vector<uint32_t> host_keys;
+    if (mt_seed >= 0) {
+        host_keys.resize(n);
+        std::mt19937 gen(static_cast<uint32_t>(mt_seed));
+        for (auto &x : host_keys) x = gen();
+    }
     hipStream_t st;
     CK(hipStreamCreate(&st));
-    uint32_t *keys[4], *partner, *ovf, *rows, *xo;
+    uint32_t *keys[4], *partner, *ovf, *slack, *xo;
     vrs::PoolPlan *pool;
-    vrs::PoolRun *runs;
     vrs::MsdPlan *msd;
     vrs::OnesweepPlanHead *head;
     unsigned long long *chk;
@@ -53,8 +60,8 @@ int main(int argc, char **argv) {
     for (auto &k : keys) CK(hipMalloc(&k, 4ull * n));
     CK(hipMalloc(&partner, 4ull * n));
     CK(hipMalloc(&ovf, 4ull * room));
-    CK(hipMalloc(&rows, vrs::pool_rows_bytes(n)));
-    CK(hipMalloc(&runs, vrs::kPoolRunBytes));
+    const uint32_t slack_cap = vrs::pool_slack_capacity(n);
+    CK(hipMalloc(&slack, 4ull * slack_cap));
     CK(hipMalloc(&pool, sizeof(vrs::PoolPlan)));
     CK(hipMalloc(&msd, sizeof(vrs::MsdPlan)));
     CK(hipMalloc(&head, sizeof(vrs::OnesweepPlanHead)));
@@ -72,12 +79,13 @@ int main(int argc, char **argv) {
     hipEvent_t ev[8];
     for (auto &e : ev) CK(hipEventCreate(&e));
     const uint32_t tiles_b = vrs::pool_tiles_b_cap(n);
-    const bool big = static_cast<uint64_t>(n) * 11u / 10u / vrs::kMsdBucketCount + 64u > vrs::pool_local_capacity(false);
+    const bool big = getenv("POOL_LAB_BIG") ? atoi(getenv("POOL_LAB_BIG")) != 0 : static_cast<uint64_t>(n) * 11u / 10u / vrs::kMsdBucketCount + 64u > vrs::pool_local_capacity(false);
     double sum[7] = {0, 0, 0, 0, 0, 0, 0};
     int counted = 0;
     for (int r = 0; r < reps + 2; ++r) {
         uint32_t *in = keys[r % 4];
-        hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, st, in, n, 12345u + r);
+        if (mt_seed >= 0) CK(hipMemcpyAsync(in, host_keys.data(), 4ull * n, hipMemcpyHostToDevice, st));
+        else hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, st, in, n, 12345u + r);
         CK(hipMemsetAsync(chk, 0, 32, st));
         hipLaunchKernelGGL(check_sorted, dim3(2048), dim3(256), 0, st, in, n, chk + 2);  // chk[3] = key sum of the input
         CK(hipMemsetAsync(reinterpret_cast<char *>(msd) + offsetof(vrs::MsdPlan, cursor_a), 0, vrs::kMsdCursorBytes, st));
@@ -86,13 +94,12 @@ int main(int argc, char **argv) {
         CK(hipEventRecord(ev[1], st));
         CK(vrs::launch_pool_pass_a(st, in, partner, ovf, n, 0, ps, pool, msd, xcc_map, false, room));
         CK(hipEventRecord(ev[2], st));
-        CK(vrs::launch_pool_plan(st, msd, pool, n, tiles_b));
+        CK(vrs::launch_pool_plan(st, msd, pool, n, tiles_b, slack_cap, partner, ovf, 0, ps));
         CK(hipEventRecord(ev[3], st));
-        CK(vrs::launch_pool_pass_b(st, partner, ovf, n, msd, pool, rows, tiles_b, 0));
+        CK(vrs::launch_pool_pass_b(st, partner, ovf, slack, n, msd, pool, tiles_b, 0, vrs::pool_local_capacity(big), slack_cap, xcc_map, 1000u + r));
         CK(hipEventRecord(ev[4], st));
-        CK(vrs::launch_pool_runs(st, msd, pool, rows, runs, n));
         CK(hipEventRecord(ev[5], st));
-        CK(vrs::launch_pool_local_sort(st, partner, ovf, in, n, msd, pool, runs, big, head, nullptr, 1));
+        CK(vrs::launch_pool_local_sort(st, slack, in, n, msd, pool, big, head, nullptr, 1));
         CK(hipEventRecord(ev[6], st));
         hipLaunchKernelGGL(check_sorted, dim3(2048), dim3(256), 0, st, in, n, chk);
         CK(hipStreamSynchronize(st));
@@ -102,16 +109,31 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(&hm, msd, 16, hipMemcpyDeviceToHost));
         CK(hipMemcpy(&hp, pool, 32, hipMemcpyDeviceToHost));
         CK(hipMemcpy(hc, chk, 32, hipMemcpyDeviceToHost));
+        if (!hm.ok || getenv("POOL_LAB_DUMP")) {  // why: the fullest bucket against its room and the local sort's capacity
+            std::vector<uint32_t> start(vrs::kMsdBucketCount + 4), cur(vrs::kMsdBucketCount);
+            CK(hipMemcpy(start.data(), reinterpret_cast<char *>(pool) + offsetof(vrs::PoolPlan, sub_start), start.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(cur.data(), reinterpret_cast<char *>(pool) + offsetof(vrs::PoolPlan, sub_cursor), cur.size() * 4, hipMemcpyDeviceToHost));
+            uint32_t worst = 0, over = 0, mx = 0;
+            double tight = 0;
+            for (uint32_t b = 0; b < vrs::kMsdBucketCount; ++b) {
+                const uint32_t room = start[b + 1] - start[b];
+                mx = std::max(mx, cur[b]);
+                if (cur[b] > room) { ++over; worst = b; }
+                if (room) tight = std::max(tight, double(cur[b]) / room);
+            }
+            std::printf("   dump: slack used %u of %u, largest bucket %u (cap %u), buckets over their room %u (e.g. %u: %u > %u), tightest fill %.3f\n", start[vrs::kMsdBucketCount],
+                        slack_cap, mx, vrs::pool_local_capacity(big), over, worst, cur[worst], start[worst + 1] - start[worst], tight);
+        }
         float t[6];
         for (int i = 0; i < 6; ++i) CK(hipEventElapsedTime(&t[i], ev[i], ev[i + 1]));
-        std::printf("rep %d: sample %.1f  passA %.1f  plan %.1f  passB %.1f  runs %.1f  local %.1f us   ok_a=%u ok=%u shift=%u  descents=%llu sum %s\n", r, t[0] * 1e3,
-                    t[1] * 1e3, t[2] * 1e3, t[3] * 1e3, t[4] * 1e3, t[5] * 1e3, hp.ok_a, hm.ok, hm.shift, hc[0], hc[1] == hc[3] ? "same" : "DIFFERENT");
+        std::printf("rep %d: sample %.1f  passA %.1f  plan %.1f  passB %.1f  (-) %.1f  local %.1f us   ok_a=%u fail=%u ok=%u shift=%u  descents=%llu sum %s\n", r, t[0] * 1e3,
+                    t[1] * 1e3, t[2] * 1e3, t[3] * 1e3, t[4] * 1e3, t[5] * 1e3, hp.ok_a, hp.fail, hm.ok, hm.shift, hc[0], hc[1] == hc[3] ? "same" : "DIFFERENT");
         if (r >= 2) {
             for (int i = 0; i < 6; ++i) sum[i] += t[i] * 1e3;
             ++counted;
         }
     }
-    std::printf("AVG n=%u: sample %.1f  passA %.1f  plan %.1f  passB %.1f  runs %.1f  local %.1f us (events bracket each launch: +~2 us each); total %.1f\n", n,
+    std::printf("AVG n=%u: sample %.1f  passA %.1f  plan %.1f  passB %.1f  (-) %.1f  local %.1f us (events bracket each launch: +~2 us each); total %.1f\n", n,
                 sum[0] / counted, sum[1] / counted, sum[2] / counted, sum[3] / counted, sum[4] / counted, sum[5] / counted,
                 (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5]) / counted);
     return 0;

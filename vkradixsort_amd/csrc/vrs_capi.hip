@@ -104,9 +104,8 @@ struct vrs_context_t {
     vrs::PoolPlan *os_pool_plan = nullptr;
     uint32_t *os_pool_overflow = nullptr;  // overflow regions of the first pass
     uint32_t os_pool_overflow_cap = 0;     //   keys they hold
-    uint32_t *os_pool_rows = nullptr;      // the second pass's (offset, count) rows
-    size_t os_pool_rows_bytes = 0;
-    vrs::PoolRun *os_pool_runs = nullptr;  // run descriptors [top byte][run slot][bucket of the top byte]
+    uint32_t *os_pool_slack = nullptr;     // the buckets' regions the second pass scatters into (about 1.5 n slots)
+    uint32_t os_pool_slack_cap = 0;        //   slots
     uint64_t os_pool_sorts = 0, os_pool_refusals = 0;
     uint32_t os_pool_min_keys = 32000000u;  // VRS_TUNE_MSD_POOL_MIN_KEYS
     bool os_cursors_open = false;        // a reserving pass may have run without the local sort that re-arms its counters behind it
@@ -463,8 +462,7 @@ int vrs_context_destroy(vrs_context ctx) {
     if (ctx->os_host_head) (void)hipHostFree(ctx->os_host_head);
     if (ctx->os_pool_plan) (void)hipFree(ctx->os_pool_plan);
     if (ctx->os_pool_overflow) (void)hipFree(ctx->os_pool_overflow);
-    if (ctx->os_pool_rows) (void)hipFree(ctx->os_pool_rows);
-    if (ctx->os_pool_runs) (void)hipFree(ctx->os_pool_runs);
+    if (ctx->os_pool_slack) (void)hipFree(ctx->os_pool_slack);
     if (ctx->os_msd_counts) (void)hipFree(ctx->os_msd_counts);
     if (ctx->os_msd_plan) (void)hipFree(ctx->os_msd_plan);
     if (ctx->os_plan_a) (void)hipFree(ctx->os_plan_a);
@@ -981,6 +979,7 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
 // ---- pool form (vrs_msd_pool.hip): the hybrid form of bare uint32 keys without the counting read: 24 bytes per key.
 static int one_read_enqueue_pool(vrs_context ctx, const struct OneReadGeometry &g);
 
+
 static int one_read_enqueue(vrs_context ctx) {
     vrs_context_t::OneRead &st = ctx->one_read;
     const uint32_t n = st.n;
@@ -1022,10 +1021,10 @@ static int one_read_enqueue(vrs_context ctx) {
         // Pool form: bare uint32 keys the hybrid form may take skip the counting read altogether.  A refusal (a sample that
         // misjudged a region, a key range the probe missed, a bucket above the local sort's capacity) costs the first pass, so
         // the default is adaptive: after one, the next 15 such sorts of the context take the counted form.
-        // (sizes: the local sort gathers a bucket from at most 56 runs -- one per second-pass tile of its top byte, about
-        // n / 256 / 8192 + 8 -- and below 3.2e7 keys the counted form's one-wave-per-bucket local sort is the faster one)
+        // (sizes: a bucket must fit the local sort's larger shape -- uniform keys up to about 2.2e8 --, in every mode: beyond it a
+        // refusal is certain; and below 3.2e7 keys the counted form's one-wave-per-bucket local sort is the faster one)
         const bool candidate = st.msd_capable && !pairs && !wide && !st.no_pool && ctx->os_pool != 0 && reserves(ctx, n, false) &&
-                               n >= ctx->os_pool_min_keys && (ctx->os_pool == 2 || n <= 115000000u);
+                               n >= ctx->os_pool_min_keys && n <= vrs::kPoolMaxKeys;
         st.pool = candidate && (ctx->os_pool == 2 || ctx->os_pool_skip == 0);
         if (candidate && !st.pool) --ctx->os_pool_skip;
     }
@@ -1111,36 +1110,31 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     vrs_context_t::OneRead &st = ctx->one_read;
     const uint32_t n = st.n;
     int rc;
-    const uint32_t room = vrs::pool_overflow_capacity(n);
-    const size_t rows_bytes = vrs::pool_rows_bytes(n);
+    const uint32_t room = vrs::pool_overflow_capacity(n), slack = vrs::pool_slack_capacity(n);
     if (!ctx->os_pool_plan) {
         vrs::PoolPlan *pp = nullptr;
-        vrs::PoolRun *runs = nullptr;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&pp), sizeof(vrs::PoolPlan));
-        if (e == hipSuccess) e = hipMemsetAsync(pp, 0, sizeof(vrs::PoolPlan), ctx->stream);  // sample counts, tickets, flags: zero between sorts
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&runs), vrs::kPoolRunBytes);
+        if (e == hipSuccess) e = hipMemsetAsync(pp, 0, sizeof(vrs::PoolPlan), ctx->stream);  // sample counts, flags: zero between sorts
         if (e != hipSuccess) {
-            if (runs) (void)hipFree(runs);
             if (pp) (void)hipFree(pp);
             return fail_hip(ctx, "pool form scratch allocation", e);
         }
         ctx->os_pool_plan = pp;
-        ctx->os_pool_runs = runs;
     }
-    if (room > ctx->os_pool_overflow_cap || rows_bytes > ctx->os_pool_rows_bytes) {
-        if (ctx->os_pool_overflow || ctx->os_pool_rows) {
+    if (room > ctx->os_pool_overflow_cap || slack > ctx->os_pool_slack_cap) {
+        if (ctx->os_pool_overflow || ctx->os_pool_slack) {
             VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->os_pool_overflow) VRS_HIP(ctx, hipFree(ctx->os_pool_overflow));
-            if (ctx->os_pool_rows) VRS_HIP(ctx, hipFree(ctx->os_pool_rows));
+            if (ctx->os_pool_slack) VRS_HIP(ctx, hipFree(ctx->os_pool_slack));
             ctx->os_pool_overflow = nullptr;
-            ctx->os_pool_rows = nullptr;
+            ctx->os_pool_slack = nullptr;
             ctx->os_pool_overflow_cap = 0;
-            ctx->os_pool_rows_bytes = 0;
+            ctx->os_pool_slack_cap = 0;
         }
         VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_overflow), static_cast<size_t>(room) * sizeof(uint32_t)));
         ctx->os_pool_overflow_cap = room;
-        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_rows), rows_bytes));
-        ctx->os_pool_rows_bytes = rows_bytes;
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_slack), static_cast<size_t>(slack) * sizeof(uint32_t)));
+        ctx->os_pool_slack_cap = slack;
     }
     if ((rc = reservation_begin(ctx))) return rc;  // the first pass's cursors: zero
     const vrs::PoolStreams ps = vrs::pool_streams(n);
@@ -1154,7 +1148,7 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     // Everything is enqueued here, before any verdict is known (the workgroups of what a verdict refuses leave at once): the
     // second verdict falls only when the second pass has run, and a host that enqueued the local sort after it would leave the
     // GPU idle for a round trip.  The local sort's shape is chosen from n alone (uniform keys: buckets of n / 16384 + a few per
-    // cent); a bucket above its capacity makes the second verdict refuse.
+    // cent); a bucket above its capacity makes the second pass flag the sort.
     const double mean_bucket = static_cast<double>(n) / vrs::kMsdBucketCount;  // (the fullest of 16384 uniform buckets: 4-4.5 deviations above)
     const bool big = static_cast<uint64_t>(mean_bucket + 5.5 * std::sqrt(mean_bucket)) + 32u > vrs::pool_local_capacity(false);
     const uint32_t tiles_b = vrs::pool_tiles_b_cap(n);
@@ -1165,14 +1159,13 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_pass_a(ctx->stream, home, partner, ctx->os_pool_overflow, n, st.key_base, ps, ctx->os_pool_plan, ctx->os_msd_plan,
                                          ctx->xcc_map, ctx->os_misplace, room, ev));
-    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b));
+    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, partner, ctx->os_pool_overflow, st.key_base, ps));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
-    VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, partner, ctx->os_pool_overflow, n, ctx->os_msd_plan, ctx->os_pool_plan, ctx->os_pool_rows, tiles_b,
-                                         st.key_base, ev));
-    VRS_HIP(ctx, vrs::launch_pool_runs(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, ctx->os_pool_rows, ctx->os_pool_runs, n));
+    VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, partner, ctx->os_pool_overflow, ctx->os_pool_slack, n, ctx->os_msd_plan, ctx->os_pool_plan, tiles_b,
+                                         st.key_base, vrs::pool_local_capacity(big), ctx->os_pool_slack_cap, ctx->xcc_map, st.stamp, ev));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
-    VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, partner, ctx->os_pool_overflow, home, n, ctx->os_msd_plan, ctx->os_pool_plan, ctx->os_pool_runs,
-                                             big, &ctx->os_plan->head, ctx->os_host_head_dev, st.stamp, ev));
+    VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, home, n, ctx->os_msd_plan, ctx->os_pool_plan, big, &ctx->os_plan->head,
+                                             ctx->os_host_head_dev, st.stamp, ev));
     ctx->os_cursors_open = false;  // the local sort re-arms the reservation counters (a refusal is handled by one_read_complete)
     st.active = true;
     return VRS_OK;

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void scatter_kernel(const K *__res
         const K *kin = keys_in + tile_begin + c0;
         const uint32_t *vin = PAIRS ? values_in + tile_begin + c0 : nullptr;
         if (valid == kChunk)  // workgroup-uniform
-            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, kin, vin, keys_out, values_out, valid, dg, run_off, NoLookback{}, nullptr, 0u, stream_in);
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, kin, vin, keys_out, values_out, valid, dg, run_off, NoLookback{}, NoPieces{}, stream_in);
         else
             scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, kin, vin, keys_out, values_out, valid, dg, run_off);
     }

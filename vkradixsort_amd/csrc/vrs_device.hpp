@@ -258,6 +258,21 @@ struct NoLookback {
     static constexpr bool kEnabled = false;
     static constexpr bool kPool = false;
 };
+// where a chunk's keys come from when they do not lie in one piece (scatter_chunk's SRC): lane p of every wave holds piece p --
+// chunk positions [lo, lo + len) (lo relative to the chunk, as a wrapped unsigned) are the virtual slots slot, slot + 1, ...;
+// virtual slots below n_virt lie in `regions`, the others in `overflow`.  Pieces [p0, p1) touch the chunk.
+struct NoPieces {
+    static constexpr bool kEnabled = false;
+};
+struct PieceSrc {
+    static constexpr bool kEnabled = true;
+    uint32_t lo, len, slot;       // per lane
+    uint32_t p0, p1, first_slot;  // wave-uniform
+    const uint32_t *regions, *overflow;
+    uint32_t n_virt;
+    using gptr = const uint32_t __attribute__((address_space(1))) *;  // (say that these are GLOBAL pointers, or the loads become flat loads)
+    __device__ __forceinline__ gptr at(uint32_t v) const { return v < n_virt ? (gptr)regions + v : (gptr)overflow + (v - n_virt); }
+};
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3u << 11) | 20u); }  // HW_REG_XCC_ID[3:0]
 
 struct StreamLookback {
@@ -382,13 +397,13 @@ __device__ __forceinline__ void recount_keys(uint32_t *cnt, const K *keys, uint3
 // a workgroup is latency-bound (one pass over its keys, few waves), so dependent
 // read -> wait -> write chains per item are what must not appear in the ISA.
 // LB: StreamLookback obtains the digit offsets by decoupled look-back instead of from `run_off`.
-// SPLIT_SRC: the chunk's keys lie in TWO places -- chunk positions below `split` at kin, the others at kin1 (both indexed by
-// the chunk position): the second MSD pass of the pool form reads a share that runs from a primary region into its overflow.
-template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, bool FULL, typename DG, typename LB = NoLookback, bool SPLIT_SRC = false>
+// SRC (PieceSrc): the chunk's keys lie in several PIECES of two buffers -- the second MSD pass of the pool form reads a top byte's
+// keys from the eight slices' primary and overflow regions, and a tile may straddle their ends.
+template <typename K, int ITEMS, int WAVES, bool PAIRS, int RANK, bool FULL, typename DG, typename LB = NoLookback, typename SRC = NoPieces>
 __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> &sm, const K *kin,
                                               const uint32_t *vin, K *kout, uint32_t *vout,
                                               uint32_t valid, const DG &dg, uint32_t &run_off, const LB lb = {},
-                                              const K *kin1 = nullptr, uint32_t split = 0, bool stream_in = false) {
+                                              const SRC src = {}, bool stream_in = false) {
     constexpr uint32_t THREADS = WAVES * 64;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -402,22 +417,37 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     // leave the memory-side cache to what the pass WRITES (the next kernel reads that): 10^8 keys, contract scatter 138 -> 128 us, the
     // MSD passes 146 -> 140, the pool form's first pass 154 -> 143; below about 3e7 keys everything fits the caches and it costs a
     // little instead (10^7 keys: 0.108 -> 0.111 ms), so the callers switch it by size
-    if (FULL && !SPLIT_SRC && (LB::kPool || stream_in)) {
+    if (FULL && !SRC::kEnabled && (LB::kPool || stream_in)) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) key[i] = __builtin_nontemporal_load(kin + seg + i * 64);
         if constexpr (PAIRS) {
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) val[i] = __builtin_nontemporal_load(vin + seg + i * 64);
         }
+    } else if constexpr (SRC::kEnabled) {
+        // every position's virtual slot first (a scalar loop over the pieces the chunk touches: usually two or three), then all loads at once
+        uint32_t vs[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) vs[i] = src.first_slot;  // (positions behind `valid`: some readable slot)
+#pragma unroll 1
+        for (uint32_t p = src.p0; p < src.p1; ++p) {
+            const uint32_t lo = __builtin_amdgcn_readlane(src.lo, p), len = __builtin_amdgcn_readlane(src.len, p), vd = __builtin_amdgcn_readlane(src.slot, p);
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const uint32_t idx = seg + i * 64;
+                vs[i] = idx - lo < len ? vd + (idx - lo) : vs[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const K k = *src.at(vs[i]);
+            key[i] = (FULL || seg + i * 64 < valid) ? k : dg.template pad<K>();
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const uint32_t idx = seg + i * 64;
-            if constexpr (SPLIT_SRC) {
-                const uint32_t j = FULL ? idx : (idx < valid ? idx : valid - 1u);
-                const K k = *(j < split ? kin + j : kin1 + j);
-                key[i] = (FULL || idx < valid) ? k : dg.template pad<K>();
-            } else if constexpr (FULL) {
+            if constexpr (FULL) {
                 key[i] = kin[idx];
             } else {
                 // unpredicated load from a clamped index, then select: the padding key (all ones, seen from the digit's base) has

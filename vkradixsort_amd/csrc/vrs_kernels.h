@@ -246,53 +246,59 @@ uint32_t msd_local_capacity_pairs_small();         // pairs and 64-bit keys, 512
 
 // ---- hybrid form WITHOUT a counting read ("pool" form, vrs_msd_pool.hip; bare uint32 keys): 24 instead of 28 bytes per key.
 // The counting read exists to tell the MSD passes where every bucket's keys go.  Here nothing is counted ahead:
-//   sample      1/32 of the input (the first 256 keys of every 8192-key tile) sizes, for every (input slice, top byte), a region
-//               of the partner buffer plus a few standard deviations of overflow room in context scratch;
+//   sample      1/32 of the input (the first 256 keys of every 8192-key tile) counted by bucket (the top 14 bits of the probed key
+//               range) and, per input slice, by top byte; the layout kernel sizes, for every (input slice, top byte), a region of the
+//               partner buffer plus a few standard deviations of overflow room in context scratch;
 //   first pass  every tile reserves its output in those regions (one L2-local atomic per tile and top byte);
-//   plan        one workgroup: exact top-byte totals from the first pass's cursors, the second pass's tile tables, verdict 1;
-//   second pass every tile of a (top byte, slice) share groups its OWN 8192 keys by the next 6 bits IN PLACE (coalesced 16-byte
-//               stores, no global atomic) and leaves a row of 64 (offset, count) pairs;
-//   runs        one workgroup per top byte: the rows -> per-bucket run descriptors, exact bucket starts, verdict 2 (every
-//               bucket fits the local sort) -- the caller's buffer is still untouched at this point;
-//   local sort  one workgroup per bucket gathers the bucket's runs (about 48 of about 128 keys), sorts them inside LDS
-//               (lean_sort_body, vrs_local_sort.hpp) and writes the bucket to its final place in the caller's buffer.
-// A region that overflows its room, a key outside the sampled range, a top byte with more tiles than a bucket may have runs or a
-// bucket above the local sort's capacity make a verdict say no (MsdPlan::ok == 0): the sort starts over in the counted form.
+//   plan        one workgroup: EXACT top-byte totals from the first pass's cursors, the second pass's tile tables, and for every one
+//               of the 16384 buckets a region of the SLACK buffer (context scratch of n + about 6 sqrt(16384 * 32 * n) slots):
+//               the bucket's share of its top byte's exact total as the sample saw it, plus six standard deviations of that; verdict 1;
+//   second pass every tile of a (top byte, slice) share scatters its keys by the next 6 bits into the buckets' slack regions,
+//               reserving its runs with one L2-local atomic per tile and bucket; a bucket that outgrows its region or the local
+//               sort's capacity, or a key outside the probed range, flags the sort;
+//   local sort  one workgroup per bucket reads the bucket -- ONE contiguous, 16-byte aligned piece of the slack buffer --, sorts it
+//               inside LDS (lean_sort_body, vrs_local_sort.hpp) and streams it to its final place in the caller's buffer, which it
+//               derives from the top byte's exact start and the second pass's counters of the buckets before it.
+// A region that overflows its room, a key outside the sampled range or a bucket above the local sort's capacity make a verdict say
+// no (MsdPlan::ok == 0) before the caller's buffer has been written: the sort starts over in the counted form.
 constexpr uint32_t kPoolTile = 8192;           // keys per tile of both passes
 constexpr uint32_t kPoolSampleKeys = 256;      // leading keys of every tile the sample kernel counts
 constexpr uint32_t kPoolSampleTiles = 32;      // tiles per workgroup of the sample kernel
-constexpr uint32_t kPoolMaxTiles = 56;         // second-pass tiles a top byte may have (its buckets' runs: 56 + 8 split pieces = one wave's scan)
-constexpr uint32_t kPoolRunSlots = kPoolMaxTiles + 8;
+constexpr uint32_t kPoolMaxKeys = 224000000u;  // the fullest of 16384 uniform buckets (mean + 5.5 deviations) must fit the local sort's 512-thread shape (14333 keys)
+constexpr uint32_t kPoolMaxTilesA = 3456;      // tiles per slice of the first pass at kPoolMaxKeys (3418)
+constexpr uint32_t kPoolMaxTilesB = 4352;      // rows of workgroups of the second pass at kPoolMaxKeys (pool_tiles_b_cap: 4313)
 struct PoolStreams {                           // the eight slices of the input the first pass walks (whole tiles), by value
     uint32_t start[8], len[8], sampled[8];     // first key, keys, keys the sample kernel counts
     uint32_t tiles_per_stream, tiles_total;
 };
-struct PoolRun {            // one run of a bucket: `len` keys from virtual slot `slot` on (slots < n: partner buffer, else overflow scratch)
-    uint32_t slot, len;
-};
 struct PoolPlan {
     uint32_t shift;             // bucket = (key - key_base) >> shift: the top 14 bits of the probed key range
     uint32_t armed;             // 1 = the sample kernel laid the regions out: the first pass runs
-    uint32_t fail;              // first pass: a region overflowed / a key outside the probed range / a CU behind no known L2 (zero between sorts)
-    uint32_t ticket;            // sample kernel: workgroups done (zero between launches)
+    uint32_t fail;              // a pass: a region overflowed / a key outside the probed range / a workgroup behind the wrong L2 (re-armed by the layout kernel)
+    uint32_t ticket;            // (unused)
     uint32_t ok_a;              // verdict 1 (plan kernel): the second pass runs
-    uint32_t runs_ticket;       // (unused)
-    uint32_t max_bucket;        // runs kernel: keys in the largest bucket (zero between sorts)
-    uint32_t pad;
+    uint32_t pad[3];
     uint32_t sample[8][256];    // sampled keys of (slice, top byte), zero between sorts
     uint32_t base[8][256];      // primary region of (slice, top byte): first slot in the partner buffer
     uint32_t cap[8][256];       //   its slots
     uint32_t obase[8][256];     // overflow region: first slot in the overflow scratch
     uint32_t ocap[8][256];
     uint32_t top_base[260];     // where top byte a starts in the sorted order (exact), [256] = n
-    uint32_t top_tiles[256];    // second-pass tiles of top byte a
     uint32_t tiles_b[8][260];   // second pass: XCD x walks entries e = 8 k + s (top byte x + 8 k, slice s): exclusive prefix of their tile counts, [256] = all
+    // Which tile a workgroup of a pass takes follows the XCC it RUNS on (list = that XCC's place in the probed order, tile = block
+    // index / 8): whatever the dispatcher's rotation, the eight blocks of a group then take eight different lists -- as long as they
+    // run on eight different XCCs.  That is observed, not promised: every workgroup leaves a claim, and a tile claimed twice refuses the sort.
+    uint32_t claim_a[8 * kPoolMaxTilesA];  // first pass: += 1 by the workgroup of (list, tile); checked and zeroed by the plan kernel
+    uint32_t claim_b[8 * kPoolMaxTilesB];  // second pass: exchanged with the sort's stamp by the workgroup of (list, tile); a stamp found there = a second claim
+    alignas(16) uint2 pieces[256][16];                     // top byte a's keys lie in 16 pieces (slice s's primary region: 2 s, its overflow region: 2 s + 1):
+                                                           //   .x = keys of the top byte up to and including the piece, .y = the piece's first virtual slot
+    alignas(16) uint32_t sub_start[kMsdBucketCount + 4];   // bucket b's region of the slack buffer: first slot (a multiple of 4), [16384] = slots in all
+    alignas(16) uint32_t sub_cursor[kMsdBucketCount];      // second pass: keys of bucket b placed so far (zeroed by the plan kernel)
 };
 PoolStreams pool_streams(uint32_t n);
 uint32_t pool_overflow_capacity(uint32_t n);   // keys of overflow scratch a sort of n keys may use
+uint32_t pool_slack_capacity(uint32_t n);      // slots of the slack buffer (regions of all buckets + one tile where refused runs are dumped)
 uint32_t pool_tiles_b_cap(uint32_t n);         // rows of workgroups of the second pass (its grid is sized before the plan is known)
-size_t pool_rows_bytes(uint32_t n);            // the second pass's (offset, count) rows: 8 * pool_tiles_b_cap(n) rows of 64 words
-constexpr size_t kPoolRunBytes = sizeof(PoolRun) * 256u * 64u * kPoolRunSlots;  // run descriptors [bucket][run slot]
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
                               PoolPlan *pool, uint32_t overflow_capacity, LaunchEvents ev = {});
 // keys_out: the partner buffer (n slots); overflow: pool_overflow_capacity(n) slots; cursors: MsdPlan::cursor_a (zero when the pass
@@ -300,20 +306,20 @@ hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t
 hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, uint32_t *overflow, uint32_t n,
                               uint32_t key_base, const PoolStreams &ps, PoolPlan *pool, MsdPlan *msd, unsigned long long xcc_map,
                               bool misplace, uint32_t overflow_capacity, LaunchEvents ev = {});
-// ONE workgroup, after the first pass: verdict 1, top-byte starts, tile tables; re-arms PoolPlan::fail / max_bucket
-hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap);
-// second pass, in place in the regions: grid of 8 * tiles_b workgroups (tiles_b = pool_tiles_b_cap(n))
-hipError_t launch_pool_pass_b(hipStream_t stream, uint32_t *regions, uint32_t *overflow, uint32_t n, MsdPlan *msd, PoolPlan *pool,
-                              uint32_t *rows, uint32_t tiles_b, uint32_t key_base, LaunchEvents ev = {});
-// 256 workgroups: run descriptors, MsdPlan::base, the largest bucket
-hipError_t launch_pool_runs(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, const uint32_t *rows, PoolRun *runs, uint32_t n);
-// gathers every bucket from its runs, sorts it, writes it to keys_out[MsdPlan::base[b] ...); big: the 512-thread shape (buckets
-// up to 14333 keys) instead of the 256-thread one (7165).  Gives verdict 2 (verdict 1, no flag from the passes, the largest bucket
-// fits the shape) = MsdPlan::ok and the host head (msd_ok, msd_max_bucket, lsd_missing = 1, stamped last); re-arms the reservation
-// counters like the counted local sort
-hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *keys_out, uint32_t n,
-                                  MsdPlan *msd, const PoolPlan *pool, const PoolRun *runs, bool big, OnesweepPlanHead *dev_head,
-                                  OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev = {});
+// after the first pass, one workgroup per top byte: top-byte starts, tile tables, piece rows, the buckets' slack regions (from a
+// sample of the first pass's OUTPUT: regions / overflow), verdict 1 (slack_capacity: slots the slack buffer has)
+hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap, uint32_t slack_capacity,
+                            const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps);
+// second pass, regions -> slack buffer: grid of 8 * tiles_b workgroups (tiles_b = pool_tiles_b_cap(n)); local_cap: keys the local
+// sort that follows takes per bucket; slack_capacity: as given to the plan (the last kPoolTile slots take refused runs)
+hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *slack, uint32_t n, MsdPlan *msd,
+                              PoolPlan *pool, uint32_t tiles_b, uint32_t key_base, uint32_t local_cap, uint32_t slack_capacity,
+                              unsigned long long xcc_map, uint32_t stamp, LaunchEvents ev = {});
+// sorts every bucket from its slack region to keys_out[its exact start ...); big: the 512-thread shape (buckets up to 14333 keys)
+// instead of the 256-thread one (7165).  Gives verdict 2 (verdict 1, no flag from the passes) = MsdPlan::ok and the host head
+// (msd_ok, lsd_missing = 1, stamped last); re-arms the first pass's reservation counters
+hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
+                                  bool big, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev = {});
 uint32_t pool_local_capacity(bool big);
 
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups

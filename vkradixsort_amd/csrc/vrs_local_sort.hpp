@@ -9,8 +9,10 @@ namespace vrs {
 
 constexpr int kLeanRow = 512 + 64;  // words per counter table: 512 digits + one dummy per lane for slots without a key
 constexpr int kLeanMaxVec = 7;      // 16-byte vectors per thread: capacity THREADS * 28 slots
-// k[4 j + c] = slot q = 4 (j THREADS + tid) + c of the bucket seen from its first 16-byte boundary `abase`; slots [mis, mis + n)
-// hold keys (mis < 4).  Sorts them and stores the sorted bucket to abase[mis .. mis + n) (16-byte vector stores inside).
+// k[4 j + c] = slot q = 4 (j THREADS + tid) + c of the bucket as it was READ (from the first 16-byte boundary at or before its
+// first key); slots [mis_in, mis_in + n) hold keys (mis_in < 4).  Sorts them and stores the sorted bucket to abase[mis .. mis + n)
+// (16-byte vector stores inside; mis < 4: the misalignment of the place it is WRITTEN to -- the same as mis_in for a bucket sorted in
+// place, any other for one that is read from elsewhere: pass 1 leaves the keys in position order, whatever slots they came from).
 // the sorted bucket's 16-byte stores.  STREAM: the bucket goes to a buffer nobody reads again soon (the pool form writes the caller's
 // buffer, its input came from elsewhere) -- a nontemporal store, which does not take room in the memory-side cache away from the
 // second pass's output the other buckets are still to read (pool form, 10^8 keys: 0.546 -> 0.529 ms).  Not for the in-place sorts of
@@ -26,9 +28,11 @@ __device__ __forceinline__ void store_sorted(uint4 *p, const uint4 &q) {
     }
 }
 
-template <int THREADS, int VEC, bool GUARD, bool STREAM = false>
+// ALIGNED_IN: mis_in == 0 (a bucket read from its own 16-byte aligned region, written elsewhere): the slots without a key are then
+// the LAST ones -- which reach up to three slots into the row before the last when the output's misalignment adds a row.
+template <int THREADS, int VEC, bool GUARD, bool STREAM = false, bool ALIGNED_IN = false>
 __device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
-                                               uint32_t *s_hist2, uint32_t *s_tmp, bool guard1, bool guard2) {
+                                               uint32_t *s_hist2, uint32_t *s_tmp, bool guard1, bool guard2, uint32_t mis_in) {
     constexpr int WAVES = THREADS / 64, ITEMS = 4 * VEC, PER = 512 / THREADS;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t end = mis + n;
@@ -41,9 +45,9 @@ __device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             uint32_t a = (k[4 * j + c] << 2) & 0x7FCu;
-            if (j == 0 || j == VEC - 1) {
+            if (ALIGNED_IN ? j >= VEC - 2 : (j == 0 || j == VEC - 1)) {
                 const uint32_t q = 4u * (j * THREADS + tid) + c;
-                a = (q - mis < n) ? a : 2048u + 4u * lane;
+                a = (q - mis_in < n) ? a : 2048u + 4u * lane;
             }
             uint32_t *counter = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_hist) + a);
             if (GUARD && guard1) {  // workgroup-uniform
@@ -89,14 +93,14 @@ __device__ __forceinline__ void lean_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             uint32_t a = (opaque(k[4 * j + c]) << 2) & 0x7FCu;
-            if (j == 0 || j == VEC - 1) {
-                // a slot behind the bucket keeps its place (position q: mis + n slots lie before the first of them, mis of those
-                // without a key), the ones before the bucket follow the keys (position n + q)
+            if (ALIGNED_IN ? j >= VEC - 2 : (j == 0 || j == VEC - 1)) {
+                // a slot behind the bucket keeps its place (position q: mis_in + n slots lie before the first of them, mis_in of
+                // those without a key), the ones before the bucket follow the keys (position n + q)
                 const uint32_t q = 4u * (j * THREADS + tid) + c;
-                const bool valid = q - mis < n;
+                const bool valid = q - mis_in < n;
                 a = valid ? a : 2048u + 4u * lane;
                 const uint32_t r = rank[4 * j + c] + *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_hist) + a);
-                rank[4 * j + c] = valid ? r : 4u * (q < mis ? n + q : q);
+                rank[4 * j + c] = valid ? r : 4u * (q < mis_in ? n + q : q);
                 continue;
             }
             rank[4 * j + c] += *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_hist) + a);

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
         lb.seed = msd->base[b];
         if (foreign) lb.region_len = msd->base[b + 1u] - lb.seed;
         if (valid == kTile)
-            scatter_chunk<K, ITEMS, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb, nullptr, 0u, stream_in);
+            scatter_chunk<K, ITEMS, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb, NoPieces{}, stream_in);
         else
             scatter_chunk<K, ITEMS, 8, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     } else {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
         lb.budget = spin_budget;
         lb.seed = threadIdx.x < (1u << sub_bits) ? msd->base[(a << sub_bits) + threadIdx.x] : 0u;
         if (valid == kTile)
-            scatter_chunk<K, ITEMS, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb, nullptr, 0u, stream_in);
+            scatter_chunk<K, ITEMS, 8, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb, NoPieces{}, stream_in);
         else
             scatter_chunk<K, ITEMS, 8, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     }
@@ -599,7 +599,7 @@ __device__ __forceinline__ void lean_sort_bucket(uint32_t *abase, uint32_t mis, 
     // Two copies of the rest.  The common one is inlined and carries no trace of the guard; the guarded one is a CALL that loads
     // the bucket again -- kept out of line so that its register demand cannot push the common path into scratch spills (spills
     // are HBM traffic: with both inlined the kernel moved 1032 instead of 800 MB per launch at 10^8 keys).
-    if (guards == 0u) lean_sort_body<THREADS, VEC, false>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false);
+    if (guards == 0u) lean_sort_body<THREADS, VEC, false>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false, mis);
     else lean_sort_guarded<THREADS, VEC>(abase, mis, n, s_keys, s_hist2, s_tmp, guards);
 }
 
@@ -619,7 +619,7 @@ __device__ __attribute__((noinline)) void lean_sort_guarded(uint32_t *abase, uin
         k[4 * j + 2] = t.z;
         k[4 * j + 3] = t.w;
     }
-    lean_sort_body<THREADS, VEC, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, (guards & 1u) != 0u, (guards & 2u) != 0u);
+    lean_sort_body<THREADS, VEC, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, (guards & 1u) != 0u, (guards & 2u) != 0u, mis);
 }
 
 // THREADS = 256: up to 7165 keys per bucket (uniform keys: N <= 1.05e8), 38 KB of LDS, four workgroups per CU;

@@ -4,29 +4,33 @@
 // form (vrs_msd_hybrid.hip, K5b) still reads them once for that.  Here they are not read for counting at all, and no pass waits
 // for a histogram either:
 //
-//   pool_sample_kernel      1/32 of the input (the first 256 keys of every 8192-key tile): probes the key range (bucket shift)
-//                           and counts the top byte per input slice; pool_layout_kernel (one workgroup behind it) lays out, for every
-//                           (slice, top byte), a PRIMARY region of the partner buffer sized by the estimate (the estimates of a slice sum to its
-//                           length, so the regions tile the n-key buffer) and an OVERFLOW region in context scratch of six
-//                           standard deviations of that estimate;
+//   pool_sample_kernel      1/32 of the input (the first 256 keys of every 8192-key tile): probes the key range (bucket shift),
+//                           counts the sampled keys by bucket (top 14 bits of the range) and, per input slice, by top byte;
+//                           pool_layout_kernel (one workgroup behind it) lays out, for every (slice, top byte), a PRIMARY region of the
+//                           partner buffer sized by the estimate (the estimates of a slice sum to its length, so the regions tile the
+//                           n-key buffer) and an OVERFLOW region in context scratch of six standard deviations of that estimate;
 //   pool_pass_a_kernel      first MSD pass (top 8 bits of the key range): a tile reserves its place in (slice, top byte)'s region
 //                           with ONE atomic add on the region's cursor, in the L2 of the XCD that runs the slice (StreamReserve's
 //                           idea, vrs_device.hpp) -- positions below the region's capacity are primary slots, the rest overflow;
 //   pool_plan_kernel        ONE workgroup: top-byte totals are the cursors' sums, exact -- where every top byte starts in the
-//                           sorted order, the second pass's tile tables, verdict 1;
-//   pool_pass_b_kernel      second MSD pass (the next 6 bits) WITHOUT any global offset: a tile groups its own 8192 keys by the 6
-//                           bits in LDS and writes them back to the slots it read them from, 16 bytes per lane, and leaves a
-//                           row of 64 (offset, count) pairs.  A bucket is then a set of RUNS, one per tile of its top byte;
-//   pool_runs_kernel        one workgroup per top byte: rows -> run descriptors per bucket, exact bucket starts (MsdPlan::base),
-//                           the largest bucket.  Up to here the caller's buffer has not been written;
-//   pool_local_sort_kernel  one workgroup per bucket -- every one derives verdict 2 from the same three words, workgroup 0 tells
-//                           the host: gathers the bucket's runs (about 48 of about 128 keys), sorts the keys by
-//                           their low 18 bits inside LDS (lean_sort_body, vrs_local_sort.hpp) and stores the bucket at its final
-//                           place in the caller's buffer.
+//                           sorted order, the second pass's tile tables; and a region of the SLACK buffer (context scratch, about
+//                           1.5 n slots) for each of the 16384 buckets: its share of the top byte's exact total as the sample saw
+//                           it plus six standard deviations, a multiple of 4 slots; verdict 1;
+//   pool_pass_b_kernel      second MSD pass (the next 6 bits), regions -> slack buffer: scatter_chunk with one L2-local reservation
+//                           per tile and bucket (SlackReserve) -- all tiles of a top byte run behind one L2.  It looks at every key:
+//                           one outside the probed range, a bucket that outgrows its region or the local sort's capacity flag the sort;
+//   pool_local_sort_kernel  one workgroup per bucket -- every one derives verdict 2 from the same two words, workgroup 0 tells
+//                           the host: reads the bucket (ONE contiguous, 16-byte aligned piece of the slack buffer) in 16-byte
+//                           vectors, sorts the keys by their low 18 bits inside LDS (lean_sort_body, vrs_local_sort.hpp) and
+//                           streams the bucket to its final place in the caller's buffer: its top byte's exact start + the second
+//                           pass's counts of the buckets before it (64 words, one load per lane).
+//
+// (Round 4 grouped every second-pass tile IN PLACE and gathered every bucket from about 48 runs: no third buffer, but a gather that
+// cost the local sort 45 us at 10^8 keys, a run-descriptor kernel, and at most 56 tiles per top byte.  CHANGELOG, round 5.)
 //
 // Nothing here is assumed about the data: a sample that misjudges a region (keys whose distribution changes inside a tile
-// with the tile's period, say) makes the first pass flag the sort, a verdict refuse, and the caller run the counted form on the
-// untouched input.  Neither MSD pass is stable (arrival order inside a region, any order inside a run); bare keys do not care.
+// with the tile's period, say) makes a pass flag the sort, a verdict refuse, and the caller run the counted form on the
+// untouched input.  Neither MSD pass is stable (arrival order inside a region); bare keys do not care.
 #include "vrs_local_sort.hpp"
 
 #include <algorithm>
@@ -38,7 +42,6 @@ namespace {
 
 constexpr uint32_t kPoolBuckets = kMsdBucketCount;        // 16384
 constexpr uint32_t kPoolMinShift = 13, kPoolMaxShift = 18;  // a 27 ... 32-bit key range (the counted form's rule)
-constexpr uint32_t kPoolFlushAt = 65535u - kPoolTile;     // a 16-bit counter may take one more tile below this
 constexpr float kPoolSigmas = 6.0f;                       // overflow room, in standard deviations of the region's estimate
 constexpr uint32_t kPoolRoomFloor = 320;
 
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__rest
         }
     }
     // The buckets are the top 14 bits of the key RANGE: every workgroup ORs the same strided 4096 keys (as the counted form's
-    // counting read does) and derives the same shift; a key outside that range is flagged by the first pass.
+    // counting read does) and derives the same shift; a key outside that range is flagged by the second pass.
     {
         // (512 keys, not the counting read's 4096: hundreds of workgroups asking the L2s for the same lines at the same time
         // is what this costs -- 4096 lines took 11 of the kernel's 30 us)
@@ -259,10 +262,20 @@ struct PoolReserve {
     }
 };
 
-// grid = 8 * tiles_per_stream workgroups; workgroup b takes tile b >> 3 of slice b & 7 -- the slice whose keys the sample counted
-// for the regions of row b & 7, and (observed placement: block b on XCD b % 8) the row whose cursors live in this CU's L2.
-// Neither is assumed: the row a workgroup ADDS TO is chosen by the XCC it finds itself on, so that a row's L2-local atomics
-// always meet in one L2, whichever slice the workgroup reads.
+// the place of the XCC this workgroup runs on in the probed order (8: an XCC the probe never saw)
+__device__ __forceinline__ uint32_t xcc_place(unsigned long long xcc_map) {
+    const uint32_t my_xcc = xcc_id();
+    uint32_t x = 8u;
+#pragma unroll
+    for (uint32_t q = 0; q < 8u; ++q)
+        if (x == 8u && xcc_of(xcc_map, q) == my_xcc) x = q;
+    return x;
+}
+
+// grid = 8 * tiles_per_stream workgroups; a workgroup on the XCC of place x takes tile b >> 3 of slice x -- the slice whose keys the
+// sample counted for the regions of row x, the row whose cursors live in this CU's L2.  (Observed placement: block b on the XCC of
+// place (b + r) % 8 with r fixed for a queue -- and a stream may move to another queue: r at the probe is not r now.  Nothing but
+// "the blocks of a group of eight run on eight XCCs" is used, and that is checked: PoolPlan::claim_a.)
 __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out,
                                                              uint32_t *__restrict__ overflow, uint32_t n, uint32_t key_base,
                                                              PoolStreams ps, PoolPlan *__restrict__ pool, MsdPlan *__restrict__ msd,
@@ -271,22 +284,17 @@ __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__r
     __shared__ uint32_t s_gbase2[kBins], s_split[kBins], s_flags;
     if (pool->armed == 0u) return;  // uniform: the sample kernel did not lay regions out (key range below 27 bits)
     const uint32_t i = blockIdx.x >> 3;
-    // misplace (test hook): odd tiles are read from the neighbouring slice
-    const uint32_t s_in = (blockIdx.x + (misplace ? (i & 1u) : 0u)) & 7u;
-    const uint32_t len = ps.len[s_in];
-    const uint32_t done = i * kPoolTile;
-    if (done >= len) return;
-    const uint32_t my_xcc = xcc_id();
-    uint32_t s_out = blockIdx.x & 7u;
-    if (xcc_of(xcc_map, s_out) != my_xcc) {  // not where block b % 8 was observed to run: the row of the L2 this CU does sit behind
-        s_out = 8u;
-        for (uint32_t x = 0; x < 8u; ++x)
-            if (s_out == 8u && xcc_of(xcc_map, x) == my_xcc) s_out = x;
-    }
+    const uint32_t s_out = xcc_place(xcc_map);
     if (s_out == 8u) {  // behind an L2 the probe never saw: no row is safe to add to -- the sort is refused
         if (threadIdx.x == 0) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&pool->claim_a[s_out * kPoolMaxTilesA + i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // misplace (test hook): odd tiles are read from the neighbouring slice
+    const uint32_t s_in = (s_out + (misplace ? (i & 1u) : 0u)) & 7u;
+    const uint32_t len = ps.len[s_in];
+    const uint32_t done = i * kPoolTile;
+    if (done >= len) return;
     if (threadIdx.x == 0) s_flags = 0;  // (set behind the chunk's barriers, read behind its last one)
     const uint32_t valid = min(kPoolTile, len - done);
     const uint32_t *kin = keys_in + ps.start[s_in] + done;
@@ -313,392 +321,323 @@ __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__r
 }
 
 // ---------------------------------------------------------------------------------------------
-// The plan, once the first pass has run: ONE workgroup of 256 threads, thread a = top byte a.
-__global__ __launch_bounds__(256) void pool_plan_kernel(MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool, uint32_t n, uint32_t tiles_b_cap) {
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_tiles[8][kBins];       // [XCD x][entry e = 8 k + s]: tiles of slice s's share of top byte x + 8 k
-    __shared__ uint32_t s_tiles_b, s_bad;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t shift = pool->shift, armed = pool->armed, failed = pool->fail;
-    if (tid == 0) {
-        s_tiles_b = 0;
-        s_bad = 0;
-    }
-    __syncthreads();
-    uint32_t keys_a = 0, tiles_a = 0;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const uint32_t c = msd->cursor_a[s][tid];
-        const uint32_t t = (c + kPoolTile - 1u) / kPoolTile;
-        keys_a += c;
-        tiles_a += t;
-        s_tiles[tid & 7u][(tid >> 3) * 8u + s] = t;
-    }
-    if (tiles_a > kPoolMaxTiles) s_bad = 1;  // a bucket of this top byte would have more runs than the local sort gathers
-    pool->top_tiles[tid] = tiles_a;
-    uint32_t incl = keys_a;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o);
-        if (lane >= static_cast<uint32_t>(o)) incl += t;
-    }
-    if (lane == 63u) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t before = incl - keys_a;
-    for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
-    pool->top_base[tid] = before;
-    if (tid == 255u) {
-        pool->top_base[256] = before + keys_a;
-        if (before + keys_a != n) s_bad = 1;  // keys the first pass did not place: it did not run, or a workgroup left early
-    }
-    // the exclusive prefix of every XCD's 256 entries: wave w takes XCDs w and w + 4, four entries per lane
-    for (uint32_t x = wave; x < 8u; x += 4u) {
-        uint32_t t[4], tot = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[j] = s_tiles[x][4 * lane + j];
-            tot += t[j];
+// The plan, once the first pass has run: workgroup a = top byte a (256 threads).  Every workgroup derives what it needs from the
+// first pass's 2048 cursors -- the EXACT keys of every (slice, top byte) share -- alone, so the 256 of them run side by side:
+//   * where the top byte starts in the sorted order (top_base), its row of 16 pieces, its place in its XCD's tile table;
+//   * the top byte's part of the slack buffer: space(c) slots for a top byte of c keys, a bound on what its 64 regions may take
+//     (below) that depends on c only -- so the part's start is a sum over the top bytes before it;
+//   * the 64 regions: the workgroup SAMPLES its top byte where the first pass left it (the leading 256 keys of every 8192 of each
+//     piece: 1/32 of the keys, about 50 KB, counted by the next 6 bits in LDS) and gives bucket b the share m_b / m of the exact
+//     total c, six standard deviations of that estimate -- one sampled key stands for R keys: sqrt(R (est + R)), the layout kernel's
+//     rule -- and a floor, rounded up to a multiple of 4 slots (every region starts on a 16-byte boundary);
+//   * workgroup 255: verdict 1.
+// space(c) = c + 6 sqrt(64 R (c + 64 R)) + 64 (floor + 4) bounds the sum of the 64 rooms (Cauchy-Schwarz over sum est_b <= c).
+constexpr float kPoolR = 40.0f;  // keys one sampled key stands for: 32, with a margin
+__device__ __forceinline__ uint32_t pool_space(uint32_t c) {
+    if (c == 0u) return 0u;
+    const float x = static_cast<float>(c);
+    return (c + static_cast<uint32_t>(kPoolSigmas * sqrtf(64.0f * kPoolR * (x + 64.0f * kPoolR))) + 64u * (kPoolRoomFloor + 4u) + 3u) & ~3u;
+}
+__global__ __launch_bounds__(256) void pool_plan_kernel(MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool, uint32_t n, uint32_t tiles_b_cap,
+                                                       uint32_t slack_capacity, const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
+                                                       uint32_t key_base, PoolStreams ps) {
+    __shared__ uint32_t s_c[kBins];              // keys of top byte t
+    __shared__ uint32_t s_red[3][4];
+    __shared__ uint32_t s_hist[4][kMsdSub];      // sampled keys of this top byte by bucket, one row per wave
+    __shared__ uint2 s_piece[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, a = blockIdx.x;
+    const uint32_t shift = pool->shift;
+    {   // the first pass's claims: (list x, tile i) exactly once for every tile the list has (the 65536 threads of the grid take one each)
+        const uint32_t w = a * 256u + tid, x = w / kPoolMaxTilesA, i = w % kPoolMaxTilesA;
+        if (x < 8u && i < ps.tiles_per_stream) {  // (the first pass's grid: tiles_per_stream rows of workgroups)
+            const uint32_t claims = pool->claim_a[w];
+            pool->claim_a[w] = 0;
+            if (claims != 1u && pool->armed != 0u) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        uint32_t inc = tot;
+    }
+    // thread t: top byte t's exact total; thread p < 16 of it: piece p of THIS top byte
+    uint32_t c_t = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) c_t += msd->cursor_a[s][tid];
+    uint32_t plen = 0, pslot = 0;
+    if (tid < 16u) {
+        const uint32_t s = tid >> 1;
+        const uint32_t c = msd->cursor_a[s][a], prim = min(c, pool->cap[s][a]);
+        plen = (tid & 1u) ? c - prim : prim;
+        pslot = (tid & 1u) ? n + pool->obase[s][a] : pool->base[s][a];
+    }
+    s_hist[wave][lane] = 0;
+    s_c[tid] = c_t;
+    // sums over the top bytes before this one: keys, slack space, tiles of the same XCD
+    const uint32_t tiles_t = (c_t + kPoolTile - 1u) / kPoolTile;
+    uint32_t r0 = tid < a ? c_t : 0u, r1 = tid < a ? pool_space(c_t) : 0u, r2 = (tid < a && ((tid ^ a) & 7u) == 0u) ? tiles_t : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        r0 += __shfl_xor(r0, o);
+        r1 += __shfl_xor(r1, o);
+        r2 += __shfl_xor(r2, o);
+    }
+    if (lane == 0u) {
+        s_red[0][wave] = r0;
+        s_red[1][wave] = r1;
+        s_red[2][wave] = r2;
+    }
+    if (tid < 16u) {  // the row of pieces: .x = keys up to and including the piece (a scan over 16 lanes), .y = its first virtual slot
+        uint32_t pend = plen;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const uint32_t t = __shfl_up(pend, o);
+            if (lane >= static_cast<uint32_t>(o)) pend += t;
+        }
+        pool->pieces[a][tid] = make_uint2(pend, pslot);
+        s_piece[tid] = make_uint2(plen, pslot);
+    }
+    __syncthreads();
+    const uint32_t top = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    const uint32_t part = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    const uint32_t tiles_before = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
+    const uint32_t c_a = s_c[a];
+    // The sample: the leading 256 keys of every 8192 of every piece are a CHUNK; thread t reads key t of every chunk, 16 chunks in
+    // flight at a time (a piece after the other would be sixteen dependent round trips).  Chunk q belongs to the piece whose chunks
+    // contain q: the pieces' chunk counts are scanned over 16 lanes, every thread finds its chunks' pieces in LDS.
+    __shared__ uint32_t s_first[17];
+    if (tid < 16u) {
+        const uint32_t chunks = (plen + kPoolTile - 1u) / kPoolTile;
+        uint32_t incl = chunks;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= static_cast<uint32_t>(o)) incl += t;
+        }
+        s_first[tid] = incl - chunks;
+        if (tid == 15u) s_first[16] = incl;
+    }
+    __syncthreads();
+    const uint32_t chunks_all = s_first[16];
+    for (uint32_t q0 = 0; q0 < chunks_all; q0 += 16u) {
+        uint32_t k[16];
+        bool live[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; ++u) {
+            const uint32_t q = min(q0 + u, chunks_all - 1u);
+            uint32_t p = 0;
+#pragma unroll
+            for (uint32_t step = 8; step >= 1; step >>= 1)
+                if (s_first[p + step] <= q) p += step;  // the last piece whose first chunk is <= q (empty pieces share their successor's: skipped)
+            const uint2 pc = s_piece[p];
+            const uint32_t idx = (q - s_first[p]) * kPoolTile + tid;
+            live[u] = q0 + u < chunks_all && idx < pc.x;
+            const uint32_t v = pc.y + (idx < pc.x ? idx : 0u);
+            k[u] = *(v < n ? regions + v : overflow + (v - n));
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; ++u)
+            if (live[u]) atomicAdd(&s_hist[wave][((k[u] - key_base) >> shift) & (kMsdSub - 1u)], 1u);
+    }
+    __syncthreads();
+    if (wave == 0u) {  // lane b = bucket b of the top byte
+        const uint32_t m_b = s_hist[0][lane] + s_hist[1][lane] + s_hist[2][lane] + s_hist[3][lane];
+        uint32_t m = m_b;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m += __shfl_xor(m, o);
+        const float total = static_cast<float>(c_a);
+        const float est = m ? floorf(total * (static_cast<float>(m_b) / static_cast<float>(m)) * 0.999999f) : 0.0f;
+        const float want = fminf(est + kPoolSigmas * sqrtf(kPoolR * (est + kPoolR)), total) + static_cast<float>(kPoolRoomFloor);
+        const uint32_t room = c_a ? (static_cast<uint32_t>(want) + 3u) & ~3u : 0u;
+        uint32_t incl = room;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t u = __shfl_up(inc, o);
-            if (lane >= static_cast<uint32_t>(o)) inc += u;
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= static_cast<uint32_t>(o)) incl += t;
         }
-        uint32_t a = inc - tot;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pool->tiles_b[x][4 * lane + j] = a;
-            a += t[j];
-        }
-        if (lane == 63u) {
-            pool->tiles_b[x][kBins] = a;
-            atomicMax(&s_tiles_b, a);
-        }
+        const uint32_t b = a * kMsdSub + lane;
+        pool->sub_start[b] = part + incl - room;
+        pool->sub_cursor[b] = 0;  // the second pass counts from zero
+        if (a == 255u && lane == 63u) pool->sub_start[kPoolBuckets] = part + incl;
     }
-    __syncthreads();
     if (tid == 0) {
-        pool->ok_a = (armed != 0u && failed == 0u && s_bad == 0u && shift >= kPoolMinShift && shift <= kPoolMaxShift && s_tiles_b <= tiles_b_cap) ? 1u : 0u;
-        pool->max_bucket = 0;  // (PoolPlan::fail stays: the second pass may still set it; the next sort's sample kernel re-arms it)
-        msd->shift = shift;
-        msd->sub_bits = kMsdSubBits;
-        msd->ok = 0;           // the local sort decides
+        pool->top_base[a] = top;
+        pool->tiles_b[a & 7u][a >> 3] = tiles_before;
+        if (a >= 248u) pool->tiles_b[a & 7u][32] = tiles_before + (c_a + kPoolTile - 1u) / kPoolTile;
+    }
+    if (a == 255u) {  // verdict 1 (every total is a function of the cursors: this workgroup has them all)
+        __shared__ uint32_t s_bad;
+        if (tid == 0) s_bad = 0;
+        __syncthreads();
+        uint32_t sum = c_t, space = pool_space(c_t);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            sum += __shfl_xor(sum, o);
+            space += __shfl_xor(space, o);
+        }
+        __syncthreads();
+        if (lane == 0u) {
+            s_red[0][wave] = sum;
+            s_red[1][wave] = space;
+        }
+        if (tid < 8u) {  // XCD tid's tiles
+            uint32_t acc = 0;
+            for (uint32_t k = 0; k < 32u; ++k) acc += (s_c[tid + 8u * k] + kPoolTile - 1u) / kPoolTile;
+            if (acc > tiles_b_cap) atomicOr(&s_bad, 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t all = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+            const uint32_t room = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+            pool->top_base[256] = all;
+            // all != n: keys the first pass did not place (it did not run, or a workgroup left early); the last kPoolTile slots of the
+            // slack buffer are where refused runs are dumped
+            pool->ok_a = (pool->armed != 0u && pool->fail == 0u && s_bad == 0u && all == n && shift >= kPoolMinShift && shift <= kPoolMaxShift &&
+                          room <= slack_capacity - kPoolTile)
+                             ? 1u
+                             : 0u;
+            // (PoolPlan::fail stays: the second pass may still set it; the next sort's layout kernel re-arms it)
+            msd->shift = shift;
+            msd->sub_bits = kMsdSubBits;
+            msd->ok = 0;  // the local sort decides
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Second pass: block b -> XCD b % 8 (no correctness in that), which walks the shares (top byte x + 8 k, slice s) in entry order
-// e = 8 k + s.  A tile reads 8192 slots of its share -- the share's positions run through its primary region, then its overflow
-// region -- groups the keys by the 6 bits below the top byte in LDS and writes them back to the SAME slots.  No offset from
-// anywhere: the tile's row says where each of its 64 runs starts and how long it is.
-struct alignas(16) PoolSmemB {
-    uint32_t keys[kPoolTile];
-    alignas(16) uint32_t whist[8][kMsdSub];  // per-wave counters of the 64 digits -> per-wave starts
+// Second pass: block b -> XCD b % 8, which walks the shares (top byte x + 8 k, slice s) in entry order e = 8 k + s.  A tile reads
+// 8192 slots of its share -- the share's positions run through its primary region, then its overflow region -- and scatters them by
+// the 6 bits below the top byte into the buckets' slack regions.
+// SlackReserve: StreamReserve's one atomic add per tile and digit -- all tiles of a top byte run behind the L2 that holds its 64
+// cursors -- with the region's capacity looked at: a run that does not fit (its region, or the local sort that follows) flags the sort
+// and is dumped in the buffer's last tile.  The write-out also checks every key against the probed range.
+struct SlackReserve {
+    static constexpr bool kEnabled = true;
+    static constexpr bool kReserves = true;
+    static constexpr bool kPool = true;
+    bool foreign = false;            // (interface of StreamLookback: a workgroup off its XCD never gets this far)
+    uint32_t recounted = 0;
+    int index = 0;
+    const void *stream_keys = nullptr;
+    uint32_t done = 0;
+    uint32_t seed = 0;
+    uint32_t *cursor = nullptr;      // this thread's bucket's cursor
+    uint32_t start = 0, cap = 0;     // the bucket's region: first slot, slots the sort may use
+    uint32_t dump = 0;               // first slot of the dump tile
+    uint32_t pad_keys = 0;
+    uint32_t above = 0, key_base = 0;  // bits no key of the probed range has
+    uint32_t *fail_word = nullptr;
+    mutable uint32_t reserved = 0, cnt = 0;
+    mutable bool reserved_yet = false;
+
+    __device__ __forceinline__ void publish(uint32_t v) const {
+        if (reserved_yet) return;  // the second call (the inclusive prefix) has nobody to tell
+        reserved_yet = true;
+        cnt = v - pad_keys;
+        if (cnt) reserved = __hip_atomic_fetch_add(cursor, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ void fetch(int, uint32_t (&)[kLbBatch]) const {}
+    __device__ __forceinline__ uint32_t resolve(uint32_t (&)[kLbBatch], bool &) const { return reserved; }
+    // run [reserved, reserved + cnt) of the region; excl: where the digit's run starts inside the tile
+    __device__ __forceinline__ void place(uint32_t *gbase, uint32_t tid, uint32_t, uint32_t excl) const {
+        const bool bad = cnt != 0u && reserved + cnt > cap;
+        if (bad) __hip_atomic_fetch_or(fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gbase[tid] = (bad ? dump : start + reserved) - excl;
+    }
+    template <typename K, int ITEMS, uint32_t THREADS, bool FULL, typename DG>
+    __device__ __forceinline__ void store(const uint32_t *, const K (&key)[ITEMS], uint32_t (&dst)[ITEMS], K *kout, uint32_t valid, const DG &) const {
+        const uint32_t tid = threadIdx.x;
+        uint32_t over = 0;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            if (FULL || i * THREADS + tid < valid) {  // (the padding key of a ragged tile is no key)
+                over |= (key[i] - key_base) & above;
+                kout[dst[i]] = key[i];
+            }
+        }
+        // a key above the probed range (or below the promised floor): the local sort, which gives the last verdict, sees this
+        if (__ballot(over != 0u) != 0ull && (tid & 63u) == 0u) __hip_atomic_fetch_or(fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 };
 
-// vector: a full tile inside the primary region (16-byte aligned): 16-byte loads and stores.  The general form (a share's ragged
-// last tile, a tile that runs on into the overflow region: one tile in seven) goes through LDS with ROLLED loops on both sides --
-// its index arithmetic unrolled would cost the common form its third workgroup per CU, and out of line (a call) it cost 80 bytes
-// of scratch per lane saved and restored through HBM: 164 MB per sort, a fifth of this pass's traffic (profiles/r04: 968 -> 8xx MB).
-__device__ __forceinline__ uint32_t pool_tile_b(PoolSmemB &sm, bool vector, uint32_t *__restrict__ t0, uint32_t *__restrict__ t1, uint32_t split,
-                                                uint32_t valid, uint32_t shift, uint32_t key_base, uint32_t *__restrict__ row) {
-    constexpr int ITEMS = 16, WAVES = 8;
-    constexpr uint32_t THREADS = WAVES * 64;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t key[ITEMS];
-    if (vector) {  // (workgroup-uniform)
-        const uint4 *v = reinterpret_cast<const uint4 *>(t0);
-#pragma unroll
-        for (int i = 0; i < ITEMS / 4; ++i) {
-            const uint4 q = v[i * THREADS + tid];
-            key[4 * i] = q.x;
-            key[4 * i + 1] = q.y;
-            key[4 * i + 2] = q.z;
-            key[4 * i + 3] = q.w;
-        }
-    } else {  // tile positions below `split` at t0, the others at t1; positions >= valid hold the padding key (digit 63, ranks last)
-#pragma unroll 1
-        for (uint32_t q = tid; q < kPoolTile; q += THREADS) sm.keys[q] = q < valid ? *(q < split ? t0 + q : t1 + q) : key_base - 1u;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) key[i] = sm.keys[wave * (ITEMS * 64) + i * 64 + lane];
-        // (the keys are written back to sm.keys two barriers further on)
+__global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
+                                                             uint32_t *__restrict__ slack, const MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool,
+                                                             uint32_t n_virt, uint32_t key_base, uint32_t local_cap, uint32_t dump,
+                                                             unsigned long long xcc_map, uint32_t stamp) {
+    __shared__ ChunkSmem<uint32_t, 16, 8, false> sm;
+    // the list follows the XCC this workgroup RUNS on (pool_pass_a_kernel): all tiles of a top byte then meet behind the L2 that
+    // holds its 64 cursors, whatever the dispatcher's rotation
+    const uint32_t x = xcc_place(xcc_map), j = blockIdx.x >> 3;
+    if (pool->ok_a == 0u) return;  // uniform (enqueued before the plan was known: it may have said no)
+    if (x == 8u) {  // behind an L2 the probe never saw
+        if (threadIdx.x == 0) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
     }
-    uint32_t *my_hist = sm.whist[wave];
-    my_hist[lane] = 0;  // this wave's own row (64 counters): its LDS operations stay in order
-    // a key outside the probed range has bits above the range's 14 + shift (a range of 32 bits has no such key)
-    const uint32_t above = shift + kMsdBits < 32u ? ~0u << (shift + kMsdBits) : 0u;
-    uint32_t rank2[ITEMS / 2], over = 0;  // two 13-bit ranks per register: 8 registers fewer, and the kernel fits a fourth workgroup per CU
-    if (vector) {
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) over |= (key[i] - key_base) & above;
-    } else {
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i)
-            if (wave * (ITEMS * 64) + i * 64 + lane < valid) over |= (key[i] - key_base) & above;  // (the padding key is no key)
-    }
-    // (key_base is a multiple of 2^24 and the 6 bits end at or below bit 24: the digit needs no subtraction)
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t d = (key[i] >> shift) & (kMsdSub - 1u);
-        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-        uint32_t r;
-        if (__ballot(d == d0) == ~0ull) {
-            uint32_t old = 0;
-            if (lane == 0u) old = __hip_atomic_fetch_add(&my_hist[d0], 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            r = __builtin_amdgcn_readfirstlane(old) + lane;
-        } else {
-            r = __hip_atomic_fetch_add(&my_hist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (i & 1) rank2[i / 2] |= r << 16;
-        else rank2[i / 2] = r;
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-    // every wave: lane l = digit l -- its total, its start inside the tile, this wave's own start
-    uint32_t tot = 0, mine = 0;
-#pragma unroll
-    for (int v = 0; v < WAVES; ++v) {
-        const uint32_t c = sm.whist[v][lane];
-        mine += static_cast<uint32_t>(v) < wave ? c : 0u;
-        tot += c;
-    }
-    uint32_t incl = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o);
-        if (lane >= static_cast<uint32_t>(o)) incl += t;
-    }
-    const uint32_t start = incl - tot;
-    if (wave == 0u) {  // the tile's row: where run l starts inside the tile, and its keys (the padding of a ragged tile is not a key)
-        const uint32_t real = tot - (lane == kMsdSub - 1u ? kPoolTile - valid : 0u);
-        row[lane] = start | (real << 16);
-    }
-    __syncthreads();  // every wave has read every row's counts
-    my_hist[lane] = start + mine;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i)  // (ranks stay below 8192: no carry; opaque: the digits are computed again, not kept in 16 registers across the barriers)
-        rank2[i / 2] += my_hist[(opaque(key[i]) >> shift) & (kMsdSub - 1u)] << (16 * (i & 1));
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) sm.keys[(rank2[i / 2] >> (16 * (i & 1))) & 0xFFFFu] = key[i];
-    __syncthreads();
-    // back to the slots the tile was read from, in tile order
-    if (vector) {
-        uint4 *v = reinterpret_cast<uint4 *>(t0);
-#pragma unroll
-        for (int i = 0; i < ITEMS / 4; ++i) v[i * THREADS + tid] = reinterpret_cast<const uint4 *>(sm.keys)[i * THREADS + tid];
-    } else {
-#pragma unroll 1
-        for (uint32_t q = tid; q < valid; q += THREADS) *(q < split ? t0 + q : t1 + q) = sm.keys[q];
-    }
-    return over;
-}
-
-__global__ __launch_bounds__(512, 8) void pool_pass_b_kernel(uint32_t *__restrict__ regions, uint32_t *__restrict__ overflow, const MsdPlan *__restrict__ msd,
-                                                             PoolPlan *__restrict__ pool, uint32_t *__restrict__ rows, uint32_t key_base) {
-    __shared__ PoolSmemB sm;
-    const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    // the claim: this sort's stamp into (list, tile)'s word -- asked for now, looked at when the tile's loads are under way
+    uint32_t claimed = 0;
+    if (threadIdx.x == 0) claimed = __hip_atomic_exchange(&pool->claim_b[j * 8u + x], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t *pt = pool->tiles_b[x];
-    if (pool->ok_a == 0u || j >= pt[kBins]) return;  // uniform (enqueued before the plan was known: it may have said no)
-    uint32_t e = 0;  // the entry whose tiles contain j: largest e with pt[e] <= j
+    if (j >= pt[32]) return;
+    uint32_t k = 0;  // the top byte whose tiles contain j: largest k with pt[k] <= j
 #pragma unroll
-    for (uint32_t step = 128; step >= 1; step >>= 1)
-        if (pt[e + step] <= j) e += step;
-    const uint32_t a = x + 8u * (e >> 3), s = e & 7u, i = j - pt[e];  // (a share's tiles in descending order, for what the first pass wrote last: no difference)
-    const uint32_t keys_sa = msd->cursor_a[s][a];               // keys of this share (the first pass's cursor)
-    const uint32_t prim = min(keys_sa, pool->cap[s][a]);        // ... of them in the primary region, the rest in the overflow region
-    const uint32_t done = i * kPoolTile;
-    const uint32_t valid = min(kPoolTile, keys_sa - done);
-    const uint32_t split = prim > done ? prim - done : 0u;      // leading tile positions that lie in the primary region
-    uint32_t *t0 = regions + pool->base[s][a] + done;
-    uint32_t *t1 = overflow + pool->obase[s][a] + (static_cast<int64_t>(done) - static_cast<int64_t>(prim));
-    uint32_t *row = rows + static_cast<size_t>(blockIdx.x) * kMsdSub;
-    const bool vector = valid == kPoolTile && split >= kPoolTile && (reinterpret_cast<uintptr_t>(t0) & 15u) == 0u;  // workgroup-uniform
-    const uint32_t over = pool_tile_b(sm, vector, t0, t1, split, valid, msd->shift, key_base, row);
-    // a key above the probed range (or below the promised floor): the local sort, which gives the last verdict, sees this
-    if (__ballot(over != 0u) != 0ull && (threadIdx.x & 63u) == 0u) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t step = 16; step >= 1; step >>= 1)
+        if (pt[k + step] <= j) k += step;
+    const uint32_t a = x + 8u * k, tile_lo = (j - pt[k]) * kPoolTile;
+    // The top byte's keys lie in 16 PIECES: slice s's primary region (piece 2 s), then its overflow region (2 s + 1).  Every wave:
+    // lane p = piece p -- its keys, its first (virtual) slot, where it starts in the top byte's run of keys.
+    // (the plan kernel's row of the top byte: 128 bytes, one load per wave)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint2 pc = pool->pieces[a][lane & 15u];
+    const uint32_t shift = pool->shift;
+    const uint32_t d = threadIdx.x & 255u, b = a * kMsdSub + min(d, kMsdSub - 1u);
+    SlackReserve lb;
+    lb.cursor = &pool->sub_cursor[b];
+    if (threadIdx.x < kMsdSub) {  // (the threads that reserve: one per bucket of the top byte)
+        lb.start = pool->sub_start[b];
+        lb.cap = min(pool->sub_start[b + 1u] - lb.start, local_cap);
+    }
+    const uint32_t pend = pc.x, pslot = pc.y;
+    const uint32_t before = __shfl_up(pend, 1);
+    const uint32_t plo = lane == 0u ? 0u : before;  // the piece holds positions [plo, pend) of the top byte
+    const uint32_t plen = lane < 16u ? pend - plo : 0u;
+    const uint32_t keys_a = __builtin_amdgcn_readlane(pend, 15);
+    const uint32_t valid = min(kPoolTile, keys_a - tile_lo);
+    const unsigned long long touch = __ballot(plen != 0u && plo < tile_lo + valid && pend > tile_lo);
+    PieceSrc src;
+    src.p0 = static_cast<uint32_t>(__builtin_ctzll(touch | (1ull << 63)));
+    src.p1 = 64u - static_cast<uint32_t>(__builtin_clzll(touch | 1ull));
+    src.lo = plo - tile_lo;
+    src.len = plen;
+    src.slot = pslot;
+    src.regions = regions;
+    src.overflow = overflow;
+    src.n_virt = n_virt;
+    const uint32_t slot0 = __builtin_amdgcn_readlane(pslot, src.p0) + (tile_lo - __builtin_amdgcn_readlane(plo, src.p0));  // the tile's first key
+    src.first_slot = slot0;
+    const BitsDigit dg{shift, kMsdSub - 1u, key_base};  // (key_base is a multiple of 2^24 and the 6 bits end at or below bit 24)
+    lb.dump = dump;
+    lb.pad_keys = d == kMsdSub - 1u ? kPoolTile - valid : 0u;  // (the padding key, key_base - 1, carries the largest digit)
+    lb.above = shift + kMsdBits < 32u ? ~0u << (shift + kMsdBits) : 0u;
+    lb.key_base = key_base;
+    lb.fail_word = &pool->fail;
+    uint32_t unused = 0;
+    // (two workgroups of one group of eight on ONE XCC: the tile has been taken twice and another not at all)
+    if (threadIdx.x == 0 && claimed == stamp) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (valid == kPoolTile && src.p1 == src.p0 + 1u)  // a full tile inside one piece: five tiles in six
+        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve>(sm, slot0 < n_virt ? regions + slot0 : overflow + (slot0 - n_virt), nullptr, slack, nullptr, valid, dg, unused, lb);
+    else if (valid == kPoolTile)
+        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve, PieceSrc>(sm, nullptr, nullptr, slack, nullptr, valid, dg, unused, lb, src);
+    else  // the top byte's ragged last tile
+        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, false, BitsDigit, SlackReserve, PieceSrc>(sm, nullptr, nullptr, slack, nullptr, valid, dg, unused, lb, src);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Runs: workgroup a = top byte a (256 threads).  The rows of its tiles -> for every bucket (a, c) its 64 run descriptors
-// (slot r = the run of the top byte's r-th tile; slots R .. R + 7 = the overflow piece of a run whose tile crosses its share's
-// primary region's end, one per slice, usually empty; the rest empty), its start in the sorted order, its size.
-// (256 / 512 / 1024 threads: 16.8 / 15.3 / 15.0 us -- the kernel is a chain of dependent loads, not of work)
-constexpr uint32_t kRunsThreads = 512, kRunsQ = kRunsThreads / kMsdSub, kRunsPer = (kPoolRunSlots + kRunsQ - 1u) / kRunsQ;
-__global__ __launch_bounds__(kRunsThreads) void pool_runs_kernel(MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool, const uint32_t *__restrict__ rows,
-                                                        PoolRun *__restrict__ runs, uint32_t n) {
-    __shared__ uint32_t s_rows[kPoolMaxTiles][kMsdSub];
-    __shared__ uint2 s_desc[kMsdSub][kPoolRunSlots + 1];  // [bucket][run slot] (+1: the buckets' rows on different banks)
-    __shared__ uint32_t s_pos[kPoolMaxTiles], s_prim[kPoolMaxTiles], s_base[kPoolMaxTiles], s_obase[kPoolMaxTiles], s_share[kPoolMaxTiles],
-        s_rowidx[kPoolMaxTiles];
-    __shared__ uint32_t s_part[kRunsQ][kMsdSub], s_tot[kMsdSub];
-    const uint32_t tid = threadIdx.x, a = blockIdx.x, x = a & 7u, e0 = (a >> 3) * 8u;
-    const uint32_t ok_a = pool->ok_a;
-    uint32_t biggest = 0;
-    if (ok_a) {
-        const uint32_t *pt = pool->tiles_b[x];
-        const uint32_t R = pool->top_tiles[a];  // <= kPoolMaxTiles (verdict 1)
-        if (tid < R) {  // run r = tid: which share, which tile of it
-            const uint32_t j = pt[e0] + tid;
-            uint32_t s = 0;
-#pragma unroll
-            for (uint32_t q = 1; q < 8u; ++q) s += pt[e0 + q] <= j ? 1u : 0u;  // entries are non-decreasing: the share whose tiles contain j
-            const uint32_t i = j - pt[e0 + s];
-            const uint32_t keys_sa = msd->cursor_a[s][a];
-            s_share[tid] = s;
-            s_pos[tid] = i * kPoolTile;                               // the tile's first position inside its share
-            s_prim[tid] = min(keys_sa, pool->cap[s][a]);              // positions below this lie in the primary region
-            s_base[tid] = pool->base[s][a];
-            s_obase[tid] = pool->obase[s][a];
-            s_rowidx[tid] = j * 8u + x;                               // the tile's row: the second pass's block index
-        }
-        for (uint32_t w = tid; w < kMsdSub * (kPoolRunSlots + 1u); w += kRunsThreads) (&s_desc[0][0])[w] = make_uint2(0, 0);
-        __syncthreads();
-        for (uint32_t w = tid; w < R * kMsdSub; w += kRunsThreads)  // the rows, coalesced (14 KB per workgroup)
-            s_rows[w >> kMsdSubBits][w & (kMsdSub - 1u)] = rows[static_cast<size_t>(s_rowidx[w >> kMsdSubBits]) * kMsdSub + (w & (kMsdSub - 1u))];
-        __syncthreads();
-        const uint32_t c = tid & (kMsdSub - 1u), q = tid >> kMsdSubBits;
-        {   // thread (q, c): the runs r in [kRunsPer q, kRunsPer q + kRunsPer) of bucket (a, c)
-            uint32_t total = 0;
-            for (uint32_t r = kRunsPer * q; r < min(kRunsPer * q + kRunsPer, R); ++r) {
-                const uint32_t w = s_rows[r][c];
-                const uint32_t off = w & 0xFFFFu, len = w >> 16;
-                const uint32_t pos = s_pos[r] + off, prim = s_prim[r];
-                uint2 d;
-                if (pos + len <= prim) {
-                    d = make_uint2(s_base[r] + pos, len);
-                } else if (pos >= prim) {
-                    d = make_uint2(n + s_obase[r] + (pos - prim), len);
-                } else {  // the run crosses from the primary region into the overflow region: two pieces (one such tile per share at most)
-                    d = make_uint2(s_base[r] + pos, prim - pos);
-                    s_desc[c][R + s_share[r]] = make_uint2(n + s_obase[r], pos + len - prim);
-                }
-                s_desc[c][r] = d;
-                total += d.y;  // (a crossing run's second piece is counted with the pieces below)
-            }
-            s_part[q][c] = total;
-        }
-        __syncthreads();
-        {   // every run's place inside the bucket: (keys before the run) | (the run's keys) << 16; the pieces behind the runs, the
-            // unused slots behind those (empty, at the bucket's end: the local sort reads the bucket's size off the last slot)
-            uint32_t off = 0;
-            for (uint32_t qq = 0; qq < q; ++qq) off += s_part[qq][c];
-            for (uint32_t r = kRunsPer * q; r < min(kRunsPer * q + kRunsPer, R); ++r) {
-                const uint32_t len = s_desc[c][r].y;
-                s_desc[c][r].y = min(off, 0xFFFFu) | (len << 16);  // (a bucket beyond 65535 keys is refused anyway)
-                off += len;
-            }
-            if (q == kRunsQ - 1u) {
-                // the second pieces of crossing runs (at most one per slice, usually none) move up behind the runs: the local sort
-                // stops at the last slot that holds keys
-                uint32_t w = R;
-                for (uint32_t r = R; r < R + 8u; ++r) {
-                    const uint2 d = s_desc[c][r];
-                    s_desc[c][r] = make_uint2(0, 0);
-                    if (d.y) {
-                        s_desc[c][w++] = make_uint2(d.x, min(off, 0xFFFFu) | (d.y << 16));
-                        off += d.y;
-                    }
-                }
-                for (uint32_t r = w; r < kPoolRunSlots; ++r) s_desc[c][r].y = min(off, 0xFFFFu);  // empty, at the bucket's end (slot 63 says its size)
-                s_tot[c] = off;  // the bucket's keys
-            }
-        }
-        __syncthreads();
-        if (tid < kMsdSub) {  // where the bucket starts: the top byte's start + the buckets before it
-            const uint32_t total = s_tot[tid];
-            uint32_t incl = total;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t t = __shfl_up(incl, o);
-                if (tid >= static_cast<uint32_t>(o)) incl += t;
-            }
-            msd->base[a * kMsdSub + tid] = pool->top_base[a] + incl - total;
-            biggest = total;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) biggest = max(biggest, __shfl_down(biggest, o));
-        }
-        // the descriptors, bucket by bucket: what one local-sort workgroup reads is 512 contiguous bytes
-        uint2 *out = reinterpret_cast<uint2 *>(runs) + static_cast<size_t>(a) * kMsdSub * kPoolRunSlots;
-        for (uint32_t w = tid; w < kMsdSub * kPoolRunSlots; w += kRunsThreads) out[w] = s_desc[w / kPoolRunSlots][w % kPoolRunSlots];
-        if (a == 255u && tid == 0) msd->base[kPoolBuckets] = n;
-    }
-    // (verdict 2 is the local sort's: every one of its workgroups reads ok_a, fail and max_bucket -- all final when it starts)
-    if (tid == 0 && biggest) __hip_atomic_fetch_max(&pool->max_bucket, biggest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Local sort: workgroup b = bucket b.  The bucket's keys lie in up to 64 runs.  They are first copied, run by run, into the
-// sort's LDS buffer -- wave w takes runs w, w + WAVES, ...; consecutive lanes read consecutive keys of a run: coalesced, no search
-// -- at word mis + (key's index in the bucket), mis = the misalignment of the bucket's FINAL place: from there every thread reads
-// its 16-byte vectors exactly as lean_sort_bucket (vrs_msd_hybrid.hip) reads them from the bucket in global memory.
-struct PoolGather {
-    const uint32_t *regions, *overflow;
-    uint32_t n_virt;
-    // (the pointers cross a function boundary: say that they are GLOBAL ones, or the loads become flat loads)
-    using gptr = const uint32_t __attribute__((address_space(1))) *;
-    __device__ __forceinline__ gptr at(uint32_t v) const { return v < n_virt ? (gptr)regions + v : (gptr)overflow + (v - n_virt); }
-};
-
-// s_keys[mis + g] = key g of the bucket; all threads of the workgroup, ends with a barrier.  dx, dy: lane l holds run l's
-// descriptor (virtual slot of its first key; keys of the bucket before it | its keys << 16) -- every wave has loaded all 64, so a
-// run's descriptor is two v_readlane away and its address a scalar: no LDS, no barrier, no search in front of the loads.
-// (inline: a call would save and restore the callee's registers through scratch, 300 bytes per thread of a kernel with 4 M threads)
-template <int THREADS>
-__device__ __forceinline__ void pool_stage(const PoolGather &gt, uint32_t dx, uint32_t dy, uint32_t *s_keys, uint32_t mis) {
-    constexpr uint32_t WAVES = THREADS / 64, PER = 64 / WAVES;  // runs per wave
-    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // ALL of the wave's runs at once, three 64-key chunks of each (a run is about 128 keys): every load of the wave is in flight
-    // before the first is written to LDS -- a workgroup lives for one memory latency here, and four would be four.  The loads of
-    // the first two chunks are unconditional, from a clamped index (a predicated load is a branch per lane); the third chunk and
-    // everything behind the last slot that holds keys are skipped wave by wave (scalar branches).
-    const uint32_t used = 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(__ballot((dy >> 16) != 0u) | 1ull)));  // slots [0, used) may hold keys
-    uint32_t x[PER][3];
-    uint32_t slot[PER], pk[PER];  // (wave-uniform: scalar registers)
-#pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) {
-        const uint32_t r = wave + u * WAVES;
-        slot[u] = __builtin_amdgcn_readlane(dx, r);
-        pk[u] = __builtin_amdgcn_readlane(dy, r);
-        x[u][0] = x[u][1] = x[u][2] = 0;
-        if (r < used) {
-            const uint32_t len = pk[u] >> 16;
-            const PoolGather::gptr src = gt.at(slot[u]);  // (an empty run's slot is 0: a valid address)
-            const uint32_t last = len ? len - 1u : 0u;
-            // (plain loads: nontemporal ones here measured 204 instead of 200 us)
-            x[u][0] = src[min(lane, last)];
-            x[u][1] = src[min(64u + lane, last)];
-            if (len > 128u) x[u][2] = src[min(128u + lane, last)];
-        }
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) {
-        const uint32_t len = pk[u] >> 16, dst = mis + (pk[u] & 0xFFFFu);
-        if (wave + u * WAVES < used) {
-#pragma unroll
-            for (uint32_t c = 0; c < 3u; ++c) {
-                const uint32_t idx = c * 64u + lane;
-                if (idx < len) s_keys[dst + idx] = x[u][c];
-            }
-            if (len > 192u) {  // a long run (skewed keys): the rest of it, 64 keys at a time
-                const PoolGather::gptr src = gt.at(slot[u]);
-                for (uint32_t idx = 192u + lane; idx < len; idx += 64u) s_keys[dst + idx] = src[idx];
-            }
-        }
-    }
-    __syncthreads();
-}
-
+// Local sort: workgroup w = bucket 16383 - w.  The bucket lies in ONE piece at the start of its slack region (a 16-byte boundary):
+// read like lean_sort_bucket (vrs_msd_hybrid.hip) reads a bucket of the counted form, sorted by lean_sort_body, written -- unlike
+// there -- somewhere else: to the bucket's final place in the caller's buffer, whose misalignment is the OUTPUT's alone.
 template <int THREADS, int VEC>
-__device__ __forceinline__ void pool_read_staged(uint32_t (&k)[4 * VEC], const uint32_t *s_keys, uint32_t nvec) {
+__device__ __forceinline__ void slack_load(uint32_t (&k)[4 * VEC], const uint32_t *src, uint32_t n) {
+    const uint32_t nvec = (n + 3u) / 4u;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         uint32_t v = j * THREADS + threadIdx.x;
         if (j == VEC - 1) v = v < nvec ? v : nvec - 1u;  // only the last row can reach behind the bucket
-        const uint4 t = reinterpret_cast<const uint4 *>(s_keys)[v];
+        const uint4 t = reinterpret_cast<const uint4 *>(src)[v];
         k[4 * j] = t.x;
         k[4 * j + 1] = t.y;
         k[4 * j + 2] = t.z;
@@ -707,38 +646,21 @@ __device__ __forceinline__ void pool_read_staged(uint32_t (&k)[4 * VEC], const u
 }
 
 template <int THREADS, int VEC>
-__device__ __attribute__((noinline)) void pool_sort_guarded(const PoolGather gt, uint32_t dx, uint32_t dy, uint32_t *abase, uint32_t mis, uint32_t n,
-                                                           uint32_t *s_keys, uint32_t *s_hist2, uint32_t *s_tmp, uint32_t guards) {
-    // (the common path has consumed the staged keys' registers: stage again -- run by run, in a loop: this function's registers
-    // are the KERNEL's registers, whichever path a bucket takes, and the form of pool_stage with every load in flight at once
-    // would cost every workgroup its occupancy)
-    __syncthreads();
-    {
-        constexpr uint32_t WAVES = THREADS / 64;
-        const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#pragma unroll 1
-        for (uint32_t r = wave; r < kPoolRunSlots; r += WAVES) {
-            const uint32_t pk = __builtin_amdgcn_readlane(dy, r);
-            const PoolGather::gptr src = gt.at(__builtin_amdgcn_readlane(dx, r));
-            const uint32_t dst = mis + (pk & 0xFFFFu);
-#pragma unroll 1
-            for (uint32_t idx = lane; idx < (pk >> 16); idx += 64u) s_keys[dst + idx] = src[idx];
-        }
-        __syncthreads();
-    }
+__device__ __attribute__((noinline)) void slack_sort_guarded(const uint32_t *src, uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
+                                                            uint32_t *s_hist2, uint32_t *s_tmp, uint32_t guards) {
+    // (out of line, loading the bucket again: this copy's registers must not cost the common path its occupancy -- lean_sort_bucket)
     uint32_t k[4 * VEC];
-    pool_read_staged<THREADS, VEC>(k, s_keys, (mis + n + 3u) / 4u);
-    __syncthreads();  // every vector is in registers before pass 1 writes the buffer
-    lean_sort_body<THREADS, VEC, true, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, (guards & 1u) != 0u, (guards & 2u) != 0u);
+    slack_load<THREADS, VEC>(k, src, n);
+    lean_sort_body<THREADS, VEC, true, true, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, (guards & 1u) != 0u, (guards & 2u) != 0u, 0u);
 }
 
 template <int THREADS, int VEC>
-__device__ __forceinline__ void pool_sort_bucket(const PoolGather &gt, uint32_t dx, uint32_t dy, uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
-                                                 uint32_t *s_hist2, uint32_t *s_tmp) {
+__device__ __forceinline__ void slack_sort_bucket(const uint32_t *src, uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *s_hist2,
+                                                  uint32_t *s_tmp) {
     constexpr int WAVES = THREADS / 64;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t k[4 * VEC];
-    pool_read_staged<THREADS, VEC>(k, s_keys, (mis + n + 3u) / 4u);
+    slack_load<THREADS, VEC>(k, src, n);
     {   // every counter table zeroed here (lean_sort_bucket does the same): WAVES tables of pass 2, then pass 1's
         constexpr uint32_t kVecs = (WAVES + 1) * kLeanRow / 4;
         for (uint32_t c = tid; c < kVecs; c += THREADS) reinterpret_cast<uint4 *>(s_hist2)[c] = make_uint4(0, 0, 0, 0);
@@ -753,49 +675,43 @@ __device__ __forceinline__ void pool_sort_bucket(const PoolGather &gt, uint32_t 
         }
         if (lane == 0u) s_tmp[16 + wave] = skew;
     }
-    __syncthreads();  // (also: every vector is in registers before pass 1 writes the buffer)
+    __syncthreads();
     uint32_t guards = 0;
 #pragma unroll
     for (int v = 0; v < WAVES; ++v) guards |= s_tmp[16 + v];
     guards = __builtin_amdgcn_readfirstlane(guards);
-    // (two copies of the rest, the guarded one out of line and staging again: see lean_sort_bucket, vrs_msd_hybrid.hip)
-    if (guards == 0u) lean_sort_body<THREADS, VEC, false, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false);
-    else pool_sort_guarded<THREADS, VEC>(gt, dx, dy, abase, mis, n, s_keys, s_hist2, s_tmp, guards);
+    if (guards == 0u) lean_sort_body<THREADS, VEC, false, true, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false, 0u);
+    else slack_sort_guarded<THREADS, VEC>(src, abase, mis, n, s_keys, s_hist2, s_tmp, guards);
 }
 
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void pool_local_sort_kernel(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
-                                                                     uint32_t *__restrict__ keys_out, uint32_t n_virt, MsdPlan *__restrict__ msd,
-                                                                     const PoolPlan *__restrict__ pool, const PoolRun *__restrict__ runs,
+__global__ __launch_bounds__(THREADS, 4) void pool_local_sort_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out,
+                                                                     MsdPlan *__restrict__ msd, const PoolPlan *__restrict__ pool,
                                                                      uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
                                                                      OnesweepPlanHead *host_head, uint32_t stamp) {
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * kLeanMaxVec + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
     __shared__ uint32_t s_tmp[32];
-    // (bucket = block index: neighbouring buckets run on different XCDs and fetch the cache lines they share twice -- 22 % more
-    // bytes than the keys -- but with XCD-contiguous ranges of buckets, xcd_contiguous_tile, the gather measured 178 instead of 160 us)
-    // (groups of 2 .. 16 neighbouring buckets per XCD, so that the lines neighbours share are fetched once: no difference, 218 us)
-    // ... and the LAST bucket first: the second pass wrote the top bytes in ascending order, the highest are what the memory-side
-    // cache still holds (215 -> 208 us)
-    const uint32_t b = kPoolBuckets - 1u - blockIdx.x;
-    // The bucket's start and its run descriptors are asked for BEFORE the verdict is looked at (both tables exist whatever it
-    // says): a workgroup lives for a few memory latencies, and the verdict's words would be one more in front of these.
-    // every wave: lane l = run l's descriptor (512 contiguous bytes of the table)
-    const uint32_t begin = msd->base[b];
-    const uint2 d = reinterpret_cast<const uint2 *>(runs)[static_cast<size_t>(b) * kPoolRunSlots + (threadIdx.x & 63u)];
-    // Verdict 2, by every workgroup from the same three words (all final when this kernel starts): verdict 1 said yes, no pass
-    // flagged the sort, and the largest bucket fits this kernel's shape.  Workgroup 0 tells the host.
-    const uint32_t mx = pool->max_bucket;
-    const uint32_t ok = (pool->ok_a != 0u && pool->fail == 0u && mx <= THREADS * 4u * kLeanMaxVec - 3u) ? 1u : 0u;
+    // the LAST bucket first: the second pass wrote the top bytes in ascending order, the highest are what the memory-side cache
+    // still holds (round 4: 215 -> 208 us)
+    const uint32_t b = kPoolBuckets - 1u - blockIdx.x, a = b >> kMsdSubBits, c = b & (kMsdSub - 1u);
+    const uint32_t lane = threadIdx.x & 63u;
+    // The bucket's region, its top byte's start and the 64 counters of the top byte (one per lane, every wave the same 256 bytes)
+    // are asked for BEFORE the verdict is looked at (all exist whatever it says): a workgroup lives for a few memory latencies.
+    const uint32_t cnt = pool->sub_cursor[(a << kMsdSubBits) + lane];
+    const uint32_t start = pool->sub_start[b], top = pool->top_base[a];
+    // Verdict 2, by every workgroup from the same two words (final when this kernel starts): verdict 1 said yes and no pass flagged
+    // the sort (a region out of room, a bucket above this kernel's capacity, a key outside the probed range).  Workgroup 0 tells the host.
+    const uint32_t ok = (pool->ok_a != 0u && pool->fail == 0u) ? 1u : 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         msd->ok = ok;
         dev_head->msd_ok = ok;
-        dev_head->msd_max_bucket = mx;
+        dev_head->msd_max_bucket = 0;
         dev_head->lsd_missing = 1u;
         if (host_head) {
             __hip_atomic_store(&host_head->lsd_missing, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_head->msd_ok, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&host_head->msd_max_bucket, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_head->msd_max_bucket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __threadfence_system();
             __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -803,22 +719,25 @@ __global__ __launch_bounds__(THREADS, 4) void pool_local_sort_kernel(const uint3
     if (ok == 0u) return;  // (enqueued before the verdicts were known, and one said no)
     // the first pass's cursors, zero for the next sort (the counted form's local sort does the same: rearm_reservation)
     if (blockIdx.x < 2u * kStreams)
-        for (uint32_t c = threadIdx.x; c < 256u; c += THREADS) cursors[blockIdx.x * 256u + c] = 0;
-    const uint32_t pk63 = __builtin_amdgcn_readlane(d.y, 63);
-    const uint32_t n = (pk63 & 0xFFFFu) + (pk63 >> 16);
+        for (uint32_t q = threadIdx.x; q < 256u; q += THREADS) cursors[blockIdx.x * 256u + q] = 0;
+    // keys of the top byte's buckets before this one: every wave sums the lanes below c
+    uint32_t before = lane < c ? cnt : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o);
+    const uint32_t n = __builtin_amdgcn_readlane(cnt, c);
+    const uint32_t begin = top + __builtin_amdgcn_readfirstlane(before);
     const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys_out + begin) >> 2) & 3u);
-    if (n == 0 || mis + n > THREADS * 4u * kLeanMaxVec) return;  // uniform; above the capacity cannot happen (verdict 2 would have said no)
+    if (n == 0 || mis + n > THREADS * 4u * kLeanMaxVec) return;  // uniform; above the capacity cannot happen (the second pass would have flagged it)
     uint32_t *abase = keys_out + begin - mis;
-    const PoolGather gt{regions, overflow, n_virt};
-    pool_stage<THREADS>(gt, d.x, d.y, s_keys, mis);
-    switch ((mis + n + 4u * THREADS - 1u) / (4u * THREADS)) {  // rows of THREADS vectors the bucket touches
-        case 1: pool_sort_bucket<THREADS, 1>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        case 2: pool_sort_bucket<THREADS, 2>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        case 3: pool_sort_bucket<THREADS, 3>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        case 4: pool_sort_bucket<THREADS, 4>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        case 5: pool_sort_bucket<THREADS, 5>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        case 6: pool_sort_bucket<THREADS, 6>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        default: pool_sort_bucket<THREADS, 7>(gt, d.x, d.y, abase, mis, n, s_keys, s_hist, s_tmp); break;
+    const uint32_t *src = slack + start;
+    switch ((mis + n + 4u * THREADS - 1u) / (4u * THREADS)) {  // rows of THREADS vectors the bucket touches where it is written
+        case 1: slack_sort_bucket<THREADS, 1>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 2: slack_sort_bucket<THREADS, 2>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 3: slack_sort_bucket<THREADS, 3>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 4: slack_sort_bucket<THREADS, 4>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 5: slack_sort_bucket<THREADS, 5>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        case 6: slack_sort_bucket<THREADS, 6>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        default: slack_sort_bucket<THREADS, 7>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
     }
 }
 
@@ -848,13 +767,20 @@ uint32_t pool_overflow_capacity(uint32_t n) {
     return static_cast<uint32_t>(std::min<double>(room, 1u << 28)) & ~31u;
 }
 
-uint32_t pool_tiles_b_cap(uint32_t n) {
-    const uint32_t tiles = (n + kPoolTile - 1u) / kPoolTile, even = (tiles + 7u) / 8u;
-    // an XCD walks 32 top bytes x 8 shares, each rounded up to whole tiles; the grid is sized before the plan is known
-    return even + even / 8u + 256u + 40u;
+uint32_t pool_slack_capacity(uint32_t n) {
+    // the plan kernel gives a top byte of c keys c + 6 sqrt(64 R (c + 64 R)) + 64 (floor + 4) slots (pool_space); over 256 top bytes
+    // with sum c = n that is at most n + 6 sqrt(16384 R (n + 16384 R)) + 16384 (floor + 4) + rounding (Cauchy-Schwarz), + the dump tile
+    const double R = 40.0;
+    const double room = 6.0 * std::sqrt(16384.0 * R * (static_cast<double>(n) + 16384.0 * R)) + 16384.0 * (kPoolRoomFloor + 4.0) + 256.0 * 4.0;
+    return (static_cast<uint32_t>(std::min<double>(static_cast<double>(n) + room, 3.9e9) + 31.0) & ~31u) + kPoolTile;
 }
 
-size_t pool_rows_bytes(uint32_t n) { return static_cast<size_t>(8u) * pool_tiles_b_cap(n) * kMsdSub * sizeof(uint32_t); }
+uint32_t pool_tiles_b_cap(uint32_t n) {
+    const uint32_t tiles = (n + kPoolTile - 1u) / kPoolTile, even = (tiles + 7u) / 8u;
+    // an XCD walks 32 top bytes, each rounded up to whole tiles; the grid is sized before the plan is known (a quarter more than
+    // an even split: skewed top bytes)
+    return even + even / 4u + 32u + 8u;
+}
 
 uint32_t pool_local_capacity(bool big) { return (big ? 512u : 256u) * 4u * kLeanMaxVec - 3u; }
 
@@ -875,33 +801,32 @@ hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint3
     return hipGetLastError();
 }
 
-hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap) {
-    hipLaunchKernelGGL(pool_plan_kernel, dim3(1), dim3(256), 0, stream, msd, pool, n, tiles_b_cap);
+hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap, uint32_t slack_capacity,
+                            const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps) {
+    if (ps.tiles_per_stream > kPoolMaxTilesA || tiles_b_cap > kPoolMaxTilesB) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pool_plan_kernel, dim3(256), dim3(256), 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps);
     return hipGetLastError();
 }
 
-hipError_t launch_pool_pass_b(hipStream_t stream, uint32_t *regions, uint32_t *overflow, uint32_t n, MsdPlan *msd, PoolPlan *pool,
-                              uint32_t *rows, uint32_t tiles_b, uint32_t key_base, LaunchEvents ev) {
-    (void)n;
+hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *slack, uint32_t n, MsdPlan *msd,
+                              PoolPlan *pool, uint32_t tiles_b, uint32_t key_base, uint32_t local_cap, uint32_t slack_capacity,
+                              unsigned long long xcc_map, uint32_t stamp, LaunchEvents ev) {
     if (tiles_b == 0) return hipSuccess;
-    VRS_LAUNCH(pool_pass_b_kernel, dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, msd, pool, rows, key_base);
+    if (tiles_b > kPoolMaxTilesB || stamp == 0u) return hipErrorInvalidValue;
+    VRS_LAUNCH(pool_pass_b_kernel, dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n, key_base, local_cap,
+               slack_capacity - kPoolTile, xcc_map, stamp);
     return hipGetLastError();
 }
 
-hipError_t launch_pool_runs(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, const uint32_t *rows, PoolRun *runs, uint32_t n) {
-    hipLaunchKernelGGL(pool_runs_kernel, dim3(256), dim3(kRunsThreads), 0, stream, msd, pool, rows, runs, n);
-    return hipGetLastError();
-}
-
-hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *keys_out, uint32_t n,
-                                  MsdPlan *msd, const PoolPlan *pool, const PoolRun *runs, bool big, OnesweepPlanHead *dev_head,
-                                  OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev) {
+hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
+                                  bool big, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev) {
+    (void)n;
     if (big)
-        VRS_LAUNCH(pool_local_sort_kernel<512>, dim3(kMsdBucketCount), dim3(512), stream, ev, regions, overflow, keys_out, n, msd, pool, runs,
-                   &msd->cursor_a[0][0], dev_head, host_head, stamp);
+        VRS_LAUNCH(pool_local_sort_kernel<512>, dim3(kMsdBucketCount), dim3(512), stream, ev, slack, keys_out, msd, pool, &msd->cursor_a[0][0], dev_head,
+                   host_head, stamp);
     else
-        VRS_LAUNCH(pool_local_sort_kernel<256>, dim3(kMsdBucketCount), dim3(256), stream, ev, regions, overflow, keys_out, n, msd, pool, runs,
-                   &msd->cursor_a[0][0], dev_head, host_head, stamp);
+        VRS_LAUNCH(pool_local_sort_kernel<256>, dim3(kMsdBucketCount), dim3(256), stream, ev, slack, keys_out, msd, pool, &msd->cursor_a[0][0], dev_head,
+                   host_head, stamp);
     return hipGetLastError();
 }
 

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
             lb.region_len = plan->group_seed[pass][next_group][d] - lb.seed;
         }
         if (valid == kTile)
-            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb, nullptr, 0u, stream_in);
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb, NoPieces{}, stream_in);
         else
             scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     } else {
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
         lb.budget = spin_budget;
         lb.seed = threadIdx.x < kBins ? plan->group_seed[pass][sd.first_group][threadIdx.x] : 0u;
         if (valid == kTile)
-            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb, nullptr, 0u, stream_in);
+            scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, true>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb, NoPieces{}, stream_in);
         else
             scatter_chunk<K, ITEMS, WAVES, PAIRS, RANK, false>(sm, keys_in + begin, vin, keys_out, values_out, valid, dg, unused, lb);
     }
