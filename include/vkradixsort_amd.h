@@ -391,7 +391,9 @@ typedef enum vrs_kernel_id {
                                         with reserved places */
     VRS_KERNEL_LOCAL_SORT = 6,       /* one-call sort, hybrid form: every top-14-bit bucket sorted inside LDS */
     VRS_KERNEL_POOL_SAMPLE = 7,      /* one-call sort, pool form: the sample (1/32 of the keys) that sizes the first MSD pass's regions */
-    VRS_KERNEL_COUNT = 8
+    VRS_KERNEL_POOL_PASS_A = 8,      /* one-call sort, pool form: the first MSD pass (pool_pass_a_kernel: reserves in sampled regions) */
+    VRS_KERNEL_POOL_PASS_B = 9,      /* one-call sort, pool form: the second MSD pass (pool_pass_b_kernel: scatters into the buckets' slack regions) */
+    VRS_KERNEL_COUNT = 10
 } vrs_kernel_id;
 
 /* When enabled, every kernel launch carries a (start, stop) hipEvent pair on its own dispatch packet
@@ -485,12 +487,19 @@ typedef enum vrs_tuning_key {
                                       everywhere */
     VRS_TUNE_MSD_POOL = 17,        /* the hybrid form of BARE uint32 keys without its counting read (24 instead of 28 bytes per key): a sample of
                                       1/32 of the keys sizes a region of the partner buffer per (input slice, top byte), the first MSD
-                                      pass reserves its output there, the second pass groups every tile by the next 6 bits in place, the
-                                      local sort gathers every bucket's runs.  A sort a verdict refuses (a region the sample misjudged, a
-                                      bucket too large) starts over in the counted form with its input untouched.  1 (default) = adaptive: after a refusal the next 15
+                                      pass reserves its output there, the second pass scatters by the next 6 or 7 bits into per-bucket
+                                      regions of a context-owned slack buffer (about 1.5 n keys, sized from a sample of the first pass's output),
+                                      the local sort reads every bucket in one piece and writes it to its final place.  A sort a verdict
+                                      refuses (a region the sample misjudged, a bucket too large) starts over in the counted form with its input untouched.  1 (default) = adaptive: after a refusal the next 15
                                       such sorts of the context take the counted form; 2 = always tried; 0 = never.  Needs
                                       VRS_TUNE_MSD_RESERVE != 0. */
     VRS_TUNE_MSD_POOL_MIN_KEYS = 18, /* the pool form is considered from this many keys on (default 3.2 * 10^7: the measured crossover with the counted form; never below 2^22) */
+    VRS_TUNE_MSD_POOL_SUB_BITS = 20, /* bits the pool form's second pass sorts by: 0 (default) = by size (6 while the buckets fit a 256-thread local sort, about 1.1 * 10^8 uniform keys, else 7), 6 or 7 */
+    VRS_TUNE_DEBUG_XCC_ROTATE = 21, /* test hook: run the placement probe again and rotate its result by `value` places (0 .. 7), as if the probe had
+                                       run on another hardware queue than the sorts do (the dispatcher starts every queue's round-robin at its
+                                       own XCC, and a stream may move between queues): the pool form's passes take their work lists by the XCC
+                                       they run on and stay exact AND fast; the look-back streams and the counted form's reservations fall back
+                                       to their placement-independent routes (exact, slower) */
     VRS_TUNE_DEBUG_XCC_STRAY_BLOCK = 19 /* test hook: run the placement probe again and pretend block `value` (0 .. 4095) of it ran on
                                        another XCC: block b -> XCC (b % 8) then holds for most blocks only, and every form that leans on
                                        it (the one-call sorts' look-back streams, reservation, the hybrid and pool forms, vrs_msd_*) is

@@ -480,14 +480,15 @@ def test_one_read_sort_u64(gpu_context, n, dist):
 
 def test_one_read_sort_1e8_equals_std_sort(gpu_context, oracle):
     """BASELINE.json config 3 through the one-call entry point, in its three large-N forms: the pool form (no counting read: a
-    sample, two MSD passes, the gathering local sort, 24 B/key: the default at this size), the counted hybrid form (a counting
+    sample, two MSD passes, the local sort, 24 B/key: the default at this size), the counted hybrid form (a counting
     read, two MSD passes, the in-place local sort, 28 B/key) and the four LSD look-back passes (36 B/key)."""
     n = 10 ** 8
     keys = np.random.RandomState(1).randint(0, 2 ** 32, size=n, dtype=np.uint32)
     ref = oracle.std_sort(keys)[0]
     gpu_context.setTuning(capi.VRS_TUNE_MSD_POOL, 1)  # (also forgets an earlier test's refusal)
     out, stats = sort_keys(gpu_context, keys)
-    assert stats["pool_sample"] == 1 and stats["digit_tables"] == 0 and stats["lookback_scatter"] == 2 and stats["local_sort"] == 1
+    assert stats["pool_sample"] == 1 and stats["digit_tables"] == 0 and stats["pool_pass_a"] == 1 and stats["pool_pass_b"] == 1 and stats["local_sort"] == 1
+    assert stats["lookback_scatter"] == 0
     assert oracle.test_sort(ref, out) == -1
     gpu_context.setTuning(capi.VRS_TUNE_MSD_POOL, 0)
     try:

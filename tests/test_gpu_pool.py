@@ -1,6 +1,7 @@
 """GPU parity tests of the pool form of vrs_sort_keys_u32 (vrs_msd_pool.hip): the hybrid form WITHOUT a counting read --
-a sample sizes a region per (input slice, top byte), the first MSD pass reserves its output there, the second groups every tile
-in place, the local sort gathers every bucket's runs (24 instead of 28 bytes per key).  The reference counts the keys once
+a sample sizes a region per (input slice, top byte), the first MSD pass reserves its output there, the second scatters into
+per-bucket regions of a slack buffer (sized from a sample of the first pass's output), the local sort reads every bucket in one
+piece and writes it to its final place (24 instead of 28 bytes per key).  The reference counts the keys once
 per pass (multi_radixsort_histograms.comp:42-50); here they are not counted at all, and the acceptance criterion stays the
 reference's own: the output equals std::sort, bit for bit (MultiRadixSort.cpp:141-161).  Whatever the sample misjudges -- a
 region, the key range, a bucket's size -- must end in a refusal and a counted sort of the untouched input, never in a wrong
@@ -67,6 +68,7 @@ def pool_ctx(gpu_context):
     ctx.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 32000000)
     ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 0)
     ctx.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 0)
+    ctx.setTuning(capi.VRS_TUNE_MSD_POOL_SUB_BITS, 0)
     ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)  # (the default of a context with its own stream)
 
 
@@ -104,12 +106,13 @@ def test_pool_form_equals_std_sort(pool_ctx, oracle, n, dist):
     out, stats, (took, refused) = sort_and_stats(pool_ctx, keys)
     assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
     if dist == "gauss" and n > 20000000:
-        # the fullest top byte holds 2.5 % of the keys: 92 tiles of the second pass, more runs than a bucket's gather takes (56)
+        # the fullest top byte holds 2.5 % of the keys: its buckets (11 700 keys) are above the local sort the form picked from n alone
         assert (took, refused) == (0, 1)
         return
-    # the form really ran, and nothing was counted ahead: a sample, two passes, the gathering local sort
+    # the form really ran, and nothing was counted ahead: a sample, its two passes, the local sort
     assert (took, refused) == (1, 0)
-    assert stats["pool_sample"] == 1 and stats["digit_tables"] == 0 and stats["lookback_scatter"] == 2 and stats["local_sort"] == 1
+    assert stats["pool_sample"] == 1 and stats["digit_tables"] == 0 and stats["lookback_scatter"] == 0 and stats["local_sort"] == 1
+    assert stats["pool_pass_a"] == 1 and stats["pool_pass_b"] == 1
 
 
 @pytest.mark.parametrize("dist", REFUSED)
@@ -147,6 +150,54 @@ def test_pool_form_with_workgroups_off_their_slices(pool_ctx, oracle):
     out, _, (took, refused) = sort_and_stats(pool_ctx, keys)
     assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
     assert took + refused == 1
+
+
+@pytest.mark.parametrize("sub_bits", [6, 7])
+@pytest.mark.parametrize("dist", ["uniform", "28bit", "halves", "dups"])
+def test_pool_form_with_either_width_of_the_second_pass(pool_ctx, oracle, sub_bits, dist):
+    """VRS_TUNE_MSD_POOL_SUB_BITS: 16384 buckets of 18 low bits or 32768 of 17 (the default follows the size: 7 bits where 6 would
+    need the 512-thread local sort)"""
+    n = 11000017
+    pool_ctx.setTuning(capi.VRS_TUNE_MSD_POOL_SUB_BITS, sub_bits)
+    keys = pool_keys(n, dist, seed=sub_bits)
+    out, stats, (took, refused) = sort_and_stats(pool_ctx, keys)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    assert (took, refused) == (1, 0) and stats["pool_pass_b"] == 1 and stats["digit_tables"] == 0
+
+
+@pytest.mark.parametrize("rotate", [1, 3, 7])
+def test_pool_form_does_not_depend_on_where_the_round_robin_starts(oracle, rotate):
+    """The dispatcher deals the blocks of a launch out to the XCCs round-robin, starting at an XCC of the hardware queue's own -- and a
+    stream may move to another queue after the context probed the placement (seen in round 5: a probe that said 0 1 2 .. 7, sorts
+    that ran 7 0 1 .. 6).  Both passes of the pool form take their work lists by the XCC they RUN on: with the probed order
+    rotated (test hook) the form is still taken, every tile is claimed exactly once, and the result is exact.  The counted form
+    and the look-back passes fall back to their placement-independent routes: exact too."""
+    with vrs.GPUContext(0) as gpu:
+        gpu.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, POOL_MIN)
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, POOL_MIN)
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL, 2)
+        gpu.setTuning(capi.VRS_TUNE_DEBUG_XCC_ROTATE, rotate)
+        for dist in ("uniform", "halves"):
+            keys = pool_keys(9000011, dist, seed=rotate)
+            out, stats, (took, refused) = sort_and_stats(gpu, keys)
+            assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+            assert (took, refused) == (1, 0), dist
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL, 0)  # the counted form, then (below its threshold) the look-back passes
+        for n in (9000011, 3000001):
+            keys = pool_keys(n, "uniform", seed=n % 97)
+            out, _, _ = sort_and_stats(gpu, keys)
+            assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+
+
+def test_pool_form_beyond_the_small_local_sort(gpu_context):
+    """1.3e8 uniform keys: 16384 buckets would need the 512-thread local sort, so the second pass takes seven bits (32768 buckets of
+    about 4000 keys) -- round 4's in-place second pass stopped at 1.15e8 keys (56 tiles per top byte)"""
+    n = 130000003
+    keys = np.random.RandomState(4).randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    gpu_context.setTuning(capi.VRS_TUNE_MSD_POOL, 1)
+    out, stats, (took, refused) = sort_and_stats(gpu_context, keys)
+    assert (took, refused) == (1, 0) and stats["digit_tables"] == 0 and stats["pool_pass_b"] == 1
+    assert np.array_equal(out, np.sort(keys))
 
 
 def test_pool_form_enqueue_only(pool_ctx, oracle):

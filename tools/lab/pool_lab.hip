@@ -60,7 +60,9 @@ int main(int argc, char **argv) {
     for (auto &k : keys) CK(hipMalloc(&k, 4ull * n));
     CK(hipMalloc(&partner, 4ull * n));
     CK(hipMalloc(&ovf, 4ull * room));
-    const uint32_t slack_cap = vrs::pool_slack_capacity(n);
+    const vrs::PoolShape shape = vrs::pool_shape(n, getenv("POOL_LAB_SUB") ? atoi(getenv("POOL_LAB_SUB")) : 0);
+    const uint32_t slack_cap = vrs::pool_slack_capacity(n, shape.sub_bits);
+    std::printf("shape: %u bits, local sort %u (capacity %u)\n", shape.sub_bits, shape.local, vrs::pool_local_capacity(shape.local));
     CK(hipMalloc(&slack, 4ull * slack_cap));
     CK(hipMalloc(&pool, sizeof(vrs::PoolPlan)));
     CK(hipMalloc(&msd, sizeof(vrs::MsdPlan)));
@@ -79,7 +81,6 @@ int main(int argc, char **argv) {
     hipEvent_t ev[8];
     for (auto &e : ev) CK(hipEventCreate(&e));
     const uint32_t tiles_b = vrs::pool_tiles_b_cap(n);
-    const bool big = getenv("POOL_LAB_BIG") ? atoi(getenv("POOL_LAB_BIG")) != 0 : static_cast<uint64_t>(n) * 11u / 10u / vrs::kMsdBucketCount + 64u > vrs::pool_local_capacity(false);
     double sum[7] = {0, 0, 0, 0, 0, 0, 0};
     int counted = 0;
     for (int r = 0; r < reps + 2; ++r) {
@@ -94,12 +95,12 @@ int main(int argc, char **argv) {
         CK(hipEventRecord(ev[1], st));
         CK(vrs::launch_pool_pass_a(st, in, partner, ovf, n, 0, ps, pool, msd, xcc_map, false, room));
         CK(hipEventRecord(ev[2], st));
-        CK(vrs::launch_pool_plan(st, msd, pool, n, tiles_b, slack_cap, partner, ovf, 0, ps));
+        CK(vrs::launch_pool_plan(st, msd, pool, n, tiles_b, slack_cap, partner, ovf, 0, ps, shape.sub_bits));
         CK(hipEventRecord(ev[3], st));
-        CK(vrs::launch_pool_pass_b(st, partner, ovf, slack, n, msd, pool, tiles_b, 0, vrs::pool_local_capacity(big), slack_cap, xcc_map, 1000u + r));
+        CK(vrs::launch_pool_pass_b(st, partner, ovf, slack, n, msd, pool, tiles_b, 0, vrs::pool_local_capacity(shape.local), slack_cap, xcc_map, 1000u + r, shape.sub_bits));
         CK(hipEventRecord(ev[4], st));
         CK(hipEventRecord(ev[5], st));
-        CK(vrs::launch_pool_local_sort(st, slack, in, n, msd, pool, big, head, nullptr, 1));
+        CK(vrs::launch_pool_local_sort(st, slack, in, n, msd, pool, shape, head, nullptr, 1));
         CK(hipEventRecord(ev[6], st));
         hipLaunchKernelGGL(check_sorted, dim3(2048), dim3(256), 0, st, in, n, chk);
         CK(hipStreamSynchronize(st));
@@ -110,19 +111,20 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(&hp, pool, 32, hipMemcpyDeviceToHost));
         CK(hipMemcpy(hc, chk, 32, hipMemcpyDeviceToHost));
         if (!hm.ok || getenv("POOL_LAB_DUMP")) {  // why: the fullest bucket against its room and the local sort's capacity
-            std::vector<uint32_t> start(vrs::kMsdBucketCount + 4), cur(vrs::kMsdBucketCount);
+            const uint32_t buckets = 256u << shape.sub_bits;
+            std::vector<uint32_t> start(buckets + 4), cur(buckets);
             CK(hipMemcpy(start.data(), reinterpret_cast<char *>(pool) + offsetof(vrs::PoolPlan, sub_start), start.size() * 4, hipMemcpyDeviceToHost));
             CK(hipMemcpy(cur.data(), reinterpret_cast<char *>(pool) + offsetof(vrs::PoolPlan, sub_cursor), cur.size() * 4, hipMemcpyDeviceToHost));
             uint32_t worst = 0, over = 0, mx = 0;
             double tight = 0;
-            for (uint32_t b = 0; b < vrs::kMsdBucketCount; ++b) {
+            for (uint32_t b = 0; b < buckets; ++b) {
                 const uint32_t room = start[b + 1] - start[b];
                 mx = std::max(mx, cur[b]);
                 if (cur[b] > room) { ++over; worst = b; }
                 if (room) tight = std::max(tight, double(cur[b]) / room);
             }
-            std::printf("   dump: slack used %u of %u, largest bucket %u (cap %u), buckets over their room %u (e.g. %u: %u > %u), tightest fill %.3f\n", start[vrs::kMsdBucketCount],
-                        slack_cap, mx, vrs::pool_local_capacity(big), over, worst, cur[worst], start[worst + 1] - start[worst], tight);
+            std::printf("   dump: slack used %u of %u, largest bucket %u (cap %u), buckets over their room %u (e.g. %u: %u > %u), tightest fill %.3f\n", start[buckets],
+                        slack_cap, mx, vrs::pool_local_capacity(shape.local), over, worst, cur[worst], start[worst + 1] - start[worst], tight);
         }
         float t[6];
         for (int i = 0; i < 6; ++i) CK(hipEventElapsedTime(&t[i], ev[i], ev[i + 1]));

@@ -29,9 +29,11 @@ VRS_KERNEL_DIGIT_TABLES = 4
 VRS_KERNEL_LOOKBACK_SCATTER = 5
 VRS_KERNEL_LOCAL_SORT = 6
 VRS_KERNEL_POOL_SAMPLE = 7
-VRS_KERNEL_COUNT = 8
+VRS_KERNEL_POOL_PASS_A = 8
+VRS_KERNEL_POOL_PASS_B = 9
+VRS_KERNEL_COUNT = 10
 KERNEL_NAMES = {0: "histogram", 1: "prefix", 2: "scatter", 3: "single", 4: "digit_tables", 5: "lookback_scatter",
-                6: "local_sort", 7: "pool_sample"}
+                6: "local_sort", 7: "pool_sample", 8: "pool_pass_a", 9: "pool_pass_b"}
 
 VRS_KEYS_INT32 = 0
 VRS_KEYS_FLOAT32_TO_SORTABLE = 1
@@ -58,6 +60,8 @@ VRS_TUNE_MSD_RESERVE = 16
 VRS_TUNE_MSD_POOL = 17
 VRS_TUNE_MSD_POOL_MIN_KEYS = 18
 VRS_TUNE_DEBUG_XCC_STRAY_BLOCK = 19
+VRS_TUNE_MSD_POOL_SUB_BITS = 20
+VRS_TUNE_DEBUG_XCC_ROTATE = 21
 # keys the local sort of one top-14-bit bucket can hold (msd_local_capacity): uint32 keys with the 256- / 512-thread workgroup, pairs and 64-bit keys
 LOCAL_SORT_SMALL_KEYS, LOCAL_SORT_MAX_KEYS = 7165, 14333
 LOCAL_SORT_SMALL_PAIRS, LOCAL_SORT_MAX_PAIRS = 6656, 13312  # pairs and 64-bit keys: 512 / 1024-thread workgroups

@@ -108,6 +108,7 @@ struct vrs_context_t {
     uint32_t os_pool_slack_cap = 0;        //   slots
     uint64_t os_pool_sorts = 0, os_pool_refusals = 0;
     uint32_t os_pool_min_keys = 32000000u;  // VRS_TUNE_MSD_POOL_MIN_KEYS
+    int os_pool_sub_bits = 0;               // VRS_TUNE_MSD_POOL_SUB_BITS: 0 = by size (pool_shape), 6 or 7
     bool os_cursors_open = false;        // a reserving pass may have run without the local sort that re-arms its counters behind it
                                          // (a refused plan, a partition with no finish, an error in between): cleared before the next use
     // a one-call sort between its two halves (see one_read_enqueue / one_read_complete)
@@ -1110,7 +1111,8 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     vrs_context_t::OneRead &st = ctx->one_read;
     const uint32_t n = st.n;
     int rc;
-    const uint32_t room = vrs::pool_overflow_capacity(n), slack = vrs::pool_slack_capacity(n);
+    const vrs::PoolShape shape = vrs::pool_shape(n, ctx->os_pool_sub_bits);
+    const uint32_t room = vrs::pool_overflow_capacity(n), slack = vrs::pool_slack_capacity(n, shape.sub_bits);
     if (!ctx->os_pool_plan) {
         vrs::PoolPlan *pp = nullptr;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&pp), sizeof(vrs::PoolPlan));
@@ -1147,24 +1149,23 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     st.stamp = ctx->os_stamp;
     // Everything is enqueued here, before any verdict is known (the workgroups of what a verdict refuses leave at once): the
     // second verdict falls only when the second pass has run, and a host that enqueued the local sort after it would leave the
-    // GPU idle for a round trip.  The local sort's shape is chosen from n alone (uniform keys: buckets of n / 16384 + a few per
-    // cent); a bucket above its capacity makes the second pass flag the sort.
-    const double mean_bucket = static_cast<double>(n) / vrs::kMsdBucketCount;  // (the fullest of 16384 uniform buckets: 4-4.5 deviations above)
-    const bool big = static_cast<uint64_t>(mean_bucket + 5.5 * std::sqrt(mean_bucket)) + 32u > vrs::pool_local_capacity(false);
+    // GPU idle for a round trip.  The form's shape -- bits of the second pass, the local sort's workgroup -- is chosen from n alone
+    // (pool_shape: uniform keys, buckets of n / 16384 or n / 32768 + a few per cent); a bucket above the local sort's capacity
+    // makes the second pass flag the sort.
     const uint32_t tiles_b = vrs::pool_tiles_b_cap(n);
     if ((rc = profile_events(ctx, VRS_KERNEL_POOL_SAMPLE, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_sample(ctx->stream, home, n, st.key_base, ps, ctx->os_pool_plan, room, ev));
     st.ev_lb_before = ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER];
     st.ev_ls_before = ctx->events_used[VRS_KERNEL_LOCAL_SORT];
-    if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+    if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_A, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_pass_a(ctx->stream, home, partner, ctx->os_pool_overflow, n, st.key_base, ps, ctx->os_pool_plan, ctx->os_msd_plan,
                                          ctx->xcc_map, ctx->os_misplace, room, ev));
-    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, partner, ctx->os_pool_overflow, st.key_base, ps));
-    if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, partner, ctx->os_pool_overflow, st.key_base, ps, shape.sub_bits));
+    if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_B, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, partner, ctx->os_pool_overflow, ctx->os_pool_slack, n, ctx->os_msd_plan, ctx->os_pool_plan, tiles_b,
-                                         st.key_base, vrs::pool_local_capacity(big), ctx->os_pool_slack_cap, ctx->xcc_map, st.stamp, ev));
+                                         st.key_base, vrs::pool_local_capacity(shape.local), ctx->os_pool_slack_cap, ctx->xcc_map, st.stamp, shape.sub_bits, ev));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
-    VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, home, n, ctx->os_msd_plan, ctx->os_pool_plan, big, &ctx->os_plan->head,
+    VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, home, n, ctx->os_msd_plan, ctx->os_pool_plan, shape, &ctx->os_plan->head,
                                              ctx->os_host_head_dev, st.stamp, ev));
     ctx->os_cursors_open = false;  // the local sort re-arms the reservation counters (a refusal is handled by one_read_complete)
     st.active = true;
@@ -1918,7 +1919,19 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             ctx->os_pool_skip = 0;
             return VRS_OK;
         case VRS_TUNE_DEBUG_XCC_STRAY_BLOCK:
-            return probe_xcc_map(ctx, value);  // (a negative value probes again as at creation)
+            if (value >= 4096) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the probe has 4096 blocks (a negative value probes again without a stray one)");
+            return probe_xcc_map(ctx, value);  // (a negative value probes again as at creation; a pending sort was settled above)
+        case VRS_TUNE_DEBUG_XCC_ROTATE: {
+            if (value < 0 || value > 7) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "rotate the probed placement by 0 .. 7 places");
+            if (const int rc = probe_xcc_map(ctx)) return rc;
+            const unsigned sh = 8u * static_cast<unsigned>(value);
+            if (sh) ctx->xcc_map = (ctx->xcc_map >> sh) | (ctx->xcc_map << (64u - sh));
+            return VRS_OK;
+        }
+        case VRS_TUNE_MSD_POOL_SUB_BITS:
+            if (value != 0 && value != 6 && value != 7) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form's second pass sorts by 6 or 7 bits (0 = by size)");
+            ctx->os_pool_sub_bits = value;
+            return VRS_OK;
         case VRS_TUNE_MSD_POOL_MIN_KEYS:
             if (value < (1 << 22)) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form takes 2^22 keys or more");
             ctx->os_pool_min_keys = static_cast<uint32_t>(value);

@@ -40,7 +40,9 @@ namespace vrs {
 
 namespace {
 
-constexpr uint32_t kPoolBuckets = kMsdBucketCount;        // 16384
+#ifndef VRS_LAB_STREAM
+#define VRS_LAB_STREAM true
+#endif
 constexpr uint32_t kPoolMinShift = 13, kPoolMaxShift = 18;  // a 27 ... 32-bit key range (the counted form's rule)
 constexpr float kPoolSigmas = 6.0f;                       // overflow room, in standard deviations of the region's estimate
 constexpr uint32_t kPoolRoomFloor = 320;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__r
         if (threadIdx.x == 0) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&pool->claim_a[s_out * kPoolMaxTilesA + i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&pool->claim_a[s_out * kPoolMaxTilesA + i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (L2-local: every claim on this word comes from this XCC)
     // misplace (test hook): odd tiles are read from the neighbouring slice
     const uint32_t s_in = (s_out + (misplace ? (i & 1u) : 0u)) & 7u;
     const uint32_t len = ps.len[s_in];
@@ -331,34 +333,42 @@ __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__r
 //     total c, six standard deviations of that estimate -- one sampled key stands for R keys: sqrt(R (est + R)), the layout kernel's
 //     rule -- and a floor, rounded up to a multiple of 4 slots (every region starts on a 16-byte boundary);
 //   * workgroup 255: verdict 1.
-// space(c) = c + 6 sqrt(64 R (c + 64 R)) + 64 (floor + 4) bounds the sum of the 64 rooms (Cauchy-Schwarz over sum est_b <= c).
+// space(c) = c + 6 sqrt(S R (c + S R)) + S (floor + 4) bounds the sum of the S = 64 or 128 rooms (Cauchy-Schwarz over sum est_b <= c).
 constexpr float kPoolR = 40.0f;  // keys one sampled key stands for: 32, with a margin
+template <uint32_t SUB>  // buckets per top byte
 __device__ __forceinline__ uint32_t pool_space(uint32_t c) {
     if (c == 0u) return 0u;
-    const float x = static_cast<float>(c);
-    return (c + static_cast<uint32_t>(kPoolSigmas * sqrtf(64.0f * kPoolR * (x + 64.0f * kPoolR))) + 64u * (kPoolRoomFloor + 4u) + 3u) & ~3u;
+    const float x = static_cast<float>(c), s = static_cast<float>(SUB);
+    return (c + static_cast<uint32_t>(kPoolSigmas * sqrtf(s * kPoolR * (x + s * kPoolR))) + SUB * (kPoolRoomFloor + 4u) + 3u) & ~3u;
 }
-__global__ __launch_bounds__(256) void pool_plan_kernel(MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool, uint32_t n, uint32_t tiles_b_cap,
+template <uint32_t SUBBITS>
+__global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool, uint32_t n, uint32_t tiles_b_cap,
                                                        uint32_t slack_capacity, const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
                                                        uint32_t key_base, PoolStreams ps) {
+    constexpr uint32_t THREADS = 512, WAVES = THREADS / 64, SUB = 1u << SUBBITS, PER = SUB / 64u;
     __shared__ uint32_t s_c[kBins];              // keys of top byte t
-    __shared__ uint32_t s_red[3][4];
-    __shared__ uint32_t s_hist[4][kMsdSub];      // sampled keys of this top byte by bucket, one row per wave
+    __shared__ uint32_t s_red[3][WAVES];
+    __shared__ uint32_t s_hist[WAVES][SUB];      // sampled keys of this top byte by bucket, one row per wave
     __shared__ uint2 s_piece[16];
+    __shared__ uint32_t s_first[17];
+    __shared__ uint32_t s_bad;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, a = blockIdx.x;
-    const uint32_t shift = pool->shift;
-    {   // the first pass's claims: (list x, tile i) exactly once for every tile the list has (the 65536 threads of the grid take one each)
+    const uint32_t shift = pool->shift, bshift = shift + kMsdSubBits - SUBBITS;  // bucket index of a key: (key - key_base) >> bshift
+    if (tid < 2u * kBins / 2u) {  // the first pass's claims: (list x, tile i) exactly once for every tile of the grid (the 256 x 256 first threads take one each)
         const uint32_t w = a * 256u + tid, x = w / kPoolMaxTilesA, i = w % kPoolMaxTilesA;
-        if (x < 8u && i < ps.tiles_per_stream) {  // (the first pass's grid: tiles_per_stream rows of workgroups)
+        if (tid < 256u && x < 8u && i < ps.tiles_per_stream) {
             const uint32_t claims = pool->claim_a[w];
             pool->claim_a[w] = 0;
             if (claims != 1u && pool->armed != 0u) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    // thread t: top byte t's exact total; thread p < 16 of it: piece p of THIS top byte
+    // thread t < 256: top byte t's exact total; thread p < 16: piece p of THIS top byte
     uint32_t c_t = 0;
+    if (tid < kBins) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) c_t += msd->cursor_a[s][tid];
+        for (int s = 0; s < 8; ++s) c_t += msd->cursor_a[s][tid];
+        s_c[tid] = c_t;
+    }
     uint32_t plen = 0, pslot = 0;
     if (tid < 16u) {
         const uint32_t s = tid >> 1;
@@ -366,11 +376,12 @@ __global__ __launch_bounds__(256) void pool_plan_kernel(MsdPlan *__restrict__ ms
         plen = (tid & 1u) ? c - prim : prim;
         pslot = (tid & 1u) ? n + pool->obase[s][a] : pool->base[s][a];
     }
-    s_hist[wave][lane] = 0;
-    s_c[tid] = c_t;
+#pragma unroll
+    for (uint32_t q = 0; q < PER; ++q) s_hist[wave][lane + 64u * q] = 0;
+    if (tid == 0) s_bad = 0;
     // sums over the top bytes before this one: keys, slack space, tiles of the same XCD
     const uint32_t tiles_t = (c_t + kPoolTile - 1u) / kPoolTile;
-    uint32_t r0 = tid < a ? c_t : 0u, r1 = tid < a ? pool_space(c_t) : 0u, r2 = (tid < a && ((tid ^ a) & 7u) == 0u) ? tiles_t : 0u;
+    uint32_t r0 = tid < a ? c_t : 0u, r1 = tid < a ? pool_space<SUB>(c_t) : 0u, r2 = (tid < a && ((tid ^ a) & 7u) == 0u) ? tiles_t : 0u;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         r0 += __shfl_xor(r0, o);
@@ -382,78 +393,91 @@ __global__ __launch_bounds__(256) void pool_plan_kernel(MsdPlan *__restrict__ ms
         s_red[1][wave] = r1;
         s_red[2][wave] = r2;
     }
-    if (tid < 16u) {  // the row of pieces: .x = keys up to and including the piece (a scan over 16 lanes), .y = its first virtual slot
-        uint32_t pend = plen;
+    if (tid < 16u) {
+        // the row of pieces: .x = keys up to and including the piece (a scan over 16 lanes), .y = its first virtual slot; and the
+        // pieces' CHUNKS (the leading 256 keys of every 8192): where each piece's chunks start in the list of all
+        const uint32_t chunks = (plen + kPoolTile - 1u) / kPoolTile;
+        uint32_t pend = plen, cend = chunks;
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
-            const uint32_t t = __shfl_up(pend, o);
-            if (lane >= static_cast<uint32_t>(o)) pend += t;
+            const uint32_t t = __shfl_up(pend, o), u = __shfl_up(cend, o);
+            if (lane >= static_cast<uint32_t>(o)) {
+                pend += t;
+                cend += u;
+            }
         }
         pool->pieces[a][tid] = make_uint2(pend, pslot);
         s_piece[tid] = make_uint2(plen, pslot);
+        s_first[tid] = cend - chunks;
+        if (tid == 15u) s_first[16] = cend;
     }
     __syncthreads();
-    const uint32_t top = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-    const uint32_t part = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
-    const uint32_t tiles_before = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
+    uint32_t top = 0, part = 0, tiles_before = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < WAVES; ++w) {
+        top += s_red[0][w];
+        part += s_red[1][w];
+        tiles_before += s_red[2][w];
+    }
     const uint32_t c_a = s_c[a];
-    // The sample: the leading 256 keys of every 8192 of every piece are a CHUNK; thread t reads key t of every chunk, 16 chunks in
-    // flight at a time (a piece after the other would be sixteen dependent round trips).  Chunk q belongs to the piece whose chunks
-    // contain q: the pieces' chunk counts are scanned over 16 lanes, every thread finds its chunks' pieces in LDS.
-    __shared__ uint32_t s_first[17];
-    if (tid < 16u) {
-        const uint32_t chunks = (plen + kPoolTile - 1u) / kPoolTile;
-        uint32_t incl = chunks;
+    // The sample: thread (h, t) = (tid / 256, tid % 256) reads key t of the chunks q = h, h + 2, ..., 32 of them in flight at a time
+    // (a piece after the other would be sixteen dependent round trips).  Chunk q belongs to the last piece whose first chunk is <= q.
+    const uint32_t chunks_all = s_first[16], half = tid >> 8, t = tid & 255u;
+    for (uint32_t q0 = half; q0 < chunks_all; q0 += 64u) {
+        uint32_t k[32], live = 0;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
-            if (lane >= static_cast<uint32_t>(o)) incl += t;
-        }
-        s_first[tid] = incl - chunks;
-        if (tid == 15u) s_first[16] = incl;
-    }
-    __syncthreads();
-    const uint32_t chunks_all = s_first[16];
-    for (uint32_t q0 = 0; q0 < chunks_all; q0 += 16u) {
-        uint32_t k[16];
-        bool live[16];
-#pragma unroll
-        for (uint32_t u = 0; u < 16u; ++u) {
-            const uint32_t q = min(q0 + u, chunks_all - 1u);
+        for (uint32_t u = 0; u < 32u; ++u) {
+            const uint32_t q = min(q0 + 2u * u, chunks_all - 1u);
             uint32_t p = 0;
 #pragma unroll
             for (uint32_t step = 8; step >= 1; step >>= 1)
-                if (s_first[p + step] <= q) p += step;  // the last piece whose first chunk is <= q (empty pieces share their successor's: skipped)
+                if (s_first[p + step] <= q) p += step;  // (empty pieces share their successor's first chunk: skipped)
             const uint2 pc = s_piece[p];
-            const uint32_t idx = (q - s_first[p]) * kPoolTile + tid;
-            live[u] = q0 + u < chunks_all && idx < pc.x;
+            const uint32_t idx = (q - s_first[p]) * kPoolTile + t;
+            live |= (q0 + 2u * u < chunks_all && idx < pc.x) ? 1u << u : 0u;
             const uint32_t v = pc.y + (idx < pc.x ? idx : 0u);
             k[u] = *(v < n ? regions + v : overflow + (v - n));
         }
 #pragma unroll
-        for (uint32_t u = 0; u < 16u; ++u)
-            if (live[u]) atomicAdd(&s_hist[wave][((k[u] - key_base) >> shift) & (kMsdSub - 1u)], 1u);
+        for (uint32_t u = 0; u < 32u; ++u)
+            if (live & (1u << u)) atomicAdd(&s_hist[wave][((k[u] - key_base) >> bshift) & (SUB - 1u)], 1u);
     }
     __syncthreads();
-    if (wave == 0u) {  // lane b = bucket b of the top byte
-        const uint32_t m_b = s_hist[0][lane] + s_hist[1][lane] + s_hist[2][lane] + s_hist[3][lane];
-        uint32_t m = m_b;
+    if (wave == 0u) {  // lane l = buckets [PER l, PER l + PER) of the top byte
+        uint32_t m_b[PER], m = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) {
+            m_b[q] = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < WAVES; ++w) m_b[q] += s_hist[w][PER * lane + q];
+            m += m_b[q];
+        }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) m += __shfl_xor(m, o);
         const float total = static_cast<float>(c_a);
-        const float est = m ? floorf(total * (static_cast<float>(m_b) / static_cast<float>(m)) * 0.999999f) : 0.0f;
-        const float want = fminf(est + kPoolSigmas * sqrtf(kPoolR * (est + kPoolR)), total) + static_cast<float>(kPoolRoomFloor);
-        const uint32_t room = c_a ? (static_cast<uint32_t>(want) + 3u) & ~3u : 0u;
-        uint32_t incl = room;
+        uint32_t room[PER], rooms = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) {
+            const float est = m ? floorf(total * (static_cast<float>(m_b[q]) / static_cast<float>(m)) * 0.999999f) : 0.0f;
+            const float want = fminf(est + kPoolSigmas * sqrtf(kPoolR * (est + kPoolR)), total) + static_cast<float>(kPoolRoomFloor);
+            room[q] = c_a ? (static_cast<uint32_t>(want) + 3u) & ~3u : 0u;
+            rooms += room[q];
+        }
+        uint32_t incl = rooms;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
-            if (lane >= static_cast<uint32_t>(o)) incl += t;
+            const uint32_t u = __shfl_up(incl, o);
+            if (lane >= static_cast<uint32_t>(o)) incl += u;
         }
-        const uint32_t b = a * kMsdSub + lane;
-        pool->sub_start[b] = part + incl - room;
-        pool->sub_cursor[b] = 0;  // the second pass counts from zero
-        if (a == 255u && lane == 63u) pool->sub_start[kPoolBuckets] = part + incl;
+        uint32_t at = part + incl - rooms;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) {
+            const uint32_t b = a * SUB + PER * lane + q;
+            pool->sub_start[b] = at;
+            pool->sub_cursor[b] = 0;  // the second pass counts from zero
+            at += room[q];
+        }
+        if (a == 255u && lane == 63u) pool->sub_start[256u * SUB] = at;
     }
     if (tid == 0) {
         pool->top_base[a] = top;
@@ -461,17 +485,13 @@ __global__ __launch_bounds__(256) void pool_plan_kernel(MsdPlan *__restrict__ ms
         if (a >= 248u) pool->tiles_b[a & 7u][32] = tiles_before + (c_a + kPoolTile - 1u) / kPoolTile;
     }
     if (a == 255u) {  // verdict 1 (every total is a function of the cursors: this workgroup has them all)
-        __shared__ uint32_t s_bad;
-        if (tid == 0) s_bad = 0;
-        __syncthreads();
-        uint32_t sum = c_t, space = pool_space(c_t);
+        uint32_t sum = c_t, space = pool_space<SUB>(c_t);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
             sum += __shfl_xor(sum, o);
             space += __shfl_xor(space, o);
         }
-        __syncthreads();
-        if (lane == 0u) {
+        if (lane == 0u) {  // (the sums above were read before the barrier in front of the sample's counting)
             s_red[0][wave] = sum;
             s_red[1][wave] = space;
         }
@@ -482,8 +502,12 @@ __global__ __launch_bounds__(256) void pool_plan_kernel(MsdPlan *__restrict__ ms
         }
         __syncthreads();
         if (tid == 0) {
-            const uint32_t all = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-            const uint32_t room = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+            uint32_t all = 0, room = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < WAVES; ++w) {
+                all += s_red[0][w];
+                room += s_red[1][w];
+            }
             pool->top_base[256] = all;
             // all != n: keys the first pass did not place (it did not run, or a workgroup left early); the last kPoolTile slots of the
             // slack buffer are where refused runs are dumped
@@ -493,7 +517,7 @@ __global__ __launch_bounds__(256) void pool_plan_kernel(MsdPlan *__restrict__ ms
                              : 0u;
             // (PoolPlan::fail stays: the second pass may still set it; the next sort's layout kernel re-arms it)
             msd->shift = shift;
-            msd->sub_bits = kMsdSubBits;
+            msd->sub_bits = SUBBITS;
             msd->ok = 0;  // the local sort decides
         }
     }
@@ -555,6 +579,7 @@ struct SlackReserve {
     }
 };
 
+template <uint32_t SUBBITS>
 __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
                                                              uint32_t *__restrict__ slack, const MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool,
                                                              uint32_t n_virt, uint32_t key_base, uint32_t local_cap, uint32_t dump,
@@ -570,7 +595,7 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     }
     // the claim: this sort's stamp into (list, tile)'s word -- asked for now, looked at when the tile's loads are under way
     uint32_t claimed = 0;
-    if (threadIdx.x == 0) claimed = __hip_atomic_exchange(&pool->claim_b[j * 8u + x], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) claimed = __hip_atomic_exchange(&pool->claim_b[j * 8u + x], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (L2-local: a second claim comes from this XCC too)
     const uint32_t *pt = pool->tiles_b[x];
     if (j >= pt[32]) return;
     uint32_t k = 0;  // the top byte whose tiles contain j: largest k with pt[k] <= j
@@ -584,10 +609,11 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     const uint32_t lane = threadIdx.x & 63u;
     const uint2 pc = pool->pieces[a][lane & 15u];
     const uint32_t shift = pool->shift;
-    const uint32_t d = threadIdx.x & 255u, b = a * kMsdSub + min(d, kMsdSub - 1u);
+    constexpr uint32_t SUB = 1u << SUBBITS;
+    const uint32_t d = threadIdx.x & 255u, b = a * SUB + min(d, SUB - 1u);
     SlackReserve lb;
     lb.cursor = &pool->sub_cursor[b];
-    if (threadIdx.x < kMsdSub) {  // (the threads that reserve: one per bucket of the top byte)
+    if (threadIdx.x < SUB) {  // (the threads that reserve: one per bucket of the top byte)
         lb.start = pool->sub_start[b];
         lb.cap = min(pool->sub_start[b + 1u] - lb.start, local_cap);
     }
@@ -609,16 +635,20 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     src.n_virt = n_virt;
     const uint32_t slot0 = __builtin_amdgcn_readlane(pslot, src.p0) + (tile_lo - __builtin_amdgcn_readlane(plo, src.p0));  // the tile's first key
     src.first_slot = slot0;
-    const BitsDigit dg{shift, kMsdSub - 1u, key_base};  // (key_base is a multiple of 2^24 and the 6 bits end at or below bit 24)
+    const BitsDigit dg{shift + kMsdSubBits - SUBBITS, SUB - 1u, key_base};  // (key_base is a multiple of 2^24 and the bits end at or below bit 24)
     lb.dump = dump;
-    lb.pad_keys = d == kMsdSub - 1u ? kPoolTile - valid : 0u;  // (the padding key, key_base - 1, carries the largest digit)
+    lb.pad_keys = d == SUB - 1u ? kPoolTile - valid : 0u;  // (the padding key, key_base - 1, carries the largest digit)
     lb.above = shift + kMsdBits < 32u ? ~0u << (shift + kMsdBits) : 0u;
     lb.key_base = key_base;
     lb.fail_word = &pool->fail;
     uint32_t unused = 0;
     // (two workgroups of one group of eight on ONE XCC: the tile has been taken twice and another not at all)
     if (threadIdx.x == 0 && claimed == stamp) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef VRS_LAB_ALL_PIECES
+    if (false)
+#else
     if (valid == kPoolTile && src.p1 == src.p0 + 1u)  // a full tile inside one piece: five tiles in six
+#endif
         scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve>(sm, slot0 < n_virt ? regions + slot0 : overflow + (slot0 - n_virt), nullptr, slack, nullptr, valid, dg, unused, lb);
     else if (valid == kPoolTile)
         scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve, PieceSrc>(sm, nullptr, nullptr, slack, nullptr, valid, dg, unused, lb, src);
@@ -680,25 +710,31 @@ __device__ __forceinline__ void slack_sort_bucket(const uint32_t *src, uint32_t 
 #pragma unroll
     for (int v = 0; v < WAVES; ++v) guards |= s_tmp[16 + v];
     guards = __builtin_amdgcn_readfirstlane(guards);
-    if (guards == 0u) lean_sort_body<THREADS, VEC, false, true, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false, 0u);
+    if (guards == 0u) lean_sort_body<THREADS, VEC, false, VRS_LAB_STREAM, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false, 0u);
     else slack_sort_guarded<THREADS, VEC>(src, abase, mis, n, s_keys, s_hist2, s_tmp, guards);
 }
 
-template <int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void pool_local_sort_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out,
-                                                                     MsdPlan *__restrict__ msd, const PoolPlan *__restrict__ pool,
-                                                                     uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
-                                                                     OnesweepPlanHead *host_head, uint32_t stamp) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * kLeanMaxVec + 4];
+// Shapes: THREADS x 4 MAXVEC slots -- 256 x 16 (buckets up to 4093 keys: 28 KB of LDS, five workgroups per CU), 256 x 28 (7165 keys,
+// four per CU), 512 x 28 (14333 keys, two per CU).  A workgroup lives for two memory round trips (its bucket's words, its keys) on
+// top of the sort itself -- about 3.8 us of an 11 us life at 6100 keys -- so more, smaller workgroups per CU keep the LDS pipe busier.
+template <int THREADS, int MAXVEC, int WGS, uint32_t SUBBITS>
+__global__ __launch_bounds__(THREADS, WGS *(THREADS / 64) / 4) void pool_local_sort_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out,
+                                                                                          MsdPlan *__restrict__ msd, const PoolPlan *__restrict__ pool,
+                                                                                          uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
+                                                                                          OnesweepPlanHead *host_head, uint32_t stamp) {
+    constexpr uint32_t SUB = 1u << SUBBITS, PER = SUB / 64u;
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * MAXVEC + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
     __shared__ uint32_t s_tmp[32];
     // the LAST bucket first: the second pass wrote the top bytes in ascending order, the highest are what the memory-side cache
-    // still holds (round 4: 215 -> 208 us)
-    const uint32_t b = kPoolBuckets - 1u - blockIdx.x, a = b >> kMsdSubBits, c = b & (kMsdSub - 1u);
+    // still holds (round 4: 215 -> 208 us; first bucket first measured 186-205 instead of 177-181 here)
+    const uint32_t b = 256u * SUB - 1u - blockIdx.x, a = b >> SUBBITS, c = b & (SUB - 1u);
     const uint32_t lane = threadIdx.x & 63u;
-    // The bucket's region, its top byte's start and the 64 counters of the top byte (one per lane, every wave the same 256 bytes)
-    // are asked for BEFORE the verdict is looked at (all exist whatever it says): a workgroup lives for a few memory latencies.
-    const uint32_t cnt = pool->sub_cursor[(a << kMsdSubBits) + lane];
+    // The bucket's region, its top byte's start and the counters of the top byte's buckets (PER per lane, every wave the same
+    // 256 or 512 bytes) are asked for BEFORE the verdict is looked at (all exist whatever it says): a workgroup lives for a few memory latencies.
+    uint32_t cnt[PER];
+#pragma unroll
+    for (uint32_t q = 0; q < PER; ++q) cnt[q] = pool->sub_cursor[(a << SUBBITS) + 64u * q + lane];
     const uint32_t start = pool->sub_start[b], top = pool->top_base[a];
     // Verdict 2, by every workgroup from the same two words (final when this kernel starts): verdict 1 said yes and no pass flagged
     // the sort (a region out of room, a bucket above this kernel's capacity, a key outside the probed range).  Workgroup 0 tells the host.
@@ -720,24 +756,39 @@ __global__ __launch_bounds__(THREADS, 4) void pool_local_sort_kernel(const uint3
     // the first pass's cursors, zero for the next sort (the counted form's local sort does the same: rearm_reservation)
     if (blockIdx.x < 2u * kStreams)
         for (uint32_t q = threadIdx.x; q < 256u; q += THREADS) cursors[blockIdx.x * 256u + q] = 0;
-    // keys of the top byte's buckets before this one: every wave sums the lanes below c
-    uint32_t before = lane < c ? cnt : 0u;
+    // keys of the top byte's buckets before this one (every wave sums the counters below c), and this bucket's own
+    uint32_t before = 0, n = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < PER; ++q) {
+        before += 64u * q + lane < c ? cnt[q] : 0u;
+        const uint32_t v = __builtin_amdgcn_readlane(cnt[q], c & 63u);
+        n = (c >> 6) == q ? v : n;
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o);
-    const uint32_t n = __builtin_amdgcn_readlane(cnt, c);
     const uint32_t begin = top + __builtin_amdgcn_readfirstlane(before);
     const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys_out + begin) >> 2) & 3u);
-    if (n == 0 || mis + n > THREADS * 4u * kLeanMaxVec) return;  // uniform; above the capacity cannot happen (the second pass would have flagged it)
+    if (n == 0 || mis + n > THREADS * 4u * MAXVEC) return;  // uniform; above the capacity cannot happen (the second pass would have flagged it)
     uint32_t *abase = keys_out + begin - mis;
     const uint32_t *src = slack + start;
-    switch ((mis + n + 4u * THREADS - 1u) / (4u * THREADS)) {  // rows of THREADS vectors the bucket touches where it is written
-        case 1: slack_sort_bucket<THREADS, 1>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        case 2: slack_sort_bucket<THREADS, 2>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        case 3: slack_sort_bucket<THREADS, 3>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        case 4: slack_sort_bucket<THREADS, 4>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        case 5: slack_sort_bucket<THREADS, 5>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        case 6: slack_sort_bucket<THREADS, 6>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        default: slack_sort_bucket<THREADS, 7>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+    const uint32_t rows = (mis + n + 4u * THREADS - 1u) / (4u * THREADS);  // rows of THREADS vectors the bucket touches where it is written
+    if constexpr (MAXVEC == 4) {
+        switch (rows) {
+            case 1: slack_sort_bucket<THREADS, 1>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+            case 2: slack_sort_bucket<THREADS, 2>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+            case 3: slack_sort_bucket<THREADS, 3>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+            default: slack_sort_bucket<THREADS, 4>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        }
+    } else {
+        switch (rows) {
+            case 1: slack_sort_bucket<THREADS, 1>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+            case 2: slack_sort_bucket<THREADS, 2>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+            case 3: slack_sort_bucket<THREADS, 3>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+            case 4: slack_sort_bucket<THREADS, 4>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+            case 5: slack_sort_bucket<THREADS, 5>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+            case 6: slack_sort_bucket<THREADS, 6>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+            default: slack_sort_bucket<THREADS, 7>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        }
     }
 }
 
@@ -767,11 +818,11 @@ uint32_t pool_overflow_capacity(uint32_t n) {
     return static_cast<uint32_t>(std::min<double>(room, 1u << 28)) & ~31u;
 }
 
-uint32_t pool_slack_capacity(uint32_t n) {
-    // the plan kernel gives a top byte of c keys c + 6 sqrt(64 R (c + 64 R)) + 64 (floor + 4) slots (pool_space); over 256 top bytes
-    // with sum c = n that is at most n + 6 sqrt(16384 R (n + 16384 R)) + 16384 (floor + 4) + rounding (Cauchy-Schwarz), + the dump tile
-    const double R = 40.0;
-    const double room = 6.0 * std::sqrt(16384.0 * R * (static_cast<double>(n) + 16384.0 * R)) + 16384.0 * (kPoolRoomFloor + 4.0) + 256.0 * 4.0;
+uint32_t pool_slack_capacity(uint32_t n, uint32_t sub_bits) {
+    // the plan kernel gives a top byte of c keys c + 6 sqrt(S R (c + S R)) + S (floor + 4) slots (pool_space, S = 2^sub_bits); over 256
+    // top bytes with sum c = n that is at most n + 6 sqrt(256 S R (n + 256 S R)) + 256 S (floor + 4) + rounding (Cauchy-Schwarz), + the dump tile
+    const double R = 40.0, B = 256.0 * static_cast<double>(1u << sub_bits);
+    const double room = 6.0 * std::sqrt(B * R * (static_cast<double>(n) + B * R)) + B * (kPoolRoomFloor + 4.0) + 256.0 * 4.0;
     return (static_cast<uint32_t>(std::min<double>(static_cast<double>(n) + room, 3.9e9) + 31.0) & ~31u) + kPoolTile;
 }
 
@@ -782,7 +833,23 @@ uint32_t pool_tiles_b_cap(uint32_t n) {
     return even + even / 4u + 32u + 8u;
 }
 
-uint32_t pool_local_capacity(bool big) { return (big ? 512u : 256u) * 4u * kLeanMaxVec - 3u; }
+uint32_t pool_local_capacity(uint32_t local) { return (local == 2u ? 512u : 256u) * 4u * (local == 0u ? 4u : static_cast<uint32_t>(kLeanMaxVec)) - 3u; }
+
+PoolShape pool_shape(uint32_t n, int forced_sub_bits) {
+    // the fullest of the uniform buckets: 4 to 4.5 deviations above the mean -- 5.5 and a little here
+    const auto fits = [&](uint32_t sub_bits, uint32_t local) {
+        const double mean = static_cast<double>(n) / (256u << sub_bits);
+        return static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u <= pool_local_capacity(local);
+    };
+    PoolShape sh{};
+    // Six bits as long as the 16384 buckets fit a 256-thread workgroup; beyond (about 1.1e8 uniform keys) seven bits keep them there
+    // (2e8 keys: 1.05 instead of 1.08 ms with the 512-thread shape).  Smaller buckets are NOT better: a workgroup's fixed work -- five
+    // counter tables to zero and scan, two memory round trips -- is a third of its life at 3000 keys (10^8 keys by seven bits: the
+    // local sort 205 instead of 176 us, with five workgroups per CU), a sixth at 6100.
+    sh.sub_bits = forced_sub_bits == 6 || forced_sub_bits == 7 ? static_cast<uint32_t>(forced_sub_bits) : (fits(6, 1) ? 6u : 7u);
+    sh.local = fits(sh.sub_bits, 0) ? 0u : fits(sh.sub_bits, 1) ? 1u : 2u;
+    return sh;
+}
 
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
                               PoolPlan *pool, uint32_t overflow_capacity, LaunchEvents ev) {
@@ -802,31 +869,45 @@ hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint3
 }
 
 hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap, uint32_t slack_capacity,
-                            const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps) {
+                            const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps, uint32_t sub_bits) {
     if (ps.tiles_per_stream > kPoolMaxTilesA || tiles_b_cap > kPoolMaxTilesB) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pool_plan_kernel, dim3(256), dim3(256), 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps);
+    if (sub_bits == 7u)
+        hipLaunchKernelGGL(pool_plan_kernel<7>, dim3(256), dim3(512), 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps);
+    else
+        hipLaunchKernelGGL(pool_plan_kernel<6>, dim3(256), dim3(512), 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps);
     return hipGetLastError();
 }
 
 hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *slack, uint32_t n, MsdPlan *msd,
                               PoolPlan *pool, uint32_t tiles_b, uint32_t key_base, uint32_t local_cap, uint32_t slack_capacity,
-                              unsigned long long xcc_map, uint32_t stamp, LaunchEvents ev) {
+                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, LaunchEvents ev) {
     if (tiles_b == 0) return hipSuccess;
     if (tiles_b > kPoolMaxTilesB || stamp == 0u) return hipErrorInvalidValue;
-    VRS_LAUNCH(pool_pass_b_kernel, dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n, key_base, local_cap,
-               slack_capacity - kPoolTile, xcc_map, stamp);
+    if (sub_bits == 7u)
+        VRS_LAUNCH(pool_pass_b_kernel<7>, dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n, key_base, local_cap,
+                   slack_capacity - kPoolTile, xcc_map, stamp);
+    else
+        VRS_LAUNCH(pool_pass_b_kernel<6>, dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n, key_base, local_cap,
+                   slack_capacity - kPoolTile, xcc_map, stamp);
     return hipGetLastError();
 }
 
 hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
-                                  bool big, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev) {
+                                  PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev) {
     (void)n;
-    if (big)
-        VRS_LAUNCH(pool_local_sort_kernel<512>, dim3(kMsdBucketCount), dim3(512), stream, ev, slack, keys_out, msd, pool, &msd->cursor_a[0][0], dev_head,
-                   host_head, stamp);
-    else
-        VRS_LAUNCH(pool_local_sort_kernel<256>, dim3(kMsdBucketCount), dim3(256), stream, ev, slack, keys_out, msd, pool, &msd->cursor_a[0][0], dev_head,
-                   host_head, stamp);
+    uint32_t *cursors = &msd->cursor_a[0][0];
+#define VRS_POOL_LOCAL(T, V, W, S)                                                                                                            \
+    VRS_LAUNCH((pool_local_sort_kernel<T, V, W, S>), dim3(256u << S), dim3(T), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head, stamp)
+    if (shape.sub_bits == 7u) {
+        if (shape.local == 0u) VRS_POOL_LOCAL(256, 4, 5, 7);
+        else if (shape.local == 1u) VRS_POOL_LOCAL(256, 7, 4, 7);
+        else VRS_POOL_LOCAL(512, 7, 2, 7);
+    } else {
+        if (shape.local == 0u) VRS_POOL_LOCAL(256, 4, 5, 6);
+        else if (shape.local == 1u) VRS_POOL_LOCAL(256, 7, 4, 6);
+        else VRS_POOL_LOCAL(512, 7, 2, 6);
+    }
+#undef VRS_POOL_LOCAL
     return hipGetLastError();
 }
 
