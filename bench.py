@@ -33,9 +33,34 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s
 BYTES_PER_KEY_SORT = 48  # 4 passes x (histogram read 4 + scatter read 4 + scatter write 4)   SURVEY.md section 8d
 BYTES_PER_KEY_SORT_ONE_READ = 36  # one counting read 4 + 4 passes x (scatter read 4 + scatter write 4): SURVEY.md section 8d's rule
 BYTES_PER_KEY_SORT_HYBRID = 28  # one counting read 4 + 2 MSD scatter passes x 8 + the LDS-local bucket sort (read 4 + write 4)
-BYTES_PER_KEY_SORT_POOL = 24  # the hybrid form without the counting read (vrs_msd_pool.hip): 2 MSD passes x 8 + the gathering local sort 8
+BYTES_PER_KEY_SORT_POOL = 24  # the hybrid form without the counting read (vrs_msd_pool.hip): 2 MSD passes x 8 + the local sort 8
 #                               (+ 0.125: the sample reads 1/32 of the keys -- not counted, like the table traffic of the other forms)
-BYTES_PER_KEY_SCATTER = 8  # the dominant kernel of either path, per launch: read 4 + write 4
+BYTES_PER_KEY_SCATTER = 8  # a scatter pass, per launch: read 4 + write 4
+# algorithmic bytes per key and launch of every byte-moving kernel (the library's profile names, vkradixsort_amd/capi.py KERNEL_NAMES)
+KERNEL_BYTES_PER_KEY = {"histogram": 4, "scatter": 8, "digit_tables": 4, "lookback_scatter": 8, "local_sort": 8, "pool_pass_a": 8, "pool_pass_b": 8}
+KERNEL_WHAT = {
+    "histogram": "histogram_kernel: the contract's RADIX_SORT_HISTOGRAMS stage, reads every key once per pass",
+    "scatter": "scatter_kernel: the contract's stable scatter, reads and writes every key once per pass",
+    "digit_tables": "digit_tables_kernel: the one counting read of the counted one-call forms",
+    "lookback_scatter": "onesweep_scatter_kernel / msd_pass_b_kernel: a scatter pass of the one-call sort's counted forms, reads and writes every key once",
+    "local_sort": "the LDS-local sort of every bucket (pool form: pool_local_sort_kernel; counted form: msd_local_sort_keys_kernel), reads and writes every key once -- LDS-bound",
+    "pool_pass_a": "pool_pass_a_kernel: the pool form's first MSD pass (reserves in sampled regions), reads and writes every key once",
+    "pool_pass_b": "pool_pass_b_kernel: the pool form's second MSD pass (scatters into the buckets' slack regions), reads and writes every key once",
+}
+
+
+def pick_dominant(kernels: dict) -> str | None:
+    """The dominant kernel of a timed path, BY KERNEL NAME: the byte-moving kernel with the largest share of the instrumented
+    time -- launches x average launch duration (kernels: name -> {"launches", "avg_us"} of one instrumented run).  Ties go
+    to the kernel that moves more bytes per launch, then to the name.  None if nothing byte-moving was timed."""
+    best, best_key = None, None
+    for name, rec in kernels.items():
+        if name not in KERNEL_BYTES_PER_KEY or not rec.get("avg_us") or not rec.get("launches"):
+            continue
+        key = (rec["launches"] * rec["avg_us"], KERNEL_BYTES_PER_KEY[name], name)
+        if best_key is None or key > best_key:
+            best, best_key = name, key
+    return best
 
 
 def mt19937_keys(seed: int, n: int) -> np.ndarray:
@@ -166,9 +191,12 @@ def bench_single(args):
         return h.value
 
     one_call = args.path == "one_call"
-    paths = {"one_call": (sort_one_call, capi.VRS_KERNEL_LOOKBACK_SCATTER, "lookback_scatter"),
-             "contract": (sort_batch, capi.VRS_KERNEL_SCATTER, "scatter")}
-    primary, dominant_id, dominant_name = paths[args.path]
+    # (function, the byte-moving kernels of the path: their launches carry events in the sampled steps of the timed region)
+    name_to_id = {v: k for k, v in capi.KERNEL_NAMES.items()}
+    paths = {"one_call": (sort_one_call, ["digit_tables", "lookback_scatter", "local_sort", "pool_pass_a", "pool_pass_b"]),
+             "contract": (sort_batch, ["histogram", "scatter"])}
+    primary, timed_names = paths[args.path]
+    timed_mask = sum(1 << name_to_id[x] for x in timed_names)
 
     def kernel_table():
         t = {}
@@ -198,10 +226,12 @@ def bench_single(args):
     run_steps(primary, W, 0)
     rearm()
 
-    # ---- timed region: exactly K steps, inputs resident.  The dominant kernel's launches of every 4th step carry HIP events
-    # on their own dispatch packets, on the stream they are launched on; nothing else is instrumented.
+    # ---- timed region: exactly K steps, inputs resident.  The byte-moving kernels' launches of every 4th step carry HIP events
+    # on their own dispatch packets, on the stream they are launched on; nothing else is instrumented.  The DOMINANT kernel is
+    # the one of them with the largest share of that time, by kernel name (pick_dominant).
     hybrid_before, recounts_before, pool_before = hybrid_sorts(), hybrid_recounts(), pool_sorts()
-    elapsed, kernels = run_steps(primary, K, 1 << dominant_id, every=args.event_every)
+    elapsed, kernels = run_steps(primary, K, timed_mask, every=args.event_every)
+    dominant_name = pick_dominant(kernels)
     hybrid_steps = hybrid_sorts() - hybrid_before  # K if every timed one-call sort took a hybrid form (pool or counted), 0 if none did
     recount_steps = hybrid_recounts() - recounts_before
     pool_after = pool_sorts()
@@ -249,7 +279,7 @@ def bench_single(args):
 
     # ---- the other path over the same batches, reported beside the headline (never as `value`)
     other_name = "contract" if one_call else "one_call"
-    other_fn, other_dom_id, other_dom_name = paths[other_name]
+    other_fn, _other_names = paths[other_name]
     rearm()
     run_steps(other_fn, 1, 0)
     rearm()
@@ -304,11 +334,14 @@ def bench_single(args):
                           else BYTES_PER_KEY_SORT_ONE_READ,
                           "contract": BYTES_PER_KEY_SORT}
     dom_us = kernels.get(dominant_name, {}).get("avg_us")
-    traffic, traffic_detail = load_traffic_profile(dominant_name, BYTES_PER_KEY_SCATTER * n) if n == 10 ** 8 else (None, {"note": "committed for N = 10^8 only"})
-    achieved = (BYTES_PER_KEY_SCATTER * n / (dom_us * 1e-6) / 1e9) if dom_us else None
+    dom_bytes = KERNEL_BYTES_PER_KEY.get(dominant_name, BYTES_PER_KEY_SCATTER) * n
+    traffic, traffic_detail = load_traffic_profile(dominant_name, dom_bytes) if n == 10 ** 8 else (None, {"note": "committed for N = 10^8 only"})
+    achieved = (dom_bytes / (dom_us * 1e-6) / 1e9) if dom_us else None
     value = n * K / elapsed / 1e9
     sort_bytes = bytes_per_key_sort[args.path] * n
+    other_dom_name = pick_dominant(other_breakdown)
     other_dom_us = other_breakdown.get(other_dom_name, {}).get("avg_us")
+    shares = {x: round(r["launches"] * r["avg_us"], 1) for x, r in kernels.items() if x in KERNEL_BYTES_PER_KEY}
     result = {
         "metric": "Gkeys/s sorting 10^8 uint32 at 1/2/4/8 MI355X; % of HBM roofline",
         "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": 1, "steps": K, "warmup": W,
@@ -324,9 +357,9 @@ def bench_single(args):
         "config": {"workload": f"BASELINE.json configs[{ {10 ** 7: 1, 10 ** 8: 2}.get(n, 2) }]: {n} uniform random uint32 keys (std::mt19937 seeds 1,2,3), "
                                f"multi_radixsort, 1xMI355X, keys resident in HBM",
                    "path": ("vrs_sort_keys_u32, pool form -- the hybrid form without a counting read: a sample of 1/32 of the keys sizes a region "
-                            "per (input slice, top byte); the first MSD pass (8 bits) reserves its output there, the second (6 bits) groups every "
-                            "tile in place, the local sort gathers every bucket's runs, sorts them by their low 18 bits inside LDS and writes them to "
-                            "their final place (24 B/key)") if pool else
+                            "per (input slice, top byte); the first MSD pass (8 bits) reserves its output there, the second (6 bits; 7 beyond 1.1e8 keys) "
+                            "scatters into per-bucket regions of a context-owned slack buffer, the local sort reads every bucket in one piece, sorts "
+                            "it by its low 18 bits inside LDS and writes it to its final place (24 B/key)") if pool else
                            (("vrs_sort_keys_u32, hybrid form: one counting read of the keys, an MSD partition by the top 14 bits in "
                              "two stable scatter passes with decoupled look-back (8 + 6 bits), then every bucket sorted by its "
                              "low 18 bits inside one workgroup's LDS (28 B/key); " + str(recount_steps) + " of the timed sorts "
@@ -339,14 +372,12 @@ def bench_single(args):
                    "passes": "2 MSD scatter passes + 1 LDS-local sort pass" if hybrid else 4,
                    "rank_mode": {1: "ballot", 2: "lds_atomic"}[gpu.lib.vrs_rank_mode(gpu.handle)], "device": dev_name,
                    "compute_units": cus},
-        "roofline": {"bound": "hbm", "kernel": f"{dominant_name} (one launch per scatter pass: reads and writes every key once"
-                                               + ("; two launches per sort in the pool form -- pool_pass_a_kernel (reserves in sampled regions) and "
-                                                  "pool_pass_b_kernel (groups every tile in place) -- about half of the step" if pool else
-                                                  "; two launches per sort in the hybrid form -- onesweep_scatter_kernel and msd_pass_b_kernel, whose tiles take their "
-                                                  "places by reservation (bare keys; payloads: decoupled look-back) -- 47 % of the step" if hybrid else "") + ")",
+        "roofline": {"bound": "hbm", "kernel": dominant_name, "kernel_is": KERNEL_WHAT.get(dominant_name),
+                     "chosen_by": "largest launches x average launch time among the byte-moving kernels whose launches carried events in the timed region",
+                     "instrumented_us_by_kernel": shares,
                      "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                     "algorithmic_bytes_per_launch": BYTES_PER_KEY_SCATTER * n, "avg_launch_us": dom_us,
+                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us,
                      "traffic": traffic, "traffic_detail": traffic_detail,
                      "traffic_source": f"profiles/{dominant_name}_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                        "this command at N = 10^8 in an earlier run (counters cannot be read from inside this run)",
@@ -357,11 +388,11 @@ def bench_single(args):
                           "achieved_GBps": round(sort_bytes * K / elapsed / 1e9, 1),
                           "frac_of_peak": round(sort_bytes * K / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
         "kernels_timed_region": kernels,
-        "kernels_timed_region_note": f"HIP events on the dominant kernel's launches of every {args.event_every}th step of the timed region",
+        "kernels_timed_region_note": f"HIP events on the byte-moving kernels' launches of every {args.event_every}th step of the timed region",
         "kernels_all_instrumented_rerun": breakdown,
         "roofline_by_kernel": {name: {"algorithmic_bytes_per_launch": bpk * n, "avg_launch_us": breakdown[name]["avg_us"],
                                       "frac": round(bpk * n / (breakdown[name]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-                               for name, bpk in (("histogram", 4), ("scatter", 8), ("digit_tables", 4), ("lookback_scatter", 8), ("local_sort", 8))
+                               for name, bpk in KERNEL_BYTES_PER_KEY.items()
                                if name in breakdown and breakdown[name]["avg_us"]},
         "roofline_by_kernel_note": "every byte-moving kernel of the timed path, from the all-kernels-instrumented rerun (launches carry events: "
                                    "a few per cent slower than in the timed region); local_sort is LDS-bound, the others HBM-bound",
@@ -371,7 +402,7 @@ def bench_single(args):
             "bytes_per_key": bytes_per_key_sort[other_name],
             "frac_of_peak": round(bytes_per_key_sort[other_name] * n * K / other_elapsed / 1e9 / HBM_PEAK_GBS, 4),
             "dominant_kernel": {"name": other_dom_name, "avg_us": other_dom_us,
-                                "frac": round(BYTES_PER_KEY_SCATTER * n / (other_dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                                "frac": round(KERNEL_BYTES_PER_KEY[other_dom_name] * n / (other_dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                                 if other_dom_us else None},
             "kernels": other_breakdown, "note": "same batches, uninstrumented timing; not the headline"},
         "verified": dict(check, timed_region_every_batch_ascending_and_permutation_of_its_input=True,

@@ -210,6 +210,27 @@ def test_pool_form_enqueue_only(pool_ctx, oracle):
         assert (took, refused) == ((1, 0) if dist == "uniform" else (0, 1))
 
 
+def test_releasing_a_buffer_of_a_pending_sort_settles_the_sort_first(pool_ctx, oracle):
+    """An enqueue-only sort whose first half was refused still owes a whole counted sort -- over the raw pointers of its two
+    buffers.  vrs_buffer_release of one of them (callers written against the blocking form release keys_tmp right after the
+    call) must run that second half before the memory goes, not hand it freed memory."""
+    pool_ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)
+    for dist in ("tile_period", "24bit", "uniform"):
+        n = 7000003
+        keys = pool_keys(n, dist, seed=13)
+        k0 = vrs.Buffer.fillDeviceWithStagingBuffer(pool_ctx, S(4 * n), keys)
+        k1 = vrs.Buffer(pool_ctx, S(4 * n))
+        pool_ctx.check(pool_ctx.lib.vrs_sort_keys_u32(pool_ctx.handle, k0.handle, k1.handle, n))
+        k1.release()  # the sort may not have settled yet
+        filler = vrs.Buffer(pool_ctx, S(4 * n))  # (likely the memory k1 just gave back)
+        filler.copyFrom(k0) if dist == "never" else None
+        out = np.empty(n, np.uint32)
+        k0.downloadWithStagingBuffer(out)
+        assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1, dist
+        k0.release()
+        filler.release()
+
+
 def test_pool_form_of_a_ranged_sort(pool_ctx, oracle):
     """vrs_sort_keys_u32_ranged: buckets and digits are taken from key - floor; a key below the promised floor refuses"""
     n = 10000007

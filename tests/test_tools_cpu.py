@@ -61,3 +61,26 @@ def test_bench_refuses_a_traffic_figure_that_is_no_pass_over_the_keys(tmp_path, 
     assert value == 8.19e8 and [q["ratio_to_algorithmic"] for q in detail["passes"]] == [1.024, 1.008]
     value, detail = bench.load_traffic_profile("absent_kernel", 8.0e8)
     assert value is None and "absent" in detail["note"]
+
+
+def test_bench_names_the_dominant_kernel_by_its_share_of_the_time():
+    """bench.py's `roofline` block is about the byte-moving kernel with the largest launches x average-launch-time of the
+    instrumented steps, by kernel NAME (round 4's line averaged two different scatter kernels under one id and called the
+    pair dominant while the local sort was the longer kernel)."""
+    bench = _load(ROOT / "bench.py", "bench_under_test_dominant")
+    # the pool form at 10^8 keys, three sampled steps: the local sort is the longest kernel
+    pool = {"pool_sample": {"launches": 3, "avg_us": 9.0}, "pool_pass_a": {"launches": 3, "avg_us": 155.0},
+            "pool_pass_b": {"launches": 3, "avg_us": 152.0}, "local_sort": {"launches": 3, "avg_us": 171.0}}
+    assert bench.pick_dominant(pool) == "local_sort"
+    # the counted form: two launches of one kernel name per sort outweigh the local sort
+    counted = {"digit_tables": {"launches": 3, "avg_us": 98.0}, "lookback_scatter": {"launches": 6, "avg_us": 150.0},
+               "local_sort": {"launches": 3, "avg_us": 161.0}}
+    assert bench.pick_dominant(counted) == "lookback_scatter"
+    # the contract path: four scatter launches of 136 us against four histogram launches of 70
+    contract = {"histogram": {"launches": 12, "avg_us": 70.0}, "prefix": {"launches": 24, "avg_us": 7.0}, "scatter": {"launches": 12, "avg_us": 136.0}}
+    assert bench.pick_dominant(contract) == "scatter"
+    # kernels that move no keys never qualify; a tie goes to the kernel with more bytes per launch
+    assert bench.pick_dominant({"prefix": {"launches": 9, "avg_us": 999.0}, "pool_sample": {"launches": 1, "avg_us": 9999.0}}) is None
+    assert bench.pick_dominant({"histogram": {"launches": 2, "avg_us": 100.0}, "scatter": {"launches": 2, "avg_us": 100.0}}) == "scatter"
+    assert bench.pick_dominant({}) is None
+    assert set(bench.KERNEL_BYTES_PER_KEY) <= set(bench.KERNEL_WHAT)

@@ -61,12 +61,21 @@ def dominant_records(rows, pairs=False):
     rec = pick_dominant(rows, lambda k: "scatter_kernel" in k and "onesweep" not in k)
     if rec:
         files["scatter_traffic.json"] = {"kernel": "scatter_kernel", "source": src, "correction": corr, **rec}
-    first = pick_dominant(rows, lambda k: "onesweep_scatter_kernel" in k or "pool_pass_a_kernel" in k)
-    second = pick_dominant(rows, lambda k: "msd_pass_b_kernel" in k or "pool_pass_b_kernel" in k)
+    first = pick_dominant(rows, lambda k: "onesweep_scatter_kernel" in k)
+    second = pick_dominant(rows, lambda k: "msd_pass_b_kernel" in k)
     if first:
         name = "lookback_scatter_pairs_traffic.json" if pairs else "lookback_scatter_traffic.json"
-        files[name] = {"kernel": "the MSD / look-back scatter passes of the one-call sort", "source": src, "correction": corr, **first,
+        files[name] = {"kernel": "the MSD / look-back scatter passes of the one-call sort's counted forms", "source": src, "correction": corr, **first,
                        "passes": [r for r in (first, second) if r]}
+    # one file per profile name of bench.py (KERNEL_BYTES_PER_KEY): whichever its `roofline` block names finds its traffic
+    for fname, what, match in (("local_sort_traffic.json", "the LDS-local sort of every bucket", lambda k: "local_sort" in k),
+                               ("pool_pass_a_traffic.json", "pool_pass_a_kernel", lambda k: "pool_pass_a_kernel" in k),
+                               ("pool_pass_b_traffic.json", "pool_pass_b_kernel", lambda k: "pool_pass_b_kernel" in k),
+                               ("histogram_traffic.json", "histogram_kernel", lambda k: "histogram_kernel" in k),
+                               ("digit_tables_traffic.json", "digit_tables_kernel", lambda k: "digit_tables_kernel" in k)):
+        rec = pick_dominant(rows, match)
+        if rec and not pairs:
+            files[fname] = {"kernel": what, "source": src, "correction": corr, **rec}
     return files
 
 

@@ -18,7 +18,7 @@ INCLUDE = REPO_ROOT / "include"
 LIB_PATH = PKG_DIR / "libvkradixsort_amd.so"
 
 HIP_SOURCES = [CSRC / "vrs_contract.hip", CSRC / "vrs_one_call.hip", CSRC / "vrs_msd_hybrid.hip", CSRC / "vrs_msd_pool.hip", CSRC / "vrs_capi.hip", CSRC / "vrs_dist.hip"]
-HIP_HEADERS = [CSRC / "vrs_kernels.h", CSRC / "vrs_device.hpp", CSRC / "vrs_local_sort.hpp", INCLUDE / "vkradixsort_amd.h"]
+HIP_HEADERS = sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.hpp")) + [INCLUDE / "vkradixsort_amd.h"]  # every object is rebuilt when any header is newer
 ARCH = "gfx950"
 
 

@@ -15,7 +15,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <new>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -101,6 +103,7 @@ struct vrs_context_t {
     // pool form (vrs_msd_pool.hip): the hybrid form of bare uint32 keys without the counting read
     int os_pool = 1;                     // VRS_TUNE_MSD_POOL: 0 never, 1 (default) adaptive -- after a refusal the next 15 such sorts take the counted form --, 2 always tried
     uint32_t os_pool_skip = 0;           // adaptive: hybrid-capable sorts of bare keys left before the pool form is tried again
+    uint32_t os_pool_skip_n = 0;         //   keys of the sort whose refusal started the count: a sort of another size class (beyond a factor of two) is another workload and starts afresh
     vrs::PoolPlan *os_pool_plan = nullptr;
     uint32_t *os_pool_overflow = nullptr;  // overflow regions of the first pass
     uint32_t os_pool_overflow_cap = 0;     //   keys they hold
@@ -148,6 +151,10 @@ namespace {
 constexpr uint32_t launch_tile_blocks(int key_bytes) { return key_bytes == 8 ? 16u : 32u; }
 
 thread_local std::string g_global_error;
+// Contexts that are alive (vrs_context_create* ... vrs_context_destroy): a buffer may outlive its context (host-language finalisers
+// run in any order), so vrs_buffer_release asks here before it touches buf->ctx.
+std::mutex g_live_mutex;
+std::set<vrs_context> g_live_contexts;
 
 // second half of a pending async one-call sort (vrs_capi.hip, "one_read_settle"); every entry point that puts work on the
 // stream or waits for it calls this first
@@ -339,6 +346,10 @@ int create_context(int device_ordinal, hipStream_t borrowed, bool borrow, vrs_co
         (void)probe_xcc_map(ctx);
         ctx->last_error.clear();
     }
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        g_live_contexts.insert(ctx);
+    }
     *out_ctx = ctx;
     return VRS_OK;
 }
@@ -444,6 +455,10 @@ int vrs_context_create_on_stream(int device_ordinal, void *hip_stream, vrs_conte
 
 int vrs_context_destroy(vrs_context ctx) {
     if (!ctx) return VRS_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        g_live_contexts.erase(ctx);
+    }
     (void)hipSetDevice(ctx->device);
     (void)settle_pending(ctx);
     (void)hipStreamSynchronize(ctx->stream);
@@ -527,8 +542,30 @@ int vrs_buffer_release(vrs_buffer buf) {
     if (!buf) return VRS_OK;
     int rc = VRS_OK;
     if (buf->ptr && buf->owned) {
-        // the owning context may already be gone (host-language finalisers run in any order): touch only the buffer
+        // the owning context may already be gone (host-language finalisers run in any order): touch it only if it is alive
         (void)hipSetDevice(buf->device);
+        {
+            // An enqueue-only sort (the default on a context with its own stream) may still owe its second half, which works on
+            // the raw pointers of its four buffers: freeing one of them first would hand that half freed memory.  Settle it, and
+            // let what is on the stream finish with the buffer, before the memory goes.  (hipFree waits for the device, but a
+            // second half enqueued AFTER it would not be waited for.)
+            bool alive;
+            {
+                std::lock_guard<std::mutex> lock(g_live_mutex);
+                alive = g_live_contexts.count(buf->ctx) != 0;
+            }
+            if (alive && buf->ctx->one_read.active) {
+                const vrs_context_t::OneRead &st = buf->ctx->one_read;
+                const char *lo = static_cast<const char *>(buf->ptr), *hi = lo + buf->size;
+                bool used = false;
+                for (const void *q : {st.kptr[0], st.kptr[1], st.vptr[0], st.vptr[1]})
+                    used = used || (q != nullptr && static_cast<const char *>(q) >= lo && static_cast<const char *>(q) < hi);
+                if (used) {
+                    const int settled = settle_pending(buf->ctx);
+                    if (settled) rc = settled;
+                }
+            }
+        }
         hipError_t e = hipFree(buf->ptr);
         if (e != hipSuccess) rc = fail_hip(nullptr, "hipFree", e);
     }
@@ -1026,6 +1063,7 @@ static int one_read_enqueue(vrs_context ctx) {
         // refusal is certain; and below 3.2e7 keys the counted form's one-wave-per-bucket local sort is the faster one)
         const bool candidate = st.msd_capable && !pairs && !wide && !st.no_pool && ctx->os_pool != 0 && reserves(ctx, n, false) &&
                                n >= ctx->os_pool_min_keys && n <= vrs::kPoolMaxKeys;
+        if (candidate && ctx->os_pool_skip && (n / 2u > ctx->os_pool_skip_n || n < ctx->os_pool_skip_n / 2u)) ctx->os_pool_skip = 0;
         st.pool = candidate && (ctx->os_pool == 2 || ctx->os_pool_skip == 0);
         if (candidate && !st.pool) --ctx->os_pool_skip;
     }
@@ -1208,7 +1246,10 @@ static int one_read_complete(vrs_context ctx, bool *done) {
         if (timed_ls) ctx->events_used[VRS_KERNEL_LOCAL_SORT] = st.ev_ls_before;
         ctx->os_cursors_open = true;
         ctx->os_pool_refusals++;
-        if (ctx->os_pool == 1) ctx->os_pool_skip = 15;
+        if (ctx->os_pool == 1) {
+            ctx->os_pool_skip = 15;
+            ctx->os_pool_skip_n = n;
+        }
         st.no_pool = true;
         st.pool = false;
         st.group = 0;

@@ -1025,6 +1025,9 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
     std::vector<uint32_t> ticket(static_cast<size_t>(R), 0u);
     for (int r = 0; r < R; ++r) {
         const uint64_t cnt = round_off[static_cast<size_t>(r) + 1] - round_off[static_cast<size_t>(r)];
+        // (an enqueue-only sort of the round before may still owe its second half: that goes on the stream BEFORE the wait for this
+        // round's keys, or it would be ordered behind the exchange it was meant to overlap)
+        if ((rc = vrs_sort_settle(ctx))) return dfail_ctx(d, rc, "vrs_sort_settle (the round before)");
         VRS_DHIP(d, hipStreamWaitEvent(d->sort_stream, d->round_done[static_cast<size_t>(r)], 0));
         if (!cnt) continue;
         if (by_top_byte && cnt >= (1u << 16)) {
