@@ -433,6 +433,13 @@ int vrs_one_call_hybrid_recounts(vrs_context ctx, uint64_t *recounts);
 /* One-call sorts of bare uint32 keys that took the pool form (the hybrid form without a counting read, VRS_TUNE_MSD_POOL), and
  * sorts whose pool form the plan refused (they ran in the counted form afterwards).  Cumulative; diagnostics only. */
 int vrs_one_call_pool_sorts(vrs_context ctx, uint64_t *pool_sorts, uint64_t *pool_refusals);
+/* The forms of the one-call sorts that share L2-resident words between workgroups rest on where the blocks of a launch run
+   ("block b on the XCC of place b % 8 of the probed order"), which the context probes when it is created.  Observed on MI355X: the
+   dispatcher's round-robin starts at an XCC of the hardware queue's own, and a HIP stream may move to another queue -- the probed
+   order is then rotated.  Every kernel checks (HW_REG_XCC_ID) and stays exact; the first workgroups that find themselves elsewhere
+   say so, and the next vrs_sort_* call probes again.  *reprobes = how often that happened; *xcc_map = the probed order (byte x =
+   the XCC of the blocks with index % 8 == x); *valid = the probe found the b % 8 rule intact.  Any pointer may be NULL. */
+int vrs_debug_xcc_placement(vrs_context ctx, uint64_t *reprobes, uint64_t *xcc_map, int *valid);
 
 /* Ranking method in effect: 1 = __ballot match-any, 2 = returning LDS atomics. */
 int vrs_rank_mode(vrs_context ctx);

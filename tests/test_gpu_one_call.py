@@ -252,6 +252,47 @@ def test_look_back_does_not_depend_on_xcd_placement(gpu_context):
     assert np.array_equal(out, np.sort(keys))
 
 
+def xcc_placement(ctx):
+    r, m, v = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
+    ctx.check(ctx.lib.vrs_debug_xcc_placement(ctx.handle, ctypes.byref(r), ctypes.byref(m), ctypes.byref(v)))
+    return r.value, m.value, v.value
+
+
+@pytest.mark.parametrize("rotate", [1, 5])
+def test_sorts_that_find_the_placement_rotated_have_it_probed_again(rotate):
+    """The round-robin of a launch's blocks over the XCCs starts at an XCC of the hardware queue's own, and a stream may move to
+    another queue after the context probed (round 5 saw it happen between two tests).  The look-back streams and the counted form's
+    reservations then take their placement-independent routes -- exact -- and their first workgroups report it; the next sort call
+    probes again: ONE sort on the slow routes, not all of them.  Test hook: the probed order rotated."""
+    with vrs.GPUContext(0) as gpu:
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL, 0)  # (the pool form takes its lists by the XCC a workgroup runs on: nothing to report)
+        n = 3000017
+        keys = make_keys(n, "uniform", seed=rotate)
+        out, _ = sort_keys(gpu, keys)  # (makes the one-call scratch, and with it the word the reports go to)
+        assert np.array_equal(out, np.sort(keys))
+        reprobes0, good_map, valid = xcc_placement(gpu)
+        assert valid == 1
+        gpu.setTuning(capi.VRS_TUNE_DEBUG_XCC_ROTATE, rotate)
+        assert xcc_placement(gpu)[1] != good_map
+        out, _ = sort_keys(gpu, keys)  # every tile off its stream's XCC: exact all the same
+        assert np.array_equal(out, np.sort(keys))
+        assert xcc_placement(gpu)[0] == reprobes0  # nobody has looked yet
+        out, _ = sort_keys(gpu, keys)  # this call looks first
+        assert np.array_equal(out, np.sort(keys))
+        reprobes, now_map, valid = xcc_placement(gpu)
+        assert reprobes == reprobes0 + 1 and now_map == good_map and valid == 1
+        out, _ = sort_keys(gpu, keys)  # ... and nothing more to report
+        assert np.array_equal(out, np.sort(keys)) and xcc_placement(gpu)[0] == reprobes
+        # the counted hybrid form (reserving MSD passes) reports the same way
+        gpu.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)
+        big = make_keys(6000011, "uniform", seed=7)
+        gpu.setTuning(capi.VRS_TUNE_DEBUG_XCC_ROTATE, rotate)
+        for _ in range(2):
+            out, stats = sort_keys(gpu, big)
+            assert np.array_equal(out, np.sort(big)) and stats["local_sort"] == 1
+        assert xcc_placement(gpu)[0] == reprobes + 1 and xcc_placement(gpu)[1] == good_map
+
+
 @pytest.mark.parametrize("stray", [9, 4095])
 def test_a_placement_that_holds_for_most_blocks_only_switches_the_l2_local_forms_off(stray):
     """The look-back streams, the reservation cursors and the pool form's regions share L2-resident words between the workgroups of

@@ -75,6 +75,8 @@ struct vrs_context_t {
     uint32_t os_spin_budget = 4096;      // polls of an unpublished look-back row before a tile recounts, VRS_TUNE_LOOKBACK_SPIN_BUDGET
     int os_hold_tile = -1;               // test hook, VRS_TUNE_DEBUG_HOLD_TILE
     bool os_misplace = false;            // test hook, VRS_TUNE_DEBUG_MISPLACE_STREAMS
+    uint32_t drift_seen = 0;             // OnesweepPlanHead::drift (host copy) as of the last probe
+    uint64_t reprobes = 0;               // probes run because sorts reported workgroups off the probed placement
     bool xcc_map_valid = false;          // the probe found block b on an XCC that depends on b % 8 only
     unsigned long long xcc_map = 0;      // byte x = that XCC for b % 8 == x
     uint64_t os_lookback_passes = 0;
@@ -298,6 +300,25 @@ int probe_xcc_map(vrs_context ctx, int stray_block = -1) {
     }
     ctx->xcc_map = map;
     ctx->xcc_map_valid = valid;
+    return VRS_OK;
+}
+
+// the word of the pinned host head the look-back / reserving kernels report placement drift in (device view), once it exists
+static uint32_t *drift_word(vrs_context ctx) { return ctx->os_host_head_dev ? &ctx->os_host_head_dev->drift : nullptr; }
+// Before a one-call sort is enqueued: did workgroups of earlier sorts find themselves on other XCCs than the probe said (the stream
+// moved to another hardware queue, whose round-robin starts elsewhere)?  Then the probe is run again -- once; the sorts in between
+// were exact, on their placement-independent routes.
+static int reprobe_if_drifted(vrs_context ctx) {
+    if (!ctx->os_host_head) return VRS_OK;
+    const uint32_t now = __atomic_load_n(&ctx->os_host_head->drift, __ATOMIC_RELAXED);
+    if (now == ctx->drift_seen) return VRS_OK;
+    VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (late reports of what is still running belong to the old placement too)
+    const bool was_valid = ctx->xcc_map_valid;
+    const int rc = probe_xcc_map(ctx);
+    if (rc) return rc;
+    if (!was_valid) ctx->xcc_map_valid = false;  // (a placement that was found broken stays distrusted: only the order is refreshed)
+    ctx->drift_seen = __atomic_load_n(&ctx->os_host_head->drift, __ATOMIC_RELAXED);
+    ctx->reprobes++;
     return VRS_OK;
 }
 
@@ -958,7 +979,7 @@ static int one_read_lookback_pass(vrs_context ctx, vrs_context_t::OneRead &st, u
     if (r) return r;
     VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, kin, kout, static_cast<const uint32_t *>(vin), static_cast<uint32_t *>(vout),
                                               ctx->os_plan, i, shift, ctx->os_status, grid_tiles, forced, ctx->scatter.atomic_rank,
-                                              ctx->xcc_map, st.key_bytes, ctx->os_spin_budget, ctx->os_hold_tile, ev, ctx->os_misplace));
+                                              ctx->xcc_map, st.key_bytes, ctx->os_spin_budget, ctx->os_hold_tile, ev, ctx->os_misplace, 0, nullptr, drift_word(ctx)));
     return VRS_OK;
 }
 
@@ -988,7 +1009,7 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
                                         pairs ? static_cast<const uint32_t *>(st.vptr[home ^ 1u]) : nullptr,
                                         pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr, ctx->os_msd_plan, ctx->os_status,
                                         tiles_b, ctx->scatter.atomic_rank, ctx->xcc_map, st.key_bytes, ctx->os_spin_budget, ev,
-                                        st.key_base, st.sub_bits, reserves(ctx, st.n, pairs)));
+                                        st.key_base, st.sub_bits, reserves(ctx, st.n, pairs), drift_word(ctx)));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
     // Launched with the plan known (it said yes), the local sort also clears the look-back status words -- it is LDS-bound and
     // has HBM time to spare, the next sort's counting read does not.  Launched blind it may leave at once: nothing is promised.
@@ -1135,7 +1156,7 @@ static int one_read_enqueue(vrs_context ctx) {
                                                   pairs ? static_cast<uint32_t *>(st.vptr[c ^ 1u]) : nullptr, ctx->os_plan_a, 0,
                                                   vrs::kShiftFromPlan, ctx->os_status, g.tiles0, false, ctx->scatter.atomic_rank,
                                                   ctx->xcc_map, key_bytes, ctx->os_spin_budget, ctx->os_hold_tile, ev, ctx->os_misplace,
-                                                  st.key_base, reserves(ctx, n, pairs) ? ctx->os_msd_plan : nullptr));
+                                                  st.key_base, reserves(ctx, n, pairs) ? ctx->os_msd_plan : nullptr, drift_word(ctx)));
     }
     for (uint32_t i = 0; i < st.blind_passes; ++i)
         if ((rc = one_read_lookback_pass(ctx, st, i, 32u * group + 8u * i, i == 0 ? g.tiles0 : g.blind_cap, false))) return rc;
@@ -1370,7 +1391,8 @@ static int sort_one_read(vrs_context ctx, vrs_buffer keys, vrs_buffer keys_tmp, 
     st.n = n;
     st.key_bytes = key_bytes;
     st.deferred = ctx->os_async;
-    int rc = one_read_enqueue(ctx);
+    int rc = reprobe_if_drifted(ctx);
+    if (rc == VRS_OK) rc = one_read_enqueue(ctx);
     if (rc) {
         st.active = false;
         return rc;
@@ -1487,7 +1509,7 @@ int vrs_msd_partition_signal_u32(vrs_context ctx, vrs_buffer keys, vrs_buffer ou
     if ((rc = profile_events(ctx, VRS_KERNEL_LOOKBACK_SCATTER, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_onesweep_scatter(ctx->stream, keys->ptr, out->ptr, nullptr, nullptr, ctx->os_plan_a, 0, vrs::kShiftFromPlan,
                                               ctx->os_status, g.tiles0, 2, ctx->scatter.atomic_rank, ctx->xcc_map, 4,
-                                              ctx->os_spin_budget, -1, ev, false, 0u, reserves(ctx, n, false) ? ctx->os_msd_plan : nullptr));
+                                              ctx->os_spin_budget, -1, ev, false, 0u, reserves(ctx, n, false) ? ctx->os_msd_plan : nullptr, drift_word(ctx)));
     return VRS_OK;
 }
 
@@ -1875,6 +1897,14 @@ int vrs_one_call_pool_sorts(vrs_context ctx, uint64_t *pool_sorts, uint64_t *poo
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     if (pool_sorts) *pool_sorts = ctx->os_pool_sorts;
     if (pool_refusals) *pool_refusals = ctx->os_pool_refusals;
+    return VRS_OK;
+}
+
+int vrs_debug_xcc_placement(vrs_context ctx, uint64_t *reprobes, uint64_t *xcc_map, int *valid) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (reprobes) *reprobes = ctx->reprobes;
+    if (xcc_map) *xcc_map = ctx->xcc_map;
+    if (valid) *valid = ctx->xcc_map_valid ? 1 : 0;
     return VRS_OK;
 }
 

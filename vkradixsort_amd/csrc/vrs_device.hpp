@@ -274,6 +274,16 @@ struct PieceSrc {
     __device__ __forceinline__ gptr at(uint32_t v) const { return v < n_virt ? (gptr)regions + v : (gptr)overflow + (v - n_virt); }
 };
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3u << 11) | 20u); }  // HW_REG_XCC_ID[3:0]
+// byte x of the probed map = the XCC the blocks with blockIdx % 8 == x ran on
+__device__ __forceinline__ uint32_t xcc_of(unsigned long long xcc_map, uint32_t x) { return static_cast<uint32_t>((xcc_map >> (8u * x)) & 0xFFu); }
+// Placement drift: the dispatcher deals a launch's blocks out to the XCCs round-robin from an XCC of the hardware queue's own, and a
+// stream may move to another queue after the context probed -- the kernels that lean on the probed order then run their
+// placement-independent routes (exact, slower) until someone probes again.  The first blocks of such a kernel say so in a word of
+// pinned host memory (nothing on the usual path: one compare per workgroup); the host probes again before its next sort.
+__device__ __forceinline__ void report_drift(uint32_t *drift, unsigned long long xcc_map) {
+    if (drift != nullptr && threadIdx.x == 0 && blockIdx.x < 64u && xcc_id() != xcc_of(xcc_map, blockIdx.x & 7u))
+        __hip_atomic_fetch_add(drift, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 struct StreamLookback {
     static constexpr bool kEnabled = true;

@@ -105,6 +105,7 @@ struct OnesweepPlanHead {
     uint32_t msd_shift_a;       // the first MSD pass's digit shift (top 8 bits of the key range)
     uint32_t lsd_missing;       // 1 = the counting read counted only the bucket histogram (fast count): no LSD plan exists
     uint32_t msd_counted;       // (the first MSD pass's plan) 1 = the bucket histogram holds every key: the probed range was 27-32 bits wide and no key lay outside it
+    uint32_t drift;             // host copy only: workgroups that found themselves on another XCC than the context's probe said (report_drift)
     uint32_t ready;             // host copy only: the sort's stamp, written after everything else
 };
 struct OnesweepPlan {
@@ -163,7 +164,10 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
                                    uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
                                    uint32_t *status, uint32_t grid_tiles, int forced, bool atomic_rank,
                                    unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, int hold_tile,
-                                   LaunchEvents ev = {}, bool misplace = false, uint32_t key_base = 0, struct MsdPlan *reserve = nullptr);
+                                   LaunchEvents ev = {}, bool misplace = false, uint32_t key_base = 0, struct MsdPlan *reserve = nullptr,
+                                   uint32_t *drift = nullptr);
+// drift: a word of pinned host memory (device view) the first blocks add to when they find themselves on another XCC than xcc_map says
+// (report_drift, vrs_device.hpp), or nullptr
 // ---- hybrid form of the one-call sort (K5b, uint32 keys): MSD partition by the top 14 bits in two look-back passes,
 // then one workgroup per bucket sorts the low 18 bits inside LDS.
 constexpr uint32_t kMsdBucketCount = 1u << 14;
@@ -224,7 +228,7 @@ constexpr uint32_t kMsdLogWords = 32;
 hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                              uint32_t *values_out, MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
                              unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev = {}, uint32_t key_base = 0, uint32_t sub_bits = 6,
-                             bool reserve = false);
+                             bool reserve = false, uint32_t *drift = nullptr);
 // key_base (uint32 keys of the hybrid form only): the caller promises keys >= key_base (a multiple of 2^24); buckets and MSD
 // digits are taken from key - key_base, so a sub-range of the key space gets the same 16384 buckets a full range would;
 // a key below it makes the counting read flag the sort and the plan refuse the hybrid form

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
                                                             const uint32_t *__restrict__ values_in, uint32_t *__restrict__ values_out,
                                                             MsdPlan *__restrict__ msd, uint32_t *__restrict__ status,
                                                             unsigned long long xcc_map, uint32_t spin_budget, uint32_t key_base,
-                                                            uint32_t sub_bits) {
+                                                            uint32_t sub_bits, uint32_t *drift) {
     constexpr uint32_t kTile = ITEMS * 8 * 64;  // the tile the plan counted with (onesweep_tile_keys)
     __shared__ ChunkSmem<K, ITEMS, 8, PAIRS> sm;
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
@@ -295,6 +295,7 @@ __global__ __launch_bounds__(512, 4) void msd_pass_b_kernel(const K *__restrict_
     // sub_bits: 6 in a whole sort; up to 8 when the caller grouped the keys by fewer bits (a kernel argument, what the plan was
     // made with: a word of the plan would be one more dependent load in front of the bucket's bounds)
     if (((a + 1u) << sub_bits) > kMsdBuckets) return;  // (no such group: the plan gave it no tiles)
+    report_drift(drift, xcc_map);
     const uint32_t first = msd->base[a << sub_bits], last = msd->base[(a + 1u) << sub_bits];
     const uint32_t done = i * kTile;
     const uint32_t begin = first + done;
@@ -1000,14 +1001,14 @@ hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *ms
 hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys_out, const uint32_t *values_in,
                              uint32_t *values_out, MsdPlan *msd, uint32_t *status, uint32_t tiles_b, bool atomic_rank,
                              unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, LaunchEvents ev, uint32_t key_base,
-                             uint32_t sub_bits, bool reserve) {
+                             uint32_t sub_bits, bool reserve, uint32_t *drift) {
     if (tiles_b == 0) return hipSuccess;
     if (sub_bits < 6u || sub_bits > 8u) return hipErrorInvalidValue;
     if (key_bytes == 8 && values_in != nullptr) return hipErrorInvalidValue;
     const dim3 grid(8 * tiles_b), block(512);
 #define VRS_PASS_B(K, ITEMS, RANK, PAIRS, RESERVE)                                                                         \
     VRS_LAUNCH((msd_pass_b_kernel<K, ITEMS, RANK, PAIRS, RESERVE>), grid, block, stream, ev, static_cast<const K *>(keys_in), \
-               static_cast<K *>(keys_out), values_in, values_out, msd, status, xcc_map, spin_budget, key_base, sub_bits)
+               static_cast<K *>(keys_out), values_in, values_out, msd, status, xcc_map, spin_budget, key_base, sub_bits, drift)
     // (the hybrid form runs only with the LDS-atomic ranking; bare keys may take their places by reservation)
     if (key_bytes == 8) {
         if (!atomic_rank) VRS_PASS_B(uint64_t, 8, RANK_BALLOT, false, false);

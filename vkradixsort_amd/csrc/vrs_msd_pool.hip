@@ -47,10 +47,6 @@ constexpr uint32_t kPoolMinShift = 13, kPoolMaxShift = 18;  // a 27 ... 32-bit k
 constexpr float kPoolSigmas = 6.0f;                       // overflow room, in standard deviations of the region's estimate
 constexpr uint32_t kPoolRoomFloor = 320;
 
-__device__ __forceinline__ uint32_t xcc_of(unsigned long long xcc_map, uint32_t x) {
-    return static_cast<uint32_t>((xcc_map >> (8u * x)) & 0xFFu);
-}
-
 // ---------------------------------------------------------------------------------------------
 // The sample.  Workgroup g takes tiles [32 g, 32 g + 32) of the input; wave w of it the tiles 32 g + w + 4 j.
 __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t key_base,

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
                                                                        uint32_t *__restrict__ status,
                                                                        unsigned long long xcc_map, int misplace,
                                                                        uint32_t spin_budget, int hold_tile, uint32_t key_base,
-                                                                       MsdPlan *__restrict__ reserve) {
+                                                                       MsdPlan *__restrict__ reserve, uint32_t *drift) {
     constexpr uint32_t kTile = ITEMS * WAVES * 64;  // the tile the plan counted with (onesweep_tile_keys)
     __shared__ ChunkSmem<K, ITEMS, WAVES, PAIRS> sm;
     const uint32_t k = blockIdx.x >> 3, i = k / (kStreams / 8);
@@ -398,6 +398,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void onesweep_scatter_kernel(const
     // counts -- a key range below 27 bits or a key outside the probed range left the bucket histogram empty or wrong, every seed
     // would be void and a reservation could run out of its range
     if (forced == 2 && plan->head.msd_counted == 0u) return;
+    report_drift(drift, xcc_map);
     const uint32_t done = i * kTile;
     const uint32_t begin = sd.start + done;
     const bool stream_in = static_cast<size_t>(sd.len) * sizeof(K) * kStreams >= kStreamInBytes;  // (streams are about equal: the pass's input)
@@ -554,7 +555,7 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
                                    uint32_t *values_out, const OnesweepPlan *plan, uint32_t pass, uint32_t shift,
                                    uint32_t *status, uint32_t grid_tiles, int forced, bool atomic_rank,
                                    unsigned long long xcc_map, int key_bytes, uint32_t spin_budget, int hold_tile,
-                                   LaunchEvents ev, bool misplace, uint32_t key_base, MsdPlan *reserve) {
+                                   LaunchEvents ev, bool misplace, uint32_t key_base, MsdPlan *reserve, uint32_t *drift) {
     const int mis = misplace ? 1 : 0, force = forced;
     if (grid_tiles == 0) return hipSuccess;
     const dim3 grid(kStreams * grid_tiles), block(64 * kLbWaves);
@@ -562,7 +563,7 @@ hipError_t launch_onesweep_scatter(hipStream_t stream, const void *keys_in, void
 #define VRS_ONESWEEP_R(K, ITEMS, PAIRS, RANK, RESERVE)                                                                \
     VRS_LAUNCH((onesweep_scatter_kernel<K, ITEMS, kLbWaves, PAIRS, RANK, 4, RESERVE>), grid, block, stream, ev,   \
                static_cast<const K *>(keys_in), static_cast<K *>(keys_out), values_in, values_out, plan, pass, force,  \
-               shift, status, xcc_map, mis, spin_budget, hold_tile, key_base, reserve)
+               shift, status, xcc_map, mis, spin_budget, hold_tile, key_base, reserve, drift)
 #define VRS_ONESWEEP(K, ITEMS, PAIRS, RANK) VRS_ONESWEEP_R(K, ITEMS, PAIRS, RANK, false)
     // the first MSD pass of the hybrid form over bare keys (LDS-atomic ranking) may take its places by reservation
     if (reserve != nullptr && !pairs && atomic_rank && shift == kShiftFromPlan) {

@@ -117,10 +117,12 @@ __device__ __forceinline__ void plan_body(uint32_t *__restrict__ tables, Oneswee
     __syncthreads();
     constexpr uint32_t kHeadWords = sizeof(OnesweepPlanHead) / sizeof(uint32_t);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(&s_head);
-    for (uint32_t i = tid; i < kHeadWords - 1u; i += 4 * kBins)  // every word but `ready` (the last one)
+    static_assert(offsetof(OnesweepPlanHead, drift) == sizeof(OnesweepPlanHead) - 8 && offsetof(OnesweepPlanHead, ready) == sizeof(OnesweepPlanHead) - 4,
+                  "the last two words are not the plan's: `drift` (kernels add to the host copy) and `ready` (the stamp)");
+    for (uint32_t i = tid; i < kHeadWords - 2u; i += 4 * kBins)  // every word but `drift` and `ready` (the last two)
         reinterpret_cast<uint32_t *>(&plan->head)[i] = src[i];
     if (host_head && tid < 64u) {  // ONE wave writes the host copy, so one wave's fence orders it before the stamp
-        for (uint32_t i = tid; i < kHeadWords - 1u; i += 64u)
+        for (uint32_t i = tid; i < kHeadWords - 2u; i += 64u)
             __hip_atomic_store(reinterpret_cast<uint32_t *>(host_head) + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __threadfence_system();
         // stamp == 0: another kernel (msd_plan_kernel) completes the head and stamps it
