@@ -1006,7 +1006,9 @@ def bench_multi(args, fabric=None):
     gr0 = ctypes.c_uint64()
     lib.vrs_dist_grouped_rounds(d, ctypes.byref(gr0))
     gpu.profileReset()
-    gpu.profileEnableMask(1 << capi.VRS_KERNEL_LOOKBACK_SCATTER)  # events ride on the dominant kernel's own launches
+    # events ride on the scatter passes' own launches: the look-back / reserving passes and, where a round is finished by the pool
+    # form's second half (vrs_msd_finish_grouped_counts_u32), its second pass
+    gpu.profileEnableMask((1 << capi.VRS_KERNEL_LOOKBACK_SCATTER) | (1 << capi.VRS_KERNEL_POOL_PASS_B))
     barrier()
     t0 = time.perf_counter()
     out_buf, out_n = None, 0
@@ -1016,6 +1018,9 @@ def bench_multi(args, fabric=None):
     elapsed = time.perf_counter() - t0
     gpu.profileEnable(False)
     lb_launches, lb_ms = gpu.profileQuery(capi.VRS_KERNEL_LOOKBACK_SCATTER)
+    pb_launches, pb_ms = gpu.profileQuery(capi.VRS_KERNEL_POOL_PASS_B)
+    pool_finish = pb_launches > 0
+    lb_launches, lb_ms = lb_launches + pb_launches, lb_ms + pb_ms
     st1 = [ctypes.c_uint64() for _ in range(3)]
     lib.vrs_dist_stats(d, *[ctypes.byref(x) for x in st1])
     hybrid_rounds, fallback_rounds, byte_steps = (b.value - a.value for a, b in zip(st0, st1))
@@ -1056,8 +1061,9 @@ def bench_multi(args, fabric=None):
         lb_achieved = lb_bytes / (lb_ms * 1e-3) / 1e9 if lb_ms > 0 else None
         # byte shape: 12 (contract partition pass) + what vrs_sort_keys_u32_ranged moves per received sub-range: 28 in its hybrid
         # form (from 1.3e7 keys on), 36 in its LSD form
-        # byte shape with the grouped finish: 12 + (counting read 4 + second MSD pass 8 + local sort 8)
-        sort_bpk = 28 if hybrid else 32 if grouped else (40 if recv_keys / max(rounds, 1) >= 1.3e7 else 48)
+        # byte shape with the grouped finish: 12 + (counting read 4 + second MSD pass 8 + local sort 8); with the counts the step
+        # has anyway (vrs_msd_finish_grouped_counts_u32: the pool form's second half): 12 + (8 + 8)
+        sort_bpk = 28 if hybrid else (28 if pool_finish else 32) if grouped else (40 if recv_keys / max(rounds, 1) >= 1.3e7 else 48)
         base = None
         if not args.no_cpu_baseline:
             from tests import _oracle
@@ -1080,8 +1086,11 @@ def bench_multi(args, fabric=None):
                                 f"{rounds} round(s), second MSD pass + LDS-local sort per received sub-range") if hybrid else
                                ("vrs_dist_sort_keys_u32, byte shape (the global top-14-bit buckets would not fit the local sort): contract "
                                 f"partition pass by the top byte, {fabric.wire} send/recv of one message per (sender, top byte) in {rounds} round(s), "
-                                "per received sub-range one counting read + second MSD pass by the next 8 bits + LDS-local sort "
-                                "(vrs_msd_finish_grouped_u32)") if grouped else
+                                + ("per received sub-range the pool form's second half -- a sample, the second MSD pass by the next 6..8 bits into "
+                                   "the buckets' slack regions, the LDS-local sort: nothing is read to be counted (vrs_msd_finish_grouped_counts_u32)"
+                                   if pool_finish else
+                                   "per received sub-range one counting read + second MSD pass by the next 8 bits + LDS-local sort "
+                                   "(vrs_msd_finish_grouped_u32)")) if grouped else
                                ("vrs_dist_sort_keys_u32, byte shape (the global top-14-bit buckets would not fit the local sort): contract "
                                 f"partition pass by the top byte, {fabric.wire} send/recv per (sender, round) in {rounds} round(s), "
                                 "vrs_sort_keys_u32_ranged per received sub-range (its own 16384 buckets)"),

@@ -267,6 +267,16 @@ int vrs_msd_finish_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, vrs_
  * bucket exceeds the local sort's capacity: about 3.6 * 10^6 keys per top byte. */
 int vrs_msd_finish_grouped_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, uint32_t num_elements, uint32_t first_top_byte,
                                uint32_t top_bytes);
+/* The same for a caller that KNOWS how many keys each of those top bytes holds (counts[0 .. top_bytes): host memory, read before the
+ * call returns; their sum must be num_elements) -- the multi-GPU step does, from the exchange's own bookkeeping.  Nothing is read to
+ * be counted: one workgroup per top byte samples 1/32 of its keys and sizes a region of the context's slack buffer per bucket (top byte
+ * and the next 6 .. 8 bits), the second MSD pass scatters there, the local sort reads every bucket in one piece -- the second half of
+ * the pool form (VRS_TUNE_MSD_POOL), 16 bytes per key instead of 20.  Refused (ticket / status as above; `grouped` untouched) when a
+ * bucket outgrows its region or the local sort's capacity, or a key does not carry the top byte its place says.  Falls back to
+ * vrs_msd_finish_grouped_u32 where the form cannot run (switched off, no workgroup shape for these buckets, fewer than 2^20 keys,
+ * counts == NULL). */
+int vrs_msd_finish_grouped_counts_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, uint32_t num_elements, uint32_t first_top_byte,
+                                      uint32_t top_bytes, const uint32_t *counts);
 int vrs_msd_finish_status(vrs_context ctx, int *took);
 int vrs_msd_finish_ticket(vrs_context ctx, uint32_t *ticket);
 int vrs_msd_finish_status_at(vrs_context ctx, uint32_t ticket, int *took);

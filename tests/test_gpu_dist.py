@@ -408,6 +408,82 @@ def test_msd_finish_grouped_sorts_keys_that_arrive_grouped_by_top_byte(first, to
         out.release()
 
 
+@pytest.mark.parametrize("first,top_bytes,n", [(0, 256, 6000001), (0x40, 64, 5000003), (0xA0, 32, 4000001), (0x10, 9, 3000007),
+                                                (0xFE, 2, 2500001), (0x7F, 1, 2000003), (0x03, 100, 7000001), (0xE0, 8, 9000001),
+                                                (0x20, 32, 70001)])
+def test_msd_finish_grouped_counts_needs_no_counting_read(first, top_bytes, n):
+    """vrs_msd_finish_grouped_counts_u32: the same second half for a caller that knows every top byte's keys (the multi-GPU step
+    does) -- the pool form's plan samples the grouped keys, the second pass scatters into the buckets' slack regions, the local sort
+    reads every bucket in one piece: 16 instead of 20 bytes per key, no counting read.  Bit-exact vs std::sort for 1 to 256 top
+    bytes; where the form has no shape for the buckets (a single top byte with 2e6 keys needs more than 8 bits) or too few keys, the
+    counted finish runs instead -- the ticket says taken either way; wrong counts are an error."""
+    lib = capi.load_library()
+    rs = np.random.RandomState(first * 1000 + top_bytes + 1)
+    keys = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    keys = (keys & np.uint32(0x00FFFFFF)) | ((rs.randint(first, first + top_bytes, size=n).astype(np.uint32)) << np.uint32(24))
+    grouped_host = keys[np.argsort(keys >> np.uint32(24), kind="stable")]
+    counts = np.bincount((grouped_host >> np.uint32(24)).astype(np.int64) - first, minlength=top_bytes).astype(np.uint32)
+    cptr = counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    with vrs.GPUContext(0) as gpu:
+        g = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), grouped_host)
+        out = vrs.Buffer(gpu, S(4 * n))
+        gpu.profileEnable(True)
+        for rep in range(2):
+            gpu.check(lib.vrs_buffer_upload(gpu.handle, g.handle, grouped_host.ctypes.data_as(ctypes.c_void_p), grouped_host.nbytes))
+            gpu.profileReset()
+            gpu.check(lib.vrs_msd_finish_grouped_counts_u32(gpu.handle, g.handle, out.handle, n, first, top_bytes, cptr))
+            t = ctypes.c_uint32()
+            gpu.check(lib.vrs_msd_finish_ticket(gpu.handle, ctypes.byref(t)))
+            took = ctypes.c_int(-1)
+            gpu.check(lib.vrs_msd_finish_status_at(gpu.handle, t.value, ctypes.byref(took)))
+            assert took.value == 1
+            res = np.empty(n, np.uint32)
+            out.downloadWithStagingBuffer(res)
+            assert np.array_equal(res, np.sort(keys))
+            pooled = gpu.profileQuery(capi.VRS_KERNEL_POOL_PASS_B)[0] == 1
+            counted = gpu.profileQuery(capi.VRS_KERNEL_DIGIT_TABLES)[0] == 1
+            assert pooled != counted
+            # the pool form's second half wherever 6 .. 8 bits below the top byte make buckets a workgroup can hold
+            assert pooled == (n >= (1 << 20) and n / (top_bytes * 256) < 13000)
+        gpu.profileEnable(False)
+        bad = counts.copy()
+        bad[0] += 1
+        assert lib.vrs_msd_finish_grouped_counts_u32(gpu.handle, g.handle, out.handle, n, first, top_bytes,
+                                                     bad.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))) == capi.VRS_ERROR_INVALID_ARGUMENT
+        g.release()
+        out.release()
+
+
+def test_msd_finish_grouped_counts_refuses_what_does_not_fit_and_keys_off_their_top_byte():
+    """a bucket beyond its region or the local sort (375 000 keys under one (top byte, next 8 bits)), a key whose top byte is not
+    the one its place says: the second pass flags the finish, nothing of `grouped` has moved"""
+    lib = capi.load_library()
+    n, first, top_bytes = 3000001, 0x20, 16
+    rs = np.random.RandomState(5)
+    keys = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    keys = (keys & np.uint32(0x00FFFFFF)) | ((rs.randint(first, first + top_bytes, size=n).astype(np.uint32)) << np.uint32(24))
+    hot = keys.copy()
+    hot[: n // 8] = (hot[: n // 8] & np.uint32(0xFFFF)) | np.uint32(0x25AB0000)
+    stray = keys[np.argsort(keys >> np.uint32(24), kind="stable")].copy()
+    with vrs.GPUContext(0) as gpu:
+        out = vrs.Buffer(gpu, S(4 * n))
+        for case, host in (("hot", hot[np.argsort(hot >> np.uint32(24), kind="stable")]), ("stray", stray)):
+            counts = np.bincount((host >> np.uint32(24)).astype(np.int64) - first, minlength=top_bytes).astype(np.uint32)
+            if case == "stray":
+                host[1234] = (host[1234] & np.uint32(0x00FFFFFF)) | np.uint32((first + top_bytes - 1) << 24)  # (counts as given: still add up)
+            g = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), host)
+            gpu.check(lib.vrs_msd_finish_grouped_counts_u32(gpu.handle, g.handle, out.handle, n, first, top_bytes,
+                                                            counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+            took = ctypes.c_int(-1)
+            gpu.check(lib.vrs_msd_finish_status(gpu.handle, ctypes.byref(took)))
+            assert took.value == 0, case
+            back = np.empty(n, np.uint32)
+            g.downloadWithStagingBuffer(back)
+            assert np.array_equal(back, host), case
+            g.release()
+        out.release()
+
+
 def test_msd_finish_grouped_refuses_a_bucket_no_workgroup_can_hold_and_rejects_bad_ranges():
     lib = capi.load_library()
     n, first, top_bytes = 3000001, 0x20, 16

@@ -1165,13 +1165,8 @@ static int one_read_enqueue(vrs_context ctx) {
     return VRS_OK;
 }
 
-static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
-    (void)g;
-    vrs_context_t::OneRead &st = ctx->one_read;
-    const uint32_t n = st.n;
-    int rc;
-    const vrs::PoolShape shape = vrs::pool_shape(n, ctx->os_pool_sub_bits);
-    const uint32_t room = vrs::pool_overflow_capacity(n), slack = vrs::pool_slack_capacity(n, shape.sub_bits);
+// the pool form's scratch: its plan (once), the first pass's overflow regions and the slack buffer (grown when a sort needs more)
+static int pool_scratch(vrs_context ctx, uint32_t room, uint32_t slack) {
     if (!ctx->os_pool_plan) {
         vrs::PoolPlan *pp = nullptr;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&pp), sizeof(vrs::PoolPlan));
@@ -1183,6 +1178,8 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
         ctx->os_pool_plan = pp;
     }
     if (room > ctx->os_pool_overflow_cap || slack > ctx->os_pool_slack_cap) {
+        room = std::max(room, ctx->os_pool_overflow_cap);  // (both are made anew: neither may shrink)
+        slack = std::max(slack, ctx->os_pool_slack_cap);
         if (ctx->os_pool_overflow || ctx->os_pool_slack) {
             VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->os_pool_overflow) VRS_HIP(ctx, hipFree(ctx->os_pool_overflow));
@@ -1197,6 +1194,17 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
         VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_slack), static_cast<size_t>(slack) * sizeof(uint32_t)));
         ctx->os_pool_slack_cap = slack;
     }
+    return VRS_OK;
+}
+
+static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
+    (void)g;
+    vrs_context_t::OneRead &st = ctx->one_read;
+    const uint32_t n = st.n;
+    int rc;
+    const vrs::PoolShape shape = vrs::pool_shape(n, ctx->os_pool_sub_bits);
+    const uint32_t room = vrs::pool_overflow_capacity(n), slack = vrs::pool_slack_capacity(n, shape.sub_bits);
+    if ((rc = pool_scratch(ctx, room, slack))) return rc;
     if ((rc = reservation_begin(ctx))) return rc;  // the first pass's cursors: zero
     const vrs::PoolStreams ps = vrs::pool_streams(n);
     const uint32_t c = st.cur;
@@ -1590,6 +1598,65 @@ int vrs_msd_finish_grouped_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer o
     st.kptr[1] = grouped->ptr;
     st.cur_at_start = 0;
     return one_read_hybrid_tail(ctx, st, g, g.tiles_b_cap, g.local_cap, true);
+}
+
+int vrs_msd_finish_grouped_counts_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, uint32_t n, uint32_t first_top_byte,
+                                      uint32_t top_bytes, const uint32_t *counts) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (!counts) return vrs_msd_finish_grouped_u32(ctx, grouped, out, n, first_top_byte, top_bytes);
+    int rc;
+    const size_t bytes = static_cast<size_t>(n) * sizeof(uint32_t);
+    if ((rc = check_buffer(ctx, grouped, bytes, "grouped"))) return rc;
+    if ((rc = check_buffer(ctx, out, bytes, "out"))) return rc;
+    if (grouped->ptr == out->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "grouped and out alias");
+    if (top_bytes == 0 || first_top_byte > 255u || first_top_byte + top_bytes > 256u)
+        return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "top bytes [first, first + count) must lie in [0, 256)");
+    vrs::PoolGroups groups{};
+    uint64_t sum = 0;
+    for (uint32_t a = 0; a < top_bytes; ++a) {
+        groups.count[a] = counts[a];
+        sum += counts[a];
+    }
+    groups.top_bytes = top_bytes;
+    if (sum != n) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the top bytes' counts do not add up to num_elements");
+    // The pool form's second half: the plan samples the grouped keys (nothing is read to be counted), the second pass scatters into
+    // the buckets' slack regions, the local sort finishes.  Where it cannot run -- the form switched off, no shape for these buckets,
+    // fewer keys than its fixed costs are worth -- the counted finish takes over.
+    const vrs::PoolShape shape = vrs::pool_grouped_shape(n, top_bytes);
+    if (ctx->os_pool == 0 || !reserves(ctx, n, false) || shape.sub_bits == 0u || n < (1u << 20) || n >= (1u << 30) || !ctx->xcc_map_valid ||
+        !ctx->atomic_rank_verified || !ctx->scatter.atomic_rank)
+        return vrs_msd_finish_grouped_u32(ctx, grouped, out, n, first_top_byte, top_bytes);
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = settle_pending(ctx))) return rc;
+    vrs_context_t::OneRead st;
+    OneReadGeometry g;
+    if ((rc = msd_half_setup(ctx, n, &st, &g, 0, top_bytes))) return rc;  // (the plan head, its host copy and the log of decisions)
+    // rows of workgroups of the second pass: the busiest XCD's tiles (XCD x walks top bytes x, x + 8, ...) -- known exactly here
+    uint32_t tiles_b = 0;
+    for (uint32_t x = 0; x < 8u; ++x) {
+        uint32_t t = 0;
+        for (uint32_t a = x; a < top_bytes; a += 8u) t += (groups.count[a] + vrs::kPoolTile - 1u) / vrs::kPoolTile;
+        tiles_b = std::max(tiles_b, t);
+    }
+    if (tiles_b > vrs::kPoolMaxTilesB) return vrs_msd_finish_grouped_u32(ctx, grouped, out, n, first_top_byte, top_bytes);
+    const uint32_t slack = vrs::pool_slack_capacity(n, shape.sub_bits, top_bytes);
+    if ((rc = pool_scratch(ctx, std::max(ctx->os_pool_overflow_cap, 32u), slack))) return rc;
+    ctx->sub_cache.valid = false;
+    if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
+    ctx->os_msd_half_stamp = ctx->os_stamp;
+    const uint32_t key_base = first_top_byte << 24;
+    const uint32_t *keys_in = static_cast<const uint32_t *>(grouped->ptr);
+    vrs::LaunchEvents ev;
+    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, keys_in, keys_in, key_base,
+                                       vrs::pool_streams(n), shape.sub_bits, &groups));
+    if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_B, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, keys_in, keys_in, ctx->os_pool_slack, n, ctx->os_msd_plan, ctx->os_pool_plan, tiles_b, key_base,
+                                         vrs::pool_local_capacity(shape.local), ctx->os_pool_slack_cap, ctx->xcc_map, ctx->os_stamp, shape.sub_bits, ev, true));
+    if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
+    VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, static_cast<uint32_t *>(out->ptr), n, ctx->os_msd_plan, ctx->os_pool_plan, shape,
+                                             &ctx->os_plan->head, ctx->os_host_head_dev, ctx->os_stamp, ev, top_bytes,
+                                             reinterpret_cast<uint32_t *>(ctx->os_host_head_dev + 1)));
+    return VRS_OK;
 }
 
 int vrs_msd_finish_status(vrs_context ctx, int *took) {

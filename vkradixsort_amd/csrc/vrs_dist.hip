@@ -910,6 +910,8 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
         grouped_finish = fullest <= 256u * 12500u && grand_total >= (1u << 16);
     }
     const bool by_top_byte = hybrid || grouped_finish;  // one message per (top byte, source), the result built in the scratch buffer
+    const char *pf_env = std::getenv("VRS_DIST_POOL_FINISH");
+    const bool pool_finish = !(pf_env && pf_env[0] == '0');
 
     // what I receive in round r: one message per (top byte, source) in that order -- the round's keys land grouped by top byte --
     // or (byte shape with whole ranged sorts) one message per source.  round_off: where round r starts in the receive buffer.
@@ -1046,7 +1048,13 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
                 if (table) (void)vrs_buffer_release(table);
             } else {
                 const uint32_t lo = parts[static_cast<size_t>(me) * R + r], hi = parts[static_cast<size_t>(me) * R + r + 1];
-                rc = vrs_msd_finish_grouped_u32(ctx, view, sview, static_cast<uint32_t>(cnt), lo, hi - lo);
+                // every top byte's keys landed in one piece and every rank knows how many there are (the gathered table): nothing
+                // needs to be read to be counted -- the pool form's second half, 16 bytes per key instead of 20
+                // (VRS_DIST_POOL_FINISH=0: the counted finish)
+                uint32_t per_byte[256];
+                for (uint32_t t = lo; t < hi; ++t) per_byte[t - lo] = static_cast<uint32_t>(byte_counts[t]);
+                rc = pool_finish ? vrs_msd_finish_grouped_counts_u32(ctx, view, sview, static_cast<uint32_t>(cnt), lo, hi - lo, per_byte)
+                                 : vrs_msd_finish_grouped_u32(ctx, view, sview, static_cast<uint32_t>(cnt), lo, hi - lo);
             }
             if (rc == VRS_OK) rc = vrs_msd_finish_ticket(ctx, &ticket[static_cast<size_t>(r)]);
             (void)vrs_buffer_release(view);

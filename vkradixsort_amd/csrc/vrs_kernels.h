@@ -269,8 +269,8 @@ constexpr uint32_t kPoolTile = 8192;           // keys per tile of both passes
 constexpr uint32_t kPoolSampleKeys = 256;      // leading keys of every tile the sample kernel counts
 constexpr uint32_t kPoolSampleTiles = 32;      // tiles per workgroup of the sample kernel
 constexpr uint32_t kPoolMaxKeys = 224000000u;  // the fullest of 16384 uniform buckets (mean + 5.5 deviations) must fit the local sort's 512-thread shape (14333 keys)
-constexpr uint32_t kPoolMaxSubBits = 7;        // the second pass sorts by 6 or 7 bits: 16384 or 32768 buckets
-constexpr uint32_t kPoolMaxBuckets = 256u << kPoolMaxSubBits;
+constexpr uint32_t kPoolMaxBuckets = 256u << 7; // the second pass sorts by 6 or 7 bits of 256 top bytes (16384 or 32768 buckets); the second half alone
+                                                // (grouped keys of fewer top bytes) also by 8
 constexpr uint32_t kPoolMaxTilesA = 3456;      // tiles per slice of the first pass at kPoolMaxKeys (3418)
 constexpr uint32_t kPoolMaxTilesB = 4352;      // rows of workgroups of the second pass at kPoolMaxKeys (pool_tiles_b_cap: 4313)
 struct PoolStreams {                           // the eight slices of the input the first pass walks (whole tiles), by value
@@ -303,13 +303,19 @@ struct PoolPlan {
 };
 PoolStreams pool_streams(uint32_t n);
 uint32_t pool_overflow_capacity(uint32_t n);   // keys of overflow scratch a sort of n keys may use
-uint32_t pool_slack_capacity(uint32_t n, uint32_t sub_bits);  // slots of the slack buffer (regions of all buckets + one tile where refused runs are dumped)
+uint32_t pool_slack_capacity(uint32_t n, uint32_t sub_bits, uint32_t top_bytes = 256);  // slots of the slack buffer (regions of all buckets + one tile where refused runs are dumped)
 // The shape of a pool sort, chosen from n alone (the form is enqueued blind): bits of the second pass and the local sort's workgroup.
 struct PoolShape {
     uint32_t sub_bits;   // 6 or 7
     uint32_t local;      // 0: 256 threads x 16 slots (up to 4093 keys per bucket, five workgroups per CU), 1: 256 x 28 (7165, four), 2: 512 x 28 (14333, two)
 };
 PoolShape pool_shape(uint32_t n, int forced_sub_bits = 0);  // forced_sub_bits: 0 = by size, 6 or 7
+// the second half alone, for n keys grouped by `top_bytes` top bytes: sub_bits 6 .. 8 (0: no shape takes them)
+PoolShape pool_grouped_shape(uint32_t n, uint32_t top_bytes);
+struct PoolGroups {          // keys of every top byte (grouped keys; by value: a kernel argument)
+    uint32_t count[256];     // zero from top_bytes on
+    uint32_t top_bytes;      // top bytes that exist: top_bytes << sub_bits buckets
+};
 uint32_t pool_local_capacity(uint32_t local);
 uint32_t pool_tiles_b_cap(uint32_t n);         // rows of workgroups of the second pass (its grid is sized before the plan is known)
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
@@ -322,16 +328,21 @@ hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint3
 // after the first pass, one workgroup per top byte: top-byte starts, tile tables, piece rows, the buckets' slack regions (from a
 // sample of the first pass's OUTPUT: regions / overflow), verdict 1 (slack_capacity: slots the slack buffer has)
 hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap, uint32_t slack_capacity,
-                            const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps, uint32_t sub_bits);
+                            const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps, uint32_t sub_bits,
+                            const PoolGroups *groups = nullptr);
+// groups != nullptr: the second half alone (vrs_msd_finish_grouped_counts_u32) -- `regions` holds keys grouped by top byte, top byte a
+// (counted from key_base >> 24) holds groups->count[a] of them; no first pass ran
 // second pass, regions -> slack buffer: grid of 8 * tiles_b workgroups (tiles_b = pool_tiles_b_cap(n)); local_cap: keys the local
 // sort that follows takes per bucket; slack_capacity: as given to the plan (the last kPoolTile slots take refused runs)
 hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *slack, uint32_t n, MsdPlan *msd,
                               PoolPlan *pool, uint32_t tiles_b, uint32_t key_base, uint32_t local_cap, uint32_t slack_capacity,
-                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, LaunchEvents ev = {});
+                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, LaunchEvents ev = {}, bool grouped = false);
 // sorts every bucket from its slack region to keys_out[its exact start ...) with the workgroup shape.local.  Gives verdict 2 (verdict 1, no flag from the passes) = MsdPlan::ok and the host head
 // (msd_ok, lsd_missing = 1, stamped last); re-arms the first pass's reservation counters
 hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
-                                  PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev = {});
+                                  PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev = {},
+                                  uint32_t top_bytes = 256, uint32_t *host_log = nullptr);
+// top_bytes: the top bytes that exist (a sort: 256; the second half alone: the caller's); host_log: see launch_msd_plan
 
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups
 hipError_t launch_xcc_probe(hipStream_t stream, uint32_t *out, uint32_t blocks);

@@ -40,9 +40,6 @@ namespace vrs {
 
 namespace {
 
-#ifndef VRS_LAB_STREAM
-#define VRS_LAB_STREAM true
-#endif
 constexpr uint32_t kPoolMinShift = 13, kPoolMaxShift = 18;  // a 27 ... 32-bit key range (the counted form's rule)
 constexpr float kPoolSigmas = 6.0f;                       // overflow room, in standard deviations of the region's estimate
 constexpr uint32_t kPoolRoomFloor = 320;
@@ -337,10 +334,13 @@ __device__ __forceinline__ uint32_t pool_space(uint32_t c) {
     const float x = static_cast<float>(c), s = static_cast<float>(SUB);
     return (c + static_cast<uint32_t>(kPoolSigmas * sqrtf(s * kPoolR * (x + s * kPoolR))) + SUB * (kPoolRoomFloor + 4u) + 3u) & ~3u;
 }
-template <uint32_t SUBBITS>
+// GROUPED (vrs_msd_finish_grouped_counts_u32: the second half alone, for keys that ARE grouped by their top byte and whose caller
+// knows how many each top byte holds -- a rank of the multi-GPU step after the exchange): the totals come from the caller (`groups`,
+// by value), a top byte is ONE piece of `regions`, no claims of a first pass to check; the rest is the same.
+template <uint32_t SUBBITS, bool GROUPED>
 __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool, uint32_t n, uint32_t tiles_b_cap,
                                                        uint32_t slack_capacity, const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
-                                                       uint32_t key_base, PoolStreams ps) {
+                                                       uint32_t key_base, PoolStreams ps, PoolGroups groups) {
     constexpr uint32_t THREADS = 512, WAVES = THREADS / 64, SUB = 1u << SUBBITS, PER = SUB / 64u;
     __shared__ uint32_t s_c[kBins];              // keys of top byte t
     __shared__ uint32_t s_red[3][WAVES];
@@ -349,10 +349,11 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
     __shared__ uint32_t s_first[17];
     __shared__ uint32_t s_bad;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, a = blockIdx.x;
-    const uint32_t shift = pool->shift, bshift = shift + kMsdSubBits - SUBBITS;  // bucket index of a key: (key - key_base) >> bshift
-    if (tid < 2u * kBins / 2u) {  // the first pass's claims: (list x, tile i) exactly once for every tile of the grid (the 256 x 256 first threads take one each)
+    // bucket index of a key: (key - key_base) >> bshift (GROUPED: the bits below the top byte; a sort: the probed range's)
+    const uint32_t shift = GROUPED ? 18u : pool->shift, bshift = shift + kMsdSubBits - SUBBITS;
+    if (!GROUPED && tid < 256u) {  // the first pass's claims: (list x, tile i) exactly once for every tile of the grid (the 256 x 256 first threads take one each)
         const uint32_t w = a * 256u + tid, x = w / kPoolMaxTilesA, i = w % kPoolMaxTilesA;
-        if (tid < 256u && x < 8u && i < ps.tiles_per_stream) {
+        if (x < 8u && i < ps.tiles_per_stream) {
             const uint32_t claims = pool->claim_a[w];
             pool->claim_a[w] = 0;
             if (claims != 1u && pool->armed != 0u) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -361,16 +362,24 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
     // thread t < 256: top byte t's exact total; thread p < 16: piece p of THIS top byte
     uint32_t c_t = 0;
     if (tid < kBins) {
+        if constexpr (GROUPED) {
+            c_t = groups.count[tid];
+        } else {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) c_t += msd->cursor_a[s][tid];
+            for (int s = 0; s < 8; ++s) c_t += msd->cursor_a[s][tid];
+        }
         s_c[tid] = c_t;
     }
     uint32_t plen = 0, pslot = 0;
     if (tid < 16u) {
-        const uint32_t s = tid >> 1;
-        const uint32_t c = msd->cursor_a[s][a], prim = min(c, pool->cap[s][a]);
-        plen = (tid & 1u) ? c - prim : prim;
-        pslot = (tid & 1u) ? n + pool->obase[s][a] : pool->base[s][a];
+        if constexpr (GROUPED) {
+            plen = tid == 0u ? groups.count[a] : 0u;  // (its slot is the top byte's start: known behind the sums below)
+        } else {
+            const uint32_t s = tid >> 1;
+            const uint32_t c = msd->cursor_a[s][a], prim = min(c, pool->cap[s][a]);
+            plen = (tid & 1u) ? c - prim : prim;
+            pslot = (tid & 1u) ? n + pool->obase[s][a] : pool->base[s][a];
+        }
     }
 #pragma unroll
     for (uint32_t q = 0; q < PER; ++q) s_hist[wave][lane + 64u * q] = 0;
@@ -402,8 +411,10 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
                 cend += u;
             }
         }
-        pool->pieces[a][tid] = make_uint2(pend, pslot);
-        s_piece[tid] = make_uint2(plen, pslot);
+        if constexpr (!GROUPED) {
+            pool->pieces[a][tid] = make_uint2(pend, pslot);
+            s_piece[tid] = make_uint2(plen, pslot);
+        }
         s_first[tid] = cend - chunks;
         if (tid == 15u) s_first[16] = cend;
     }
@@ -416,6 +427,14 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
         tiles_before += s_red[2][w];
     }
     const uint32_t c_a = s_c[a];
+    if constexpr (GROUPED) {  // the top byte is one piece of `regions`, at its place in the grouped keys
+        if (tid < 16u) {
+            pool->pieces[a][tid] = make_uint2(c_a, top);
+            s_piece[tid] = make_uint2(tid == 0u ? c_a : 0u, top);
+        }
+        if (a == 0u && tid == 0u) pool->fail = 0;  // (a sort's layout kernel re-arms it; nobody sets it before the second pass here)
+        __syncthreads();
+    }
     // The sample: thread (h, t) = (tid / 256, tid % 256) reads key t of the chunks q = h, h + 2, ..., 32 of them in flight at a time
     // (a piece after the other would be sixteen dependent round trips).  Chunk q belongs to the last piece whose first chunk is <= q.
     const uint32_t chunks_all = s_first[16], half = tid >> 8, t = tid & 255u;
@@ -439,7 +458,8 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
             if (live & (1u << u)) atomicAdd(&s_hist[wave][((k[u] - key_base) >> bshift) & (SUB - 1u)], 1u);
     }
     __syncthreads();
-    if (wave == 0u) {  // lane l = buckets [PER l, PER l + PER) of the top byte
+    const uint32_t top_bytes = GROUPED ? groups.top_bytes : 256u;  // (the tables hold top_bytes << SUBBITS buckets: the workgroups behind them have none)
+    if (wave == 0u && a < top_bytes) {  // lane l = buckets [PER l, PER l + PER) of the top byte
         uint32_t m_b[PER], m = 0;
 #pragma unroll
         for (uint32_t q = 0; q < PER; ++q) {
@@ -473,7 +493,7 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
             pool->sub_cursor[b] = 0;  // the second pass counts from zero
             at += room[q];
         }
-        if (a == 255u && lane == 63u) pool->sub_start[256u * SUB] = at;
+        if (a == top_bytes - 1u && lane == 63u) pool->sub_start[top_bytes * SUB] = at;
     }
     if (tid == 0) {
         pool->top_base[a] = top;
@@ -507,11 +527,15 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
             pool->top_base[256] = all;
             // all != n: keys the first pass did not place (it did not run, or a workgroup left early); the last kPoolTile slots of the
             // slack buffer are where refused runs are dumped
-            pool->ok_a = (pool->armed != 0u && pool->fail == 0u && s_bad == 0u && all == n && shift >= kPoolMinShift && shift <= kPoolMaxShift &&
-                          room <= slack_capacity - kPoolTile)
-                             ? 1u
-                             : 0u;
+            if constexpr (GROUPED)
+                pool->ok_a = (s_bad == 0u && all == n && room <= slack_capacity - kPoolTile) ? 1u : 0u;  // (all != n: the caller's counts are not these keys')
+            else
+                pool->ok_a = (pool->armed != 0u && pool->fail == 0u && s_bad == 0u && all == n && shift >= kPoolMinShift && shift <= kPoolMaxShift &&
+                              room <= slack_capacity - kPoolTile)
+                                 ? 1u
+                                 : 0u;
             // (PoolPlan::fail stays: the second pass may still set it; the next sort's layout kernel re-arms it)
+            if constexpr (GROUPED) pool->shift = shift;
             msd->shift = shift;
             msd->sub_bits = SUBBITS;
             msd->ok = 0;  // the local sort decides
@@ -579,7 +603,7 @@ template <uint32_t SUBBITS>
 __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
                                                              uint32_t *__restrict__ slack, const MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool,
                                                              uint32_t n_virt, uint32_t key_base, uint32_t local_cap, uint32_t dump,
-                                                             unsigned long long xcc_map, uint32_t stamp) {
+                                                             unsigned long long xcc_map, uint32_t stamp, uint32_t grouped) {
     __shared__ ChunkSmem<uint32_t, 16, 8, false> sm;
     // the list follows the XCC this workgroup RUNS on (pool_pass_a_kernel): all tiles of a top byte then meet behind the L2 that
     // holds its 64 cursors, whatever the dispatcher's rotation
@@ -634,17 +658,14 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     const BitsDigit dg{shift + kMsdSubBits - SUBBITS, SUB - 1u, key_base};  // (key_base is a multiple of 2^24 and the bits end at or below bit 24)
     lb.dump = dump;
     lb.pad_keys = d == SUB - 1u ? kPoolTile - valid : 0u;  // (the padding key, key_base - 1, carries the largest digit)
-    lb.above = shift + kMsdBits < 32u ? ~0u << (shift + kMsdBits) : 0u;
-    lb.key_base = key_base;
+    // a sort: no key may have bits above the probed range; grouped keys (the caller's promise): every key of this tile carries top byte a
+    lb.above = grouped ? 0xFF000000u : (shift + kMsdBits < 32u ? ~0u << (shift + kMsdBits) : 0u);
+    lb.key_base = grouped ? key_base + (a << 24) : key_base;
     lb.fail_word = &pool->fail;
     uint32_t unused = 0;
     // (two workgroups of one group of eight on ONE XCC: the tile has been taken twice and another not at all)
     if (threadIdx.x == 0 && claimed == stamp) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef VRS_LAB_ALL_PIECES
-    if (false)
-#else
     if (valid == kPoolTile && src.p1 == src.p0 + 1u)  // a full tile inside one piece: five tiles in six
-#endif
         scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve>(sm, slot0 < n_virt ? regions + slot0 : overflow + (slot0 - n_virt), nullptr, slack, nullptr, valid, dg, unused, lb);
     else if (valid == kPoolTile)
         scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve, PieceSrc>(sm, nullptr, nullptr, slack, nullptr, valid, dg, unused, lb, src);
@@ -706,7 +727,7 @@ __device__ __forceinline__ void slack_sort_bucket(const uint32_t *src, uint32_t 
 #pragma unroll
     for (int v = 0; v < WAVES; ++v) guards |= s_tmp[16 + v];
     guards = __builtin_amdgcn_readfirstlane(guards);
-    if (guards == 0u) lean_sort_body<THREADS, VEC, false, VRS_LAB_STREAM, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false, 0u);
+    if (guards == 0u) lean_sort_body<THREADS, VEC, false, true, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false, 0u);
     else slack_sort_guarded<THREADS, VEC>(src, abase, mis, n, s_keys, s_hist2, s_tmp, guards);
 }
 
@@ -717,14 +738,14 @@ template <int THREADS, int MAXVEC, int WGS, uint32_t SUBBITS>
 __global__ __launch_bounds__(THREADS, WGS *(THREADS / 64) / 4) void pool_local_sort_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out,
                                                                                           MsdPlan *__restrict__ msd, const PoolPlan *__restrict__ pool,
                                                                                           uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
-                                                                                          OnesweepPlanHead *host_head, uint32_t stamp) {
+                                                                                          OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log) {
     constexpr uint32_t SUB = 1u << SUBBITS, PER = SUB / 64u;
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * MAXVEC + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
     __shared__ uint32_t s_tmp[32];
     // the LAST bucket first: the second pass wrote the top bytes in ascending order, the highest are what the memory-side cache
     // still holds (round 4: 215 -> 208 us; first bucket first measured 186-205 instead of 177-181 here)
-    const uint32_t b = 256u * SUB - 1u - blockIdx.x, a = b >> SUBBITS, c = b & (SUB - 1u);
+    const uint32_t b = gridDim.x - 1u - blockIdx.x, a = b >> SUBBITS, c = b & (SUB - 1u);  // (the grid: the top bytes that exist x SUB)
     const uint32_t lane = threadIdx.x & 63u;
     // The bucket's region, its top byte's start and the counters of the top byte's buckets (PER per lane, every wave the same
     // 256 or 512 bytes) are asked for BEFORE the verdict is looked at (all exist whatever it says): a workgroup lives for a few memory latencies.
@@ -744,6 +765,8 @@ __global__ __launch_bounds__(THREADS, WGS *(THREADS / 64) / 4) void pool_local_s
             __hip_atomic_store(&host_head->lsd_missing, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_head->msd_ok, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_head->msd_max_bucket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // (a finish among several enqueued before any is asked about: its decision also goes to the log, vrs_msd_finish_status_at)
+            if (host_log) __hip_atomic_store(&host_log[stamp & (kMsdLogWords - 1u)], (stamp << 1) | ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __threadfence_system();
             __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -814,10 +837,10 @@ uint32_t pool_overflow_capacity(uint32_t n) {
     return static_cast<uint32_t>(std::min<double>(room, 1u << 28)) & ~31u;
 }
 
-uint32_t pool_slack_capacity(uint32_t n, uint32_t sub_bits) {
-    // the plan kernel gives a top byte of c keys c + 6 sqrt(S R (c + S R)) + S (floor + 4) slots (pool_space, S = 2^sub_bits); over 256
-    // top bytes with sum c = n that is at most n + 6 sqrt(256 S R (n + 256 S R)) + 256 S (floor + 4) + rounding (Cauchy-Schwarz), + the dump tile
-    const double R = 40.0, B = 256.0 * static_cast<double>(1u << sub_bits);
+uint32_t pool_slack_capacity(uint32_t n, uint32_t sub_bits, uint32_t top_bytes) {
+    // the plan kernel gives a top byte of c keys c + 6 sqrt(S R (c + S R)) + S (floor + 4) slots (pool_space, S = 2^sub_bits); over T
+    // top bytes with sum c = n that is at most n + 6 sqrt(T S R (n + T S R)) + T S (floor + 4) + rounding (Cauchy-Schwarz), + the dump tile
+    const double R = 40.0, B = static_cast<double>(top_bytes) * static_cast<double>(1u << sub_bits);
     const double room = 6.0 * std::sqrt(B * R * (static_cast<double>(n) + B * R)) + B * (kPoolRoomFloor + 4.0) + 256.0 * 4.0;
     return (static_cast<uint32_t>(std::min<double>(static_cast<double>(n) + room, 3.9e9) + 31.0) & ~31u) + kPoolTile;
 }
@@ -865,46 +888,78 @@ hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint3
 }
 
 hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap, uint32_t slack_capacity,
-                            const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps, uint32_t sub_bits) {
+                            const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps, uint32_t sub_bits,
+                            const PoolGroups *groups) {
     if (ps.tiles_per_stream > kPoolMaxTilesA || tiles_b_cap > kPoolMaxTilesB) return hipErrorInvalidValue;
-    if (sub_bits == 7u)
-        hipLaunchKernelGGL(pool_plan_kernel<7>, dim3(256), dim3(512), 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps);
-    else
-        hipLaunchKernelGGL(pool_plan_kernel<6>, dim3(256), dim3(512), 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps);
+    const dim3 grid(256), block(512);
+    if (groups) {
+        if (sub_bits == 8u) hipLaunchKernelGGL((pool_plan_kernel<8, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups);
+        else if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups);
+        else hipLaunchKernelGGL((pool_plan_kernel<6, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups);
+    } else {
+        const PoolGroups none{};
+        if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none);
+        else hipLaunchKernelGGL((pool_plan_kernel<6, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *slack, uint32_t n, MsdPlan *msd,
                               PoolPlan *pool, uint32_t tiles_b, uint32_t key_base, uint32_t local_cap, uint32_t slack_capacity,
-                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, LaunchEvents ev) {
+                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, LaunchEvents ev, bool grouped) {
     if (tiles_b == 0) return hipSuccess;
     if (tiles_b > kPoolMaxTilesB || stamp == 0u) return hipErrorInvalidValue;
-    if (sub_bits == 7u)
-        VRS_LAUNCH(pool_pass_b_kernel<7>, dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n, key_base, local_cap,
-                   slack_capacity - kPoolTile, xcc_map, stamp);
-    else
-        VRS_LAUNCH(pool_pass_b_kernel<6>, dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n, key_base, local_cap,
-                   slack_capacity - kPoolTile, xcc_map, stamp);
+    // (grouped keys lie in `regions` alone: no slot is an overflow slot)
+    const uint32_t n_virt = grouped ? 0xFFFFFFFFu : n, g = grouped ? 1u : 0u;
+#define VRS_POOL_B(S)                                                                                                                         \
+    VRS_LAUNCH(pool_pass_b_kernel<S>, dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n_virt, key_base, local_cap, \
+               slack_capacity - kPoolTile, xcc_map, stamp, g)
+    if (sub_bits == 8u) VRS_POOL_B(8);
+    else if (sub_bits == 7u) VRS_POOL_B(7);
+    else VRS_POOL_B(6);
+#undef VRS_POOL_B
     return hipGetLastError();
 }
 
 hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
-                                  PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev) {
+                                  PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev,
+                                  uint32_t top_bytes, uint32_t *host_log) {
     (void)n;
     uint32_t *cursors = &msd->cursor_a[0][0];
+    if (top_bytes == 0u || top_bytes > 256u || (top_bytes << shape.sub_bits) > kPoolMaxBuckets) return hipErrorInvalidValue;
 #define VRS_POOL_LOCAL(T, V, W, S)                                                                                                            \
-    VRS_LAUNCH((pool_local_sort_kernel<T, V, W, S>), dim3(256u << S), dim3(T), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head, stamp)
-    if (shape.sub_bits == 7u) {
-        if (shape.local == 0u) VRS_POOL_LOCAL(256, 4, 5, 7);
-        else if (shape.local == 1u) VRS_POOL_LOCAL(256, 7, 4, 7);
-        else VRS_POOL_LOCAL(512, 7, 2, 7);
-    } else {
-        if (shape.local == 0u) VRS_POOL_LOCAL(256, 4, 5, 6);
-        else if (shape.local == 1u) VRS_POOL_LOCAL(256, 7, 4, 6);
-        else VRS_POOL_LOCAL(512, 7, 2, 6);
-    }
+    VRS_LAUNCH((pool_local_sort_kernel<T, V, W, S>), dim3(top_bytes << S), dim3(T), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head, \
+               stamp, host_log)
+#define VRS_POOL_LOCAL_S(S)                                    \
+    do {                                                       \
+        if (shape.local == 0u) VRS_POOL_LOCAL(256, 4, 5, S);   \
+        else if (shape.local == 1u) VRS_POOL_LOCAL(256, 7, 4, S); \
+        else VRS_POOL_LOCAL(512, 7, 2, S);                     \
+    } while (0)
+    if (shape.sub_bits == 8u) VRS_POOL_LOCAL_S(8);
+    else if (shape.sub_bits == 7u) VRS_POOL_LOCAL_S(7);
+    else VRS_POOL_LOCAL_S(6);
+#undef VRS_POOL_LOCAL_S
 #undef VRS_POOL_LOCAL
     return hipGetLastError();
+}
+
+PoolShape pool_grouped_shape(uint32_t n, uint32_t top_bytes) {
+    // S bits below the top byte for the second pass, 24 - S <= 18 for the local sort, top_bytes << S buckets within the plan's tables:
+    // the smallest S whose (uniform) buckets fit a 256-thread local sort, else the largest that fits at all; sub_bits 0 = none does
+    PoolShape best{0u, 0u};
+    for (uint32_t s = 6u; s <= 8u; ++s) {
+        if ((top_bytes << s) > kPoolMaxBuckets) break;
+        const double mean = static_cast<double>(n) / (static_cast<double>(top_bytes) * (1u << s));
+        const uint64_t need = static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u;
+        for (uint32_t local = 0u; local <= 2u; ++local) {
+            if (need > pool_local_capacity(local)) continue;
+            if (best.sub_bits == 0u || (best.local == 2u && local < 2u)) best = PoolShape{s, local};
+            break;
+        }
+        if (best.sub_bits != 0u && best.local < 2u) break;
+    }
+    return best;
 }
 
 }  // namespace vrs
