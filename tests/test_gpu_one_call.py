@@ -208,6 +208,45 @@ def test_one_call_pairs_u64(gpu_context, shift, min_keys):
         b.release()
 
 
+@pytest.mark.parametrize("dist,n", [("uniform", (1 << 22) + 12345), ("44bit", (1 << 22) + 1), ("ties", 5000011), ("sorted", 4500001), ("low32", 4200001),
+                                    ("big_buckets", 70000001)])
+def test_hybrid_form_for_u64_keys_with_payloads(gpu_context, dist, n):
+    """vrs_sort_pairs_u64 in the hybrid form (round 5; the reference's SORT_64_BIT stub, MultiRadixSort.h:10-18, has neither 64-bit
+    keys nor payloads): one counting read, two STABLE MSD passes (look-back), the buckets sorted inside LDS with their payloads
+    -- instead of two groups of four look-back passes.  Equal to a stable argsort, payloads included; plenty of equal keys
+    ("ties": 2^20 distinct values), 32-bit values in 64-bit keys (two LDS passes), buckets beyond the small local sort (7e7 pairs:
+    4270 per bucket)."""
+    ctx, lib = gpu_context, gpu_context.lib
+    rs = np.random.RandomState(n % 1000)
+    keys = make_keys64(n if dist != "big_buckets" else n, "uniform" if dist in ("ties", "big_buckets") else dist, seed=n % 89)
+    if dist == "ties":
+        keys = (keys >> np.uint64(44)) << np.uint64(44)
+    vals = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 23)  # (64-bit keys: half of it)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID, 1)
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(8 * n), keys)
+    v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
+    k1, v1 = vrs.Buffer(ctx, S(8 * n)), vrs.Buffer(ctx, S(4 * n))
+    h0 = hybrid_sorts(ctx)
+    ctx.profileReset()
+    ctx.profileEnable(True)
+    try:
+        ctx.check(lib.vrs_sort_pairs_u64(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+        ok, ov = np.empty(n, np.uint64), np.empty(n, np.uint32)
+        k0.downloadWithStagingBuffer(ok)
+        v0.downloadWithStagingBuffer(ov)
+        stats = {name: launches(ctx, kid) for kid, name in capi.KERNEL_NAMES.items()}
+    finally:
+        ctx.profileEnable(False)
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 0)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ok, keys[order]) and np.array_equal(ov, vals[order])
+    took = hybrid_sorts(ctx) - h0
+    assert took == 1 and stats["local_sort"] == 1 and stats["lookback_scatter"] == 2 and stats["digit_tables"] == 1, stats
+    for b in (k0, k1, v0, v1):
+        b.release()
+
+
 @pytest.mark.parametrize("kind", ["keys", "pairs", "u64"])
 def test_engine_mirror_one_call_flag(gpu_context, kind):
     """engine.MultiRadixSort.m_oneCallSort (C++: engine::MultiRadixSort::m_oneCallSort): same execute(), same checks."""

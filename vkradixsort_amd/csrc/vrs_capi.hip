@@ -891,14 +891,16 @@ static OneReadGeometry one_read_geometry(vrs_context ctx, const vrs_context_t::O
     }
     // the local sort's capacity per bucket; launched blind, the workgroup shape of bare uint32 keys is chosen from N alone
     // (uniform keys: buckets of N / 16384 +- a few per cent)
-    g.local_cap = vrs::msd_local_capacity(pairs || wide);
+    g.local_cap = wide && pairs ? vrs::msd_local_capacity_pairs_u64(false) : vrs::msd_local_capacity(pairs || wide);
     if (st.blind_tail) {
         // uniform keys: N / 16384 + a few per cent -- unless the caller knows better (a sub-range of a larger sort: vrs_msd_finish_u32)
         // (the fullest of 16384 buckets of uniform keys lies 4-4.5 deviations above the mean; one that does not fit after all is a
         // refusal, not an error)
         const double mean = static_cast<double>(n) / vrs::kMsdBucketCount;
         const uint64_t expect = st.bucket_hint ? st.bucket_hint : static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u;
-        if (pairs || wide) {
+        if (pairs && wide) {
+            if (expect <= vrs::msd_local_capacity_pairs_u64(true)) g.local_cap = vrs::msd_local_capacity_pairs_u64(true);
+        } else if (pairs || wide) {
             if (expect <= vrs::msd_local_capacity_pairs_small()) g.local_cap = vrs::msd_local_capacity_pairs_small();
         } else if (expect <= vrs::msd_local_capacity_wave()) {
             g.local_cap = vrs::msd_local_capacity_wave();
@@ -1022,7 +1024,8 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
     uint32_t *clear = clears ? ctx->os_status : nullptr;
     const size_t clear_words = clears ? ctx->os_status_rows * VRS_RADIX_SORT_BINS : 0;
     if (wide)
-        VRS_HIP(ctx, vrs::launch_msd_local_sort_u64(ctx->stream, st.kptr[home], ctx->os_msd_plan, max_bucket, ev, clear, clear_words));
+        VRS_HIP(ctx, vrs::launch_msd_local_sort_u64(ctx->stream, st.kptr[home], ctx->os_msd_plan, max_bucket, ev, clear, clear_words,
+                                                    pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr));
     else
         VRS_HIP(ctx, vrs::launch_msd_local_sort(ctx->stream, static_cast<uint32_t *>(st.kptr[home]),
                                                 pairs ? static_cast<uint32_t *>(st.vptr[home]) : nullptr, ctx->os_msd_plan, max_bucket, ev,
@@ -1056,11 +1059,11 @@ static int one_read_enqueue(vrs_context ctx) {
         const uint32_t set = ctx->os_hybrid_min_keys;
         const uint32_t hybrid_min = set == 0u ? (wide ? 20000000u : pairs ? 25000000u : 13000000u)
                                               : (wide ? set / 2u : pairs ? set / 8u * 5u : set);
-        bool wide_try = wide && !pairs;
+        bool wide_try = wide;  // (with payloads too: round 5)
         if (wide_try && !st.no_hybrid && ctx->os_wide_refused && (++ctx->os_wide_skipped % 16u) != 0u) wide_try = false;
         st.msd_capable = !st.no_hybrid && (key_bytes == 4 || wide_try) && ctx->os_hybrid && ctx->atomic_rank_verified &&
                          ctx->scatter.atomic_rank && n >= hybrid_min && n >= (1u << 22) &&
-                         static_cast<uint64_t>(n) <= 2ull * vrs::kMsdBucketCount * vrs::msd_local_capacity(pairs || wide) &&
+                         static_cast<uint64_t>(n) <= 2ull * vrs::kMsdBucketCount * (wide && pairs ? vrs::msd_local_capacity_pairs_u64(false) : vrs::msd_local_capacity(pairs || wide)) &&
                          (ctx->os_groups == 0 || ctx->os_groups == 8);
         // enqueued completely (enqueue-only calls): like the fast count it implies, only while the context's last hybrid-capable
         // sort of this kind took the form (or always: VRS_TUNE_HYBRID_FAST_COUNT = 2) -- a refusal of a blind tail costs a second

@@ -238,7 +238,8 @@ hipError_t launch_msd_count_u64(hipStream_t stream, const void *keys, uint32_t n
                                 size_t status_words, int compute_units, uint32_t *msd_counts, LaunchEvents ev = {});
 // clear_status / clear_words (a multiple of 4): look-back status words the kernel clears on the side (for the next sort), or nullptr
 hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev = {},
-                                     uint32_t *clear_status = nullptr, size_t clear_words = 0);
+                                     uint32_t *clear_status = nullptr, size_t clear_words = 0, uint32_t *values = nullptr);
+// values: uint32 payloads that follow their 64-bit keys (buckets up to msd_local_capacity_pairs_u64(false) elements)
 // max_bucket: the plan's msd_max_bucket (picks the workgroup shape: 256 threads up to 7165 keys, else 512)
 hipError_t launch_msd_local_sort(hipStream_t stream, uint32_t *keys, uint32_t *values, MsdPlan *msd, uint32_t max_bucket,
                                  LaunchEvents ev = {}, uint32_t *clear_status = nullptr, size_t clear_words = 0);
@@ -247,6 +248,7 @@ uint32_t msd_local_capacity_small();  // bare uint32 keys, 256-thread workgroup:
 uint32_t msd_local_capacity_wave();   // bare uint32 keys, one wave per bucket: 1789
 uint32_t msd_local_capacity(bool pairs_or_wide);  // pairs and 64-bit keys: 13312, uint32 keys: 14333
 uint32_t msd_local_capacity_pairs_small();         // pairs and 64-bit keys, 512-thread workgroup (two per CU): 6656
+uint32_t msd_local_capacity_pairs_u64(bool small); // 64-bit keys with payloads: 4096 (two workgroups per CU) / 6656 (one)
 
 // ---- hybrid form WITHOUT a counting read ("pool" form, vrs_msd_pool.hip; bare uint32 keys): 24 instead of 28 bytes per key.
 // The counting read exists to tell the MSD passes where every bucket's keys go.  Here nothing is counted ahead:

@@ -982,6 +982,83 @@ __global__ __launch_bounds__(THREADS, 4) void msd_local_sort_u64_kernel(uint64_t
 }
 
 
+// 64-bit keys WITH uint32 payloads (vrs_sort_pairs_u64; the reference's SORT_64_BIT stub, MultiRadixSort.h:10-18, has neither): the same
+// passes as local_sort_bucket_u64, every one of them STABLE -- the two MSD passes in front are (look-back), and std::stable_sort is
+// what the result is compared with -- and the payloads follow their keys through LDS.  512 threads x 8 elements (4096 per bucket: 64 KB
+// of LDS, two workgroups per CU) or x 13 (6656: 96 KB, one per CU).
+template <int THREADS, int ITEMS>
+__device__ __forceinline__ void local_sort_bucket_pairs_u64(uint64_t *bucket, uint32_t *bvals, uint32_t n, uint32_t passes, uint64_t *s_keys,
+                                                            uint32_t *s_vals, uint32_t *s_hist, uint32_t *s_tmp) {
+    constexpr int BITS = 9;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint64_t key[ITEMS];
+    uint32_t val[ITEMS];
+    const uint32_t seg = wave * (ITEMS * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t idx = seg + i * 64;
+        key[i] = bucket[idx < n ? idx : n - 1u];
+        val[i] = bvals[idx < n ? idx : n - 1u];
+    }
+    if (passes == 0u) return;  // one distinct key per bucket: the order the stable MSD passes left is the answer
+    bool sorted = false;
+    if (passes > 4u) {
+        // more than 36 low bits: the TOP four digits first, then a look at the neighbours (local_sort_bucket_u64) -- equal keys are
+        // in their arrival order either way, every pass being stable
+        for (uint32_t p_ = passes - 4u; p_ < passes; ++p_)
+            local_pass<THREADS, ITEMS, BITS, true, true, uint64_t>(key, val, s_keys, s_vals, s_hist, s_tmp, BITS * p_, n);
+        int bad = 0;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t idx = seg + i * 64;
+            if (idx + 1u < n) bad |= key[i] > s_keys[idx + 1u] ? 1 : 0;  // s_keys still holds what the last pass left
+        }
+        sorted = __syncthreads_or(bad) == 0;
+    }
+    if (!sorted)
+        for (uint32_t p_ = 0; p_ < passes; ++p_)
+            local_pass<THREADS, ITEMS, BITS, true, true, uint64_t>(key, val, s_keys, s_vals, s_hist, s_tmp, BITS * p_, n);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t idx = seg + i * 64;
+        if (idx < n) {
+            bucket[idx] = key[i];
+            bvals[idx] = val[i];
+        }
+    }
+}
+
+constexpr int kLocalPairsU64Threads = 512, kLocalPairsU64Small = 8, kLocalPairsU64Big = 13;
+constexpr uint32_t kLocalCapPairsU64Small = kLocalPairsU64Threads * kLocalPairsU64Small;  // 4096
+constexpr uint32_t kLocalCapPairsU64 = kLocalPairsU64Threads * kLocalPairsU64Big;         // 6656
+template <int ITEMS_MAX>
+__global__ __launch_bounds__(kLocalPairsU64Threads, 2) void msd_local_sort_pairs_u64_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ values,
+                                                                                           const MsdPlan *__restrict__ msd, StatusClear sc,
+                                                                                           uint32_t *__restrict__ cursors) {
+    constexpr int THREADS = kLocalPairsU64Threads, WAVES = THREADS / 64;
+    constexpr uint32_t CAP = THREADS * ITEMS_MAX;
+    __shared__ uint64_t s_keys[CAP];
+    __shared__ uint32_t s_vals[CAP];
+    __shared__ uint32_t s_hist[WAVES << 9];
+    __shared__ uint32_t s_tmp[1 + WAVES];
+    if (msd->ok == 0u) return;
+    rearm_reservation(cursors, THREADS);
+    clear_status_share(sc, THREADS);
+    const uint32_t bkt = local_sort_bucket_of_block();
+    const uint32_t begin = msd->base[bkt], n = msd->base[bkt + 1] - begin;
+    if (n == 0 || n > CAP) return;
+    const uint32_t passes = (msd->shift + 8u) / 9u;
+    uint64_t *bucket = keys + begin;
+    uint32_t *bvals = values + begin;
+    const uint32_t used = (n + THREADS - 1u) / THREADS;
+    if (used <= 2) local_sort_bucket_pairs_u64<THREADS, 2>(bucket, bvals, n, passes, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 4) local_sort_bucket_pairs_u64<THREADS, 4>(bucket, bvals, n, passes, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 6) local_sort_bucket_pairs_u64<THREADS, 6>(bucket, bvals, n, passes, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 8 || ITEMS_MAX <= 8) local_sort_bucket_pairs_u64<THREADS, 8>(bucket, bvals, n, passes, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 10) local_sort_bucket_pairs_u64<THREADS, ITEMS_MAX >= 10 ? 10 : ITEMS_MAX>(bucket, bvals, n, passes, s_keys, s_vals, s_hist, s_tmp);
+    else local_sort_bucket_pairs_u64<THREADS, ITEMS_MAX>(bucket, bvals, n, passes, s_keys, s_vals, s_hist, s_tmp);
+}
+
 hipError_t launch_msd_plan(hipStream_t stream, uint32_t *msd_counts, MsdPlan *msd, OnesweepPlan *plan_a,
                            OnesweepPlan *plan_lsd, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t n, uint32_t tile,
                            uint32_t tiles_b_cap, uint32_t local_cap, uint32_t *tables, uint32_t group_len, uint32_t tile_cap,
@@ -1004,13 +1081,14 @@ hipError_t launch_msd_pass_b(hipStream_t stream, const void *keys_in, void *keys
                              uint32_t sub_bits, bool reserve, uint32_t *drift) {
     if (tiles_b == 0) return hipSuccess;
     if (sub_bits < 6u || sub_bits > 8u) return hipErrorInvalidValue;
-    if (key_bytes == 8 && values_in != nullptr) return hipErrorInvalidValue;
     const dim3 grid(8 * tiles_b), block(512);
 #define VRS_PASS_B(K, ITEMS, RANK, PAIRS, RESERVE)                                                                         \
     VRS_LAUNCH((msd_pass_b_kernel<K, ITEMS, RANK, PAIRS, RESERVE>), grid, block, stream, ev, static_cast<const K *>(keys_in), \
                static_cast<K *>(keys_out), values_in, values_out, msd, status, xcc_map, spin_budget, key_base, sub_bits, drift)
     // (the hybrid form runs only with the LDS-atomic ranking; bare keys may take their places by reservation)
-    if (key_bytes == 8) {
+    if (key_bytes == 8 && values_in != nullptr) {  // (payloads: stable, by look-back)
+        if (atomic_rank) VRS_PASS_B(uint64_t, 8, RANK_ATOMIC, true, false); else VRS_PASS_B(uint64_t, 8, RANK_BALLOT, true, false);
+    } else if (key_bytes == 8) {
         if (!atomic_rank) VRS_PASS_B(uint64_t, 8, RANK_BALLOT, false, false);
         else if (reserve) VRS_PASS_B(uint64_t, 8, RANK_ATOMIC, false, true);
         else VRS_PASS_B(uint64_t, 8, RANK_ATOMIC, false, false);
@@ -1036,9 +1114,16 @@ hipError_t launch_msd_count_u64(hipStream_t stream, const void *keys, uint32_t n
 }
 
 hipError_t launch_msd_local_sort_u64(hipStream_t stream, void *keys, MsdPlan *msd, uint32_t max_bucket, LaunchEvents ev,
-                                     uint32_t *clear_status, size_t clear_words) {
-    if (max_bucket > kLocalCapBig) return hipErrorInvalidValue;  // the plan would have refused
+                                     uint32_t *clear_status, size_t clear_words, uint32_t *values) {
+    if (max_bucket > (values ? kLocalCapPairsU64 : kLocalCapBig)) return hipErrorInvalidValue;  // the plan would have refused
     const StatusClear sc{reinterpret_cast<uint4 *>(clear_status), static_cast<uint32_t>(clear_words / 4)};
+    if (values != nullptr) {
+        if (max_bucket > kLocalCapPairsU64Small)
+            VRS_LAUNCH(msd_local_sort_pairs_u64_kernel<kLocalPairsU64Big>, dim3(kMsdBuckets), dim3(kLocalPairsU64Threads), stream, ev, static_cast<uint64_t *>(keys), values, msd, sc, &msd->cursor_a[0][0]);
+        else
+            VRS_LAUNCH(msd_local_sort_pairs_u64_kernel<kLocalPairsU64Small>, dim3(kMsdBuckets), dim3(kLocalPairsU64Threads), stream, ev, static_cast<uint64_t *>(keys), values, msd, sc, &msd->cursor_a[0][0]);
+        return hipGetLastError();
+    }
     if (max_bucket > kLocalCap)
         VRS_LAUNCH(msd_local_sort_u64_kernel<kLocalPairThreadsBig>, dim3(kMsdBuckets), dim3(kLocalPairThreadsBig), stream, ev, static_cast<uint64_t *>(keys), msd, sc, &msd->cursor_a[0][0]);
     else
@@ -1067,5 +1152,6 @@ uint32_t msd_local_capacity_small() { return kLeanCap; }
 uint32_t msd_local_capacity_wave() { return kWaveCap; }
 uint32_t msd_local_capacity(bool pairs_or_wide) { return pairs_or_wide ? kLocalCapBig : kLeanBigCap; }
 uint32_t msd_local_capacity_pairs_small() { return kLocalCap; }
+uint32_t msd_local_capacity_pairs_u64(bool small) { return small ? kLocalCapPairsU64Small : kLocalCapPairsU64; }
 
 }  // namespace vrs
