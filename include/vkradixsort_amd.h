@@ -443,6 +443,10 @@ int vrs_one_call_hybrid_recounts(vrs_context ctx, uint64_t *recounts);
 /* One-call sorts of bare uint32 keys that took the pool form (the hybrid form without a counting read, VRS_TUNE_MSD_POOL), and
  * sorts whose pool form the plan refused (they ran in the counted form afterwards).  Cumulative; diagnostics only. */
 int vrs_one_call_pool_sorts(vrs_context ctx, uint64_t *pool_sorts, uint64_t *pool_refusals);
+/* sorts of the pool form whose local sort was enqueued a second time in a larger workgroup shape: the shape is chosen from
+   num_elements alone (the form is enqueued blind), and a bucket of skewed keys may hold more than it takes -- no refusal, the bucket
+   lies whole in its slack region; the settle asks for the larger shape (one more kernel, one more host round trip) */
+int vrs_one_call_pool_retries(vrs_context ctx, uint64_t *retries);
 /* The forms of the one-call sorts that share L2-resident words between workgroups rest on where the blocks of a launch run
    ("block b on the XCC of place b % 8 of the probed order"), which the context probes when it is created.  Observed on MI355X: the
    dispatcher's round-robin starts at an XCC of the hardware queue's own, and a HIP stream may move to another queue -- the probed

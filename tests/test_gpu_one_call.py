@@ -12,6 +12,16 @@ import vkradixsort_amd as vrs
 from vkradixsort_amd import capi
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def pool_form_from_its_round_4_threshold(gpu_context):
+    """The subjects of this file are the LSD form and the counted hybrid form at test sizes of a few million keys.  Since round 5 the
+    pool form takes bare uint32 keys from 2^22 on (tests/test_gpu_pool.py): here it keeps round 4's threshold on the shared context,
+    so that the sizes below reach the forms they are about and 10^8 keys still take the pool form."""
+    gpu_context.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 32000000)
+    yield
+    gpu_context.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 1 << 22)
 S = vrs.Buffer.BufferSettings
 
 

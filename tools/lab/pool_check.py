@@ -105,6 +105,7 @@ def run_time(n, reps):
         src = [vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), k) for k in keys]
         bat = [vrs.Buffer(gpu, S(4 * n)) for _ in range(reps)]
         k1 = vrs.Buffer(gpu, S(4 * n))
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, 1 << 22)  # (mode 0: whatever the library takes without the pool form)
         for mode in (2, 0, 2, 0):
             gpu.setTuning(capi.VRS_TUNE_MSD_POOL, mode)
             for timed in (False, True, True):

@@ -111,8 +111,8 @@ struct vrs_context_t {
     uint32_t os_pool_overflow_cap = 0;     //   keys they hold
     uint32_t *os_pool_slack = nullptr;     // the buckets' regions the second pass scatters into (about 1.5 n slots)
     uint32_t os_pool_slack_cap = 0;        //   slots
-    uint64_t os_pool_sorts = 0, os_pool_refusals = 0;
-    uint32_t os_pool_min_keys = 32000000u;  // VRS_TUNE_MSD_POOL_MIN_KEYS
+    uint64_t os_pool_sorts = 0, os_pool_refusals = 0, os_pool_retries = 0;  // (retries: sorts whose local sort was enqueued again in a larger shape)
+    uint32_t os_pool_min_keys = 1u << 22;   // VRS_TUNE_MSD_POOL_MIN_KEYS: the form's own floor -- with one wave per small bucket it beats the LSD passes from there on (labs/r05_pool_form.txt section 6)
     int os_pool_sub_bits = 0;               // VRS_TUNE_MSD_POOL_SUB_BITS: 0 = by size (pool_shape), 6 or 7
     bool os_cursors_open = false;        // a reserving pass may have run without the local sort that re-arms its counters behind it
                                          // (a refused plan, a partition with no finish, an error in between): cleared before the next use
@@ -129,6 +129,8 @@ struct vrs_context_t {
         uint32_t blind_passes = 0;
         bool msd_capable = false, fast_count = false, blind_tail = false, no_hybrid = false;
         bool pool = false, no_pool = false;  // the pool form is on the stream / was refused for this sort
+        uint32_t pool_sub_bits = 0, pool_local = 0;  // its shape; pool_retried: a larger local sort has been enqueued behind a first one that left
+        bool pool_retried = false;
         size_t ev_lb_before = 0, ev_ls_before = 0;
         uint32_t key_base = 0;      // vrs_sort_keys_u32_ranged: every key is promised to be >= this (a multiple of 2^24)
         uint32_t bucket_hint = 0;   // blind tail: expected largest bucket (0 = from n); picks the local sort's workgroup shape
@@ -1060,9 +1062,13 @@ static int one_read_enqueue(vrs_context ctx) {
         const uint32_t hybrid_min = set == 0u ? (wide ? 20000000u : pairs ? 25000000u : 13000000u)
                                               : (wide ? set / 2u : pairs ? set / 8u * 5u : set);
         bool wide_try = wide;  // (with payloads too: round 5)
+        // bare uint32 keys the pool form may take: from ITS threshold on (below the counted form's: its first half costs a sample,
+        // not a counting read)
+        const bool pool_size = !pairs && !wide && !st.no_pool && ctx->os_pool != 0 && reserves(ctx, n, false) && n >= ctx->os_pool_min_keys &&
+                               n <= vrs::kPoolMaxKeys && (ctx->os_pool == 2 || ctx->os_pool_skip == 0 || n / 2u > ctx->os_pool_skip_n || n < ctx->os_pool_skip_n / 2u);
         if (wide_try && !st.no_hybrid && ctx->os_wide_refused && (++ctx->os_wide_skipped % 16u) != 0u) wide_try = false;
         st.msd_capable = !st.no_hybrid && (key_bytes == 4 || wide_try) && ctx->os_hybrid && ctx->atomic_rank_verified &&
-                         ctx->scatter.atomic_rank && n >= hybrid_min && n >= (1u << 22) &&
+                         ctx->scatter.atomic_rank && (n >= hybrid_min || pool_size) && n >= (1u << 22) &&
                          static_cast<uint64_t>(n) <= 2ull * vrs::kMsdBucketCount * (wide && pairs ? vrs::msd_local_capacity_pairs_u64(false) : vrs::msd_local_capacity(pairs || wide)) &&
                          (ctx->os_groups == 0 || ctx->os_groups == 8);
         // enqueued completely (enqueue-only calls): like the fast count it implies, only while the context's last hybrid-capable
@@ -1206,6 +1212,9 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     const uint32_t n = st.n;
     int rc;
     const vrs::PoolShape shape = vrs::pool_shape(n, ctx->os_pool_sub_bits);
+    st.pool_sub_bits = shape.sub_bits;
+    st.pool_local = shape.local;
+    st.pool_retried = false;
     const uint32_t room = vrs::pool_overflow_capacity(n), slack = vrs::pool_slack_capacity(n, shape.sub_bits);
     if ((rc = pool_scratch(ctx, room, slack))) return rc;
     if ((rc = reservation_begin(ctx))) return rc;  // the first pass's cursors: zero
@@ -1271,6 +1280,26 @@ static int one_read_complete(vrs_context ctx, bool *done) {
             ctx->os_hybrid_sorts++;
             ctx->os_pool_sorts++;
             return finish();
+        }
+        if (head.msd_max_bucket != 0u && !st.pool_retried) {
+            // Not refused, only misjudged: a bucket has more keys than the local sort that was enqueued blind takes (its shape came from
+            // n alone; skewed keys).  Every bucket lies whole in its region: a local sort of a larger shape finishes the sort.
+            uint32_t local = 4u;
+            for (uint32_t cand : {0u, 1u, 2u})
+                if (local == 4u && head.msd_max_bucket <= vrs::pool_local_capacity(cand)) local = cand;
+            if (local != 4u) {
+                vrs::LaunchEvents ev;
+                if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
+                if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
+                st.stamp = ctx->os_stamp;
+                st.pool_retried = true;
+                st.pool_local = local;
+                ctx->os_pool_retries++;
+                VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, static_cast<uint32_t *>(st.kptr[st.cur_at_start]), n, ctx->os_msd_plan,
+                                                         ctx->os_pool_plan, vrs::PoolShape{st.pool_sub_bits, local}, &ctx->os_plan->head, ctx->os_host_head_dev,
+                                                         st.stamp, ev, 256, nullptr, true));
+                return VRS_OK;  // (still active: the settle waits for this one's word)
+            }
         }
         // Refused: no key of the caller's buffer has moved (the passes wrote the partner and the context's scratch only; the
         // local sort left at once).  Hand the events of what left at once back (what ran stays on the books: the two
@@ -1967,6 +1996,12 @@ int vrs_one_call_pool_sorts(vrs_context ctx, uint64_t *pool_sorts, uint64_t *poo
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     if (pool_sorts) *pool_sorts = ctx->os_pool_sorts;
     if (pool_refusals) *pool_refusals = ctx->os_pool_refusals;
+    return VRS_OK;
+}
+
+int vrs_one_call_pool_retries(vrs_context ctx, uint64_t *retries) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (retries) *retries = ctx->os_pool_retries;
     return VRS_OK;
 }
 

@@ -427,7 +427,7 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     // leave the memory-side cache to what the pass WRITES (the next kernel reads that): 10^8 keys, contract scatter 138 -> 128 us, the
     // MSD passes 146 -> 140, the pool form's first pass 154 -> 143; below about 3e7 keys everything fits the caches and it costs a
     // little instead (10^7 keys: 0.108 -> 0.111 ms), so the callers switch it by size
-    if (FULL && !SRC::kEnabled && (LB::kPool || stream_in)) {
+    if (FULL && !SRC::kEnabled && stream_in) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) key[i] = __builtin_nontemporal_load(kin + seg + i * 64);
         if constexpr (PAIRS) {

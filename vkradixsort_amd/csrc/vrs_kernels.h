@@ -282,10 +282,13 @@ struct PoolStreams {                           // the eight slices of the input 
 struct PoolPlan {
     uint32_t shift;             // bucket = (key - key_base) >> shift: the top 14 bits of the probed key range
     uint32_t armed;             // 1 = the sample kernel laid the regions out: the first pass runs
-    uint32_t fail;              // a pass: a region overflowed / a key outside the probed range / a workgroup behind the wrong L2 (re-armed by the layout kernel)
+    uint32_t fail;              // bit 0: a pass found a region out of room / a key outside the probed range / a workgroup behind an unknown L2 / a tile
+                                //   claimed twice: the sort is refused; bit 1: a bucket has more keys than the local sort that was enqueued takes
+                                //   (it lies whole in its region: a local sort of a larger shape can still finish the sort).  Re-armed by the layout kernel
     uint32_t ticket;            // (unused)
     uint32_t ok_a;              // verdict 1 (plan kernel): the second pass runs
-    uint32_t pad[3];
+    uint32_t max_bucket;        // second pass: the fullest bucket AMONG those beyond the enqueued local sort's capacity (zero if none; re-armed by the plan kernel)
+    uint32_t pad[2];
     uint32_t sample[8][256];    // sampled keys of (slice, top byte), zero between sorts
     uint32_t base[8][256];      // primary region of (slice, top byte): first slot in the partner buffer
     uint32_t cap[8][256];       //   its slots
@@ -309,7 +312,7 @@ uint32_t pool_slack_capacity(uint32_t n, uint32_t sub_bits, uint32_t top_bytes =
 // The shape of a pool sort, chosen from n alone (the form is enqueued blind): bits of the second pass and the local sort's workgroup.
 struct PoolShape {
     uint32_t sub_bits;   // 6 or 7
-    uint32_t local;      // 0: 256 threads x 16 slots (up to 4093 keys per bucket, five workgroups per CU), 1: 256 x 28 (7165, four), 2: 512 x 28 (14333, two)
+    uint32_t local;      // 4 / 3: one WAVE per bucket (up to 1021 / 1789 keys), 0: 256 threads x 16 slots (4093, five workgroups per CU), 1: 256 x 28 (7165, four), 2: 512 x 28 (14333, two)
 };
 PoolShape pool_shape(uint32_t n, int forced_sub_bits = 0);  // forced_sub_bits: 0 = by size, 6 or 7
 // the second half alone, for n keys grouped by `top_bytes` top bytes: sub_bits 6 .. 8 (0: no shape takes them)
@@ -343,7 +346,8 @@ hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const
 // (msd_ok, lsd_missing = 1, stamped last); re-arms the first pass's reservation counters
 hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
                                   PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev = {},
-                                  uint32_t top_bytes = 256, uint32_t *host_log = nullptr);
+                                  uint32_t top_bytes = 256, uint32_t *host_log = nullptr, bool retry = false);
+// retry: the second attempt after a first local sort found a bucket beyond its shape (PoolPlan::fail bit 1): that bit no longer refuses
 // top_bytes: the top bytes that exist (a sort: 256; the second half alone: the caller's); host_log: see launch_msd_plan
 
 // out[b] = HW_REG_XCC_ID of block b of a `blocks`-block grid of 512-thread workgroups

@@ -656,31 +656,8 @@ constexpr uint32_t kLeanCap = 256u * 4u * kLeanMaxVec - 3u, kLeanBigCap = 512u *
 // on barriers with their lanes mostly empty.  The same two 9-bit passes and the same slot / dummy-counter scheme as
 // lean_sort_bucket, one 512-counter table reused by both passes (a single wave ranks in instruction, then lane order: stable).
 // What made 10^7 keys worth the hybrid form: 16384 buckets of 610 keys take 16 us here, 60 us with 256 threads per bucket.
-__device__ __forceinline__ void wave_phase() {  // orders this wave's LDS traffic for the compiler; the hardware keeps it in order anyway
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// exclusive prefix of the 512 byte-counters of a wave's table, 8 per lane, starting at `start`
-__device__ __forceinline__ void wave_scan512(uint32_t *tbl, uint32_t lane, uint32_t start) {
-    uint4 a = reinterpret_cast<uint4 *>(tbl)[2 * lane], b = reinterpret_cast<uint4 *>(tbl)[2 * lane + 1];
-    const uint32_t s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-    uint32_t incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o);
-        if (lane >= static_cast<uint32_t>(o)) incl += t;
-    }
-    uint32_t acc = incl - s + start;
-    uint4 oa, ob;
-    oa.x = acc; acc += a.x; oa.y = acc; acc += a.y; oa.z = acc; acc += a.z; oa.w = acc; acc += a.w;
-    ob.x = acc; acc += b.x; ob.y = acc; acc += b.y; ob.z = acc; acc += b.z; ob.w = acc;
-    reinterpret_cast<uint4 *>(tbl)[2 * lane] = oa;
-    reinterpret_cast<uint4 *>(tbl)[2 * lane + 1] = ob;
-}
-template <int VEC, bool GUARD>
-__device__ __forceinline__ void wave_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
-                                               uint32_t *tbl, bool guard1, bool guard2);
+// (wave_phase, wave_scan512, wave_sort_body: vrs_local_sort.hpp)
+
 template <int VEC>
 __device__ __attribute__((noinline)) void wave_sort_guarded(uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *tbl,
                                                            uint32_t skew);
@@ -717,7 +694,7 @@ __device__ __forceinline__ void wave_sort_bucket(uint32_t *abase, uint32_t mis, 
     }
     skew = __builtin_amdgcn_readfirstlane(skew);
     wave_phase();
-    if (skew == 0u) wave_sort_body<VEC, false>(k, abase, mis, n, s_keys, tbl, false, false);
+    if (skew == 0u) wave_sort_body<VEC, false>(k, abase, mis, n, s_keys, tbl, false, false, mis);
     else wave_sort_guarded<VEC>(abase, mis, n, s_keys, tbl, skew);  // out of line, loads the bucket again: see lean_sort_bucket
 }
 
@@ -738,115 +715,9 @@ __device__ __attribute__((noinline)) void wave_sort_guarded(uint32_t *abase, uin
         k[4 * j + 2] = t.z;
         k[4 * j + 3] = t.w;
     }
-    wave_sort_body<VEC, true>(k, abase, mis, n, s_keys, tbl, (skew & 1u) != 0u, (skew & 2u) != 0u);
+    wave_sort_body<VEC, true>(k, abase, mis, n, s_keys, tbl, (skew & 1u) != 0u, (skew & 2u) != 0u, mis);
 }
 
-template <int VEC, bool GUARD>
-__device__ __forceinline__ void wave_sort_body(uint32_t (&k)[4 * VEC], uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
-                                               uint32_t *tbl, bool guard1, bool guard2) {
-    constexpr int ITEMS = 4 * VEC;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t end = mis + n, nvec = (end + 3u) / 4u;
-    uint32_t rank[ITEMS];
-    char *tb = reinterpret_cast<char *>(tbl);
-    const auto zero_table = [&] {
-        reinterpret_cast<uint4 *>(tbl)[2 * lane] = make_uint4(0, 0, 0, 0);
-        reinterpret_cast<uint4 *>(tbl)[2 * lane + 1] = make_uint4(0, 0, 0, 0);
-        if (lane < 16u) reinterpret_cast<uint4 *>(tbl)[128 + lane] = make_uint4(0, 0, 0, 0);
-    };
-    const auto ranked_add = [&](uint32_t a, bool guard) -> uint32_t {
-        uint32_t *counter = reinterpret_cast<uint32_t *>(tb + a);
-        if (GUARD && guard) {
-            const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
-            if (__ballot(a == a0) == ~0ull) {
-                uint32_t old = 0;
-                if (lane == 0u) old = __hip_atomic_fetch_add(counter, 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                return __builtin_amdgcn_readfirstlane(old) + 4u * lane;
-            }
-        }
-        return __hip_atomic_fetch_add(counter, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    // ---- pass 1: low 9 bits (any order of ties)
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        uint32_t a = (k[i] << 2) & 0x7FCu;
-        if (i < 4 || i >= ITEMS - 4) {
-            const uint32_t q = 4u * ((i >> 2) * 64 + lane) + (i & 3);
-            a = (q - mis < n) ? a : 2048u + 4u * lane;
-        }
-        rank[i] = ranked_add(a, guard1);
-    }
-    wave_phase();
-    wave_scan512(tbl, lane, 0u);
-    wave_phase();
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        uint32_t a = (opaque(k[i]) << 2) & 0x7FCu;
-        if (i < 4 || i >= ITEMS - 4) {
-            const uint32_t q = 4u * ((i >> 2) * 64 + lane) + (i & 3);
-            const bool valid = q - mis < n;
-            a = valid ? a : 2048u + 4u * lane;
-            const uint32_t r = rank[i] + *reinterpret_cast<const uint32_t *>(tb + a);
-            rank[i] = valid ? r : 4u * (q < mis ? n + q : q);
-            continue;
-        }
-        rank[i] += *reinterpret_cast<const uint32_t *>(tb + a);
-    }
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t Lb = rank[i];
-        const uint32_t ph = (Lb & ~1023u) | ((Lb & 252u) << 2) | ((Lb >> 6) & 12u);
-        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_keys) + ph) = k[i];
-    }
-    wave_phase();
-    zero_table();  // behind pass 1's base reads in the LDS queue
-#pragma unroll
-    for (int g = 0; g < VEC; ++g) {
-        const uint4 t = reinterpret_cast<const uint4 *>(s_keys + g * 256)[lane];
-        k[4 * g] = t.x;
-        k[4 * g + 1] = t.y;
-        k[4 * g + 2] = t.z;
-        k[4 * g + 3] = t.w;
-    }
-    wave_phase();
-    // ---- pass 2: high 9 bits, stable (instruction order, then lane order); any slot may be empty here: a bucket of a few rows
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        uint32_t a = (k[i] >> 7) & 0x7FCu;
-        a = (i * 64 + lane < n) ? a : 2048u + 4u * lane;
-        rank[i] = ranked_add(a, guard2);
-    }
-    wave_phase();
-    wave_scan512(tbl, lane, 4u * mis);
-    wave_phase();
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t L = i * 64 + lane;
-        uint32_t a = (opaque(k[i]) >> 7) & 0x7FCu;
-        a = L < n ? a : 2048u + 4u * lane;
-        const uint32_t r = rank[i] + *reinterpret_cast<const uint32_t *>(tb + a);
-        rank[i] = L < n ? r : 4u * (mis + L);
-    }
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_keys) + rank[i]) = k[i];
-    wave_phase();
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        const uint32_t v = j * 64 + lane;
-        if (v < nvec) {
-            const uint4 q4 = reinterpret_cast<const uint4 *>(s_keys)[v];
-            const uint32_t q = 4u * v;
-            if (q >= mis && q + 4u <= end) {
-                reinterpret_cast<uint4 *>(abase)[v] = q4;
-            } else {
-                if (q + 0u - mis < n) abase[q + 0u] = q4.x;
-                if (q + 1u - mis < n) abase[q + 1u] = q4.y;
-                if (q + 2u - mis < n) abase[q + 2u] = q4.z;
-                if (q + 3u - mis < n) abase[q + 3u] = q4.w;
-            }
-        }
-    }
-}
 constexpr uint32_t kWaveCap = 64u * 4u * kLeanMaxVec - 3u;  // 1789 keys
 __global__ __launch_bounds__(64, 4) void msd_local_sort_wave_kernel(uint32_t *__restrict__ keys, const MsdPlan *__restrict__ msd, StatusClear sc,
                                                                   uint32_t *__restrict__ cursors) {

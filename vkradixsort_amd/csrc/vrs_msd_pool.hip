@@ -310,7 +310,8 @@ __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__r
     lb.fail_word = &pool->fail;
     uint32_t unused = 0;
     if (valid == kPoolTile)
-        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true>(sm, kin, nullptr, keys_out, nullptr, valid, dg, unused, lb);
+        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true>(sm, kin, nullptr, keys_out, nullptr, valid, dg, unused, lb, NoPieces{},
+                                                                 static_cast<size_t>(n) * sizeof(uint32_t) >= kStreamInBytes);  // (inputs beyond the caches: vrs_device.hpp)
     else
         scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, false>(sm, kin, nullptr, keys_out, nullptr, valid, dg, unused, lb);
 }
@@ -535,6 +536,7 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
                                  ? 1u
                                  : 0u;
             // (PoolPlan::fail stays: the second pass may still set it; the next sort's layout kernel re-arms it)
+            pool->max_bucket = 0;
             if constexpr (GROUPED) pool->shift = shift;
             msd->shift = shift;
             msd->sub_bits = SUBBITS;
@@ -561,7 +563,9 @@ struct SlackReserve {
     uint32_t done = 0;
     uint32_t seed = 0;
     uint32_t *cursor = nullptr;      // this thread's bucket's cursor
-    uint32_t start = 0, cap = 0;     // the bucket's region: first slot, slots the sort may use
+    uint32_t start = 0, cap = 0;     // the bucket's region: first slot, its slots
+    uint32_t local_cap = 0;          // keys the enqueued local sort takes per bucket
+    uint32_t *max_bucket = nullptr;
     uint32_t dump = 0;               // first slot of the dump tile
     uint32_t pad_keys = 0;
     uint32_t above = 0, key_base = 0;  // bits no key of the probed range has
@@ -579,8 +583,16 @@ struct SlackReserve {
     __device__ __forceinline__ uint32_t resolve(uint32_t (&)[kLbBatch], bool &) const { return reserved; }
     // run [reserved, reserved + cnt) of the region; excl: where the digit's run starts inside the tile
     __device__ __forceinline__ void place(uint32_t *gbase, uint32_t tid, uint32_t, uint32_t excl) const {
-        const bool bad = cnt != 0u && reserved + cnt > cap;
-        if (bad) __hip_atomic_fetch_or(fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t end = reserved + cnt;
+        const bool bad = cnt != 0u && end > cap;
+        if (bad) {
+            __hip_atomic_fetch_or(fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (cnt != 0u && end > local_cap) {
+            // in its region, but more than the local sort enqueued behind this pass takes: that one leaves at once, and a larger one
+            // can finish the sort (the host asks for it when it sees this)
+            __hip_atomic_fetch_or(fail_word, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(max_bucket, end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         gbase[tid] = (bad ? dump : start + reserved) - excl;
     }
     template <typename K, int ITEMS, uint32_t THREADS, bool FULL, typename DG>
@@ -635,8 +647,10 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     lb.cursor = &pool->sub_cursor[b];
     if (threadIdx.x < SUB) {  // (the threads that reserve: one per bucket of the top byte)
         lb.start = pool->sub_start[b];
-        lb.cap = min(pool->sub_start[b + 1u] - lb.start, local_cap);
+        lb.cap = pool->sub_start[b + 1u] - lb.start;
     }
+    lb.local_cap = local_cap;
+    lb.max_bucket = &pool->max_bucket;
     const uint32_t pend = pc.x, pslot = pc.y;
     const uint32_t before = __shfl_up(pend, 1);
     const uint32_t plo = lane == 0u ? 0u : before;  // the piece holds positions [plo, pend) of the top byte
@@ -666,7 +680,8 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     // (two workgroups of one group of eight on ONE XCC: the tile has been taken twice and another not at all)
     if (threadIdx.x == 0 && claimed == stamp) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (valid == kPoolTile && src.p1 == src.p0 + 1u)  // a full tile inside one piece: five tiles in six
-        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve>(sm, slot0 < n_virt ? regions + slot0 : overflow + (slot0 - n_virt), nullptr, slack, nullptr, valid, dg, unused, lb);
+        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve>(sm, slot0 < n_virt ? regions + slot0 : overflow + (slot0 - n_virt), nullptr, slack, nullptr, valid, dg, unused, lb, NoPieces{},
+                                                                                         static_cast<size_t>(pool->top_base[256]) * sizeof(uint32_t) >= kStreamInBytes);
     else if (valid == kPoolTile)
         scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve, PieceSrc>(sm, nullptr, nullptr, slack, nullptr, valid, dg, unused, lb, src);
     else  // the top byte's ragged last tile
@@ -731,20 +746,16 @@ __device__ __forceinline__ void slack_sort_bucket(const uint32_t *src, uint32_t 
     else slack_sort_guarded<THREADS, VEC>(src, abase, mis, n, s_keys, s_hist2, s_tmp, guards);
 }
 
-// Shapes: THREADS x 4 MAXVEC slots -- 256 x 16 (buckets up to 4093 keys: 28 KB of LDS, five workgroups per CU), 256 x 28 (7165 keys,
-// four per CU), 512 x 28 (14333 keys, two per CU).  A workgroup lives for two memory round trips (its bucket's words, its keys) on
-// top of the sort itself -- about 3.8 us of an 11 us life at 6100 keys -- so more, smaller workgroups per CU keep the LDS pipe busier.
-template <int THREADS, int MAXVEC, int WGS, uint32_t SUBBITS>
-__global__ __launch_bounds__(THREADS, WGS *(THREADS / 64) / 4) void pool_local_sort_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out,
-                                                                                          MsdPlan *__restrict__ msd, const PoolPlan *__restrict__ pool,
-                                                                                          uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
-                                                                                          OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log) {
+// What every workgroup of a local sort does first, whatever its shape: workgroup w = bucket (buckets - 1 - w) -- the LAST bucket
+// first: the second pass wrote the top bytes in ascending order, the highest are what the memory-side cache still holds (round 4:
+// 215 -> 208 us; first bucket first measured 186-205 instead of 177-181 here).  False: nothing to sort (the verdict said no, the
+// bucket is empty).
+template <int THREADS, uint32_t CAPACITY, uint32_t SUBBITS>
+__device__ __forceinline__ bool pool_bucket(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out, MsdPlan *__restrict__ msd,
+                                            const PoolPlan *__restrict__ pool, uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
+                                            OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log, uint32_t retry, const uint32_t *&src,
+                                            uint32_t *&abase, uint32_t &mis, uint32_t &n) {
     constexpr uint32_t SUB = 1u << SUBBITS, PER = SUB / 64u;
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * MAXVEC + 4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
-    __shared__ uint32_t s_tmp[32];
-    // the LAST bucket first: the second pass wrote the top bytes in ascending order, the highest are what the memory-side cache
-    // still holds (round 4: 215 -> 208 us; first bucket first measured 186-205 instead of 177-181 here)
     const uint32_t b = gridDim.x - 1u - blockIdx.x, a = b >> SUBBITS, c = b & (SUB - 1u);  // (the grid: the top bytes that exist x SUB)
     const uint32_t lane = threadIdx.x & 63u;
     // The bucket's region, its top byte's start and the counters of the top byte's buckets (PER per lane, every wave the same
@@ -755,28 +766,33 @@ __global__ __launch_bounds__(THREADS, WGS *(THREADS / 64) / 4) void pool_local_s
     const uint32_t start = pool->sub_start[b], top = pool->top_base[a];
     // Verdict 2, by every workgroup from the same two words (final when this kernel starts): verdict 1 said yes and no pass flagged
     // the sort (a region out of room, a bucket above this kernel's capacity, a key outside the probed range).  Workgroup 0 tells the host.
-    const uint32_t ok = (pool->ok_a != 0u && pool->fail == 0u) ? 1u : 0u;
+    // A bucket beyond THIS kernel's shape (fail bit 1; the shape was chosen from n alone) is no refusal of the form: the bucket lies
+    // whole in its region, this kernel leaves, and the host -- told the bucket's size -- enqueues a larger shape (retry: that second one).
+    const uint32_t flags = pool->fail, mx = pool->max_bucket;
+    const uint32_t ok = (pool->ok_a != 0u && (flags & (retry ? 1u : 3u)) == 0u && (retry == 0u || mx <= CAPACITY - 3u)) ? 1u : 0u;
+    const uint32_t again = (ok == 0u && retry == 0u && pool->ok_a != 0u && flags == 2u) ? mx : 0u;  // != 0: a larger local sort finishes the sort
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         msd->ok = ok;
         dev_head->msd_ok = ok;
-        dev_head->msd_max_bucket = 0;
+        dev_head->msd_max_bucket = again;
         dev_head->lsd_missing = 1u;
         if (host_head) {
             __hip_atomic_store(&host_head->lsd_missing, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_head->msd_ok, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&host_head->msd_max_bucket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_head->msd_max_bucket, again, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             // (a finish among several enqueued before any is asked about: its decision also goes to the log, vrs_msd_finish_status_at)
             if (host_log) __hip_atomic_store(&host_log[stamp & (kMsdLogWords - 1u)], (stamp << 1) | ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __threadfence_system();
             __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (ok == 0u) return;  // (enqueued before the verdicts were known, and one said no)
+    if (ok == 0u) return false;  // (enqueued before the verdicts were known, and one said no)
     // the first pass's cursors, zero for the next sort (the counted form's local sort does the same: rearm_reservation)
     if (blockIdx.x < 2u * kStreams)
         for (uint32_t q = threadIdx.x; q < 256u; q += THREADS) cursors[blockIdx.x * 256u + q] = 0;
     // keys of the top byte's buckets before this one (every wave sums the counters below c), and this bucket's own
-    uint32_t before = 0, n = 0;
+    uint32_t before = 0;
+    n = 0;
 #pragma unroll
     for (uint32_t q = 0; q < PER; ++q) {
         before += 64u * q + lane < c ? cnt[q] : 0u;
@@ -786,10 +802,27 @@ __global__ __launch_bounds__(THREADS, WGS *(THREADS / 64) / 4) void pool_local_s
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o);
     const uint32_t begin = top + __builtin_amdgcn_readfirstlane(before);
-    const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys_out + begin) >> 2) & 3u);
-    if (n == 0 || mis + n > THREADS * 4u * MAXVEC) return;  // uniform; above the capacity cannot happen (the second pass would have flagged it)
-    uint32_t *abase = keys_out + begin - mis;
-    const uint32_t *src = slack + start;
+    mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys_out + begin) >> 2) & 3u);
+    if (n == 0 || mis + n > CAPACITY) return false;  // uniform; above the capacity cannot happen (the second pass would have flagged it)
+    abase = keys_out + begin - mis;
+    src = slack + start;
+    return true;
+}
+
+// Shapes: THREADS x 4 MAXVEC slots -- 256 x 16 (buckets up to 4093 keys: 28 KB of LDS, five workgroups per CU), 256 x 28 (7165 keys,
+// four per CU), 512 x 28 (14333 keys, two per CU); and ONE WAVE per bucket (below) for buckets up to 1789 keys.  A workgroup lives for
+// two memory round trips (its bucket's words, its keys) on top of the sort itself -- about 5 us of an 11 us life at 6100 keys.
+template <int THREADS, int MAXVEC, int WGS, uint32_t SUBBITS>
+__global__ __launch_bounds__(THREADS, WGS *(THREADS / 64) / 4) void pool_local_sort_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out,
+                                                                                          MsdPlan *__restrict__ msd, const PoolPlan *__restrict__ pool,
+                                                                                          uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
+                                                                                          OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log, uint32_t retry) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * MAXVEC + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
+    __shared__ uint32_t s_tmp[32];
+    const uint32_t *src;
+    uint32_t *abase, mis, n;
+    if (!pool_bucket<THREADS, THREADS * 4u * MAXVEC, SUBBITS>(slack, keys_out, msd, pool, cursors, dev_head, host_head, stamp, host_log, retry, src, abase, mis, n)) return;
     const uint32_t rows = (mis + n + 4u * THREADS - 1u) / (4u * THREADS);  // rows of THREADS vectors the bucket touches where it is written
     if constexpr (MAXVEC == 4) {
         switch (rows) {
@@ -807,6 +840,82 @@ __global__ __launch_bounds__(THREADS, WGS *(THREADS / 64) / 4) void pool_local_s
             case 5: slack_sort_bucket<THREADS, 5>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
             case 6: slack_sort_bucket<THREADS, 6>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
             default: slack_sort_bucket<THREADS, 7>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
+        }
+    }
+}
+
+// Small buckets (up to 1789 keys: uniform inputs below about 2.6e7 keys): ONE WAVE per bucket, no workgroup barrier anywhere
+// (msd_local_sort_wave_kernel's idea, vrs_msd_hybrid.hip: 16 independent buckets per CU instead of workgroups whose fixed work is most of
+// their life) -- with it the pool form is worth taking from about 10^7 keys on.
+template <int VEC>
+__device__ __forceinline__ void slack_wave_load(uint32_t (&k)[4 * VEC], const uint32_t *src, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u, nvec = (n + 3u) / 4u;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        uint32_t v = j * 64 + lane;
+        if (j == VEC - 1) v = v < nvec ? v : nvec - 1u;
+        const uint4 t = reinterpret_cast<const uint4 *>(src)[v];
+        k[4 * j] = t.x;
+        k[4 * j + 1] = t.y;
+        k[4 * j + 2] = t.z;
+        k[4 * j + 3] = t.w;
+    }
+}
+template <int VEC>
+__device__ __attribute__((noinline)) void slack_wave_sort_guarded(const uint32_t *src, uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *tbl,
+                                                                 uint32_t skew) {
+    uint32_t k[4 * VEC];
+    slack_wave_load<VEC>(k, src, n);
+    wave_sort_body<VEC, true, true, true>(k, abase, mis, n, s_keys, tbl, (skew & 1u) != 0u, (skew & 2u) != 0u, 0u);
+}
+template <int VEC>
+__device__ __forceinline__ void slack_wave_sort_bucket(const uint32_t *src, uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *tbl) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t k[4 * VEC];
+    slack_wave_load<VEC>(k, src, n);
+    // the table zeroed: 576 words, two 16-byte stores per lane + one more from the first 16 lanes
+    reinterpret_cast<uint4 *>(tbl)[2 * lane] = make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4 *>(tbl)[2 * lane + 1] = make_uint4(0, 0, 0, 0);
+    if (lane < 16u) reinterpret_cast<uint4 *>(tbl)[128 + lane] = make_uint4(0, 0, 0, 0);
+    uint32_t skew = 0;  // does an instruction of the first row put half its lanes on one counter?  bit 0: pass 1, bit 1: pass 2
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t a1 = k[c] & 511u, a2 = (k[c] >> 9) & 511u;
+        skew |= __popcll(__ballot(a1 == __builtin_amdgcn_readfirstlane(a1))) >= 32 ? 1u : 0u;
+        skew |= __popcll(__ballot(a2 == __builtin_amdgcn_readfirstlane(a2))) >= 32 ? 2u : 0u;
+    }
+    skew = __builtin_amdgcn_readfirstlane(skew);
+    wave_phase();
+    if (skew == 0u) wave_sort_body<VEC, false, true, true>(k, abase, mis, n, s_keys, tbl, false, false, 0u);
+    else slack_wave_sort_guarded<VEC>(src, abase, mis, n, s_keys, tbl, skew);
+}
+template <uint32_t SUBBITS, int MAXVEC>  // MAXVEC 7: buckets up to 1789 keys (9.5 KB of LDS, 16 buckets per CU at a time); four rows (1021 keys, 25 per CU) measured the same
+__global__ __launch_bounds__(64, 4) void pool_local_sort_wave_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out, MsdPlan *__restrict__ msd,
+                                                                   const PoolPlan *__restrict__ pool, uint32_t *__restrict__ cursors,
+                                                                   OnesweepPlanHead *__restrict__ dev_head, OnesweepPlanHead *host_head, uint32_t stamp,
+                                                                   uint32_t *host_log, uint32_t retry) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[64 * 4 * MAXVEC + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tbl[kLeanRow];
+    const uint32_t *src;
+    uint32_t *abase, mis, n;
+    if (!pool_bucket<64, 64u * 4u * MAXVEC, SUBBITS>(slack, keys_out, msd, pool, cursors, dev_head, host_head, stamp, host_log, retry, src, abase, mis, n)) return;
+    const uint32_t rows = (mis + n + 255u) / 256u;
+    if constexpr (MAXVEC == 4) {
+        switch (rows) {
+            case 1: slack_wave_sort_bucket<1>(src, abase, mis, n, s_keys, s_tbl); break;
+            case 2: slack_wave_sort_bucket<2>(src, abase, mis, n, s_keys, s_tbl); break;
+            case 3: slack_wave_sort_bucket<3>(src, abase, mis, n, s_keys, s_tbl); break;
+            default: slack_wave_sort_bucket<4>(src, abase, mis, n, s_keys, s_tbl); break;
+        }
+    } else {
+        switch (rows) {
+            case 1: slack_wave_sort_bucket<1>(src, abase, mis, n, s_keys, s_tbl); break;
+            case 2: slack_wave_sort_bucket<2>(src, abase, mis, n, s_keys, s_tbl); break;
+            case 3: slack_wave_sort_bucket<3>(src, abase, mis, n, s_keys, s_tbl); break;
+            case 4: slack_wave_sort_bucket<4>(src, abase, mis, n, s_keys, s_tbl); break;
+            case 5: slack_wave_sort_bucket<5>(src, abase, mis, n, s_keys, s_tbl); break;
+            case 6: slack_wave_sort_bucket<6>(src, abase, mis, n, s_keys, s_tbl); break;
+            default: slack_wave_sort_bucket<7>(src, abase, mis, n, s_keys, s_tbl); break;
         }
     }
 }
@@ -852,7 +961,10 @@ uint32_t pool_tiles_b_cap(uint32_t n) {
     return even + even / 4u + 32u + 8u;
 }
 
-uint32_t pool_local_capacity(uint32_t local) { return (local == 2u ? 512u : 256u) * 4u * (local == 0u ? 4u : static_cast<uint32_t>(kLeanMaxVec)) - 3u; }
+uint32_t pool_local_capacity(uint32_t local) {
+    if (local == 3u) return 64u * 4u * kLeanMaxVec - 3u;  // one wave per bucket: 1789
+    return (local == 2u ? 512u : 256u) * 4u * (local == 0u ? 4u : static_cast<uint32_t>(kLeanMaxVec)) - 3u;
+}
 
 PoolShape pool_shape(uint32_t n, int forced_sub_bits) {
     // the fullest of the uniform buckets: 4 to 4.5 deviations above the mean -- 5.5 and a little here
@@ -866,7 +978,7 @@ PoolShape pool_shape(uint32_t n, int forced_sub_bits) {
     // counter tables to zero and scan, two memory round trips -- is a third of its life at 3000 keys (10^8 keys by seven bits: the
     // local sort 205 instead of 176 us, with five workgroups per CU), a sixth at 6100.
     sh.sub_bits = forced_sub_bits == 6 || forced_sub_bits == 7 ? static_cast<uint32_t>(forced_sub_bits) : (fits(6, 1) ? 6u : 7u);
-    sh.local = fits(sh.sub_bits, 0) ? 0u : fits(sh.sub_bits, 1) ? 1u : 2u;
+    sh.local = fits(sh.sub_bits, 3) ? 3u : fits(sh.sub_bits, 0) ? 0u : fits(sh.sub_bits, 1) ? 1u : 2u;
     return sh;
 }
 
@@ -923,16 +1035,20 @@ hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const
 
 hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
                                   PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev,
-                                  uint32_t top_bytes, uint32_t *host_log) {
+                                  uint32_t top_bytes, uint32_t *host_log, bool retry) {
     (void)n;
+    const uint32_t again = retry ? 1u : 0u;
     uint32_t *cursors = &msd->cursor_a[0][0];
     if (top_bytes == 0u || top_bytes > 256u || (top_bytes << shape.sub_bits) > kPoolMaxBuckets) return hipErrorInvalidValue;
 #define VRS_POOL_LOCAL(T, V, W, S)                                                                                                            \
     VRS_LAUNCH((pool_local_sort_kernel<T, V, W, S>), dim3(top_bytes << S), dim3(T), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head, \
-               stamp, host_log)
+               stamp, host_log, again)
 #define VRS_POOL_LOCAL_S(S)                                    \
     do {                                                       \
-        if (shape.local == 0u) VRS_POOL_LOCAL(256, 4, 5, S);   \
+        if (shape.local == 3u)                                 \
+            VRS_LAUNCH((pool_local_sort_wave_kernel<S, 7>), dim3(top_bytes << S), dim3(64), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head, \
+                       stamp, host_log, again);                \
+        else if (shape.local == 0u) VRS_POOL_LOCAL(256, 4, 5, S);   \
         else if (shape.local == 1u) VRS_POOL_LOCAL(256, 7, 4, S); \
         else VRS_POOL_LOCAL(512, 7, 2, S);                     \
     } while (0)
@@ -952,12 +1068,12 @@ PoolShape pool_grouped_shape(uint32_t n, uint32_t top_bytes) {
         if ((top_bytes << s) > kPoolMaxBuckets) break;
         const double mean = static_cast<double>(n) / (static_cast<double>(top_bytes) * (1u << s));
         const uint64_t need = static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u;
-        for (uint32_t local = 0u; local <= 2u; ++local) {
+        for (uint32_t local : {3u, 0u, 1u, 2u}) {
             if (need > pool_local_capacity(local)) continue;
-            if (best.sub_bits == 0u || (best.local == 2u && local < 2u)) best = PoolShape{s, local};
+            if (best.sub_bits == 0u || (best.local == 2u && local != 2u)) best = PoolShape{s, local};
             break;
         }
-        if (best.sub_bits != 0u && best.local < 2u) break;
+        if (best.sub_bits != 0u && best.local != 2u) break;
     }
     return best;
 }
