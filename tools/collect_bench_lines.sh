@@ -1,6 +1,6 @@
 #!/bin/bash
-# The bench lines committed under profiles/ (unprofiled, as printed), all on ONE box:  gpurun -- 'tools/collect_bench_lines.sh r04'
-TAG=${1:-r04}
+# The bench lines committed under profiles/ (unprofiled, as printed), all on ONE box:  gpurun -- 'tools/collect_bench_lines.sh r05'
+TAG=${1:-r05}
 OUT=$PWD/gpurun_out/lines_$TAG
 rm -rf $OUT; mkdir -p $OUT
 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
