@@ -443,6 +443,11 @@ int vrs_one_call_hybrid_recounts(vrs_context ctx, uint64_t *recounts);
 /* One-call sorts of bare uint32 keys that took the pool form (the hybrid form without a counting read, VRS_TUNE_MSD_POOL), and
  * sorts whose pool form the plan refused (they ran in the counted form afterwards).  Cumulative; diagnostics only. */
 int vrs_one_call_pool_sorts(vrs_context ctx, uint64_t *pool_sorts, uint64_t *pool_refusals);
+/* What the pool form would do with num_elements bare uint32 keys (host only, no device needed): *sub_bits = bits of its second pass
+   (6 or 7; 0 = the form does not take this size), *bucket_capacity = keys per bucket the local sort it enqueues takes (1789: one wave
+   per bucket; 4093 / 7165: 256 threads; 14333: 512), *scratch_bytes = context scratch a sort of this size needs beside the caller's two
+   buffers (slack buffer + first-pass overflow room + plan).  Any pointer may be NULL. */
+int vrs_pool_form_shape(uint32_t num_elements, uint32_t *sub_bits, uint32_t *bucket_capacity, uint64_t *scratch_bytes);
 /* sorts of the pool form whose local sort was enqueued a second time in a larger workgroup shape: the shape is chosen from
    num_elements alone (the form is enqueued blind), and a bucket of skewed keys may hold more than it takes -- no refusal, the bucket
    lies whole in its slack region; the settle asks for the larger shape (one more kernel, one more host round trip) */

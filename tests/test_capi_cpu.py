@@ -264,3 +264,24 @@ def test_dist_transport_table_layout():
     assert [f[0] for f in capi.DistTransport._fields_] == ["user", "all_gather", "all_reduce", "group_start", "send", "recv",
                                                            "group_end", "error_string"]
     assert capi.MSD_COUNT_WORDS == 16384 + 2048 + 64 and capi.MSD_SHIFT_WORD == 16384 + 2048
+
+
+def test_pool_form_shape_by_size(lib):
+    """vrs_pool_form_shape (host only): the shape the pool form picks from the size alone -- one wave per bucket while uniform buckets
+    (+ 5.5 deviations) stay below 1789 keys, then the 256-thread workgroups, seven bits in the second pass where six would need the
+    512-thread one -- and the context scratch that costs (about 1.5 N slots of slack buffer)."""
+    def shape(n):
+        sb, cap, scratch = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+        assert lib.vrs_pool_form_shape(n, ctypes.byref(sb), ctypes.byref(cap), ctypes.byref(scratch)) == 0
+        return sb.value, cap.value, scratch.value
+    assert shape(1000) == (0, 0, 0) and shape((1 << 22) - 1) == (0, 0, 0) and shape(300000000)[0] == 0
+    assert shape(1 << 22)[:2] == (6, 1789) and shape(10 ** 7)[:2] == (6, 1789) and shape(2 * 10 ** 7)[:2] == (6, 1789)
+    assert shape(4 * 10 ** 7)[:2] == (6, 4093) and shape(10 ** 8)[:2] == (6, 7165)
+    assert shape(13 * 10 ** 7)[:2] == (7, 7165) and shape(2 * 10 ** 8)[:2] == (7, 7165) and shape(224000000)[0] == 7
+    prev = 0
+    for n in (1 << 22, 10 ** 7, 5 * 10 ** 7, 10 ** 8):  # the scratch grows with N; per key it shrinks (320 slots of floor per bucket weigh on small inputs)
+        s = shape(n)[2]
+        assert s > prev and 1.6 * 4 * n < s < 6.0 * 4 * n, (n, s)
+        prev = s
+    assert 1.65 * 4e8 < shape(10 ** 8)[2] < 1.75 * 4e8  # 1.54 N of slack buffer + 0.18 N of first-pass overflow room
+    assert lib.vrs_pool_form_shape(10 ** 8, None, None, None) == 0

@@ -168,6 +168,7 @@ _SIGNATURES = [
     ("vrs_one_call_hybrid_recounts", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_one_call_pool_sorts", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     ("vrs_one_call_pool_retries", c_int, [c_void_p, POINTER(c_uint64)]),
+    ("vrs_pool_form_shape", c_int, [c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint64)]),
     ("vrs_debug_xcc_placement", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_int)]),
     ("vrs_debug_download_offsets", c_int, [c_void_p, c_void_p, c_size_t]),
     ("vrs_debug_atomic_rank_selftest", c_int, [c_void_p, c_uint32, c_uint32, POINTER(c_uint64)]),

@@ -1999,6 +1999,17 @@ int vrs_one_call_pool_sorts(vrs_context ctx, uint64_t *pool_sorts, uint64_t *poo
     return VRS_OK;
 }
 
+int vrs_pool_form_shape(uint32_t n, uint32_t *sub_bits, uint32_t *bucket_capacity, uint64_t *scratch_bytes) {
+    const bool takes = n >= (1u << 22) && n <= vrs::kPoolMaxKeys;
+    const vrs::PoolShape shape = takes ? vrs::pool_shape(n) : vrs::PoolShape{0u, 0u};
+    if (sub_bits) *sub_bits = shape.sub_bits;
+    if (bucket_capacity) *bucket_capacity = takes ? vrs::pool_local_capacity(shape.local) : 0u;
+    if (scratch_bytes)
+        *scratch_bytes = takes ? (static_cast<uint64_t>(vrs::pool_slack_capacity(n, shape.sub_bits)) + vrs::pool_overflow_capacity(n)) * sizeof(uint32_t) + sizeof(vrs::PoolPlan)
+                               : 0u;
+    return VRS_OK;
+}
+
 int vrs_one_call_pool_retries(vrs_context ctx, uint64_t *retries) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     if (retries) *retries = ctx->os_pool_retries;
