@@ -274,6 +274,7 @@ constexpr uint32_t kPoolMaxKeys = 224000000u;  // the fullest of 16384 uniform b
 constexpr uint32_t kPoolMaxBuckets = 256u << 7; // the second pass sorts by 6 or 7 bits of 256 top bytes (16384 or 32768 buckets); the second half alone
                                                 // (grouped keys of fewer top bytes) also by 8
 constexpr uint32_t kPoolMaxTilesA = 3456;      // tiles per slice of the first pass at kPoolMaxKeys (3418)
+constexpr uint32_t kPoolTileGeneral = 0xFFFFFFFFu;
 constexpr uint32_t kPoolMaxTilesB = 4352;      // rows of workgroups of the second pass at kPoolMaxKeys (pool_tiles_b_cap: 4313)
 struct PoolStreams {                           // the eight slices of the input the first pass walks (whole tiles), by value
     uint32_t start[8], len[8], sampled[8];     // first key, keys, keys the sample kernel counts
@@ -301,6 +302,10 @@ struct PoolPlan {
     // run on eight different XCCs.  That is observed, not promised: every workgroup leaves a claim, and a tile claimed twice refuses the sort.
     uint32_t claim_a[8 * kPoolMaxTilesA];  // first pass: += 1 by the workgroup of (list, tile); checked and zeroed by the plan kernel
     uint32_t claim_b[8 * kPoolMaxTilesB];  // second pass: exchanged with the sort's stamp by the workgroup of (list, tile); a stamp found there = a second claim
+    // second pass, tile j of XCD x's list: .x = the virtual slot of the tile's first key if the tile is 8192 keys inside ONE piece (five
+    // tiles in six: its loads then depend on this one word), else kPoolTileGeneral (it gathers from the top byte's piece row);
+    // .y = top byte | the tile's index inside its top byte << 8
+    alignas(16) uint2 tile_map[8][kPoolMaxTilesB];
     alignas(16) uint2 pieces[256][16];                     // top byte a's keys lie in 16 pieces (slice s's primary region: 2 s, its overflow region: 2 s + 1):
                                                            //   .x = keys of the top byte up to and including the piece, .y = the piece's first virtual slot
     alignas(16) uint32_t sub_start[kPoolMaxBuckets + 4];   // bucket b's region of the slack buffer: first slot (a multiple of 4), [buckets] = slots in all

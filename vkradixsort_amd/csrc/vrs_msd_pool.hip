@@ -436,6 +436,20 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
         if (a == 0u && tid == 0u) pool->fail = 0;  // (a sort's layout kernel re-arms it; nobody sets it before the second pass here)
         __syncthreads();
     }
+    {   // the second pass's tile map: thread i = tile i of this top byte (a tile is 8192 positions of the top byte's run of keys)
+        const uint32_t tiles_a = (c_a + kPoolTile - 1u) / kPoolTile, x = a & 7u;
+        for (uint32_t i = tid; i < tiles_a; i += THREADS) {
+            const uint32_t tile_lo = i * kPoolTile;
+            uint32_t plo = 0, slot0 = kPoolTileGeneral;
+#pragma unroll
+            for (uint32_t p = 0; p < 16u; ++p) {  // the piece that holds the tile's first position
+                const uint2 pc = s_piece[p];
+                if (tile_lo >= plo && tile_lo + kPoolTile <= plo + pc.x) slot0 = pc.y + (tile_lo - plo);  // ... and all of the tile
+                plo += pc.x;
+            }
+            if (tiles_before + i < kPoolMaxTilesB) pool->tile_map[x][tiles_before + i] = make_uint2(slot0, a | (i << 8));
+        }
+    }
     // The sample: thread (h, t) = (tid / 256, tid % 256) reads key t of the chunks q = h, h + 2, ..., 32 of them in flight at a time
     // (a piece after the other would be sixteen dependent round trips).  Chunk q belongs to the last piece whose first chunk is <= q.
     const uint32_t chunks_all = s_first[16], half = tid >> 8, t = tid & 255u;
@@ -628,18 +642,17 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     // the claim: this sort's stamp into (list, tile)'s word -- asked for now, looked at when the tile's loads are under way
     uint32_t claimed = 0;
     if (threadIdx.x == 0) claimed = __hip_atomic_exchange(&pool->claim_b[j * 8u + x], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (L2-local: a second claim comes from this XCC too)
-    const uint32_t *pt = pool->tiles_b[x];
-    if (j >= pt[32]) return;
-    uint32_t k = 0;  // the top byte whose tiles contain j: largest k with pt[k] <= j
-#pragma unroll
-    for (uint32_t step = 16; step >= 1; step >>= 1)
-        if (pt[k + step] <= j) k += step;
-    const uint32_t a = x + 8u * k, tile_lo = (j - pt[k]) * kPoolTile;
-    // The top byte's keys lie in 16 PIECES: slice s's primary region (piece 2 s), then its overflow region (2 s + 1).  Every wave:
-    // lane p = piece p -- its keys, its first (virtual) slot, where it starts in the top byte's run of keys.
-    // (the plan kernel's row of the top byte: 128 bytes, one load per wave)
+    // which tile: one word pair of the plan kernel's map (its second word: the top byte and the tile's index in it)
+    const uint2 entry = pool->tile_map[x][j < kPoolMaxTilesB ? j : 0u];
+    if (j >= pool->tiles_b[x][32]) return;
+    const uint32_t a = entry.y & 255u, tile_lo = (entry.y >> 8) * kPoolTile;
+    const bool one_piece = entry.x != kPoolTileGeneral;  // uniform: a full tile inside one piece -- its loads wait for nothing else
+    // The top byte's keys lie in 16 PIECES: slice s's primary region (piece 2 s), then its overflow region (2 s + 1).  A tile that
+    // touches several: every wave, lane p = piece p -- its keys, its first (virtual) slot, where it starts in the top byte's run of keys
+    // (the plan kernel's row of the top byte: 128 bytes, one load per wave).
     const uint32_t lane = threadIdx.x & 63u;
-    const uint2 pc = pool->pieces[a][lane & 15u];
+    uint2 pc = make_uint2(0, 0);
+    if (!one_piece) pc = pool->pieces[a][lane & 15u];
     const uint32_t shift = pool->shift;
     constexpr uint32_t SUB = 1u << SUBBITS;
     const uint32_t d = threadIdx.x & 255u, b = a * SUB + min(d, SUB - 1u);
@@ -656,7 +669,7 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     const uint32_t plo = lane == 0u ? 0u : before;  // the piece holds positions [plo, pend) of the top byte
     const uint32_t plen = lane < 16u ? pend - plo : 0u;
     const uint32_t keys_a = __builtin_amdgcn_readlane(pend, 15);
-    const uint32_t valid = min(kPoolTile, keys_a - tile_lo);
+    const uint32_t valid = one_piece ? kPoolTile : min(kPoolTile, keys_a - tile_lo);
     const unsigned long long touch = __ballot(plen != 0u && plo < tile_lo + valid && pend > tile_lo);
     PieceSrc src;
     src.p0 = static_cast<uint32_t>(__builtin_ctzll(touch | (1ull << 63)));
@@ -667,7 +680,7 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     src.regions = regions;
     src.overflow = overflow;
     src.n_virt = n_virt;
-    const uint32_t slot0 = __builtin_amdgcn_readlane(pslot, src.p0) + (tile_lo - __builtin_amdgcn_readlane(plo, src.p0));  // the tile's first key
+    const uint32_t slot0 = one_piece ? entry.x : __builtin_amdgcn_readlane(pslot, src.p0) + (tile_lo - __builtin_amdgcn_readlane(plo, src.p0));  // the tile's first key
     src.first_slot = slot0;
     const BitsDigit dg{shift + kMsdSubBits - SUBBITS, SUB - 1u, key_base};  // (key_base is a multiple of 2^24 and the bits end at or below bit 24)
     lb.dump = dump;
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     uint32_t unused = 0;
     // (two workgroups of one group of eight on ONE XCC: the tile has been taken twice and another not at all)
     if (threadIdx.x == 0 && claimed == stamp) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (valid == kPoolTile && src.p1 == src.p0 + 1u)  // a full tile inside one piece: five tiles in six
+    if (one_piece)  // five tiles in six
         scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve>(sm, slot0 < n_virt ? regions + slot0 : overflow + (slot0 - n_virt), nullptr, slack, nullptr, valid, dg, unused, lb, NoPieces{},
                                                                                          static_cast<size_t>(pool->top_base[256]) * sizeof(uint32_t) >= kStreamInBytes);
     else if (valid == kPoolTile)
