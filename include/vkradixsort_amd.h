@@ -452,6 +452,9 @@ int vrs_pool_form_shape(uint32_t num_elements, uint32_t *sub_bits, uint32_t *buc
    num_elements alone (the form is enqueued blind), and a bucket of skewed keys may hold more than it takes -- no refusal, the bucket
    lies whole in its slack region; the settle asks for the larger shape (one more kernel, one more host round trip) */
 int vrs_one_call_pool_retries(vrs_context ctx, uint64_t *retries);
+/* VRS_TUNE_MSD_POOL_REUSE_LAYOUT: *reused = pool sorts that started in the regions of an earlier sort, *stale = those of them whose keys
+   did not fit (run again with their own sample).  Either pointer may be NULL. */
+int vrs_one_call_pool_layouts(vrs_context ctx, uint64_t *reused, uint64_t *stale);
 /* The forms of the one-call sorts that share L2-resident words between workgroups rest on where the blocks of a launch run
    ("block b on the XCC of place b % 8 of the probed order"), which the context probes when it is created.  Observed on MI355X: the
    dispatcher's round-robin starts at an XCC of the hardware queue's own, and a HIP stream may move to another queue -- the probed
@@ -521,6 +524,11 @@ typedef enum vrs_tuning_key {
                                       VRS_TUNE_MSD_RESERVE != 0. */
     VRS_TUNE_MSD_POOL_MIN_KEYS = 18, /* the pool form is considered from this many keys on (default 3.2 * 10^7: the measured crossover with the counted form; never below 2^22) */
     VRS_TUNE_MSD_POOL_SUB_BITS = 20, /* bits the pool form's second pass sorts by: 0 (default) = by size (6 while the buckets fit a 256-thread local sort, about 1.1 * 10^8 uniform keys, else 7), 6 or 7 */
+    VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 22, /* 1 (default): a pool sort of the same size and key floor as the context's last TAKEN one runs its first
+                                       pass in the regions that sort's sample laid out -- no sample and no layout kernel (13 us and two launch gaps
+                                       at 10^8 keys).  Verified like any layout: keys it does not fit (another distribution, another key range)
+                                       flag the sort, which then runs again with a sample of its own (vrs_one_call_pool_layouts counts both).
+                                       0: every sort samples */
     VRS_TUNE_DEBUG_XCC_ROTATE = 21, /* test hook: run the placement probe again and rotate its result by `value` places (0 .. 7), as if the probe had
                                        run on another hardware queue than the sorts do (the dispatcher starts every queue's round-robin at its
                                        own XCC, and a stream may move between queues): the pool form's passes take their work lists by the XCC

@@ -24,7 +24,11 @@ def oracle():
 def gpu_context():
     """One GPUContext for the whole GPU session; fails loudly when the HIP library or device is missing."""
     import vkradixsort_amd as vrs
+    from vkradixsort_amd import capi
     ctx = vrs.GPUContext(int(os.environ.get("VRS_DEVICE", "0")))
     ctx.init()
+    # the tests that share this context count kernels sort by sort: every pool sort samples (the kept layouts of
+    # VRS_TUNE_MSD_POOL_REUSE_LAYOUT have tests of their own, on contexts of their own: tests/test_gpu_pool.py)
+    ctx.setTuning(capi.VRS_TUNE_MSD_POOL_REUSE_LAYOUT, 0)
     yield ctx
     ctx.shutdown()

@@ -204,6 +204,49 @@ def test_pool_form_beyond_the_small_local_sort(gpu_context):
     assert np.array_equal(out, np.sort(keys))
 
 
+def pool_layouts(ctx):
+    a, b = ctypes.c_uint64(), ctypes.c_uint64()
+    ctx.check(ctx.lib.vrs_one_call_pool_layouts(ctx.handle, ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
+
+
+def test_a_kept_layout_serves_the_next_sort_of_its_size_and_is_dropped_when_it_does_not_fit(oracle):
+    """VRS_TUNE_MSD_POOL_REUSE_LAYOUT (the default): the second sort of a size runs its first pass in the regions the first one's sample
+    laid out -- no sample kernel --; other keys of the same distribution fit; keys of ANOTHER distribution (here: another key range, and
+    slices that differ) do not: that sort is flagged like any sort whose regions overflow, runs again with a sample of its own, and is
+    exact; a size change samples; switched off, every sort samples."""
+    n = 6000011
+    with vrs.GPUContext(0) as gpu:
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL, 2)
+        first = pool_keys(n, "uniform", seed=1)
+        out, stats, (took, refused) = sort_and_stats(gpu, first)
+        assert oracle.test_sort(oracle.std_sort(first)[0], out) == -1 and (took, refused) == (1, 0) and stats["pool_sample"] == 1
+        assert pool_layouts(gpu) == (0, 0)
+        for seed in (2, 3):  # other uniform keys: the kept regions fit
+            keys = pool_keys(n, "uniform", seed=seed)
+            out, stats, (took, refused) = sort_and_stats(gpu, keys)
+            assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+            assert (took, refused) == (1, 0) and stats["pool_sample"] == 0 and stats["pool_pass_a"] == 1
+        assert pool_layouts(gpu) == (2, 0)
+        for dist in ("28bit", "halves"):  # another key range / other regions: stale, sampled again, exact, no refusal of the FORM
+            keys = pool_keys(n, dist, seed=4)
+            out, stats, (took, refused) = sort_and_stats(gpu, keys)
+            assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1, dist
+            assert (took, refused) == (1, 0) and stats["pool_sample"] == 1 and stats["pool_pass_a"] == 2, (dist, stats)
+            out, stats, (took, refused) = sort_and_stats(gpu, keys)  # ... and ITS layout serves the next sort of these keys
+            assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1 and stats["pool_sample"] == 0
+        reused, stale = pool_layouts(gpu)
+        assert (reused, stale) == (6, 2)
+        other = pool_keys(n + 8192, "uniform", seed=5)  # another size: sampled
+        out, stats, _ = sort_and_stats(gpu, other)
+        assert oracle.test_sort(oracle.std_sort(other)[0], out) == -1 and stats["pool_sample"] == 1
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL_REUSE_LAYOUT, 0)
+        for _ in range(2):
+            out, stats, _ = sort_and_stats(gpu, other)
+            assert oracle.test_sort(oracle.std_sort(other)[0], out) == -1 and stats["pool_sample"] == 1
+        assert pool_layouts(gpu)[0] == reused
+
+
 def test_pool_form_enqueue_only(pool_ctx, oracle):
     """VRS_TUNE_ASYNC_SORT: the call returns with the whole form enqueued; a refusal is handled by the settle"""
     pool_ctx.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)

@@ -62,6 +62,7 @@ VRS_TUNE_MSD_POOL_MIN_KEYS = 18
 VRS_TUNE_DEBUG_XCC_STRAY_BLOCK = 19
 VRS_TUNE_MSD_POOL_SUB_BITS = 20
 VRS_TUNE_DEBUG_XCC_ROTATE = 21
+VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 22
 # keys the local sort of one top-14-bit bucket can hold (msd_local_capacity): uint32 keys with the 256- / 512-thread workgroup, pairs and 64-bit keys
 LOCAL_SORT_SMALL_KEYS, LOCAL_SORT_MAX_KEYS = 7165, 14333
 LOCAL_SORT_SMALL_PAIRS, LOCAL_SORT_MAX_PAIRS = 6656, 13312  # pairs and 64-bit keys: 512 / 1024-thread workgroups
@@ -168,6 +169,7 @@ _SIGNATURES = [
     ("vrs_one_call_hybrid_recounts", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_one_call_pool_sorts", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     ("vrs_one_call_pool_retries", c_int, [c_void_p, POINTER(c_uint64)]),
+    ("vrs_one_call_pool_layouts", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     ("vrs_pool_form_shape", c_int, [c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint64)]),
     ("vrs_debug_xcc_placement", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_int)]),
     ("vrs_debug_download_offsets", c_int, [c_void_p, c_void_p, c_size_t]),

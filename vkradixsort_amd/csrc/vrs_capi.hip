@@ -114,6 +114,15 @@ struct vrs_context_t {
     uint64_t os_pool_sorts = 0, os_pool_refusals = 0, os_pool_retries = 0;  // (retries: sorts whose local sort was enqueued again in a larger shape)
     uint32_t os_pool_min_keys = 1u << 22;   // VRS_TUNE_MSD_POOL_MIN_KEYS: the form's own floor -- with one wave per small bucket it beats the LSD passes from there on (labs/r05_pool_form.txt section 6)
     int os_pool_sub_bits = 0;               // VRS_TUNE_MSD_POOL_SUB_BITS: 0 = by size (pool_shape), 6 or 7
+    uint32_t os_pool_epoch = 0;             // pool sorts / finishes enqueued: its parity picks the PoolPlan::fail word of each
+    // The regions of the first pass, kept from one sort to the next (VRS_TUNE_MSD_POOL_REUSE_LAYOUT, default on): a sort of the same
+    // size and key floor as the context's last TAKEN pool sort runs its first pass in the regions that sort's sample laid out -- no
+    // sample and layout kernel (13 us and two launch gaps at 10^8 keys).  Nothing is trusted: a region that does not fit, a key
+    // outside the kept range flag the sort as ever; a refusal forgets the layout and the re-run samples.
+    bool os_pool_reuse = true;
+    bool os_pool_layout_valid = false;
+    uint32_t os_pool_layout_n = 0, os_pool_layout_base = 0;
+    uint64_t os_pool_layout_reuses = 0, os_pool_stale_layouts = 0;  // sorts that started in a kept layout / of those, sorts it did not fit (run again, sampled)
     bool os_cursors_open = false;        // a reserving pass may have run without the local sort that re-arms its counters behind it
                                          // (a refused plan, a partition with no finish, an error in between): cleared before the next use
     // a one-call sort between its two halves (see one_read_enqueue / one_read_complete)
@@ -131,6 +140,8 @@ struct vrs_context_t {
         bool pool = false, no_pool = false;  // the pool form is on the stream / was refused for this sort
         uint32_t pool_sub_bits = 0, pool_local = 0;  // its shape; pool_retried: a larger local sort has been enqueued behind a first one that left
         bool pool_retried = false;
+        uint32_t pool_par = 0;     // parity of its pool epoch
+        bool pool_reused = false;  // its first pass ran in a kept layout
         size_t ev_lb_before = 0, ev_ls_before = 0;
         uint32_t key_base = 0;      // vrs_sort_keys_u32_ranged: every key is promised to be >= this (a multiple of 2^24)
         uint32_t bucket_hint = 0;   // blind tail: expected largest bucket (0 = from n); picks the local sort's workgroup shape
@@ -1232,20 +1243,28 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     // (pool_shape: uniform keys, buckets of n / 16384 or n / 32768 + a few per cent); a bucket above the local sort's capacity
     // makes the second pass flag the sort.
     const uint32_t tiles_b = vrs::pool_tiles_b_cap(n);
-    if ((rc = profile_events(ctx, VRS_KERNEL_POOL_SAMPLE, &ev))) return rc;
-    VRS_HIP(ctx, vrs::launch_pool_sample(ctx->stream, home, n, st.key_base, ps, ctx->os_pool_plan, room, ev));
+    const uint32_t par = (++ctx->os_pool_epoch) & 1u;
+    st.pool_par = par;
+    st.pool_reused = ctx->os_pool_reuse && ctx->os_pool_layout_valid && ctx->os_pool_layout_n == n && ctx->os_pool_layout_base == st.key_base;
+    if (!st.pool_reused) {
+        if ((rc = profile_events(ctx, VRS_KERNEL_POOL_SAMPLE, &ev))) return rc;
+        VRS_HIP(ctx, vrs::launch_pool_sample(ctx->stream, home, n, st.key_base, ps, ctx->os_pool_plan, room, par, ev));
+        ctx->os_pool_layout_valid = false;  // (until this sort is known to have been taken)
+    } else {
+        ctx->os_pool_layout_reuses++;
+    }
     st.ev_lb_before = ctx->events_used[VRS_KERNEL_LOOKBACK_SCATTER];
     st.ev_ls_before = ctx->events_used[VRS_KERNEL_LOCAL_SORT];
     if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_A, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_pass_a(ctx->stream, home, partner, ctx->os_pool_overflow, n, st.key_base, ps, ctx->os_pool_plan, ctx->os_msd_plan,
-                                         ctx->xcc_map, ctx->os_misplace, room, ev));
-    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, partner, ctx->os_pool_overflow, st.key_base, ps, shape.sub_bits));
+                                         ctx->xcc_map, ctx->os_misplace, room, par, ev));
+    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, partner, ctx->os_pool_overflow, st.key_base, ps, shape.sub_bits, par));
     if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_B, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, partner, ctx->os_pool_overflow, ctx->os_pool_slack, n, ctx->os_msd_plan, ctx->os_pool_plan, tiles_b,
-                                         st.key_base, vrs::pool_local_capacity(shape.local), ctx->os_pool_slack_cap, ctx->xcc_map, st.stamp, shape.sub_bits, ev));
+                                         st.key_base, vrs::pool_local_capacity(shape.local), ctx->os_pool_slack_cap, ctx->xcc_map, st.stamp, shape.sub_bits, par, ev));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, home, n, ctx->os_msd_plan, ctx->os_pool_plan, shape, &ctx->os_plan->head,
-                                             ctx->os_host_head_dev, st.stamp, ev));
+                                             ctx->os_host_head_dev, st.stamp, par, ev));
     ctx->os_cursors_open = false;  // the local sort re-arms the reservation counters (a refusal is handled by one_read_complete)
     st.active = true;
     return VRS_OK;
@@ -1279,6 +1298,9 @@ static int one_read_complete(vrs_context ctx, bool *done) {
             st.cur = st.cur_at_start;
             ctx->os_hybrid_sorts++;
             ctx->os_pool_sorts++;
+            ctx->os_pool_layout_valid = true;  // its regions held: the next sort of this size may start in them
+            ctx->os_pool_layout_n = n;
+            ctx->os_pool_layout_base = st.key_base;
             return finish();
         }
         if (head.msd_max_bucket != 0u && !st.pool_retried) {
@@ -1297,7 +1319,7 @@ static int one_read_complete(vrs_context ctx, bool *done) {
                 ctx->os_pool_retries++;
                 VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, static_cast<uint32_t *>(st.kptr[st.cur_at_start]), n, ctx->os_msd_plan,
                                                          ctx->os_pool_plan, vrs::PoolShape{st.pool_sub_bits, local}, &ctx->os_plan->head, ctx->os_host_head_dev,
-                                                         st.stamp, ev, 256, nullptr, true));
+                                                         st.stamp, st.pool_par, ev, 256, nullptr, true));
                 return VRS_OK;  // (still active: the settle waits for this one's word)
             }
         }
@@ -1306,6 +1328,15 @@ static int one_read_complete(vrs_context ctx, bool *done) {
         // passes).  The reservation counters hold what the first pass reserved and no local sort re-armed them.
         if (timed_ls) ctx->events_used[VRS_KERNEL_LOCAL_SORT] = st.ev_ls_before;
         ctx->os_cursors_open = true;
+        ctx->os_pool_layout_valid = false;
+        if (st.pool_reused) {
+            // the KEPT layout did not fit these keys (another distribution, another key range): no verdict on the form -- the same
+            // sort again, sampled this time
+            ctx->os_pool_stale_layouts++;
+            st.group = 0;
+            st.cur = st.cur_at_start;
+            return one_read_enqueue(ctx);
+        }
         ctx->os_pool_refusals++;
         if (ctx->os_pool == 1) {
             ctx->os_pool_skip = 15;
@@ -1676,17 +1707,19 @@ int vrs_msd_finish_grouped_counts_u32(vrs_context ctx, vrs_buffer grouped, vrs_b
     ctx->sub_cache.valid = false;
     if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
     ctx->os_msd_half_stamp = ctx->os_stamp;
+    ctx->os_pool_layout_valid = false;  // (the plan of grouped keys rewrites words a kept layout rests on: PoolPlan::shift)
+    const uint32_t par = (++ctx->os_pool_epoch) & 1u;
     const uint32_t key_base = first_top_byte << 24;
     const uint32_t *keys_in = static_cast<const uint32_t *>(grouped->ptr);
     vrs::LaunchEvents ev;
     VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, keys_in, keys_in, key_base,
-                                       vrs::pool_streams(n), shape.sub_bits, &groups));
+                                       vrs::pool_streams(n), shape.sub_bits, par, &groups));
     if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_B, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, keys_in, keys_in, ctx->os_pool_slack, n, ctx->os_msd_plan, ctx->os_pool_plan, tiles_b, key_base,
-                                         vrs::pool_local_capacity(shape.local), ctx->os_pool_slack_cap, ctx->xcc_map, ctx->os_stamp, shape.sub_bits, ev, true));
+                                         vrs::pool_local_capacity(shape.local), ctx->os_pool_slack_cap, ctx->xcc_map, ctx->os_stamp, shape.sub_bits, par, ev, true));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, static_cast<uint32_t *>(out->ptr), n, ctx->os_msd_plan, ctx->os_pool_plan, shape,
-                                             &ctx->os_plan->head, ctx->os_host_head_dev, ctx->os_stamp, ev, top_bytes,
+                                             &ctx->os_plan->head, ctx->os_host_head_dev, ctx->os_stamp, par, ev, top_bytes,
                                              reinterpret_cast<uint32_t *>(ctx->os_host_head_dev + 1)));
     return VRS_OK;
 }
@@ -2016,6 +2049,13 @@ int vrs_one_call_pool_retries(vrs_context ctx, uint64_t *retries) {
     return VRS_OK;
 }
 
+int vrs_one_call_pool_layouts(vrs_context ctx, uint64_t *reused, uint64_t *stale) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (reused) *reused = ctx->os_pool_layout_reuses;
+    if (stale) *stale = ctx->os_pool_stale_layouts;
+    return VRS_OK;
+}
+
 int vrs_debug_xcc_placement(vrs_context ctx, uint64_t *reprobes, uint64_t *xcc_map, int *valid) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     if (reprobes) *reprobes = ctx->reprobes;
@@ -2115,9 +2155,14 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             if (sh) ctx->xcc_map = (ctx->xcc_map >> sh) | (ctx->xcc_map << (64u - sh));
             return VRS_OK;
         }
+        case VRS_TUNE_MSD_POOL_REUSE_LAYOUT:
+            ctx->os_pool_reuse = value != 0;
+            ctx->os_pool_layout_valid = false;
+            return VRS_OK;
         case VRS_TUNE_MSD_POOL_SUB_BITS:
             if (value != 0 && value != 6 && value != 7) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form's second pass sorts by 6 or 7 bits (0 = by size)");
             ctx->os_pool_sub_bits = value;
+            ctx->os_pool_layout_valid = false;
             return VRS_OK;
         case VRS_TUNE_MSD_POOL_MIN_KEYS:
             if (value < (1 << 22)) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form takes 2^22 keys or more");

@@ -283,13 +283,15 @@ struct PoolStreams {                           // the eight slices of the input 
 struct PoolPlan {
     uint32_t shift;             // bucket = (key - key_base) >> shift: the top 14 bits of the probed key range
     uint32_t armed;             // 1 = the sample kernel laid the regions out: the first pass runs
-    uint32_t fail;              // bit 0: a pass found a region out of room / a key outside the probed range / a workgroup behind an unknown L2 / a tile
+    uint32_t fail[2];           // (one word per PARITY of the context's pool epoch: the plan kernel of a sort zeroes the OTHER one, so the next sort's
+                                //   first pass -- which may run without a sample and layout kernel in front, see launch_pool_sample -- finds its word clear)
+                                // bit 0: a pass found a region out of room / a key outside the probed range / a workgroup behind an unknown L2 / a tile
                                 //   claimed twice: the sort is refused; bit 1: a bucket has more keys than the local sort that was enqueued takes
                                 //   (it lies whole in its region: a local sort of a larger shape can still finish the sort).  Re-armed by the layout kernel
     uint32_t ticket;            // (unused)
     uint32_t ok_a;              // verdict 1 (plan kernel): the second pass runs
     uint32_t max_bucket;        // second pass: the fullest bucket AMONG those beyond the enqueued local sort's capacity (zero if none; re-armed by the plan kernel)
-    uint32_t pad[2];
+    uint32_t pad[1];
     uint32_t sample[8][256];    // sampled keys of (slice, top byte), zero between sorts
     uint32_t base[8][256];      // primary region of (slice, top byte): first slot in the partner buffer
     uint32_t cap[8][256];       //   its slots
@@ -328,30 +330,31 @@ struct PoolGroups {          // keys of every top byte (grouped keys; by value: 
 };
 uint32_t pool_local_capacity(uint32_t local);
 uint32_t pool_tiles_b_cap(uint32_t n);         // rows of workgroups of the second pass (its grid is sized before the plan is known)
+// par: the parity of the context's pool epoch (0 / 1; the same for all kernels of one sort: PoolPlan::fail)
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
-                              PoolPlan *pool, uint32_t overflow_capacity, LaunchEvents ev = {});
+                              PoolPlan *pool, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev = {});
 // keys_out: the partner buffer (n slots); overflow: pool_overflow_capacity(n) slots; cursors: MsdPlan::cursor_a (zero when the pass
 // starts); misplace: test hook, odd rows of workgroups walk the neighbouring slice
 hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, uint32_t *overflow, uint32_t n,
                               uint32_t key_base, const PoolStreams &ps, PoolPlan *pool, MsdPlan *msd, unsigned long long xcc_map,
-                              bool misplace, uint32_t overflow_capacity, LaunchEvents ev = {});
+                              bool misplace, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev = {});
 // after the first pass, one workgroup per top byte: top-byte starts, tile tables, piece rows, the buckets' slack regions (from a
 // sample of the first pass's OUTPUT: regions / overflow), verdict 1 (slack_capacity: slots the slack buffer has)
 hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap, uint32_t slack_capacity,
                             const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps, uint32_t sub_bits,
-                            const PoolGroups *groups = nullptr);
+                            uint32_t par, const PoolGroups *groups = nullptr);
 // groups != nullptr: the second half alone (vrs_msd_finish_grouped_counts_u32) -- `regions` holds keys grouped by top byte, top byte a
 // (counted from key_base >> 24) holds groups->count[a] of them; no first pass ran
 // second pass, regions -> slack buffer: grid of 8 * tiles_b workgroups (tiles_b = pool_tiles_b_cap(n)); local_cap: keys the local
 // sort that follows takes per bucket; slack_capacity: as given to the plan (the last kPoolTile slots take refused runs)
 hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *slack, uint32_t n, MsdPlan *msd,
                               PoolPlan *pool, uint32_t tiles_b, uint32_t key_base, uint32_t local_cap, uint32_t slack_capacity,
-                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, LaunchEvents ev = {}, bool grouped = false);
+                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, uint32_t par, LaunchEvents ev = {}, bool grouped = false);
 // sorts every bucket from its slack region to keys_out[its exact start ...) with the workgroup shape.local.  Gives verdict 2 (verdict 1, no flag from the passes) = MsdPlan::ok and the host head
 // (msd_ok, lsd_missing = 1, stamped last); re-arms the first pass's reservation counters
 hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
-                                  PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev = {},
-                                  uint32_t top_bytes = 256, uint32_t *host_log = nullptr, bool retry = false);
+                                  PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t par,
+                                  LaunchEvents ev = {}, uint32_t top_bytes = 256, uint32_t *host_log = nullptr, bool retry = false);
 // retry: the second attempt after a first local sort found a bucket beyond its shape (PoolPlan::fail bit 1): that bit no longer refuses
 // top_bytes: the top bytes that exist (a sort: 256; the second half alone: the caller's); host_log: see launch_msd_plan
 

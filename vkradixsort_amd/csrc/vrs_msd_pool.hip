@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__rest
 
 // The regions, from the sample: ONE workgroup of 256 threads, thread d = top byte d of all eight slices.  (A kernel of its own:
 // as the sample kernel's last workgroup -- a ticket, which needs every workgroup's adds acknowledged first -- it took 13 us.)
-__global__ __launch_bounds__(256) void pool_layout_kernel(PoolStreams ps, PoolPlan *__restrict__ pool, uint32_t overflow_capacity) {
+__global__ __launch_bounds__(256) void pool_layout_kernel(PoolStreams ps, PoolPlan *__restrict__ pool, uint32_t overflow_capacity, uint32_t par) {
     __shared__ uint32_t s_wave[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t shift = pool->shift;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void pool_layout_kernel(PoolStreams ps, PoolPl
         br += room[s];
     }
     if (tid == 0) {
-        pool->fail = 0;  // re-armed here: the passes of THIS sort set it, its local sort reads it
+        pool->fail[par] = 0;  // re-armed here: the passes of THIS sort set it, its local sort reads it
         // a key range below 27 bits is left to the LSD passes, like the counted form does (vrs_msd_hybrid.hip, msd_plan_kernel)
         pool->armed = (shift >= kPoolMinShift && shift <= kPoolMaxShift && total_room <= overflow_capacity) ? 1u : 0u;
     }
@@ -274,14 +274,14 @@ __device__ __forceinline__ uint32_t xcc_place(unsigned long long xcc_map) {
 __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out,
                                                              uint32_t *__restrict__ overflow, uint32_t n, uint32_t key_base,
                                                              PoolStreams ps, PoolPlan *__restrict__ pool, MsdPlan *__restrict__ msd,
-                                                             unsigned long long xcc_map, int misplace, uint32_t overflow_capacity) {
+                                                             unsigned long long xcc_map, int misplace, uint32_t overflow_capacity, uint32_t par) {
     __shared__ ChunkSmem<uint32_t, 16, 8, false> sm;
     __shared__ uint32_t s_gbase2[kBins], s_split[kBins], s_flags;
     if (pool->armed == 0u) return;  // uniform: the sample kernel did not lay regions out (key range below 27 bits)
     const uint32_t i = blockIdx.x >> 3;
     const uint32_t s_out = xcc_place(xcc_map);
     if (s_out == 8u) {  // behind an L2 the probe never saw: no row is safe to add to -- the sort is refused
-        if (threadIdx.x == 0) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_fetch_or(&pool->fail[par], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     if (threadIdx.x == 0) __hip_atomic_fetch_add(&pool->claim_a[s_out * kPoolMaxTilesA + i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (L2-local: every claim on this word comes from this XCC)
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__r
     lb.gbase2 = s_gbase2;
     lb.split = s_split;
     lb.flags = &s_flags;
-    lb.fail_word = &pool->fail;
+    lb.fail_word = &pool->fail[par];
     uint32_t unused = 0;
     if (valid == kPoolTile)
         scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true>(sm, kin, nullptr, keys_out, nullptr, valid, dg, unused, lb, NoPieces{},
@@ -341,7 +341,7 @@ __device__ __forceinline__ uint32_t pool_space(uint32_t c) {
 template <uint32_t SUBBITS, bool GROUPED>
 __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool, uint32_t n, uint32_t tiles_b_cap,
                                                        uint32_t slack_capacity, const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
-                                                       uint32_t key_base, PoolStreams ps, PoolGroups groups) {
+                                                       uint32_t key_base, PoolStreams ps, PoolGroups groups, uint32_t par) {
     constexpr uint32_t THREADS = 512, WAVES = THREADS / 64, SUB = 1u << SUBBITS, PER = SUB / 64u;
     __shared__ uint32_t s_c[kBins];              // keys of top byte t
     __shared__ uint32_t s_red[3][WAVES];
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
         if (x < 8u && i < ps.tiles_per_stream) {
             const uint32_t claims = pool->claim_a[w];
             pool->claim_a[w] = 0;
-            if (claims != 1u && pool->armed != 0u) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (claims != 1u && pool->armed != 0u) __hip_atomic_fetch_or(&pool->fail[par], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // thread t < 256: top byte t's exact total; thread p < 16: piece p of THIS top byte
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
             pool->pieces[a][tid] = make_uint2(c_a, top);
             s_piece[tid] = make_uint2(tid == 0u ? c_a : 0u, top);
         }
-        if (a == 0u && tid == 0u) pool->fail = 0;  // (a sort's layout kernel re-arms it; nobody sets it before the second pass here)
+        if (a == 0u && tid == 0u) pool->fail[par] = 0;  // (a sort's layout kernel re-arms it; nobody sets it before the second pass here)
         __syncthreads();
     }
     {   // the second pass's tile map: thread i = tile i of this top byte (a tile is 8192 positions of the top byte's run of keys)
@@ -545,12 +545,13 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
             if constexpr (GROUPED)
                 pool->ok_a = (s_bad == 0u && all == n && room <= slack_capacity - kPoolTile) ? 1u : 0u;  // (all != n: the caller's counts are not these keys')
             else
-                pool->ok_a = (pool->armed != 0u && pool->fail == 0u && s_bad == 0u && all == n && shift >= kPoolMinShift && shift <= kPoolMaxShift &&
+                pool->ok_a = (pool->armed != 0u && pool->fail[par] == 0u && s_bad == 0u && all == n && shift >= kPoolMinShift && shift <= kPoolMaxShift &&
                               room <= slack_capacity - kPoolTile)
                                  ? 1u
                                  : 0u;
             // (PoolPlan::fail stays: the second pass may still set it; the next sort's layout kernel re-arms it)
             pool->max_bucket = 0;
+            pool->fail[par ^ 1u] = 0;  // the NEXT sort's word (its first pass may be its first kernel)
             if constexpr (GROUPED) pool->shift = shift;
             msd->shift = shift;
             msd->sub_bits = SUBBITS;
@@ -629,14 +630,14 @@ template <uint32_t SUBBITS>
 __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
                                                              uint32_t *__restrict__ slack, const MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool,
                                                              uint32_t n_virt, uint32_t key_base, uint32_t local_cap, uint32_t dump,
-                                                             unsigned long long xcc_map, uint32_t stamp, uint32_t grouped) {
+                                                             unsigned long long xcc_map, uint32_t stamp, uint32_t grouped, uint32_t par) {
     __shared__ ChunkSmem<uint32_t, 16, 8, false> sm;
     // the list follows the XCC this workgroup RUNS on (pool_pass_a_kernel): all tiles of a top byte then meet behind the L2 that
     // holds its 64 cursors, whatever the dispatcher's rotation
     const uint32_t x = xcc_place(xcc_map), j = blockIdx.x >> 3;
     if (pool->ok_a == 0u) return;  // uniform (enqueued before the plan was known: it may have said no)
     if (x == 8u) {  // behind an L2 the probe never saw
-        if (threadIdx.x == 0) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_fetch_or(&pool->fail[par], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     // the claim: this sort's stamp into (list, tile)'s word -- asked for now, looked at when the tile's loads are under way
@@ -688,10 +689,10 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     // a sort: no key may have bits above the probed range; grouped keys (the caller's promise): every key of this tile carries top byte a
     lb.above = grouped ? 0xFF000000u : (shift + kMsdBits < 32u ? ~0u << (shift + kMsdBits) : 0u);
     lb.key_base = grouped ? key_base + (a << 24) : key_base;
-    lb.fail_word = &pool->fail;
+    lb.fail_word = &pool->fail[par];
     uint32_t unused = 0;
     // (two workgroups of one group of eight on ONE XCC: the tile has been taken twice and another not at all)
-    if (threadIdx.x == 0 && claimed == stamp) __hip_atomic_fetch_or(&pool->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && claimed == stamp) __hip_atomic_fetch_or(&pool->fail[par], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (one_piece)  // five tiles in six
         scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve>(sm, slot0 < n_virt ? regions + slot0 : overflow + (slot0 - n_virt), nullptr, slack, nullptr, valid, dg, unused, lb, NoPieces{},
                                                                                          static_cast<size_t>(pool->top_base[256]) * sizeof(uint32_t) >= kStreamInBytes);
@@ -766,8 +767,8 @@ __device__ __forceinline__ void slack_sort_bucket(const uint32_t *src, uint32_t 
 template <int THREADS, uint32_t CAPACITY, uint32_t SUBBITS>
 __device__ __forceinline__ bool pool_bucket(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out, MsdPlan *__restrict__ msd,
                                             const PoolPlan *__restrict__ pool, uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
-                                            OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log, uint32_t retry, const uint32_t *&src,
-                                            uint32_t *&abase, uint32_t &mis, uint32_t &n) {
+                                            OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log, uint32_t retry, uint32_t par,
+                                            const uint32_t *&src, uint32_t *&abase, uint32_t &mis, uint32_t &n) {
     constexpr uint32_t SUB = 1u << SUBBITS, PER = SUB / 64u;
     const uint32_t b = gridDim.x - 1u - blockIdx.x, a = b >> SUBBITS, c = b & (SUB - 1u);  // (the grid: the top bytes that exist x SUB)
     const uint32_t lane = threadIdx.x & 63u;
@@ -781,7 +782,7 @@ __device__ __forceinline__ bool pool_bucket(const uint32_t *__restrict__ slack, 
     // the sort (a region out of room, a bucket above this kernel's capacity, a key outside the probed range).  Workgroup 0 tells the host.
     // A bucket beyond THIS kernel's shape (fail bit 1; the shape was chosen from n alone) is no refusal of the form: the bucket lies
     // whole in its region, this kernel leaves, and the host -- told the bucket's size -- enqueues a larger shape (retry: that second one).
-    const uint32_t flags = pool->fail, mx = pool->max_bucket;
+    const uint32_t flags = pool->fail[par], mx = pool->max_bucket;
     const uint32_t ok = (pool->ok_a != 0u && (flags & (retry ? 1u : 3u)) == 0u && (retry == 0u || mx <= CAPACITY - 3u)) ? 1u : 0u;
     const uint32_t again = (ok == 0u && retry == 0u && pool->ok_a != 0u && flags == 2u) ? mx : 0u;  // != 0: a larger local sort finishes the sort
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -829,13 +830,13 @@ template <int THREADS, int MAXVEC, int WGS, uint32_t SUBBITS>
 __global__ __launch_bounds__(THREADS, WGS *(THREADS / 64) / 4) void pool_local_sort_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out,
                                                                                           MsdPlan *__restrict__ msd, const PoolPlan *__restrict__ pool,
                                                                                           uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
-                                                                                          OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log, uint32_t retry) {
+                                                                                          OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log, uint32_t retry, uint32_t par) {
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * MAXVEC + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
     __shared__ uint32_t s_tmp[32];
     const uint32_t *src;
     uint32_t *abase, mis, n;
-    if (!pool_bucket<THREADS, THREADS * 4u * MAXVEC, SUBBITS>(slack, keys_out, msd, pool, cursors, dev_head, host_head, stamp, host_log, retry, src, abase, mis, n)) return;
+    if (!pool_bucket<THREADS, THREADS * 4u * MAXVEC, SUBBITS>(slack, keys_out, msd, pool, cursors, dev_head, host_head, stamp, host_log, retry, par, src, abase, mis, n)) return;
     const uint32_t rows = (mis + n + 4u * THREADS - 1u) / (4u * THREADS);  // rows of THREADS vectors the bucket touches where it is written
     if constexpr (MAXVEC == 4) {
         switch (rows) {
@@ -906,12 +907,12 @@ template <uint32_t SUBBITS, int MAXVEC>  // MAXVEC 7: buckets up to 1789 keys (9
 __global__ __launch_bounds__(64, 4) void pool_local_sort_wave_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out, MsdPlan *__restrict__ msd,
                                                                    const PoolPlan *__restrict__ pool, uint32_t *__restrict__ cursors,
                                                                    OnesweepPlanHead *__restrict__ dev_head, OnesweepPlanHead *host_head, uint32_t stamp,
-                                                                   uint32_t *host_log, uint32_t retry) {
+                                                                   uint32_t *host_log, uint32_t retry, uint32_t par) {
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[64 * 4 * MAXVEC + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_tbl[kLeanRow];
     const uint32_t *src;
     uint32_t *abase, mis, n;
-    if (!pool_bucket<64, 64u * 4u * MAXVEC, SUBBITS>(slack, keys_out, msd, pool, cursors, dev_head, host_head, stamp, host_log, retry, src, abase, mis, n)) return;
+    if (!pool_bucket<64, 64u * 4u * MAXVEC, SUBBITS>(slack, keys_out, msd, pool, cursors, dev_head, host_head, stamp, host_log, retry, par, src, abase, mis, n)) return;
     const uint32_t rows = (mis + n + 255u) / 256u;
     if constexpr (MAXVEC == 4) {
         switch (rows) {
@@ -996,49 +997,49 @@ PoolShape pool_shape(uint32_t n, int forced_sub_bits) {
 }
 
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
-                              PoolPlan *pool, uint32_t overflow_capacity, LaunchEvents ev) {
+                              PoolPlan *pool, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev) {
     if (n == 0 || ps.tiles_per_stream < kPoolSampleTiles) return hipErrorInvalidValue;  // (a sample workgroup's tiles span at most two slices)
     const uint32_t grid = (ps.tiles_total + kPoolSampleTiles - 1u) / kPoolSampleTiles;
     VRS_LAUNCH(pool_sample_kernel, dim3(grid), dim3(256), stream, ev, keys, n, key_base, ps, pool);
-    hipLaunchKernelGGL(pool_layout_kernel, dim3(1), dim3(256), 0, stream, ps, pool, overflow_capacity);
+    hipLaunchKernelGGL(pool_layout_kernel, dim3(1), dim3(256), 0, stream, ps, pool, overflow_capacity, par);
     return hipGetLastError();
 }
 
 hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, uint32_t *overflow, uint32_t n,
                               uint32_t key_base, const PoolStreams &ps, PoolPlan *pool, MsdPlan *msd, unsigned long long xcc_map,
-                              bool misplace, uint32_t overflow_capacity, LaunchEvents ev) {
+                              bool misplace, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev) {
     VRS_LAUNCH(pool_pass_a_kernel, dim3(8u * ps.tiles_per_stream), dim3(512), stream, ev, keys_in, keys_out, overflow, n, key_base, ps, pool, msd,
-               xcc_map, misplace ? 1 : 0, overflow_capacity);
+               xcc_map, misplace ? 1 : 0, overflow_capacity, par);
     return hipGetLastError();
 }
 
 hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap, uint32_t slack_capacity,
                             const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps, uint32_t sub_bits,
-                            const PoolGroups *groups) {
+                            uint32_t par, const PoolGroups *groups) {
     if (ps.tiles_per_stream > kPoolMaxTilesA || tiles_b_cap > kPoolMaxTilesB) return hipErrorInvalidValue;
     const dim3 grid(256), block(512);
     if (groups) {
-        if (sub_bits == 8u) hipLaunchKernelGGL((pool_plan_kernel<8, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups);
-        else if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups);
-        else hipLaunchKernelGGL((pool_plan_kernel<6, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups);
+        if (sub_bits == 8u) hipLaunchKernelGGL((pool_plan_kernel<8, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par);
+        else if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par);
+        else hipLaunchKernelGGL((pool_plan_kernel<6, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par);
     } else {
         const PoolGroups none{};
-        if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none);
-        else hipLaunchKernelGGL((pool_plan_kernel<6, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none);
+        if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none, par);
+        else hipLaunchKernelGGL((pool_plan_kernel<6, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none, par);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *slack, uint32_t n, MsdPlan *msd,
                               PoolPlan *pool, uint32_t tiles_b, uint32_t key_base, uint32_t local_cap, uint32_t slack_capacity,
-                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, LaunchEvents ev, bool grouped) {
+                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, uint32_t par, LaunchEvents ev, bool grouped) {
     if (tiles_b == 0) return hipSuccess;
     if (tiles_b > kPoolMaxTilesB || stamp == 0u) return hipErrorInvalidValue;
     // (grouped keys lie in `regions` alone: no slot is an overflow slot)
     const uint32_t n_virt = grouped ? 0xFFFFFFFFu : n, g = grouped ? 1u : 0u;
 #define VRS_POOL_B(S)                                                                                                                         \
     VRS_LAUNCH(pool_pass_b_kernel<S>, dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n_virt, key_base, local_cap, \
-               slack_capacity - kPoolTile, xcc_map, stamp, g)
+               slack_capacity - kPoolTile, xcc_map, stamp, g, par)
     if (sub_bits == 8u) VRS_POOL_B(8);
     else if (sub_bits == 7u) VRS_POOL_B(7);
     else VRS_POOL_B(6);
@@ -1047,20 +1048,20 @@ hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const
 }
 
 hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
-                                  PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, LaunchEvents ev,
-                                  uint32_t top_bytes, uint32_t *host_log, bool retry) {
+                                  PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t par,
+                                  LaunchEvents ev, uint32_t top_bytes, uint32_t *host_log, bool retry) {
     (void)n;
     const uint32_t again = retry ? 1u : 0u;
     uint32_t *cursors = &msd->cursor_a[0][0];
     if (top_bytes == 0u || top_bytes > 256u || (top_bytes << shape.sub_bits) > kPoolMaxBuckets) return hipErrorInvalidValue;
 #define VRS_POOL_LOCAL(T, V, W, S)                                                                                                            \
     VRS_LAUNCH((pool_local_sort_kernel<T, V, W, S>), dim3(top_bytes << S), dim3(T), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head, \
-               stamp, host_log, again)
+               stamp, host_log, again, par)
 #define VRS_POOL_LOCAL_S(S)                                    \
     do {                                                       \
         if (shape.local == 3u)                                 \
             VRS_LAUNCH((pool_local_sort_wave_kernel<S, 7>), dim3(top_bytes << S), dim3(64), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head, \
-                       stamp, host_log, again);                \
+                       stamp, host_log, again, par);           \
         else if (shape.local == 0u) VRS_POOL_LOCAL(256, 4, 5, S);   \
         else if (shape.local == 1u) VRS_POOL_LOCAL(256, 7, 4, S); \
         else VRS_POOL_LOCAL(512, 7, 2, S);                     \
