@@ -237,6 +237,15 @@ def test_a_kept_layout_serves_the_next_sort_of_its_size_and_is_dropped_when_it_d
             assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1 and stats["pool_sample"] == 0
         reused, stale = pool_layouts(gpu)
         assert (reused, stale) == (6, 2)
+        # ... and keys that miss the kept regions by far: the sorted output of a sort (every slice then holds 32 of the 256 top bytes,
+        # eight times what their regions take -- the soak's case: the first pass's cursors count what was ASKED for, and the plan
+        # kernel's sample must not follow them behind the overflow scratch)
+        rnd = pool_keys(n, "uniform", seed=9)
+        out, _, _ = sort_and_stats(gpu, rnd)          # (sampled: the layout of uniform keys in random order)
+        out2, stats, (took, refused) = sort_and_stats(gpu, out)  # the same keys, sorted: stale
+        assert np.array_equal(out2, out) and oracle.test_sort(oracle.std_sort(rnd)[0], out) == -1 and took + refused == 1
+        reused, stale = pool_layouts(gpu)
+        assert (reused, stale) == (7, 3)
         other = pool_keys(n + 8192, "uniform", seed=5)  # another size: sampled
         out, stats, _ = sort_and_stats(gpu, other)
         assert oracle.test_sort(oracle.std_sort(other)[0], out) == -1 and stats["pool_sample"] == 1

@@ -41,6 +41,11 @@ def soak(budget, seed=1, mode="keys", max_keys=10 ** 8):
     with vrs.GPUContext(0, stream=torch.cuda.current_stream().cuda_stream) as gpu:
         gpu.setTuning(capi.VRS_TUNE_DEBUG_MISPLACE_STREAMS, 1 if mode == "misplaced" else 0)
         gpu.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 1 << 22)  # the hybrid form wherever its buckets fit, not only from 4e7 keys on
+        import os
+        if os.environ.get("VRS_SOAK_REUSE_LAYOUT") == "0":
+            gpu.setTuning(capi.VRS_TUNE_MSD_POOL_REUSE_LAYOUT, 0)
+        if os.environ.get("VRS_SOAK_POOL") == "0":
+            gpu.setTuning(capi.VRS_TUNE_MSD_POOL, 0)
         while time.time() < t_end:
             n = int(rs.choice([rs.randint(1 << 20, 1 << 23), rs.randint(1 << 23, 6 * 10 ** 7), 10 ** 8]))
             n = min(n, max_keys)

@@ -378,7 +378,9 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
         } else {
             const uint32_t s = tid >> 1;
             const uint32_t c = msd->cursor_a[s][a], prim = min(c, pool->cap[s][a]);
-            plen = (tid & 1u) ? c - prim : prim;
+            // (a share that outgrew its room -- the first pass flagged the sort, nothing below will be used -- must still not send the
+            // sample behind the overflow scratch: a cursor counts what was ASKED for)
+            plen = (tid & 1u) ? min(c - prim, pool->ocap[s][a]) : prim;
             pslot = (tid & 1u) ? n + pool->obase[s][a] : pool->base[s][a];
         }
     }
