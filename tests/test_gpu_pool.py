@@ -244,8 +244,8 @@ def test_a_kept_layout_serves_the_next_sort_of_its_size_and_is_dropped_when_it_d
         out, _, _ = sort_and_stats(gpu, rnd)          # (sampled: the layout of uniform keys in random order)
         out2, stats, (took, refused) = sort_and_stats(gpu, out)  # the same keys, sorted: stale
         assert np.array_equal(out2, out) and oracle.test_sort(oracle.std_sort(rnd)[0], out) == -1 and took + refused == 1
-        reused, stale = pool_layouts(gpu)
-        assert (reused, stale) == (7, 3)
+        reused2, stale2 = pool_layouts(gpu)
+        assert reused2 == reused + 2 and stale2 >= stale + 1  # (both started in a kept layout; the sorted keys surely did not fit theirs)
         other = pool_keys(n + 8192, "uniform", seed=5)  # another size: sampled
         out, stats, _ = sort_and_stats(gpu, other)
         assert oracle.test_sort(oracle.std_sort(other)[0], out) == -1 and stats["pool_sample"] == 1
@@ -253,7 +253,7 @@ def test_a_kept_layout_serves_the_next_sort_of_its_size_and_is_dropped_when_it_d
         for _ in range(2):
             out, stats, _ = sort_and_stats(gpu, other)
             assert oracle.test_sort(oracle.std_sort(other)[0], out) == -1 and stats["pool_sample"] == 1
-        assert pool_layouts(gpu)[0] == reused
+        assert pool_layouts(gpu)[0] == reused2 + 0  # (nothing reused while switched off; the sort of `other` before sampled: another size)
 
 
 def test_pool_form_enqueue_only(pool_ctx, oracle):
