@@ -455,6 +455,11 @@ def bench_pairs(args):
         gpu.check(gpu.lib.vrs_one_call_hybrid_sorts(gpu.handle, ctypes.byref(h)))
         return h.value
 
+    def pool_sorts():
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        gpu.check(gpu.lib.vrs_one_call_pool_sorts(gpu.handle, ctypes.byref(a), ctypes.byref(b)))
+        return a.value
+
     def kernel_table():
         t = {}
         for kid, name in capi.KERNEL_NAMES.items():
@@ -480,9 +485,12 @@ def bench_pairs(args):
     rearm()
     run_steps(W, 0)
     rearm()
-    h0 = hybrid_sorts()
-    elapsed, kernels = run_steps(K, 1 << capi.VRS_KERNEL_LOOKBACK_SCATTER, every=args.event_every)
-    hybrid_steps = hybrid_sorts() - h0
+    h0, p0 = hybrid_sorts(), pool_sorts()
+    # every byte-moving kernel of either form carries events in the timed region; the dominant one is named from them (pick_dominant)
+    moving = sum(1 << k for k in (capi.VRS_KERNEL_LOOKBACK_SCATTER, capi.VRS_KERNEL_LOCAL_SORT, capi.VRS_KERNEL_POOL_PASS_A, capi.VRS_KERNEL_POOL_PASS_B,
+                                   capi.VRS_KERNEL_DIGIT_TABLES))
+    elapsed, kernels = run_steps(K, moving, every=args.event_every)
+    hybrid_steps, pool_steps = hybrid_sorts() - h0, pool_sorts() - p0
     # every output of the timed region: keys ascending and a permutation of the input's, payloads a permutation of 0 .. n-1
     key_prints = [p_.verifyKeys(n)[1:] for p_ in pristine]
     val_print = pristine_vals.verifyKeys(n)[1:]
@@ -517,10 +525,17 @@ def bench_pairs(args):
     _, breakdown = run_steps(K, (1 << capi.VRS_KERNEL_COUNT) - 1)
     if hybrid_steps not in (0, K):
         raise SystemExit(f"the timed steps mixed the two forms of the one-call sort ({hybrid_steps} of {K} hybrid)")
-    hybrid = hybrid_steps == K
-    bpp = 52 if hybrid else 68  # counting read 4 + (2 MSD passes + local sort | 4 LSD passes) x (read 8 + write 8)
-    dom_us = kernels.get("lookback_scatter", {}).get("avg_us")
-    achieved = 16 * n / (dom_us * 1e-6) / 1e9 if dom_us else None
+    if pool_steps not in (0, K):
+        raise SystemExit(f"the timed steps mixed the pool and the counted form ({pool_steps} of {K} pool)")
+    hybrid, pool = hybrid_steps == K, pool_steps == K
+    # counting read 4 + (2 MSD passes + local sort | 4 LSD passes) x (read 8 + write 8); the pool form has no counting read
+    bpp = 48 if pool else 52 if hybrid else 68
+    pair_bytes = {"digit_tables": 4, "lookback_scatter": 16, "local_sort": 16, "pool_pass_a": 16, "pool_pass_b": 16}
+    dom_name = pick_dominant({k_: v for k_, v in kernels.items() if k_ in pair_bytes})
+    dom_us = kernels.get(dom_name, {}).get("avg_us")
+    dom_bytes = pair_bytes.get(dom_name, 16) * n
+    achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us else None
+    traffic_name = "lookback_scatter_pairs" if dom_name == "lookback_scatter" else f"{dom_name}_pairs"
     result = {
         "metric": "Gkeys/s sorting 10^8 uint32 at 1/2/4/8 MI355X; % of HBM roofline",
         "value": round(n * K / elapsed / 1e9, 3), "unit": "Gkeys/s", "n_gpus": 1, "steps": K, "warmup": W,
@@ -528,15 +543,19 @@ def bench_pairs(args):
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[3]: {n} uint32 key + uint32 payload pairs (keys: std::mt19937 seeds 1,2,3; payload = "
                                "input position), 1xMI355X, resident in HBM; every key counts once (a pair per key)",
-                   "path": ("vrs_sort_pairs_u32, hybrid form: one counting read of the keys, two stable MSD scatter passes with decoupled "
+                   "path": ("vrs_sort_pairs_u32, stable pool form: no counting read -- two stable MSD scatter passes by decoupled look-back inside "
+                            "sampled regions (keys + payloads), LDS-local bucket sort from the slack buffers to the caller's -- 48 B/pair") if pool else
+                           ("vrs_sort_pairs_u32, hybrid form: one counting read of the keys, two stable MSD scatter passes with decoupled "
                             "look-back (keys + payloads), LDS-local bucket sort -- 52 B/pair") if hybrid else
                            "vrs_sort_pairs_u32: one counting read + four stable look-back scatter passes -- 68 B/pair",
                    "num_elements": n, "device": dev_name, "compute_units": cus},
-        "roofline": {"bound": "hbm", "kernel": "lookback_scatter with payloads (reads and writes every key and payload once per launch)",
+        "roofline": {"bound": "hbm", "kernel": dom_name, "kernel_is": (KERNEL_WHAT.get(dom_name) or "") + " -- here with payloads: every key and payload read and written once per launch",
+                     "chosen_by": "largest launches x average launch time among the byte-moving kernels whose launches carried events in the timed region",
+                     "instrumented_us_by_kernel": {x: round(r["launches"] * r["avg_us"], 1) for x, r in kernels.items() if x in pair_bytes},
                      "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "algorithmic_bytes_per_launch": 16 * n,
-                     "avg_launch_us": dom_us, "traffic": load_traffic_profile("lookback_scatter_pairs", 16.0 * n)[0] if n == 10 ** 8 else None,
-                     "traffic_source": "profiles/lookback_scatter_pairs_traffic.json (rocprofv3 --pmc passes of an earlier run of this command)"},
+                     "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "algorithmic_bytes_per_launch": dom_bytes,
+                     "avg_launch_us": dom_us, "traffic": load_traffic_profile(traffic_name, float(dom_bytes))[0] if n == 10 ** 8 else None,
+                     "traffic_source": f"profiles/{traffic_name}_traffic.json (rocprofv3 --pmc passes of an earlier run of this command)"},
         "sort_roofline": {"algorithmic_bytes": bpp * n, "bytes_per_key": bpp, "achieved_GBps": round(bpp * n * K / elapsed / 1e9, 1),
                           "frac_of_peak": round(bpp * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
         "kernels_timed_region": kernels, "kernels_all_instrumented_rerun": breakdown,

@@ -529,6 +529,10 @@ typedef enum vrs_tuning_key {
                                        at 10^8 keys).  Verified like any layout: keys it does not fit (another distribution, another key range)
                                        flag the sort, which then runs again with a sample of its own (vrs_one_call_pool_layouts counts both).
                                        0: every sort samples */
+    VRS_TUNE_MSD_POOL_PAIRS = 23, /* 1 (default): uint32 key + uint32 payload pairs may take the pool form too -- its STABLE variant: a tile's place in
+                                     a sampled region is its rank there (decoupled look-back, one chain per input slice / per top byte) instead
+                                     of a reservation, so equal keys keep their input order; 48 instead of 52 bytes per pair.  0: pairs always
+                                     take the counted form */
     VRS_TUNE_DEBUG_XCC_ROTATE = 21, /* test hook: run the placement probe again and rotate its result by `value` places (0 .. 7), as if the probe had
                                        run on another hardware queue than the sorts do (the dispatcher starts every queue's round-robin at its
                                        own XCC, and a stream may move between queues): the pool form's passes take their work lists by the XCC

@@ -331,3 +331,90 @@ def test_pool_form_default_at_1e8_keys(gpu_context, oracle):
     out, stats, (took, refused) = sort_and_stats(gpu_context, keys)
     assert (took, refused) == (1, 0) and stats["digit_tables"] == 0 and stats["pool_sample"] == 1
     assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+
+
+# ---- key + payload pairs: the STABLE pool form (round 5) --------------------------------------------------------------------
+def sort_pairs_and_stats(ctx, keys, vals):
+    lib, n = ctx.lib, keys.size
+    k0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys)
+    v0 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals)
+    k1, v1 = vrs.Buffer(ctx, S(4 * n)), vrs.Buffer(ctx, S(4 * n))
+    ctx.profileReset()
+    ctx.profileEnable(True)
+    before = pool_counts(ctx)
+    try:
+        ctx.check(lib.vrs_sort_pairs_u32(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+        ok, ov = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        k0.downloadWithStagingBuffer(ok)
+        v0.downloadWithStagingBuffer(ov)
+        stats = {name: launches(ctx, kid) for kid, name in capi.KERNEL_NAMES.items()}
+    finally:
+        ctx.profileEnable(False)
+        for b in (k0, k1, v0, v1):
+            b.release()
+    after = pool_counts(ctx)
+    return ok, ov, stats, (after[0] - before[0], after[1] - before[1])
+
+
+@pytest.mark.parametrize("dist", ["uniform", "28bit", "halves", "dups", "ties", "gauss"])
+@pytest.mark.parametrize("n", [POOL_MIN + 77, 9000001, 30000001])
+def test_pool_form_of_pairs_is_stable(pool_ctx, oracle, n, dist):
+    """Pairs through the pool form: no counting read, and both passes place a tile by its RANK in the sampled region (decoupled
+    look-back) -- payloads of equal keys come out in input order, as the reference's LSD passes leave them
+    (multi_radixsort.comp:130-141).  `ties`: 2^16 distinct keys, long runs of equal keys in every bucket."""
+    if dist == "ties":
+        keys = (make_keys(n, "uniform", seed=6) & np.uint32(0xFFFF)) * np.uint32(65537)
+    else:
+        keys = pool_keys(n, dist, seed=n % 991)
+    vals = make_keys(n, "uniform", seed=8)
+    ok, ov, stats, (took, refused) = sort_pairs_and_stats(pool_ctx, keys, vals)
+    rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
+    assert np.array_equal(ok, rk) and np.array_equal(ov, rv)
+    assert (took, refused) == (1, 0), stats
+    assert stats["pool_pass_a"] == 1 and stats["pool_pass_b"] == 1 and stats["digit_tables"] == 0 and stats["lookback_scatter"] == 0
+    assert stats["local_sort"] == (2 if dist == "gauss" and n > 20000000 else 1)  # (gauss: the fullest buckets need the larger local sort -- a retry, no refusal)
+
+
+@pytest.mark.parametrize("dist", ["tile_period", "hot_bucket", "rare_high_bit", "24bit"])
+def test_pool_form_of_pairs_refuses_and_the_counted_form_sorts_the_untouched_input(pool_ctx, oracle, dist):
+    n = 9000001
+    keys = pool_keys(n, dist, seed=3)
+    vals = make_keys(n, "uniform", seed=9)
+    ok, ov, stats, (took, refused) = sort_pairs_and_stats(pool_ctx, keys, vals)
+    rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
+    assert np.array_equal(ok, rk) and np.array_equal(ov, rv)
+    assert took == 0 and (refused == 1 or dist == "24bit")  # (24 bits: the sample kernel arms nothing -- the LSD passes run; the others: a pass flags the sort)
+
+
+def test_pool_form_of_pairs_back_to_back_and_switched_off(pool_ctx, oracle):
+    """three sorts of one size on one context (the second and third start in the first one's kept layout when layouts are kept; the
+    look-back words are cleared by every taken sort's local sort), then the form switched off: the counted form sorts the same"""
+    n = 12000017
+    vals = np.arange(n, dtype=np.uint32)
+    for seed in (1, 2, 3):
+        keys = make_keys(n, "uniform", seed=seed)
+        ok, ov, stats, (took, refused) = sort_pairs_and_stats(pool_ctx, keys, vals)
+        assert (took, refused) == (1, 0)
+        order = np.argsort(keys, kind="stable").astype(np.uint32)
+        assert np.array_equal(ov, order) and np.array_equal(ok, keys[order])
+    pool_ctx.setTuning(capi.VRS_TUNE_MSD_POOL_PAIRS, 0)
+    try:
+        keys = make_keys(n, "uniform", seed=4)
+        ok, ov, stats, (took, refused) = sort_pairs_and_stats(pool_ctx, keys, vals)
+        order = np.argsort(keys, kind="stable").astype(np.uint32)
+        assert (took, refused) == (0, 0) and stats["digit_tables"] == 1 and np.array_equal(ov, order)
+    finally:
+        pool_ctx.setTuning(capi.VRS_TUNE_MSD_POOL_PAIRS, 1)
+
+
+def test_pool_form_of_pairs_at_1e8(gpu_context):
+    """configs[3]'s size with the defaults: 10^8 pairs, payload = input position"""
+    ctx = gpu_context
+    n = 100000000
+    keys = make_keys(n, "uniform", seed=1)
+    vals = np.arange(n, dtype=np.uint32)
+    ok, ov, stats, (took, refused) = sort_pairs_and_stats(ctx, keys, vals)
+    assert (took, refused) == (1, 0), stats
+    assert np.all(ok[1:] >= ok[:-1]) and np.array_equal(keys[ov], ok)
+    same = ok[1:] == ok[:-1]
+    assert np.all(ov[1:][same] > ov[:-1][same])  # equal keys: input order

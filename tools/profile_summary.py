@@ -74,8 +74,8 @@ def dominant_records(rows, pairs=False):
                                ("histogram_traffic.json", "histogram_kernel", lambda k: "histogram_kernel" in k),
                                ("digit_tables_traffic.json", "digit_tables_kernel", lambda k: "digit_tables_kernel" in k)):
         rec = pick_dominant(rows, match)
-        if rec and not pairs:
-            files[fname] = {"kernel": what, "source": src, "correction": corr, **rec}
+        if rec:  # (a --pairs run: <kernel>_pairs_traffic.json -- the kernels' payload-carrying instantiations)
+            files[fname.replace("_traffic", "_pairs_traffic") if pairs else fname] = {"kernel": what, "source": src, "correction": corr, **rec}
     return files
 
 

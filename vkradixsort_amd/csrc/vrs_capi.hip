@@ -111,6 +111,10 @@ struct vrs_context_t {
     uint32_t os_pool_overflow_cap = 0;     //   keys they hold
     uint32_t *os_pool_slack = nullptr;     // the buckets' regions the second pass scatters into (about 1.5 n slots)
     uint32_t os_pool_slack_cap = 0;        //   slots
+    uint32_t *os_pool_overflow_vals = nullptr, *os_pool_slack_vals = nullptr;  // key + payload pairs: the payloads' twins of the two (made with the first pool sort of pairs)
+    uint32_t os_pool_vals_overflow_cap = 0, os_pool_vals_slack_cap = 0;
+    int os_pool_pairs = 1;                 // VRS_TUNE_MSD_POOL_PAIRS: key + payload pairs may take the (stable) pool form
+    uint64_t os_pool_pair_sorts = 0;
     uint64_t os_pool_sorts = 0, os_pool_refusals = 0, os_pool_retries = 0;  // (retries: sorts whose local sort was enqueued again in a larger shape)
     uint32_t os_pool_min_keys = 1u << 22;   // VRS_TUNE_MSD_POOL_MIN_KEYS: the form's own floor -- with one wave per small bucket it beats the LSD passes from there on (labs/r05_pool_form.txt section 6)
     int os_pool_sub_bits = 0;               // VRS_TUNE_MSD_POOL_SUB_BITS: 0 = by size (pool_shape), 6 or 7
@@ -513,6 +517,8 @@ int vrs_context_destroy(vrs_context ctx) {
     if (ctx->os_pool_plan) (void)hipFree(ctx->os_pool_plan);
     if (ctx->os_pool_overflow) (void)hipFree(ctx->os_pool_overflow);
     if (ctx->os_pool_slack) (void)hipFree(ctx->os_pool_slack);
+    if (ctx->os_pool_overflow_vals) (void)hipFree(ctx->os_pool_overflow_vals);
+    if (ctx->os_pool_slack_vals) (void)hipFree(ctx->os_pool_slack_vals);
     if (ctx->os_msd_counts) (void)hipFree(ctx->os_msd_counts);
     if (ctx->os_msd_plan) (void)hipFree(ctx->os_msd_plan);
     if (ctx->os_plan_a) (void)hipFree(ctx->os_plan_a);
@@ -922,6 +928,8 @@ static OneReadGeometry one_read_geometry(vrs_context ctx, const vrs_context_t::O
         }
     }
     g.rows = static_cast<size_t>(S) * std::max(g.tile_cap, st.msd_capable ? g.tiles_b_cap : 0u);  // status rows: one region for all passes (tagged words)
+    if (st.pool && pairs)  // the stable pool form's two passes: a row per tile of the slices' lists / of the XCDs' lists
+        g.rows = std::max(g.rows, static_cast<size_t>(8) * std::max(vrs::pool_streams(n).tiles_per_stream, vrs::pool_tiles_b_cap(n)));
     return g;
 }
 
@@ -1075,6 +1083,7 @@ static int one_read_enqueue(vrs_context ctx) {
         bool wide_try = wide;  // (with payloads too: round 5)
         // bare uint32 keys the pool form may take: from ITS threshold on (below the counted form's: its first half costs a sample,
         // not a counting read)
+        // (pairs: the stable pool form, from the counted form's threshold on -- it has not been measured below)
         const bool pool_size = !pairs && !wide && !st.no_pool && ctx->os_pool != 0 && reserves(ctx, n, false) && n >= ctx->os_pool_min_keys &&
                                n <= vrs::kPoolMaxKeys && (ctx->os_pool == 2 || ctx->os_pool_skip == 0 || n / 2u > ctx->os_pool_skip_n || n < ctx->os_pool_skip_n / 2u);
         if (wide_try && !st.no_hybrid && ctx->os_wide_refused && (++ctx->os_wide_skipped % 16u) != 0u) wide_try = false;
@@ -1102,8 +1111,8 @@ static int one_read_enqueue(vrs_context ctx) {
         // the default is adaptive: after one, the next 15 such sorts of the context take the counted form.
         // (sizes: a bucket must fit the local sort's larger shape -- uniform keys up to about 2.2e8 --, in every mode: beyond it a
         // refusal is certain; and below 3.2e7 keys the counted form's one-wave-per-bucket local sort is the faster one)
-        const bool candidate = st.msd_capable && !pairs && !wide && !st.no_pool && ctx->os_pool != 0 && reserves(ctx, n, false) &&
-                               n >= ctx->os_pool_min_keys && n <= vrs::kPoolMaxKeys;
+        const bool candidate = st.msd_capable && !wide && !st.no_pool && ctx->os_pool != 0 && n >= ctx->os_pool_min_keys && n <= vrs::kPoolMaxKeys &&
+                               (pairs ? ctx->os_pool_pairs != 0 && n <= 13000u * vrs::kMsdBucketCount : reserves(ctx, n, false));
         if (candidate && ctx->os_pool_skip && (n / 2u > ctx->os_pool_skip_n || n < ctx->os_pool_skip_n / 2u)) ctx->os_pool_skip = 0;
         st.pool = candidate && (ctx->os_pool == 2 || ctx->os_pool_skip == 0);
         if (candidate && !st.pool) --ctx->os_pool_skip;
@@ -1186,7 +1195,7 @@ static int one_read_enqueue(vrs_context ctx) {
 }
 
 // the pool form's scratch: its plan (once), the first pass's overflow regions and the slack buffer (grown when a sort needs more)
-static int pool_scratch(vrs_context ctx, uint32_t room, uint32_t slack) {
+static int pool_scratch(vrs_context ctx, uint32_t room, uint32_t slack, bool pairs = false) {
     if (!ctx->os_pool_plan) {
         vrs::PoolPlan *pp = nullptr;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&pp), sizeof(vrs::PoolPlan));
@@ -1214,6 +1223,22 @@ static int pool_scratch(vrs_context ctx, uint32_t room, uint32_t slack) {
         VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_slack), static_cast<size_t>(slack) * sizeof(uint32_t)));
         ctx->os_pool_slack_cap = slack;
     }
+    if (pairs && (ctx->os_pool_vals_overflow_cap < ctx->os_pool_overflow_cap || ctx->os_pool_vals_slack_cap < ctx->os_pool_slack_cap)) {
+        // the payloads' twins: the keys' sizes, so that one slot number serves both
+        if (ctx->os_pool_overflow_vals || ctx->os_pool_slack_vals) {
+            VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->os_pool_overflow_vals) VRS_HIP(ctx, hipFree(ctx->os_pool_overflow_vals));
+            if (ctx->os_pool_slack_vals) VRS_HIP(ctx, hipFree(ctx->os_pool_slack_vals));
+            ctx->os_pool_overflow_vals = nullptr;
+            ctx->os_pool_slack_vals = nullptr;
+            ctx->os_pool_vals_overflow_cap = 0;
+            ctx->os_pool_vals_slack_cap = 0;
+        }
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_overflow_vals), static_cast<size_t>(ctx->os_pool_overflow_cap) * sizeof(uint32_t)));
+        ctx->os_pool_vals_overflow_cap = ctx->os_pool_overflow_cap;
+        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_slack_vals), static_cast<size_t>(ctx->os_pool_slack_cap) * sizeof(uint32_t)));
+        ctx->os_pool_vals_slack_cap = ctx->os_pool_slack_cap;
+    }
     return VRS_OK;
 }
 
@@ -1222,13 +1247,30 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     vrs_context_t::OneRead &st = ctx->one_read;
     const uint32_t n = st.n;
     int rc;
-    const vrs::PoolShape shape = vrs::pool_shape(n, ctx->os_pool_sub_bits);
+    const bool pairs = st.vptr[0] != nullptr;
+    const vrs::PoolShape shape = pairs ? vrs::pool_shape_pairs(n) : vrs::pool_shape(n, ctx->os_pool_sub_bits);
     st.pool_sub_bits = shape.sub_bits;
     st.pool_local = shape.local;
     st.pool_retried = false;
     const uint32_t room = vrs::pool_overflow_capacity(n), slack = vrs::pool_slack_capacity(n, shape.sub_bits);
-    if ((rc = pool_scratch(ctx, room, slack))) return rc;
+    if ((rc = pool_scratch(ctx, room, slack, pairs))) return rc;
     if ((rc = reservation_begin(ctx))) return rc;  // the first pass's cursors: zero
+    // Pairs: the passes are stable -- decoupled look-back through the one-call sort's status words, which must be clear when the
+    // first pass starts (the local sort of a taken sort leaves them so) and are written from here on
+    vrs::PoolPayloads pv{};
+    if (pairs) {
+        if (!ctx->os_status_clean)
+            VRS_HIP(ctx, hipMemsetAsync(ctx->os_status, 0, ctx->os_status_rows * VRS_RADIX_SORT_BINS * sizeof(uint32_t), ctx->stream));
+        ctx->os_status_clean = false;
+        pv.values_home = static_cast<uint32_t *>(st.vptr[st.cur]);
+        pv.values_partner = static_cast<uint32_t *>(st.vptr[st.cur ^ 1u]);
+        pv.overflow_values = ctx->os_pool_overflow_vals;
+        pv.slack_values = ctx->os_pool_slack_vals;
+        pv.status = ctx->os_status;
+        pv.status_words = ctx->os_status_rows * VRS_RADIX_SORT_BINS;
+        pv.spin_budget = ctx->os_spin_budget;
+    }
+    const vrs::PoolPayloads *pvp = pairs ? &pv : nullptr;
     const vrs::PoolStreams ps = vrs::pool_streams(n);
     const uint32_t c = st.cur;
     uint32_t *home = static_cast<uint32_t *>(st.kptr[c]), *partner = static_cast<uint32_t *>(st.kptr[c ^ 1u]);
@@ -1257,14 +1299,15 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     st.ev_ls_before = ctx->events_used[VRS_KERNEL_LOCAL_SORT];
     if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_A, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_pass_a(ctx->stream, home, partner, ctx->os_pool_overflow, n, st.key_base, ps, ctx->os_pool_plan, ctx->os_msd_plan,
-                                         ctx->xcc_map, ctx->os_misplace, room, par, ev));
+                                         ctx->xcc_map, ctx->os_misplace, room, par, ev, pvp));
     VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, partner, ctx->os_pool_overflow, st.key_base, ps, shape.sub_bits, par));
     if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_B, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, partner, ctx->os_pool_overflow, ctx->os_pool_slack, n, ctx->os_msd_plan, ctx->os_pool_plan, tiles_b,
-                                         st.key_base, vrs::pool_local_capacity(shape.local), ctx->os_pool_slack_cap, ctx->xcc_map, st.stamp, shape.sub_bits, par, ev));
+                                         st.key_base, vrs::pool_local_capacity(shape.local), ctx->os_pool_slack_cap, ctx->xcc_map, st.stamp, shape.sub_bits, par, ev,
+                                         false, pvp));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, home, n, ctx->os_msd_plan, ctx->os_pool_plan, shape, &ctx->os_plan->head,
-                                             ctx->os_host_head_dev, st.stamp, par, ev));
+                                             ctx->os_host_head_dev, st.stamp, par, ev, 256, nullptr, false, pvp));
     ctx->os_cursors_open = false;  // the local sort re-arms the reservation counters (a refusal is handled by one_read_complete)
     st.active = true;
     return VRS_OK;
@@ -1298,6 +1341,10 @@ static int one_read_complete(vrs_context ctx, bool *done) {
             st.cur = st.cur_at_start;
             ctx->os_hybrid_sorts++;
             ctx->os_pool_sorts++;
+            if (pairs) {
+                ctx->os_pool_pair_sorts++;
+                ctx->os_status_clean = true;  // (the local sort cleared the look-back words behind the two passes)
+            }
             ctx->os_pool_layout_valid = true;  // its regions held: the next sort of this size may start in them
             ctx->os_pool_layout_n = n;
             ctx->os_pool_layout_base = st.key_base;
@@ -1306,20 +1353,27 @@ static int one_read_complete(vrs_context ctx, bool *done) {
         if (head.msd_max_bucket != 0u && !st.pool_retried) {
             // Not refused, only misjudged: a bucket has more keys than the local sort that was enqueued blind takes (its shape came from
             // n alone; skewed keys).  Every bucket lies whole in its region: a local sort of a larger shape finishes the sort.
-            uint32_t local = 4u;
-            for (uint32_t cand : {0u, 1u, 2u})
-                if (local == 4u && head.msd_max_bucket <= vrs::pool_local_capacity(cand)) local = cand;
-            if (local != 4u) {
+            uint32_t local = 99u;
+            for (uint32_t cand : {0u, 1u, 2u, 5u})
+                if (local == 99u && (cand == 5u) == pairs && head.msd_max_bucket <= vrs::pool_local_capacity(cand)) local = cand;
+            if (local != 99u) {
                 vrs::LaunchEvents ev;
                 if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
                 if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
                 st.stamp = ctx->os_stamp;
+                vrs::PoolPayloads pv{};
+                if (pairs) {
+                    pv.values_home = static_cast<uint32_t *>(st.vptr[st.cur_at_start]);
+                    pv.slack_values = ctx->os_pool_slack_vals;
+                    pv.status = ctx->os_status;
+                    pv.status_words = ctx->os_status_rows * VRS_RADIX_SORT_BINS;
+                }
                 st.pool_retried = true;
                 st.pool_local = local;
                 ctx->os_pool_retries++;
                 VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, static_cast<uint32_t *>(st.kptr[st.cur_at_start]), n, ctx->os_msd_plan,
                                                          ctx->os_pool_plan, vrs::PoolShape{st.pool_sub_bits, local}, &ctx->os_plan->head, ctx->os_host_head_dev,
-                                                         st.stamp, st.pool_par, ev, 256, nullptr, true));
+                                                         st.stamp, st.pool_par, ev, 256, nullptr, true, pairs ? &pv : nullptr));
                 return VRS_OK;  // (still active: the settle waits for this one's word)
             }
         }
@@ -2155,6 +2209,9 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             if (sh) ctx->xcc_map = (ctx->xcc_map >> sh) | (ctx->xcc_map << (64u - sh));
             return VRS_OK;
         }
+        case VRS_TUNE_MSD_POOL_PAIRS:
+            ctx->os_pool_pairs = value != 0 ? 1 : 0;
+            return VRS_OK;
         case VRS_TUNE_MSD_POOL_REUSE_LAYOUT:
             ctx->os_pool_reuse = value != 0;
             ctx->os_pool_layout_valid = false;

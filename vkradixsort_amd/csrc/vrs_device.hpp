@@ -256,6 +256,7 @@ __device__ __forceinline__ void lb_store_l2(uint32_t *p, uint32_t v) {
 
 struct NoLookback {
     static constexpr bool kEnabled = false;
+    static constexpr bool kReserves = false;
     static constexpr bool kPool = false;
 };
 // where a chunk's keys come from when they do not lie in one piece (scatter_chunk's SRC): lane p of every wave holds piece p --
@@ -270,8 +271,10 @@ struct PieceSrc {
     uint32_t p0, p1, first_slot;  // wave-uniform
     const uint32_t *regions, *overflow;
     uint32_t n_virt;
+    const uint32_t *vregions = nullptr, *voverflow = nullptr;  // the payloads' twins of the two buffers (pairs only)
     using gptr = const uint32_t __attribute__((address_space(1))) *;  // (say that these are GLOBAL pointers, or the loads become flat loads)
     __device__ __forceinline__ gptr at(uint32_t v) const { return v < n_virt ? (gptr)regions + v : (gptr)overflow + (v - n_virt); }
+    __device__ __forceinline__ gptr val_at(uint32_t v) const { return v < n_virt ? (gptr)vregions + v : (gptr)voverflow + (v - n_virt); }
 };
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3u << 11) | 20u); }  // HW_REG_XCC_ID[3:0]
 // byte x of the probed map = the XCC the blocks with blockIdx % 8 == x ran on
@@ -453,6 +456,10 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
             const K k = *src.at(vs[i]);
             key[i] = (FULL || seg + i * 64 < valid) ? k : dg.template pad<K>();
         }
+        if constexpr (PAIRS) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) val[i] = *src.val_at(vs[i]);
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -585,20 +592,32 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     }
     __syncthreads();
     VRS_MARK(4);
-    if constexpr (LB::kEnabled) {
+    if constexpr (LB::kEnabled && !LB::kReserves) {  // (a reservation never waits)
         if (sm.lb_gave_up) {  // workgroup-uniform, never in a healthy run: a predecessor did not publish in time
-            uint32_t *cnt = sm.whist[0];  // the per-wave counters are dead from here on
-            __syncthreads();
-            if (tid < kBins) cnt[tid] = 0;
-            __syncthreads();
-            recount_keys(cnt, static_cast<const K *>(lb.stream_keys), lb.done, dg);
-            __syncthreads();
-            if (tid < kBins) {
-                const uint32_t before = cnt[tid];
-                lb_inclusive = kLbInclusive | (before + lb_total);
-                sm.gbase[tid] = lb.seed + before - lb_excl;
+            if constexpr (LB::kPool) {
+                // the pool form's stable passes: the sort is refused (the caller's keys have not moved); the tile's keys go to SOME
+                // place inside its regions
+                __syncthreads();
+                if (tid < kBins) {
+                    lb.refuse();
+                    lb_inclusive = kLbInclusive | lb_total;
+                    lb.place(sm.gbase, tid, 0u, lb_excl);
+                }
+                __syncthreads();
+            } else {
+                uint32_t *cnt = sm.whist[0];  // the per-wave counters are dead from here on
+                __syncthreads();
+                if (tid < kBins) cnt[tid] = 0;
+                __syncthreads();
+                recount_keys(cnt, static_cast<const K *>(lb.stream_keys), lb.done, dg);
+                __syncthreads();
+                if (tid < kBins) {
+                    const uint32_t before = cnt[tid];
+                    lb_inclusive = kLbInclusive | (before + lb_total);
+                    sm.gbase[tid] = lb.seed + before - lb_excl;
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
 
@@ -630,9 +649,13 @@ __device__ __forceinline__ void scatter_chunk(ChunkSmem<K, ITEMS, WAVES, PAIRS> 
     if constexpr (PAIRS) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) val[i] = sm.vals[i * THREADS + tid];
+        if constexpr (LB::kPool) {
+            lb.template store_values<ITEMS, THREADS, FULL>(val, dst, vout, valid);  // (dst: what store() made of it)
+        } else {
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            if (FULL || i * THREADS + tid < valid) vout[dst[i]] = val[i];
+            for (int i = 0; i < ITEMS; ++i) {
+                if (FULL || i * THREADS + tid < valid) vout[dst[i]] = val[i];
+            }
         }
     }
     // the next chunk's first barrier (after it zeroes the counters) separates these LDS reads from its writes

@@ -319,9 +319,23 @@ uint32_t pool_slack_capacity(uint32_t n, uint32_t sub_bits, uint32_t top_bytes =
 // The shape of a pool sort, chosen from n alone (the form is enqueued blind): bits of the second pass and the local sort's workgroup.
 struct PoolShape {
     uint32_t sub_bits;   // 6 or 7
-    uint32_t local;      // 4 / 3: one WAVE per bucket (up to 1021 / 1789 keys), 0: 256 threads x 16 slots (4093, five workgroups per CU), 1: 256 x 28 (7165, four), 2: 512 x 28 (14333, two)
+    uint32_t local;      // 3: one WAVE per bucket (up to 1789 keys), 0: 256 threads x 16 slots (4093, five workgroups per CU), 1: 256 x 28 (7165, four), 2: 512 x 28 (14333, two);
+                         // key + payload pairs: 4: 512 threads x 13 pairs (6656), 5: 1024 x 13 (13312)
 };
 PoolShape pool_shape(uint32_t n, int forced_sub_bits = 0);  // forced_sub_bits: 0 = by size, 6 or 7
+PoolShape pool_shape_pairs(uint32_t n);
+// Key + payload pairs (the STABLE pool form: a tile's place in a region is its rank there, by decoupled look-back): the payloads'
+// twins of the keys' buffers and the look-back's status words (the one-call sort's; `status_words` of them, all cleared by the local
+// sort of a sort that is taken).  By value: a kernel argument.
+struct PoolPayloads {
+    uint32_t *values_home = nullptr;      // the caller's payloads: read by the first pass, written by the local sort
+    uint32_t *values_partner = nullptr;   // the primary regions' twin
+    uint32_t *overflow_values = nullptr;  // the overflow regions' twin
+    uint32_t *slack_values = nullptr;     // the slack buffer's twin
+    uint32_t *status = nullptr;
+    size_t status_words = 0;
+    uint32_t spin_budget = 0;
+};
 // the second half alone, for n keys grouped by `top_bytes` top bytes: sub_bits 6 .. 8 (0: no shape takes them)
 PoolShape pool_grouped_shape(uint32_t n, uint32_t top_bytes);
 struct PoolGroups {          // keys of every top byte (grouped keys; by value: a kernel argument)
@@ -337,7 +351,7 @@ hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t
 // starts); misplace: test hook, odd rows of workgroups walk the neighbouring slice
 hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, uint32_t *overflow, uint32_t n,
                               uint32_t key_base, const PoolStreams &ps, PoolPlan *pool, MsdPlan *msd, unsigned long long xcc_map,
-                              bool misplace, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev = {});
+                              bool misplace, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev = {}, const PoolPayloads *pv = nullptr);
 // after the first pass, one workgroup per top byte: top-byte starts, tile tables, piece rows, the buckets' slack regions (from a
 // sample of the first pass's OUTPUT: regions / overflow), verdict 1 (slack_capacity: slots the slack buffer has)
 hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap, uint32_t slack_capacity,
@@ -349,12 +363,14 @@ hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, ui
 // sort that follows takes per bucket; slack_capacity: as given to the plan (the last kPoolTile slots take refused runs)
 hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *slack, uint32_t n, MsdPlan *msd,
                               PoolPlan *pool, uint32_t tiles_b, uint32_t key_base, uint32_t local_cap, uint32_t slack_capacity,
-                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, uint32_t par, LaunchEvents ev = {}, bool grouped = false);
+                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, uint32_t par, LaunchEvents ev = {}, bool grouped = false,
+                              const PoolPayloads *pv = nullptr);
 // sorts every bucket from its slack region to keys_out[its exact start ...) with the workgroup shape.local.  Gives verdict 2 (verdict 1, no flag from the passes) = MsdPlan::ok and the host head
 // (msd_ok, lsd_missing = 1, stamped last); re-arms the first pass's reservation counters
 hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
                                   PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t par,
-                                  LaunchEvents ev = {}, uint32_t top_bytes = 256, uint32_t *host_log = nullptr, bool retry = false);
+                                  LaunchEvents ev = {}, uint32_t top_bytes = 256, uint32_t *host_log = nullptr, bool retry = false,
+                                  const PoolPayloads *pv = nullptr);
 // retry: the second attempt after a first local sort found a bucket beyond its shape (PoolPlan::fail bit 1): that bit no longer refuses
 // top_bytes: the top bytes that exist (a sort: 256; the second half alone: the caller's); host_log: see launch_msd_plan
 

@@ -354,4 +354,178 @@ __device__ __forceinline__ void wave_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
     }
 }
 
+// One LSD pass over the keys a workgroup holds in registers (wave-striped: wave v owns ITEMS * 64 consecutive positions,
+// item i of lane l is position v * ITEMS * 64 + i * 64 + l; positions >= n hold nothing and stay where they are), through
+// LDS: counters fed by returning LDS atomics, a scan over the bins, re-bucketing, striped read-back.
+// STABLE: one counter table per wave (lane order inside an instruction is the RANK_ATOMIC property, item order and wave order
+// come from the tables' prefix) -- equal digits keep their order.  Not STABLE: ONE table for the workgroup, a quarter of the
+// zeroing and scanning; equal digits come out in any order -- enough for the FIRST pass over bare keys (keys that tie in
+// this digit are told apart by the later pass or are equal), never for payloads.
+template <int THREADS, int ITEMS, int BITS, bool PAIRS, bool STABLE, typename K = uint32_t>
+__device__ __forceinline__ void local_pass(K (&key)[ITEMS], uint32_t (&val)[PAIRS ? ITEMS : 1], K *s_keys,
+                                           uint32_t *s_vals, uint32_t *s_hist, uint32_t *s_tmp, uint32_t shift, uint32_t n) {
+    // thread t scans bins [t * PER, (t + 1) * PER); a workgroup of more threads than bins (1024 threads, 512 bins: the large
+    // buckets of pairs and 64-bit keys) leaves its upper waves out of the scan
+    constexpr int WAVES = THREADS / 64, BINS = 1 << BITS, TABLES = STABLE ? WAVES : 1, PER = BINS >= THREADS ? BINS / THREADS : 1;
+    static_assert(PER * THREADS == BINS || (PER == 1 && THREADS % BINS == 0), "every scanning thread owns PER whole bins");
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool scans = THREADS <= BINS || tid < static_cast<uint32_t>(BINS);  // wave-uniform
+    for (uint32_t c = tid; c < TABLES * BINS; c += THREADS) s_hist[c] = 0;
+    __syncthreads();
+    uint32_t *my = s_hist + (STABLE ? wave * BINS : 0u);
+    const uint32_t seg = wave * (ITEMS * 64) + lane;
+    uint32_t rank[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        rank[i] = seg + i * 64;
+        if (rank[i] < n) {
+            const uint32_t d = static_cast<uint32_t>(key[i] >> shift) & (BINS - 1);
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+            const uint64_t active = __ballot(1);
+            if (__ballot(d == d0) == active) {  // one digit value for the whole instruction: one add instead of up to 64 on one counter
+                uint32_t old = 0;
+                if (__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(active >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(active), 0u)) == 0u)
+                    old = __hip_atomic_fetch_add(&my[d0], static_cast<uint32_t>(__popcll(active)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rank[i] = __builtin_amdgcn_readfirstlane(old) +
+                          __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(active >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(active), 0u));
+            } else {
+                rank[i] = __hip_atomic_fetch_add(&my[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+    {   // exclusive prefix over (bin, table): thread t owns bins [t * PER, (t + 1) * PER)
+        uint32_t c[TABLES][PER], total = 0;
+#pragma unroll
+        for (int v = 0; v < TABLES; ++v) {
+            if constexpr (PER == 2) {
+                const uint2 q = reinterpret_cast<const uint2 *>(s_hist + v * BINS)[tid];
+                c[v][0] = q.x;
+                c[v][1] = q.y;
+                total += q.x + q.y;
+            } else {
+#pragma unroll
+                for (int p_ = 0; p_ < PER; ++p_) {
+                    c[v][p_] = scans ? s_hist[v * BINS + tid * PER + p_] : 0u;
+                    total += c[v][p_];
+                }
+            }
+        }
+        uint32_t incl = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= static_cast<uint32_t>(o)) incl += t;
+        }
+        if (lane == 63u) s_tmp[wave] = incl;
+        __syncthreads();
+        uint32_t acc = incl - total;
+#pragma unroll
+        for (int v = 0; v < WAVES; ++v) acc += (static_cast<uint32_t>(v) < wave) ? s_tmp[v] : 0u;
+        uint32_t out[TABLES][PER];
+#pragma unroll
+        for (int p_ = 0; p_ < PER; ++p_) {
+#pragma unroll
+            for (int v = 0; v < TABLES; ++v) {
+                out[v][p_] = acc;
+                acc += c[v][p_];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < TABLES; ++v) {
+            if constexpr (PER == 2) {
+                reinterpret_cast<uint2 *>(s_hist + v * BINS)[tid] = make_uint2(out[v][0], out[v][1]);
+            } else {
+#pragma unroll
+                for (int p_ = 0; p_ < PER; ++p_)
+                    if (scans) s_hist[v * BINS + tid * PER + p_] = out[v][p_];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (seg + i * 64 < n) rank[i] += my[static_cast<uint32_t>(key[i] >> shift) & (BINS - 1)];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (seg + i * 64 < n) s_keys[rank[i]] = key[i];
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if (seg + i * 64 < n) s_vals[rank[i]] = val[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) key[i] = s_keys[seg + i * 64];
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) val[i] = s_vals[seg + i * 64];
+    }
+    __syncthreads();
+}
+
+// the bucket with ITEMS keys per thread (n <= ITEMS * THREADS): read once, two stable 9-bit passes, written back -- in place
+// (the counted form) or to another place (the pool form's pairs: from the slack buffers to the caller's)
+template <int THREADS, int ITEMS, bool PAIRS, bool STREAM = false>  // STREAM: nobody reads the output soon -- its stores go around the caches
+__device__ __forceinline__ void local_sort_bucket_to(const uint32_t *src, const uint32_t *src_vals, uint32_t *bucket, uint32_t *bucket_vals, uint32_t n,
+                                                     uint32_t *s_keys, uint32_t *s_vals, uint32_t *s_hist, uint32_t *s_tmp) {
+    constexpr int BITS = 9;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t key[ITEMS], val[PAIRS ? ITEMS : 1];
+    const uint32_t seg = wave * (ITEMS * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t idx = seg + i * 64;
+        const uint32_t k = src[idx < n ? idx : n - 1u];
+        key[i] = k;  // positions >= n hold nothing: the passes leave them alone and they are not written
+    }
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t idx = seg + i * 64;
+            val[i] = src_vals[idx < n ? idx : n - 1u];
+        }
+    }
+    local_pass<THREADS, ITEMS, BITS, PAIRS, PAIRS>(key, val, s_keys, s_vals, s_hist, s_tmp, 0, n);  // bare keys: any order of ties
+    local_pass<THREADS, ITEMS, BITS, PAIRS, true>(key, val, s_keys, s_vals, s_hist, s_tmp, BITS, n);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t idx = seg + i * 64;
+        if (idx < n) {
+            if constexpr (STREAM) __builtin_nontemporal_store(key[i], bucket + idx);
+            else bucket[idx] = key[i];
+        }
+    }
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t idx = seg + i * 64;
+            if (idx < n) {
+                if constexpr (STREAM) __builtin_nontemporal_store(val[i], bucket_vals + idx);
+                else bucket_vals[idx] = val[i];
+            }
+        }
+    }
+}
+
+template <int THREADS, int ITEMS, bool PAIRS>
+__device__ __forceinline__ void local_sort_bucket(uint32_t *bucket, uint32_t *bucket_vals, uint32_t n, uint32_t *s_keys,
+                                                  uint32_t *s_vals, uint32_t *s_hist, uint32_t *s_tmp) {
+    local_sort_bucket_to<THREADS, ITEMS, PAIRS>(bucket, bucket_vals, bucket, bucket_vals, n, s_keys, s_vals, s_hist, s_tmp);
+}
+
+// The local sort is the last kernel of a hybrid sort and LDS-bound: it has HBM time to spare, so it also clears the look-back
+// status words for the NEXT sort (the counting read, which is HBM-bound, then skips its 15.6 MB of zero stores): workgroup b
+// of `blocks` clears the b-th share of status[0, vecs).
+struct StatusClear {
+    uint4 *status;   // nullptr: nothing to clear
+    uint32_t vecs;
+};
+__device__ __forceinline__ void clear_status_share(const StatusClear &sc, uint32_t threads) {
+    if (sc.status == nullptr) return;
+    const uint32_t per = (sc.vecs + gridDim.x - 1u) / gridDim.x;
+    const uint32_t z0 = blockIdx.x * per, z1 = min(z0 + per, sc.vecs);
+    for (uint32_t c = z0 + threadIdx.x; c < z1; c += threads) sc.status[c] = make_uint4(0, 0, 0, 0);
+}
+
 }  // namespace vrs

@@ -216,8 +216,10 @@ struct PoolReserve {
     }
     __device__ __forceinline__ void fetch(int, uint32_t (&)[kLbBatch]) const {}
     __device__ __forceinline__ uint32_t resolve(uint32_t (&)[kLbBatch], bool &) const { return reserved; }
+    __device__ __forceinline__ void refuse() const {}  // (a reservation never waits: scatter_chunk's give-up path is dead code here)
     // run [reserved, reserved + cnt) of the region's position space; excl: where the digit's run starts inside the tile
-    __device__ __forceinline__ void place(uint32_t *gbase, uint32_t tid, uint32_t, uint32_t excl) const {
+    __device__ __forceinline__ void place(uint32_t *gbase, uint32_t tid, uint32_t, uint32_t excl) const { place_run(gbase, tid, reserved, excl); }
+    __device__ __forceinline__ void place_run(uint32_t *gbase, uint32_t tid, uint32_t reserved, uint32_t excl) const {
         const uint32_t end = reserved + cnt;
         uint32_t g, g2 = 0, sp = 0xFFFFFFFFu;
         bool bad = false;
@@ -255,6 +257,49 @@ struct PoolReserve {
             if (FULL || i * THREADS + tid < valid) *p = key[i];
         }
     }
+    // payloads (the stable form below): to the twins of the two buffers, at the slots store() decided
+    uint32_t *overflow_values = nullptr;
+    template <int ITEMS, uint32_t THREADS, bool FULL>
+    __device__ __forceinline__ void store_values(const uint32_t (&val)[ITEMS], const uint32_t (&dst)[ITEMS], uint32_t *vout, uint32_t valid) const {
+        const uint32_t tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            uint32_t *p = dst[i] < n_virt ? vout + dst[i] : overflow_values + min(dst[i] - n_virt, overflow_last);
+            if (FULL || i * THREADS + tid < valid) *p = val[i];
+        }
+    }
+};
+
+// The STABLE first pass (key + payload pairs): the same regions, the same split of a share's positions into primary and overflow
+// slots -- but a tile's place in its share is its RANK there, the keys of the slice's earlier tiles with that top byte, which the
+// decoupled look-back of the counted form's passes delivers (StreamLookback, vrs_device.hpp: one chain per slice, every tile of it
+// behind the same L2).  Rank order is input order, so a share read primary part first, overflow part second, is read in input
+// order.  The cursors are still added to (nobody waits for the answer): the plan kernel takes the shares' exact sizes from them.
+struct PoolLookback : StreamLookback {
+    static constexpr bool kPool = true;
+    PoolReserve at;  // the regions' arithmetic (its reservation is not used)
+    __device__ __forceinline__ void publish(uint32_t v) const {
+        if (!at.reserved_yet) {  // the first call: this tile's count
+            at.reserved_yet = true;
+            at.cnt = v - at.pad_keys;
+            if (at.cnt) __hip_atomic_fetch_add(at.cursor, at.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            at.rb = at.region[0];
+            at.rc = at.region[8 * 256];
+            at.ob = at.region[16 * 256];
+            at.oc = at.region[24 * 256];
+        }
+        StreamLookback::publish(v);
+    }
+    __device__ __forceinline__ void refuse() const { __hip_atomic_fetch_or(at.fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void place(uint32_t *gbase, uint32_t tid, uint32_t before, uint32_t excl) const { at.place_run(gbase, tid, before, excl); }
+    template <typename K, int ITEMS, uint32_t THREADS, bool FULL, typename DG>
+    __device__ __forceinline__ void store(const uint32_t *g, const K (&key)[ITEMS], uint32_t (&dst)[ITEMS], K *kout, uint32_t valid, const DG &dg) const {
+        at.template store<K, ITEMS, THREADS, FULL>(g, key, dst, kout, valid, dg);
+    }
+    template <int ITEMS, uint32_t THREADS, bool FULL>
+    __device__ __forceinline__ void store_values(const uint32_t (&val)[ITEMS], const uint32_t (&dst)[ITEMS], uint32_t *vout, uint32_t valid) const {
+        at.template store_values<ITEMS, THREADS, FULL>(val, dst, vout, valid);
+    }
 };
 
 // the place of the XCC this workgroup runs on in the probed order (8: an XCC the probe never saw)
@@ -271,11 +316,13 @@ __device__ __forceinline__ uint32_t xcc_place(unsigned long long xcc_map) {
 // sample counted for the regions of row x, the row whose cursors live in this CU's L2.  (Observed placement: block b on the XCC of
 // place (b + r) % 8 with r fixed for a queue -- and a stream may move to another queue: r at the probe is not r now.  Nothing but
 // "the blocks of a group of eight run on eight XCCs" is used, and that is checked: PoolPlan::claim_a.)
+template <bool PAIRS>
 __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out,
                                                              uint32_t *__restrict__ overflow, uint32_t n, uint32_t key_base,
                                                              PoolStreams ps, PoolPlan *__restrict__ pool, MsdPlan *__restrict__ msd,
-                                                             unsigned long long xcc_map, int misplace, uint32_t overflow_capacity, uint32_t par) {
-    __shared__ ChunkSmem<uint32_t, 16, 8, false> sm;
+                                                             unsigned long long xcc_map, int misplace, uint32_t overflow_capacity, uint32_t par,
+                                                             PoolPayloads pv) {
+    __shared__ ChunkSmem<uint32_t, 16, 8, PAIRS> sm;
     __shared__ uint32_t s_gbase2[kBins], s_split[kBins], s_flags;
     if (pool->armed == 0u) return;  // uniform: the sample kernel did not lay regions out (key range below 27 bits)
     const uint32_t i = blockIdx.x >> 3;
@@ -297,23 +344,42 @@ __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__r
     RadixDigit<uint32_t> dg;
     dg.shift = pool->shift + (kMsdBits - 8u);
     dg.base = key_base;
-    PoolReserve lb;
-    lb.cursor = &msd->cursor_a[s_out][d];
-    lb.region = &pool->base[s_out][d];
-    lb.pad_keys = d == 255u ? kPoolTile - valid : 0u;
-    lb.n_virt = n;
-    lb.overflow = overflow;
-    lb.overflow_last = overflow_capacity - 1u;
-    lb.gbase2 = s_gbase2;
-    lb.split = s_split;
-    lb.flags = &s_flags;
-    lb.fail_word = &pool->fail[par];
+    PoolReserve at;
+    at.cursor = &msd->cursor_a[s_out][d];
+    at.region = &pool->base[s_out][d];
+    at.pad_keys = d == 255u ? kPoolTile - valid : 0u;
+    at.n_virt = n;
+    at.overflow = overflow;
+    at.overflow_last = overflow_capacity - 1u;
+    at.gbase2 = s_gbase2;
+    at.split = s_split;
+    at.flags = &s_flags;
+    at.fail_word = &pool->fail[par];
     uint32_t unused = 0;
-    if (valid == kPoolTile)
-        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true>(sm, kin, nullptr, keys_out, nullptr, valid, dg, unused, lb, NoPieces{},
-                                                                 static_cast<size_t>(n) * sizeof(uint32_t) >= kStreamInBytes);  // (inputs beyond the caches: vrs_device.hpp)
-    else
-        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, false>(sm, kin, nullptr, keys_out, nullptr, valid, dg, unused, lb);
+    const bool stream_in = static_cast<size_t>(n) * sizeof(uint32_t) >= kStreamInBytes;  // (inputs beyond the caches: vrs_device.hpp)
+    if constexpr (PAIRS) {
+        // payloads: the tile's place in (slice, top byte)'s share is its rank there (PoolLookback) -- one chain per slice, row i of it
+        at.overflow_values = pv.overflow_values;
+        PoolLookback lb;
+        lb.at = at;
+        lb.stream_keys = keys_in + ps.start[s_in];
+        lb.done = done;
+        lb.col = pv.status + static_cast<size_t>(s_out) * kBins + d;
+        lb.stride = static_cast<size_t>(8) * kBins;
+        lb.index = static_cast<int>(i);
+        lb.tag = 1u << kLbTagShift;
+        lb.budget = pv.spin_budget;
+        const uint32_t *vin = pv.values_home + ps.start[s_in] + done;
+        if (valid == kPoolTile)
+            scatter_chunk<uint32_t, 16, 8, true, RANK_ATOMIC, true>(sm, kin, vin, keys_out, pv.values_partner, valid, dg, unused, lb, NoPieces{}, stream_in);
+        else
+            scatter_chunk<uint32_t, 16, 8, true, RANK_ATOMIC, false>(sm, kin, vin, keys_out, pv.values_partner, valid, dg, unused, lb);
+    } else {
+        if (valid == kPoolTile)
+            scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true>(sm, kin, nullptr, keys_out, nullptr, valid, dg, unused, at, NoPieces{}, stream_in);
+        else
+            scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, false>(sm, kin, nullptr, keys_out, nullptr, valid, dg, unused, at);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -598,8 +664,10 @@ struct SlackReserve {
     }
     __device__ __forceinline__ void fetch(int, uint32_t (&)[kLbBatch]) const {}
     __device__ __forceinline__ uint32_t resolve(uint32_t (&)[kLbBatch], bool &) const { return reserved; }
+    __device__ __forceinline__ void refuse() const {}  // (a reservation never waits)
     // run [reserved, reserved + cnt) of the region; excl: where the digit's run starts inside the tile
-    __device__ __forceinline__ void place(uint32_t *gbase, uint32_t tid, uint32_t, uint32_t excl) const {
+    __device__ __forceinline__ void place(uint32_t *gbase, uint32_t tid, uint32_t, uint32_t excl) const { place_run(gbase, tid, reserved, excl); }
+    __device__ __forceinline__ void place_run(uint32_t *gbase, uint32_t tid, uint32_t reserved, uint32_t excl) const {
         const uint32_t end = reserved + cnt;
         const bool bad = cnt != 0u && end > cap;
         if (bad) {
@@ -626,14 +694,47 @@ struct SlackReserve {
         // a key above the probed range (or below the promised floor): the local sort, which gives the last verdict, sees this
         if (__ballot(over != 0u) != 0ull && (tid & 63u) == 0u) __hip_atomic_fetch_or(fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    template <int ITEMS, uint32_t THREADS, bool FULL>
+    __device__ __forceinline__ void store_values(const uint32_t (&val)[ITEMS], const uint32_t (&dst)[ITEMS], uint32_t *vout, uint32_t valid) const {
+        const uint32_t tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if (FULL || i * THREADS + tid < valid) vout[dst[i]] = val[i];
+    }
 };
 
-template <uint32_t SUBBITS>
-__global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
+// The STABLE second pass (pairs): a tile's place in a bucket's region is its rank in the bucket -- the keys of the top byte's earlier
+// tiles with that digit: one look-back chain per top byte (the counted form's second pass, msd_pass_b_kernel, has the same chains).
+// The buckets' cursors are still added to: the local sort reads the buckets' sizes there.
+struct SlackLookback : StreamLookback {
+    static constexpr bool kPool = true;
+    SlackReserve at;
+    __device__ __forceinline__ void publish(uint32_t v) const {
+        if (!at.reserved_yet) {
+            at.reserved_yet = true;
+            at.cnt = v - at.pad_keys;
+            if (at.cnt) __hip_atomic_fetch_add(at.cursor, at.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        StreamLookback::publish(v);
+    }
+    __device__ __forceinline__ void refuse() const { __hip_atomic_fetch_or(at.fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void place(uint32_t *gbase, uint32_t tid, uint32_t before, uint32_t excl) const { at.place_run(gbase, tid, before, excl); }
+    template <typename K, int ITEMS, uint32_t THREADS, bool FULL, typename DG>
+    __device__ __forceinline__ void store(const uint32_t *g, const K (&key)[ITEMS], uint32_t (&dst)[ITEMS], K *kout, uint32_t valid, const DG &dg) const {
+        at.template store<K, ITEMS, THREADS, FULL>(g, key, dst, kout, valid, dg);
+    }
+    template <int ITEMS, uint32_t THREADS, bool FULL>
+    __device__ __forceinline__ void store_values(const uint32_t (&val)[ITEMS], const uint32_t (&dst)[ITEMS], uint32_t *vout, uint32_t valid) const {
+        at.template store_values<ITEMS, THREADS, FULL>(val, dst, vout, valid);
+    }
+};
+
+template <uint32_t SUBBITS, bool PAIRS>
+__global__ __launch_bounds__(512, PAIRS ? 4 : 6) void pool_pass_b_kernel(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
                                                              uint32_t *__restrict__ slack, const MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool,
                                                              uint32_t n_virt, uint32_t key_base, uint32_t local_cap, uint32_t dump,
-                                                             unsigned long long xcc_map, uint32_t stamp, uint32_t grouped, uint32_t par) {
-    __shared__ ChunkSmem<uint32_t, 16, 8, false> sm;
+                                                             unsigned long long xcc_map, uint32_t stamp, uint32_t grouped, uint32_t par, PoolPayloads pv) {
+    __shared__ ChunkSmem<uint32_t, 16, 8, PAIRS> sm;
     // the list follows the XCC this workgroup RUNS on (pool_pass_a_kernel): all tiles of a top byte then meet behind the L2 that
     // holds its 64 cursors, whatever the dispatcher's rotation
     const uint32_t x = xcc_place(xcc_map), j = blockIdx.x >> 3;
@@ -659,14 +760,14 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     const uint32_t shift = pool->shift;
     constexpr uint32_t SUB = 1u << SUBBITS;
     const uint32_t d = threadIdx.x & 255u, b = a * SUB + min(d, SUB - 1u);
-    SlackReserve lb;
-    lb.cursor = &pool->sub_cursor[b];
+    SlackReserve at;
+    at.cursor = &pool->sub_cursor[b];
     if (threadIdx.x < SUB) {  // (the threads that reserve: one per bucket of the top byte)
-        lb.start = pool->sub_start[b];
-        lb.cap = pool->sub_start[b + 1u] - lb.start;
+        at.start = pool->sub_start[b];
+        at.cap = pool->sub_start[b + 1u] - at.start;
     }
-    lb.local_cap = local_cap;
-    lb.max_bucket = &pool->max_bucket;
+    at.local_cap = local_cap;
+    at.max_bucket = &pool->max_bucket;
     const uint32_t pend = pc.x, pslot = pc.y;
     const uint32_t before = __shfl_up(pend, 1);
     const uint32_t plo = lane == 0u ? 0u : before;  // the piece holds positions [plo, pend) of the top byte
@@ -686,22 +787,44 @@ __global__ __launch_bounds__(512, 6) void pool_pass_b_kernel(const uint32_t *__r
     const uint32_t slot0 = one_piece ? entry.x : __builtin_amdgcn_readlane(pslot, src.p0) + (tile_lo - __builtin_amdgcn_readlane(plo, src.p0));  // the tile's first key
     src.first_slot = slot0;
     const BitsDigit dg{shift + kMsdSubBits - SUBBITS, SUB - 1u, key_base};  // (key_base is a multiple of 2^24 and the bits end at or below bit 24)
-    lb.dump = dump;
-    lb.pad_keys = d == SUB - 1u ? kPoolTile - valid : 0u;  // (the padding key, key_base - 1, carries the largest digit)
+    at.dump = dump;
+    at.pad_keys = d == SUB - 1u ? kPoolTile - valid : 0u;  // (the padding key, key_base - 1, carries the largest digit)
     // a sort: no key may have bits above the probed range; grouped keys (the caller's promise): every key of this tile carries top byte a
-    lb.above = grouped ? 0xFF000000u : (shift + kMsdBits < 32u ? ~0u << (shift + kMsdBits) : 0u);
-    lb.key_base = grouped ? key_base + (a << 24) : key_base;
-    lb.fail_word = &pool->fail[par];
+    at.above = grouped ? 0xFF000000u : (shift + kMsdBits < 32u ? ~0u << (shift + kMsdBits) : 0u);
+    at.key_base = grouped ? key_base + (a << 24) : key_base;
+    at.fail_word = &pool->fail[par];
     uint32_t unused = 0;
     // (two workgroups of one group of eight on ONE XCC: the tile has been taken twice and another not at all)
     if (threadIdx.x == 0 && claimed == stamp) __hip_atomic_fetch_or(&pool->fail[par], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (one_piece)  // five tiles in six
-        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve>(sm, slot0 < n_virt ? regions + slot0 : overflow + (slot0 - n_virt), nullptr, slack, nullptr, valid, dg, unused, lb, NoPieces{},
-                                                                                         static_cast<size_t>(pool->top_base[256]) * sizeof(uint32_t) >= kStreamInBytes);
-    else if (valid == kPoolTile)
-        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve, PieceSrc>(sm, nullptr, nullptr, slack, nullptr, valid, dg, unused, lb, src);
-    else  // the top byte's ragged last tile
-        scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, false, BitsDigit, SlackReserve, PieceSrc>(sm, nullptr, nullptr, slack, nullptr, valid, dg, unused, lb, src);
+    const bool stream_in = static_cast<size_t>(pool->top_base[256]) * sizeof(uint32_t) >= kStreamInBytes;
+    const uint32_t *kin = slot0 < n_virt ? regions + slot0 : overflow + (slot0 - n_virt);
+    if constexpr (PAIRS) {
+        // payloads: the tile's place in a bucket is its rank there (SlackLookback) -- the chain of top byte a: the rows of its tiles
+        // in list x, 8 rows apart (tile i of the top byte is tile j of the list)
+        src.vregions = pv.values_partner;
+        src.voverflow = pv.overflow_values;
+        SlackLookback lb;
+        lb.at = at;
+        lb.col = pv.status + (static_cast<size_t>(j - (entry.y >> 8)) * 8u + x) * kBins + d;
+        lb.stride = static_cast<size_t>(8) * kBins;
+        lb.index = static_cast<int>(entry.y >> 8);
+        lb.tag = 6u << kLbTagShift;
+        lb.budget = pv.spin_budget;
+        const uint32_t *vin = slot0 < n_virt ? pv.values_partner + slot0 : pv.overflow_values + (slot0 - n_virt);
+        if (one_piece)
+            scatter_chunk<uint32_t, 16, 8, true, RANK_ATOMIC, true, BitsDigit, SlackLookback>(sm, kin, vin, slack, pv.slack_values, valid, dg, unused, lb, NoPieces{}, stream_in);
+        else if (valid == kPoolTile)
+            scatter_chunk<uint32_t, 16, 8, true, RANK_ATOMIC, true, BitsDigit, SlackLookback, PieceSrc>(sm, nullptr, nullptr, slack, pv.slack_values, valid, dg, unused, lb, src);
+        else
+            scatter_chunk<uint32_t, 16, 8, true, RANK_ATOMIC, false, BitsDigit, SlackLookback, PieceSrc>(sm, nullptr, nullptr, slack, pv.slack_values, valid, dg, unused, lb, src);
+    } else {
+        if (one_piece)  // five tiles in six
+            scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve>(sm, kin, nullptr, slack, nullptr, valid, dg, unused, at, NoPieces{}, stream_in);
+        else if (valid == kPoolTile)
+            scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, true, BitsDigit, SlackReserve, PieceSrc>(sm, nullptr, nullptr, slack, nullptr, valid, dg, unused, at, src);
+        else  // the top byte's ragged last tile
+            scatter_chunk<uint32_t, 16, 8, false, RANK_ATOMIC, false, BitsDigit, SlackReserve, PieceSrc>(sm, nullptr, nullptr, slack, nullptr, valid, dg, unused, at, src);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -770,7 +893,7 @@ template <int THREADS, uint32_t CAPACITY, uint32_t SUBBITS>
 __device__ __forceinline__ bool pool_bucket(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out, MsdPlan *__restrict__ msd,
                                             const PoolPlan *__restrict__ pool, uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
                                             OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log, uint32_t retry, uint32_t par,
-                                            const uint32_t *&src, uint32_t *&abase, uint32_t &mis, uint32_t &n) {
+                                            const uint32_t *&src, uint32_t *&abase, uint32_t &mis, uint32_t &n, const StatusClear sc = {nullptr, 0u}) {
     constexpr uint32_t SUB = 1u << SUBBITS, PER = SUB / 64u;
     const uint32_t b = gridDim.x - 1u - blockIdx.x, a = b >> SUBBITS, c = b & (SUB - 1u);  // (the grid: the top bytes that exist x SUB)
     const uint32_t lane = threadIdx.x & 63u;
@@ -803,6 +926,7 @@ __device__ __forceinline__ bool pool_bucket(const uint32_t *__restrict__ slack, 
         }
     }
     if (ok == 0u) return false;  // (enqueued before the verdicts were known, and one said no)
+    clear_status_share(sc, THREADS);  // (pairs: the look-back words of the two passes, clear for the next sort -- every workgroup its share)
     // the first pass's cursors, zero for the next sort (the counted form's local sort does the same: rearm_reservation)
     if (blockIdx.x < 2u * kStreams)
         for (uint32_t q = threadIdx.x; q < 256u; q += THREADS) cursors[blockIdx.x * 256u + q] = 0;
@@ -858,6 +982,39 @@ __global__ __launch_bounds__(THREADS, WGS *(THREADS / 64) / 4) void pool_local_s
             default: slack_sort_bucket<THREADS, 7>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
         }
     }
+}
+
+// Key + payload pairs: the bucket's keys and payloads from the two slack buffers (the same region in both), two STABLE 9-bit passes
+// inside LDS (local_pass, vrs_local_sort.hpp: the counted form's local sort of pairs), written to the bucket's final place in the
+// caller's two buffers.  512 threads x up to 13 pairs (two workgroups per CU), or 1024 x 13 for buckets of up to 13312.
+constexpr int kPoolPairItems = 13;
+template <int THREADS, uint32_t SUBBITS>
+__global__ __launch_bounds__(THREADS, 4) void pool_local_sort_pairs_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out,
+                                                                          MsdPlan *__restrict__ msd, const PoolPlan *__restrict__ pool,
+                                                                          uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
+                                                                          OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log, uint32_t retry,
+                                                                          uint32_t par, PoolPayloads pv) {
+    constexpr int WAVES = THREADS / 64;
+    constexpr uint32_t CAP = THREADS * kPoolPairItems;
+    __shared__ uint32_t s_keys[CAP];
+    __shared__ uint32_t s_vals[CAP];
+    __shared__ uint32_t s_hist[WAVES << 9];
+    __shared__ uint32_t s_tmp[1 + WAVES];
+    const uint32_t *src;
+    uint32_t *abase, mis, n;
+    const StatusClear sc{reinterpret_cast<uint4 *>(pv.status), static_cast<uint32_t>(pv.status_words / 4u)};
+    if (!pool_bucket<THREADS, CAP + 3u, SUBBITS>(slack, keys_out, msd, pool, cursors, dev_head, host_head, stamp, host_log, retry, par, src, abase, mis, n, sc)) return;
+    if (n > CAP) return;  // (cannot happen: the second pass flags a bucket above the capacity it was told)
+    uint32_t *bucket = abase + mis, *bvals = pv.values_home + (bucket - keys_out);
+    const uint32_t *svals = pv.slack_values + (src - slack);
+    const uint32_t used = (n + THREADS - 1u) / THREADS;
+    if (used <= 2) local_sort_bucket_to<THREADS, 2, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 4) local_sort_bucket_to<THREADS, 4, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 6) local_sort_bucket_to<THREADS, 6, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 8) local_sort_bucket_to<THREADS, 8, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 10) local_sort_bucket_to<THREADS, 10, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else if (used <= 12) local_sort_bucket_to<THREADS, 12, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
+    else local_sort_bucket_to<THREADS, kPoolPairItems, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
 }
 
 // Small buckets (up to 1789 keys: uniform inputs below about 2.6e7 keys): ONE WAVE per bucket, no workgroup barrier anywhere
@@ -978,6 +1135,7 @@ uint32_t pool_tiles_b_cap(uint32_t n) {
 }
 
 uint32_t pool_local_capacity(uint32_t local) {
+    if (local == 4u || local == 5u) return (local == 4u ? 512u : 1024u) * kPoolPairItems;  // pairs: 6656 / 13312
     if (local == 3u) return 64u * 4u * kLeanMaxVec - 3u;  // one wave per bucket: 1789
     return (local == 2u ? 512u : 256u) * 4u * (local == 0u ? 4u : static_cast<uint32_t>(kLeanMaxVec)) - 3u;
 }
@@ -998,6 +1156,12 @@ PoolShape pool_shape(uint32_t n, int forced_sub_bits) {
     return sh;
 }
 
+PoolShape pool_shape_pairs(uint32_t n) {
+    // pairs: six bits, the local sort's shape by the fullest uniform bucket (pool_shape's rule); local 4 = 512 threads, 5 = 1024
+    const double mean = static_cast<double>(n) / kMsdBuckets;
+    return PoolShape{6u, static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u <= pool_local_capacity(4u) ? 4u : 5u};
+}
+
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
                               PoolPlan *pool, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev) {
     if (n == 0 || ps.tiles_per_stream < kPoolSampleTiles) return hipErrorInvalidValue;  // (a sample workgroup's tiles span at most two slices)
@@ -1009,9 +1173,13 @@ hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t
 
 hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, uint32_t *overflow, uint32_t n,
                               uint32_t key_base, const PoolStreams &ps, PoolPlan *pool, MsdPlan *msd, unsigned long long xcc_map,
-                              bool misplace, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev) {
-    VRS_LAUNCH(pool_pass_a_kernel, dim3(8u * ps.tiles_per_stream), dim3(512), stream, ev, keys_in, keys_out, overflow, n, key_base, ps, pool, msd,
-               xcc_map, misplace ? 1 : 0, overflow_capacity, par);
+                              bool misplace, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev, const PoolPayloads *pv) {
+    if (pv)
+        VRS_LAUNCH(pool_pass_a_kernel<true>, dim3(8u * ps.tiles_per_stream), dim3(512), stream, ev, keys_in, keys_out, overflow, n, key_base, ps, pool, msd,
+                   xcc_map, 0, overflow_capacity, par, *pv);
+    else
+        VRS_LAUNCH(pool_pass_a_kernel<false>, dim3(8u * ps.tiles_per_stream), dim3(512), stream, ev, keys_in, keys_out, overflow, n, key_base, ps, pool, msd,
+                   xcc_map, misplace ? 1 : 0, overflow_capacity, par, PoolPayloads{});
     return hipGetLastError();
 }
 
@@ -1034,14 +1202,21 @@ hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, ui
 
 hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *slack, uint32_t n, MsdPlan *msd,
                               PoolPlan *pool, uint32_t tiles_b, uint32_t key_base, uint32_t local_cap, uint32_t slack_capacity,
-                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, uint32_t par, LaunchEvents ev, bool grouped) {
+                              unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, uint32_t par, LaunchEvents ev, bool grouped,
+                              const PoolPayloads *pv) {
     if (tiles_b == 0) return hipSuccess;
     if (tiles_b > kPoolMaxTilesB || stamp == 0u) return hipErrorInvalidValue;
     // (grouped keys lie in `regions` alone: no slot is an overflow slot)
     const uint32_t n_virt = grouped ? 0xFFFFFFFFu : n, g = grouped ? 1u : 0u;
+    if (pv) {  // pairs: six bits, a sort
+        if (sub_bits != 6u || grouped) return hipErrorInvalidValue;
+        VRS_LAUNCH((pool_pass_b_kernel<6, true>), dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n_virt, key_base, local_cap,
+                   slack_capacity - kPoolTile, xcc_map, stamp, g, par, *pv);
+        return hipGetLastError();
+    }
 #define VRS_POOL_B(S)                                                                                                                         \
-    VRS_LAUNCH(pool_pass_b_kernel<S>, dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n_virt, key_base, local_cap, \
-               slack_capacity - kPoolTile, xcc_map, stamp, g, par)
+    VRS_LAUNCH((pool_pass_b_kernel<S, false>), dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n_virt, key_base, local_cap, \
+               slack_capacity - kPoolTile, xcc_map, stamp, g, par, PoolPayloads{})
     if (sub_bits == 8u) VRS_POOL_B(8);
     else if (sub_bits == 7u) VRS_POOL_B(7);
     else VRS_POOL_B(6);
@@ -1051,11 +1226,21 @@ hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const
 
 hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
                                   PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t par,
-                                  LaunchEvents ev, uint32_t top_bytes, uint32_t *host_log, bool retry) {
+                                  LaunchEvents ev, uint32_t top_bytes, uint32_t *host_log, bool retry, const PoolPayloads *pv) {
     (void)n;
     const uint32_t again = retry ? 1u : 0u;
     uint32_t *cursors = &msd->cursor_a[0][0];
     if (top_bytes == 0u || top_bytes > 256u || (top_bytes << shape.sub_bits) > kPoolMaxBuckets) return hipErrorInvalidValue;
+    if (pv || shape.local >= 4u) {  // pairs
+        if (!pv || shape.sub_bits != 6u || top_bytes != 256u || (shape.local != 4u && shape.local != 5u)) return hipErrorInvalidValue;
+        if (shape.local == 4u)
+            VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 6>), dim3(kMsdBuckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
+                       stamp, host_log, again, par, *pv);
+        else
+            VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 6>), dim3(kMsdBuckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
+                       stamp, host_log, again, par, *pv);
+        return hipGetLastError();
+    }
 #define VRS_POOL_LOCAL(T, V, W, S)                                                                                                            \
     VRS_LAUNCH((pool_local_sort_kernel<T, V, W, S>), dim3(top_bytes << S), dim3(T), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head, \
                stamp, host_log, again, par)
