@@ -127,6 +127,9 @@ def bench_single(args):
         gpu.setTuning(capi.VRS_TUNE_RANK_MODE, args.rank_mode)
     if args.variant:
         gpu.setTuning(capi.VRS_TUNE_SCATTER_VARIANT, args.variant)
+    for kv in (args.tune or []):  # lab switch: --tune KEY=VALUE (numeric ids of include/vkradixsort_amd.h); named in the line's config
+        k_, v_ = kv.split("=")
+        gpu.setTuning(int(k_), int(v_))
     dev_name, cus, mem = gpu.deviceInfo()
     nbuf = max(K, W, 1)
     need = (nbuf + len(host_keys) + 1) * 4 * n
@@ -431,6 +434,9 @@ def bench_pairs(args):
     iota = np.arange(n, dtype=np.uint32)
     gpu = vrs.GPUContext(int(os.environ.get("LOCAL_RANK", "0")))
     gpu.init()
+    for kv in (getattr(args, "tune", None) or []):
+        k_, v_ = kv.split("=")
+        gpu.setTuning(int(k_), int(v_))
     dev_name, cus, mem = gpu.deviceInfo()
     nbuf = max(K, W, 1)
     if (2 * nbuf + len(host_keys) + 3) * 4 * n > 0.8 * mem:
@@ -1193,6 +1199,7 @@ def main():
                          "(one GPU: all ranks share it -- exercises every rank-to-rank path, measures no scaling)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="N = 1: the dominant kernel's launches carry HIP events in every this-many-th step of the timed region")
+    ap.add_argument("--tune", action="append", help="lab switch: KEY=VALUE, a vrs_tuning id and its value (repeatable); the default line never uses it")
     ap.add_argument("--pairs", action="store_true", help="N = 1: BASELINE.json configs[3], key + payload pairs through vrs_sort_pairs_u32")
     ap.add_argument("--dist-path", choices=["c", "python"], default="c",
                     help="N > 1: the step behind the C ABI (vrs_dist_*, hybrid shape; default) or the Python orchestration "
@@ -1227,6 +1234,8 @@ def main():
             os.write(guard._saved, (json.dumps(result) + "\n").encode())
         return
     result = bench_pairs(args) if args.pairs else bench_single(args)
+    if result is not None and args.tune:
+        result["config"]["lab_tunings"] = list(args.tune)  # (not the default line)
     if result is not None and not args.pairs and args.n == 10 ** 8 and args.path == "one_call" and not args.no_configs:
         result["configs"] = other_configs(args)
     if result is not None:

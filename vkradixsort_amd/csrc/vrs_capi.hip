@@ -124,8 +124,9 @@ struct vrs_context_t {
     // sample and layout kernel (13 us and two launch gaps at 10^8 keys).  Nothing is trusted: a region that does not fit, a key
     // outside the kept range flag the sort as ever; a refusal forgets the layout and the re-run samples.
     bool os_pool_reuse = true;
+    bool os_pool_reuse_rooms = true;      // ... and the buckets' slack regions with them (the plan kernel then samples nothing): VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 2 keeps the first pass's regions only
     bool os_pool_layout_valid = false;
-    uint32_t os_pool_layout_n = 0, os_pool_layout_base = 0;
+    uint32_t os_pool_layout_n = 0, os_pool_layout_base = 0, os_pool_layout_sub_bits = 0;
     uint64_t os_pool_layout_reuses = 0, os_pool_stale_layouts = 0;  // sorts that started in a kept layout / of those, sorts it did not fit (run again, sampled)
     bool os_cursors_open = false;        // a reserving pass may have run without the local sort that re-arms its counters behind it
                                          // (a refused plan, a partition with no finish, an error in between): cleared before the next use
@@ -1300,7 +1301,9 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_A, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_pass_a(ctx->stream, home, partner, ctx->os_pool_overflow, n, st.key_base, ps, ctx->os_pool_plan, ctx->os_msd_plan,
                                          ctx->xcc_map, ctx->os_misplace, room, par, ev, pvp));
-    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, partner, ctx->os_pool_overflow, st.key_base, ps, shape.sub_bits, par));
+    const bool keep_rooms = st.pool_reused && ctx->os_pool_reuse_rooms && ctx->os_pool_layout_sub_bits == shape.sub_bits;
+    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, partner, ctx->os_pool_overflow, st.key_base, ps, shape.sub_bits, par,
+                                       nullptr, keep_rooms));
     if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_B, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, partner, ctx->os_pool_overflow, ctx->os_pool_slack, n, ctx->os_msd_plan, ctx->os_pool_plan, tiles_b,
                                          st.key_base, vrs::pool_local_capacity(shape.local), ctx->os_pool_slack_cap, ctx->xcc_map, st.stamp, shape.sub_bits, par, ev,
@@ -1348,6 +1351,7 @@ static int one_read_complete(vrs_context ctx, bool *done) {
             ctx->os_pool_layout_valid = true;  // its regions held: the next sort of this size may start in them
             ctx->os_pool_layout_n = n;
             ctx->os_pool_layout_base = st.key_base;
+            ctx->os_pool_layout_sub_bits = st.pool_sub_bits;
             return finish();
         }
         if (head.msd_max_bucket != 0u && !st.pool_retried) {
@@ -2214,6 +2218,7 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             return VRS_OK;
         case VRS_TUNE_MSD_POOL_REUSE_LAYOUT:
             ctx->os_pool_reuse = value != 0;
+            ctx->os_pool_reuse_rooms = value == 1;
             ctx->os_pool_layout_valid = false;
             return VRS_OK;
         case VRS_TUNE_MSD_POOL_SUB_BITS:

@@ -356,7 +356,7 @@ hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint3
 // sample of the first pass's OUTPUT: regions / overflow), verdict 1 (slack_capacity: slots the slack buffer has)
 hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap, uint32_t slack_capacity,
                             const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps, uint32_t sub_bits,
-                            uint32_t par, const PoolGroups *groups = nullptr);
+                            uint32_t par, const PoolGroups *groups = nullptr, bool keep_rooms = false);
 // groups != nullptr: the second half alone (vrs_msd_finish_grouped_counts_u32) -- `regions` holds keys grouped by top byte, top byte a
 // (counted from key_base >> 24) holds groups->count[a] of them; no first pass ran
 // second pass, regions -> slack buffer: grid of 8 * tiles_b workgroups (tiles_b = pool_tiles_b_cap(n)); local_cap: keys the local

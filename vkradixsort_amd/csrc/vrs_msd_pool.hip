@@ -407,7 +407,10 @@ __device__ __forceinline__ uint32_t pool_space(uint32_t c) {
 template <uint32_t SUBBITS, bool GROUPED>
 __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool, uint32_t n, uint32_t tiles_b_cap,
                                                        uint32_t slack_capacity, const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
-                                                       uint32_t key_base, PoolStreams ps, PoolGroups groups, uint32_t par) {
+                                                       uint32_t key_base, PoolStreams ps, PoolGroups groups, uint32_t par, uint32_t keep) {
+    // keep (a sort that started in a KEPT layout, launch_pool_sample): the buckets' slack regions are kept too -- PoolPlan::sub_start as the
+    // context's last taken sort of this size left it; no sample of the first pass's output, no rooms to size (the second pass verifies
+    // them as ever: a bucket out of room flags the sort, which then runs again with samples of its own)
     constexpr uint32_t THREADS = 512, WAVES = THREADS / 64, SUB = 1u << SUBBITS, PER = SUB / 64u;
     __shared__ uint32_t s_c[kBins];              // keys of top byte t
     __shared__ uint32_t s_red[3][WAVES];
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
     }
     // The sample: thread (h, t) = (tid / 256, tid % 256) reads key t of the chunks q = h, h + 2, ..., 32 of them in flight at a time
     // (a piece after the other would be sixteen dependent round trips).  Chunk q belongs to the last piece whose first chunk is <= q.
-    const uint32_t chunks_all = s_first[16], half = tid >> 8, t = tid & 255u;
+    const uint32_t chunks_all = keep ? 0u : s_first[16], half = tid >> 8, t = tid & 255u;
     for (uint32_t q0 = half; q0 < chunks_all; q0 += 64u) {
         uint32_t k[32], live = 0;
 #pragma unroll
@@ -542,7 +545,10 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
     }
     __syncthreads();
     const uint32_t top_bytes = GROUPED ? groups.top_bytes : 256u;  // (the tables hold top_bytes << SUBBITS buckets: the workgroups behind them have none)
-    if (wave == 0u && a < top_bytes) {  // lane l = buckets [PER l, PER l + PER) of the top byte
+    if (wave == 0u && a < top_bytes && keep) {  // the regions stay: the second pass counts from zero
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) pool->sub_cursor[a * SUB + PER * lane + q] = 0;
+    } else if (wave == 0u && a < top_bytes) {  // lane l = buckets [PER l, PER l + PER) of the top byte
         uint32_t m_b[PER], m = 0;
 #pragma unroll
         for (uint32_t q = 0; q < PER; ++q) {
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
                 pool->ok_a = (s_bad == 0u && all == n && room <= slack_capacity - kPoolTile) ? 1u : 0u;  // (all != n: the caller's counts are not these keys')
             else
                 pool->ok_a = (pool->armed != 0u && pool->fail[par] == 0u && s_bad == 0u && all == n && shift >= kPoolMinShift && shift <= kPoolMaxShift &&
-                              room <= slack_capacity - kPoolTile)
+                              (keep != 0u || room <= slack_capacity - kPoolTile))  // (kept regions: the table that fit this buffer when it was made)
                                  ? 1u
                                  : 0u;
             // (PoolPlan::fail stays: the second pass may still set it; the next sort's layout kernel re-arms it)
@@ -1185,17 +1191,18 @@ hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint3
 
 hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap, uint32_t slack_capacity,
                             const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps, uint32_t sub_bits,
-                            uint32_t par, const PoolGroups *groups) {
-    if (ps.tiles_per_stream > kPoolMaxTilesA || tiles_b_cap > kPoolMaxTilesB) return hipErrorInvalidValue;
+                            uint32_t par, const PoolGroups *groups, bool keep_rooms) {
+    if (ps.tiles_per_stream > kPoolMaxTilesA || tiles_b_cap > kPoolMaxTilesB || (groups && keep_rooms)) return hipErrorInvalidValue;
     const dim3 grid(256), block(512);
+    const uint32_t keep = keep_rooms ? 1u : 0u;
     if (groups) {
-        if (sub_bits == 8u) hipLaunchKernelGGL((pool_plan_kernel<8, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par);
-        else if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par);
-        else hipLaunchKernelGGL((pool_plan_kernel<6, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par);
+        if (sub_bits == 8u) hipLaunchKernelGGL((pool_plan_kernel<8, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par, 0u);
+        else if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par, 0u);
+        else hipLaunchKernelGGL((pool_plan_kernel<6, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par, 0u);
     } else {
         const PoolGroups none{};
-        if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none, par);
-        else hipLaunchKernelGGL((pool_plan_kernel<6, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none, par);
+        if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none, par, keep);
+        else hipLaunchKernelGGL((pool_plan_kernel<6, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none, par, keep);
     }
     return hipGetLastError();
 }
