@@ -524,7 +524,9 @@ typedef enum vrs_tuning_key {
                                       VRS_TUNE_MSD_RESERVE != 0. */
     VRS_TUNE_MSD_POOL_MIN_KEYS = 18, /* the pool form is considered from this many keys on (default 3.2 * 10^7: the measured crossover with the counted form; never below 2^22) */
     VRS_TUNE_MSD_POOL_SUB_BITS = 20, /* bits the pool form's second pass sorts by: 0 (default) = by size (6 while the buckets fit a 256-thread local sort, about 1.1 * 10^8 uniform keys, else 7), 6 or 7 */
-    VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 22, /* 1 (default): a pool sort of the same size and key floor as the context's last TAKEN one runs its first
+    VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 22, /* (2: what follows; 1, the default: also the buckets' slack regions are kept -- the plan kernel of such a sort
+                                       samples nothing; verified by the second pass like the first pass's regions by the first.)
+                                       1 (default): a pool sort of the same size and key floor as the context's last TAKEN one runs its first
                                        pass in the regions that sort's sample laid out -- no sample and no layout kernel (13 us and two launch gaps
                                        at 10^8 keys).  Verified like any layout: keys it does not fit (another distribution, another key range)
                                        flag the sort, which then runs again with a sample of its own (vrs_one_call_pool_layouts counts both).
