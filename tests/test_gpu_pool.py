@@ -418,3 +418,30 @@ def test_pool_form_of_pairs_at_1e8(gpu_context):
     assert np.all(ok[1:] >= ok[:-1]) and np.array_equal(keys[ov], ok)
     same = ok[1:] == ok[:-1]
     assert np.all(ov[1:][same] > ov[:-1][same])  # equal keys: input order
+
+
+@pytest.mark.parametrize("hook", ["hold_tile", "no_patience"])
+def test_pool_form_of_pairs_with_a_tile_that_never_publishes(pool_ctx, oracle, hook):
+    """The stable passes wait for their predecessors' look-back rows -- never without a bound: a tile whose predecessor does not publish
+    within the spin budget refuses the sort (the caller's buffers have not been written), and the counted form sorts it.  hold_tile: tile
+    3 of every slice never publishes in the first pass; no_patience: a budget of zero polls (whoever finds a row unpublished gives up)."""
+    n = 9000001
+    keys = pool_keys(n, "dups", seed=21)
+    vals = make_keys(n, "uniform", seed=22)
+    if hook == "hold_tile":
+        pool_ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, 3)
+        pool_ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 16)
+    else:
+        pool_ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 0)
+    try:
+        ok, ov, stats, (took, refused) = sort_pairs_and_stats(pool_ctx, keys, vals)
+    finally:
+        pool_ctx.setTuning(capi.VRS_TUNE_DEBUG_HOLD_TILE, -1)
+        pool_ctx.setTuning(capi.VRS_TUNE_LOOKBACK_SPIN_BUDGET, 4096)
+    rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
+    assert np.array_equal(ok, rk) and np.array_equal(ov, rv)
+    if hook == "hold_tile":
+        assert (took, refused) == (0, 1), stats
+    # and the next sort of the context is none the worse for it
+    ok, ov, stats, (took, refused) = sort_pairs_and_stats(pool_ctx, keys, vals)
+    assert np.array_equal(ok, rk) and np.array_equal(ov, rv)

@@ -1270,6 +1270,7 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
         pv.status = ctx->os_status;
         pv.status_words = ctx->os_status_rows * VRS_RADIX_SORT_BINS;
         pv.spin_budget = ctx->os_spin_budget;
+        pv.hold_tile = ctx->os_hold_tile;
     }
     const vrs::PoolPayloads *pvp = pairs ? &pv : nullptr;
     const vrs::PoolStreams ps = vrs::pool_streams(n);

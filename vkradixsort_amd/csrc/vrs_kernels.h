@@ -335,6 +335,7 @@ struct PoolPayloads {
     uint32_t *status = nullptr;
     size_t status_words = 0;
     uint32_t spin_budget = 0;
+    int hold_tile = -1;                   // test hook (VRS_TUNE_DEBUG_HOLD_TILE): this tile of every slice never publishes in the first pass
 };
 // the second half alone, for n keys grouped by `top_bytes` top bytes: sub_bits 6 .. 8 (0: no shape takes them)
 PoolShape pool_grouped_shape(uint32_t n, uint32_t top_bytes);

@@ -369,6 +369,7 @@ __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__r
         lb.index = static_cast<int>(i);
         lb.tag = 1u << kLbTagShift;
         lb.budget = pv.spin_budget;
+        lb.hold = pv.hold_tile >= 0 && i == static_cast<uint32_t>(pv.hold_tile);
         const uint32_t *vin = pv.values_home + ps.start[s_in] + done;
         if (valid == kPoolTile)
             scatter_chunk<uint32_t, 16, 8, true, RANK_ATOMIC, true>(sm, kin, vin, keys_out, pv.values_partner, valid, dg, unused, lb, NoPieces{}, stream_in);
