@@ -5,7 +5,7 @@ OUT=$PWD/gpurun_out/lines_$TAG
 rm -rf $OUT; mkdir -p $OUT
 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
 python bench.py --n 1e7 --steps 50 --warmup 5 > $OUT/${TAG}_bench_line_1e7.json 2> $OUT/bench_1e7.err
-python bench.py --pairs --steps 10 --warmup 2 > $OUT/${TAG}_bench_line_pairs.json 2> $OUT/bench_pairs.err
+python bench.py --pairs > $OUT/${TAG}_bench_line_pairs.json 2> $OUT/bench_pairs.err
 for R in 1 4; do
   VRS_BENCH_FORCE_MULTI=1 python bench.py --rounds $R --rounds-forced --steps 10 --warmup 2 > $OUT/${TAG}_bench_multi_world1_R$R.json 2> $OUT/multi_R$R.err
   VRS_DIST_SHAPE=byte VRS_BENCH_FORCE_MULTI=1 python bench.py --rounds $R --rounds-forced --steps 10 --warmup 2 > $OUT/${TAG}_bench_multi_world1_byte_shape_R$R.json 2> $OUT/multi_byte_R$R.err
