@@ -1089,6 +1089,10 @@ def bench_multi(args, fabric=None):
         # byte shape with the grouped finish: 12 + (counting read 4 + second MSD pass 8 + local sort 8); with the counts the step
         # has anyway (vrs_msd_finish_grouped_counts_u32: the pool form's second half): 12 + (8 + 8)
         sort_bpk = 28 if hybrid else (28 if pool_finish else 32) if grouped else (40 if recv_keys / max(rounds, 1) >= 1.3e7 else 48)
+        # the exchange reads what it sends and writes what it lands: 8 bytes per key -- but for the keys a rank keeps for itself when the
+        # byte shape's rounds are finished by the pool form's second half (they stay where the partition pass wrote them: 1 / world)
+        own_in_place = grouped and pool_finish and os.environ.get("VRS_DIST_COPY_OWN") != "1"
+        xchg_bpk = round(8.0 * (world - 1) / world, 2) if own_in_place else 8
         base = None
         if not args.no_cpu_baseline:
             from tests import _oracle
@@ -1124,10 +1128,12 @@ def bench_multi(args, fabric=None):
                        "rounds_tried_in_warmup_ms": {str(k): round(v * 1e3, 3) for k, v in tried.items()},
                        "received_sub_ranges": {"finished_in_hybrid_shape": int(hybrid_rounds), "finished_grouped_in_byte_shape": int(grouped_rounds),
                                                "sorted_from_scratch_after_a_refused_plan": int(fallback_rounds)},
-                       "hbm_bytes_per_key": sort_bpk + 8,
+                       "hbm_bytes_per_key": sort_bpk + xchg_bpk,
+                       "own_keys": ("left where the partition pass wrote them: the finish reads every top byte as two pieces "
+                                    "(vrs_msd_finish_grouped_split_u32)") if own_in_place else "copied beside the received ones",
                        "hbm_bytes_per_key_breakdown": ({"counting_read": 4, "first_msd_pass": 8, "exchange_read_and_landing_write": 8,
                                                         "second_msd_pass": 8, "local_sort": 8} if hybrid else
-                                                       {"partition_pass": 12, "exchange_read_and_landing_write": 8,
+                                                       {"partition_pass": 12, "exchange_read_and_landing_write": xchg_bpk,
                                                         "local_sorts": sort_bpk - 12})},
             "roofline": {"bound": "hbm", "kernel": "lookback_scatter (rank 0's launches in the timed region: the first MSD pass over the "
                                                    "shard and the second pass over every received sub-range)",
@@ -1136,8 +1142,8 @@ def bench_multi(args, fabric=None):
                          "launches": lb_launches, "avg_launch_us": round(lb_ms / lb_launches * 1e3, 2) if lb_launches else None,
                          "algorithmic_bytes_per_launch": round(lb_bytes / lb_launches) if lb_launches else None,
                          "traffic": None},
-            "step_roofline": {"bytes_per_key": sort_bpk + 8, "achieved_GBps_per_gpu": round((sort_bpk + 8) * n * K / elapsed / 1e9, 1),
-                              "frac_of_peak": round((sort_bpk + 8) * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+            "step_roofline": {"bytes_per_key": sort_bpk + xchg_bpk, "achieved_GBps_per_gpu": round((sort_bpk + xchg_bpk) * n * K / elapsed / 1e9, 1),
+                              "frac_of_peak": round((sort_bpk + xchg_bpk) * n * K / elapsed / 1e9 / HBM_PEAK_GBS, 4),
                               "note": "per GPU, whole step incl. the exchange's read of the sent keys and write of the received ones"},
             "shard_sizes": [x[2] for x in g],
             "verified": check,

@@ -277,6 +277,16 @@ int vrs_msd_finish_grouped_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer o
  * counts == NULL). */
 int vrs_msd_finish_grouped_counts_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, uint32_t num_elements, uint32_t first_top_byte,
                                       uint32_t top_bytes, const uint32_t *counts);
+/* The same with a part of every top byte's keys lying ELSEWHERE -- the keys a rank of the multi-GPU step keeps for itself stay where its
+ * partition pass wrote them instead of being copied beside the received ones (1 / world of the exchange's 8 bytes per key): top byte a's
+ * range of `grouped` is laid out for all counts[a] keys, its LAST own_counts[a] slots are a hole, and those keys are own_counts[a]
+ * consecutive keys of `own`, the top bytes' own parts following each other from key own_offset on.  The second pass reads a top byte as
+ * two pieces; nothing else changes (verdicts, ticket / status as above; `grouped` and `own` untouched by a refusal).  Where the pool
+ * form's second half cannot run the own parts are copied into their holes and vrs_msd_finish_grouped_u32 runs.  own == NULL (and
+ * own_counts == NULL): vrs_msd_finish_grouped_counts_u32. */
+int vrs_msd_finish_grouped_split_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer own, uint64_t own_offset, vrs_buffer out,
+                                     uint32_t num_elements, uint32_t first_top_byte, uint32_t top_bytes, const uint32_t *counts,
+                                     const uint32_t *own_counts);
 int vrs_msd_finish_status(vrs_context ctx, int *took);
 int vrs_msd_finish_ticket(vrs_context ctx, uint32_t *ticket);
 int vrs_msd_finish_status_at(vrs_context ctx, uint32_t ticket, int *took);

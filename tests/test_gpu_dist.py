@@ -507,3 +507,62 @@ def test_msd_finish_grouped_refuses_a_bucket_no_workgroup_can_hold_and_rejects_b
         assert lib.vrs_msd_finish_grouped_u32(gpu.handle, g.handle, g.handle, n, 0, 16) == capi.VRS_ERROR_INVALID_ARGUMENT
         g.release()
         out.release()
+
+
+@pytest.mark.parametrize("first,top_bytes,n,own_share", [(0, 256, 6000001, 0.125), (0, 256, 6000001, 1.0), (0x40, 64, 5000003, 0.5),
+                                                          (0x10, 9, 3000007, 0.3), (0xE0, 8, 9000001, 0.0), (0x20, 32, 70001, 0.4),
+                                                          (0x7F, 1, 2000003, 0.6), (0x03, 100, 7000001, 0.9)])
+def test_msd_finish_grouped_split_reads_a_ranks_own_keys_where_they_lie(first, top_bytes, n, own_share):
+    """vrs_msd_finish_grouped_split_u32: a part of every top byte's keys -- what a rank keeps for itself -- is not in the grouped buffer
+    (the LAST slots of the top byte's range there are a hole) but in a second buffer, the top bytes' own parts one after the other from
+    an offset on.  The second pass reads a top byte as two pieces; the result is std::sort's, the hole's content is never looked at,
+    neither buffer is written.  Where the form cannot run (too few keys, no shape) the own parts are copied into the holes and the
+    counted finish runs."""
+    lib = capi.load_library()
+    rs = np.random.RandomState(first * 1000 + top_bytes + 7)
+    keys = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    keys = (keys & np.uint32(0x00FFFFFF)) | ((rs.randint(first, first + top_bytes, size=n).astype(np.uint32)) << np.uint32(24))
+    grouped_host = keys[np.argsort(keys >> np.uint32(24), kind="stable")]
+    counts = np.bincount((grouped_host >> np.uint32(24)).astype(np.int64) - first, minlength=top_bytes).astype(np.uint32)
+    own_counts = np.minimum(counts, (counts * own_share + rs.randint(0, 3, size=top_bytes)).astype(np.uint32)) if own_share < 1.0 else counts.copy()
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+    own_offset = 12345
+    own_host = np.full(own_offset + int(own_own := own_counts.sum()) + 99, 0xDEADBEEF, np.uint32)
+    holed = grouped_host.copy()
+    at = own_offset
+    for a in range(top_bytes):
+        lo = starts[a] + int(counts[a]) - int(own_counts[a])
+        own_host[at:at + int(own_counts[a])] = grouped_host[lo:lo + int(own_counts[a])]
+        holed[lo:lo + int(own_counts[a])] = 0x0BADF00D  # the hole: garbage with a wrong top byte
+        at += int(own_counts[a])
+    P = ctypes.POINTER(ctypes.c_uint32)
+    with vrs.GPUContext(0) as gpu:
+        g = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), holed)
+        o = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * own_host.size), own_host)
+        out = vrs.Buffer(gpu, S(4 * n))
+        gpu.profileEnable(True)
+        gpu.profileReset()
+        gpu.check(lib.vrs_msd_finish_grouped_split_u32(gpu.handle, g.handle, o.handle, own_offset, out.handle, n, first, top_bytes,
+                                                       counts.ctypes.data_as(P), own_counts.ctypes.data_as(P)))
+        took = ctypes.c_int(-1)
+        gpu.check(lib.vrs_msd_finish_status(gpu.handle, ctypes.byref(took)))
+        assert took.value == 1
+        res = np.empty(n, np.uint32)
+        out.downloadWithStagingBuffer(res)
+        assert np.array_equal(res, np.sort(keys))
+        pooled = gpu.profileQuery(capi.VRS_KERNEL_POOL_PASS_B)[0] == 1
+        gpu.profileEnable(False)
+        assert pooled == (n >= (1 << 20) and n / (top_bytes * 256) < 13000)
+        back = np.empty(own_host.size, np.uint32)
+        o.downloadWithStagingBuffer(back)
+        assert np.array_equal(back, own_host)
+        if pooled:  # (the counted finish filled the holes: that is its way in)
+            gb = np.empty(n, np.uint32)
+            g.downloadWithStagingBuffer(gb)
+            assert np.array_equal(gb, holed)
+        bad = own_counts.copy()
+        bad[0] = counts[0] + 1
+        assert lib.vrs_msd_finish_grouped_split_u32(gpu.handle, g.handle, o.handle, own_offset, out.handle, n, first, top_bytes,
+                                                    counts.ctypes.data_as(P), bad.ctypes.data_as(P)) == capi.VRS_ERROR_INVALID_ARGUMENT
+        for b in (g, o, out):
+            b.release()

@@ -154,6 +154,7 @@ _SIGNATURES = [
     ("vrs_msd_partition_signal_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     ("vrs_msd_finish_grouped_u32", c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_uint32, c_uint32]),
     ("vrs_msd_finish_grouped_counts_u32", c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, POINTER(c_uint32)]),
+    ("vrs_msd_finish_grouped_split_u32", c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32)]),
     ("vrs_msd_finish_status", c_int, [c_void_p, POINTER(c_int)]),
     ("vrs_msd_finish_ticket", c_int, [c_void_p, POINTER(c_uint32)]),
     ("vrs_msd_finish_status_at", c_int, [c_void_p, c_uint32, POINTER(c_int)]),

@@ -1724,8 +1724,40 @@ int vrs_msd_finish_grouped_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer o
 
 int vrs_msd_finish_grouped_counts_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer out, uint32_t n, uint32_t first_top_byte,
                                       uint32_t top_bytes, const uint32_t *counts) {
+    return vrs_msd_finish_grouped_split_u32(ctx, grouped, nullptr, 0, out, n, first_top_byte, top_bytes, counts, nullptr);
+}
+
+// the own parts into the holes of the grouped buffer (neighbouring ones merged: device copies are launch-bound below a megabyte)
+static int fill_own_holes(vrs_context ctx, vrs_buffer grouped, vrs_buffer own, uint64_t own_offset, uint32_t top_bytes, const uint32_t *counts,
+                          const uint32_t *own_counts) {
+    uint32_t *dst = static_cast<uint32_t *>(grouped->ptr);
+    const uint32_t *src = static_cast<const uint32_t *>(own->ptr) + own_offset;
+    uint64_t at = 0, from = 0, run_dst = 0, run_src = 0, run_len = 0;
+    for (uint32_t a = 0; a <= top_bytes; ++a) {
+        const uint64_t hole = a < top_bytes ? at + counts[a] - own_counts[a] : 0, len = a < top_bytes ? own_counts[a] : 0;
+        if (a < top_bytes && len && run_len && run_dst + run_len == hole && run_src + run_len == from) {
+            run_len += len;
+        } else {
+            if (run_len) VRS_HIP(ctx, hipMemcpyAsync(dst + run_dst, src + run_src, run_len * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            run_dst = hole;
+            run_src = from;
+            run_len = len;
+        }
+        if (a < top_bytes) {
+            at += counts[a];
+            from += len;
+        }
+    }
+    return VRS_OK;
+}
+
+int vrs_msd_finish_grouped_split_u32(vrs_context ctx, vrs_buffer grouped, vrs_buffer own, uint64_t own_offset, vrs_buffer out, uint32_t n,
+                                     uint32_t first_top_byte, uint32_t top_bytes, const uint32_t *counts, const uint32_t *own_counts) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
-    if (!counts) return vrs_msd_finish_grouped_u32(ctx, grouped, out, n, first_top_byte, top_bytes);
+    if (!counts) {
+        if (own || own_counts) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "own keys elsewhere need the top bytes' counts");
+        return vrs_msd_finish_grouped_u32(ctx, grouped, out, n, first_top_byte, top_bytes);
+    }
     int rc;
     const size_t bytes = static_cast<size_t>(n) * sizeof(uint32_t);
     if ((rc = check_buffer(ctx, grouped, bytes, "grouped"))) return rc;
@@ -1733,21 +1765,43 @@ int vrs_msd_finish_grouped_counts_u32(vrs_context ctx, vrs_buffer grouped, vrs_b
     if (grouped->ptr == out->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "grouped and out alias");
     if (top_bytes == 0 || first_top_byte > 255u || first_top_byte + top_bytes > 256u)
         return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "top bytes [first, first + count) must lie in [0, 256)");
+    if ((own != nullptr) != (own_counts != nullptr)) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "own and own_counts go together");
     vrs::PoolGroups groups{};
-    uint64_t sum = 0;
+    uint64_t sum = 0, own_sum = 0;
     for (uint32_t a = 0; a < top_bytes; ++a) {
         groups.count[a] = counts[a];
         sum += counts[a];
+        if (own_counts) {
+            if (own_counts[a] > counts[a]) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "a top byte has more own keys than keys");
+            groups.own[a] = own_counts[a];
+            own_sum += own_counts[a];
+        }
     }
     groups.top_bytes = top_bytes;
     if (sum != n) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the top bytes' counts do not add up to num_elements");
+    if (own_sum == 0) own = nullptr;  // (nothing lies elsewhere)
+    if (own) {
+        if ((rc = check_buffer(ctx, own, (own_offset + own_sum) * sizeof(uint32_t), "own"))) return rc;
+        if (own->ptr == out->ptr || own->ptr == grouped->ptr) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "own aliases grouped or out");
+        if (own_offset + own_sum > 0x7FFFFFFFull) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "own keys beyond slot 2^31");
+        groups.own_first = static_cast<uint32_t>(own_offset);
+    }
+    // where the form cannot run, the counted finish takes over -- over keys in ONE piece: the own parts are copied into their holes first
+    const auto counted = [&]() -> int {
+        if (own) {
+            VRS_HIP(ctx, hipSetDevice(ctx->device));
+            if (const int e = settle_pending(ctx)) return e;
+            if (const int e = fill_own_holes(ctx, grouped, own, own_offset, top_bytes, counts, own_counts)) return e;
+        }
+        return vrs_msd_finish_grouped_u32(ctx, grouped, out, n, first_top_byte, top_bytes);
+    };
     // The pool form's second half: the plan samples the grouped keys (nothing is read to be counted), the second pass scatters into
     // the buckets' slack regions, the local sort finishes.  Where it cannot run -- the form switched off, no shape for these buckets,
     // fewer keys than its fixed costs are worth -- the counted finish takes over.
     const vrs::PoolShape shape = vrs::pool_grouped_shape(n, top_bytes);
     if (ctx->os_pool == 0 || !reserves(ctx, n, false) || shape.sub_bits == 0u || n < (1u << 20) || n >= (1u << 30) || !ctx->xcc_map_valid ||
         !ctx->atomic_rank_verified || !ctx->scatter.atomic_rank)
-        return vrs_msd_finish_grouped_u32(ctx, grouped, out, n, first_top_byte, top_bytes);
+        return counted();
     VRS_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = settle_pending(ctx))) return rc;
     vrs_context_t::OneRead st;
@@ -1760,7 +1814,7 @@ int vrs_msd_finish_grouped_counts_u32(vrs_context ctx, vrs_buffer grouped, vrs_b
         for (uint32_t a = x; a < top_bytes; a += 8u) t += (groups.count[a] + vrs::kPoolTile - 1u) / vrs::kPoolTile;
         tiles_b = std::max(tiles_b, t);
     }
-    if (tiles_b > vrs::kPoolMaxTilesB) return vrs_msd_finish_grouped_u32(ctx, grouped, out, n, first_top_byte, top_bytes);
+    if (tiles_b > vrs::kPoolMaxTilesB) return counted();
     const uint32_t slack = vrs::pool_slack_capacity(n, shape.sub_bits, top_bytes);
     if ((rc = pool_scratch(ctx, std::max(ctx->os_pool_overflow_cap, 32u), slack))) return rc;
     ctx->sub_cache.valid = false;
@@ -1770,11 +1824,12 @@ int vrs_msd_finish_grouped_counts_u32(vrs_context ctx, vrs_buffer grouped, vrs_b
     const uint32_t par = (++ctx->os_pool_epoch) & 1u;
     const uint32_t key_base = first_top_byte << 24;
     const uint32_t *keys_in = static_cast<const uint32_t *>(grouped->ptr);
+    const uint32_t *keys_own = own ? static_cast<const uint32_t *>(own->ptr) : keys_in;  // (virtual slots from n on)
     vrs::LaunchEvents ev;
-    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, keys_in, keys_in, key_base,
+    VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, keys_in, keys_own, key_base,
                                        vrs::pool_streams(n), shape.sub_bits, par, &groups));
     if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_B, &ev))) return rc;
-    VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, keys_in, keys_in, ctx->os_pool_slack, n, ctx->os_msd_plan, ctx->os_pool_plan, tiles_b, key_base,
+    VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, keys_in, keys_own, ctx->os_pool_slack, n, ctx->os_msd_plan, ctx->os_pool_plan, tiles_b, key_base,
                                          vrs::pool_local_capacity(shape.local), ctx->os_pool_slack_cap, ctx->xcc_map, ctx->os_stamp, shape.sub_bits, par, ev, true));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, static_cast<uint32_t *>(out->ptr), n, ctx->os_msd_plan, ctx->os_pool_plan, shape,

@@ -912,6 +912,15 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
     const bool by_top_byte = hybrid || grouped_finish;  // one message per (top byte, source), the result built in the scratch buffer
     const char *pf_env = std::getenv("VRS_DIST_POOL_FINISH");
     const bool pool_finish = !(pf_env && pf_env[0] == '0');
+    // Byte shape finished by the pool form's second half: the keys this rank keeps for itself are NOT copied beside the received ones --
+    // they stay where the partition pass wrote them (the grouped buffer) and the finish reads every top byte as two pieces
+    // (vrs_msd_finish_grouped_split_u32): 1 / world of the exchange's 8 bytes per key never moves.  The receive buffer keeps the layout
+    // it would have had, with every top byte's own part LAST: a hole, filled only if the round has to be sorted another way.
+    // (VRS_DIST_COPY_OWN=1: the copies as before)
+    const char *co_env = std::getenv("VRS_DIST_COPY_OWN");
+    const bool own_in_place = grouped_finish && pool_finish && !(co_env && co_env[0] == '1');
+    struct OwnHole { uint64_t dst, src, len; };
+    std::vector<std::vector<OwnHole>> holes(static_cast<size_t>(R));
 
     // what I receive in round r: one message per (top byte, source) in that order -- the round's keys land grouped by top byte --
     // or (byte shape with whole ranged sorts) one message per source.  round_off: where round r starts in the receive buffer.
@@ -966,7 +975,19 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
             }
             off += b - a;
         };
-        if (by_top_byte) {
+        if (own_in_place) {
+            for (uint32_t t = lo; t < hi; ++t) {
+                for (int s = 0; s < world; ++s)
+                    if (s != me) land(s, t, t + 1);
+                const uint64_t a = base[static_cast<size_t>(me)][t], b = base[static_cast<size_t>(me)][t + 1];
+                if (b > a) {  // (neighbouring holes whose sources follow each other too are one copy, should it come to that)
+                    std::vector<OwnHole> &h = holes[static_cast<size_t>(r)];
+                    if (!h.empty() && h.back().dst + h.back().len == off && h.back().src + h.back().len == a) h.back().len += b - a;
+                    else h.push_back(OwnHole{off, a, b - a});
+                }
+                off += b - a;
+            }
+        } else if (by_top_byte) {
             for (uint32_t t = lo; t < hi; ++t)
                 for (int s = 0; s < world; ++s) land(s, t, t + 1);
         } else {
@@ -1012,6 +1033,11 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
     // one round sorted with vrs_sort_keys_u32_ranged: every key of the round is >= its first top byte << 24, so the sort buckets the
     // sub-range as if it were a whole key range (hybrid shape: the step's output is the scratch buffer)
     const auto ranged_round = [&](int r, uint64_t cnt) -> int {
+        // (own keys left in place: into their holes first -- on the sort stream, behind the round's exchange)
+        for (const OwnHole &h : holes[static_cast<size_t>(r)])
+            if (hipMemcpyAsync(recv + h.dst, grouped + h.src, h.len * 4, hipMemcpyDeviceToDevice, d->sort_stream) != hipSuccess)
+                return VRS_ERROR_HIP;
+        holes[static_cast<size_t>(r)].clear();
         vrs_buffer view = nullptr, sview = nullptr;
         int e = vrs_buffer_wrap(ctx, recv + round_off[static_cast<size_t>(r)], cnt * 4, &view);
         if (e == VRS_OK) e = vrs_buffer_wrap(ctx, scratch + round_off[static_cast<size_t>(r)], cnt * 4, &sview);
@@ -1051,10 +1077,17 @@ int vrs_dist_sort_keys_u32(vrs_dist d, vrs_buffer keys, uint32_t n, vrs_buffer *
                 // every top byte's keys landed in one piece and every rank knows how many there are (the gathered table): nothing
                 // needs to be read to be counted -- the pool form's second half, 16 bytes per key instead of 20
                 // (VRS_DIST_POOL_FINISH=0: the counted finish)
-                uint32_t per_byte[256];
-                for (uint32_t t = lo; t < hi; ++t) per_byte[t - lo] = static_cast<uint32_t>(byte_counts[t]);
-                rc = pool_finish ? vrs_msd_finish_grouped_counts_u32(ctx, view, sview, static_cast<uint32_t>(cnt), lo, hi - lo, per_byte)
-                                 : vrs_msd_finish_grouped_u32(ctx, view, sview, static_cast<uint32_t>(cnt), lo, hi - lo);
+                uint32_t per_byte[256], own_byte[256];
+                for (uint32_t t = lo; t < hi; ++t) {
+                    per_byte[t - lo] = static_cast<uint32_t>(byte_counts[t]);
+                    own_byte[t - lo] = static_cast<uint32_t>(base[static_cast<size_t>(me)][t + 1] - base[static_cast<size_t>(me)][t]);
+                }
+                if (own_in_place)  // (this round's own keys: the grouped buffer from the first of its top bytes on)
+                    rc = vrs_msd_finish_grouped_split_u32(ctx, view, d->grouped, base[static_cast<size_t>(me)][lo], sview, static_cast<uint32_t>(cnt), lo,
+                                                          hi - lo, per_byte, own_byte);
+                else
+                    rc = pool_finish ? vrs_msd_finish_grouped_counts_u32(ctx, view, sview, static_cast<uint32_t>(cnt), lo, hi - lo, per_byte)
+                                     : vrs_msd_finish_grouped_u32(ctx, view, sview, static_cast<uint32_t>(cnt), lo, hi - lo);
             }
             if (rc == VRS_OK) rc = vrs_msd_finish_ticket(ctx, &ticket[static_cast<size_t>(r)]);
             (void)vrs_buffer_release(view);

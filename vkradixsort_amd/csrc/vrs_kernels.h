@@ -342,6 +342,11 @@ PoolShape pool_grouped_shape(uint32_t n, uint32_t top_bytes);
 struct PoolGroups {          // keys of every top byte (grouped keys; by value: a kernel argument)
     uint32_t count[256];     // zero from top_bytes on
     uint32_t top_bytes;      // top bytes that exist: top_bytes << sub_bits buckets
+    // A part of every top byte's keys may lie ELSEWHERE (a rank's own keys, left where its partition pass wrote them): the LAST own[a]
+    // slots of top byte a's range of the grouped buffer are a hole, and those keys are own[a] consecutive slots of a second buffer (the
+    // second pass's `overflow` pointer), the top bytes' own parts following each other from slot own_first on.  All zero: none.
+    uint32_t own_first;
+    uint32_t own[256];
 };
 uint32_t pool_local_capacity(uint32_t local);
 uint32_t pool_tiles_b_cap(uint32_t n);         // rows of workgroups of the second pass (its grid is sized before the plan is known)

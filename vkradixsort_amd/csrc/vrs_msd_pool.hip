@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
     // them as ever: a bucket out of room flags the sort, which then runs again with samples of its own)
     constexpr uint32_t THREADS = 512, WAVES = THREADS / 64, SUB = 1u << SUBBITS, PER = SUB / 64u;
     __shared__ uint32_t s_c[kBins];              // keys of top byte t
-    __shared__ uint32_t s_red[3][WAVES];
+    __shared__ uint32_t s_red[4][WAVES];
     __shared__ uint32_t s_hist[WAVES][SUB];      // sampled keys of this top byte by bucket, one row per wave
     __shared__ uint2 s_piece[16];
     __shared__ uint32_t s_first[17];
@@ -444,7 +444,8 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
     uint32_t plen = 0, pslot = 0;
     if (tid < 16u) {
         if constexpr (GROUPED) {
-            plen = tid == 0u ? groups.count[a] : 0u;  // (its slot is the top byte's start: known behind the sums below)
+            // (two pieces: the keys in the grouped buffer, the own keys elsewhere; their slots are known behind the sums below)
+            plen = tid == 0u ? groups.count[a] - groups.own[a] : tid == 1u ? groups.own[a] : 0u;
         } else {
             const uint32_t s = tid >> 1;
             const uint32_t c = msd->cursor_a[s][a], prim = min(c, pool->cap[s][a]);
@@ -460,16 +461,19 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
     // sums over the top bytes before this one: keys, slack space, tiles of the same XCD
     const uint32_t tiles_t = (c_t + kPoolTile - 1u) / kPoolTile;
     uint32_t r0 = tid < a ? c_t : 0u, r1 = tid < a ? pool_space<SUB>(c_t) : 0u, r2 = (tid < a && ((tid ^ a) & 7u) == 0u) ? tiles_t : 0u;
+    uint32_t r3 = (GROUPED && tid < a) ? groups.own[tid & 255u] : 0u;  // own keys of the top bytes before this one
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         r0 += __shfl_xor(r0, o);
         r1 += __shfl_xor(r1, o);
         r2 += __shfl_xor(r2, o);
+        if constexpr (GROUPED) r3 += __shfl_xor(r3, o);
     }
     if (lane == 0u) {
         s_red[0][wave] = r0;
         s_red[1][wave] = r1;
         s_red[2][wave] = r2;
+        s_red[3][wave] = r3;
     }
     if (tid < 16u) {
         // the row of pieces: .x = keys up to and including the piece (a scan over 16 lanes), .y = its first virtual slot; and the
@@ -492,18 +496,20 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
         if (tid == 15u) s_first[16] = cend;
     }
     __syncthreads();
-    uint32_t top = 0, part = 0, tiles_before = 0;
+    uint32_t top = 0, part = 0, tiles_before = 0, own_before = 0;
 #pragma unroll
     for (uint32_t w = 0; w < WAVES; ++w) {
         top += s_red[0][w];
         part += s_red[1][w];
         tiles_before += s_red[2][w];
+        own_before += s_red[3][w];
     }
     const uint32_t c_a = s_c[a];
-    if constexpr (GROUPED) {  // the top byte is one piece of `regions`, at its place in the grouped keys
+    if constexpr (GROUPED) {  // the top byte: a piece of `regions` at its place in the grouped keys, then (if any) its own keys elsewhere
         if (tid < 16u) {
-            pool->pieces[a][tid] = make_uint2(c_a, top);
-            s_piece[tid] = make_uint2(tid == 0u ? c_a : 0u, top);
+            const uint32_t own_a = groups.own[a], here = c_a - own_a, own_slot = n + groups.own_first + own_before;  // (virtual slots from n on: the second buffer)
+            pool->pieces[a][tid] = make_uint2(tid == 0u ? here : c_a, tid == 0u ? top : own_slot);
+            s_piece[tid] = make_uint2(tid == 0u ? here : tid == 1u ? own_a : 0u, tid == 0u ? top : own_slot);
         }
         if (a == 0u && tid == 0u) pool->fail[par] = 0;  // (a sort's layout kernel re-arms it; nobody sets it before the second pass here)
         __syncthreads();
@@ -1215,7 +1221,8 @@ hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const
     if (tiles_b == 0) return hipSuccess;
     if (tiles_b > kPoolMaxTilesB || stamp == 0u) return hipErrorInvalidValue;
     // (grouped keys lie in `regions` alone: no slot is an overflow slot)
-    const uint32_t n_virt = grouped ? 0xFFFFFFFFu : n, g = grouped ? 1u : 0u;
+    // (... unless a part of them lies in a second buffer, PoolGroups::own: those are the slots from n on)
+    const uint32_t n_virt = (grouped && regions == overflow) ? 0xFFFFFFFFu : n, g = grouped ? 1u : 0u;
     if (pv) {  // pairs: six bits, a sort
         if (sub_bits != 6u || grouped) return hipErrorInvalidValue;
         VRS_LAUNCH((pool_pass_b_kernel<6, true>), dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n_virt, key_base, local_cap,
