@@ -1113,7 +1113,7 @@ def bench_multi(args, fabric=None):
                        "path": ("vrs_dist_sort_keys_u32, hybrid shape: counting read + first MSD pass of the shard, one all-gather + one "
                                 f"all-reduce of counts, {fabric.wire} send/recv of one message per (sender, top byte) in "
                                 f"{rounds} round(s), second MSD pass + LDS-local sort per received sub-range") if hybrid else
-                               ("vrs_dist_sort_keys_u32, byte shape (the global top-14-bit buckets would not fit the local sort): contract "
+                               ("vrs_dist_sort_keys_u32, byte shape (the step's default; VRS_DIST_SHAPE=hybrid asks for the other): contract "
                                 f"partition pass by the top byte, {fabric.wire} send/recv of one message per (sender, top byte) in {rounds} round(s), "
                                 + ("per received sub-range the pool form's second half -- a sample, the second MSD pass by the next 6..8 bits into "
                                    "the buckets' slack regions, the LDS-local sort: nothing is read to be counted (vrs_msd_finish_grouped_counts_u32)"

@@ -13,6 +13,13 @@ import vkradixsort_amd as vrs
 from vkradixsort_amd import capi
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _hybrid_shape_unless_the_test_says_otherwise(monkeypatch):
+    """the tests of this file were written when the hybrid shape was the step's default: they keep asking for it (a test that wants
+    the byte shape sets VRS_DIST_SHAPE itself; test_the_step_takes_the_byte_shape_by_default unsets it)"""
+    monkeypatch.setenv("VRS_DIST_SHAPE", "hybrid")
 S = vrs.Buffer.BufferSettings
 
 
@@ -566,3 +573,15 @@ def test_msd_finish_grouped_split_reads_a_ranks_own_keys_where_they_lie(first, t
                                                     counts.ctypes.data_as(P), bad.ctypes.data_as(P)) == capi.VRS_ERROR_INVALID_ARGUMENT
         for b in (g, o, out):
             b.release()
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_the_step_takes_the_byte_shape_by_default(world, monkeypatch):
+    """no VRS_DIST_SHAPE: the byte shape -- contract partition pass, the rank's own keys left in place, every round finished by the
+    pool form's second half (since round 5 it moves fewer bytes than the hybrid shape at every world size and takes every total)"""
+    monkeypatch.delenv("VRS_DIST_SHAPE", raising=False)
+    shards = [keys_of("uniform", 3000017 - 200001 * r, 1000 + r) for r in range(world)]
+    res = run_ranks(shards, 2)
+    check_sorted_ranges(shards, res)
+    for outs, (hybrid_rounds, fallback_rounds, byte_steps, grouped, _splitters) in res:
+        assert hybrid_rounds == 0 and fallback_rounds == 0 and byte_steps == 2 and grouped == 2 * 2

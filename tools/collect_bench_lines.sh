@@ -7,8 +7,8 @@ python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
 python bench.py --n 1e7 --steps 50 --warmup 5 > $OUT/${TAG}_bench_line_1e7.json 2> $OUT/bench_1e7.err
 python bench.py --pairs > $OUT/${TAG}_bench_line_pairs.json 2> $OUT/bench_pairs.err
 for R in 1 4; do
-  VRS_BENCH_FORCE_MULTI=1 python bench.py --rounds $R --rounds-forced --steps 10 --warmup 2 > $OUT/${TAG}_bench_multi_world1_R$R.json 2> $OUT/multi_R$R.err
-  VRS_DIST_SHAPE=byte VRS_BENCH_FORCE_MULTI=1 python bench.py --rounds $R --rounds-forced --steps 10 --warmup 2 > $OUT/${TAG}_bench_multi_world1_byte_shape_R$R.json 2> $OUT/multi_byte_R$R.err
+  VRS_DIST_SHAPE=hybrid VRS_BENCH_FORCE_MULTI=1 python bench.py --rounds $R --rounds-forced --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_multi_world1_hybrid_shape_R$R.json 2> $OUT/multi_R$R.err
+  VRS_BENCH_FORCE_MULTI=1 python bench.py --rounds $R --rounds-forced --steps 10 --warmup 2 > $OUT/${TAG}_bench_multi_world1_byte_shape_R$R.json 2> $OUT/multi_byte_R$R.err
   VRS_DIST_COPY_OWN=1 VRS_DIST_SHAPE=byte VRS_BENCH_FORCE_MULTI=1 python bench.py --rounds $R --rounds-forced --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_multi_world1_byte_shape_copy_own_R$R.json 2> $OUT/multi_byte_copy_R$R.err
 done
 python bench.py --loopback-ranks 8 --n 2e6 --steps 5 > $OUT/${TAG}_bench_multi_loopback_world8.json 2> $OUT/loop8.err

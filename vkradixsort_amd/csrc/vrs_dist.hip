@@ -17,11 +17,13 @@
 //     4. per round, while the later rounds are on the wire: vrs_msd_finish_u32 (second MSD pass + LDS-local sort) with the
 //        all-reduced histogram masked to the round's buckets.  A round whose plan refuses (a bucket beyond the local
 //        sort's capacity) is sorted by vrs_sort_keys_u32 instead -- a rank-local matter.
-//   byte shape (chosen by ALL ranks together from the gathered rows: a total whose global top-14-bit buckets would not fit
-//     the local sort -- about 2e8 keys, so every step of 8 x 1e8 --, a key range below 27 bits, ranks that probed different
-//     ranges, or VRS_DIST_SHAPE=byte; 32 B/key per GPU): contract partition pass by the top byte (12 B/key), the same
-//     exchange, and per received sub-range vrs_msd_finish_grouped_u32: ONE counting read, the second MSD pass by the next 8
-//     bits, the local sort (20 B/key).  A sub-range it cannot take (a top byte with more keys than its 256 sub-buckets
+//   byte shape (the DEFAULT since round 5; under VRS_DIST_SHAPE=hybrid what ALL ranks fall back to together, from the gathered
+//     rows: a total whose global top-14-bit buckets would not fit the local sort -- about 2e8 keys, so every step of 8 x 1e8 --,
+//     a key range below 27 bits, ranks that probed different ranges; 28 + 8 (1 - 1 / world) B/key per GPU): contract partition
+//     pass by the top byte (12 B/key), the same exchange -- but the rank's own keys stay where the partition pass wrote them --,
+//     and per received sub-range the pool form's second half (vrs_msd_finish_grouped_split_u32: 16 B/key, nothing is read to be
+//     counted; VRS_DIST_POOL_FINISH=0: vrs_msd_finish_grouped_u32 -- ONE counting read, the second MSD pass by the next 8
+//     bits, the local sort: 20 B/key).  A sub-range it cannot take (a top byte with more keys than its 256 sub-buckets
 //     hold: then one message per (sender, round), decided by all ranks from the summed top-byte counts; or a refused plan)
 //     is sorted whole by vrs_sort_keys_u32_ranged (28 B/key).  A total too large for the hybrid shape is remembered: the
 //     following steps start here (no counting read + first pass for nothing, one all-gather), every 64th looks again.
@@ -162,7 +164,7 @@ struct vrs_dist_t {
     bool has_transport = false;
     vrs_dist_transport tr{};
     RcclEndpoint *rccl = nullptr;  // owned; the transport's `user` when vrs_dist_create made it
-    bool byte_shape_only = false;  // VRS_DIST_SHAPE=byte
+    bool byte_shape_only = true;   // unless VRS_DIST_SHAPE=hybrid
     uint64_t hybrid_max_bucket = kHybridShapeMaxBucket;
     bool too_large_for_hybrid = false;  // the last step that tried found N_total / 16384 beyond the local sort: the same on every rank
     uint64_t steps = 0;
@@ -512,8 +514,11 @@ int vrs_dist_create_with_transport(vrs_context ctx, const vrs_dist_transport *tr
         d->tr = *transport;
         d->has_transport = true;
     }
+    // The byte shape is the default since round 5: with its rounds finished by the pool form's second half and the rank's own keys left
+    // in place it moves 28 + 8 (1 - 1 / world) bytes per key where the hybrid shape moves 28 + 8, needs one collective less, and takes
+    // every total (world size 1, 10^8 keys: 0.63 against 0.82 ms).  VRS_DIST_SHAPE=hybrid: the hybrid shape wherever its buckets fit.
     const char *shape = std::getenv("VRS_DIST_SHAPE");
-    d->byte_shape_only = shape && std::strcmp(shape, "byte") == 0;
+    d->byte_shape_only = !(shape && std::strcmp(shape, "hybrid") == 0);
     if (const char *gf = std::getenv("VRS_DIST_GROUPED_FINISH")) d->no_grouped_finish = std::strcmp(gf, "0") == 0;
     if (const char *ss = std::getenv("VRS_DIST_SAMPLED_SPLITTERS")) d->no_sampled_splitters = std::strcmp(ss, "0") == 0;
     if (const char *mb = std::getenv("VRS_DIST_HYBRID_MAX_BUCKET")) {  // test knob: the "total too large for the hybrid shape" path at test sizes
