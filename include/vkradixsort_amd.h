@@ -541,6 +541,9 @@ typedef enum vrs_tuning_key {
                                        at 10^8 keys).  Verified like any layout: keys it does not fit (another distribution, another key range)
                                        flag the sort, which then runs again with a sample of its own (vrs_one_call_pool_layouts counts both).
                                        0: every sort samples */
+    VRS_TUNE_MSD_POOL_TOP_BITS = 24, /* how the pool form cuts a sort's 16384 buckets between its two passes: 7 (default) = 128 x 128, a first pass by 7 bits
+                                        and a second by 7; 8 = 256 x 64 (the cut until late in round 5); 6 = 64 x 256.  Sorts whose second pass takes
+                                        7 bits of 256 top bytes anyway (beyond about 1.1e8 keys) are not affected */
     VRS_TUNE_MSD_POOL_PAIRS = 23, /* 1 (default): uint32 key + uint32 payload pairs may take the pool form too -- its STABLE variant: a tile's place in
                                      a sampled region is its rank there (decoupled look-back, one chain per input slice / per top byte) instead
                                      of a reservation, so equal keys keep their input order; 48 instead of 52 bytes per pair.  0: pairs always

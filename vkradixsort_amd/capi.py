@@ -64,6 +64,7 @@ VRS_TUNE_MSD_POOL_SUB_BITS = 20
 VRS_TUNE_DEBUG_XCC_ROTATE = 21
 VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 22
 VRS_TUNE_MSD_POOL_PAIRS = 23
+VRS_TUNE_MSD_POOL_TOP_BITS = 24
 # keys the local sort of one top-14-bit bucket can hold (msd_local_capacity): uint32 keys with the 256- / 512-thread workgroup, pairs and 64-bit keys
 LOCAL_SORT_SMALL_KEYS, LOCAL_SORT_MAX_KEYS = 7165, 14333
 LOCAL_SORT_SMALL_PAIRS, LOCAL_SORT_MAX_PAIRS = 6656, 13312  # pairs and 64-bit keys: 512 / 1024-thread workgroups

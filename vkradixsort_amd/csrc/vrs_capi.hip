@@ -113,6 +113,8 @@ struct vrs_context_t {
     uint32_t os_pool_slack_cap = 0;        //   slots
     uint32_t *os_pool_overflow_vals = nullptr, *os_pool_slack_vals = nullptr;  // key + payload pairs: the payloads' twins of the two (made with the first pool sort of pairs)
     uint32_t os_pool_vals_overflow_cap = 0, os_pool_vals_slack_cap = 0;
+    int os_pool_top_bits = 7;              // VRS_TUNE_MSD_POOL_TOP_BITS: how a sort's 16384 buckets are cut between the two passes -- 7 + 7 bits (default: the first pass, which
+                                           // reads cold input, writes 64-key segments instead of 32-key ones: pairs -2.4 %, 10^7 keys -2.5 %, 10^8 keys -1 %), 8 + 6, or 6 + 8
     int os_pool_pairs = 1;                 // VRS_TUNE_MSD_POOL_PAIRS: key + payload pairs may take the (stable) pool form
     uint64_t os_pool_pair_sorts = 0;
     uint64_t os_pool_sorts = 0, os_pool_refusals = 0, os_pool_retries = 0;  // (retries: sorts whose local sort was enqueued again in a larger shape)
@@ -145,6 +147,7 @@ struct vrs_context_t {
         bool pool = false, no_pool = false;  // the pool form is on the stream / was refused for this sort
         uint32_t pool_sub_bits = 0, pool_local = 0;  // its shape; pool_retried: a larger local sort has been enqueued behind a first one that left
         bool pool_retried = false;
+        uint32_t pool_top_bits = 8;  // bits of its first pass
         uint32_t pool_par = 0;     // parity of its pool epoch
         bool pool_reused = false;  // its first pass ran in a kept layout
         size_t ev_lb_before = 0, ev_ls_before = 0;
@@ -1249,11 +1252,15 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     const uint32_t n = st.n;
     int rc;
     const bool pairs = st.vptr[0] != nullptr;
-    const vrs::PoolShape shape = pairs ? vrs::pool_shape_pairs(n) : vrs::pool_shape(n, ctx->os_pool_sub_bits);
+    vrs::PoolShape shape = pairs ? vrs::pool_shape_pairs(n) : vrs::pool_shape(n, ctx->os_pool_sub_bits);
+    // (lab: 7 + 7 bits -- the same 16384 buckets, cut 128 x 128; only where the usual cut is 256 x 64)
+    const uint32_t top_bits = (ctx->os_pool_top_bits != 8 && shape.sub_bits == 6u) ? static_cast<uint32_t>(ctx->os_pool_top_bits) : 8u, top_bytes = 1u << top_bits;
+    shape.sub_bits += 8u - top_bits;
+    st.pool_top_bits = top_bits;
     st.pool_sub_bits = shape.sub_bits;
     st.pool_local = shape.local;
     st.pool_retried = false;
-    const uint32_t room = vrs::pool_overflow_capacity(n), slack = vrs::pool_slack_capacity(n, shape.sub_bits);
+    const uint32_t room = vrs::pool_overflow_capacity(n), slack = vrs::pool_slack_capacity(n, shape.sub_bits, top_bytes);
     if ((rc = pool_scratch(ctx, room, slack, pairs))) return rc;
     if ((rc = reservation_begin(ctx))) return rc;  // the first pass's cursors: zero
     // Pairs: the passes are stable -- decoupled look-back through the one-call sort's status words, which must be clear when the
@@ -1289,10 +1296,11 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     const uint32_t tiles_b = vrs::pool_tiles_b_cap(n);
     const uint32_t par = (++ctx->os_pool_epoch) & 1u;
     st.pool_par = par;
-    st.pool_reused = ctx->os_pool_reuse && ctx->os_pool_layout_valid && ctx->os_pool_layout_n == n && ctx->os_pool_layout_base == st.key_base;
+    st.pool_reused = ctx->os_pool_reuse && ctx->os_pool_layout_valid && ctx->os_pool_layout_n == n && ctx->os_pool_layout_base == st.key_base &&
+                     (ctx->os_pool_layout_sub_bits >> 8) == top_bits;
     if (!st.pool_reused) {
         if ((rc = profile_events(ctx, VRS_KERNEL_POOL_SAMPLE, &ev))) return rc;
-        VRS_HIP(ctx, vrs::launch_pool_sample(ctx->stream, home, n, st.key_base, ps, ctx->os_pool_plan, room, par, ev));
+        VRS_HIP(ctx, vrs::launch_pool_sample(ctx->stream, home, n, st.key_base, ps, ctx->os_pool_plan, room, par, ev, top_bits));
         ctx->os_pool_layout_valid = false;  // (until this sort is known to have been taken)
     } else {
         ctx->os_pool_layout_reuses++;
@@ -1301,17 +1309,17 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     st.ev_ls_before = ctx->events_used[VRS_KERNEL_LOCAL_SORT];
     if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_A, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_pass_a(ctx->stream, home, partner, ctx->os_pool_overflow, n, st.key_base, ps, ctx->os_pool_plan, ctx->os_msd_plan,
-                                         ctx->xcc_map, ctx->os_misplace, room, par, ev, pvp));
-    const bool keep_rooms = st.pool_reused && ctx->os_pool_reuse_rooms && ctx->os_pool_layout_sub_bits == shape.sub_bits;
+                                         ctx->xcc_map, ctx->os_misplace, room, par, ev, pvp, top_bits));
+    const bool keep_rooms = st.pool_reused && ctx->os_pool_reuse_rooms && (ctx->os_pool_layout_sub_bits & 255u) == shape.sub_bits;
     VRS_HIP(ctx, vrs::launch_pool_plan(ctx->stream, ctx->os_msd_plan, ctx->os_pool_plan, n, tiles_b, ctx->os_pool_slack_cap, partner, ctx->os_pool_overflow, st.key_base, ps, shape.sub_bits, par,
-                                       nullptr, keep_rooms));
+                                       nullptr, keep_rooms, top_bits));
     if ((rc = profile_events(ctx, VRS_KERNEL_POOL_PASS_B, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_pass_b(ctx->stream, partner, ctx->os_pool_overflow, ctx->os_pool_slack, n, ctx->os_msd_plan, ctx->os_pool_plan, tiles_b,
                                          st.key_base, vrs::pool_local_capacity(shape.local), ctx->os_pool_slack_cap, ctx->xcc_map, st.stamp, shape.sub_bits, par, ev,
-                                         false, pvp));
+                                         false, pvp, top_bits));
     if ((rc = profile_events(ctx, VRS_KERNEL_LOCAL_SORT, &ev))) return rc;
     VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, home, n, ctx->os_msd_plan, ctx->os_pool_plan, shape, &ctx->os_plan->head,
-                                             ctx->os_host_head_dev, st.stamp, par, ev, 256, nullptr, false, pvp));
+                                             ctx->os_host_head_dev, st.stamp, par, ev, top_bytes, nullptr, false, pvp));
     ctx->os_cursors_open = false;  // the local sort re-arms the reservation counters (a refusal is handled by one_read_complete)
     st.active = true;
     return VRS_OK;
@@ -1352,7 +1360,7 @@ static int one_read_complete(vrs_context ctx, bool *done) {
             ctx->os_pool_layout_valid = true;  // its regions held: the next sort of this size may start in them
             ctx->os_pool_layout_n = n;
             ctx->os_pool_layout_base = st.key_base;
-            ctx->os_pool_layout_sub_bits = st.pool_sub_bits;
+            ctx->os_pool_layout_sub_bits = st.pool_sub_bits | (st.pool_top_bits << 8);
             return finish();
         }
         if (head.msd_max_bucket != 0u && !st.pool_retried) {
@@ -1378,7 +1386,7 @@ static int one_read_complete(vrs_context ctx, bool *done) {
                 ctx->os_pool_retries++;
                 VRS_HIP(ctx, vrs::launch_pool_local_sort(ctx->stream, ctx->os_pool_slack, static_cast<uint32_t *>(st.kptr[st.cur_at_start]), n, ctx->os_msd_plan,
                                                          ctx->os_pool_plan, vrs::PoolShape{st.pool_sub_bits, local}, &ctx->os_plan->head, ctx->os_host_head_dev,
-                                                         st.stamp, st.pool_par, ev, 256, nullptr, true, pairs ? &pv : nullptr));
+                                                         st.stamp, st.pool_par, ev, 1u << st.pool_top_bits, nullptr, true, pairs ? &pv : nullptr));
                 return VRS_OK;  // (still active: the settle waits for this one's word)
             }
         }
@@ -2269,6 +2277,11 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             if (sh) ctx->xcc_map = (ctx->xcc_map >> sh) | (ctx->xcc_map << (64u - sh));
             return VRS_OK;
         }
+        case VRS_TUNE_MSD_POOL_TOP_BITS:
+            if (value < 6 || value > 8) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form's first pass sorts by 8 bits (lab: 7)");
+            ctx->os_pool_top_bits = value;
+            ctx->os_pool_layout_valid = false;
+            return VRS_OK;
         case VRS_TUNE_MSD_POOL_PAIRS:
             ctx->os_pool_pairs = value != 0 ? 1 : 0;
             return VRS_OK;

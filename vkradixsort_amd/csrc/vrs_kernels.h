@@ -352,17 +352,18 @@ uint32_t pool_local_capacity(uint32_t local);
 uint32_t pool_tiles_b_cap(uint32_t n);         // rows of workgroups of the second pass (its grid is sized before the plan is known)
 // par: the parity of the context's pool epoch (0 / 1; the same for all kernels of one sort: PoolPlan::fail)
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
-                              PoolPlan *pool, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev = {});
+                              PoolPlan *pool, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev = {}, uint32_t top_bits = 8);
+// top_bits (every launcher of the form; lab switch VRS_TUNE_MSD_POOL_TOP_BITS): bits of the first pass's digit, 8 -- or 7, with a second pass of 7
 // keys_out: the partner buffer (n slots); overflow: pool_overflow_capacity(n) slots; cursors: MsdPlan::cursor_a (zero when the pass
 // starts); misplace: test hook, odd rows of workgroups walk the neighbouring slice
 hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, uint32_t *overflow, uint32_t n,
                               uint32_t key_base, const PoolStreams &ps, PoolPlan *pool, MsdPlan *msd, unsigned long long xcc_map,
-                              bool misplace, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev = {}, const PoolPayloads *pv = nullptr);
+                              bool misplace, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev = {}, const PoolPayloads *pv = nullptr, uint32_t top_bits = 8);
 // after the first pass, one workgroup per top byte: top-byte starts, tile tables, piece rows, the buckets' slack regions (from a
 // sample of the first pass's OUTPUT: regions / overflow), verdict 1 (slack_capacity: slots the slack buffer has)
 hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap, uint32_t slack_capacity,
                             const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps, uint32_t sub_bits,
-                            uint32_t par, const PoolGroups *groups = nullptr, bool keep_rooms = false);
+                            uint32_t par, const PoolGroups *groups = nullptr, bool keep_rooms = false, uint32_t top_bits = 8);
 // groups != nullptr: the second half alone (vrs_msd_finish_grouped_counts_u32) -- `regions` holds keys grouped by top byte, top byte a
 // (counted from key_base >> 24) holds groups->count[a] of them; no first pass ran
 // second pass, regions -> slack buffer: grid of 8 * tiles_b workgroups (tiles_b = pool_tiles_b_cap(n)); local_cap: keys the local
@@ -370,7 +371,7 @@ hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, ui
 hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *slack, uint32_t n, MsdPlan *msd,
                               PoolPlan *pool, uint32_t tiles_b, uint32_t key_base, uint32_t local_cap, uint32_t slack_capacity,
                               unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, uint32_t par, LaunchEvents ev = {}, bool grouped = false,
-                              const PoolPayloads *pv = nullptr);
+                              const PoolPayloads *pv = nullptr, uint32_t top_bits = 8);
 // sorts every bucket from its slack region to keys_out[its exact start ...) with the workgroup shape.local.  Gives verdict 2 (verdict 1, no flag from the passes) = MsdPlan::ok and the host head
 // (msd_ok, lsd_missing = 1, stamped last); re-arms the first pass's reservation counters
 hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,

@@ -25,6 +25,9 @@
 //                           streams the bucket to its final place in the caller's buffer: its top byte's exact start + the second
 //                           pass's counts of the buckets before it (64 words, one load per lane).
 //
+// ("Top byte" = the first pass's digit: 8 bits of the key range until late in round 5, 7 by default since -- and 7 for the second pass:
+// the same 16384 buckets, cut 128 x 128, `top_bits` below)
+//
 // (Round 4 grouped every second-pass tile IN PLACE and gathered every bucket from about 48 runs: no third buffer, but a gather that
 // cost the local sort 45 us at 10^8 keys, a run-descriptor kernel, and at most 56 tiles per top byte.  CHANGELOG, round 5.)
 //
@@ -47,7 +50,7 @@ constexpr uint32_t kPoolRoomFloor = 320;
 // ---------------------------------------------------------------------------------------------
 // The sample.  Workgroup g takes tiles [32 g, 32 g + 32) of the input; wave w of it the tiles 32 g + w + 4 j.
 __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t key_base,
-                                                          PoolStreams ps, PoolPlan *__restrict__ pool) {
+                                                          PoolStreams ps, PoolPlan *__restrict__ pool, uint32_t top_bits) {
     constexpr int kPerWave = kPoolSampleTiles / 4;        // tiles per wave
     constexpr int kLoads = kPoolSampleKeys / 64;          // 4-byte loads per lane and tile
     __shared__ uint32_t s_hist[2][256];
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void pool_sample_kernel(const uint32_t *__rest
     __syncthreads();
     const uint32_t bits = s_or ? 32u - static_cast<uint32_t>(__clz(static_cast<int>(s_or))) : 0u;
     const uint32_t shift = bits > kMsdBits ? bits - kMsdBits : 0u;
-    const uint32_t dshift = shift + (kMsdBits - 8u);  // the first pass's digit: the top 8 bits of the range
+    const uint32_t dshift = shift + (kMsdBits - top_bits);  // the first pass's digit: the top 8 (lab: 7) bits of the range
 #pragma unroll
     for (int j = 0; j < kPerWave; ++j) {
         const uint32_t t = t0 + wave + 4u * j;
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__r
                                                              uint32_t *__restrict__ overflow, uint32_t n, uint32_t key_base,
                                                              PoolStreams ps, PoolPlan *__restrict__ pool, MsdPlan *__restrict__ msd,
                                                              unsigned long long xcc_map, int misplace, uint32_t overflow_capacity, uint32_t par,
-                                                             PoolPayloads pv) {
+                                                             PoolPayloads pv, uint32_t top_bits) {
     __shared__ ChunkSmem<uint32_t, 16, 8, PAIRS> sm;
     __shared__ uint32_t s_gbase2[kBins], s_split[kBins], s_flags;
     if (pool->armed == 0u) return;  // uniform: the sample kernel did not lay regions out (key range below 27 bits)
@@ -342,12 +345,12 @@ __global__ __launch_bounds__(512, 4) void pool_pass_a_kernel(const uint32_t *__r
     const uint32_t *kin = keys_in + ps.start[s_in] + done;
     const uint32_t d = threadIdx.x & 255u;
     RadixDigit<uint32_t> dg;
-    dg.shift = pool->shift + (kMsdBits - 8u);
+    dg.shift = pool->shift + (kMsdBits - top_bits);
     dg.base = key_base;
     PoolReserve at;
     at.cursor = &msd->cursor_a[s_out][d];
     at.region = &pool->base[s_out][d];
-    at.pad_keys = d == 255u ? kPoolTile - valid : 0u;
+    at.pad_keys = d == dg(dg.template pad<uint32_t>()) ? kPoolTile - valid : 0u;  // (the padding key carries the largest digit: 255, or 127 of 7 bits)
     at.n_virt = n;
     at.overflow = overflow;
     at.overflow_last = overflow_capacity - 1u;
@@ -408,7 +411,7 @@ __device__ __forceinline__ uint32_t pool_space(uint32_t c) {
 template <uint32_t SUBBITS, bool GROUPED>
 __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool, uint32_t n, uint32_t tiles_b_cap,
                                                        uint32_t slack_capacity, const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
-                                                       uint32_t key_base, PoolStreams ps, PoolGroups groups, uint32_t par, uint32_t keep) {
+                                                       uint32_t key_base, PoolStreams ps, PoolGroups groups, uint32_t par, uint32_t keep, uint32_t top_bits) {
     // keep (a sort that started in a KEPT layout, launch_pool_sample): the buckets' slack regions are kept too -- PoolPlan::sub_start as the
     // context's last taken sort of this size left it; no sample of the first pass's output, no rooms to size (the second pass verifies
     // them as ever: a bucket out of room flags the sort, which then runs again with samples of its own)
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
     __shared__ uint32_t s_bad;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, a = blockIdx.x;
     // bucket index of a key: (key - key_base) >> bshift (GROUPED: the bits below the top byte; a sort: the probed range's)
-    const uint32_t shift = GROUPED ? 18u : pool->shift, bshift = shift + kMsdSubBits - SUBBITS;
+    const uint32_t shift = GROUPED ? 18u : pool->shift, bshift = shift + kMsdBits - top_bits - SUBBITS;
     if (!GROUPED && tid < 256u) {  // the first pass's claims: (list x, tile i) exactly once for every tile of the grid (the 256 x 256 first threads take one each)
         const uint32_t w = a * 256u + tid, x = w / kPoolMaxTilesA, i = w % kPoolMaxTilesA;
         if (x < 8u && i < ps.tiles_per_stream) {
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(512) void pool_plan_kernel(MsdPlan *__restrict__ ms
             if (live & (1u << u)) atomicAdd(&s_hist[wave][((k[u] - key_base) >> bshift) & (SUB - 1u)], 1u);
     }
     __syncthreads();
-    const uint32_t top_bytes = GROUPED ? groups.top_bytes : 256u;  // (the tables hold top_bytes << SUBBITS buckets: the workgroups behind them have none)
+    const uint32_t top_bytes = GROUPED ? groups.top_bytes : 1u << top_bits;  // (the tables hold top_bytes << SUBBITS buckets: the workgroups behind them have none)
     if (wave == 0u && a < top_bytes && keep) {  // the regions stay: the second pass counts from zero
 #pragma unroll
         for (uint32_t q = 0; q < PER; ++q) pool->sub_cursor[a * SUB + PER * lane + q] = 0;
@@ -746,7 +749,8 @@ template <uint32_t SUBBITS, bool PAIRS>
 __global__ __launch_bounds__(512, PAIRS ? 4 : 6) void pool_pass_b_kernel(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ overflow,
                                                              uint32_t *__restrict__ slack, const MsdPlan *__restrict__ msd, PoolPlan *__restrict__ pool,
                                                              uint32_t n_virt, uint32_t key_base, uint32_t local_cap, uint32_t dump,
-                                                             unsigned long long xcc_map, uint32_t stamp, uint32_t grouped, uint32_t par, PoolPayloads pv) {
+                                                             unsigned long long xcc_map, uint32_t stamp, uint32_t grouped, uint32_t par, PoolPayloads pv,
+                                                             uint32_t top_bits) {
     __shared__ ChunkSmem<uint32_t, 16, 8, PAIRS> sm;
     // the list follows the XCC this workgroup RUNS on (pool_pass_a_kernel): all tiles of a top byte then meet behind the L2 that
     // holds its 64 cursors, whatever the dispatcher's rotation
@@ -799,7 +803,7 @@ __global__ __launch_bounds__(512, PAIRS ? 4 : 6) void pool_pass_b_kernel(const u
     src.n_virt = n_virt;
     const uint32_t slot0 = one_piece ? entry.x : __builtin_amdgcn_readlane(pslot, src.p0) + (tile_lo - __builtin_amdgcn_readlane(plo, src.p0));  // the tile's first key
     src.first_slot = slot0;
-    const BitsDigit dg{shift + kMsdSubBits - SUBBITS, SUB - 1u, key_base};  // (key_base is a multiple of 2^24 and the bits end at or below bit 24)
+    const BitsDigit dg{shift + kMsdBits - top_bits - SUBBITS, SUB - 1u, key_base};  // (key_base is a multiple of 2^24 and the bits end at or below bit 24)
     at.dump = dump;
     at.pad_keys = d == SUB - 1u ? kPoolTile - valid : 0u;  // (the padding key, key_base - 1, carries the largest digit)
     // a sort: no key may have bits above the probed range; grouped keys (the caller's promise): every key of this tile carries top byte a
@@ -1176,40 +1180,41 @@ PoolShape pool_shape_pairs(uint32_t n) {
 }
 
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
-                              PoolPlan *pool, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev) {
+                              PoolPlan *pool, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev, uint32_t top_bits) {
     if (n == 0 || ps.tiles_per_stream < kPoolSampleTiles) return hipErrorInvalidValue;  // (a sample workgroup's tiles span at most two slices)
     const uint32_t grid = (ps.tiles_total + kPoolSampleTiles - 1u) / kPoolSampleTiles;
-    VRS_LAUNCH(pool_sample_kernel, dim3(grid), dim3(256), stream, ev, keys, n, key_base, ps, pool);
+    VRS_LAUNCH(pool_sample_kernel, dim3(grid), dim3(256), stream, ev, keys, n, key_base, ps, pool, top_bits);
     hipLaunchKernelGGL(pool_layout_kernel, dim3(1), dim3(256), 0, stream, ps, pool, overflow_capacity, par);
     return hipGetLastError();
 }
 
 hipError_t launch_pool_pass_a(hipStream_t stream, const uint32_t *keys_in, uint32_t *keys_out, uint32_t *overflow, uint32_t n,
                               uint32_t key_base, const PoolStreams &ps, PoolPlan *pool, MsdPlan *msd, unsigned long long xcc_map,
-                              bool misplace, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev, const PoolPayloads *pv) {
+                              bool misplace, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev, const PoolPayloads *pv, uint32_t top_bits) {
     if (pv)
         VRS_LAUNCH(pool_pass_a_kernel<true>, dim3(8u * ps.tiles_per_stream), dim3(512), stream, ev, keys_in, keys_out, overflow, n, key_base, ps, pool, msd,
-                   xcc_map, 0, overflow_capacity, par, *pv);
+                   xcc_map, 0, overflow_capacity, par, *pv, top_bits);
     else
         VRS_LAUNCH(pool_pass_a_kernel<false>, dim3(8u * ps.tiles_per_stream), dim3(512), stream, ev, keys_in, keys_out, overflow, n, key_base, ps, pool, msd,
-                   xcc_map, misplace ? 1 : 0, overflow_capacity, par, PoolPayloads{});
+                   xcc_map, misplace ? 1 : 0, overflow_capacity, par, PoolPayloads{}, top_bits);
     return hipGetLastError();
 }
 
 hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, uint32_t n, uint32_t tiles_b_cap, uint32_t slack_capacity,
                             const uint32_t *regions, const uint32_t *overflow, uint32_t key_base, const PoolStreams &ps, uint32_t sub_bits,
-                            uint32_t par, const PoolGroups *groups, bool keep_rooms) {
+                            uint32_t par, const PoolGroups *groups, bool keep_rooms, uint32_t top_bits) {
     if (ps.tiles_per_stream > kPoolMaxTilesA || tiles_b_cap > kPoolMaxTilesB || (groups && keep_rooms)) return hipErrorInvalidValue;
     const dim3 grid(256), block(512);
     const uint32_t keep = keep_rooms ? 1u : 0u;
     if (groups) {
-        if (sub_bits == 8u) hipLaunchKernelGGL((pool_plan_kernel<8, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par, 0u);
-        else if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par, 0u);
-        else hipLaunchKernelGGL((pool_plan_kernel<6, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par, 0u);
+        if (sub_bits == 8u) hipLaunchKernelGGL((pool_plan_kernel<8, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par, 0u, 8u);
+        else if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par, 0u, 8u);
+        else hipLaunchKernelGGL((pool_plan_kernel<6, true>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, *groups, par, 0u, 8u);
     } else {
         const PoolGroups none{};
-        if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none, par, keep);
-        else hipLaunchKernelGGL((pool_plan_kernel<6, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none, par, keep);
+        if (sub_bits == 8u) hipLaunchKernelGGL((pool_plan_kernel<8, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none, par, keep, top_bits);
+        else if (sub_bits == 7u) hipLaunchKernelGGL((pool_plan_kernel<7, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none, par, keep, top_bits);
+        else hipLaunchKernelGGL((pool_plan_kernel<6, false>), grid, block, 0, stream, msd, pool, n, tiles_b_cap, slack_capacity, regions, overflow, key_base, ps, none, par, keep, top_bits);
     }
     return hipGetLastError();
 }
@@ -1217,21 +1222,31 @@ hipError_t launch_pool_plan(hipStream_t stream, MsdPlan *msd, PoolPlan *pool, ui
 hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const uint32_t *overflow, uint32_t *slack, uint32_t n, MsdPlan *msd,
                               PoolPlan *pool, uint32_t tiles_b, uint32_t key_base, uint32_t local_cap, uint32_t slack_capacity,
                               unsigned long long xcc_map, uint32_t stamp, uint32_t sub_bits, uint32_t par, LaunchEvents ev, bool grouped,
-                              const PoolPayloads *pv) {
+                              const PoolPayloads *pv, uint32_t top_bits) {
     if (tiles_b == 0) return hipSuccess;
     if (tiles_b > kPoolMaxTilesB || stamp == 0u) return hipErrorInvalidValue;
     // (grouped keys lie in `regions` alone: no slot is an overflow slot)
     // (... unless a part of them lies in a second buffer, PoolGroups::own: those are the slots from n on)
     const uint32_t n_virt = (grouped && regions == overflow) ? 0xFFFFFFFFu : n, g = grouped ? 1u : 0u;
     if (pv) {  // pairs: six bits, a sort
-        if (sub_bits != 6u || grouped) return hipErrorInvalidValue;
+        if ((sub_bits != 6u && sub_bits != 7u && sub_bits != 8u) || grouped) return hipErrorInvalidValue;
+        if (sub_bits == 8u) {
+            VRS_LAUNCH((pool_pass_b_kernel<8, true>), dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n_virt, key_base, local_cap,
+                       slack_capacity - kPoolTile, xcc_map, stamp, g, par, *pv, top_bits);
+            return hipGetLastError();
+        }
+        if (sub_bits == 7u) {
+            VRS_LAUNCH((pool_pass_b_kernel<7, true>), dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n_virt, key_base, local_cap,
+                       slack_capacity - kPoolTile, xcc_map, stamp, g, par, *pv, top_bits);
+            return hipGetLastError();
+        }
         VRS_LAUNCH((pool_pass_b_kernel<6, true>), dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n_virt, key_base, local_cap,
-                   slack_capacity - kPoolTile, xcc_map, stamp, g, par, *pv);
+                   slack_capacity - kPoolTile, xcc_map, stamp, g, par, *pv, top_bits);
         return hipGetLastError();
     }
 #define VRS_POOL_B(S)                                                                                                                         \
     VRS_LAUNCH((pool_pass_b_kernel<S, false>), dim3(8u * tiles_b), dim3(512), stream, ev, regions, overflow, slack, msd, pool, n_virt, key_base, local_cap, \
-               slack_capacity - kPoolTile, xcc_map, stamp, g, par, PoolPayloads{})
+               slack_capacity - kPoolTile, xcc_map, stamp, g, par, PoolPayloads{}, top_bits)
     if (sub_bits == 8u) VRS_POOL_B(8);
     else if (sub_bits == 7u) VRS_POOL_B(7);
     else VRS_POOL_B(6);
@@ -1247,7 +1262,25 @@ hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uin
     uint32_t *cursors = &msd->cursor_a[0][0];
     if (top_bytes == 0u || top_bytes > 256u || (top_bytes << shape.sub_bits) > kPoolMaxBuckets) return hipErrorInvalidValue;
     if (pv || shape.local >= 4u) {  // pairs
-        if (!pv || shape.sub_bits != 6u || top_bytes != 256u || (shape.local != 4u && shape.local != 5u)) return hipErrorInvalidValue;
+        if (!pv || (shape.local != 4u && shape.local != 5u) || (top_bytes << shape.sub_bits) != kMsdBuckets) return hipErrorInvalidValue;
+        if (shape.sub_bits == 8u) {
+            if (shape.local == 4u)
+                VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 8>), dim3(kMsdBuckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
+                           stamp, host_log, again, par, *pv);
+            else
+                VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 8>), dim3(kMsdBuckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
+                           stamp, host_log, again, par, *pv);
+            return hipGetLastError();
+        }
+        if (shape.sub_bits == 7u) {  // (lab: 7 + 7 bits)
+            if (shape.local == 4u)
+                VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 7>), dim3(kMsdBuckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
+                           stamp, host_log, again, par, *pv);
+            else
+                VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 7>), dim3(kMsdBuckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
+                           stamp, host_log, again, par, *pv);
+            return hipGetLastError();
+        }
         if (shape.local == 4u)
             VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 6>), dim3(kMsdBuckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
                        stamp, host_log, again, par, *pv);
