@@ -445,3 +445,24 @@ def test_pool_form_of_pairs_with_a_tile_that_never_publishes(pool_ctx, oracle, h
     # and the next sort of the context is none the worse for it
     ok, ov, stats, (took, refused) = sort_pairs_and_stats(pool_ctx, keys, vals)
     assert np.array_equal(ok, rk) and np.array_equal(ov, rv)
+
+
+@pytest.mark.parametrize("top_bits", [6, 8])
+@pytest.mark.parametrize("dist", ["uniform", "gauss", "dups"])
+def test_pool_form_with_the_other_cuts_of_its_buckets(pool_ctx, oracle, top_bits, dist):
+    """VRS_TUNE_MSD_POOL_TOP_BITS: the 16384 buckets cut 8 + 6 bits between the two passes (the default until late in round 5) or 6 + 8
+    instead of 7 + 7 -- the same buckets, the same result, for keys and for pairs (the ragged last tile's padding key carries the
+    largest digit of whatever width)"""
+    n = 9000001
+    keys = pool_keys(n, dist, seed=top_bits)
+    vals = make_keys(n, "uniform", seed=31)
+    pool_ctx.setTuning(capi.VRS_TUNE_MSD_POOL_TOP_BITS, top_bits)
+    try:
+        out, stats, (took, refused) = sort_and_stats(pool_ctx, keys)
+        assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1 and (took, refused) == (1, 0)
+        ok, ov, stats, (took, refused) = sort_pairs_and_stats(pool_ctx, keys, vals)
+        rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
+        assert np.array_equal(ok, rk) and np.array_equal(ov, rv) and (took, refused) == (1, 0)
+    finally:
+        pool_ctx.setTuning(capi.VRS_TUNE_MSD_POOL_TOP_BITS, 7)
+    assert pool_ctx.lib.vrs_set_tuning(pool_ctx.handle, capi.VRS_TUNE_MSD_POOL_TOP_BITS, 5) == capi.VRS_ERROR_INVALID_ARGUMENT
