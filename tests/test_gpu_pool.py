@@ -466,3 +466,17 @@ def test_pool_form_with_the_other_cuts_of_its_buckets(pool_ctx, oracle, top_bits
     finally:
         pool_ctx.setTuning(capi.VRS_TUNE_MSD_POOL_TOP_BITS, 7)
     assert pool_ctx.lib.vrs_set_tuning(pool_ctx.handle, capi.VRS_TUNE_MSD_POOL_TOP_BITS, 5) == capi.VRS_ERROR_INVALID_ARGUMENT
+
+
+def test_pool_form_of_pairs_beyond_the_512_thread_local_sort(gpu_context):
+    """1.3e8 pairs: 16384 buckets of 7900 would need the 1024-thread local sort; the second pass takes seven bits instead (32768 buckets
+    of 3970) and the 512-thread workgroup stays"""
+    ctx = gpu_context
+    n = 130000000
+    keys = make_keys(n, "uniform", seed=3)
+    vals = np.arange(n, dtype=np.uint32)
+    ok, ov, stats, (took, refused) = sort_pairs_and_stats(ctx, keys, vals)
+    assert (took, refused) == (1, 0), stats
+    assert np.all(ok[1:] >= ok[:-1]) and np.array_equal(keys[ov], ok)
+    same = ok[1:] == ok[:-1]
+    assert np.all(ov[1:][same] > ov[:-1][same])

@@ -38,7 +38,7 @@ def timed(gpu, n, K=8, reps=3):
 
 with vrs.GPUContext(0) as gpu:
     print("n          lsd      counted  pool")
-    for n in (6 * 10 ** 6, 8 * 10 ** 6, 10 ** 7, 12 * 10 ** 6, 16 * 10 ** 6, 2 * 10 ** 7, 25 * 10 ** 6, 3 * 10 ** 7, 5 * 10 ** 7, 10 ** 8, 15 * 10 ** 7):
+    for n in [int(float(a)) for a in sys.argv[1:]] or (6 * 10 ** 6, 8 * 10 ** 6, 10 ** 7, 12 * 10 ** 6, 16 * 10 ** 6, 2 * 10 ** 7, 25 * 10 ** 6, 3 * 10 ** 7, 5 * 10 ** 7, 10 ** 8, 15 * 10 ** 7):
         row = []
         for mode in ("lsd", "counted", "pool"):
             gpu.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, (1 << 30) if mode == "lsd" else (1 << 22))

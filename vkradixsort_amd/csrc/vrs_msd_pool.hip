@@ -1174,9 +1174,16 @@ PoolShape pool_shape(uint32_t n, int forced_sub_bits) {
 }
 
 PoolShape pool_shape_pairs(uint32_t n) {
-    // pairs: six bits, the local sort's shape by the fullest uniform bucket (pool_shape's rule); local 4 = 512 threads, 5 = 1024
-    const double mean = static_cast<double>(n) / kMsdBuckets;
-    return PoolShape{6u, static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u <= pool_local_capacity(4u) ? 4u : 5u};
+    // pairs: the local sort's shape by the fullest uniform bucket (pool_shape's rule); local 4 = 512 threads, 5 = 1024.  Six bits while
+    // the 16384 buckets fit the 512-thread workgroup (about 1.05e8 pairs); beyond, seven bits keep them there (32768 buckets: 2e8 pairs
+    // 2.35 -> 2.0 ms); the 1024-thread workgroup only where even those do not fit
+    const auto fits = [&](uint32_t sub_bits, uint32_t local) {
+        const double mean = static_cast<double>(n) / (256u << sub_bits);
+        return static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u <= pool_local_capacity(local);
+    };
+    if (fits(6, 4)) return PoolShape{6u, 4u};
+    if (fits(7, 4)) return PoolShape{7u, 4u};
+    return PoolShape{6u, 5u};
 }
 
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
@@ -1262,30 +1269,31 @@ hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uin
     uint32_t *cursors = &msd->cursor_a[0][0];
     if (top_bytes == 0u || top_bytes > 256u || (top_bytes << shape.sub_bits) > kPoolMaxBuckets) return hipErrorInvalidValue;
     if (pv || shape.local >= 4u) {  // pairs
-        if (!pv || (shape.local != 4u && shape.local != 5u) || (top_bytes << shape.sub_bits) != kMsdBuckets) return hipErrorInvalidValue;
+        if (!pv || (shape.local != 4u && shape.local != 5u)) return hipErrorInvalidValue;
+        const uint32_t buckets = top_bytes << shape.sub_bits;
         if (shape.sub_bits == 8u) {
             if (shape.local == 4u)
-                VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 8>), dim3(kMsdBuckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
+                VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 8>), dim3(buckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
                            stamp, host_log, again, par, *pv);
             else
-                VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 8>), dim3(kMsdBuckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
+                VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 8>), dim3(buckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
                            stamp, host_log, again, par, *pv);
             return hipGetLastError();
         }
         if (shape.sub_bits == 7u) {  // (lab: 7 + 7 bits)
             if (shape.local == 4u)
-                VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 7>), dim3(kMsdBuckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
+                VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 7>), dim3(buckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
                            stamp, host_log, again, par, *pv);
             else
-                VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 7>), dim3(kMsdBuckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
+                VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 7>), dim3(buckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
                            stamp, host_log, again, par, *pv);
             return hipGetLastError();
         }
         if (shape.local == 4u)
-            VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 6>), dim3(kMsdBuckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
+            VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 6>), dim3(buckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
                        stamp, host_log, again, par, *pv);
         else
-            VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 6>), dim3(kMsdBuckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
+            VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 6>), dim3(buckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
                        stamp, host_log, again, par, *pv);
         return hipGetLastError();
     }
