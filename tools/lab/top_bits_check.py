@@ -1,5 +1,6 @@
+"""Lab: the pool form with another cut of its buckets (VRS_TUNE_MSD_POOL_TOP_BITS), keys and pairs against numpy.   python tools/lab/top_bits_check.py [6|7|8]"""
 import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent.parent))
 import vkradixsort_amd as vrs
 from vkradixsort_amd import capi
 S=vrs.Buffer.BufferSettings
