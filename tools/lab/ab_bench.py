@@ -38,6 +38,10 @@ with vrs.GPUContext(0) as gpu:
         gpu.setTuning(4, int(float(os.environ["VRS_ONE_CALL_MIN"])))
     if os.environ.get("VRS_POOL"):
         gpu.setTuning(17, int(os.environ["VRS_POOL"]))
+    if os.environ.get("VRS_TOP_BITS"):
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL_TOP_BITS, int(os.environ["VRS_TOP_BITS"]))
+    if os.environ.get("VRS_SUB_BITS"):
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL_SUB_BITS, int(os.environ["VRS_SUB_BITS"]))
     if os.environ.get("VRS_FUSED_PLAN"):
         gpu.setTuning(10, int(os.environ["VRS_FUSED_PLAN"]))
 

@@ -10,7 +10,9 @@ import csv, glob, collections
 for f in sorted(glob.glob('gpurun_out/lds_pmc/*/*counter_collection.csv')+glob.glob('gpurun_out/lds_pmc/*/*/*counter_collection.csv')):
     acc=collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        k=r['Kernel_Name'].split('(')[0][:50]
+        import re
+        m=re.search(r'(\w+_kernel(?:<[^>(]*>)?)', r['Kernel_Name'])  # (names in an anonymous namespace carry a '(' before the kernel's own)
+        k=m.group(1) if m else r['Kernel_Name'][:50]
         acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in acc.items():
         if 'pool_local' in k or 'pass_b' in k or 'pass_a' in k or 'lean' in k or 'msd_local' in k:

@@ -2291,7 +2291,7 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             ctx->os_pool_layout_valid = false;
             return VRS_OK;
         case VRS_TUNE_MSD_POOL_SUB_BITS:
-            if (value != 0 && value != 6 && value != 7) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form's second pass sorts by 6 or 7 bits (0 = by size)");
+            if (value != 0 && (value < 6 || value > 8)) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form's second pass sorts by 6, 7 or 8 bits (0 = by size)");
             ctx->os_pool_sub_bits = value;
             ctx->os_pool_layout_valid = false;
             return VRS_OK;

@@ -271,8 +271,8 @@ constexpr uint32_t kPoolTile = 8192;           // keys per tile of both passes
 constexpr uint32_t kPoolSampleKeys = 256;      // leading keys of every tile the sample kernel counts
 constexpr uint32_t kPoolSampleTiles = 32;      // tiles per workgroup of the sample kernel
 constexpr uint32_t kPoolMaxKeys = 224000000u;  // the fullest of 16384 uniform buckets (mean + 5.5 deviations) must fit the local sort's 512-thread shape (14333 keys)
-constexpr uint32_t kPoolMaxBuckets = 256u << 7; // the second pass sorts by 6 or 7 bits of 256 top bytes (16384 or 32768 buckets); the second half alone
-                                                // (grouped keys of fewer top bytes) also by 8
+constexpr uint32_t kPoolMaxBuckets = 256u << 8; // the second pass sorts by 6 or 7 bits of 256 top bytes (16384 or 32768 buckets); the second half alone
+                                                // (grouped keys) and the 8 + 8 cut (VRS_TUNE_MSD_POOL_SUB_BITS 8: 65536 buckets, one wave each) also by 8
 constexpr uint32_t kPoolMaxTilesA = 3456;      // tiles per slice of the first pass at kPoolMaxKeys (3418)
 constexpr uint32_t kPoolTileGeneral = 0xFFFFFFFFu;
 constexpr uint32_t kPoolMaxTilesB = 4352;      // rows of workgroups of the second pass at kPoolMaxKeys (pool_tiles_b_cap: 4313)
@@ -322,7 +322,7 @@ struct PoolShape {
     uint32_t local;      // 3: one WAVE per bucket (up to 1789 keys), 0: 256 threads x 16 slots (4093, five workgroups per CU), 1: 256 x 28 (7165, four), 2: 512 x 28 (14333, two);
                          // key + payload pairs: 4: 512 threads x 13 pairs (6656), 5: 1024 x 13 (13312)
 };
-PoolShape pool_shape(uint32_t n, int forced_sub_bits = 0);  // forced_sub_bits: 0 = by size, 6 or 7
+PoolShape pool_shape(uint32_t n, int forced_sub_bits = 0);  // forced_sub_bits: 0 = by size, 6, 7 or 8
 PoolShape pool_shape_pairs(uint32_t n);
 // Key + payload pairs (the STABLE pool form: a tile's place in a region is its rank there, by decoupled look-back): the payloads'
 // twins of the keys' buffers and the look-back's status words (the one-call sort's; `status_words` of them, all cleared by the local

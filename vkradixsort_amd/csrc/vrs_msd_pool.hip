@@ -1168,7 +1168,7 @@ PoolShape pool_shape(uint32_t n, int forced_sub_bits) {
     // (2e8 keys: 1.05 instead of 1.08 ms with the 512-thread shape).  Smaller buckets are NOT better: a workgroup's fixed work -- five
     // counter tables to zero and scan, two memory round trips -- is a third of its life at 3000 keys (10^8 keys by seven bits: the
     // local sort 205 instead of 176 us, with five workgroups per CU), a sixth at 6100.
-    sh.sub_bits = forced_sub_bits == 6 || forced_sub_bits == 7 ? static_cast<uint32_t>(forced_sub_bits) : (fits(6, 1) ? 6u : 7u);
+    sh.sub_bits = forced_sub_bits >= 6 && forced_sub_bits <= 8 ? static_cast<uint32_t>(forced_sub_bits) : (fits(6, 1) ? 6u : 7u);
     sh.local = fits(sh.sub_bits, 3) ? 3u : fits(sh.sub_bits, 0) ? 0u : fits(sh.sub_bits, 1) ? 1u : 2u;
     return sh;
 }
