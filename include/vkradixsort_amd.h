@@ -453,15 +453,30 @@ int vrs_one_call_hybrid_recounts(vrs_context ctx, uint64_t *recounts);
 /* One-call sorts of bare uint32 keys that took the pool form (the hybrid form without a counting read, VRS_TUNE_MSD_POOL), and
  * sorts whose pool form the plan refused (they ran in the counted form afterwards).  Cumulative; diagnostics only. */
 int vrs_one_call_pool_sorts(vrs_context ctx, uint64_t *pool_sorts, uint64_t *pool_refusals);
-/* What the pool form would do with num_elements bare uint32 keys (host only, no device needed): *sub_bits = bits of its second pass
-   (6 or 7; 0 = the form does not take this size), *bucket_capacity = keys per bucket the local sort it enqueues takes (1789: one wave
+/* What the pool form would do with num_elements bare uint32 keys (host only, no device needed): *sub_bits = S where the sort has
+   256 << S buckets (6 or 7; 0 = the form does not take this size) -- the COUNT of buckets, not the cut: with the default cut a sort of
+   16384 buckets runs a first pass by 7 bits and a second by 7, vrs_pool_form_shape_ex reports that --, *bucket_capacity = keys per bucket the local sort it enqueues takes (1789: one wave
    per bucket; 4093 / 7165: 256 threads; 14333: 512), *scratch_bytes = context scratch a sort of this size needs beside the caller's two
    buffers (slack buffer + first-pass overflow room + plan).  Any pointer may be NULL. */
 int vrs_pool_form_shape(uint32_t num_elements, uint32_t *sub_bits, uint32_t *bucket_capacity, uint64_t *scratch_bytes);
+/* The same with the cut as it runs: pairs != 0 = uint32 key + uint32 payload pairs (the stable pool form: other shapes, and the
+   payloads' twins of the slack buffer and the overflow room in *scratch_bytes); top_bits_setting = VRS_TUNE_MSD_POOL_TOP_BITS as set on
+   the context (0 = the library's default, 7).  *first_pass_bits / *second_pass_bits = the digits of the two MSD passes (7 + 7 by
+   default, 8 + 7 where 32768 buckets are needed; 0 / 0 = the form does not take this size).  Any pointer may be NULL. */
+int vrs_pool_form_shape_ex(uint32_t num_elements, int pairs, int top_bits_setting, uint32_t *first_pass_bits, uint32_t *second_pass_bits,
+                           uint32_t *bucket_capacity, uint64_t *scratch_bytes);
 /* sorts of the pool form whose local sort was enqueued a second time in a larger workgroup shape: the shape is chosen from
    num_elements alone (the form is enqueued blind), and a bucket of skewed keys may hold more than it takes -- no refusal, the bucket
    lies whole in its slack region; the settle asks for the larger shape (one more kernel, one more host round trip) */
 int vrs_one_call_pool_retries(vrs_context ctx, uint64_t *retries);
+/* The pool form keeps its scratch -- the slack buffer and the first pass's overflow regions, about 1.55 n uint32 slots for the largest sort
+   the context has taken in that form (616 MB at 10^8 keys), twice that once pairs took it (vrs_pool_form_shape reports it) -- until the
+   context is destroyed.  vrs_context_trim_scratch gives it back to the device now (after settling and waiting for what is on the stream;
+   *released_bytes may be NULL); the next pool sort allocates again.  A device with no room for it is no error of a sort: the sort takes a
+   form that needs no such scratch (28 / 36 bytes per key instead of 24), vrs_one_call_pool_no_memory counts those sorts, and with the
+   adaptive setting (VRS_TUNE_MSD_POOL = 1) the next 15 sorts of that size do not ask again. */
+int vrs_context_trim_scratch(vrs_context ctx, uint64_t *released_bytes);
+int vrs_one_call_pool_no_memory(vrs_context ctx, uint64_t *sorts);
 /* VRS_TUNE_MSD_POOL_REUSE_LAYOUT: *reused = pool sorts that started in the regions of an earlier sort, *stale = those of them whose keys
    did not fit (run again with their own sample).  Either pointer may be NULL. */
 int vrs_one_call_pool_layouts(vrs_context ctx, uint64_t *reused, uint64_t *stale);
@@ -532,8 +547,11 @@ typedef enum vrs_tuning_key {
                                       refuses (a region the sample misjudged, a bucket too large) starts over in the counted form with its input untouched.  1 (default) = adaptive: after a refusal the next 15
                                       such sorts of the context take the counted form; 2 = always tried; 0 = never.  Needs
                                       VRS_TUNE_MSD_RESERVE != 0. */
-    VRS_TUNE_MSD_POOL_MIN_KEYS = 18, /* the pool form is considered from this many keys on (default 3.2 * 10^7: the measured crossover with the counted form; never below 2^22) */
-    VRS_TUNE_MSD_POOL_SUB_BITS = 20, /* bits the pool form's second pass sorts by: 0 (default) = by size (6 while the buckets fit a 256-thread local sort, about 1.1 * 10^8 uniform keys, else 7), 6 or 7 */
+    VRS_TUNE_MSD_POOL_MIN_KEYS = 18, /* the pool form is considered from this many keys on (default and floor 2^22: with one wave per small bucket it beats the
+                                        LSD passes from there on, profiles/labs/r05_pool_form.txt section 6) */
+    VRS_TUNE_MSD_POOL_SUB_BITS = 20, /* S where a pool sort of bare keys has 256 << S buckets: 0 (default) = by size (6 while the buckets fit a 256-thread local sort, about
+                                        1.1 * 10^8 uniform keys, else 7), 6, 7 or 8 (8 with VRS_TUNE_MSD_POOL_TOP_BITS 8: 65536 buckets of one wave each, a lab
+                                        setting -- profiles/labs/r06_cut_8_8.txt) */
     VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 22, /* (2: what follows; 1, the default: also the buckets' slack regions are kept -- the plan kernel of such a sort
                                        samples nothing; verified by the second pass like the first pass's regions by the first.)
                                        1 (default): a pool sort of the same size and key floor as the context's last TAKEN one runs its first
@@ -548,6 +566,7 @@ typedef enum vrs_tuning_key {
                                      a sampled region is its rank there (decoupled look-back, one chain per input slice / per top byte) instead
                                      of a reservation, so equal keys keep their input order; 48 instead of 52 bytes per pair.  0: pairs always
                                      take the counted form */
+    VRS_TUNE_DEBUG_POOL_NO_MEMORY = 25, /* test hook: the next `value` allocations of the pool form's scratch fail as if the device were full */
     VRS_TUNE_DEBUG_XCC_ROTATE = 21, /* test hook: run the placement probe again and rotate its result by `value` places (0 .. 7), as if the probe had
                                        run on another hardware queue than the sorts do (the dispatcher starts every queue's round-robin at its
                                        own XCC, and a stream may move between queues): the pool form's passes take their work lists by the XCC

@@ -285,3 +285,26 @@ def test_pool_form_shape_by_size(lib):
         prev = s
     assert 1.65 * 4e8 < shape(10 ** 8)[2] < 1.75 * 4e8  # 1.54 N of slack buffer + 0.18 N of first-pass overflow room
     assert lib.vrs_pool_form_shape(10 ** 8, None, None, None) == 0
+
+
+def test_pool_form_shape_ex_reports_the_cut_that_runs(lib):
+    """vrs_pool_form_shape_ex (host only): the two passes' digits as one_read_enqueue_pool cuts them (7 + 7 by default: ADVICE r5 found
+    vrs_pool_form_shape reporting '6' where the second pass takes 7 bits), pairs with their own shapes and the payloads' twins in the scratch,
+    and no shape at all beyond the last size whose fullest uniform bucket fits (pairs: about 2.07e8 -- the candidate bound was wider)."""
+    def ex(n, pairs=0, top=0):
+        a, b, cap, scratch = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+        assert lib.vrs_pool_form_shape_ex(n, pairs, top, ctypes.byref(a), ctypes.byref(b), ctypes.byref(cap), ctypes.byref(scratch)) == 0
+        return a.value, b.value, cap.value, scratch.value
+    assert ex(10 ** 8)[:3] == (7, 7, 7165) and ex(10 ** 8, top=8)[:3] == (8, 6, 7165) and ex(10 ** 8, top=6)[:3] == (6, 8, 7165)
+    assert ex(13 * 10 ** 7)[:3] == (8, 7, 7165) and ex(10 ** 7)[:3] == (7, 7, 1789)
+    assert ex(10 ** 8, pairs=1)[:3] == (7, 7, 6656) and ex(2 * 10 ** 8, pairs=1)[:3] == (8, 7, 6656)
+    assert ex(1000)[:2] == (0, 0) and ex(300000000)[:2] == (0, 0)
+    keys, pairs = ex(10 ** 8)[3], ex(10 ** 8, pairs=1)[3]
+    assert 1.9 * keys < pairs < 2.05 * keys  # the payloads' twins of the slack buffer and the overflow room
+    # the last pairs size with a shape: beyond it every sort would be refused after both passes ran
+    lo, hi = 10 ** 8, 3 * 10 ** 8
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        lo, hi = (mid, hi) if ex(mid, pairs=1)[0] else (lo, mid)
+    assert 2.0e8 < lo < 2.13e8 and ex(lo, pairs=1)[2] == 13312
+    assert lib.vrs_pool_form_shape_ex(10 ** 8, 0, 5, None, None, None, None) != 0

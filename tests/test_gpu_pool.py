@@ -480,3 +480,81 @@ def test_pool_form_of_pairs_beyond_the_512_thread_local_sort(gpu_context):
     assert np.all(ok[1:] >= ok[:-1]) and np.array_equal(keys[ov], ok)
     same = ok[1:] == ok[:-1]
     assert np.all(ov[1:][same] > ov[:-1][same])
+
+
+def _u64(ctx, fn):
+    v = ctypes.c_uint64()
+    ctx.check(getattr(ctx.lib, fn)(ctx.handle, ctypes.byref(v)))
+    return v.value
+
+
+def test_no_room_for_the_scratch_is_no_error_of_the_sort(pool_ctx, oracle):
+    """a device with no room for the pool form's scratch (about 1.5 n slots) must not fail the sort -- the counted / LSD forms need
+    none.  VRS_TUNE_DEBUG_POOL_NO_MEMORY makes the next allocation fail like a full device."""
+    ctx = pool_ctx
+    freed = ctypes.c_uint64()
+    ctx.check(ctx.lib.vrs_context_trim_scratch(ctx.handle, ctypes.byref(freed)))  # (so that the sort below HAS to allocate)
+    n = POOL_MIN + 4099
+    keys = make_keys(n, "uniform", 31)
+    before = _u64(ctx, "vrs_one_call_pool_no_memory")
+    ctx.setTuning(capi.VRS_TUNE_DEBUG_POOL_NO_MEMORY, 1)
+    out, stats, (took, refused) = sort_and_stats(ctx, keys)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+    assert (took, refused) == (0, 0) and stats["pool_pass_a"] == 0 and _u64(ctx, "vrs_one_call_pool_no_memory") == before + 1
+    # with room again the form is taken (VRS_TUNE_MSD_POOL = 2 here: no adaptive skip), and what it allocated can be given back
+    out, stats, (took, refused) = sort_and_stats(ctx, keys)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1 and (took, refused) == (1, 0)
+    ctx.check(ctx.lib.vrs_context_trim_scratch(ctx.handle, ctypes.byref(freed)))
+    assert freed.value >= 4 * n  # the slack buffer alone holds n keys and their room
+    out, stats, (took, refused) = sort_and_stats(ctx, keys)
+    assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1 and (took, refused) == (1, 0)
+    ctx.check(ctx.lib.vrs_context_trim_scratch(ctx.handle, None))
+
+
+def test_no_room_for_the_payload_twins(pool_ctx):
+    """... and pairs: the keys' scratch exists, the payloads' twins find no room -- the counted form sorts the pairs, stable."""
+    ctx = pool_ctx
+    n = POOL_MIN + 77
+    keys = make_keys(n, "uniform", 5) & np.uint32(0xFFFF0FFF)
+    vals = np.arange(n, dtype=np.uint32)
+    ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, 8 * POOL_MIN // 5 + 8)  # (pairs: the hybrid threshold is 5/8 of the setting)
+    ctx.check(ctx.lib.vrs_context_trim_scratch(ctx.handle, None))
+    sort_and_stats(ctx, make_keys(n, "uniform", 6))  # the keys' scratch, of the size the pairs ask for too
+    k0, k1 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), keys), vrs.Buffer(ctx, S(4 * n))
+    v0, v1 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), vals), vrs.Buffer(ctx, S(4 * n))
+    before = _u64(ctx, "vrs_one_call_pool_no_memory")
+    try:
+        ctx.setTuning(capi.VRS_TUNE_DEBUG_POOL_NO_MEMORY, 1)  # the next allocation: the payloads' twin of the overflow room
+        ctx.check(ctx.lib.vrs_sort_pairs_u32(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+        ov = np.empty(n, np.uint32)
+        v0.downloadWithStagingBuffer(ov)
+        assert np.array_equal(ov, np.argsort(keys, kind="stable").astype(np.uint32))
+        assert _u64(ctx, "vrs_one_call_pool_no_memory") == before + 1
+    finally:
+        ctx.setTuning(capi.VRS_TUNE_DEBUG_POOL_NO_MEMORY, 0)
+        for b in (k0, k1, v0, v1):
+            b.release()
+
+
+def test_stale_layouts_back_off(oracle):
+    """kept layouts had no back-off -- a workload of equal n whose distribution changes from sort to sort (here: uniform keys and
+    28-bit keys, alternating) found every kept layout stale: two passes, a host round trip and the whole sort again, each time.
+    After two stale layouts in a row the next 16 candidates sample for themselves.  (A context of its own: the shared one keeps no layouts.)"""
+    n = POOL_MIN + 123457
+    a = make_keys(n, "uniform", 3)
+    b = pool_keys(n, "28bit", 4)  # another key range: another layout altogether (and one the form takes)
+    with vrs.GPUContext(0) as ctx:
+        ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, POOL_MIN)
+        ctx.setTuning(capi.VRS_TUNE_MSD_POOL_MIN_KEYS, POOL_MIN)
+        ctx.setTuning(capi.VRS_TUNE_MSD_POOL, 2)
+        sort_and_stats(ctx, a)  # a layout to keep
+        assert pool_layouts(ctx) == (0, 0)
+        for i in range(12):
+            keys = b if i % 2 == 0 else a
+            out, _, _ = sort_and_stats(ctx, keys)
+            assert oracle.test_sort(oracle.std_sort(keys)[0], out) == -1
+        # every reused layout was stale (the distributions alternate) -- but only two sorts paid for finding out, not all twelve
+        assert pool_layouts(ctx) == (2, 2)
+        for i in range(8):  # the pause ends after 16 candidates: a kept layout is tried again (and with a steady workload it fits)
+            sort_and_stats(ctx, a)
+        assert pool_layouts(ctx) == (4, 2)  # (ten candidates paused in the loop, six here, then two that reuse and fit)

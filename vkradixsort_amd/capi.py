@@ -65,6 +65,7 @@ VRS_TUNE_DEBUG_XCC_ROTATE = 21
 VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 22
 VRS_TUNE_MSD_POOL_PAIRS = 23
 VRS_TUNE_MSD_POOL_TOP_BITS = 24
+VRS_TUNE_DEBUG_POOL_NO_MEMORY = 25
 # keys the local sort of one top-14-bit bucket can hold (msd_local_capacity): uint32 keys with the 256- / 512-thread workgroup, pairs and 64-bit keys
 LOCAL_SORT_SMALL_KEYS, LOCAL_SORT_MAX_KEYS = 7165, 14333
 LOCAL_SORT_SMALL_PAIRS, LOCAL_SORT_MAX_PAIRS = 6656, 13312  # pairs and 64-bit keys: 512 / 1024-thread workgroups
@@ -174,6 +175,9 @@ _SIGNATURES = [
     ("vrs_one_call_pool_retries", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_one_call_pool_layouts", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     ("vrs_pool_form_shape", c_int, [c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint64)]),
+    ("vrs_pool_form_shape_ex", c_int, [c_uint32, c_int, c_int, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint64)]),
+    ("vrs_context_trim_scratch", c_int, [c_void_p, POINTER(c_uint64)]),
+    ("vrs_one_call_pool_no_memory", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_debug_xcc_placement", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_int)]),
     ("vrs_debug_download_offsets", c_int, [c_void_p, c_void_p, c_size_t]),
     ("vrs_debug_atomic_rank_selftest", c_int, [c_void_p, c_uint32, c_uint32, POINTER(c_uint64)]),

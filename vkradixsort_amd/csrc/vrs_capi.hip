@@ -129,6 +129,9 @@ struct vrs_context_t {
     bool os_pool_reuse_rooms = true;      // ... and the buckets' slack regions with them (the plan kernel then samples nothing): VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 2 keeps the first pass's regions only
     bool os_pool_layout_valid = false;
     uint32_t os_pool_layout_n = 0, os_pool_layout_base = 0, os_pool_layout_sub_bits = 0;
+    uint32_t os_pool_stale_run = 0, os_pool_reuse_pause = 0;  // kept layouts found stale in a row / sorts left that sample for themselves although a layout is kept
+    uint32_t os_pool_fail_alloc = 0;       // VRS_TUNE_DEBUG_POOL_NO_MEMORY: allocations of the pool form's scratch left to fail (test hook)
+    uint64_t os_pool_no_memory = 0;        // pool sorts / finishes that found no room for the form's scratch and took another form
     uint64_t os_pool_layout_reuses = 0, os_pool_stale_layouts = 0;  // sorts that started in a kept layout / of those, sorts it did not fit (run again, sampled)
     bool os_cursors_open = false;        // a reserving pass may have run without the local sort that re-arms its counters behind it
                                          // (a refused plan, a partition with no finish, an error in between): cleared before the next use
@@ -593,11 +596,12 @@ int vrs_buffer_release(vrs_buffer buf) {
             // the raw pointers of its four buffers: freeing one of them first would hand that half freed memory.  Settle it, and
             // let what is on the stream finish with the buffer, before the memory goes.  (hipFree waits for the device, but a
             // second half enqueued AFTER it would not be waited for.)
-            bool alive;
-            {
-                std::lock_guard<std::mutex> lock(g_live_mutex);
-                alive = g_live_contexts.count(buf->ctx) != 0;
-            }
+            // The registry's lock is held from the look-up to the end of the settle: vrs_context_destroy takes it before it frees anything,
+            // so a context found alive here stays alive while its pending sort is settled (a destroy on another thread waits).  A context is
+            // otherwise one thread's at a time (include/vkradixsort_amd.h, "Threading"): releasing a buffer WHILE another thread sorts with
+            // its context is the caller's to serialise.
+            std::lock_guard<std::mutex> lock(g_live_mutex);
+            const bool alive = g_live_contexts.count(buf->ctx) != 0;
             if (alive && buf->ctx->one_read.active) {
                 const vrs_context_t::OneRead &st = buf->ctx->one_read;
                 const char *lo = static_cast<const char *>(buf->ptr), *hi = lo + buf->size;
@@ -1065,6 +1069,7 @@ static int one_read_hybrid_tail(vrs_context ctx, vrs_context_t::OneRead &st, con
 
 // ---- pool form (vrs_msd_pool.hip): the hybrid form of bare uint32 keys without the counting read: 24 bytes per key.
 static int one_read_enqueue_pool(vrs_context ctx, const struct OneReadGeometry &g);
+constexpr int kPoolNoMemory = -4242;  // (internal: pool_scratch found no room on the device; never leaves the library)
 
 
 static int one_read_enqueue(vrs_context ctx) {
@@ -1114,9 +1119,10 @@ static int one_read_enqueue(vrs_context ctx) {
         // misjudged a region, a key range the probe missed, a bucket above the local sort's capacity) costs the first pass, so
         // the default is adaptive: after one, the next 15 such sorts of the context take the counted form.
         // (sizes: a bucket must fit the local sort's larger shape -- uniform keys up to about 2.2e8 --, in every mode: beyond it a
-        // refusal is certain; and below 3.2e7 keys the counted form's one-wave-per-bucket local sort is the faster one)
+        // refusal is certain; pairs up to pool_max_pairs(), the last size whose fullest uniform bucket fits a pairs shape; from
+        // os_pool_min_keys on, 2^22 by default: round 5's one-wave local sort made the form the faster one from its own floor)
         const bool candidate = st.msd_capable && !wide && !st.no_pool && ctx->os_pool != 0 && n >= ctx->os_pool_min_keys && n <= vrs::kPoolMaxKeys &&
-                               (pairs ? ctx->os_pool_pairs != 0 && n <= 13000u * vrs::kMsdBucketCount : reserves(ctx, n, false));
+                               (pairs ? ctx->os_pool_pairs != 0 && n <= vrs::pool_max_pairs() : reserves(ctx, n, false));
         if (candidate && ctx->os_pool_skip && (n / 2u > ctx->os_pool_skip_n || n < ctx->os_pool_skip_n / 2u)) ctx->os_pool_skip = 0;
         st.pool = candidate && (ctx->os_pool == 2 || ctx->os_pool_skip == 0);
         if (candidate && !st.pool) --ctx->os_pool_skip;
@@ -1124,7 +1130,19 @@ static int one_read_enqueue(vrs_context ctx) {
     const OneReadGeometry g = one_read_geometry(ctx, st);
     int rc = one_read_scratch(ctx, st, g);
     if (rc) return rc;
-    if (msd && st.pool) return one_read_enqueue_pool(ctx, g);
+    if (msd && st.pool) {
+        rc = one_read_enqueue_pool(ctx, g);
+        if (rc != kPoolNoMemory) return rc;
+        // no room on the device for the form's scratch: nothing was enqueued -- the same sort in a form that needs none (and the next
+        // sorts of this size do not ask again at once: the adaptive skip, as after a refusal)
+        st.no_pool = true;
+        st.pool = false;
+        if (ctx->os_pool == 1) {
+            ctx->os_pool_skip = 15;
+            ctx->os_pool_skip_n = n;
+        }
+        return one_read_enqueue(ctx);
+    }
     vrs::LaunchEvents ev;
     // the digit tables must be all zero when a counting read starts; plan_kernel leaves them so.  Should anything fail
     // between the two launches, re-arm them for the next sort.
@@ -1198,15 +1216,47 @@ static int one_read_enqueue(vrs_context ctx) {
     return VRS_OK;
 }
 
-// the pool form's scratch: its plan (once), the first pass's overflow regions and the slack buffer (grown when a sort needs more)
+// the pool form's scratch: its plan (once), the first pass's overflow regions and the slack buffer (grown when a sort needs more).
+// kPoolNoMemory: the device has no room for it (about 1.5 n slots, twice that for pairs) -- not an error of the SORT: whatever was
+// allocated is released and the caller takes a form that needs no such scratch (the counted form, the LSD passes).
+static void pool_scratch_release(vrs_context ctx, bool payloads_only = false) {
+    const auto drop = [](uint32_t *&p, uint32_t &cap) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    };
+    drop(ctx->os_pool_overflow_vals, ctx->os_pool_vals_overflow_cap);
+    drop(ctx->os_pool_slack_vals, ctx->os_pool_vals_slack_cap);
+    if (payloads_only) return;
+    drop(ctx->os_pool_overflow, ctx->os_pool_overflow_cap);
+    drop(ctx->os_pool_slack, ctx->os_pool_slack_cap);
+    ctx->os_pool_layout_valid = false;  // (a kept layout speaks of slots of the buffers that just went)
+}
 static int pool_scratch(vrs_context ctx, uint32_t room, uint32_t slack, bool pairs = false) {
+    const auto alloc = [&](uint32_t *&p, uint32_t &cap, uint32_t slots) -> hipError_t {
+        if (ctx->os_pool_fail_alloc) {  // test hook (VRS_TUNE_DEBUG_POOL_NO_MEMORY): as if the device were full
+            --ctx->os_pool_fail_alloc;
+            return hipErrorOutOfMemory;
+        }
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), static_cast<size_t>(slots) * sizeof(uint32_t));
+        if (e == hipSuccess) cap = slots;
+        else p = nullptr;
+        return e;
+    };
+    const auto no_room = [&](hipError_t e, bool payloads_only) -> int {
+        (void)hipGetLastError();  // (the failed hipMalloc is no sticky error of the stream's work)
+        pool_scratch_release(ctx, payloads_only);
+        ctx->os_pool_no_memory++;
+        if (e == hipErrorOutOfMemory) return kPoolNoMemory;
+        return fail_hip(ctx, "pool form scratch allocation", e);
+    };
     if (!ctx->os_pool_plan) {
         vrs::PoolPlan *pp = nullptr;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&pp), sizeof(vrs::PoolPlan));
         if (e == hipSuccess) e = hipMemsetAsync(pp, 0, sizeof(vrs::PoolPlan), ctx->stream);  // sample counts, flags: zero between sorts
         if (e != hipSuccess) {
             if (pp) (void)hipFree(pp);
-            return fail_hip(ctx, "pool form scratch allocation", e);
+            return no_room(e, false);
         }
         ctx->os_pool_plan = pp;
     }
@@ -1215,33 +1265,21 @@ static int pool_scratch(vrs_context ctx, uint32_t room, uint32_t slack, bool pai
         slack = std::max(slack, ctx->os_pool_slack_cap);
         if (ctx->os_pool_overflow || ctx->os_pool_slack) {
             VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->os_pool_overflow) VRS_HIP(ctx, hipFree(ctx->os_pool_overflow));
-            if (ctx->os_pool_slack) VRS_HIP(ctx, hipFree(ctx->os_pool_slack));
-            ctx->os_pool_overflow = nullptr;
-            ctx->os_pool_slack = nullptr;
-            ctx->os_pool_overflow_cap = 0;
-            ctx->os_pool_slack_cap = 0;
+            pool_scratch_release(ctx);  // (the payloads' twins with them: they are made to the keys' sizes)
         }
-        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_overflow), static_cast<size_t>(room) * sizeof(uint32_t)));
-        ctx->os_pool_overflow_cap = room;
-        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_slack), static_cast<size_t>(slack) * sizeof(uint32_t)));
-        ctx->os_pool_slack_cap = slack;
+        hipError_t e = alloc(ctx->os_pool_overflow, ctx->os_pool_overflow_cap, room);
+        if (e == hipSuccess) e = alloc(ctx->os_pool_slack, ctx->os_pool_slack_cap, slack);
+        if (e != hipSuccess) return no_room(e, false);
     }
     if (pairs && (ctx->os_pool_vals_overflow_cap < ctx->os_pool_overflow_cap || ctx->os_pool_vals_slack_cap < ctx->os_pool_slack_cap)) {
         // the payloads' twins: the keys' sizes, so that one slot number serves both
         if (ctx->os_pool_overflow_vals || ctx->os_pool_slack_vals) {
             VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->os_pool_overflow_vals) VRS_HIP(ctx, hipFree(ctx->os_pool_overflow_vals));
-            if (ctx->os_pool_slack_vals) VRS_HIP(ctx, hipFree(ctx->os_pool_slack_vals));
-            ctx->os_pool_overflow_vals = nullptr;
-            ctx->os_pool_slack_vals = nullptr;
-            ctx->os_pool_vals_overflow_cap = 0;
-            ctx->os_pool_vals_slack_cap = 0;
+            pool_scratch_release(ctx, true);
         }
-        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_overflow_vals), static_cast<size_t>(ctx->os_pool_overflow_cap) * sizeof(uint32_t)));
-        ctx->os_pool_vals_overflow_cap = ctx->os_pool_overflow_cap;
-        VRS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->os_pool_slack_vals), static_cast<size_t>(ctx->os_pool_slack_cap) * sizeof(uint32_t)));
-        ctx->os_pool_vals_slack_cap = ctx->os_pool_slack_cap;
+        hipError_t e = alloc(ctx->os_pool_overflow_vals, ctx->os_pool_vals_overflow_cap, ctx->os_pool_overflow_cap);
+        if (e == hipSuccess) e = alloc(ctx->os_pool_slack_vals, ctx->os_pool_vals_slack_cap, ctx->os_pool_slack_cap);
+        if (e != hipSuccess) return no_room(e, true);
     }
     return VRS_OK;
 }
@@ -1252,10 +1290,9 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     const uint32_t n = st.n;
     int rc;
     const bool pairs = st.vptr[0] != nullptr;
-    vrs::PoolShape shape = pairs ? vrs::pool_shape_pairs(n) : vrs::pool_shape(n, ctx->os_pool_sub_bits);
-    // (lab: 7 + 7 bits -- the same 16384 buckets, cut 128 x 128; only where the usual cut is 256 x 64)
-    const uint32_t top_bits = (ctx->os_pool_top_bits != 8 && shape.sub_bits == 6u) ? static_cast<uint32_t>(ctx->os_pool_top_bits) : 8u, top_bytes = 1u << top_bits;
-    shape.sub_bits += 8u - top_bits;
+    const vrs::PoolCut cut = vrs::pool_cut(n, pairs, ctx->os_pool_top_bits, pairs ? 0 : ctx->os_pool_sub_bits);
+    const vrs::PoolShape shape{cut.sub_bits, cut.local};
+    const uint32_t top_bits = cut.top_bits, top_bytes = 1u << top_bits;
     st.pool_top_bits = top_bits;
     st.pool_sub_bits = shape.sub_bits;
     st.pool_local = shape.local;
@@ -1298,6 +1335,13 @@ static int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
     st.pool_par = par;
     st.pool_reused = ctx->os_pool_reuse && ctx->os_pool_layout_valid && ctx->os_pool_layout_n == n && ctx->os_pool_layout_base == st.key_base &&
                      (ctx->os_pool_layout_sub_bits >> 8) == top_bits;
+    // Back-off: a workload whose distribution changes from sort to sort at equal n (sorted, then random; alternating key ranges) finds
+    // every kept layout stale -- two passes, a host round trip and the whole sort again, each time.  After two stale layouts in a row the
+    // next 16 sorts that could have started in a kept layout sample for themselves; then one tries again.
+    if (st.pool_reused && ctx->os_pool_reuse_pause) {
+        --ctx->os_pool_reuse_pause;
+        st.pool_reused = false;
+    }
     if (!st.pool_reused) {
         if ((rc = profile_events(ctx, VRS_KERNEL_POOL_SAMPLE, &ev))) return rc;
         VRS_HIP(ctx, vrs::launch_pool_sample(ctx->stream, home, n, st.key_base, ps, ctx->os_pool_plan, room, par, ev, top_bits));
@@ -1357,6 +1401,7 @@ static int one_read_complete(vrs_context ctx, bool *done) {
                 ctx->os_pool_pair_sorts++;
                 ctx->os_status_clean = true;  // (the local sort cleared the look-back words behind the two passes)
             }
+            if (st.pool_reused) ctx->os_pool_stale_run = 0;  // (a kept layout fitted)
             ctx->os_pool_layout_valid = true;  // its regions held: the next sort of this size may start in them
             ctx->os_pool_layout_n = n;
             ctx->os_pool_layout_base = st.key_base;
@@ -1400,6 +1445,10 @@ static int one_read_complete(vrs_context ctx, bool *done) {
             // the KEPT layout did not fit these keys (another distribution, another key range): no verdict on the form -- the same
             // sort again, sampled this time
             ctx->os_pool_stale_layouts++;
+            if (++ctx->os_pool_stale_run >= 2u) {
+                ctx->os_pool_stale_run = 0;
+                ctx->os_pool_reuse_pause = 16;
+            }
             st.group = 0;
             st.cur = st.cur_at_start;
             return one_read_enqueue(ctx);
@@ -1824,7 +1873,7 @@ int vrs_msd_finish_grouped_split_u32(vrs_context ctx, vrs_buffer grouped, vrs_bu
     }
     if (tiles_b > vrs::kPoolMaxTilesB) return counted();
     const uint32_t slack = vrs::pool_slack_capacity(n, shape.sub_bits, top_bytes);
-    if ((rc = pool_scratch(ctx, std::max(ctx->os_pool_overflow_cap, 32u), slack))) return rc;
+    if ((rc = pool_scratch(ctx, std::max(ctx->os_pool_overflow_cap, 32u), slack))) return rc == kPoolNoMemory ? counted() : rc;  // (no room for the slack buffer: the counted finish needs none)
     ctx->sub_cache.valid = false;
     if (++ctx->os_stamp == 0) ctx->os_stamp = 1;
     ctx->os_msd_half_stamp = ctx->os_stamp;
@@ -2165,6 +2214,39 @@ int vrs_pool_form_shape(uint32_t n, uint32_t *sub_bits, uint32_t *bucket_capacit
     return VRS_OK;
 }
 
+int vrs_pool_form_shape_ex(uint32_t n, int pairs, int top_bits_setting, uint32_t *first_pass_bits, uint32_t *second_pass_bits, uint32_t *bucket_capacity,
+                           uint64_t *scratch_bytes) {
+    if (top_bits_setting == 0) top_bits_setting = 7;  // the library's default cut (vrs_context_t::os_pool_top_bits)
+    if (top_bits_setting < 6 || top_bits_setting > 8) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "top_bits: 0 (the default), 6, 7 or 8");
+    const bool takes = n >= (1u << 22) && (pairs ? n <= vrs::pool_max_pairs() : n <= vrs::kPoolMaxKeys);
+    const vrs::PoolCut cut = takes ? vrs::pool_cut(n, pairs != 0, top_bits_setting, 0) : vrs::PoolCut{0u, 0u, 0u};
+    if (first_pass_bits) *first_pass_bits = cut.top_bits;
+    if (second_pass_bits) *second_pass_bits = cut.sub_bits;
+    if (bucket_capacity) *bucket_capacity = takes ? vrs::pool_local_capacity(cut.local) : 0u;
+    if (scratch_bytes) {
+        const uint64_t slots = takes ? static_cast<uint64_t>(vrs::pool_slack_capacity(n, cut.sub_bits, 1u << cut.top_bits)) + vrs::pool_overflow_capacity(n) : 0u;
+        *scratch_bytes = takes ? slots * sizeof(uint32_t) * (pairs ? 2u : 1u) + sizeof(vrs::PoolPlan) : 0u;  // (pairs: the payloads' twins of both buffers)
+    }
+    return VRS_OK;
+}
+
+int vrs_context_trim_scratch(vrs_context ctx, uint64_t *released_bytes) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    VRS_HIP(ctx, hipSetDevice(ctx->device));
+    if (const int rc = settle_pending(ctx)) return rc;
+    VRS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (a sort on the stream may still read the buffers)
+    const uint64_t bytes = (static_cast<uint64_t>(ctx->os_pool_overflow_cap) + ctx->os_pool_slack_cap + ctx->os_pool_vals_overflow_cap + ctx->os_pool_vals_slack_cap) * sizeof(uint32_t);
+    pool_scratch_release(ctx);
+    if (released_bytes) *released_bytes = bytes;
+    return VRS_OK;
+}
+
+int vrs_one_call_pool_no_memory(vrs_context ctx, uint64_t *sorts) {
+    if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
+    if (sorts) *sorts = ctx->os_pool_no_memory;
+    return VRS_OK;
+}
+
 int vrs_one_call_pool_retries(vrs_context ctx, uint64_t *retries) {
     if (!ctx) return fail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "context is NULL");
     if (retries) *retries = ctx->os_pool_retries;
@@ -2278,17 +2360,22 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             return VRS_OK;
         }
         case VRS_TUNE_MSD_POOL_TOP_BITS:
-            if (value < 6 || value > 8) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form's first pass sorts by 8 bits (lab: 7)");
+            if (value < 6 || value > 8) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form's first pass sorts by 6, 7 (the default) or 8 bits");
             ctx->os_pool_top_bits = value;
             ctx->os_pool_layout_valid = false;
             return VRS_OK;
         case VRS_TUNE_MSD_POOL_PAIRS:
             ctx->os_pool_pairs = value != 0 ? 1 : 0;
             return VRS_OK;
+        case VRS_TUNE_DEBUG_POOL_NO_MEMORY:
+            if (value < 0) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "allocations left to fail: 0 or more");
+            ctx->os_pool_fail_alloc = static_cast<uint32_t>(value);
+            return VRS_OK;
         case VRS_TUNE_MSD_POOL_REUSE_LAYOUT:
             ctx->os_pool_reuse = value != 0;
             ctx->os_pool_reuse_rooms = value == 1;
             ctx->os_pool_layout_valid = false;
+            ctx->os_pool_stale_run = ctx->os_pool_reuse_pause = 0;
             return VRS_OK;
         case VRS_TUNE_MSD_POOL_SUB_BITS:
             if (value != 0 && (value < 6 || value > 8)) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form's second pass sorts by 6, 7 or 8 bits (0 = by size)");

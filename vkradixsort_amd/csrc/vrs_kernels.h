@@ -324,6 +324,12 @@ struct PoolShape {
 };
 PoolShape pool_shape(uint32_t n, int forced_sub_bits = 0);  // forced_sub_bits: 0 = by size, 6, 7 or 8
 PoolShape pool_shape_pairs(uint32_t n);
+struct PoolCut {
+    uint32_t top_bits, sub_bits;  // bits of the first and of the second pass
+    uint32_t local;               // PoolShape::local
+};
+PoolCut pool_cut(uint32_t n, bool pairs, int top_bits_setting, int forced_sub_bits);  // what one_read_enqueue_pool runs (host only)
+uint32_t pool_max_pairs();  // the most pairs whose fullest uniform bucket fits the shape pool_shape_pairs gives them
 // Key + payload pairs (the STABLE pool form: a tile's place in a region is its rank there, by decoupled look-back): the payloads'
 // twins of the keys' buffers and the look-back's status words (the one-call sort's; `status_words` of them, all cleared by the local
 // sort of a sort that is taken).  By value: a kernel argument.

@@ -1186,6 +1186,36 @@ PoolShape pool_shape_pairs(uint32_t n) {
     return PoolShape{6u, 5u};
 }
 
+PoolCut pool_cut(uint32_t n, bool pairs, int top_bits_setting, int forced_sub_bits) {
+    // the shape by size in the 8 + S naming (256 << S buckets), then the cut of those bits between the passes: the setting (default 7 + 7)
+    // only where the usual cut would be 8 + 6 -- sorts whose second pass takes 7 or 8 bits of 256 top bytes keep that cut
+    PoolShape shape = pairs ? pool_shape_pairs(n) : pool_shape(n, forced_sub_bits);
+    PoolCut cut{};
+    cut.top_bits = (top_bits_setting != 8 && shape.sub_bits == 6u) ? static_cast<uint32_t>(top_bits_setting) : 8u;
+    cut.sub_bits = shape.sub_bits + 8u - cut.top_bits;
+    cut.local = shape.local;
+    return cut;
+}
+
+uint32_t pool_max_pairs() {
+    // the largest n whose fullest uniform bucket (pool_shape_pairs' rule) fits the shape that function returns: beyond it the second pass
+    // flags every sort and no larger pairs shape exists -- such sorts must not be candidates at all (found by bisection, once)
+    static const uint32_t limit = [] {
+        const auto fits = [](uint32_t n) {
+            const PoolShape sh = pool_shape_pairs(n);
+            const double mean = static_cast<double>(n) / (256u << sh.sub_bits);
+            return static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u <= pool_local_capacity(sh.local);
+        };
+        uint32_t lo = 1u << 22, hi = 300000000u;  // fits(lo), !fits(hi)
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            (fits(mid) ? lo : hi) = mid;
+        }
+        return lo;
+    }();
+    return limit;
+}
+
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
                               PoolPlan *pool, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev, uint32_t top_bits) {
     if (n == 0 || ps.tiles_per_stream < kPoolSampleTiles) return hipErrorInvalidValue;  // (a sample workgroup's tiles span at most two slices)
