@@ -395,6 +395,9 @@ int vrs_dist_grouped_rounds(vrs_dist dist, uint64_t *grouped_rounds);
 int vrs_dist_splitter_steps(vrs_dist dist, uint64_t *splitter_steps);
 typedef struct vrs_dist_loopback_t *vrs_dist_loopback;
 int vrs_dist_loopback_create(int world, vrs_dist_loopback *out_hub);
+/* the same hub over HOST memory (buffers are host pointers, transfers memcpy, streams ignored, no HIP call): the hub's matching and
+ * barriers on a machine without a GPU -- test infrastructure of the sanitizer builds, not a transport for vrs_dist_create_with_transport */
+int vrs_dist_loopback_create_host(int world, vrs_dist_loopback *out_hub);
 /* fills *out with rank `rank`'s end of the hub; call it on the thread that drives the rank, its device current */
 int vrs_dist_loopback_transport(vrs_dist_loopback hub, int rank, vrs_dist_transport *out);
 int vrs_dist_loopback_destroy(vrs_dist_loopback hub);

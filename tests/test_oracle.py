@@ -46,6 +46,43 @@ def test_oracle_reproduces_golden(oracle, path):
     assert oracle.test_sort(g["sorted"], cur) == -1
 
 
+@pytest.mark.parametrize("subgroup_size", [32, 64])
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: p.stem)
+def test_two_independent_restatements_agree_on_every_stage_table(oracle, path, subgroup_size):
+    """The stage-level fixtures (histogram table, per-workgroup offset table, every pass's output) are pinned by TWO restatements of the
+    reference's shaders that share no code: oracle/vrs_oracle.c (the net effect: counters and running offsets, in C) and
+    tests/golden/glsl_emulation.py (the shader text invocation by invocation: LDS atomicAdd, the bin_flags bit masks and bitCount,
+    subgroupAdd / subgroupExclusiveAdd / subgroupElect / subgroupBroadcast with SUBGROUP_SIZE 32 and 64).  The reference itself ships no
+    vectors and cannot be built here; two restatements agreeing table for table is what can be had."""
+    from tests.golden import glsl_emulation as glsl
+    g = np.load(path)
+    n, B, seed, tbz, W = (int(x) for x in g["meta"])
+    assert glsl.workgroup_count(n, B) == W == oracle.workgroup_count(n, B)
+    cur = g["keys"]
+    for i, (hist, offsets, out) in enumerate(glsl.multi_radixsort(g["keys"], B, subgroup_size)):
+        hist, offsets = hist.ravel(), offsets.ravel()  # (the fixtures and the oracle keep the [W][256] tables flat)
+        assert np.array_equal(hist, g[f"hist{i}"]) and np.array_equal(hist, oracle.histograms(cur, 8 * i, W, B))
+        assert np.array_equal(offsets, g[f"offsets{i}"]) and np.array_equal(offsets, oracle.offsets(hist, W))
+        assert np.array_equal(out, g[f"pass{i}"]) and np.array_equal(out, oracle.scatter(cur, hist, 8 * i, W, B))
+        cur = out
+    assert np.array_equal(cur, g["sorted"])
+
+
+@pytest.mark.parametrize("n,B", [(1, 1), (255, 1), (256, 1), (257, 2), (513, 1), (3000, 5)])
+def test_the_literal_emulation_on_ragged_sizes_and_ties(oracle, n, B):
+    """edge sizes the fixtures do not hold, and keys with many ties (a digit that fills whole rounds: the offset advances by the count)"""
+    from tests.golden import glsl_emulation as glsl
+    keys = np.random.RandomState(n * 7 + B).randint(0, 2 ** 32, size=n, dtype=np.uint32) & np.uint32(0x0F0F00FF)
+    W = oracle.workgroup_count(n, B)
+    cur = keys
+    for i, (hist, offsets, out) in enumerate(glsl.multi_radixsort(keys, B, 64 if n % 2 else 32)):
+        hist, offsets = hist.ravel(), offsets.ravel()
+        assert np.array_equal(hist, oracle.histograms(cur, 8 * i, W, B)) and np.array_equal(offsets, oracle.offsets(hist, W))
+        assert np.array_equal(out, oracle.scatter(cur, hist, 8 * i, W, B))
+        cur = out
+    assert np.array_equal(cur, np.sort(keys))
+
+
 @pytest.mark.parametrize("n,B", [(0, 1), (1, 1), (255, 1), (256, 1), (257, 1), (1000, 32), (1000, 1), (65536, 4),
                                  (100003, 7), (8192, 32), (8193, 32), (50000, 4096)])
 def test_oracle_equals_std_sort(oracle, n, B):

@@ -108,3 +108,130 @@ def build_host_logic_test(force: bool = False) -> Path:
         _run([cxx, "-O2", "-std=c++20", f"-I{HOST / 'include'}", f"-I{INCLUDE}", src, "-o", exe, f"-L{PKG_DIR}",
               "-lvkradixsort_host", "-lvkradixsort_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
     return exe
+
+
+# ---------------------------------------------------------------------------------------------
+# Sanitizer builds (the reference runs with Vulkan validation layers whenever NDEBUG is not defined,
+# engine/include/engine/core/GPUContext.h:84-90 -- here: the host code of the library, the C++ host mirror, the host-only entry points
+# and the oracle under AddressSanitizer + UndefinedBehaviorSanitizer, the loopback hub's thread rendezvous under ThreadSanitizer).
+# Everything is compiled by ONE compiler (ROCm's clang, which hipcc is) so that one sanitizer runtime serves the process; device code is
+# left as it is (-fno-gpu-sanitize).  Output: vkradixsort_amd/_build/san_<kind>/.
+SAN_FLAGS = {
+    "asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"],
+    "tsan": ["-fsanitize=thread", "-fno-omit-frame-pointer", "-g", "-O1"],
+}
+
+
+def _clangxx() -> str:
+    for cand in (os.environ.get("VRS_CLANGXX"), "/opt/rocm/lib/llvm/bin/clang++", shutil.which("amdclang++"), shutil.which("clang++")):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("clang++ not found (the sanitizer builds use ROCm's clang for host and device code alike)")
+
+
+def san_dir(kind: str) -> Path:
+    d = PKG_DIR / "_build" / f"san_{kind}"
+    d.mkdir(parents=True, exist_ok=True)
+    return d
+
+
+def build_sanitized(kind: str = "asan", force: bool = False) -> dict:
+    """The library, the C++ host mirror + host_logic_test, capi_host_sanity and (asan only) the oracle's self-test, instrumented.
+    Returns {name: path} of the executables to run (their rpath finds the instrumented libraries and the sanitizer runtime)."""
+    from concurrent.futures import ThreadPoolExecutor
+    flags = SAN_FLAGS[kind]
+    out = san_dir(kind)
+    lib = out / "libvkradixsort_amd.so"
+    objs = [out / (src.stem + ".o") for src in HIP_SOURCES]
+    stale = [(src, obj) for src, obj in zip(HIP_SOURCES, objs) if force or _stale(obj, [src] + HIP_HEADERS)]
+    with ThreadPoolExecutor(max_workers=max(len(stale), 1)) as pool:
+        list(pool.map(lambda so: _run([_hipcc(), f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-fno-gpu-sanitize", "-shared-libsan", *flags, "-c",
+                                       f"-I{INCLUDE}", f"-I{CSRC}", so[0], "-o", so[1]]), stale))
+    if stale or force or _stale(lib, objs):
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-fPIC", "-shared", "-fno-gpu-sanitize", "-shared-libsan", *flags, *objs, "-ldl", "-o", lib])
+    cxx = _clangxx()
+    rt_dir = subprocess.run([cxx, "-print-runtime-dir"], capture_output=True, text=True).stdout.strip()
+    rt_alt = str(Path(rt_dir).parent / "linux")  # (where ROCm's clang keeps libclang_rt.*-x86_64.so)
+    common = ["-std=c++20", "-fPIC", "-pthread", "-shared-libsan", *flags, f"-I{HOST / 'include'}", f"-I{INCLUDE}"]
+    link = [f"-L{out}", "-lvkradixsort_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", f"-Wl,-rpath,{rt_dir}", f"-Wl,-rpath,{rt_alt}"]
+    hdrs = list((HOST / "include").rglob("*.h")) + [INCLUDE / "vkradixsort_amd.h"]
+    exes = {}
+    # (the host mirror's sources go INTO the test executable: as a second instrumented shared library its globals were registered twice by
+    #  the runtime -- reported as a violation of the one-definition rule although nothing is defined twice)
+    # (-asan-globals=0 for the host mirror only: its class templates are instantiated for uint32 and uint64 keys, every string literal inside them is
+    #  emitted per instantiation, the linker folds the identical copies, and the runtime then finds two instrumented globals at one -- misaligned --
+    #  address and aborts with "odr-violation" before main; heap, stack and use-after-free checks are unaffected)
+    no_globals = ["-mllvm", "-asan-globals=0"] if kind == "asan" else []
+    for name, srcs, extra in (("host_logic_test", [HOST / "test" / "host_logic_test.cpp", *host_sources()], no_globals),
+                              ("capi_host_sanity", [HOST / "test" / "capi_host_sanity.cpp"], [])):
+        exe = out / name
+        if force or _stale(exe, [*srcs, lib] + hdrs):
+            _run([cxx, *common, *srcs, "-o", exe, *extra, *link])
+        exes[name] = exe
+    if kind == "asan":
+        oracle = REPO_ROOT / "oracle"
+        exe = out / "oracle_selftest"
+        srcs = [oracle / "oracle_selftest.cpp", oracle / "vrs_stdsort.cpp", oracle / "vrs_oracle.c"]
+        if force or _stale(exe, srcs):
+            obj = out / "vrs_oracle_c.o"
+            _run([str(Path(cxx).parent / "clang"), "-std=c11", "-fPIC", *flags, "-c", srcs[2], "-o", obj])
+            _run([cxx, "-std=c++17", "-pthread", "-shared-libsan", *flags, srcs[0], srcs[1], obj, "-o", exe, f"-Wl,-rpath,{rt_dir}", f"-Wl,-rpath,{rt_alt}"])
+        exes["oracle_selftest"] = exe
+    return exes
+
+
+def sanitizer_env(kind: str) -> dict:
+    """The environment the instrumented executables (and a python that preloads the runtime) run in."""
+    env = dict(os.environ)
+    if kind == "asan":
+        # (leaks: the HIP runtime keeps what it allocates until exit; the link order check: python itself is not instrumented)
+        env["ASAN_OPTIONS"] = "detect_leaks=0:verify_asan_link_order=0:abort_on_error=0:halt_on_error=1"
+        env["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
+    else:
+        env["TSAN_OPTIONS"] = "halt_on_error=1:second_deadlock_stack=1"
+    return env
+
+
+def sanitizer_runtime(kind: str) -> Path:
+    """The shared sanitizer runtime to LD_PRELOAD into an uninstrumented host (python + ctypes loading the instrumented library)."""
+    cxx = _clangxx()
+    rt_dir = Path(subprocess.run([cxx, "-print-runtime-dir"], capture_output=True, text=True).stdout.strip())
+    name = f"libclang_rt.{kind}-x86_64.so" if kind != "asan" else "libclang_rt.asan-x86_64.so"
+    for d in (rt_dir, rt_dir.parent / "linux"):
+        if (d / name).exists():
+            return d / name
+    raise RuntimeError(f"{name} not found under {rt_dir}")
+
+
+def run_sanitized(kind: str = "asan", force: bool = False) -> int:
+    """Builds and runs every instrumented executable; returns the number that failed (their output is printed)."""
+    failed = 0
+    exes = build_sanitized(kind, force)
+    runs = [(name, [str(exe)]) for name, exe in exes.items()]
+    if kind == "tsan":
+        runs = [("capi_host_sanity hub", [str(exes["capi_host_sanity"]), "hub"])]
+    for name, cmd in runs:
+        proc = subprocess.run(cmd, capture_output=True, text=True, env=sanitizer_env(kind), cwd=str(REPO_ROOT))
+        bad = proc.returncode != 0 or any(t in proc.stdout + proc.stderr for t in ("ERROR: AddressSanitizer", "runtime error:", "WARNING: ThreadSanitizer"))
+        print(f"[{kind}] {name}: {'FAILED' if bad else 'clean'} (exit {proc.returncode})")
+        if bad:
+            failed += 1
+            print(proc.stdout[-4000:], proc.stderr[-8000:])
+    return failed
+
+
+if __name__ == "__main__":
+    import argparse
+    import sys
+    ap = argparse.ArgumentParser(description="in-tree builds of vkradixsort_amd")
+    ap.add_argument("--asan", action="store_true", help="build and run the AddressSanitizer + UndefinedBehaviorSanitizer targets")
+    ap.add_argument("--tsan", action="store_true", help="build and run the ThreadSanitizer target (the loopback hub's rendezvous)")
+    ap.add_argument("--force", action="store_true")
+    args = ap.parse_args()
+    if not (args.asan or args.tsan):
+        build_library(args.force)
+        build_host(args.force)
+        build_host_logic_test(args.force)
+        sys.exit(0)
+    bad = (run_sanitized("asan", args.force) if args.asan else 0) + (run_sanitized("tsan", args.force) if args.tsan else 0)
+    sys.exit(1 if bad else 0)

@@ -10,7 +10,11 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_int, c_size
                     c_void_p)
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libvkradixsort_amd.so"
+import os as _os
+
+# VRS_LIB: another build of the SAME library (the sanitizer builds: vkradixsort_amd/_build/san_asan/libvkradixsort_amd.so under a preloaded
+# runtime, tools/asan_fuzz.sh) -- never another implementation: there is none
+LIB_PATH = Path(_os.environ["VRS_LIB"]).resolve() if _os.environ.get("VRS_LIB") else Path(__file__).resolve().parent / "libvkradixsort_amd.so"
 
 VRS_OK = 0
 VRS_ERROR_INVALID_ARGUMENT = 1
@@ -148,6 +152,7 @@ _SIGNATURES = [
     ("vrs_dist_grouped_rounds", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_dist_splitter_steps", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_dist_loopback_create", c_int, [c_int, POINTER(c_void_p)]),
+    ("vrs_dist_loopback_create_host", c_int, [c_int, POINTER(c_void_p)]),
     ("vrs_dist_loopback_transport", c_int, [c_void_p, c_int, c_void_p]),
     ("vrs_dist_loopback_destroy", c_int, [c_void_p]),
     ("vrs_msd_partition_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),

@@ -243,6 +243,8 @@ struct vrs_dist_loopback_t {
     int arrived = 0;
     uint64_t generation = 0;
     bool broken = false;  // a rank failed inside a collective: everyone leaves with an error instead of waiting
+    bool host_memory = false;  // vrs_dist_loopback_create_host: the buffers are HOST memory, every transfer a memcpy at the rendezvous, no HIP call
+                               // anywhere (the hub's matching and barriers run without a device: the sanitizer builds' CPU tests)
     std::vector<LoopEndpoint> ends;
     // what the ranks publish for the collective in flight
     std::vector<const void *> src;
@@ -274,15 +276,26 @@ int loop_break(vrs_dist_loopback_t *h, int code) {
     return code;
 }
 constexpr int kLoopErrHip = 1, kLoopErrPeer = 2, kLoopErrUsage = 3;
+// the hub's three device operations; in host-memory mode the barriers alone order the ranks (a copy is done when memcpy returns)
+bool loop_record(vrs_dist_loopback_t *h, hipEvent_t ev, hipStream_t st) { return h->host_memory || hipEventRecord(ev, st) == hipSuccess; }
+bool loop_wait(vrs_dist_loopback_t *h, hipStream_t st, hipEvent_t ev) { return h->host_memory || hipStreamWaitEvent(st, ev, 0) == hipSuccess; }
+bool loop_copy(vrs_dist_loopback_t *h, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st, bool sync) {
+    if (h->host_memory) {
+        std::memcpy(dst, src, bytes);
+        return true;
+    }
+    if (hipMemcpyAsync(dst, src, bytes, kind, st) != hipSuccess) return false;
+    return !sync || hipStreamSynchronize(st) == hipSuccess;
+}
 
 // after the copies of a collective: every rank waits (on its stream) until all ranks' copies have run, so that whatever it
 // enqueues next may overwrite the buffers it offered
 int loop_release(LoopEndpoint *e, hipStream_t st) {
     vrs_dist_loopback_t *h = e->hub;
-    if (hipEventRecord(h->done[e->rank], st) != hipSuccess) return loop_break(h, kLoopErrHip);
+    if (!loop_record(h, h->done[e->rank], st)) return loop_break(h, kLoopErrHip);
     if (!loop_barrier(h)) return kLoopErrPeer;
     for (int s = 0; s < h->world; ++s)
-        if (s != e->rank && hipStreamWaitEvent(st, h->done[s], 0) != hipSuccess) return loop_break(h, kLoopErrHip);
+        if (s != e->rank && !loop_wait(h, st, h->done[s])) return loop_break(h, kLoopErrHip);
     if (!loop_barrier(h)) return kLoopErrPeer;  // nobody re-records its events before everybody has waited on them
     return 0;
 }
@@ -293,29 +306,27 @@ int loop_gather_like(void *u, const void *send, void *recv, size_t words, void *
     hipStream_t st = static_cast<hipStream_t>(stream);
     h->src[e->rank] = send;
     h->words[e->rank] = words;
-    if (hipEventRecord(h->ready[e->rank], st) != hipSuccess) return loop_break(h, kLoopErrHip);
+    if (!loop_record(h, h->ready[e->rank], st)) return loop_break(h, kLoopErrHip);
     if (!loop_barrier(h)) return kLoopErrPeer;
     for (int s = 0; s < h->world; ++s)
         if (h->words[s] != words) return loop_break(h, kLoopErrUsage);
     if (!reduce) {
         for (int s = 0; s < h->world; ++s) {
-            if (s != e->rank && hipStreamWaitEvent(st, h->ready[s], 0) != hipSuccess) return loop_break(h, kLoopErrHip);
-            if (hipMemcpyAsync(static_cast<uint32_t *>(recv) + static_cast<size_t>(s) * words, h->src[s], words * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            if (s != e->rank && !loop_wait(h, st, h->ready[s])) return loop_break(h, kLoopErrHip);
+            if (!loop_copy(h, static_cast<uint32_t *>(recv) + static_cast<size_t>(s) * words, h->src[s], words * 4, hipMemcpyDeviceToDevice, st, false))
                 return loop_break(h, kLoopErrHip);
         }
     } else {
         // sum of the ranks' buffers through the host (a few KB: this transport is not the fast path of anything)
         std::vector<uint32_t> acc(words, 0), tmp(words);
         for (int s = 0; s < h->world; ++s) {
-            if (s != e->rank && hipStreamWaitEvent(st, h->ready[s], 0) != hipSuccess) return loop_break(h, kLoopErrHip);
-            if (hipMemcpyAsync(tmp.data(), h->src[s], words * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-                return loop_break(h, kLoopErrHip);
+            if (s != e->rank && !loop_wait(h, st, h->ready[s])) return loop_break(h, kLoopErrHip);
+            if (!loop_copy(h, tmp.data(), h->src[s], words * 4, hipMemcpyDeviceToHost, st, true)) return loop_break(h, kLoopErrHip);
             for (size_t i = 0; i < words; ++i) acc[i] += tmp[i];
         }
         // every rank has read every offer before anyone's result may land in a buffer that is also an offer (in-place use)
         if (!loop_barrier(h)) return kLoopErrPeer;
-        if (hipMemcpyAsync(recv, acc.data(), words * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-            return loop_break(h, kLoopErrHip);
+        if (!loop_copy(h, recv, acc.data(), words * 4, hipMemcpyHostToDevice, st, true)) return loop_break(h, kLoopErrHip);
     }
     return loop_release(e, st);
 }
@@ -351,8 +362,9 @@ int loop_group_end(void *u) {
     if (!e->grouping) return loop_break(h, kLoopErrUsage);
     e->grouping = false;
     hipStream_t st = e->group_stream;  // nullptr: this rank has nothing to move in this group (it still takes part)
+    if (h->host_memory && (!e->sends.empty() || !e->recvs.empty())) st = reinterpret_cast<hipStream_t>(h);  // (host memory: any non-null token; never handed to HIP)
     h->sends[e->rank] = e->sends;
-    if (st && hipEventRecord(h->ready[e->rank], st) != hipSuccess) return loop_break(h, kLoopErrHip);
+    if (st && !loop_record(h, h->ready[e->rank], st)) return loop_break(h, kLoopErrHip);
     // a rank without operations records nothing: nobody will wait on its event, because nobody receives from it
     if (!loop_barrier(h)) return kLoopErrPeer;
     std::vector<size_t> next(static_cast<size_t>(h->world), 0);
@@ -361,19 +373,18 @@ int loop_group_end(void *u) {
         size_t &k = next[static_cast<size_t>(r.peer)];
         while (k < theirs.size() && theirs[k].peer != e->rank) ++k;
         if (k == theirs.size() || theirs[k].words != r.words) return loop_break(h, kLoopErrUsage);  // unmatched receive
-        if (hipStreamWaitEvent(st, h->ready[r.peer], 0) != hipSuccess ||
-            hipMemcpyAsync(r.dst, theirs[k].src, r.words * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        if (!loop_wait(h, st, h->ready[r.peer]) || !loop_copy(h, r.dst, theirs[k].src, r.words * 4, hipMemcpyDeviceToDevice, st, false))
             return loop_break(h, kLoopErrHip);
         ++k;
     }
     // release: senders may reuse what they offered once the receivers' copies have run
     if (st) {
-        if (hipEventRecord(h->done[e->rank], st) != hipSuccess) return loop_break(h, kLoopErrHip);
+        if (!loop_record(h, h->done[e->rank], st)) return loop_break(h, kLoopErrHip);
     }
     if (!loop_barrier(h)) return kLoopErrPeer;
     if (st)
         for (const LoopOp &s : e->sends)
-            if (hipStreamWaitEvent(st, h->done[s.peer], 0) != hipSuccess) return loop_break(h, kLoopErrHip);
+            if (!loop_wait(h, st, h->done[s.peer])) return loop_break(h, kLoopErrHip);
     if (!loop_barrier(h)) return kLoopErrPeer;
     return 0;
 }
@@ -410,12 +421,21 @@ int vrs_dist_loopback_create(int world, vrs_dist_loopback *out) {
     return VRS_OK;
 }
 
+// The same hub over HOST memory: send / recv / gather buffers are host pointers, every transfer a memcpy made at the rendezvous, the
+// `hip_stream` arguments ignored -- no HIP call anywhere, so the hub's matching, barriers and failure paths run (and can be put under
+// ThreadSanitizer) on a machine without a GPU.  Not a transport for vrs_dist_create_with_transport (its buffers are device memory).
+int vrs_dist_loopback_create_host(int world, vrs_dist_loopback *out) {
+    const int rc = vrs_dist_loopback_create(world, out);
+    if (rc == VRS_OK) (*out)->host_memory = true;
+    return rc;
+}
+
 // Fills `out` with rank `rank`'s end of the hub.  Call on the thread (and with the device current) that will drive this rank:
 // the rank's events are made here.
 int vrs_dist_loopback_transport(vrs_dist_loopback hub, int rank, vrs_dist_transport *out) {
     if (!hub || !out || rank < 0 || rank >= hub->world) return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "hub, out or rank invalid");
     const size_t r = static_cast<size_t>(rank);
-    if (!hub->ready[r] && (hipEventCreateWithFlags(&hub->ready[r], hipEventDisableTiming) != hipSuccess ||
+    if (!hub->host_memory && !hub->ready[r] && (hipEventCreateWithFlags(&hub->ready[r], hipEventDisableTiming) != hipSuccess ||
                            hipEventCreateWithFlags(&hub->done[r], hipEventDisableTiming) != hipSuccess))
         return dfail(nullptr, VRS_ERROR_HIP, "hipEventCreate failed");
     out->user = &hub->ends[r];
