@@ -453,6 +453,29 @@ int vrs_one_call_hybrid_sorts(vrs_context ctx, uint64_t *hybrid_sorts);
  * as LSD sorts with a second counting read.  Cumulative; diagnostics only. */
 int vrs_one_call_hybrid_recounts(vrs_context ctx, uint64_t *recounts);
 
+/* WHICH FORM a one-call sort takes (host only, no device needed): the dispatcher's own decision function, so that its table --
+ * form x size x kind x settings x what an earlier refusal left behind -- can be walked by a test.  key_bytes 4 or 8, pairs != 0 = with
+ * uint32 payloads; knobs[VRS_FORM_KNOB_*] for knob_count entries, a negative entry (or one beyond knob_count) = what a fresh context on
+ * a device whose probes passed holds; *form = VRS_FORM_*; memory_out (may be NULL): [0] = the adaptive pool skip, [1] = the 64-bit
+ * keys' skip counter as the decision leaves them. */
+typedef enum vrs_sort_form {
+    VRS_FORM_NONE = 0,     /* nothing to sort */
+    VRS_FORM_SINGLE = 1,   /* one single_radixsort launch */
+    VRS_FORM_CONTRACT = 2, /* the reference's two stages, pass by pass */
+    VRS_FORM_LSD = 3,      /* one counting read + a look-back scatter pass per key byte */
+    VRS_FORM_COUNTED = 4,  /* the counted hybrid form */
+    VRS_FORM_POOL = 5      /* the pool form (pairs: its stable variant) */
+} vrs_sort_form;
+typedef enum vrs_form_knob {
+    VRS_FORM_KNOB_SINGLE_MAX_KEYS = 0, VRS_FORM_KNOB_ONE_CALL_MIN_KEYS = 1, VRS_FORM_KNOB_HYBRID_MIN_KEYS = 2, VRS_FORM_KNOB_POOL_MIN_KEYS = 3,
+    VRS_FORM_KNOB_HYBRID = 4, VRS_FORM_KNOB_POOL = 5, VRS_FORM_KNOB_POOL_PAIRS = 6, VRS_FORM_KNOB_RESERVE = 7, VRS_FORM_KNOB_GROUPS = 8,
+    VRS_FORM_KNOB_XCC_MAP_VALID = 9, VRS_FORM_KNOB_ATOMIC_RANK = 10,           /* what the context found out about the device */
+    VRS_FORM_KNOB_POOL_SKIP = 11, VRS_FORM_KNOB_POOL_SKIP_N = 12, VRS_FORM_KNOB_WIDE_REFUSED = 13, VRS_FORM_KNOB_WIDE_SKIPPED = 14, /* memory */
+    VRS_FORM_KNOB_NO_POOL = 15, VRS_FORM_KNOB_NO_HYBRID = 16,                   /* this sort is a retry after a refusal of that form */
+    VRS_FORM_KNOB_COUNT = 17
+} vrs_form_knob;
+int vrs_sort_form_for(uint32_t num_elements, int key_bytes, int pairs, const int64_t *knobs, int knob_count, int *form, int64_t *memory_out);
+
 /* One-call sorts of bare uint32 keys that took the pool form (the hybrid form without a counting read, VRS_TUNE_MSD_POOL), and
  * sorts whose pool form the plan refused (they ran in the counted form afterwards).  Cumulative; diagnostics only. */
 int vrs_one_call_pool_sorts(vrs_context ctx, uint64_t *pool_sorts, uint64_t *pool_refusals);

@@ -1,6 +1,6 @@
 // oracle_selftest.cpp -- the CPU oracle (oracle/vrs_oracle.c, vrs_stdsort.cpp: TEST INFRASTRUCTURE, never linked into the product) under
 // AddressSanitizer + UndefinedBehaviorSanitizer: every entry point on ragged, empty and tile-edge sizes, against std::sort / std::stable_sort.
-// Built and run by `python -m vkradixsort_amd.build --asan` (tests/test_sanitizers_cpu.py); a checker with an out-of-bounds read would
+// Built by `make -C oracle selftest-asan`, run by tests/test_sanitizers_cpu.py; a checker with an out-of-bounds read would
 // pin nothing.
 #include <algorithm>
 #include <cstdint>

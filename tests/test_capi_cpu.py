@@ -308,3 +308,71 @@ def test_pool_form_shape_ex_reports_the_cut_that_runs(lib):
         lo, hi = (mid, hi) if ex(mid, pairs=1)[0] else (lo, mid)
     assert 2.0e8 < lo < 2.13e8 and ex(lo, pairs=1)[2] == 13312
     assert lib.vrs_pool_form_shape_ex(10 ** 8, 0, 5, None, None, None, None) != 0
+
+
+def _form(lib, n, key_bytes=4, pairs=0, **knobs):
+    """vrs_sort_form_for with named knobs (capi.FORM_KNOBS); returns (form name, [pool skip, wide skipped] afterwards)"""
+    arr = (ctypes.c_int64 * len(capi.FORM_KNOBS))(*[-1] * len(capi.FORM_KNOBS))
+    for name, value in knobs.items():
+        arr[capi.FORM_KNOBS.index(name)] = int(value)
+    form, mem = ctypes.c_int(-1), (ctypes.c_int64 * 2)()
+    assert lib.vrs_sort_form_for(n, key_bytes, pairs, arr, len(capi.FORM_KNOBS), ctypes.byref(form), mem) == 0
+    return capi.FORM_NAMES[form.value], list(mem)
+
+
+def test_the_dispatchers_decision_table(lib):
+    """Which form a one-call sort takes -- form x size x kind x settings x what an earlier refusal left behind -- through the dispatcher's
+    own decision function (csrc/vrs_sort_form.hpp: sort_all_passes and one_read_enqueue ask the same one), without a device.  The reference
+    has two fixed paths (single_radixsort for small inputs, multi_radixsort otherwise: README.md:18-21); here the sizes where each of the
+    five forms takes over are the measured crossovers, and every one of them is pinned."""
+    f = lambda *a, **k: _form(lib, *a, **k)[0]  # noqa: E731
+    # ---- bare uint32 keys, a fresh context
+    assert f(0) == "none" and f(1) == "single" and f(4096) == "single" and f(4097) == "contract" and f(8191) == "contract"
+    assert f(8192) == "lsd" and f((1 << 22) - 1) == "lsd" and f(1 << 22) == "pool" and f(10 ** 8) == "pool" and f(224000000) == "pool"
+    assert f(224000001) == "counted" and f(2 * 16384 * 14333) == "counted" and f(2 * 16384 * 14333 + 1) == "lsd"
+    assert f((1 << 30) - 1) == "lsd" and f(1 << 30) == "contract" and f(4294967295) == "contract"
+    # ---- settings
+    assert f(10 ** 8, pool=0) == "counted" and f(12999999, pool=0) == "lsd" and f(13000000, pool=0) == "counted"
+    assert f(10 ** 8, hybrid=0) == "lsd" and f(10 ** 8, atomic_rank=0) == "lsd" and f(10 ** 8, groups=16) == "lsd" and f(10 ** 8, groups=8) == "pool"
+    assert f(10 ** 8, reserve=0) == "counted" and f(5 * 10 ** 6, reserve=0) == "lsd"  # (the pool form's passes reserve their output)
+    assert f(10 ** 8, xcc_map_valid=0) == "contract" and f(3000, xcc_map_valid=0) == "single"
+    assert f(10 ** 5, one_call_min_keys=0) == "contract" and f(5000, one_call_min_keys=4097) == "lsd" and f(100, single_max_keys=50) == "contract"
+    assert f(5 * 10 ** 6, pool_min_keys=6 * 10 ** 6) == "lsd" and f(2 * 10 ** 7, pool_min_keys=3 * 10 ** 7) == "counted"
+    assert f(5 * 10 ** 6, hybrid_min_keys=1 << 22, pool=0) == "counted"
+    # ---- pairs (the stable pool form from the counted form's threshold on), 64-bit keys (never the pool form)
+    assert f(100, pairs=1) == "contract" and f(8192, pairs=1) == "lsd" and f(24999999, pairs=1) == "lsd" and f(25 * 10 ** 6, pairs=1) == "pool"
+    assert f(25 * 10 ** 6, pairs=1, pool_pairs=0) == "counted" and f(25 * 10 ** 6, pairs=1, reserve=0) == "pool"  # (pairs look back, they never reserve)
+    assert f(2 * 10 ** 8, pairs=1) == "pool" and f(215 * 10 ** 6, pairs=1) == "counted" and f(2 * 16384 * 13312 + 1, pairs=1) == "lsd"
+    assert f(100, 8) == "contract" and f(19999999, 8) == "lsd" and f(2 * 10 ** 7, 8) == "counted" and f(10 ** 8, 8, pairs=1) == "counted"
+    assert f(2 * 16384 * 6656 + 1, 8, pairs=1) == "lsd" and f(2 * 16384 * 13312, 8) == "counted"
+    # ---- a retry after a refusal: one form down
+    assert f(10 ** 8, no_pool=1) == "counted" and f(5 * 10 ** 6, no_pool=1) == "lsd" and f(10 ** 8, no_pool=1, no_hybrid=1) == "lsd"
+    assert f(10 ** 8, pairs=1, no_pool=1) == "counted" and f(10 ** 8, 8, no_hybrid=1) == "lsd"
+    # ---- what the context remembers: after a refusal the next 15 pool candidates of that size class take the counted form ...
+    form, mem = _form(lib, 10 ** 8, pool_skip=15, pool_skip_n=10 ** 8)
+    assert form == "counted" and mem[0] == 14
+    assert _form(lib, 10 ** 8, pool_skip=1, pool_skip_n=10 ** 8) == ("counted", [0, 0]) and f(10 ** 8, pool_skip=0, pool_skip_n=10 ** 8) == "pool"
+    # ... another size class (beyond a factor of two) is another workload and starts afresh; VRS_TUNE_MSD_POOL = 2 never skips
+    assert _form(lib, 4 * 10 ** 7, pool_skip=15, pool_skip_n=10 ** 8) == ("pool", [0, 0]) and _form(lib, 201 * 10 ** 6, pool_skip=15, pool_skip_n=10 ** 8)[0] == "pool"
+    assert f(10 ** 8, pool=2, pool_skip=15, pool_skip_n=10 ** 8) == "pool"
+    # (below the counted form's threshold a skipped pool candidate falls to the LSD passes, and the count stands)
+    assert _form(lib, 5 * 10 ** 6, pool_skip=7, pool_skip_n=5 * 10 ** 6) == ("lsd", [7, 0])
+    # 64-bit keys: after a refusal only every 16th sort tries the hybrid form again
+    assert _form(lib, 5 * 10 ** 7, 8, wide_refused=1, wide_skipped=0) == ("lsd", [0, 1])
+    assert _form(lib, 5 * 10 ** 7, 8, wide_refused=1, wide_skipped=15) == ("counted", [0, 16])
+    assert _form(lib, 5 * 10 ** 7, 8, wide_refused=0, wide_skipped=3) == ("counted", [0, 3])
+    # ---- arguments
+    bad = ctypes.c_int()
+    assert lib.vrs_sort_form_for(10, 3, 0, None, 0, ctypes.byref(bad), None) != 0 and lib.vrs_sort_form_for(10, 4, 0, None, 0, None, None) != 0
+    assert lib.vrs_sort_form_for(10, 4, 0, None, 3, ctypes.byref(bad), None) != 0
+    assert lib.vrs_sort_form_for(10 ** 8, 4, 0, None, 0, ctypes.byref(bad), None) == 0 and capi.FORM_NAMES[bad.value] == "pool"
+
+
+def test_no_source_file_of_the_library_outgrows_its_seams():
+    """round 5's vrs_capi.hip was one 2314-line file holding five sort forms; it is split along its seams now (context and buffers,
+    contract stages, the one-call dispatcher and settle, the pool form's host side, the hybrid form's halves), and stays so"""
+    from pathlib import Path
+    csrc = Path(capi.__file__).resolve().parent / "csrc"
+    sizes = {p.name: sum(1 for _ in p.open()) for p in csrc.iterdir() if p.suffix in (".hip", ".hpp", ".h")}
+    assert max(sizes.values()) <= 1200, sizes
+    assert {"vrs_capi.hip", "vrs_capi_contract.hip", "vrs_capi_sort.hip", "vrs_capi_pool.hip", "vrs_capi_msd.hip", "vrs_host.hpp", "vrs_sort_form.hpp"} <= set(sizes)

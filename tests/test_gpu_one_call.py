@@ -1136,3 +1136,49 @@ def test_ranged_sort_buckets_a_sub_range_of_the_key_space(gpu_context, span_bits
     finally:
         ctx.setTuning(capi.VRS_TUNE_HYBRID_MIN_KEYS, capi.HYBRID_MIN_KEYS_DEFAULT)
         ctx.setTuning(capi.VRS_TUNE_MSD_RESERVE, 1)
+
+
+@pytest.mark.parametrize("n,kind", [(3000, "keys"), (5000, "keys"), (100000, "keys"), ((1 << 22) + 11, "keys"), (14000000, "keys"),
+                                    (9000, "pairs"), (300000, "u64"), (26000000, "pairs"), (21000000, "u64")])
+def test_the_form_that_runs_is_the_form_the_decision_function_names(oracle, n, kind):
+    """vrs_sort_form_for (host only; tests/test_capi_cpu.py walks its whole table) against what a fresh context really launches: the
+    dispatcher asks the same function, so the kernels that run must be those of the form it names -- and the result std::sort's."""
+    import ctypes
+    rs = np.random.RandomState(n % 1009)
+    wide, pairs = kind == "u64", kind == "pairs"
+    keys = rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+    if wide:
+        keys = (keys.astype(np.uint64) << np.uint64(32)) | rs.randint(0, 2 ** 32, size=n, dtype=np.uint64)
+    form = ctypes.c_int()
+    with vrs.GPUContext(0) as ctx:  # a fresh context: the defaults vrs_sort_form_for assumes
+        assert ctx.lib.vrs_sort_form_for(n, 8 if wide else 4, int(pairs), None, 0, ctypes.byref(form), None) == 0
+        name = capi.FORM_NAMES[form.value]
+        S = vrs.Buffer.BufferSettings
+        k0, k1 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(keys.nbytes), keys), vrs.Buffer(ctx, S(keys.nbytes))
+        v0 = v1 = None
+        if pairs:
+            v0, v1 = vrs.Buffer.fillDeviceWithStagingBuffer(ctx, S(4 * n), np.arange(n, dtype=np.uint32)), vrs.Buffer(ctx, S(4 * n))
+        ctx.profileReset()
+        ctx.profileEnable(True)
+        if pairs:
+            ctx.check(ctx.lib.vrs_sort_pairs_u32(ctx.handle, k0.handle, k1.handle, v0.handle, v1.handle, n))
+        elif wide:
+            ctx.check(ctx.lib.vrs_sort_keys_u64(ctx.handle, k0.handle, k1.handle, n))
+        else:
+            ctx.check(ctx.lib.vrs_sort_keys_u32(ctx.handle, k0.handle, k1.handle, n))
+        out = np.empty_like(keys)
+        k0.downloadWithStagingBuffer(out)
+        ran = {nm: launches(ctx, kid) for kid, nm in capi.KERNEL_NAMES.items()}
+        ctx.profileEnable(False)
+        for b in (k0, k1, v0, v1):
+            if b is not None:
+                b.release()
+    assert np.array_equal(out, np.sort(keys))
+    expect = {"single": ran["single"] == 1 and ran["histogram"] == 0 and ran["digit_tables"] == 0,
+              "contract": ran["histogram"] == keys.dtype.itemsize and ran["scatter"] == keys.dtype.itemsize and ran["digit_tables"] == 0,
+              "lsd": ran["digit_tables"] >= 1 and ran["local_sort"] == 0 and ran["pool_pass_a"] == 0 and ran["histogram"] == 0,
+              "counted": ran["digit_tables"] == 1 and ran["local_sort"] >= 1 and ran["pool_pass_a"] == 0,
+              "pool": ran["pool_pass_a"] == 1 and ran["pool_pass_b"] == 1 and ran["local_sort"] >= 1 and ran["digit_tables"] == 0}
+    assert expect[name], (name, ran)
+    assert name == {3000: "single", 5000: "contract", 100000: "lsd", (1 << 22) + 11: "pool", 14000000: "pool", 9000: "lsd", 300000: "lsd",
+                    26000000: "pool", 21000000: "counted"}[n]

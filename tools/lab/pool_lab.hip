@@ -3,6 +3,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I vkradixsort_amd/csrc [-DVRS_POOL_...] tools/lab/pool_lab.hip -o tools/lab/pool_lab_X
 //   tools/lab/pool_lab_X [n] [reps]
 #include "../../vkradixsort_amd/csrc/vrs_msd_pool.hip"
+#include "../../vkradixsort_amd/csrc/vrs_msd_pool_local.hip"
+#include "../../vkradixsort_amd/csrc/vrs_pool_shape.hip"
 
 #include <cstdio>
 #include <cstdlib>

@@ -17,7 +17,8 @@ HOST = PKG_DIR / "host"
 INCLUDE = REPO_ROOT / "include"
 LIB_PATH = PKG_DIR / "libvkradixsort_amd.so"
 
-HIP_SOURCES = [CSRC / "vrs_contract.hip", CSRC / "vrs_one_call.hip", CSRC / "vrs_msd_hybrid.hip", CSRC / "vrs_msd_pool.hip", CSRC / "vrs_capi.hip", CSRC / "vrs_dist.hip"]
+HIP_SOURCES = [CSRC / name for name in ("vrs_contract.hip", "vrs_one_call.hip", "vrs_msd_hybrid.hip", "vrs_msd_pool.hip", "vrs_msd_pool_local.hip", "vrs_pool_shape.hip",
+                                        "vrs_capi.hip", "vrs_capi_contract.hip", "vrs_capi_sort.hip", "vrs_capi_pool.hip", "vrs_capi_msd.hip", "vrs_dist.hip")]
 HIP_HEADERS = sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.hpp")) + [INCLUDE / "vkradixsort_amd.h"]  # every object is rebuilt when any header is newer
 ARCH = "gfx950"
 
@@ -112,8 +113,8 @@ def build_host_logic_test(force: bool = False) -> Path:
 
 # ---------------------------------------------------------------------------------------------
 # Sanitizer builds (the reference runs with Vulkan validation layers whenever NDEBUG is not defined,
-# engine/include/engine/core/GPUContext.h:84-90 -- here: the host code of the library, the C++ host mirror, the host-only entry points
-# and the oracle under AddressSanitizer + UndefinedBehaviorSanitizer, the loopback hub's thread rendezvous under ThreadSanitizer).
+# engine/include/engine/core/GPUContext.h:84-90 -- here: the host code of the library, the C++ host mirror and the host-only entry points
+# under AddressSanitizer + UndefinedBehaviorSanitizer, the loopback hub's thread rendezvous under ThreadSanitizer).
 # Everything is compiled by ONE compiler (ROCm's clang, which hipcc is) so that one sanitizer runtime serves the process; device code is
 # left as it is (-fno-gpu-sanitize).  Output: vkradixsort_amd/_build/san_<kind>/.
 SAN_FLAGS = {
@@ -136,7 +137,8 @@ def san_dir(kind: str) -> Path:
 
 
 def build_sanitized(kind: str = "asan", force: bool = False) -> dict:
-    """The library, the C++ host mirror + host_logic_test, capi_host_sanity and (asan only) the oracle's self-test, instrumented.
+    """The library, the C++ host mirror with host_logic_test and capi_host_sanity, instrumented.  (The CPU checker under tests/ has a
+    sanitizer target of its own in its Makefile: the product package never touches it.)
     Returns {name: path} of the executables to run (their rpath finds the instrumented libraries and the sanitizer runtime)."""
     from concurrent.futures import ThreadPoolExecutor
     flags = SAN_FLAGS[kind]
@@ -168,15 +170,6 @@ def build_sanitized(kind: str = "asan", force: bool = False) -> dict:
         if force or _stale(exe, [*srcs, lib] + hdrs):
             _run([cxx, *common, *srcs, "-o", exe, *extra, *link])
         exes[name] = exe
-    if kind == "asan":
-        oracle = REPO_ROOT / "oracle"
-        exe = out / "oracle_selftest"
-        srcs = [oracle / "oracle_selftest.cpp", oracle / "vrs_stdsort.cpp", oracle / "vrs_oracle.c"]
-        if force or _stale(exe, srcs):
-            obj = out / "vrs_oracle_c.o"
-            _run([str(Path(cxx).parent / "clang"), "-std=c11", "-fPIC", *flags, "-c", srcs[2], "-o", obj])
-            _run([cxx, "-std=c++17", "-pthread", "-shared-libsan", *flags, srcs[0], srcs[1], obj, "-o", exe, f"-Wl,-rpath,{rt_dir}", f"-Wl,-rpath,{rt_alt}"])
-        exes["oracle_selftest"] = exe
     return exes
 
 

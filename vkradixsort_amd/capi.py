@@ -70,6 +70,9 @@ VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 22
 VRS_TUNE_MSD_POOL_PAIRS = 23
 VRS_TUNE_MSD_POOL_TOP_BITS = 24
 VRS_TUNE_DEBUG_POOL_NO_MEMORY = 25
+FORM_NAMES = {0: "none", 1: "single", 2: "contract", 3: "lsd", 4: "counted", 5: "pool"}
+FORM_KNOBS = ["single_max_keys", "one_call_min_keys", "hybrid_min_keys", "pool_min_keys", "hybrid", "pool", "pool_pairs", "reserve", "groups", "xcc_map_valid",
+              "atomic_rank", "pool_skip", "pool_skip_n", "wide_refused", "wide_skipped", "no_pool", "no_hybrid"]
 # keys the local sort of one top-14-bit bucket can hold (msd_local_capacity): uint32 keys with the 256- / 512-thread workgroup, pairs and 64-bit keys
 LOCAL_SORT_SMALL_KEYS, LOCAL_SORT_MAX_KEYS = 7165, 14333
 LOCAL_SORT_SMALL_PAIRS, LOCAL_SORT_MAX_PAIRS = 6656, 13312  # pairs and 64-bit keys: 512 / 1024-thread workgroups
@@ -180,6 +183,7 @@ _SIGNATURES = [
     ("vrs_one_call_pool_retries", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_one_call_pool_layouts", c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     ("vrs_pool_form_shape", c_int, [c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint64)]),
+    ("vrs_sort_form_for", c_int, [c_uint32, c_int, c_int, POINTER(ctypes.c_int64), c_int, POINTER(c_int), POINTER(ctypes.c_int64)]),
     ("vrs_pool_form_shape_ex", c_int, [c_uint32, c_int, c_int, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint64)]),
     ("vrs_context_trim_scratch", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_one_call_pool_no_memory", c_int, [c_void_p, POINTER(c_uint64)]),

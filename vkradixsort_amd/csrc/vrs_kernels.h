@@ -268,6 +268,8 @@ uint32_t msd_local_capacity_pairs_u64(bool small); // 64-bit keys with payloads:
 // A region that overflows its room, a key outside the sampled range or a bucket above the local sort's capacity make a verdict say
 // no (MsdPlan::ok == 0) before the caller's buffer has been written: the sort starts over in the counted form.
 constexpr uint32_t kPoolTile = 8192;           // keys per tile of both passes
+constexpr uint32_t kPoolRoomFloor = 320;        // slots every region gets on top of its six deviations
+constexpr int kPoolPairItems = 13;              // pairs per thread of the pairs' local sort (512 or 1024 threads: buckets up to 6656 / 13312)
 constexpr uint32_t kPoolSampleKeys = 256;      // leading keys of every tile the sample kernel counts
 constexpr uint32_t kPoolSampleTiles = 32;      // tiles per workgroup of the sample kernel
 constexpr uint32_t kPoolMaxKeys = 224000000u;  // the fullest of 16384 uniform buckets (mean + 5.5 deviations) must fit the local sort's 512-thread shape (14333 keys)

@@ -19,7 +19,7 @@
 //   pool_pass_b_kernel      second MSD pass (the next 6 bits), regions -> slack buffer: scatter_chunk with one L2-local reservation
 //                           per tile and bucket (SlackReserve) -- all tiles of a top byte run behind one L2.  It looks at every key:
 //                           one outside the probed range, a bucket that outgrows its region or the local sort's capacity flag the sort;
-//   pool_local_sort_kernel  one workgroup per bucket -- every one derives verdict 2 from the same two words, workgroup 0 tells
+//   pool_local_sort_kernel  (vrs_msd_pool_local.hip) one workgroup per bucket -- every one derives verdict 2 from the same two words, workgroup 0 tells
 //                           the host: reads the bucket (ONE contiguous, 16-byte aligned piece of the slack buffer) in 16-byte
 //                           vectors, sorts the keys by their low 18 bits inside LDS (lean_sort_body, vrs_local_sort.hpp) and
 //                           streams the bucket to its final place in the caller's buffer: its top byte's exact start + the second
@@ -45,7 +45,6 @@ namespace {
 
 constexpr uint32_t kPoolMinShift = 13, kPoolMaxShift = 18;  // a 27 ... 32-bit key range (the counted form's rule)
 constexpr float kPoolSigmas = 6.0f;                       // overflow room, in standard deviations of the region's estimate
-constexpr uint32_t kPoolRoomFloor = 320;
 
 // ---------------------------------------------------------------------------------------------
 // The sample.  Workgroup g takes tiles [32 g, 32 g + 32) of the input; wave w of it the tiles 32 g + w + 4 j.
@@ -844,377 +843,10 @@ __global__ __launch_bounds__(512, PAIRS ? 4 : 6) void pool_pass_b_kernel(const u
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Local sort: workgroup w = bucket 16383 - w.  The bucket lies in ONE piece at the start of its slack region (a 16-byte boundary):
-// read like lean_sort_bucket (vrs_msd_hybrid.hip) reads a bucket of the counted form, sorted by lean_sort_body, written -- unlike
-// there -- somewhere else: to the bucket's final place in the caller's buffer, whose misalignment is the OUTPUT's alone.
-template <int THREADS, int VEC>
-__device__ __forceinline__ void slack_load(uint32_t (&k)[4 * VEC], const uint32_t *src, uint32_t n) {
-    const uint32_t nvec = (n + 3u) / 4u;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        uint32_t v = j * THREADS + threadIdx.x;
-        if (j == VEC - 1) v = v < nvec ? v : nvec - 1u;  // only the last row can reach behind the bucket
-        const uint4 t = reinterpret_cast<const uint4 *>(src)[v];
-        k[4 * j] = t.x;
-        k[4 * j + 1] = t.y;
-        k[4 * j + 2] = t.z;
-        k[4 * j + 3] = t.w;
-    }
-}
-
-template <int THREADS, int VEC>
-__device__ __attribute__((noinline)) void slack_sort_guarded(const uint32_t *src, uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys,
-                                                            uint32_t *s_hist2, uint32_t *s_tmp, uint32_t guards) {
-    // (out of line, loading the bucket again: this copy's registers must not cost the common path its occupancy -- lean_sort_bucket)
-    uint32_t k[4 * VEC];
-    slack_load<THREADS, VEC>(k, src, n);
-    lean_sort_body<THREADS, VEC, true, true, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, (guards & 1u) != 0u, (guards & 2u) != 0u, 0u);
-}
-
-template <int THREADS, int VEC>
-__device__ __forceinline__ void slack_sort_bucket(const uint32_t *src, uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *s_hist2,
-                                                  uint32_t *s_tmp) {
-    constexpr int WAVES = THREADS / 64;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t k[4 * VEC];
-    slack_load<THREADS, VEC>(k, src, n);
-    {   // every counter table zeroed here (lean_sort_bucket does the same): WAVES tables of pass 2, then pass 1's
-        constexpr uint32_t kVecs = (WAVES + 1) * kLeanRow / 4;
-        for (uint32_t c = tid; c < kVecs; c += THREADS) reinterpret_cast<uint4 *>(s_hist2)[c] = make_uint4(0, 0, 0, 0);
-    }
-    {   // does some instruction of this wave's first row put half its lanes on one counter?  bit 0: pass 1, bit 1: pass 2
-        uint32_t skew = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t a1 = k[c] & 511u, a2 = (k[c] >> 9) & 511u;
-            skew |= __popcll(__ballot(a1 == __builtin_amdgcn_readfirstlane(a1))) >= 32 ? 1u : 0u;
-            skew |= __popcll(__ballot(a2 == __builtin_amdgcn_readfirstlane(a2))) >= 32 ? 2u : 0u;
-        }
-        if (lane == 0u) s_tmp[16 + wave] = skew;
-    }
-    __syncthreads();
-    uint32_t guards = 0;
-#pragma unroll
-    for (int v = 0; v < WAVES; ++v) guards |= s_tmp[16 + v];
-    guards = __builtin_amdgcn_readfirstlane(guards);
-    if (guards == 0u) lean_sort_body<THREADS, VEC, false, true, true>(k, abase, mis, n, s_keys, s_hist2, s_tmp, false, false, 0u);
-    else slack_sort_guarded<THREADS, VEC>(src, abase, mis, n, s_keys, s_hist2, s_tmp, guards);
-}
-
-// What every workgroup of a local sort does first, whatever its shape: workgroup w = bucket (buckets - 1 - w) -- the LAST bucket
-// first: the second pass wrote the top bytes in ascending order, the highest are what the memory-side cache still holds (round 4:
-// 215 -> 208 us; first bucket first measured 186-205 instead of 177-181 here).  False: nothing to sort (the verdict said no, the
-// bucket is empty).
-template <int THREADS, uint32_t CAPACITY, uint32_t SUBBITS>
-__device__ __forceinline__ bool pool_bucket(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out, MsdPlan *__restrict__ msd,
-                                            const PoolPlan *__restrict__ pool, uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
-                                            OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log, uint32_t retry, uint32_t par,
-                                            const uint32_t *&src, uint32_t *&abase, uint32_t &mis, uint32_t &n, const StatusClear sc = {nullptr, 0u}) {
-    constexpr uint32_t SUB = 1u << SUBBITS, PER = SUB / 64u;
-    const uint32_t b = gridDim.x - 1u - blockIdx.x, a = b >> SUBBITS, c = b & (SUB - 1u);  // (the grid: the top bytes that exist x SUB)
-    const uint32_t lane = threadIdx.x & 63u;
-    // The bucket's region, its top byte's start and the counters of the top byte's buckets (PER per lane, every wave the same
-    // 256 or 512 bytes) are asked for BEFORE the verdict is looked at (all exist whatever it says): a workgroup lives for a few memory latencies.
-    uint32_t cnt[PER];
-#pragma unroll
-    for (uint32_t q = 0; q < PER; ++q) cnt[q] = pool->sub_cursor[(a << SUBBITS) + 64u * q + lane];
-    const uint32_t start = pool->sub_start[b], top = pool->top_base[a];
-    // Verdict 2, by every workgroup from the same two words (final when this kernel starts): verdict 1 said yes and no pass flagged
-    // the sort (a region out of room, a bucket above this kernel's capacity, a key outside the probed range).  Workgroup 0 tells the host.
-    // A bucket beyond THIS kernel's shape (fail bit 1; the shape was chosen from n alone) is no refusal of the form: the bucket lies
-    // whole in its region, this kernel leaves, and the host -- told the bucket's size -- enqueues a larger shape (retry: that second one).
-    const uint32_t flags = pool->fail[par], mx = pool->max_bucket;
-    const uint32_t ok = (pool->ok_a != 0u && (flags & (retry ? 1u : 3u)) == 0u && (retry == 0u || mx <= CAPACITY - 3u)) ? 1u : 0u;
-    const uint32_t again = (ok == 0u && retry == 0u && pool->ok_a != 0u && flags == 2u) ? mx : 0u;  // != 0: a larger local sort finishes the sort
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        msd->ok = ok;
-        dev_head->msd_ok = ok;
-        dev_head->msd_max_bucket = again;
-        dev_head->lsd_missing = 1u;
-        if (host_head) {
-            __hip_atomic_store(&host_head->lsd_missing, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&host_head->msd_ok, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&host_head->msd_max_bucket, again, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            // (a finish among several enqueued before any is asked about: its decision also goes to the log, vrs_msd_finish_status_at)
-            if (host_log) __hip_atomic_store(&host_log[stamp & (kMsdLogWords - 1u)], (stamp << 1) | ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __threadfence_system();
-            __hip_atomic_store(&host_head->ready, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-    if (ok == 0u) return false;  // (enqueued before the verdicts were known, and one said no)
-    clear_status_share(sc, THREADS);  // (pairs: the look-back words of the two passes, clear for the next sort -- every workgroup its share)
-    // the first pass's cursors, zero for the next sort (the counted form's local sort does the same: rearm_reservation)
-    if (blockIdx.x < 2u * kStreams)
-        for (uint32_t q = threadIdx.x; q < 256u; q += THREADS) cursors[blockIdx.x * 256u + q] = 0;
-    // keys of the top byte's buckets before this one (every wave sums the counters below c), and this bucket's own
-    uint32_t before = 0;
-    n = 0;
-#pragma unroll
-    for (uint32_t q = 0; q < PER; ++q) {
-        before += 64u * q + lane < c ? cnt[q] : 0u;
-        const uint32_t v = __builtin_amdgcn_readlane(cnt[q], c & 63u);
-        n = (c >> 6) == q ? v : n;
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o);
-    const uint32_t begin = top + __builtin_amdgcn_readfirstlane(before);
-    mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(keys_out + begin) >> 2) & 3u);
-    if (n == 0 || mis + n > CAPACITY) return false;  // uniform; above the capacity cannot happen (the second pass would have flagged it)
-    abase = keys_out + begin - mis;
-    src = slack + start;
-    return true;
-}
-
-// Shapes: THREADS x 4 MAXVEC slots -- 256 x 16 (buckets up to 4093 keys: 28 KB of LDS, five workgroups per CU), 256 x 28 (7165 keys,
-// four per CU), 512 x 28 (14333 keys, two per CU); and ONE WAVE per bucket (below) for buckets up to 1789 keys.  A workgroup lives for
-// two memory round trips (its bucket's words, its keys) on top of the sort itself -- about 5 us of an 11 us life at 6100 keys.
-template <int THREADS, int MAXVEC, int WGS, uint32_t SUBBITS>
-__global__ __launch_bounds__(THREADS, WGS *(THREADS / 64) / 4) void pool_local_sort_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out,
-                                                                                          MsdPlan *__restrict__ msd, const PoolPlan *__restrict__ pool,
-                                                                                          uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
-                                                                                          OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log, uint32_t retry, uint32_t par) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[THREADS * 4 * MAXVEC + 4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_hist[(THREADS / 64 + 1) * kLeanRow];
-    __shared__ uint32_t s_tmp[32];
-    const uint32_t *src;
-    uint32_t *abase, mis, n;
-    if (!pool_bucket<THREADS, THREADS * 4u * MAXVEC, SUBBITS>(slack, keys_out, msd, pool, cursors, dev_head, host_head, stamp, host_log, retry, par, src, abase, mis, n)) return;
-    const uint32_t rows = (mis + n + 4u * THREADS - 1u) / (4u * THREADS);  // rows of THREADS vectors the bucket touches where it is written
-    if constexpr (MAXVEC == 4) {
-        switch (rows) {
-            case 1: slack_sort_bucket<THREADS, 1>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-            case 2: slack_sort_bucket<THREADS, 2>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-            case 3: slack_sort_bucket<THREADS, 3>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-            default: slack_sort_bucket<THREADS, 4>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        }
-    } else {
-        switch (rows) {
-            case 1: slack_sort_bucket<THREADS, 1>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-            case 2: slack_sort_bucket<THREADS, 2>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-            case 3: slack_sort_bucket<THREADS, 3>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-            case 4: slack_sort_bucket<THREADS, 4>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-            case 5: slack_sort_bucket<THREADS, 5>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-            case 6: slack_sort_bucket<THREADS, 6>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-            default: slack_sort_bucket<THREADS, 7>(src, abase, mis, n, s_keys, s_hist, s_tmp); break;
-        }
-    }
-}
-
-// Key + payload pairs: the bucket's keys and payloads from the two slack buffers (the same region in both), two STABLE 9-bit passes
-// inside LDS (local_pass, vrs_local_sort.hpp: the counted form's local sort of pairs), written to the bucket's final place in the
-// caller's two buffers.  512 threads x up to 13 pairs (two workgroups per CU), or 1024 x 13 for buckets of up to 13312.
-constexpr int kPoolPairItems = 13;
-template <int THREADS, uint32_t SUBBITS>
-__global__ __launch_bounds__(THREADS, 4) void pool_local_sort_pairs_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out,
-                                                                          MsdPlan *__restrict__ msd, const PoolPlan *__restrict__ pool,
-                                                                          uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
-                                                                          OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log, uint32_t retry,
-                                                                          uint32_t par, PoolPayloads pv) {
-    constexpr int WAVES = THREADS / 64;
-    constexpr uint32_t CAP = THREADS * kPoolPairItems;
-    __shared__ uint32_t s_keys[CAP];
-    __shared__ uint32_t s_vals[CAP];
-    __shared__ uint32_t s_hist[WAVES << 9];
-    __shared__ uint32_t s_tmp[1 + WAVES];
-    const uint32_t *src;
-    uint32_t *abase, mis, n;
-    const StatusClear sc{reinterpret_cast<uint4 *>(pv.status), static_cast<uint32_t>(pv.status_words / 4u)};
-    if (!pool_bucket<THREADS, CAP + 3u, SUBBITS>(slack, keys_out, msd, pool, cursors, dev_head, host_head, stamp, host_log, retry, par, src, abase, mis, n, sc)) return;
-    if (n > CAP) return;  // (cannot happen: the second pass flags a bucket above the capacity it was told)
-    uint32_t *bucket = abase + mis, *bvals = pv.values_home + (bucket - keys_out);
-    const uint32_t *svals = pv.slack_values + (src - slack);
-    const uint32_t used = (n + THREADS - 1u) / THREADS;
-    if (used <= 2) local_sort_bucket_to<THREADS, 2, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-    else if (used <= 4) local_sort_bucket_to<THREADS, 4, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-    else if (used <= 6) local_sort_bucket_to<THREADS, 6, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-    else if (used <= 8) local_sort_bucket_to<THREADS, 8, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-    else if (used <= 10) local_sort_bucket_to<THREADS, 10, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-    else if (used <= 12) local_sort_bucket_to<THREADS, 12, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-    else local_sort_bucket_to<THREADS, kPoolPairItems, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
-}
-
-// Small buckets (up to 1789 keys: uniform inputs below about 2.6e7 keys): ONE WAVE per bucket, no workgroup barrier anywhere
-// (msd_local_sort_wave_kernel's idea, vrs_msd_hybrid.hip: 16 independent buckets per CU instead of workgroups whose fixed work is most of
-// their life) -- with it the pool form is worth taking from about 10^7 keys on.
-template <int VEC>
-__device__ __forceinline__ void slack_wave_load(uint32_t (&k)[4 * VEC], const uint32_t *src, uint32_t n) {
-    const uint32_t lane = threadIdx.x & 63u, nvec = (n + 3u) / 4u;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        uint32_t v = j * 64 + lane;
-        if (j == VEC - 1) v = v < nvec ? v : nvec - 1u;
-        const uint4 t = reinterpret_cast<const uint4 *>(src)[v];
-        k[4 * j] = t.x;
-        k[4 * j + 1] = t.y;
-        k[4 * j + 2] = t.z;
-        k[4 * j + 3] = t.w;
-    }
-}
-template <int VEC>
-__device__ __attribute__((noinline)) void slack_wave_sort_guarded(const uint32_t *src, uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *tbl,
-                                                                 uint32_t skew) {
-    uint32_t k[4 * VEC];
-    slack_wave_load<VEC>(k, src, n);
-    wave_sort_body<VEC, true, true, true>(k, abase, mis, n, s_keys, tbl, (skew & 1u) != 0u, (skew & 2u) != 0u, 0u);
-}
-template <int VEC>
-__device__ __forceinline__ void slack_wave_sort_bucket(const uint32_t *src, uint32_t *abase, uint32_t mis, uint32_t n, uint32_t *s_keys, uint32_t *tbl) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t k[4 * VEC];
-    slack_wave_load<VEC>(k, src, n);
-    // the table zeroed: 576 words, two 16-byte stores per lane + one more from the first 16 lanes
-    reinterpret_cast<uint4 *>(tbl)[2 * lane] = make_uint4(0, 0, 0, 0);
-    reinterpret_cast<uint4 *>(tbl)[2 * lane + 1] = make_uint4(0, 0, 0, 0);
-    if (lane < 16u) reinterpret_cast<uint4 *>(tbl)[128 + lane] = make_uint4(0, 0, 0, 0);
-    uint32_t skew = 0;  // does an instruction of the first row put half its lanes on one counter?  bit 0: pass 1, bit 1: pass 2
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const uint32_t a1 = k[c] & 511u, a2 = (k[c] >> 9) & 511u;
-        skew |= __popcll(__ballot(a1 == __builtin_amdgcn_readfirstlane(a1))) >= 32 ? 1u : 0u;
-        skew |= __popcll(__ballot(a2 == __builtin_amdgcn_readfirstlane(a2))) >= 32 ? 2u : 0u;
-    }
-    skew = __builtin_amdgcn_readfirstlane(skew);
-    wave_phase();
-    if (skew == 0u) wave_sort_body<VEC, false, true, true>(k, abase, mis, n, s_keys, tbl, false, false, 0u);
-    else slack_wave_sort_guarded<VEC>(src, abase, mis, n, s_keys, tbl, skew);
-}
-template <uint32_t SUBBITS, int MAXVEC>  // MAXVEC 7: buckets up to 1789 keys (9.5 KB of LDS, 16 buckets per CU at a time); four rows (1021 keys, 25 per CU) measured the same
-__global__ __launch_bounds__(64, 4) void pool_local_sort_wave_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out, MsdPlan *__restrict__ msd,
-                                                                   const PoolPlan *__restrict__ pool, uint32_t *__restrict__ cursors,
-                                                                   OnesweepPlanHead *__restrict__ dev_head, OnesweepPlanHead *host_head, uint32_t stamp,
-                                                                   uint32_t *host_log, uint32_t retry, uint32_t par) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[64 * 4 * MAXVEC + 4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_tbl[kLeanRow];
-    const uint32_t *src;
-    uint32_t *abase, mis, n;
-    if (!pool_bucket<64, 64u * 4u * MAXVEC, SUBBITS>(slack, keys_out, msd, pool, cursors, dev_head, host_head, stamp, host_log, retry, par, src, abase, mis, n)) return;
-    const uint32_t rows = (mis + n + 255u) / 256u;
-    if constexpr (MAXVEC == 4) {
-        switch (rows) {
-            case 1: slack_wave_sort_bucket<1>(src, abase, mis, n, s_keys, s_tbl); break;
-            case 2: slack_wave_sort_bucket<2>(src, abase, mis, n, s_keys, s_tbl); break;
-            case 3: slack_wave_sort_bucket<3>(src, abase, mis, n, s_keys, s_tbl); break;
-            default: slack_wave_sort_bucket<4>(src, abase, mis, n, s_keys, s_tbl); break;
-        }
-    } else {
-        switch (rows) {
-            case 1: slack_wave_sort_bucket<1>(src, abase, mis, n, s_keys, s_tbl); break;
-            case 2: slack_wave_sort_bucket<2>(src, abase, mis, n, s_keys, s_tbl); break;
-            case 3: slack_wave_sort_bucket<3>(src, abase, mis, n, s_keys, s_tbl); break;
-            case 4: slack_wave_sort_bucket<4>(src, abase, mis, n, s_keys, s_tbl); break;
-            case 5: slack_wave_sort_bucket<5>(src, abase, mis, n, s_keys, s_tbl); break;
-            case 6: slack_wave_sort_bucket<6>(src, abase, mis, n, s_keys, s_tbl); break;
-            default: slack_wave_sort_bucket<7>(src, abase, mis, n, s_keys, s_tbl); break;
-        }
-    }
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // host side
-PoolStreams pool_streams(uint32_t n) {
-    PoolStreams ps{};
-    ps.tiles_total = (n + kPoolTile - 1u) / kPoolTile;
-    ps.tiles_per_stream = std::max<uint32_t>((ps.tiles_total + 7u) / 8u, 1u);
-    for (uint32_t s = 0; s < 8u; ++s) {
-        const uint64_t a = std::min<uint64_t>(static_cast<uint64_t>(s) * ps.tiles_per_stream * kPoolTile, n);
-        const uint64_t b = std::min<uint64_t>(static_cast<uint64_t>(s + 1u) * ps.tiles_per_stream * kPoolTile, n);
-        ps.start[s] = static_cast<uint32_t>(a);
-        ps.len[s] = static_cast<uint32_t>(b - a);
-        const uint32_t full = ps.len[s] / kPoolTile, rest = ps.len[s] % kPoolTile;
-        ps.sampled[s] = full * kPoolSampleKeys + std::min(rest, kPoolSampleKeys);
-    }
-    return ps;
-}
-
-uint32_t pool_overflow_capacity(uint32_t n) {
-    // sum over the 2048 regions of [six deviations of an estimate scaled up 32-fold + rounding + floor], bounded by
-    // Cauchy-Schwarz: sum sqrt(r e_i) <= sqrt(2048 r n); r is 32 but for the slices' ragged last tiles
-    const double room = 6.0 * std::sqrt(2048.0 * 33.0 * (static_cast<double>(n) + 2048.0 * 33.0)) + 2048.0 * (kPoolRoomFloor + 64.0);
-    return static_cast<uint32_t>(std::min<double>(room, 1u << 28)) & ~31u;
-}
-
-uint32_t pool_slack_capacity(uint32_t n, uint32_t sub_bits, uint32_t top_bytes) {
-    // the plan kernel gives a top byte of c keys c + 6 sqrt(S R (c + S R)) + S (floor + 4) slots (pool_space, S = 2^sub_bits); over T
-    // top bytes with sum c = n that is at most n + 6 sqrt(T S R (n + T S R)) + T S (floor + 4) + rounding (Cauchy-Schwarz), + the dump tile
-    const double R = 40.0, B = static_cast<double>(top_bytes) * static_cast<double>(1u << sub_bits);
-    const double room = 6.0 * std::sqrt(B * R * (static_cast<double>(n) + B * R)) + B * (kPoolRoomFloor + 4.0) + 256.0 * 4.0;
-    return (static_cast<uint32_t>(std::min<double>(static_cast<double>(n) + room, 3.9e9) + 31.0) & ~31u) + kPoolTile;
-}
-
-uint32_t pool_tiles_b_cap(uint32_t n) {
-    const uint32_t tiles = (n + kPoolTile - 1u) / kPoolTile, even = (tiles + 7u) / 8u;
-    // an XCD walks 32 top bytes, each rounded up to whole tiles; the grid is sized before the plan is known (a quarter more than
-    // an even split: skewed top bytes)
-    return even + even / 4u + 32u + 8u;
-}
-
-uint32_t pool_local_capacity(uint32_t local) {
-    if (local == 4u || local == 5u) return (local == 4u ? 512u : 1024u) * kPoolPairItems;  // pairs: 6656 / 13312
-    if (local == 3u) return 64u * 4u * kLeanMaxVec - 3u;  // one wave per bucket: 1789
-    return (local == 2u ? 512u : 256u) * 4u * (local == 0u ? 4u : static_cast<uint32_t>(kLeanMaxVec)) - 3u;
-}
-
-PoolShape pool_shape(uint32_t n, int forced_sub_bits) {
-    // the fullest of the uniform buckets: 4 to 4.5 deviations above the mean -- 5.5 and a little here
-    const auto fits = [&](uint32_t sub_bits, uint32_t local) {
-        const double mean = static_cast<double>(n) / (256u << sub_bits);
-        return static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u <= pool_local_capacity(local);
-    };
-    PoolShape sh{};
-    // Six bits as long as the 16384 buckets fit a 256-thread workgroup; beyond (about 1.1e8 uniform keys) seven bits keep them there
-    // (2e8 keys: 1.05 instead of 1.08 ms with the 512-thread shape).  Smaller buckets are NOT better: a workgroup's fixed work -- five
-    // counter tables to zero and scan, two memory round trips -- is a third of its life at 3000 keys (10^8 keys by seven bits: the
-    // local sort 205 instead of 176 us, with five workgroups per CU), a sixth at 6100.
-    sh.sub_bits = forced_sub_bits >= 6 && forced_sub_bits <= 8 ? static_cast<uint32_t>(forced_sub_bits) : (fits(6, 1) ? 6u : 7u);
-    sh.local = fits(sh.sub_bits, 3) ? 3u : fits(sh.sub_bits, 0) ? 0u : fits(sh.sub_bits, 1) ? 1u : 2u;
-    return sh;
-}
-
-PoolShape pool_shape_pairs(uint32_t n) {
-    // pairs: the local sort's shape by the fullest uniform bucket (pool_shape's rule); local 4 = 512 threads, 5 = 1024.  Six bits while
-    // the 16384 buckets fit the 512-thread workgroup (about 1.05e8 pairs); beyond, seven bits keep them there (32768 buckets: 2e8 pairs
-    // 2.35 -> 2.0 ms); the 1024-thread workgroup only where even those do not fit
-    const auto fits = [&](uint32_t sub_bits, uint32_t local) {
-        const double mean = static_cast<double>(n) / (256u << sub_bits);
-        return static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u <= pool_local_capacity(local);
-    };
-    if (fits(6, 4)) return PoolShape{6u, 4u};
-    if (fits(7, 4)) return PoolShape{7u, 4u};
-    return PoolShape{6u, 5u};
-}
-
-PoolCut pool_cut(uint32_t n, bool pairs, int top_bits_setting, int forced_sub_bits) {
-    // the shape by size in the 8 + S naming (256 << S buckets), then the cut of those bits between the passes: the setting (default 7 + 7)
-    // only where the usual cut would be 8 + 6 -- sorts whose second pass takes 7 or 8 bits of 256 top bytes keep that cut
-    PoolShape shape = pairs ? pool_shape_pairs(n) : pool_shape(n, forced_sub_bits);
-    PoolCut cut{};
-    cut.top_bits = (top_bits_setting != 8 && shape.sub_bits == 6u) ? static_cast<uint32_t>(top_bits_setting) : 8u;
-    cut.sub_bits = shape.sub_bits + 8u - cut.top_bits;
-    cut.local = shape.local;
-    return cut;
-}
-
-uint32_t pool_max_pairs() {
-    // the largest n whose fullest uniform bucket (pool_shape_pairs' rule) fits the shape that function returns: beyond it the second pass
-    // flags every sort and no larger pairs shape exists -- such sorts must not be candidates at all (found by bisection, once)
-    static const uint32_t limit = [] {
-        const auto fits = [](uint32_t n) {
-            const PoolShape sh = pool_shape_pairs(n);
-            const double mean = static_cast<double>(n) / (256u << sh.sub_bits);
-            return static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u <= pool_local_capacity(sh.local);
-        };
-        uint32_t lo = 1u << 22, hi = 300000000u;  // fits(lo), !fits(hi)
-        while (hi - lo > 1u) {
-            const uint32_t mid = lo + (hi - lo) / 2u;
-            (fits(mid) ? lo : hi) = mid;
-        }
-        return lo;
-    }();
-    return limit;
-}
 
 hipError_t launch_pool_sample(hipStream_t stream, const uint32_t *keys, uint32_t n, uint32_t key_base, const PoolStreams &ps,
                               PoolPlan *pool, uint32_t overflow_capacity, uint32_t par, LaunchEvents ev, uint32_t top_bits) {
@@ -1289,80 +921,6 @@ hipError_t launch_pool_pass_b(hipStream_t stream, const uint32_t *regions, const
     else VRS_POOL_B(6);
 #undef VRS_POOL_B
     return hipGetLastError();
-}
-
-hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
-                                  PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t par,
-                                  LaunchEvents ev, uint32_t top_bytes, uint32_t *host_log, bool retry, const PoolPayloads *pv) {
-    (void)n;
-    const uint32_t again = retry ? 1u : 0u;
-    uint32_t *cursors = &msd->cursor_a[0][0];
-    if (top_bytes == 0u || top_bytes > 256u || (top_bytes << shape.sub_bits) > kPoolMaxBuckets) return hipErrorInvalidValue;
-    if (pv || shape.local >= 4u) {  // pairs
-        if (!pv || (shape.local != 4u && shape.local != 5u)) return hipErrorInvalidValue;
-        const uint32_t buckets = top_bytes << shape.sub_bits;
-        if (shape.sub_bits == 8u) {
-            if (shape.local == 4u)
-                VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 8>), dim3(buckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
-                           stamp, host_log, again, par, *pv);
-            else
-                VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 8>), dim3(buckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
-                           stamp, host_log, again, par, *pv);
-            return hipGetLastError();
-        }
-        if (shape.sub_bits == 7u) {  // (lab: 7 + 7 bits)
-            if (shape.local == 4u)
-                VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 7>), dim3(buckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
-                           stamp, host_log, again, par, *pv);
-            else
-                VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 7>), dim3(buckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
-                           stamp, host_log, again, par, *pv);
-            return hipGetLastError();
-        }
-        if (shape.local == 4u)
-            VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 6>), dim3(buckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
-                       stamp, host_log, again, par, *pv);
-        else
-            VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 6>), dim3(buckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
-                       stamp, host_log, again, par, *pv);
-        return hipGetLastError();
-    }
-#define VRS_POOL_LOCAL(T, V, W, S)                                                                                                            \
-    VRS_LAUNCH((pool_local_sort_kernel<T, V, W, S>), dim3(top_bytes << S), dim3(T), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head, \
-               stamp, host_log, again, par)
-#define VRS_POOL_LOCAL_S(S)                                    \
-    do {                                                       \
-        if (shape.local == 3u)                                 \
-            VRS_LAUNCH((pool_local_sort_wave_kernel<S, 7>), dim3(top_bytes << S), dim3(64), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head, \
-                       stamp, host_log, again, par);           \
-        else if (shape.local == 0u) VRS_POOL_LOCAL(256, 4, 5, S);   \
-        else if (shape.local == 1u) VRS_POOL_LOCAL(256, 7, 4, S); \
-        else VRS_POOL_LOCAL(512, 7, 2, S);                     \
-    } while (0)
-    if (shape.sub_bits == 8u) VRS_POOL_LOCAL_S(8);
-    else if (shape.sub_bits == 7u) VRS_POOL_LOCAL_S(7);
-    else VRS_POOL_LOCAL_S(6);
-#undef VRS_POOL_LOCAL_S
-#undef VRS_POOL_LOCAL
-    return hipGetLastError();
-}
-
-PoolShape pool_grouped_shape(uint32_t n, uint32_t top_bytes) {
-    // S bits below the top byte for the second pass, 24 - S <= 18 for the local sort, top_bytes << S buckets within the plan's tables:
-    // the smallest S whose (uniform) buckets fit a 256-thread local sort, else the largest that fits at all; sub_bits 0 = none does
-    PoolShape best{0u, 0u};
-    for (uint32_t s = 6u; s <= 8u; ++s) {
-        if ((top_bytes << s) > kPoolMaxBuckets) break;
-        const double mean = static_cast<double>(n) / (static_cast<double>(top_bytes) * (1u << s));
-        const uint64_t need = static_cast<uint64_t>(mean + 5.5 * std::sqrt(mean)) + 32u;
-        for (uint32_t local : {3u, 0u, 1u, 2u}) {
-            if (need > pool_local_capacity(local)) continue;
-            if (best.sub_bits == 0u || (best.local == 2u && local != 2u)) best = PoolShape{s, local};
-            break;
-        }
-        if (best.sub_bits != 0u && best.local != 2u) break;
-    }
-    return best;
 }
 
 }  // namespace vrs
