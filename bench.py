@@ -68,6 +68,24 @@ def mt19937_keys(seed: int, n: int) -> np.ndarray:
     return np.random.RandomState(seed).randint(0, 2 ** 32, size=n, dtype=np.uint32)
 
 
+def pool_path_text(lib, n: int, top_bits_setting: int = 0, pairs: bool = False) -> str:
+    """config.path of a line whose timed sorts took the pool form, built from what the LIBRARY reports for this size and cut
+    (vrs_pool_form_shape_ex: host only) -- round 5's line still said "8 bits ... 6 bits" after the default became 7 + 7
+    (tests/test_tools_cpu.py fails when the text and the library disagree)."""
+    import ctypes
+    a, b, cap, scratch = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+    if lib.vrs_pool_form_shape_ex(n, int(pairs), int(top_bits_setting), ctypes.byref(a), ctypes.byref(b), ctypes.byref(cap), ctypes.byref(scratch)) != 0 or a.value == 0:
+        raise SystemExit(f"vrs_pool_form_shape_ex has no pool shape for n = {n}")
+    low = 32 - a.value - b.value
+    local = "one wave per bucket" if cap.value == 1789 else f"one {1024 if cap.value == 13312 else 512 if cap.value in (14333, 6656) else 256}-thread workgroup per bucket"
+    what = "vrs_sort_pairs_u32, the STABLE pool form (a tile's place in a region is its rank there: decoupled look-back)" if pairs else "vrs_sort_keys_u32, pool form"
+    return (f"{what} -- the hybrid form without a counting read: a sample of 1/32 of the keys sizes a region per (input slice, first digit); "
+            f"the first MSD pass ({a.value} bits) {'places' if pairs else 'reserves'} its output there, the second ({b.value} bits: {1 << (a.value + b.value)} buckets) "
+            f"scatters into per-bucket regions of a context-owned slack buffer ({scratch.value / 1e6:.0f} MB of context scratch), the local sort ({local}, up to {cap.value} "
+            f"{'pairs' if pairs else 'keys'}) reads every bucket in one piece, sorts it by its low {low} bits inside LDS and writes it to its final place "
+            f"({48 if pairs else 24} B/{'pair' if pairs else 'key'})")
+
+
 def load_traffic_profile(kernel: str = "scatter", algorithmic_bytes: float = 0.0):
     """HBM bytes per launch of the dominant kernel(s) from the committed rocprofv3 --pmc passes (profiles/), if present:
     (bytes per launch of the first dominant kernel or None, detail).  A figure below half the algorithmic bytes cannot be a
@@ -80,7 +98,7 @@ def load_traffic_profile(kernel: str = "scatter", algorithmic_bytes: float = 0.0
     except Exception as e:  # noqa: BLE001
         return None, {"note": f"profiles/{kernel}_traffic.json is unreadable: {e}"}
     passes = rec.get("passes") or [rec]
-    detail = {"round": rec.get("round"), "passes": []}
+    detail = {"round": rec.get("round"), "commit": rec.get("commit"), "box": rec.get("box"), "passes": []}
     for q in passes:
         b = q.get("hbm_bytes_per_launch")
         ratio = (b / algorithmic_bytes) if (b and algorithmic_bytes) else None
@@ -127,9 +145,11 @@ def bench_single(args):
         gpu.setTuning(capi.VRS_TUNE_RANK_MODE, args.rank_mode)
     if args.variant:
         gpu.setTuning(capi.VRS_TUNE_SCATTER_VARIANT, args.variant)
+    tuned = {}
     for kv in (args.tune or []):  # lab switch: --tune KEY=VALUE (numeric ids of include/vkradixsort_amd.h); named in the line's config
         k_, v_ = kv.split("=")
         gpu.setTuning(int(k_), int(v_))
+        tuned[int(k_)] = int(v_)
     dev_name, cus, mem = gpu.deviceInfo()
     nbuf = max(K, W, 1)
     need = (nbuf + len(host_keys) + 1) * 4 * n
@@ -318,6 +338,43 @@ def bench_single(args):
         gpu.waitIdle()
         blocking = (time.perf_counter() - t0) / K * 1e3
         gpu.setTuning(capi.VRS_TUNE_ASYNC_SORT, 1)
+    # ---- the same batches with every sort sampling for itself (VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 0): the timed region's sorts after the first
+    # start in the regions the context kept from the sort before -- a steady workload's gain, reported beside what a sort costs without it
+    every_samples = None
+    changing = None
+    if one_call:
+        rearm()
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL_REUSE_LAYOUT, 0)
+        gpu.waitIdle()
+        t0 = time.perf_counter()
+        for i in range(K):
+            primary(batches[i])
+        gpu.waitIdle()
+        every_samples = (time.perf_counter() - t0) / K * 1e3
+        gpu.setTuning(capi.VRS_TUNE_MSD_POOL_REUSE_LAYOUT, 1)
+        # ---- a workload that CHANGES from sort to sort at equal n: uniform keys and the reference's own 28-bit keys (MultiRadixSort.cpp:110-118:
+        # uniform_int_distribution over [0, 0x0FFFFFFF]) alternating -- every kept layout is stale for the next sort; after two the context stops
+        # trying for 16 sorts (the back-off ADVICE r5 asked for; before it every such sort ran its two passes twice)
+        import ctypes
+        narrow = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), host_keys[0] >> np.uint32(4))
+        lay0 = (ctypes.c_uint64(), ctypes.c_uint64())
+        gpu.check(gpu.lib.vrs_one_call_pool_layouts(gpu.handle, ctypes.byref(lay0[0]), ctypes.byref(lay0[1])))
+        for i in range(K):
+            batches[i].copyFrom(narrow if i % 2 else pristine[i % len(pristine)])
+        gpu.waitIdle()
+        t0 = time.perf_counter()
+        for i in range(K):
+            primary(batches[i])
+        gpu.waitIdle()
+        changing_ms = (time.perf_counter() - t0) / K * 1e3
+        lay1 = (ctypes.c_uint64(), ctypes.c_uint64())
+        gpu.check(gpu.lib.vrs_one_call_pool_layouts(gpu.handle, ctypes.byref(lay1[0]), ctypes.byref(lay1[1])))
+        ok_changing = all(batches[i].verifyKeys(n)[0] == 0 for i in range(K))
+        changing = {"ms_per_step": round(changing_ms, 4), "kept_layouts_tried": lay1[0].value - lay0[0].value, "of_them_stale": lay1[1].value - lay0[1].value,
+                    "every_batch_ascending": ok_changing,
+                    "note": "K further steps, uniform keys and 28-bit keys (the reference's own distribution) alternating: a kept layout never fits the next sort; "
+                            "after two stale ones the context samples for the next 16 sorts (outside the timed region)"}
+        narrow.release()
     # ---- what a plain device-to-device copy of one batch achieves here (read + write bytes), beside the 8 TB/s figure
     copy_times = []
     for i in range(6):
@@ -357,12 +414,13 @@ def bench_single(args):
                                   "or vrs_queue_wait_idle settles what the plan still asks for)" if one_call else "stage calls (asynchronous)",
                   "blocking_form_ms_per_step": round(blocking, 4) if blocking else None,
                   "blocking_form_note": "VRS_TUNE_ASYNC_SORT = 0: every call waits for its plan's head; same batches back to back, outside the timed region"},
+        "every_sort_samples_ms_per_step": round(every_samples, 4) if every_samples else None,
+        "every_sort_samples_note": "VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 0: no sort starts in the regions an earlier one laid out (the timed region's sorts after the "
+                                   "first do: a steady workload's gain); same batches back to back, outside the timed region",
+        "changing_inputs": changing,
         "config": {"workload": f"BASELINE.json configs[{ {10 ** 7: 1, 10 ** 8: 2}.get(n, 2) }]: {n} uniform random uint32 keys (std::mt19937 seeds 1,2,3), "
                                f"multi_radixsort, 1xMI355X, keys resident in HBM",
-                   "path": ("vrs_sort_keys_u32, pool form -- the hybrid form without a counting read: a sample of 1/32 of the keys sizes a region "
-                            "per (input slice, top byte); the first MSD pass (8 bits) reserves its output there, the second (6 bits; 7 beyond 1.1e8 keys) "
-                            "scatters into per-bucket regions of a context-owned slack buffer, the local sort reads every bucket in one piece, sorts "
-                            "it by its low 18 bits inside LDS and writes it to its final place (24 B/key)") if pool else
+                   "path": pool_path_text(gpu.lib, n, tuned.get(capi.VRS_TUNE_MSD_POOL_TOP_BITS, 0)) if pool else
                            (("vrs_sort_keys_u32, hybrid form: one counting read of the keys, an MSD partition by the top 14 bits in "
                              "two stable scatter passes with decoupled look-back (8 + 6 bits), then every bucket sorted by its "
                              "low 18 bits inside one workgroup's LDS (28 B/key); " + str(recount_steps) + " of the timed sorts "
@@ -383,7 +441,8 @@ def bench_single(args):
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us,
                      "traffic": traffic, "traffic_detail": traffic_detail,
                      "traffic_source": f"profiles/{dominant_name}_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                       "this command at N = 10^8 in an earlier run (counters cannot be read from inside this run)",
+                                       "this command at N = 10^8 in an earlier run (counters cannot be read from inside this run); its "
+                                       "commit and box are in traffic_detail",
                      "measured_d2d_copy_GBps": round(copy_gbps, 1),
                      "measured_d2d_copy_note": "hipMemcpyDtoD of one batch in this run, read + write bytes: what this box's "
                                                "HBM delivers for a mixed read/write stream, beside the 8 TB/s spec peak"},
@@ -549,8 +608,7 @@ def bench_pairs(args):
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[3]: {n} uint32 key + uint32 payload pairs (keys: std::mt19937 seeds 1,2,3; payload = "
                                "input position), 1xMI355X, resident in HBM; every key counts once (a pair per key)",
-                   "path": ("vrs_sort_pairs_u32, stable pool form: no counting read -- two stable MSD scatter passes by decoupled look-back inside "
-                            "sampled regions (keys + payloads), LDS-local bucket sort from the slack buffers to the caller's -- 48 B/pair") if pool else
+                   "path": pool_path_text(gpu.lib, n, 0, pairs=True) if pool else
                            ("vrs_sort_pairs_u32, hybrid form: one counting read of the keys, two stable MSD scatter passes with decoupled "
                             "look-back (keys + payloads), LDS-local bucket sort -- 52 B/pair") if hybrid else
                            "vrs_sort_pairs_u32: one counting read + four stable look-back scatter passes -- 68 B/pair",

@@ -401,6 +401,12 @@ int vrs_dist_loopback_create_host(int world, vrs_dist_loopback *out_hub);
 /* fills *out with rank `rank`'s end of the hub; call it on the thread that drives the rank, its device current */
 int vrs_dist_loopback_transport(vrs_dist_loopback hub, int rank, vrs_dist_transport *out);
 int vrs_dist_loopback_destroy(vrs_dist_loopback hub);
+/* A wire that costs something (a model of xGMI's point-to-point links for the SCHEDULE's sake -- how much of the exchange a given number
+ * of rounds exposes --, never a measurement): every group of sends / receives holds the receiving rank's stream for (the most bytes one peer
+ * sends it in the group) / link_gbps [10^9 bytes per second and link direction] + latency_us, every all-gather / all-reduce for latency_us.
+ * 0 / 0 (the default) = the free wire.  Also read from VRS_LOOPBACK_LINK_GBPS / VRS_LOOPBACK_LATENCY_US when the hub is made.  Call
+ * between steps. */
+int vrs_dist_loopback_set_wire(vrs_dist_loopback hub, double link_gbps, double latency_us);
 
 /* ---- measurement (no reference counterpart) ------------------------- */
 

@@ -585,3 +585,73 @@ def test_the_step_takes_the_byte_shape_by_default(world, monkeypatch):
     check_sorted_ranges(shards, res)
     for outs, (hybrid_rounds, fallback_rounds, byte_steps, grouped, _splitters) in res:
         assert hybrid_rounds == 0 and fallback_rounds == 0 and byte_steps == 2 and grouped == 2 * 2
+
+
+@pytest.mark.parametrize("shape", ["hybrid", "byte"])
+def test_a_wire_that_costs_something_changes_the_timing_not_the_result(monkeypatch, shape):
+    """vrs_dist_loopback_set_wire (round 5's verdict: the step had only ever run over a wire that costs nothing -- device copies): every
+    group of sends / receives holds the receiver's stream for (bytes on its busiest link) / rate + a latency, every small collective for
+    the latency.  Three ranks, two rounds: the ranges are still std::sort of the shards' concatenation, bit for bit -- and a slower wire
+    makes a slower step (the model is really in the path)."""
+    import time
+    monkeypatch.setenv("VRS_DIST_SHAPE", shape)
+    world, n = 3, 1500003
+    shards = [keys_of("uniform", n + 17 * r, 40 + r) for r in range(world)]
+    allkeys = np.sort(np.concatenate(shards))
+    lib = capi.load_library()
+    hub = ctypes.c_void_p()
+    assert lib.vrs_dist_loopback_create(world, ctypes.byref(hub)) == 0
+    cap = int(n * 1.3) + 70000
+    gate = threading.Barrier(world)
+    times = {}
+    outs = {}
+    errors = []
+
+    def rank_main(r):
+        try:
+            with vrs.GPUContext(0) as gpu:
+                tr = capi.DistTransport()
+                assert lib.vrs_dist_loopback_transport(hub, r, ctypes.byref(tr)) == 0
+                d = ctypes.c_void_p()
+                assert lib.vrs_dist_create_with_transport(gpu.handle, ctypes.byref(tr), r, world, cap, 2, ctypes.byref(d)) == 0
+                kb = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * shards[r].size), shards[r])
+                out_buf, out_n = ctypes.c_void_p(), ctypes.c_uint32()
+                for label, gbps, lat in (("free", 0.0, 0.0), ("slow", 0.5, 50.0), ("free_again", 0.0, 0.0)):
+                    gate.wait()
+                    if r == 0:
+                        assert lib.vrs_dist_loopback_set_wire(hub, gbps, lat) == 0
+                    gate.wait()
+                    best = None
+                    for _ in range(3):
+                        gpu.waitIdle()
+                        gate.wait()
+                        t0 = time.perf_counter()
+                        assert lib.vrs_dist_sort_keys_u32(d, kb.handle, shards[r].size, ctypes.byref(out_buf), ctypes.byref(out_n)) == 0
+                        gpu.waitIdle()
+                        dt = time.perf_counter() - t0
+                        best = dt if best is None else min(best, dt)
+                    out = np.empty(out_n.value, np.uint32)
+                    gpu.check(lib.vrs_buffer_download(gpu.handle, out_buf, out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+                    outs[(label, r)] = out
+                    times[(label, r)] = best
+                kb.release()
+                lib.vrs_dist_destroy(d)
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            gate.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not [t for t in threads if t.is_alive()] and not errors, errors
+    assert lib.vrs_dist_loopback_set_wire(None, 1.0, 0.0) != 0 and lib.vrs_dist_loopback_set_wire(hub, -1.0, 0.0) != 0
+    lib.vrs_dist_loopback_destroy(hub)
+    for label in ("free", "slow", "free_again"):
+        assert np.array_equal(np.concatenate([outs[(label, r)] for r in range(world)]), allkeys), label
+    # a rank receives about 2/3 of 6 MB from two peers: 2 MB on its busiest link = 4 ms at 0.5 GB/s, plus 50 us for each of the collectives
+    free = max(times[("free", r)] for r in range(world))
+    slow = max(times[("slow", r)] for r in range(world))
+    again = max(times[("free_again", r)] for r in range(world))
+    assert slow > free + 3e-3 and again < free + 2e-3, (free, slow, again)

@@ -84,3 +84,24 @@ def test_bench_names_the_dominant_kernel_by_its_share_of_the_time():
     assert bench.pick_dominant({"histogram": {"launches": 2, "avg_us": 100.0}, "scatter": {"launches": 2, "avg_us": 100.0}}) == "scatter"
     assert bench.pick_dominant({}) is None
     assert set(bench.KERNEL_BYTES_PER_KEY) <= set(bench.KERNEL_WHAT)
+
+
+def test_the_line_describes_the_cut_the_library_runs():
+    """round 5's driver line said "first MSD pass (8 bits) ... second (6 bits; 7 beyond 1.1e8)" while the timed kernels were the 7 + 7 cut:
+    config.path is now built from vrs_pool_form_shape_ex -- this fails when the text and the shape the library reports disagree."""
+    import ctypes
+    import re
+    from vkradixsort_amd import capi
+    bench = _load(ROOT / "bench.py", "bench_for_path_text")
+    lib = capi.load_library()
+    for n, top, pairs in [(10 ** 8, 0, False), (10 ** 8, 8, False), (10 ** 8, 6, False), (10 ** 7, 0, False), (13 * 10 ** 7, 0, False),
+                          (10 ** 8, 0, True), (2 * 10 ** 8, 0, True)]:
+        a, b, cap, scratch = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+        assert lib.vrs_pool_form_shape_ex(n, int(pairs), top, ctypes.byref(a), ctypes.byref(b), ctypes.byref(cap), ctypes.byref(scratch)) == 0
+        text = bench.pool_path_text(lib, n, top, pairs)
+        first, second = re.search(r"first MSD pass \((\d+) bits\)", text), re.search(r"the second \((\d+) bits: (\d+) buckets\)", text)
+        assert first and second, text
+        assert (int(first.group(1)), int(second.group(1)), int(second.group(2))) == (a.value, b.value, 1 << (a.value + b.value)), text
+        assert f"up to {cap.value} " in text and f"low {32 - a.value - b.value} bits" in text and f"{scratch.value / 1e6:.0f} MB" in text
+        assert ("48 B/pair" in text) == pairs and ("24 B/key" in text) != pairs
+    assert "(7 bits)" in bench.pool_path_text(lib, 10 ** 8) and "(8 bits)" not in bench.pool_path_text(lib, 10 ** 8)  # the default cut: 7 + 7

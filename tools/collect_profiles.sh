@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence bench.py's numbers are judged against.  Run on the GPU box:
-#   gpurun -- 'tools/collect_profiles.sh r03'                       the default bench command (configs[2], 10^8 keys)
+#   gpurun -- "VRS_COMMIT=$(git rev-parse --short HEAD) tools/collect_profiles.sh r06"      the default bench command (configs[2], 10^8 keys);
+#                                                                   VRS_COMMIT stamps the traffic files (the GPU box has no .git)
 #   gpurun -- 'tools/collect_profiles.sh r03_pairs --pairs'         configs[3]
 #   gpurun -- 'tools/collect_profiles.sh r03_1e7 --n 1e7 --steps 50 --warmup 5'   configs[1]
 # then copy gpurun_out/profiles_<tag>/<tag>_* (and the *_traffic.json files) into profiles/ (tracked).

@@ -110,8 +110,20 @@ if __name__ == "__main__":
     write = counter_per_dispatch("pmc_write", "WRITE_SIZE")
     rows = traffic_rows(fetch, write)
     json.dump(rows, open(f"{out}/{rnd}_hbm_traffic_per_launch.json", "w"), indent=1)
+    # every traffic file says which code and which box it came from (VRS_COMMIT: the caller's `git rev-parse --short HEAD` -- the GPU box has no
+    # .git --; the box: host name + the device's unique id): round 5's files were overwritten in place with neither
+    import os
+    import socket
+    import subprocess
+    try:
+        uid = subprocess.run(["rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=20).stdout
+        uid = next((ln.split(":")[-1].strip() for ln in uid.splitlines() if "Unique ID" in ln), "")
+    except Exception:  # noqa: BLE001
+        uid = ""
+    stamp = {"round": rnd, "commit": os.environ.get("VRS_COMMIT", "unknown"), "box": f"{socket.gethostname()} {uid}".strip()}
     for fname, rec in dominant_records(rows, pairs="pairs" in rnd).items():
-        json.dump(dict(rec, round=rnd), open(f"{out}/{fname}", "w"), indent=1)
+        json.dump(dict(rec, **stamp), open(f"{out}/{fname}", "w"), indent=1)
+    json.dump(stamp, open(f"{out}/{rnd}_stamp.json", "w"), indent=1)
     print(open(f"{out}/{rnd}_bench_kernel_stats.csv").read())
     print(json.dumps(rows, indent=1))
 

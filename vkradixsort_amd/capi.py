@@ -156,6 +156,7 @@ _SIGNATURES = [
     ("vrs_dist_splitter_steps", c_int, [c_void_p, POINTER(c_uint64)]),
     ("vrs_dist_loopback_create", c_int, [c_int, POINTER(c_void_p)]),
     ("vrs_dist_loopback_create_host", c_int, [c_int, POINTER(c_void_p)]),
+    ("vrs_dist_loopback_set_wire", c_int, [c_void_p, c_double, c_double]),
     ("vrs_dist_loopback_transport", c_int, [c_void_p, c_int, c_void_p]),
     ("vrs_dist_loopback_destroy", c_int, [c_void_p]),
     ("vrs_msd_partition_u32", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),

@@ -243,6 +243,12 @@ struct vrs_dist_loopback_t {
     int arrived = 0;
     uint64_t generation = 0;
     bool broken = false;  // a rank failed inside a collective: everyone leaves with an error instead of waiting
+    // A wire that costs something (vrs_dist_loopback_set_wire; VRS_LOOPBACK_LINK_GBPS / VRS_LOOPBACK_LATENCY_US at creation): every group of
+    // sends / receives holds the receiver's stream for (the most bytes it gets from ONE peer) / link_gbps -- the peers' links carry their
+    // messages side by side, a peer's messages share its link -- plus latency_us, every gather / reduce for latency_us.  A model of xGMI's
+    // point-to-point links for the schedule's sake (what of the wire is exposed, per R), not a measurement of anything.
+    double link_gbps = 0.0;    // 0: the wire is free (device copies only)
+    double latency_us = 0.0;
     bool host_memory = false;  // vrs_dist_loopback_create_host: the buffers are HOST memory, every transfer a memcpy at the rendezvous, no HIP call
                                // anywhere (the hub's matching and barriers run without a device: the sanitizer builds' CPU tests)
     std::vector<LoopEndpoint> ends;
@@ -276,6 +282,17 @@ int loop_break(vrs_dist_loopback_t *h, int code) {
     return code;
 }
 constexpr int kLoopErrHip = 1, kLoopErrPeer = 2, kLoopErrUsage = 3;
+__global__ void wire_delay_kernel(unsigned long long ticks) {  // holds its stream for `ticks` of the 100 MHz wall clock
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+bool loop_wire(vrs_dist_loopback_t *h, hipStream_t st, size_t bytes_on_busiest_link) {
+    if (h->host_memory || st == nullptr || (h->link_gbps <= 0.0 && h->latency_us <= 0.0)) return true;
+    const double us = h->latency_us + (h->link_gbps > 0.0 ? static_cast<double>(bytes_on_busiest_link) / (h->link_gbps * 1e3) : 0.0);
+    if (us <= 0.0) return true;
+    hipLaunchKernelGGL(wire_delay_kernel, dim3(1), dim3(64), 0, st, static_cast<unsigned long long>(us * 100.0));
+    return hipGetLastError() == hipSuccess;
+}
 // the hub's three device operations; in host-memory mode the barriers alone order the ranks (a copy is done when memcpy returns)
 bool loop_record(vrs_dist_loopback_t *h, hipEvent_t ev, hipStream_t st) { return h->host_memory || hipEventRecord(ev, st) == hipSuccess; }
 bool loop_wait(vrs_dist_loopback_t *h, hipStream_t st, hipEvent_t ev) { return h->host_memory || hipStreamWaitEvent(st, ev, 0) == hipSuccess; }
@@ -310,6 +327,7 @@ int loop_gather_like(void *u, const void *send, void *recv, size_t words, void *
     if (!loop_barrier(h)) return kLoopErrPeer;
     for (int s = 0; s < h->world; ++s)
         if (h->words[s] != words) return loop_break(h, kLoopErrUsage);
+    if (h->world > 1 && !loop_wire(h, st, words * 4)) return loop_break(h, kLoopErrHip);
     if (!reduce) {
         for (int s = 0; s < h->world; ++s) {
             if (s != e->rank && !loop_wait(h, st, h->ready[s])) return loop_break(h, kLoopErrHip);
@@ -367,6 +385,12 @@ int loop_group_end(void *u) {
     if (st && !loop_record(h, h->ready[e->rank], st)) return loop_break(h, kLoopErrHip);
     // a rank without operations records nothing: nobody will wait on its event, because nobody receives from it
     if (!loop_barrier(h)) return kLoopErrPeer;
+    {   // the wire: this group's receives, per peer (a peer's messages share one link, the peers' links run side by side)
+        std::vector<size_t> from(static_cast<size_t>(h->world), 0);
+        size_t busiest = 0;
+        for (const LoopOp &r : e->recvs) busiest = std::max(busiest, from[static_cast<size_t>(r.peer)] += r.words * 4);
+        if (!e->recvs.empty() && !loop_wire(h, st, busiest)) return loop_break(h, kLoopErrHip);
+    }
     std::vector<size_t> next(static_cast<size_t>(h->world), 0);
     for (const LoopOp &r : e->recvs) {
         const std::vector<LoopOp> &theirs = h->sends[r.peer];
@@ -417,7 +441,17 @@ int vrs_dist_loopback_create(int world, vrs_dist_loopback *out) {
         h->ends[static_cast<size_t>(r)].hub = h;
         h->ends[static_cast<size_t>(r)].rank = r;
     }
+    if (const char *v = std::getenv("VRS_LOOPBACK_LINK_GBPS")) h->link_gbps = std::max(0.0, std::atof(v));
+    if (const char *v = std::getenv("VRS_LOOPBACK_LATENCY_US")) h->latency_us = std::max(0.0, std::atof(v));
     *out = h;
+    return VRS_OK;
+}
+
+int vrs_dist_loopback_set_wire(vrs_dist_loopback hub, double link_gbps, double latency_us) {
+    if (!hub || link_gbps < 0.0 || latency_us < 0.0) return dfail(nullptr, VRS_ERROR_INVALID_ARGUMENT, "hub is NULL or a rate / latency is negative");
+    std::lock_guard<std::mutex> lk(hub->m);  // (between steps: no collective is in flight)
+    hub->link_gbps = link_gbps;
+    hub->latency_us = latency_us;
     return VRS_OK;
 }
 
