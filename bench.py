@@ -355,7 +355,6 @@ def bench_single(args):
         # ---- a workload that CHANGES from sort to sort at equal n: uniform keys and the reference's own 28-bit keys (MultiRadixSort.cpp:110-118:
         # uniform_int_distribution over [0, 0x0FFFFFFF]) alternating -- every kept layout is stale for the next sort; after two the context stops
         # trying for 16 sorts (the back-off ADVICE r5 asked for; before it every such sort ran its two passes twice)
-        import ctypes
         narrow = vrs.Buffer.fillDeviceWithStagingBuffer(gpu, S(4 * n), host_keys[0] >> np.uint32(4))
         lay0 = (ctypes.c_uint64(), ctypes.c_uint64())
         gpu.check(gpu.lib.vrs_one_call_pool_layouts(gpu.handle, ctypes.byref(lay0[0]), ctypes.byref(lay0[1])))
