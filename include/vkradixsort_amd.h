@@ -598,6 +598,12 @@ typedef enum vrs_tuning_key {
                                      a sampled region is its rank there (decoupled look-back, one chain per input slice / per top byte) instead
                                      of a reservation, so equal keys keep their input order; 48 instead of 52 bytes per pair.  0: pairs always
                                      take the counted form */
+    VRS_TUNE_MSD_POOL_PAIRS_PACKED = 26, /* the local sort of a pool sort of pairs, per bucket: -1 (default) = by size, 1 = always, 0 = never in its PACKED form --
+                                     inside a bucket a key's high bits are the bucket's, so a pair is sorted as ONE word (the key's low 18 bits | the
+                                     pair's place in the bucket as read), the payloads wait in registers and take the words' LDS array once the words
+                                     are sorted: 43 instead of 70 KB of LDS, three workgroups per CU instead of two.  5-9 % faster from 2.6e7 to 8e7
+                                     pairs; level at 10^8 and 2e8 (buckets of 12-13 rows), where the form that carries the payloads through both
+                                     passes stays (profiles/labs/r06_pairs_packed.txt) */
     VRS_TUNE_DEBUG_POOL_NO_MEMORY = 25, /* test hook: the next `value` allocations of the pool form's scratch fail as if the device were full */
     VRS_TUNE_DEBUG_XCC_ROTATE = 21, /* test hook: run the placement probe again and rotate its result by `value` places (0 .. 7), as if the probe had
                                        run on another hardware queue than the sorts do (the dispatcher starts every queue's round-robin at its

@@ -407,8 +407,8 @@ def test_pool_form_of_pairs_back_to_back_and_switched_off(pool_ctx, oracle):
         pool_ctx.setTuning(capi.VRS_TUNE_MSD_POOL_PAIRS, 1)
 
 
-def test_pool_form_of_pairs_at_1e8(gpu_context):
-    """configs[3]'s size with the defaults: 10^8 pairs, payload = input position"""
+def test_pool_form_of_pairs_at_1e8(gpu_context, oracle):
+    """configs[3]'s size with the defaults: 10^8 pairs, payload = input position -- bit for bit what std::stable_sort leaves"""
     ctx = gpu_context
     n = 100000000
     keys = make_keys(n, "uniform", seed=1)
@@ -418,6 +418,31 @@ def test_pool_form_of_pairs_at_1e8(gpu_context):
     assert np.all(ok[1:] >= ok[:-1]) and np.array_equal(keys[ov], ok)
     same = ok[1:] == ok[:-1]
     assert np.all(ov[1:][same] > ov[:-1][same])  # equal keys: input order
+    rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
+    assert np.array_equal(ok, rk) and np.array_equal(ov, rv)
+
+
+@pytest.mark.parametrize("packed", [0, 1])
+@pytest.mark.parametrize("dist", ["uniform", "28bit", "dups", "ties", "gauss"])
+@pytest.mark.parametrize("n", [POOL_MIN + 77, 30000001])
+def test_both_forms_of_the_pairs_local_sort(pool_ctx, oracle, n, dist, packed):
+    """The pairs' local sort either carries the payloads through both LDS passes or sorts ONE word per pair (the key's bits below the bucket's
+    | the pair's place in the bucket) and fetches each payload once, by place (VRS_TUNE_MSD_POOL_PAIRS_PACKED; by default the buckets' mean
+    size decides).  Both are stable sorts of every bucket: bit for bit std::stable_sort's answer.  28bit: a bucket's keys differ in 14 bits,
+    not 18; ties / dups: runs of equal keys whose payloads must keep their input order; gauss at 3e7: the retry in the 1024-thread shape."""
+    if dist == "ties":
+        keys = (make_keys(n, "uniform", seed=6) & np.uint32(0xFFFF)) * np.uint32(65537)
+    else:
+        keys = pool_keys(n, dist, seed=n % 983)
+    vals = make_keys(n, "uniform", seed=11)
+    pool_ctx.setTuning(capi.VRS_TUNE_MSD_POOL_PAIRS_PACKED, packed)
+    try:
+        ok, ov, stats, (took, refused) = sort_pairs_and_stats(pool_ctx, keys, vals)
+    finally:
+        pool_ctx.setTuning(capi.VRS_TUNE_MSD_POOL_PAIRS_PACKED, -1)
+    rk, rv, _ = oracle.stable_sort_pairs(keys, vals)
+    assert np.array_equal(ok, rk) and np.array_equal(ov, rv)
+    assert (took, refused) == (1, 0), stats
 
 
 @pytest.mark.parametrize("hook", ["hold_tile", "no_patience"])

@@ -13,6 +13,7 @@ with vrs.GPUContext(0) as gpu:
     src=vrs.Buffer.fillDeviceWithStagingBuffer(gpu,S(4*n),keys); vsrc=vrs.Buffer.fillDeviceWithStagingBuffer(gpu,S(4*n),vals)
     kb=[vrs.Buffer(gpu,S(4*n)) for _ in range(K)]; vb=[vrs.Buffer(gpu,S(4*n)) for _ in range(K)]
     kt,vt=vrs.Buffer(gpu,S(4*n)),vrs.Buffer(gpu,S(4*n))
+    if os.environ.get('VRS_PACKED'): gpu.setTuning(capi.VRS_TUNE_MSD_POOL_PAIRS_PACKED, int(os.environ['VRS_PACKED']))
     best=1e9
     for rep in range(4):
         for i in range(K): kb[i].copyFrom(src); vb[i].copyFrom(vsrc)

@@ -70,6 +70,7 @@ VRS_TUNE_MSD_POOL_REUSE_LAYOUT = 22
 VRS_TUNE_MSD_POOL_PAIRS = 23
 VRS_TUNE_MSD_POOL_TOP_BITS = 24
 VRS_TUNE_DEBUG_POOL_NO_MEMORY = 25
+VRS_TUNE_MSD_POOL_PAIRS_PACKED = 26
 FORM_NAMES = {0: "none", 1: "single", 2: "contract", 3: "lsd", 4: "counted", 5: "pool"}
 FORM_KNOBS = ["single_max_keys", "one_call_min_keys", "hybrid_min_keys", "pool_min_keys", "hybrid", "pool", "pool_pairs", "reserve", "groups", "xcc_map_valid",
               "atomic_rank", "pool_skip", "pool_skip_n", "wide_refused", "wide_skipped", "no_pool", "no_hybrid"]

@@ -681,6 +681,10 @@ int vrs_set_tuning(vrs_context ctx, int key, int value) {
             ctx->os_pool_layout_valid = false;
             ctx->os_pool_stale_run = ctx->os_pool_reuse_pause = 0;
             return VRS_OK;
+        case VRS_TUNE_MSD_POOL_PAIRS_PACKED:
+            if (value < -1 || value > 1) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pairs' packed local sort: -1 (by size), 0 (never) or 1 (always)");
+            ctx->os_pool_pairs_packed = value;
+            return VRS_OK;
         case VRS_TUNE_MSD_POOL_SUB_BITS:
             if (value != 0 && (value < 6 || value > 8)) return fail(ctx, VRS_ERROR_INVALID_ARGUMENT, "the pool form's second pass sorts by 6, 7 or 8 bits (0 = by size)");
             ctx->os_pool_sub_bits = value;

@@ -105,6 +105,8 @@ int one_read_enqueue_pool(vrs_context ctx, const OneReadGeometry &g) {
         pv.status_words = ctx->os_status_rows * VRS_RADIX_SORT_BINS;
         pv.spin_budget = ctx->os_spin_budget;
         pv.hold_tile = ctx->os_hold_tile;
+        pv.top_bits = top_bits;
+        pv.packed = ctx->os_pool_pairs_packed;
     }
     const vrs::PoolPayloads *pvp = pairs ? &pv : nullptr;
     const vrs::PoolStreams ps = vrs::pool_streams(n);

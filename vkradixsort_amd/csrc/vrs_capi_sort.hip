@@ -459,6 +459,8 @@ int one_read_complete(vrs_context ctx, bool *done) {
                     pv.slack_values = ctx->os_pool_slack_vals;
                     pv.status = ctx->os_status;
                     pv.status_words = ctx->os_status_rows * VRS_RADIX_SORT_BINS;
+                    pv.top_bits = st.pool_top_bits;
+                    pv.packed = ctx->os_pool_pairs_packed;
                 }
                 st.pool_retried = true;
                 st.pool_local = local;

@@ -116,6 +116,7 @@ struct vrs_context_t {
     int os_pool_top_bits = 7;              // VRS_TUNE_MSD_POOL_TOP_BITS: how a sort's 16384 buckets are cut between the two passes -- 7 + 7 bits (default: the first pass, which
                                            // reads cold input, writes 64-key segments instead of 32-key ones: pairs -2.4 %, 10^7 keys -2.5 %, 10^8 keys -1 %), 8 + 6, or 6 + 8
     int os_pool_pairs = 1;                 // VRS_TUNE_MSD_POOL_PAIRS: key + payload pairs may take the (stable) pool form
+    int os_pool_pairs_packed = -1;         // VRS_TUNE_MSD_POOL_PAIRS_PACKED: the pairs' local sort in its packed form: -1 by size, 0 never, 1 always
     uint64_t os_pool_pair_sorts = 0;
     uint64_t os_pool_sorts = 0, os_pool_refusals = 0, os_pool_retries = 0;  // (retries: sorts whose local sort was enqueued again in a larger shape)
     uint32_t os_pool_min_keys = 1u << 22;   // VRS_TUNE_MSD_POOL_MIN_KEYS: the form's own floor -- with one wave per small bucket it beats the LSD passes from there on (labs/r05_pool_form.txt section 6)

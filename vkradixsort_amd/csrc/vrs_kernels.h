@@ -269,6 +269,7 @@ uint32_t msd_local_capacity_pairs_u64(bool small); // 64-bit keys with payloads:
 // no (MsdPlan::ok == 0) before the caller's buffer has been written: the sort starts over in the counted form.
 constexpr uint32_t kPoolTile = 8192;           // keys per tile of both passes
 constexpr uint32_t kPoolRoomFloor = 320;        // slots every region gets on top of its six deviations
+constexpr uint32_t kPoolPackedPairsMean = 5120;  // pairs: buckets of up to this many pairs on average take the local sort's packed form (launch_pool_local_sort)
 constexpr int kPoolPairItems = 13;              // pairs per thread of the pairs' local sort (512 or 1024 threads: buckets up to 6656 / 13312)
 constexpr uint32_t kPoolSampleKeys = 256;      // leading keys of every tile the sample kernel counts
 constexpr uint32_t kPoolSampleTiles = 32;      // tiles per workgroup of the sample kernel
@@ -344,6 +345,8 @@ struct PoolPayloads {
     size_t status_words = 0;
     uint32_t spin_budget = 0;
     int hold_tile = -1;                   // test hook (VRS_TUNE_DEBUG_HOLD_TILE): this tile of every slice never publishes in the first pass
+    int packed = -1;                      // VRS_TUNE_MSD_POOL_PAIRS_PACKED: the local sort's packed form -- -1 by the buckets' mean size, 0 never, 1 always
+    uint32_t top_bits = 8;                // bits the first pass took (the cut of the buckets' bits between the passes): the local sort derives the bits a bucket's keys differ in
 };
 // the second half alone, for n keys grouped by `top_bytes` top bytes: sub_bits 6 .. 8 (0: no shape takes them)
 PoolShape pool_grouped_shape(uint32_t n, uint32_t top_bytes);

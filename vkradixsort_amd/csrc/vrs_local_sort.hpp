@@ -361,9 +361,14 @@ __device__ __forceinline__ void wave_sort_body(uint32_t (&k)[4 * VEC], uint32_t 
 // come from the tables' prefix) -- equal digits keep their order.  Not STABLE: ONE table for the workgroup, a quarter of the
 // zeroing and scanning; equal digits come out in any order -- enough for the FIRST pass over bare keys (keys that tie in
 // this digit are told apart by the later pass or are equal), never for payloads.
-template <int THREADS, int ITEMS, int BITS, bool PAIRS, bool STABLE, typename K = uint32_t>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// scanned(): called once the pass has scanned its counters, in front of the keys' scatter through LDS -- the scan's registers are free again and a
+// scatter, a barrier and a read-back lie ahead: where a caller starts loads it wants in flight behind the pass.
+template <int THREADS, int ITEMS, int BITS, bool PAIRS, bool STABLE, typename K = uint32_t, typename Hook = NoHook>
 __device__ __forceinline__ void local_pass(K (&key)[ITEMS], uint32_t (&val)[PAIRS ? ITEMS : 1], K *s_keys,
-                                           uint32_t *s_vals, uint32_t *s_hist, uint32_t *s_tmp, uint32_t shift, uint32_t n) {
+                                           uint32_t *s_vals, uint32_t *s_hist, uint32_t *s_tmp, uint32_t shift, uint32_t n, Hook scanned = Hook()) {
     // thread t scans bins [t * PER, (t + 1) * PER); a workgroup of more threads than bins (1024 threads, 512 bins: the large
     // buckets of pairs and 64-bit keys) leaves its upper waves out of the scan
     constexpr int WAVES = THREADS / 64, BINS = 1 << BITS, TABLES = STABLE ? WAVES : 1, PER = BINS >= THREADS ? BINS / THREADS : 1;
@@ -443,6 +448,7 @@ __device__ __forceinline__ void local_pass(K (&key)[ITEMS], uint32_t (&val)[PAIR
         }
     }
     __syncthreads();
+    scanned();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
         if (seg + i * 64 < n) rank[i] += my[static_cast<uint32_t>(key[i] >> shift) & (BINS - 1)];
@@ -504,6 +510,65 @@ __device__ __forceinline__ void local_sort_bucket_to(const uint32_t *src, const 
                 if constexpr (STREAM) __builtin_nontemporal_store(val[i], bucket_vals + idx);
                 else bucket_vals[idx] = val[i];
             }
+        }
+    }
+}
+
+// The pool form's bucket of key + payload PAIRS, sorted as ONE word per pair: inside a bucket every key has the same bits from `lowbits` up
+// (the bucket's index; lowbits <= 18), and a pair's place in the bucket as it was read fits IDXB bits -- word = (the key's low bits) << IDXB | place.
+// Two STABLE 9-bit passes over the words' key bits leave equal keys in the order of their places, which is the order they came in.  The payloads
+// take no part in the passes: they are read into registers while the second pass runs, put into the SAME LDS array the words were sorted in once
+// that pass has read it back (payload of place p at slot p), and fetched by the place each sorted word carries.  One array instead of two: 43 KB
+// of LDS per workgroup instead of 70, three workgroups per CU instead of two.
+template <int THREADS, int ITEMS, int IDXB, bool STREAM>
+__device__ __forceinline__ void local_sort_packed_pairs_to(const uint32_t *src, const uint32_t *src_vals, uint32_t *bucket, uint32_t *bucket_vals, uint32_t n,
+                                                           uint32_t lowbits, uint32_t *s_keys, uint32_t *s_hist, uint32_t *s_tmp) {
+    static_assert(THREADS * ITEMS <= (1 << IDXB) && IDXB + 18 <= 32, "a pair's place and 18 key bits share a word");
+    constexpr int BITS = 9;
+    constexpr uint32_t PLACE = (1u << IDXB) - 1u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t seg = wave * (ITEMS * 64) + lane;
+    const uint32_t lowmask = (1u << lowbits) - 1u;
+    uint32_t word[ITEMS], val[ITEMS], none[1], high = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t idx = seg + i * 64;
+        const uint32_t k = src[idx < n ? idx : n - 1u];
+        word[i] = ((k & lowmask) << IDXB) | idx;  // positions >= n hold nothing: the passes leave them alone and they are not written
+        if (i == 0) high = k & ~lowmask;          // (the same in every key of the bucket)
+    }
+    local_pass<THREADS, ITEMS, BITS, false, true>(word, none, s_keys, nullptr, s_hist, s_tmp, IDXB, n);
+    // (every place of the workgroup's THREADS * ITEMS is read and staged, the ones behind the bucket with a payload nobody asks for: under
+    //  `if (idx < n)` the compiler sinks each load into its branch -- thirteen memory round trips one after the other)
+    const auto load_payloads = [&] {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t idx = seg + i * 64;
+            val[i] = src_vals[idx < n ? idx : n - 1u];
+        }
+    };
+    // (the payloads' loads start behind the second pass's scan: thirteen more registers through the whole pass would cost the third workgroup)
+    local_pass<THREADS, ITEMS, BITS, false, true, uint32_t>(word, none, s_keys, nullptr, s_hist, s_tmp, IDXB + BITS, n, load_payloads);  // (ends behind a barrier: s_keys is free)
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) s_keys[seg + i * 64] = val[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) val[i] = s_keys[word[i] & PLACE];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t idx = seg + i * 64;
+        if (idx < n) {
+            const uint32_t k = high | (word[i] >> IDXB);
+            if constexpr (STREAM) __builtin_nontemporal_store(k, bucket + idx);
+            else bucket[idx] = k;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t idx = seg + i * 64;
+        if (idx < n) {
+            if constexpr (STREAM) __builtin_nontemporal_store(val[i], bucket_vals + idx);
+            else bucket_vals[idx] = val[i];
         }
     }
 }

@@ -4,6 +4,9 @@
 // second verdict from the same two words, workgroup 0 tells the host.  The reference has no counterpart (its four passes are global).
 #include "vrs_local_sort.hpp"
 
+#include <cstdlib>
+
+
 namespace vrs {
 
 namespace {
@@ -168,8 +171,8 @@ __global__ __launch_bounds__(THREADS, WGS *(THREADS / 64) / 4) void pool_local_s
 // Key + payload pairs: the bucket's keys and payloads from the two slack buffers (the same region in both), two STABLE 9-bit passes
 // inside LDS (local_pass, vrs_local_sort.hpp: the counted form's local sort of pairs), written to the bucket's final place in the
 // caller's two buffers.  512 threads x up to 13 pairs (two workgroups per CU), or 1024 x 13 for buckets of up to 13312.
-template <int THREADS, uint32_t SUBBITS>
-__global__ __launch_bounds__(THREADS, 4) void pool_local_sort_pairs_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out,
+template <int THREADS, uint32_t SUBBITS, bool PACKED>
+__global__ __launch_bounds__(THREADS, (PACKED && THREADS == 512) ? 6 : 4) void pool_local_sort_pairs_kernel(const uint32_t *__restrict__ slack, uint32_t *__restrict__ keys_out,
                                                                           MsdPlan *__restrict__ msd, const PoolPlan *__restrict__ pool,
                                                                           uint32_t *__restrict__ cursors, OnesweepPlanHead *__restrict__ dev_head,
                                                                           OnesweepPlanHead *host_head, uint32_t stamp, uint32_t *host_log, uint32_t retry,
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(THREADS, 4) void pool_local_sort_pairs_kernel(const
     constexpr int WAVES = THREADS / 64;
     constexpr uint32_t CAP = THREADS * kPoolPairItems;
     __shared__ uint32_t s_keys[CAP];
-    __shared__ uint32_t s_vals[CAP];
+    __shared__ uint32_t s_vals[PACKED ? 1 : CAP];  // (packed: the payloads take the words' array once the words are sorted)
     __shared__ uint32_t s_hist[WAVES << 9];
     __shared__ uint32_t s_tmp[1 + WAVES];
     const uint32_t *src;
@@ -188,6 +191,18 @@ __global__ __launch_bounds__(THREADS, 4) void pool_local_sort_pairs_kernel(const
     uint32_t *bucket = abase + mis, *bvals = pv.values_home + (bucket - keys_out);
     const uint32_t *svals = pv.slack_values + (src - slack);
     const uint32_t used = (n + THREADS - 1u) / THREADS;
+    // the bits a bucket's keys differ in: below the first pass's digit (the top byte's shift + what the cut left of the byte) and the second pass's bits
+    const uint32_t lowbits = pool->shift + kMsdBits - pv.top_bits - SUBBITS;
+    constexpr int IDXB = THREADS == 512 ? 13 : 14;
+    if constexpr (PACKED) {
+        if (lowbits > 18u) return;  // (cannot happen: the top byte's shift is at most 24, and the two passes took 14 bits or more of the range)
+        if (used <= 4) local_sort_packed_pairs_to<THREADS, 4, IDXB, true>(src, svals, bucket, bvals, n, lowbits, s_keys, s_hist, s_tmp);
+        else if (used <= 8) local_sort_packed_pairs_to<THREADS, 8, IDXB, true>(src, svals, bucket, bvals, n, lowbits, s_keys, s_hist, s_tmp);
+        else if (used <= 10) local_sort_packed_pairs_to<THREADS, 10, IDXB, true>(src, svals, bucket, bvals, n, lowbits, s_keys, s_hist, s_tmp);
+        else if (used <= 12) local_sort_packed_pairs_to<THREADS, 12, IDXB, true>(src, svals, bucket, bvals, n, lowbits, s_keys, s_hist, s_tmp);
+        else local_sort_packed_pairs_to<THREADS, kPoolPairItems, IDXB, true>(src, svals, bucket, bvals, n, lowbits, s_keys, s_hist, s_tmp);
+        return;
+    }
     if (used <= 2) local_sort_bucket_to<THREADS, 2, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
     else if (used <= 4) local_sort_bucket_to<THREADS, 4, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
     else if (used <= 6) local_sort_bucket_to<THREADS, 6, true, true>(src, svals, bucket, bvals, n, s_keys, s_vals, s_hist, s_tmp);
@@ -278,37 +293,35 @@ __global__ __launch_bounds__(64, 4) void pool_local_sort_wave_kernel(const uint3
 hipError_t launch_pool_local_sort(hipStream_t stream, const uint32_t *slack, uint32_t *keys_out, uint32_t n, MsdPlan *msd, const PoolPlan *pool,
                                   PoolShape shape, OnesweepPlanHead *dev_head, OnesweepPlanHead *host_head, uint32_t stamp, uint32_t par,
                                   LaunchEvents ev, uint32_t top_bytes, uint32_t *host_log, bool retry, const PoolPayloads *pv) {
-    (void)n;
     const uint32_t again = retry ? 1u : 0u;
     uint32_t *cursors = &msd->cursor_a[0][0];
     if (top_bytes == 0u || top_bytes > 256u || (top_bytes << shape.sub_bits) > kPoolMaxBuckets) return hipErrorInvalidValue;
     if (pv || shape.local >= 4u) {  // pairs
         if (!pv || (shape.local != 4u && shape.local != 5u)) return hipErrorInvalidValue;
         const uint32_t buckets = top_bytes << shape.sub_bits;
+        // the packed form (one word per pair in LDS, three workgroups per CU) for buckets of up to ten rows of the 512-thread workgroup on average:
+        // 5-9 % faster from 2.6e7 to 8e7 pairs, level or 1 % behind at 12-13 rows (10^8, 2e8 pairs) -- profiles/labs/r06_pairs_packed.txt
+        const bool packed = pv->packed == 1 || (pv->packed < 0 && shape.local == 4u && n / buckets <= kPoolPackedPairsMean);
+#define VRS_POOL_PAIRS(T, S)                                                                                                                          \
+    do {                                                                                                                                              \
+        if (packed)                                                                                                                                   \
+            VRS_LAUNCH((pool_local_sort_pairs_kernel<T, S, true>), dim3(buckets), dim3(T), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, \
+                       host_head, stamp, host_log, again, par, *pv);                                                                                  \
+        else                                                                                                                                          \
+            VRS_LAUNCH((pool_local_sort_pairs_kernel<T, S, false>), dim3(buckets), dim3(T), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, \
+                       host_head, stamp, host_log, again, par, *pv);                                                                                  \
+    } while (0)
         if (shape.sub_bits == 8u) {
-            if (shape.local == 4u)
-                VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 8>), dim3(buckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
-                           stamp, host_log, again, par, *pv);
-            else
-                VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 8>), dim3(buckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
-                           stamp, host_log, again, par, *pv);
-            return hipGetLastError();
+            if (shape.local == 4u) VRS_POOL_PAIRS(512, 8);
+            else VRS_POOL_PAIRS(1024, 8);
+        } else if (shape.sub_bits == 7u) {
+            if (shape.local == 4u) VRS_POOL_PAIRS(512, 7);
+            else VRS_POOL_PAIRS(1024, 7);
+        } else {
+            if (shape.local == 4u) VRS_POOL_PAIRS(512, 6);
+            else VRS_POOL_PAIRS(1024, 6);
         }
-        if (shape.sub_bits == 7u) {  // (lab: 7 + 7 bits)
-            if (shape.local == 4u)
-                VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 7>), dim3(buckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
-                           stamp, host_log, again, par, *pv);
-            else
-                VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 7>), dim3(buckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
-                           stamp, host_log, again, par, *pv);
-            return hipGetLastError();
-        }
-        if (shape.local == 4u)
-            VRS_LAUNCH((pool_local_sort_pairs_kernel<512, 6>), dim3(buckets), dim3(512), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
-                       stamp, host_log, again, par, *pv);
-        else
-            VRS_LAUNCH((pool_local_sort_pairs_kernel<1024, 6>), dim3(buckets), dim3(1024), stream, ev, slack, keys_out, msd, pool, cursors, dev_head, host_head,
-                       stamp, host_log, again, par, *pv);
+#undef VRS_POOL_PAIRS
         return hipGetLastError();
     }
 #define VRS_POOL_LOCAL(T, V, W, S)                                                                                                            \
