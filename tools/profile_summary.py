@@ -113,11 +113,13 @@ if __name__ == "__main__":
     # every traffic file says which code and which box it came from (VRS_COMMIT: the caller's `git rev-parse --short HEAD` -- the GPU box has no
     # .git --; the box: host name + the device's unique id): round 5's files were overwritten in place with neither
     import os
+    import re
     import socket
     import subprocess
     try:
         uid = subprocess.run(["rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=20).stdout
-        uid = next((ln.split(":")[-1].strip() for ln in uid.splitlines() if "Unique ID" in ln), "")
+        m = re.search(r"Unique ID:\s*(0x[0-9a-fA-F]+|[0-9a-fA-F]{8,})", uid)  # (not the table's "==== Unique ID ====" header line)
+        uid = m.group(1) if m else ""
     except Exception:  # noqa: BLE001
         uid = ""
     stamp = {"round": rnd, "commit": os.environ.get("VRS_COMMIT", "unknown"), "box": f"{socket.gethostname()} {uid}".strip()}
