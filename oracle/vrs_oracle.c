@@ -19,6 +19,10 @@
  * std::sort path; tests/test_oracle.py checks equality on every fixture).  The
  * STAGE-LEVEL tables (histograms / offsets) are "parity unpinned": they follow the
  * shader text cited below but no reference-produced vector exists to pin them.
+ * What stands in for one since round 6: tests/golden/glsl_emulation.py, a second,
+ * independent restatement (a literal per-invocation emulation of both shaders: LDS
+ * atomicAdd, bin_flags masks, bitCount, subgroup operations for SUBGROUP_SIZE 32 and 64),
+ * asserted equal to this one on every fixture (make_golden.py, tests/test_oracle.py).
  *
  * Citations are file:line into /root/reference.
  */
