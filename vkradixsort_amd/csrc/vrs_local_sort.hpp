@@ -553,7 +553,7 @@ __device__ __forceinline__ void local_sort_packed_pairs_to(const uint32_t *src, 
     for (int i = 0; i < ITEMS; ++i) s_keys[seg + i * 64] = val[i];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) val[i] = s_keys[word[i] & PLACE];
+    for (int i = 0; i < ITEMS; ++i) val[i] = s_keys[seg + i * 64 < n ? word[i] & PLACE : 0u];  // (a position behind the bucket holds no word: nothing to fetch)
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t idx = seg + i * 64;
