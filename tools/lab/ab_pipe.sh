@@ -1,7 +1,12 @@
-# round 6, verdict item 1(c): the pipelined local sort (tools/lab/patches/r06_pipelined_local_sort.patch) against the product's, LDS counters of both
+# round 6: the pipelined local sort with the next bucket's keys asked for BETWEEN this bucket's two passes (a thread holds nothing there)
 mkdir -p gpurun_out/r06b
-VRS_PMC_CMD="env VRS_LIB=tools/lab/libs/libvrs_free4.so python tools/lab/ab_bench.py free4 1e8 6" bash tools/lab/lds_pmc.sh pmc_free4 > gpurun_out/r06b/pmc_free4.txt 2>&1
-VRS_PMC_CMD="env VRS_LIB=tools/lab/libs/libvrs_rank3.so VRS_LAB_LOCAL_PIPE=768 python tools/lab/ab_bench.py rank3 1e8 6" bash tools/lab/lds_pmc.sh pmc_rank3 > gpurun_out/r06b/pmc_rank3.txt 2>&1
-VRS_PMC_CMD="python tools/lab/ab_bench.py base 1e8 6" bash tools/lab/lds_pmc.sh pmc_base > gpurun_out/r06b/pmc_base.txt 2>&1
-rm -rf gpurun_out/pmc_free4 gpurun_out/pmc_rank3 gpurun_out/pmc_base
-tail -5 gpurun_out/r06b/pmc_*.txt
+{
+for rep in 1 2; do
+VRS_LIB=tools/lab/libs/libvrs_pipe.so VRS_LAB_LOCAL_PIPE=0 python tools/lab/ab_bench.py base 1e8 12
+VRS_LIB=tools/lab/libs/libvrs_pipe.so python tools/lab/ab_bench.py free_top 1e8 12
+VRS_LIB=tools/lab/libs/libvrs_freemid.so python tools/lab/ab_bench.py free_mid 1e8 12
+VRS_LIB=tools/lab/libs/libvrs_rankmid.so python tools/lab/ab_bench.py rank_mid 1e8 12
+VRS_LIB=tools/lab/libs/libvrs_rankmid3.so VRS_LAB_LOCAL_PIPE=768 python tools/lab/ab_bench.py rank_mid3 1e8 12
+done
+} > gpurun_out/r06b/ab_mid.txt 2>&1
+grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" gpurun_out/r06b/ab_mid.txt
