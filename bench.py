@@ -43,7 +43,7 @@ KERNEL_WHAT = {
     "scatter": "scatter_kernel: the contract's stable scatter, reads and writes every key once per pass",
     "digit_tables": "digit_tables_kernel: the one counting read of the counted one-call forms",
     "lookback_scatter": "onesweep_scatter_kernel / msd_pass_b_kernel: a scatter pass of the one-call sort's counted forms, reads and writes every key once",
-    "local_sort": "the LDS-local sort of every bucket (pool form: pool_local_sort_kernel; counted form: msd_local_sort_keys_kernel), reads and writes every key once -- LDS-bound",
+    "local_sort": "the LDS-local sort of every bucket (pool form: pool_local_sort_kernel; counted form: msd_local_sort_keys_kernel), reads and writes every key once; at 10^8 keys its memory skeleton alone (the same kernel without its two LDS passes) takes 147-153 us, the passes add 25-33 (profiles/labs/r06_local_sort_skeleton.txt)",
     "pool_pass_a": "pool_pass_a_kernel: the pool form's first MSD pass (reserves in sampled regions), reads and writes every key once",
     "pool_pass_b": "pool_pass_b_kernel: the pool form's second MSD pass (scatters into the buckets' slack regions), reads and writes every key once",
 }
@@ -456,7 +456,7 @@ def bench_single(args):
                                for name, bpk in KERNEL_BYTES_PER_KEY.items()
                                if name in breakdown and breakdown[name]["avg_us"]},
         "roofline_by_kernel_note": "every byte-moving kernel of the timed path, from the all-kernels-instrumented rerun (launches carry events: "
-                                   "a few per cent slower than in the timed region); local_sort is LDS-bound, the others HBM-bound",
+                                   "a few per cent slower than in the timed region); all three run at or near the rate a device copy reaches on the box (measured_d2d_copy_GBps); the local sort carries 25-33 us of LDS work on top",
         "ms_per_step_uninstrumented_rerun": round(unprofiled / K * 1e3, 4),
         f"{other_name}_path": {
             "value": round(n * K / other_elapsed / 1e9, 3), "unit": "Gkeys/s", "ms_per_step": round(other_elapsed / K * 1e3, 4),
