@@ -303,8 +303,14 @@ def test_config3_1e8_pairs(gpu_context, oracle, one_call):
     m = vrs.MultiRadixSort(NUM_BLOCKS_PER_WORKGROUP=32, keys=keys, values=vals, quiet=True)
     m.m_oneCallSort = one_call
     m.setup(gpu_context)
+    took, refused = ctypes.c_uint64(), ctypes.c_uint64()
+    gpu_context.check(gpu_context.lib.vrs_one_call_pool_sorts(gpu_context.handle, ctypes.byref(took), ctypes.byref(refused)))
+    before = (took.value, refused.value)
     m.enqueueSort()
     gpu_context.waitIdle()
+    gpu_context.check(gpu_context.lib.vrs_one_call_pool_sorts(gpu_context.handle, ctypes.byref(took), ctypes.byref(refused)))
+    if one_call:  # with the defaults 10^8 pairs take the (stable) pool form: what the bit-for-bit compare below is a compare OF
+        assert (took.value - before[0], refused.value - before[1]) == (1, 0)
     ok = m.download()
     ov = np.empty(n, np.uint32)
     m.m_valueBuffers[0].downloadWithStagingBuffer(ov)
