@@ -7,6 +7,7 @@
 #include "../../vkradixsort_amd/csrc/vrs_pool_shape.hip"
 
 #include <cstdio>
+#include <unistd.h>
 #include <cstdlib>
 #include <random>
 #include <vector>
@@ -80,7 +81,7 @@ int main(int argc, char **argv) {
     unsigned long long xcc_map = 0;
     for (int b = 0; b < 8; ++b) xcc_map |= static_cast<unsigned long long>(hx[b] & 0xFF) << (8 * b);
     const vrs::PoolStreams ps = vrs::pool_streams(n);
-    hipEvent_t ev[8];
+    hipEvent_t ev[10];
     for (auto &e : ev) CK(hipEventCreate(&e));
     const uint32_t tiles_b = vrs::pool_tiles_b_cap(n);
     double sum[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -102,9 +103,24 @@ int main(int argc, char **argv) {
         CK(hipEventRecord(ev[3], st));
         CK(vrs::launch_pool_pass_b(st, partner, ovf, slack, n, msd, pool, tiles_b, 0, vrs::pool_local_capacity(shape.local), slack_cap, xcc_map, 1000u + r, shape.sub_bits, par));
         CK(hipEventRecord(ev[4], st));
+        if (getenv("POOL_LAB_ISOLATE")) {  // the local sort on a QUIET chip: whatever the second pass left dirty in the caches has been written back
+            CK(hipStreamSynchronize(st));
+            usleep(3000);
+        }
         CK(hipEventRecord(ev[5], st));
         CK(vrs::launch_pool_local_sort(st, slack, in, n, msd, pool, shape, head, nullptr, 1, par));
         CK(hipEventRecord(ev[6], st));
+        float again_us = 0;
+        if (getenv("POOL_LAB_ISOLATE")) {  // ... and once more (the same buckets from the same regions to the same places), behind another quiet period
+            CK(hipStreamSynchronize(st));
+            usleep(3000);
+            CK(hipEventRecord(ev[8], st));
+            CK(vrs::launch_pool_local_sort(st, slack, in, n, msd, pool, shape, head, nullptr, 1, par));
+            CK(hipEventRecord(ev[9], st));
+            CK(hipStreamSynchronize(st));
+            CK(hipEventElapsedTime(&again_us, ev[8], ev[9]));
+            again_us *= 1e3f;
+        }
         hipLaunchKernelGGL(check_sorted, dim3(2048), dim3(256), 0, st, in, n, chk);
         CK(hipStreamSynchronize(st));
         vrs::MsdPlan hm;
@@ -133,6 +149,7 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 6; ++i) CK(hipEventElapsedTime(&t[i], ev[i], ev[i + 1]));
         std::printf("rep %d: sample %.1f  passA %.1f  plan %.1f  passB %.1f  (-) %.1f  local %.1f us   ok_a=%u fail=%u ok=%u shift=%u  descents=%llu sum %s\n", r, t[0] * 1e3,
                     t[1] * 1e3, t[2] * 1e3, t[3] * 1e3, t[4] * 1e3, t[5] * 1e3, hp.ok_a, hp.fail[r & 1], hm.ok, hm.shift, hc[0], hc[1] == hc[3] ? "same" : "DIFFERENT");
+        if (again_us != 0) std::printf("        (local sort behind a quiet period: the figure above; once more behind another: %.1f us)\n", again_us);
         if (r >= 2) {
             for (int i = 0; i < 6; ++i) sum[i] += t[i] * 1e3;
             ++counted;
